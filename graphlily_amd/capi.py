@@ -1,0 +1,290 @@
+"""ctypes binding of libgraphlily_hip.so (include/graphlily_hip.h).
+
+This is the same C ABI the C++ module headers under include/graphlily/ call; the
+Python side exists so pytest and bench.py can drive the HIP path.  There is no
+CPU fallback here: if the shared library is missing, or no HIP device is
+present, the calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgraphlily_hip.so")
+
+# graphlily/global.h:83-87, :103-107
+GL_OP_MULADD, GL_OP_ANDOR, GL_OP_ADDMIN = 0, 1, 2
+GL_NOMASK, GL_MASK_WRITETOZERO, GL_MASK_WRITETOONE = 0, 1, 2
+
+GL_OK = 0
+GL_ERR_INVALID_ARG = -1
+GL_ERR_HIP = -2
+GL_ERR_NOT_INITIALIZED = -3
+GL_ERR_IO = -4
+
+# graphlily/global.h:69 idx_val_t with val_t = float
+IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
+
+# every symbol include/graphlily_hip.h declares (tests check the .so exports them all)
+EXPORTS = [
+    "gl_init", "gl_device_count", "gl_set_stream", "gl_sync", "gl_last_error", "gl_version",
+    "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32",
+    "gl_spmv_plan_create", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_run",
+    "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
+    "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
+    "gl_assign_sparse_new_frontier", "gl_sparse_to_dense",
+    "gl_npz_csr_open", "gl_npz_csr_read", "gl_npz_csr_close",
+]
+
+
+class GraphLilyError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("graphlily_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libgraphlily_hip.so (built in-tree by __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GraphLilyError(GL_ERR_NOT_INITIALIZED,
+                             "%s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u32, u64, f32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float, ctypes.c_int
+    P = ctypes.POINTER
+    sigs = {
+        "gl_init": [i32], "gl_device_count": [P(i32)], "gl_set_stream": [vp], "gl_sync": [],
+        "gl_buf_alloc": [P(vp), ctypes.c_size_t], "gl_buf_free": [vp],
+        "gl_buf_h2d": [vp, vp, ctypes.c_size_t], "gl_buf_d2h": [vp, vp, ctypes.c_size_t],
+        "gl_buf_d2d": [vp, vp, ctypes.c_size_t], "gl_buf_fill_f32": [vp, f32, ctypes.c_size_t],
+        "gl_spmv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
+        "gl_spmv_plan_destroy": [vp], "gl_spmv_plan_info": [vp, P(u64), P(u64), P(u32)],
+        "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
+        "gl_spmspv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
+        "gl_spmspv_plan_destroy": [vp], "gl_spmspv_plan_info": [vp, P(u64), P(u64)],
+        "gl_spmspv_run": [vp, vp, vp, vp, i32, f32, i32],
+        "gl_sparse_nnz": [vp, P(u32)],
+        "gl_ewise_add": [vp, vp, u32, f32], "gl_assign_dense": [vp, vp, u32, f32, i32],
+        "gl_assign_sparse": [vp, vp, f32, u32], "gl_assign_sparse_new_frontier": [vp, vp, vp, u32],
+        "gl_sparse_to_dense": [vp, vp, u32, f32, u32],
+        "gl_npz_csr_open": [ctypes.c_char_p, P(vp), P(u32), P(u32), P(u64)],
+        "gl_npz_csr_read": [vp, vp, vp, vp], "gl_npz_csr_close": [vp],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = i32
+    L.gl_last_error.restype = ctypes.c_char_p
+    L.gl_last_error.argtypes = []
+    L.gl_version.restype = ctypes.c_char_p
+    L.gl_version.argtypes = []
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != GL_OK:
+        raise GraphLilyError(rc, lib().gl_last_error().decode("utf-8", "replace"))
+
+
+def _np_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None and a.size else ctypes.c_void_p(0)
+
+
+def init(device=0):
+    check(lib().gl_init(int(device)))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = lib().gl_device_count(ctypes.byref(n))
+    return n.value if rc == GL_OK else 0
+
+
+def set_stream(hip_stream):
+    check(lib().gl_set_stream(ctypes.c_void_p(hip_stream or 0)))
+
+
+def sync():
+    check(lib().gl_sync())
+
+
+class DeviceBuffer:
+    """A device allocation handle: the role cl::Buffer plays in the reference's module API
+    (shareable between modules via bind_*_buf).  Either owns memory from gl_buf_alloc or
+    wraps a foreign device pointer (e.g. a torch tensor kept alive by `keepalive`)."""
+
+    def __init__(self, nbytes=0, ptr=None, keepalive=None):
+        self.nbytes = int(nbytes)
+        self._owned = ptr is None
+        self.keepalive = keepalive
+        if self._owned:
+            p = ctypes.c_void_p(0)
+            check(lib().gl_buf_alloc(ctypes.byref(p), self.nbytes))
+            self.ptr = p.value or 0
+        else:
+            self.ptr = int(ptr)
+
+    @classmethod
+    def from_host(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes)
+        b.write(arr)
+        return b
+
+    @classmethod
+    def from_torch(cls, t):
+        return cls(t.numel() * t.element_size(), ptr=t.data_ptr(), keepalive=t)
+
+    def write(self, arr, offset_bytes=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset_bytes + arr.nbytes <= self.nbytes, "host array larger than device buffer"
+        check(lib().gl_buf_h2d(ctypes.c_void_p(self.ptr + offset_bytes), _np_ptr(arr), arr.nbytes))
+
+    def read(self, dtype, count=None, offset_bytes=0):
+        dtype = np.dtype(dtype)
+        if count is None:
+            count = (self.nbytes - offset_bytes) // dtype.itemsize
+        out = np.empty(count, dtype=dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        check(lib().gl_buf_d2h(_np_ptr(out), ctypes.c_void_p(self.ptr + offset_bytes), out.nbytes))
+        return out
+
+    def free(self):
+        if self._owned and self.ptr:
+            lib().gl_buf_free(ctypes.c_void_p(self.ptr))
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def copy_d2d(dst, src, nbytes):
+    assert nbytes <= dst.nbytes and nbytes <= src.nbytes
+    check(lib().gl_buf_d2d(ctypes.c_void_p(dst.ptr), ctypes.c_void_p(src.ptr), int(nbytes)))
+
+
+def _p(buf):
+    return ctypes.c_void_p(buf.ptr if buf is not None else 0)
+
+
+class SpMVPlan:
+    def __init__(self, num_rows, num_cols, indptr, indices, data, row_begin=0, row_end=None):
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.uint32)
+        self.indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        self.data = np.ascontiguousarray(data, dtype=np.float32)
+        row_end = num_rows if row_end is None else row_end
+        h = ctypes.c_void_p(0)
+        check(lib().gl_spmv_plan_create(ctypes.byref(h), num_rows, num_cols, _np_ptr(self.indptr),
+                                        _np_ptr(self.indices), _np_ptr(self.data), row_begin, row_end))
+        self.handle = h.value
+        self.num_rows, self.num_cols, self.row_begin, self.row_end = num_rows, num_cols, row_begin, row_end
+        # host CSR copies are only needed during creation
+        self.indptr = self.indices = self.data = None
+
+    def info(self):
+        nnz, nbytes, ntiles = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint32(0)
+        check(lib().gl_spmv_plan_info(ctypes.c_void_p(self.handle), ctypes.byref(nnz), ctypes.byref(nbytes),
+                                      ctypes.byref(ntiles)))
+        return {"nnz": nnz.value, "device_bytes": nbytes.value, "num_tiles": ntiles.value}
+
+    def run(self, x, mask, y, op, zero, mask_type):
+        check(lib().gl_spmv_run(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero),
+                                int(mask_type)))
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            lib().gl_spmv_plan_destroy(ctypes.c_void_p(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class SpMSpVPlan:
+    def __init__(self, num_rows, num_cols, indptr, indices, data, row_begin=0, row_end=None):
+        indptr = np.ascontiguousarray(indptr, dtype=np.uint32)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        row_end = num_rows if row_end is None else row_end
+        h = ctypes.c_void_p(0)
+        check(lib().gl_spmspv_plan_create(ctypes.byref(h), num_rows, num_cols, _np_ptr(indptr), _np_ptr(indices),
+                                          _np_ptr(data), row_begin, row_end))
+        self.handle = h.value
+        self.num_rows, self.num_cols, self.row_begin, self.row_end = num_rows, num_cols, row_begin, row_end
+
+    def info(self):
+        nnz, nbytes = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        check(lib().gl_spmspv_plan_info(ctypes.c_void_p(self.handle), ctypes.byref(nnz), ctypes.byref(nbytes)))
+        return {"nnz": nnz.value, "device_bytes": nbytes.value}
+
+    def run(self, vector, mask, result, op, zero, mask_type):
+        check(lib().gl_spmspv_run(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op),
+                                  float(zero), int(mask_type)))
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            lib().gl_spmspv_plan_destroy(ctypes.c_void_p(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def sparse_nnz(buf):
+    n = ctypes.c_uint32(0)
+    check(lib().gl_sparse_nnz(_p(buf), ctypes.byref(n)))
+    return n.value
+
+
+def ewise_add(inp, out, length, val):
+    check(lib().gl_ewise_add(_p(inp), _p(out), int(length), float(val)))
+
+
+def assign_dense(mask, inout, length, val, mask_type):
+    check(lib().gl_assign_dense(_p(mask), _p(inout), int(length), float(val), int(mask_type)))
+
+
+def assign_sparse(mask, inout, val, max_entries):
+    check(lib().gl_assign_sparse(_p(mask), _p(inout), float(val), int(max_entries)))
+
+
+def assign_sparse_new_frontier(mask, inout, new_frontier, max_entries):
+    check(lib().gl_assign_sparse_new_frontier(_p(mask), _p(inout), _p(new_frontier), int(max_entries)))
+
+
+def sparse_to_dense(sparse, dense, rng, zero, max_entries):
+    check(lib().gl_sparse_to_dense(_p(sparse), _p(dense), int(rng), float(zero), int(max_entries)))
+
+
+def fill_f32(buf, value, count):
+    check(lib().gl_buf_fill_f32(_p(buf), float(value), int(count)))
+
+
+def npz_load_csr(path):
+    """-> (num_rows, num_cols, data f32, indices u32, indptr u32); host only, no GPU needed."""
+    h = ctypes.c_void_p(0)
+    nr, nc, nnz = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint64(0)
+    check(lib().gl_npz_csr_open(os.fsencode(path), ctypes.byref(h), ctypes.byref(nr), ctypes.byref(nc),
+                                ctypes.byref(nnz)))
+    data = np.empty(nnz.value, dtype=np.float32)
+    indices = np.empty(nnz.value, dtype=np.uint32)
+    indptr = np.empty(nr.value + 1, dtype=np.uint32)
+    check(lib().gl_npz_csr_read(h, _np_ptr(data), _np_ptr(indices), _np_ptr(indptr)))
+    return nr.value, nc.value, data, indices, indptr

@@ -1,0 +1,162 @@
+// Element-wise "apply" operators of the overlay (modes 3-6, hw/overlay.cpp:380-411)
+// and the sparse->dense conversion used at the push->pull switch.
+// All are bandwidth-trivial, grid-stride, one launch each (the SSSP-mode sparse
+// assign adds the ordered compaction of gl_compact.h for its new frontier).
+#include "gl_common.h"
+#include "gl_compact.h"
+
+namespace gl {
+
+static void *g_scratch = nullptr;
+static size_t g_scratch_bytes = 0;
+
+int scratch_reserve(size_t bytes, void **d_ptr) {
+    if (bytes > g_scratch_bytes) {
+        // previous users are ordered on the stream; drain before releasing
+        GL_HIP(hipStreamSynchronize(ctx().stream));
+        if (g_scratch) GL_HIP(hipFree(g_scratch));
+        g_scratch = nullptr;
+        g_scratch_bytes = 0;
+        size_t want = bytes < (1u << 16) ? (1u << 16) : bytes;
+        GL_HIP(hipMalloc(&g_scratch, want));
+        g_scratch_bytes = want;
+    }
+    *d_ptr = g_scratch;
+    return GL_OK;
+}
+
+static inline unsigned stream_grid(uint64_t items_per_thread_total) {
+    unsigned blocks = cdiv(items_per_thread_total, 256);
+    unsigned cap = (unsigned)ctx().num_cus * 8u;
+    if (blocks > cap) blocks = cap;
+    return blocks ? blocks : 1u;
+}
+
+// hw/kernel_add_scalar_vector_dense_impl.h:6-27
+__global__ __launch_bounds__(256) void ewise_add_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                        uint32_t len, float val, bool vec4) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    if (vec4) {
+        const uint32_t n4 = len >> 2;
+        const float4 *in4 = reinterpret_cast<const float4 *>(in);
+        float4 *out4 = reinterpret_cast<float4 *>(out);
+        for (uint32_t i = tid; i < n4; i += stride) {
+            float4 v = in4[i];
+            v.x += val; v.y += val; v.z += val; v.w += val;
+            out4[i] = v;
+        }
+        for (uint32_t i = (n4 << 2) + tid; i < len; i += stride) out[i] = in[i] + val;
+    } else {
+        for (uint32_t i = tid; i < len; i += stride) out[i] = in[i] + val;
+    }
+}
+
+// hw/kernel_assign_vector_dense_impl.h:8-47
+template <int MASK>
+__global__ __launch_bounds__(256) void assign_dense_kernel(const float *__restrict__ mask, float *__restrict__ inout,
+                                                           uint32_t len, float val) {
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < len; i += stride) {
+        if (mask_allows<MASK>(mask[i], 0.0f)) inout[i] = val;
+    }
+}
+
+// hw/kernel_assign_vector_sparse_no_new_frontier_impl.h:4-55
+__global__ __launch_bounds__(256) void assign_sparse_kernel(const gl_idx_val *__restrict__ mask, float *__restrict__ inout,
+                                                            float val) {
+    const uint32_t n = mask[0].index;
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) inout[mask[1u + i].index] = val;
+}
+
+// hw/kernel_assign_vector_sparse_new_frontier_impl.h:4-78: candidates are the mask
+// entries; kept (and relaxed) when inout[idx] > v.  Mask indices are unique (they
+// come from a SpMSpV result), so entries do not interact.
+struct RelaxSource {
+    const gl_idx_val *mask;
+    float *inout;
+    __device__ uint32_t size() const { return mask[0].index; }
+    __device__ bool get(uint32_t i, gl_idx_val &out) const {
+        out = mask[1u + i];
+        return inout[out.index] > out.val;
+    }
+    __device__ void consumed(uint32_t i) const {
+        gl_idx_val m = mask[1u + i];
+        if (inout[m.index] > m.val) inout[m.index] = m.val;
+    }
+};
+
+// graphlily/global.h:153-164
+__global__ __launch_bounds__(256) void sparse_scatter_kernel(const gl_idx_val *__restrict__ sv, float *__restrict__ dense,
+                                                             uint32_t range) {
+    const uint32_t n = sv[0].index;
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
+        gl_idx_val e = sv[1u + i];
+        if (e.index < range) dense[e.index] = e.val;
+    }
+}
+
+}  // namespace gl
+
+extern "C" {
+
+int gl_ewise_add(const float *d_in, float *d_out, uint32_t len, float val) {
+    GL_REQUIRE_INIT();
+    if (len == 0) return GL_OK;
+    GL_ARG(d_in != nullptr && d_out != nullptr);
+    const bool vec4 = ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0;
+    gl::ewise_add_kernel<<<gl::stream_grid(vec4 ? (len + 3) / 4 : len), 256, 0, gl::ctx().stream>>>(d_in, d_out, len, val, vec4);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int gl_assign_dense(const float *d_mask, float *d_inout, uint32_t len, float val, int mask_type) {
+    GL_REQUIRE_INIT();
+    if (mask_type != GL_MASK_WRITETOZERO && mask_type != GL_MASK_WRITETOONE)
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_assign_dense: Invalid mask type %d", mask_type);
+    if (len == 0) return GL_OK;
+    GL_ARG(d_mask != nullptr && d_inout != nullptr);
+    hipStream_t s = gl::ctx().stream;
+    if (mask_type == GL_MASK_WRITETOZERO)
+        gl::assign_dense_kernel<GL_MASK_WRITETOZERO><<<gl::stream_grid(len), 256, 0, s>>>(d_mask, d_inout, len, val);
+    else
+        gl::assign_dense_kernel<GL_MASK_WRITETOONE><<<gl::stream_grid(len), 256, 0, s>>>(d_mask, d_inout, len, val);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int gl_assign_sparse(const gl_idx_val *d_mask, float *d_inout, float val, uint32_t max_entries) {
+    GL_REQUIRE_INIT();
+    GL_ARG(d_mask != nullptr && d_inout != nullptr);
+    if (max_entries == 0) return GL_OK;
+    gl::assign_sparse_kernel<<<gl::stream_grid(max_entries), 256, 0, gl::ctx().stream>>>(d_mask, d_inout, val);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int gl_assign_sparse_new_frontier(const gl_idx_val *d_mask, float *d_inout, gl_idx_val *d_new_frontier,
+                                  uint32_t max_entries) {
+    GL_REQUIRE_INIT();
+    GL_ARG(d_mask != nullptr && d_inout != nullptr && d_new_frontier != nullptr);
+    GL_ARG((const void *)d_mask != (const void *)d_new_frontier);
+    void *counts = nullptr;
+    int rc = gl::scratch_reserve((size_t)(gl::cdiv(max_entries, gl::kCompactChunk) + 1) * sizeof(uint32_t), &counts);
+    if (rc != GL_OK) return rc;
+    gl::RelaxSource src{d_mask, d_inout};
+    // head of the new frontier is {count, 0} (kernel_assign_vector_sparse_new_frontier_impl.h:73-77)
+    return gl::run_compaction(src, max_entries, (uint32_t *)counts, d_new_frontier, 0.0f, gl::ctx().stream);
+}
+
+int gl_sparse_to_dense(const gl_idx_val *d_sparse, float *d_dense, uint32_t range, float zero, uint32_t max_entries) {
+    GL_REQUIRE_INIT();
+    GL_ARG(d_sparse != nullptr && d_dense != nullptr);
+    int rc = gl_buf_fill_f32(d_dense, zero, range);
+    if (rc != GL_OK) return rc;
+    if (max_entries == 0) return GL_OK;
+    gl::sparse_scatter_kernel<<<gl::stream_grid(max_entries), 256, 0, gl::ctx().stream>>>(d_sparse, d_dense, range);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+}  // extern "C"

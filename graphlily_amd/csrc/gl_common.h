@@ -1,0 +1,110 @@
+// Internal helpers shared by the translation units of libgraphlily_hip.so.
+// gfx950 (MI355X, CDNA4) only: wavefront = 64 lanes everywhere.
+#ifndef GL_COMMON_H_
+#define GL_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "graphlily_hip.h"
+
+namespace gl {
+
+constexpr int kWave = 64;
+
+// graphlily/global.h:80 / hw/math_constants.h: FLOAT_INF
+constexpr float kFloatInf = 999999999.0f;
+
+struct Context {
+    bool initialized = false;
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // current stream (own or adopted)
+    int num_cus = 256;
+};
+
+Context &ctx();
+
+int set_error(int code, const char *fmt, ...);
+
+#define GL_REQUIRE_INIT()                                                           \
+    do {                                                                            \
+        if (!gl::ctx().initialized)                                                 \
+            return gl::set_error(GL_ERR_NOT_INITIALIZED,                            \
+                                 "%s: gl_init() has not succeeded (no HIP device?)", __func__); \
+    } while (0)
+
+#define GL_HIP(expr)                                                                \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess)                                                       \
+            return gl::set_error(GL_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
+                                 hipGetErrorString(e_));                            \
+    } while (0)
+
+#define GL_ARG(cond)                                                                \
+    do {                                                                            \
+        if (!(cond))                                                                \
+            return gl::set_error(GL_ERR_INVALID_ARG, "%s: invalid argument: %s", __func__, #cond); \
+    } while (0)
+
+#define GL_LAUNCH_CHECK() GL_HIP(hipGetLastError())
+
+static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------ semirings
+// The three semirings of graphlily/global.h:96-100 as compile-time policies.
+// mul = the (x) ALU, add = the (+) ALU (hw/float_pe.h:36-77).  `ident` is the
+// value used for padding lanes inside a reduction (neutral for add), and
+// finish() folds the runtime SemiringType::zero in exactly once, reproducing
+// "accumulator initialised to zero" of the reference loops.
+template <int OP>
+struct Semiring;
+
+template <>
+struct Semiring<GL_OP_MULADD> {
+    __device__ static float ident(float) { return 0.0f; }
+    __device__ static float mul(float a, float b) { return a * b; }
+    __device__ static float add(float a, float b) { return a + b; }
+    __device__ static float finish(float zero, float s) { return zero + s; }
+};
+
+template <>
+struct Semiring<GL_OP_ANDOR> {
+    __device__ static float ident(float) { return 0.0f; }
+    __device__ static float mul(float a, float b) { return (a != 0.0f && b != 0.0f) ? 1.0f : 0.0f; }
+    __device__ static float add(float a, float b) { return (a != 0.0f || b != 0.0f) ? 1.0f : 0.0f; }
+    __device__ static float finish(float zero, float s) { return (zero != 0.0f || s != 0.0f) ? 1.0f : 0.0f; }
+};
+
+template <>
+struct Semiring<GL_OP_ADDMIN> {
+    __device__ static float ident(float) { return __builtin_inff(); }
+    __device__ static float mul(float a, float b) { return a + b; }
+    // std::min(acc, t) == (t < acc) ? t : acc
+    __device__ static float add(float a, float b) { return (b < a) ? b : a; }
+    __device__ static float finish(float zero, float s) { return (s < zero) ? s : zero; }
+};
+
+// streamed-once 8-byte load (matrix streams): non-temporal so the stream does not
+// evict the dense vector from L2
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 load_stream_nt(const uint2 *p) {
+    u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t *>(p));
+    return make_uint2(v.x, v.y);
+}
+
+// mask test shared by SpMV epilogue and dense assign: "does the mask allow a write here?"
+template <int MASK>
+__device__ __forceinline__ bool mask_allows(float m, float ref) {
+    if (MASK == GL_MASK_WRITETOZERO) return m == ref;
+    if (MASK == GL_MASK_WRITETOONE) return m != ref;
+    return true;
+}
+
+}  // namespace gl
+
+#endif  // GL_COMMON_H_

@@ -1,0 +1,141 @@
+// Ordered stream compaction shared by SpMSpV (dense accumulator -> sparse
+// result) and the SSSP-mode sparse assign (mask list -> new frontier).
+//
+// The reference emits its sparse outputs in an unspecified, lane-round-robin
+// order (hw/kernel_spmspv_impl.h:253-286).  This build emits them in candidate
+// order (ascending row for SpMSpV, mask order for the assign), so results are
+// reproducible run to run.  Three small launches: per-block counts, one-block
+// scan of the counts (+ head element), ordered write.
+//
+// A "source" functor provides:
+//   __device__ uint32_t size() const;                       // number of candidates
+//   __device__ bool     get(uint32_t i, gl_idx_val &out);   // candidate i kept? payload
+//   __device__ void     consumed(uint32_t i);               // called once per candidate in the write pass
+#ifndef GL_COMPACT_H_
+#define GL_COMPACT_H_
+
+#include "gl_common.h"
+
+namespace gl {
+
+constexpr uint32_t kCompactThreads = 256;
+constexpr uint32_t kCompactItems = 4;
+constexpr uint32_t kCompactChunk = kCompactThreads * kCompactItems;
+
+// exclusive prefix of `flag` over the 256 threads of a block, in thread order; total in *block_total
+__device__ __forceinline__ uint32_t block_rank_256(bool flag, uint32_t *lds4, uint32_t *block_total) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint64_t b = __ballot(flag);
+    const uint32_t in_wave = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) lds4[w] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        uint32_t c = lds4[i];
+        if (i < w) before += c;
+        total += c;
+    }
+    __syncthreads();
+    *block_total = total;
+    return before + in_wave;
+}
+
+template <typename Src>
+__global__ __launch_bounds__(256) void compact_count_kernel(Src src, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t n = src.size();
+    const uint32_t base = blockIdx.x * kCompactChunk;
+    uint32_t c = 0;
+    if (base < n) {
+#pragma unroll
+        for (uint32_t j = 0; j < kCompactItems; j++) {
+            uint32_t i = base + j * kCompactThreads + threadIdx.x;
+            gl_idx_val tmp;
+            c += (i < n && src.get(i, tmp)) ? 1u : 0u;
+        }
+    }
+    // block sum
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) c += __shfl_down(c, dlt);
+    if ((threadIdx.x & 63u) == 0) lds4[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+// single block: counts[] -> exclusive offsets in place; out[0] = {total, head_val}
+static __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__restrict__ counts, uint32_t nblocks,
+                                                            gl_idx_val *__restrict__ out, float head_val) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 1024u) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = (i < nblocks) ? counts[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
+            uint32_t up = __shfl_up(incl, dlt);
+            if (lane >= dlt) incl += up;
+        }
+        if (lane == 63) wave_tot[w] = incl;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (uint32_t k = 0; k < w; k++) before += wave_tot[k];
+        if (i < nblocks) counts[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0].index = carry_s;
+        out[0].val = head_val;
+    }
+}
+
+template <typename Src>
+__global__ __launch_bounds__(256) void compact_write_kernel(Src src, const uint32_t *__restrict__ offsets,
+                                                            gl_idx_val *__restrict__ out) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t n = src.size();
+    const uint32_t base = blockIdx.x * kCompactChunk;
+    if (base >= n) return;
+    uint32_t pos = offsets[blockIdx.x];
+#pragma unroll
+    for (uint32_t j = 0; j < kCompactItems; j++) {
+        uint32_t i = base + j * kCompactThreads + threadIdx.x;
+        gl_idx_val item;
+        bool keep = false;
+        if (i < n) {
+            keep = src.get(i, item);
+            src.consumed(i);
+        }
+        uint32_t total;
+        uint32_t rank = block_rank_256(keep, lds4, &total);
+        if (keep) out[1u + pos + rank] = item;
+        pos += total;
+    }
+}
+
+// Runs the three phases for at most `max_items` candidates (host-side bound for the grid).
+template <typename Src>
+static int run_compaction(Src src, uint32_t max_items, uint32_t *d_counts, gl_idx_val *d_out, float head_val,
+                          hipStream_t s) {
+    uint32_t nblocks = cdiv(max_items, kCompactChunk);
+    if (nblocks == 0) nblocks = 1;
+    compact_count_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts);
+    GL_LAUNCH_CHECK();
+    compact_scan_kernel<<<1, 1024, 0, s>>>(d_counts, nblocks, d_out, head_val);
+    GL_LAUNCH_CHECK();
+    compact_write_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// grow-only device scratch owned by the runtime (used where no plan exists to hold workspace)
+int scratch_reserve(size_t bytes, void **d_ptr);
+
+}  // namespace gl
+
+#endif  // GL_COMPACT_H_

@@ -1,0 +1,343 @@
+// SpMSpV over a semiring for MI355X (gfx950): sparse y = mask( A_csc (x) sparse x ).
+//
+// Replaces SpMSpVModule::load_and_format_matrix -> formatCSC
+// (module/spmspv_module.h:263-286, io/data_formatter.h:543-721) and kernel_spmspv
+// (hw/kernel_spmspv_impl.h:448-562).
+//
+// Layout: the CSC is kept as indptr[num_cols+1] plus one packed 8-byte stream
+// { row, val } in column order (the FPGA's 8-wide column packets padded with
+// (0, zero) entries, data_formatter.h:674-680, are not needed: a wavefront reads
+// any contiguous run of a column coalesced).
+//
+// Kernels per run:
+//  1. scatter: a workgroup takes 256 entries of the sparse input vector, stages
+//     (column start, degree prefix, value) in LDS, and its threads then walk the
+//     concatenated work list -- a binary search in LDS maps a work item to its
+//     column -- so the non-zeros of the active columns are spread evenly over
+//     the lanes whatever the degree mix.  Columns above a degree threshold are
+//     parked in a hub list and processed by the whole grid (kernel 1b).
+//     Products go into a dense accumulator with atomics: float add for (+,*),
+//     plain store of 1 for (||,&&), ordered-integer min for (min,+).
+//  2. ordered compaction of the accumulator into the (index, value) list with
+//     the mask applied (gl_compact.h); the pass also resets the accumulator to
+//     `zero`, restoring the invariant for the next run (the FPGA re-zeroes its
+//     output buffer per call instead, kernel_spmspv_impl.h:505-516).
+#include "gl_common.h"
+#include "gl_compact.h"
+
+#include <cstring>
+#include <vector>
+
+struct gl_spmspv_plan_s {
+    uint32_t num_rows = 0, num_cols = 0, row_begin = 0, row_end = 0;
+    uint64_t nnz = 0;
+    uint32_t *d_indptr = nullptr;  // num_cols + 1, offsets into d_stream
+    uint2 *d_stream = nullptr;     // {row, val bits}
+    float *d_acc = nullptr;        // dense accumulator over the shard's rows
+    float acc_fill = 0.0f;
+    bool acc_valid = false;        // d_acc is known to be all == acc_fill
+    uint32_t *d_counts = nullptr;  // compaction workspace
+    uint32_t *d_hub = nullptr;     // [0] = count, then hub entry slots (index into the input vector)
+    uint32_t hub_capacity = 0;
+    uint64_t device_bytes = 0;
+};
+
+namespace gl {
+
+constexpr uint32_t kHubDegree = 8192;  // columns at least this long are processed by the whole grid
+
+struct ScatterArgs {
+    const uint32_t *indptr;
+    const uint2 *stream;
+    const gl_idx_val *vec;
+    float *acc;
+    uint32_t *hub;
+    uint32_t hub_capacity;
+    uint32_t row_begin;
+    uint32_t num_cols;
+};
+
+// ordered-integer trick: for IEEE floats, a >= 0 compares like int, a < 0 like reversed uint
+__device__ __forceinline__ void atomic_min_float(float *addr, float v) {
+    if (v >= 0.0f)
+        atomicMin((int *)addr, __float_as_int(v));
+    else
+        atomicMax((unsigned int *)addr, __float_as_uint(v));
+}
+
+template <int OP>
+__device__ __forceinline__ void scatter_one(float *acc, uint32_t row, float a, float xv) {
+    if (OP == GL_OP_MULADD) {
+        unsafeAtomicAdd(&acc[row], a * xv);
+    } else if (OP == GL_OP_ANDOR) {
+        if (a != 0.0f && xv != 0.0f) acc[row] = 1.0f;
+    } else {
+        // saturating add of the (min,+) PE: hw/float_pe.h:24-33, spmspv_module.h:482-491
+        float incr;
+        if (a > kFloatInf || xv > kFloatInf) {
+            incr = kFloatInf;
+        } else {
+            incr = a + xv;
+            if (incr > kFloatInf) incr = kFloatInf;
+        }
+        atomic_min_float(&acc[row], incr);
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void spmspv_scatter_kernel(ScatterArgs a) {
+    __shared__ uint32_t s_start[256];
+    __shared__ uint32_t s_off[257];  // exclusive degree prefix, s_off[256] = total
+    __shared__ float s_val[256];
+    __shared__ uint32_t s_wave[4];
+    const uint32_t vnnz = a.vec[0].index;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+
+    for (uint32_t batch = blockIdx.x * 256u; batch < vnnz; batch += gridDim.x * 256u) {
+        const uint32_t e = batch + threadIdx.x;
+        uint32_t start = 0, deg = 0;
+        float xv = 0.0f;
+        if (e < vnnz) {
+            gl_idx_val iv = a.vec[1u + e];
+            if (iv.index < a.num_cols) {
+                start = a.indptr[iv.index];
+                deg = a.indptr[iv.index + 1u] - start;
+                xv = iv.val;
+                if (deg >= kHubDegree) {
+                    uint32_t slot = atomicAdd(&a.hub[0], 1u);
+                    if (slot < a.hub_capacity) {
+                        a.hub[1u + slot] = e;
+                        deg = 0;  // handled by the hub kernel
+                    }
+                }
+            }
+        }
+        // block-wide exclusive scan of deg
+        uint32_t incl = deg;
+#pragma unroll
+        for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
+            uint32_t up = __shfl_up(incl, dlt);
+            if (lane >= dlt) incl += up;
+        }
+        if (lane == 63) s_wave[w] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < w; k++) before += s_wave[k];
+        s_start[threadIdx.x] = start;
+        s_val[threadIdx.x] = xv;
+        s_off[threadIdx.x] = before + incl - deg;
+        if (threadIdx.x == 255) s_off[256] = before + incl;
+        __syncthreads();
+        const uint32_t total = s_off[256];
+        for (uint32_t wi = threadIdx.x; wi < total; wi += 256u) {
+            // largest j with s_off[j] <= wi
+            uint32_t lo = 0, hi = 255;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                uint32_t mid = (lo + hi + 1u) >> 1;
+                if (s_off[mid] <= wi) lo = mid; else hi = mid - 1u;
+            }
+            const uint2 rv = a.stream[s_start[lo] + (wi - s_off[lo])];
+            scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), s_val[lo]);
+        }
+        __syncthreads();
+    }
+}
+
+// hub columns: every block takes a strided share of each parked column
+template <int OP>
+__global__ __launch_bounds__(256) void spmspv_hub_kernel(ScatterArgs a) {
+    uint32_t nhub = a.hub[0];
+    if (nhub > a.hub_capacity) nhub = a.hub_capacity;
+    for (uint32_t h = 0; h < nhub; h++) {
+        const gl_idx_val iv = a.vec[1u + a.hub[1u + h]];
+        const uint32_t start = a.indptr[iv.index];
+        const uint32_t deg = a.indptr[iv.index + 1u] - start;
+        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < deg; k += gridDim.x * 256u) {
+            const uint2 rv = a.stream[start + k];
+            scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), iv.val);
+        }
+    }
+}
+
+__global__ void hub_reset_kernel(uint32_t *hub) { hub[0] = 0; }
+
+// compaction source over the dense accumulator
+template <int MASK>
+struct AccSource {
+    float *acc;
+    const float *mask;
+    uint32_t nrows;      // rows in the shard
+    uint32_t row_begin;
+    float zero;
+    __device__ uint32_t size() const { return nrows; }
+    __device__ bool get(uint32_t i, gl_idx_val &out) const {
+        float v = acc[i];
+        if (v == zero) return false;  // checkout_results: dense_data != zero (kernel_spmspv_impl.h:199-226)
+        if (MASK != GL_NOMASK) {
+            // write_back_gmem compares the mask with `zero` (kernel_spmspv_impl.h:262-283)
+            if (!mask_allows<MASK>(mask[row_begin + i], zero)) return false;
+        }
+        out.index = row_begin + i;
+        out.val = v;
+        return true;
+    }
+    __device__ void consumed(uint32_t i) const {
+        if (acc[i] != zero) acc[i] = zero;
+    }
+};
+
+template <int OP>
+static int launch_scatter(const ScatterArgs &a, uint32_t grid, hipStream_t s) {
+    hub_reset_kernel<<<1, 1, 0, s>>>(a.hub);
+    GL_LAUNCH_CHECK();
+    spmspv_scatter_kernel<OP><<<grid, 256, 0, s>>>(a);
+    GL_LAUNCH_CHECK();
+    spmspv_hub_kernel<OP><<<1024, 256, 0, s>>>(a);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+}  // namespace gl
+
+extern "C" {
+
+int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_cols,
+                          const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
+                          uint32_t row_begin, uint32_t row_end) {
+    GL_REQUIRE_INIT();
+    GL_ARG(plan != nullptr && h_indptr != nullptr);
+    GL_ARG(row_begin <= row_end && row_end <= num_rows);
+    const uint64_t nnz_all = h_indptr[num_cols];
+    GL_ARG(nnz_all == 0 || (h_indices != nullptr && h_data != nullptr));
+    const bool whole = (row_begin == 0 && row_end == num_rows);
+
+    std::vector<uint32_t> indptr(num_cols + 1ull);
+    std::vector<uint2> stream;
+    stream.reserve(whole ? nnz_all : nnz_all / 2);
+    for (uint32_t c = 0; c < num_cols; c++) {
+        indptr[c] = (uint32_t)stream.size();
+        GL_ARG(h_indptr[c + 1] >= h_indptr[c] && h_indptr[c + 1] <= nnz_all);
+        for (uint64_t i = h_indptr[c]; i < h_indptr[c + 1]; i++) {
+            uint32_t r = h_indices[i];
+            if (r >= num_rows)
+                return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_create: row index %u out of range (num_rows %u)", r, num_rows);
+            if (r >= row_begin && r < row_end) stream.push_back(make_uint2(r, __builtin_bit_cast(uint32_t, h_data[i])));
+        }
+    }
+    indptr[num_cols] = (uint32_t)stream.size();
+
+    gl_spmspv_plan p = new gl_spmspv_plan_s();
+    p->num_rows = num_rows;
+    p->num_cols = num_cols;
+    p->row_begin = row_begin;
+    p->row_end = row_end;
+    p->nnz = stream.size();
+    const uint32_t nrows = row_end - row_begin;
+    p->hub_capacity = 4096;
+    auto fail = [&](hipError_t e) {
+        gl_spmspv_plan_destroy(p);
+        return gl::set_error(GL_ERR_HIP, "gl_spmspv_plan_create: %s", hipGetErrorString(e));
+    };
+    hipError_t e;
+    size_t b_indptr = indptr.size() * sizeof(uint32_t), b_stream = stream.size() * sizeof(uint2);
+    size_t b_acc = (size_t)(nrows ? nrows : 1) * sizeof(float);
+    size_t b_counts = (size_t)(gl::cdiv(nrows, gl::kCompactChunk) + 1) * sizeof(uint32_t);
+    size_t b_hub = (size_t)(p->hub_capacity + 1) * sizeof(uint32_t);
+    if ((e = hipMalloc((void **)&p->d_indptr, b_indptr)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_stream, b_stream ? b_stream : 16)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_acc, b_acc)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_counts, b_counts)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_hub, b_hub)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(p->d_indptr, indptr.data(), b_indptr, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if (b_stream && (e = hipMemcpy(p->d_stream, stream.data(), b_stream, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    p->device_bytes = b_indptr + b_stream + b_acc + b_counts + b_hub;
+    *plan = p;
+    return GL_OK;
+}
+
+int gl_spmspv_plan_destroy(gl_spmspv_plan p) {
+    if (!p) return GL_OK;
+    (void)hipFree(p->d_indptr);
+    (void)hipFree(p->d_stream);
+    (void)hipFree(p->d_acc);
+    (void)hipFree(p->d_counts);
+    (void)hipFree(p->d_hub);
+    delete p;
+    return GL_OK;
+}
+
+int gl_spmspv_plan_info(gl_spmspv_plan p, uint64_t *nnz, uint64_t *device_bytes) {
+    GL_ARG(p != nullptr);
+    if (nnz) *nnz = p->nnz;
+    if (device_bytes) *device_bytes = p->device_bytes;
+    return GL_OK;
+}
+
+int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
+                  int op, float zero, int mask_type) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && d_vector != nullptr && d_result != nullptr);
+    GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
+    GL_ARG(op == GL_OP_MULADD || op == GL_OP_ANDOR || op == GL_OP_ADDMIN);
+    GL_ARG(mask_type == GL_NOMASK || mask_type == GL_MASK_WRITETOZERO || mask_type == GL_MASK_WRITETOONE);
+    hipStream_t s = gl::ctx().stream;
+    const uint32_t nrows = p->row_end - p->row_begin;
+
+    // accumulator invariant: all entries == zero on entry (bitwise compare so -0/NaN refill too)
+    if (!p->acc_valid || memcmp(&p->acc_fill, &zero, sizeof(float)) != 0) {
+        int rc = gl_buf_fill_f32(p->d_acc, zero, nrows);
+        if (rc != GL_OK) return rc;
+        p->acc_fill = zero;
+        p->acc_valid = true;
+    }
+
+    gl::ScatterArgs a;
+    a.indptr = p->d_indptr;
+    a.stream = p->d_stream;
+    a.vec = d_vector;
+    a.acc = p->d_acc;
+    a.hub = p->d_hub;
+    a.hub_capacity = p->hub_capacity;
+    a.row_begin = p->row_begin;
+    a.num_cols = p->num_cols;
+    uint32_t grid = gl::cdiv(p->num_cols, 256);
+    uint32_t cap = (uint32_t)gl::ctx().num_cus * 8u;
+    if (grid > cap) grid = cap;
+    if (grid == 0) grid = 1;
+    int rc;
+    switch (op) {
+        case GL_OP_MULADD: rc = gl::launch_scatter<GL_OP_MULADD>(a, grid, s); break;
+        case GL_OP_ANDOR: rc = gl::launch_scatter<GL_OP_ANDOR>(a, grid, s); break;
+        default: rc = gl::launch_scatter<GL_OP_ADDMIN>(a, grid, s); break;
+    }
+    if (rc != GL_OK) return rc;
+
+    switch (mask_type) {
+        case GL_NOMASK: {
+            gl::AccSource<GL_NOMASK> src{p->d_acc, d_mask, nrows, p->row_begin, zero};
+            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s);
+        }
+        case GL_MASK_WRITETOZERO: {
+            gl::AccSource<GL_MASK_WRITETOZERO> src{p->d_acc, d_mask, nrows, p->row_begin, zero};
+            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s);
+        }
+        default: {
+            gl::AccSource<GL_MASK_WRITETOONE> src{p->d_acc, d_mask, nrows, p->row_begin, zero};
+            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s);
+        }
+    }
+}
+
+int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz) {
+    GL_REQUIRE_INIT();
+    GL_ARG(d_sparse != nullptr && nnz != nullptr);
+    hipStream_t s = gl::ctx().stream;
+    uint32_t v = 0;
+    GL_HIP(hipMemcpyAsync(&v, &d_sparse->index, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+    *nnz = v;
+    return GL_OK;
+}
+
+}  // extern "C"

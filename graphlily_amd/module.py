@@ -1,0 +1,374 @@
+"""Python mirror of the graphlily::module operator API on top of the HIP C ABI.
+
+Same class names, method names, argument meaning and blocking behaviour as the reference's
+header-only modules, so parity tests read like the reference's tests/test_module_*.cpp:
+
+  BaseModule                  module/base_module.h:10-133
+  SpMVModule                  module/spmv_module.h:37-532
+  SpMSpVModule                module/spmspv_module.h:27-520
+  eWiseAddModule              module/add_scalar_vector_dense_module.h:19-204
+  AssignVectorDenseModule     module/assign_vector_dense_module.h:19-246
+  AssignVectorSparseModule    module/assign_vector_sparse_module.h:19-335
+
+The C++ twin (the actual drop-in for C++ callers) lives in include/graphlily/module/*.h and calls
+the same entry points.  Device buffers are capi.DeviceBuffer handles and play the role of the
+public cl::Buffer members (`vector_buf`, `mask_buf`, ...), including being shareable via bind_*.
+`compute_reference_results` is deliberately absent: the CPU reference is test infrastructure
+(oracle/) and the product never routes through it.
+"""
+import collections
+import sys
+
+import numpy as np
+
+from . import capi
+from .capi import IDX_VAL
+
+# ---------------------------------------------------------------- graphlily/global.h
+kMulAdd, kLogicalAndOr, kAddMin = 0, 1, 2                    # :83-87
+kNoMask, kMaskWriteToZero, kMaskWriteToOne = 0, 1, 2         # :103-107
+SemiringType = collections.namedtuple("SemiringType", ["op", "one", "zero"])  # :90-94
+UFIXED_INF = 255.0                                           # :79
+FLOAT_INF = 999999999.0                                      # :80
+ArithmeticSemiring = SemiringType(kMulAdd, 1.0, 0.0)         # :96
+LogicalSemiring = SemiringType(kLogicalAndOr, 1.0, 0.0)      # :97
+# :99-100 -- the reference ships the ap_ufixed line (zero = 255); with val_t = float the FLOAT_INF
+# line is the one to enable.  `zero` is a runtime field here, so either works.
+TropicalSemiring = SemiringType(kAddMin, 0.0, FLOAT_INF)
+TropicalSemiringUfixed = SemiringType(kAddMin, 0.0, UFIXED_INF)
+pack_size = 8                                                # :57
+num_hbm_channels = 16                                        # :59
+idx_marker = 0xFFFFFFFF                                      # :66
+
+
+def _fatal(msg):
+    """The reference reports errors by printing and exit(EXIT_FAILURE) (xcl2.hpp:40-46)."""
+    print(msg, file=sys.stderr)
+    raise SystemExit(1)
+
+
+def make_sparse_vec(indices, vals, head_val=0.0):
+    """aligned_sparse_vec_t with the count in [0].index (module/spmspv_module.h:53-60)."""
+    indices = np.asarray(indices)
+    v = np.zeros(len(indices) + 1, dtype=IDX_VAL)
+    v["index"][0] = len(indices)
+    v["val"][0] = head_val
+    v["index"][1:] = indices
+    v["val"][1:] = vals
+    return v
+
+
+def convert_sparse_vec_to_dense_vec(sparse_vector, rng, zero):
+    """graphlily/global.h:153-164"""
+    dense = np.full(rng, zero, dtype=np.float32)
+    nnz = int(sparse_vector["index"][0])
+    dense[sparse_vector["index"][1:nnz + 1]] = sparse_vector["val"][1:nnz + 1]
+    return dense
+
+
+class BaseModule:
+    def __init__(self, kernel_name="overlay"):
+        self.kernel_name_ = kernel_name
+        self.target_ = "hw"
+        self.device_ = 0
+        self.blocking = True  # every reference call ends in command_queue_.finish()
+
+    def get_kernel_name(self):
+        return self.kernel_name_
+
+    def set_target(self, target):
+        assert target in ("sw_emu", "hw_emu", "hw")  # base_module.h:74-77
+        self.target_ = target
+
+    def set_device(self, device):
+        self.device_ = int(device)
+
+    def set_up_runtime(self, xclbin_file_path=None):
+        """No bitstream on a GPU: the path is accepted and ignored; this selects the device."""
+        capi.init(self.device_)
+
+    def copy_buffer_device_to_device(self, src, dst, nbytes):
+        capi.copy_d2d(dst, src, nbytes)
+        capi.sync()
+
+    def _finish(self):
+        if self.blocking:
+            capi.sync()
+
+
+class SpMVModule(BaseModule):
+    def __init__(self, num_channels=num_hbm_channels, out_buf_len=0, vec_buf_len=0):
+        super().__init__()
+        # FPGA buffer geometry; kept for signature parity, the GPU tiling is chosen by the plan
+        self.num_channels_, self.out_buf_len_, self.vec_buf_len_ = num_channels, out_buf_len, vec_buf_len
+        self.mask_type_ = kNoMask
+        self.semiring_ = ArithmeticSemiring
+        self.csr_matrix_ = None
+        self.plan_ = None
+        self.row_begin_, self.row_end_ = 0, None
+        self.vector_buf = self.mask_buf = self.results_buf = None
+
+    def set_semiring(self, semiring):
+        self.semiring_ = semiring
+
+    def set_mask_type(self, mask_type):
+        self.mask_type_ = mask_type
+
+    def set_row_shard(self, row_begin, row_end):
+        """Multi-GPU extension: this device owns rows [row_begin, row_end) of the matrix."""
+        self.row_begin_, self.row_end_ = int(row_begin), int(row_end)
+
+    def get_num_rows(self):
+        return self.csr_matrix_.num_rows
+
+    def get_num_cols(self):
+        return self.csr_matrix_.num_cols
+
+    def get_nnz(self):
+        return int(self.csr_matrix_.adj_indptr[self.csr_matrix_.num_rows])
+
+    def load_and_format_matrix(self, csr_matrix_float, skip_empty_rows=True):
+        # skip_empty_rows only changes the FPGA stream encoding; results are identical either way
+        self.csr_matrix_ = csr_matrix_float
+        self.skip_empty_rows_ = skip_empty_rows
+
+    def send_matrix_host_to_device(self):
+        m = self.csr_matrix_
+        re = m.num_rows if self.row_end_ is None else self.row_end_
+        self.plan_ = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data,
+                                   self.row_begin_, re)
+        self.results_buf = capi.DeviceBuffer(4 * m.num_rows)
+        capi.fill_f32(self.results_buf, 0.0, m.num_rows)  # spmv_module.h:368-369
+
+    def send_vector_host_to_device(self, vector):
+        vector = np.ascontiguousarray(vector, dtype=np.float32)
+        self.vector_buf = capi.DeviceBuffer(4 * self.get_num_cols())
+        self.vector_buf.write(vector[:self.get_num_cols()])
+
+    def send_mask_host_to_device(self, mask):
+        mask = np.ascontiguousarray(mask, dtype=np.float32)
+        self.mask_buf = capi.DeviceBuffer(4 * self.get_num_rows())
+        self.mask_buf.write(mask[:self.get_num_rows()])
+
+    def bind_mask_buf(self, src_buf):
+        self.mask_buf = src_buf
+
+    def bind_vector_buf(self, src_buf):
+        self.vector_buf = src_buf
+
+    def bind_results_buf(self, src_buf):
+        self.results_buf = src_buf
+
+    def run(self):
+        mask = self.mask_buf if self.mask_type_ != kNoMask else None
+        self.plan_.run(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
+                       self.mask_type_)
+        self._finish()
+
+    def send_vector_device_to_host(self):
+        return self.vector_buf.read(np.float32, self.get_num_cols())
+
+    def send_mask_device_to_host(self):
+        return self.mask_buf.read(np.float32, self.get_num_rows())
+
+    def send_results_device_to_host(self):
+        return self.results_buf.read(np.float32, self.get_num_rows())
+
+
+class SpMSpVModule(BaseModule):
+    def __init__(self, out_buf_len=0):
+        super().__init__()
+        self.out_buf_len_ = out_buf_len
+        self.mask_type_ = kNoMask
+        self.semiring_ = ArithmeticSemiring
+        self.csc_matrix_ = None
+        self.plan_ = None
+        self.row_begin_, self.row_end_ = 0, None
+        self.vector_buf = self.mask_buf = self.results_buf = None
+
+    def set_semiring(self, semiring):
+        self.semiring_ = semiring
+
+    def set_mask_type(self, mask_type):
+        self.mask_type_ = mask_type
+
+    def set_row_shard(self, row_begin, row_end):
+        self.row_begin_, self.row_end_ = int(row_begin), int(row_end)
+
+    def get_num_rows(self):
+        return self.csc_matrix_.num_rows
+
+    def get_num_cols(self):
+        return self.csc_matrix_.num_cols
+
+    def get_nnz(self):
+        return int(self.csc_matrix_.adj_indptr[self.csc_matrix_.num_cols])
+
+    def load_and_format_matrix(self, csc_matrix_float):
+        self.csc_matrix_ = csc_matrix_float
+
+    def send_matrix_host_to_device(self):
+        m = self.csc_matrix_
+        re = m.num_rows if self.row_end_ is None else self.row_end_
+        self.plan_ = capi.SpMSpVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data,
+                                     self.row_begin_, re)
+        # results: num_rows + 1 sparse elements, zero-initialised (spmspv_module.h:283-285)
+        self.results_buf = capi.DeviceBuffer(8 * (m.num_rows + 1))
+        self.results_buf.write(np.zeros(m.num_rows + 1, dtype=IDX_VAL))
+
+    def send_vector_host_to_device(self, vector):
+        """The vector may be shorter than num_cols + 1; the device copy is always that long
+        (spmspv_module.h:280, :379)."""
+        vector = np.ascontiguousarray(vector, dtype=IDX_VAL)
+        self.vector_buf = capi.DeviceBuffer(8 * (self.get_num_cols() + 1))
+        self.vector_buf.write(vector[:self.get_num_cols() + 1])
+
+    def send_mask_host_to_device(self, mask):
+        mask = np.ascontiguousarray(mask, dtype=np.float32)
+        self.mask_buf = capi.DeviceBuffer(4 * mask.shape[0])
+        self.mask_buf.write(mask)
+
+    def bind_mask_buf(self, src_buf):
+        self.mask_buf = src_buf
+
+    def bind_vector_buf(self, src_buf):
+        self.vector_buf = src_buf
+
+    def run(self):
+        mask = self.mask_buf if self.mask_type_ != kNoMask else None
+        self.plan_.run(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
+                       self.mask_type_)
+        self._finish()
+
+    def get_results_nnz(self):
+        return capi.sparse_nnz(self.results_buf)
+
+    def send_vector_device_to_host(self):
+        return self.vector_buf.read(IDX_VAL, self.get_num_cols() + 1)
+
+    def send_mask_device_to_host(self):
+        return self.mask_buf.read(np.float32)
+
+    def send_results_device_to_host(self):
+        return self.results_buf.read(IDX_VAL, self.get_num_rows() + 1)
+
+
+class eWiseAddModule(BaseModule):
+    def __init__(self):
+        super().__init__()
+        self.in_buf = self.out_buf = None
+
+    def send_in_host_to_device(self, in_vec):
+        self.in_buf = capi.DeviceBuffer.from_host(np.ascontiguousarray(in_vec, dtype=np.float32))
+
+    def allocate_out_buf(self, length):
+        self.out_buf = capi.DeviceBuffer(4 * length)
+
+    def bind_in_buf(self, src_buf):
+        self.in_buf = src_buf
+
+    def bind_out_buf(self, src_buf):
+        self.out_buf = src_buf
+
+    def run(self, length, val):
+        capi.ewise_add(self.in_buf, self.out_buf, length, val)
+        self._finish()
+
+    def send_out_device_to_host(self):
+        return self.out_buf.read(np.float32)
+
+
+class AssignVectorDenseModule(BaseModule):
+    def __init__(self):
+        super().__init__()
+        self.mask_type_ = None
+        self.mask_buf = self.inout_buf = None
+
+    def set_mask_type(self, mask_type):
+        if mask_type == kNoMask:
+            _fatal("Please set the mask type")  # assign_vector_dense_module.h:88-95
+        self.mask_type_ = mask_type
+
+    def send_mask_host_to_device(self, mask):
+        self.mask_buf = capi.DeviceBuffer.from_host(np.ascontiguousarray(mask, dtype=np.float32))
+
+    def send_inout_host_to_device(self, inout):
+        self.inout_buf = capi.DeviceBuffer.from_host(np.ascontiguousarray(inout, dtype=np.float32))
+
+    def bind_mask_buf(self, src_buf):
+        self.mask_buf = src_buf
+
+    def bind_inout_buf(self, src_buf):
+        self.inout_buf = src_buf
+
+    def run(self, length, val):
+        if self.mask_type_ not in (kMaskWriteToZero, kMaskWriteToOne):
+            _fatal("Invalid mask type")  # assign_vector_dense_module.h:242-245
+        capi.assign_dense(self.mask_buf, self.inout_buf, length, val, self.mask_type_)
+        self._finish()
+
+    def send_mask_device_to_host(self):
+        return self.mask_buf.read(np.float32)
+
+    def send_inout_device_to_host(self):
+        return self.inout_buf.read(np.float32)
+
+
+class AssignVectorSparseModule(BaseModule):
+    def __init__(self, generate_new_frontier):
+        super().__init__()
+        self.generate_new_frontier_ = bool(generate_new_frontier)
+        self.mask_buf = self.inout_buf = self.new_frontier_buf = None
+
+    def send_mask_host_to_device(self, mask):
+        mask = np.ascontiguousarray(mask, dtype=IDX_VAL)
+        self.mask_buf = capi.DeviceBuffer.from_host(mask)
+        if self.generate_new_frontier_:
+            # the new frontier can never be longer than the mask (assign_vector_sparse_module.h:238-253)
+            self.new_frontier_buf = capi.DeviceBuffer(mask.nbytes)
+            self.new_frontier_buf.write(np.zeros(mask.shape[0], dtype=IDX_VAL))
+
+    def send_inout_host_to_device(self, inout):
+        self.inout_buf = capi.DeviceBuffer.from_host(np.ascontiguousarray(inout, dtype=np.float32))
+
+    def bind_mask_buf(self, src_buf):
+        self.mask_buf = src_buf
+
+    def bind_inout_buf(self, src_buf):
+        self.inout_buf = src_buf
+
+    def bind_new_frontier_buf(self, src_buf):
+        if not self.generate_new_frontier_:
+            _fatal("[ERROR]: this->generate_new_frontier_ should be true")
+        self.new_frontier_buf = src_buf
+
+    def _max_entries(self):
+        cap = self.mask_buf.nbytes // 8 - 1
+        if self.generate_new_frontier_:
+            cap = min(cap, self.new_frontier_buf.nbytes // 8 - 1)
+        return max(cap, 0)
+
+    def run(self, val=None):
+        if val is None:
+            # SSSP mode (assign_vector_sparse_module.h:295-303)
+            if not self.generate_new_frontier_:
+                _fatal("[ERROR]: this->generate_new_frontier_ should be true")
+            capi.assign_sparse_new_frontier(self.mask_buf, self.inout_buf, self.new_frontier_buf,
+                                            self._max_entries())
+        else:
+            # BFS mode (assign_vector_sparse_module.h:278-292)
+            if self.generate_new_frontier_:
+                _fatal("[ERROR]: this->generate_new_frontier_ should be false")
+            capi.assign_sparse(self.mask_buf, self.inout_buf, val, self._max_entries())
+        self._finish()
+
+    def send_mask_device_to_host(self):
+        return self.mask_buf.read(IDX_VAL)
+
+    def send_inout_device_to_host(self):
+        return self.inout_buf.read(np.float32)
+
+    def send_new_frontier_device_to_host(self):
+        if not self.generate_new_frontier_:
+            _fatal("[ERROR]: this->generate_new_frontier_ should be true")
+        return self.new_frontier_buf.read(IDX_VAL)

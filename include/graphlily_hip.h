@@ -1,0 +1,173 @@
+/*
+ * graphlily_hip.h -- C ABI of libgraphlily_hip.so, the MI355X (gfx950) backend
+ * behind the graphlily::module operator API.
+ *
+ * This is the drop-in boundary: everything the reference does by talking to
+ * the FPGA through OpenCL/XRT -- cl::Buffer + enqueueMigrateMemObjects,
+ * enqueueCopyBuffer, and enqueueTask(overlay, mode=1..6) -- is replaced by the
+ * entry points below.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *  - Every function returns GL_OK (0) or a negative gl_status; the message of
+ *    the last failure on the calling thread is available via gl_last_error().
+ *    Nothing throws across the boundary.  (The reference prints and exits,
+ *    xrt/includes/xcl2/xcl2.hpp:40-46; the C++ module layer in
+ *    include/graphlily/ keeps that convention on top of these codes.)
+ *  - `d_` parameters are DEVICE pointers (from gl_buf_alloc or any other HIP
+ *    allocation on the current device, e.g. a torch tensor's data_ptr()).
+ *  - Work is enqueued on the library's current stream (gl_set_stream) and is
+ *    asynchronous; gl_sync() is the analogue of command_queue_.finish().
+ *  - val_t is float (graphlily/global.h:64), idx_t is uint32_t (:65), a
+ *    sparse-vector element is {uint32 index; float val} with element [0]
+ *    holding the non-zero count in .index (global.h:69, spmspv_module.h:53-60).
+ *  - There is no CPU fallback: without a HIP device gl_init fails and every
+ *    compute entry point returns GL_ERR_NOT_INITIALIZED.
+ */
+#ifndef GRAPHLILY_HIP_H_
+#define GRAPHLILY_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gl_status {
+    GL_OK = 0,
+    GL_ERR_INVALID_ARG = -1,
+    GL_ERR_HIP = -2,
+    GL_ERR_NOT_INITIALIZED = -3,
+    GL_ERR_IO = -4,
+    GL_ERR_UNSUPPORTED = -5
+} gl_status;
+
+/* graphlily/global.h:83-87 OperationType */
+typedef enum gl_op { GL_OP_MULADD = 0, GL_OP_ANDOR = 1, GL_OP_ADDMIN = 2 } gl_op;
+/* graphlily/global.h:103-107 MaskType */
+typedef enum gl_mask { GL_NOMASK = 0, GL_MASK_WRITETOZERO = 1, GL_MASK_WRITETOONE = 2 } gl_mask;
+
+/* graphlily/global.h:69 idx_val_t (val_t = float) */
+typedef struct gl_idx_val { uint32_t index; float val; } gl_idx_val;
+
+typedef struct gl_spmv_plan_s *gl_spmv_plan;     /* formatted matrix for SpMV   */
+typedef struct gl_spmspv_plan_s *gl_spmspv_plan; /* formatted matrix for SpMSpV */
+
+/* ------------------------------------------------------------------ runtime
+ * Replaces BaseModule::set_up_runtime / ModuleCollection::set_up_runtime
+ * (module/base_module.h:106-133, app/module_collection.h:69-114): device
+ * discovery, context, command queue.  No bitstream to load. */
+int gl_init(int device);                /* hipSetDevice + library stream        */
+int gl_device_count(int *count);
+int gl_set_stream(void *hip_stream);    /* adopt a caller-owned hipStream_t (NULL = library stream) */
+int gl_sync(void);                      /* command_queue_.finish()              */
+const char *gl_last_error(void);
+const char *gl_version(void);
+
+/* ------------------------------------------------------------------ buffers
+ * Replace cl::Buffer(CL_MEM_USE_HOST_PTR) + enqueueMigrateMemObjects
+ * (e.g. module/spmv_module.h:424-439, :229-253) and
+ * BaseModule::copy_buffer_device_to_device (module/base_module.h:82-85). */
+int gl_buf_alloc(void **d_ptr, size_t bytes);
+int gl_buf_free(void *d_ptr);
+int gl_buf_h2d(void *d_dst, const void *h_src, size_t bytes);   /* blocking */
+int gl_buf_d2h(void *h_dst, const void *d_src, size_t bytes);   /* blocking */
+int gl_buf_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async    */
+int gl_buf_fill_f32(float *d_dst, float value, size_t count);   /* async    */
+
+/* --------------------------------------------------------------------- SpMV
+ * gl_spmv_plan_create replaces SpMVModule::load_and_format_matrix +
+ * send_matrix_host_to_device (module/spmv_module.h:281-420): it re-lays the
+ * host CSR (io/data_loader.h:18-30) out as the CDNA4 row-segment stream and
+ * uploads it.  [row_begin,row_end) selects the row shard this device owns
+ * (0,num_rows = whole matrix); x is always indexed by global column and y by
+ * global row, so a shard writes y[row_begin..row_end) of a full-length y. */
+int gl_spmv_plan_create(gl_spmv_plan *plan,
+                        uint32_t num_rows, uint32_t num_cols,
+                        const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
+                        uint32_t row_begin, uint32_t row_end);
+int gl_spmv_plan_destroy(gl_spmv_plan plan);
+/* nnz held by this plan (its shard) and device bytes of the formatted matrix */
+int gl_spmv_plan_info(gl_spmv_plan plan, uint64_t *nnz, uint64_t *device_bytes, uint32_t *num_tiles);
+
+/* gl_spmv_run replaces enqueueTask(overlay, mode = 1) (module/spmv_module.h:471-475,
+ * hw/overlay.cpp:308-330 -> hw/kernel_spmv_impl.h:392-819):
+ *   y[r] = mask_r ? ( zero (+) sum_{i in row r} A_i (x) x[col_i] ) : 0
+ * op selects ((+),(x)): MULADD (+,*), ANDOR (||,&&), ADDMIN (min,+); `zero` is
+ * SemiringType::zero (global.h:90-94).  d_mask may be NULL iff mask_type is
+ * GL_NOMASK.  WriteToZero keeps rows with mask==0, WriteToOne rows with
+ * mask!=0; masked-off rows are written as literal 0 (kernel_spmv_impl.h:361-386,
+ * spmv_module.h:518-530). */
+int gl_spmv_run(gl_spmv_plan plan, const float *d_x, const float *d_mask, float *d_y,
+                int op, float zero, int mask_type);
+
+/* ------------------------------------------------------------------- SpMSpV
+ * gl_spmspv_plan_create replaces SpMSpVModule::load_and_format_matrix +
+ * send_matrix_host_to_device (module/spmspv_module.h:263-370, formatCSC
+ * io/data_formatter.h:543-721) for a host CSC (io/data_loader.h:92-104).
+ * [row_begin,row_end) keeps only the entries whose row falls in the shard. */
+int gl_spmspv_plan_create(gl_spmspv_plan *plan,
+                          uint32_t num_rows, uint32_t num_cols,
+                          const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
+                          uint32_t row_begin, uint32_t row_end);
+int gl_spmspv_plan_destroy(gl_spmspv_plan plan);
+int gl_spmspv_plan_info(gl_spmspv_plan plan, uint64_t *nnz, uint64_t *device_bytes);
+
+/* gl_spmspv_run replaces enqueueTask(overlay, mode = 2) (module/spmspv_module.h:436-441,
+ * hw/kernel_spmspv_impl.h:448-562).  d_vector is a sparse vector (count in
+ * [0].index, at most num_cols entries); d_result receives the sparse result:
+ * [0] = {nnz, zero}, then every row r (ascending) with acc[r] != zero whose mask
+ * allows it: NOMASK all, WriteToOne mask[r] != zero, WriteToZero mask[r] == zero
+ * (hw/kernel_spmspv_impl.h:262-283 -- note: compared with `zero`, not 0).
+ * d_result must hold rows_in_shard + 1 elements.  The (min,+) product saturates
+ * at FLOAT_INF = 999999999 (hw/float_pe.h:24-33). */
+int gl_spmspv_run(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask,
+                  gl_idx_val *d_result, int op, float zero, int mask_type);
+
+/* SpMSpVModule::get_results_nnz (module/spmspv_module.h:239-242): the one
+ * device->host control read per push iteration.  Blocking. */
+int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz);
+
+/* ---------------------------------------------------------------- apply ops */
+/* mode 3, eWiseAddModule::run (module/add_scalar_vector_dense_module.h:179-192,
+ * hw/kernel_add_scalar_vector_dense_impl.h:6-27): out[i] = in[i] + val. */
+int gl_ewise_add(const float *d_in, float *d_out, uint32_t len, float val);
+
+/* mode 4, AssignVectorDenseModule::run (module/assign_vector_dense_module.h:208-220,
+ * hw/kernel_assign_vector_dense_impl.h:8-47): WriteToZero: mask[i]==0 -> inout[i]=val;
+ * WriteToOne: mask[i]!=0 -> inout[i]=val; NOMASK is GL_ERR_INVALID_ARG. */
+int gl_assign_dense(const float *d_mask, float *d_inout, uint32_t len, float val, int mask_type);
+
+/* mode 5, AssignVectorSparseModule::run(val) (module/assign_vector_sparse_module.h:278-292,
+ * hw/kernel_assign_vector_sparse_no_new_frontier_impl.h:4-55):
+ * inout[mask[k].index] = val for k in 1..mask[0].index.  max_entries bounds the
+ * launch (capacity of d_mask minus the head). */
+int gl_assign_sparse(const gl_idx_val *d_mask, float *d_inout, float val, uint32_t max_entries);
+
+/* mode 6, AssignVectorSparseModule::run() (module/assign_vector_sparse_module.h:295-303,
+ * hw/kernel_assign_vector_sparse_new_frontier_impl.h:4-78): for every mask entry
+ * (idx,v): if inout[idx] > v { inout[idx] = v; push (idx,v) }.  d_new_frontier
+ * gets head {count, 0} and the pushed entries in mask order. d_scratch is optional. */
+int gl_assign_sparse_new_frontier(const gl_idx_val *d_mask, float *d_inout,
+                                  gl_idx_val *d_new_frontier, uint32_t max_entries);
+
+/* ---------------------------------------------------------------- utilities */
+/* convert_sparse_vec_to_dense_vec (graphlily/global.h:153-164) on device; replaces
+ * the host round trip at the push->pull switch (app/bfs.h:196-201). */
+int gl_sparse_to_dense(const gl_idx_val *d_sparse, float *d_dense, uint32_t range, float zero,
+                       uint32_t max_entries);
+
+/* scipy-npz CSR loader: replaces cnpy::npz_load in
+ * load_csr_matrix_from_float_npz (io/data_loader.h:51-70).  Two-call protocol:
+ * gl_npz_csr_open parses the file and reports sizes, gl_npz_csr_read copies
+ * into caller arrays and closes the handle (gl_npz_csr_close to abandon). */
+typedef struct gl_npz_csr_s *gl_npz_csr;
+int gl_npz_csr_open(const char *path, gl_npz_csr *handle,
+                    uint32_t *num_rows, uint32_t *num_cols, uint64_t *nnz);
+int gl_npz_csr_read(gl_npz_csr handle, float *data, uint32_t *indices, uint32_t *indptr);
+int gl_npz_csr_close(gl_npz_csr handle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHLILY_HIP_H_ */

@@ -1,0 +1,72 @@
+"""Scratch perf probe (not part of the product): time gl_spmv_run on a paper-graph stand-in."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphlily_amd import capi, datasets, io  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graph", default="ogbn_products")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--ops", default="0")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    capi.init(0)
+    capi.set_stream(torch.cuda.current_stream().cuda_stream)
+    t0 = time.time()
+    m = datasets.paper_graph(args.graph, args.scale, device=dev)
+    io.util_round_csr_matrix_dim(m, 128, 8)
+    m.adj_data = np.full(m.nnz, np.float32(1.0 / m.num_rows), dtype=np.float32)
+    t1 = time.time()
+    lens = np.diff(m.adj_indptr.astype(np.int64))
+    print("graph %s: n=%d nnz=%d gen %.1fs; deg max %d mean %.1f median %d empty %d" %
+          (args.graph, m.num_rows, m.nnz, t1 - t0, lens.max(), lens.mean(), np.median(lens), (lens == 0).sum()),
+          flush=True)
+    plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data)
+    print("plan create %.1fs" % (time.time() - t1), plan.info(), flush=True)
+    x = torch.randint(0, 2, (m.num_cols,), device=dev).float()
+    mask = torch.randint(0, 2, (m.num_rows,), device=dev).float()
+    y = torch.zeros(m.num_rows, device=dev)
+    bx, bm, by = (capi.DeviceBuffer.from_torch(t) for t in (x, mask, y))
+    nbytes = 8 * m.nnz + 12 * m.num_rows + 4
+    for op in [int(o) for o in args.ops.split(",")]:
+        for mt in (0, 1):
+            zero = 0.0 if op < 2 else 255.0
+            for _ in range(3):
+                plan.run(bx, bm, by, op, zero, mt)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                plan.run(bx, bm, by, op, zero, mt)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            print("op %d mask %d: %.3f ms  %.1f GTEPS  %.0f GB/s effective (%.1f%% of 8 TB/s)" %
+                  (op, mt, ms, m.nnz / ms / 1e6, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80), flush=True)
+    # streaming ceiling for reference: float4 copy of a 2 GiB buffer
+    a = torch.empty(1 << 29, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print("copy ceiling: %.0f GB/s (read+write)" % (2 * a.numel() * 4 / ms / 1e6))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""Shared helpers for the parity tests (the oracle is the checker, never the thing under test)."""
+import numpy as np
+
+from graphlily_amd import datasets, io
+from oracle import oracle as O
+
+
+def to_oracle(m):
+    cls = O.CSC if isinstance(m, io.CSCMatrix) else O.CSR
+    return cls(m.num_rows, m.num_cols, m.adj_data, m.adj_indices, m.adj_indptr)
+
+
+def rand01(n, seed):
+    """The reference draws x and masks as rand() % 2 (tests/test_module_spmv_spmspv.cpp:105-111);
+    seeded here."""
+    return np.random.default_rng(seed).integers(0, 2, size=n).astype(np.float32)
+
+
+def named_matrix(name):
+    if name == "dense_32":
+        return datasets.dense(32)
+    if name == "dense_1K":
+        return datasets.dense(1024)
+    if name == "uniform_10K_10":
+        return datasets.uniform(10000, 10, seed=7)
+    if name == "rmat_20K":          # power-law: a few rows far longer than a tile, many empty rows
+        return datasets.rmat(20000, 400000, seed=11, symmetric=False)
+    if name == "rmat_sym_50K":
+        return datasets.rmat(50000, 1500000, seed=12, symmetric=True)
+    if name == "gplus_small":       # googleplus stand-in at 1/8 scale
+        return datasets.paper_graph("googleplus", scale=0.125)
+    raise KeyError(name)
+
+
+def spmv_prepare(name, row_div=128, col_div=8):
+    """Matrix preparation of the reference SpMV test (tests/test_module_spmv_spmspv.cpp:144-151):
+    pad rows to num_hbm_channels*pack_size and cols to pack_size, values = 1/num_rows."""
+    m = named_matrix(name)
+    io.util_round_csr_matrix_dim(m, row_div, col_div)
+    m.adj_data = np.full(m.adj_data.shape[0], np.float32(1.0 / m.num_rows), dtype=np.float32)
+    return m
+
+
+SEMIRINGS = {"Arithmetic": (0, 0.0), "Logical": (1, 0.0), "Tropical": (2, 255.0), "TropicalFloatInf": (2, 999999999.0)}
+MASKS = {"NoMask": 0, "WriteToZero": 1, "WriteToOne": 2}
+
+
+def assert_parity(got, ref, op, what=""):
+    """Bit-exact for the boolean and (min,+) semirings; 1e-5 relative for float (+,x)
+    (BASELINE.json north_star).  The tiny atol only absorbs sums that are exactly 0 in one order."""
+    got = np.asarray(got, dtype=np.float32)
+    ref = np.asarray(ref, dtype=np.float32)
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, got.shape, ref.shape)
+    if op == 0:
+        ok = np.allclose(got, ref, rtol=1e-5, atol=1e-9)
+        if not ok:
+            bad = np.nonzero(~np.isclose(got, ref, rtol=1e-5, atol=1e-9))[0]
+            raise AssertionError("%s: %d mismatches, first at %d: got %r ref %r" %
+                                 (what, bad.size, bad[0], got[bad[0]], ref[bad[0]]))
+    else:
+        if not np.array_equal(got, ref):
+            bad = np.nonzero(got != ref)[0]
+            raise AssertionError("%s: %d mismatches (bit-exact required), first at %d: got %r ref %r" %
+                                 (what, bad.size, bad[0], got[bad[0]], ref[bad[0]]))

@@ -1,0 +1,162 @@
+"""GPU parity: SpMSpVModule through the C ABI vs the CPU oracle.
+Cases follow TEST(SpMSpV, MultipleCases) (tests/test_module_spmv_spmspv.cpp:244-314): the bank-conflict
+CSC, dense_1K, uniform_10K_10 and a google+ stand-in at the reference's vector sparsities, all three
+semirings x all three masks.  As in the reference (:236-240) the sparse result is compared after
+convert_sparse_vec_to_dense_vec; on top, this build's documented ordering (ascending, unique) is checked."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from graphlily_amd import datasets, io, module as M
+from oracle import oracle as O
+
+from helpers import MASKS, SEMIRINGS, assert_parity, named_matrix, rand01, to_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _strided_vector(num_cols, sparsity, seed):
+    """tests/test_module_spmv_spmspv.cpp:196-209: every k-th column, values (rand()%10)/10."""
+    nnz = int(np.floor(num_cols * (1 - sparsity)))
+    inc = num_cols // nnz
+    vals = (np.random.default_rng(seed).integers(0, 10, size=nnz) / 10.0).astype(np.float32)
+    return M.make_sparse_vec(np.arange(nnz, dtype=np.uint32) * inc, vals)
+
+
+def _run(gpu, csc, sem, mask_name, v, mask, shard=None):
+    op, zero = SEMIRINGS[sem]
+    mod = M.SpMSpVModule(512)
+    mod.set_semiring(M.SemiringType(op, 1.0, zero))
+    mod.set_mask_type(MASKS[mask_name])
+    mod.set_up_runtime()
+    if shard:
+        mod.set_row_shard(*shard)
+    mod.load_and_format_matrix(csc)
+    mod.send_matrix_host_to_device()
+    mod.send_mask_host_to_device(mask)
+    mod.send_vector_host_to_device(v)
+    mod.run()
+    res = mod.send_results_device_to_host()
+    nnz = mod.get_results_nnz()
+    assert nnz == int(res["index"][0])
+    idx = res["index"][1:nnz + 1].astype(np.int64)
+    assert np.all(np.diff(idx) > 0), "result indices must be ascending and unique"
+    assert res["val"][0] == np.float32(zero)          # head {nnz, Zero} (kernel_spmspv_impl.h:551-555)
+    assert not np.any(res["val"][1:nnz + 1] == np.float32(zero)), "entries equal to zero must not be emitted"
+    return M.convert_sparse_vec_to_dense_vec(res, csc.num_rows, zero), mod
+
+
+def _case(gpu, csc, sem, mask_name, sparsity, seed=0):
+    v = _strided_vector(csc.num_cols, sparsity, seed)
+    mask = rand01(csc.num_rows, seed + 100)
+    got, _ = _run(gpu, csc, sem, mask_name, v, mask)
+    op, zero = SEMIRINGS[sem]
+    ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS[mask_name])
+    assert_parity(got, ref, op, "%s/%s/%.4f" % (sem, mask_name, sparsity))
+
+
+def _csc(name):
+    if name == "conflict1024":
+        return datasets.conflict(1024)
+    c = io.csr2csc(named_matrix(name))
+    c.adj_data = np.full(c.nnz, np.float32(1.0 / c.num_rows), dtype=np.float32)   # :252-266
+    return c
+
+
+@pytest.mark.parametrize("name,sparsity", [("conflict1024", 0.0), ("dense_1K", 0.5), ("uniform_10K_10", 0.5),
+                                            ("gplus_small", 0.99), ("dense_1K", 0.99)])
+def test_reference_arithmetic_cases(gpu, name, sparsity):
+    _case(gpu, _csc(name), "Arithmetic", "NoMask", sparsity)
+
+
+@pytest.mark.parametrize("mask_name", list(MASKS))
+@pytest.mark.parametrize("sem", ["Arithmetic", "Logical", "Tropical"])
+def test_dense_1K_all_semirings_masks(gpu, sem, mask_name):
+    _case(gpu, _csc("dense_1K"), sem, mask_name, 0.99)
+
+
+@pytest.mark.parametrize("mask_name", list(MASKS))
+@pytest.mark.parametrize("sem", ["Logical", "Tropical", "TropicalFloatInf", "Arithmetic"])
+@pytest.mark.parametrize("sparsity", [0.9, 0.999])
+def test_power_law(gpu, sem, mask_name, sparsity):
+    """gplus stand-in: hub columns exceed the hub threshold, short columns dominate the count."""
+    c = io.csr2csc(named_matrix("gplus_small"))
+    if sem.startswith("Tropical"):
+        c.adj_data = np.random.default_rng(2).integers(1, 5, size=c.nnz).astype(np.float32)
+    op, zero = SEMIRINGS[sem]
+    v = _strided_vector(c.num_cols, sparsity, 3)
+    if sem.startswith("Tropical"):
+        # mask values drawn from {zero, 0}: the SpMSpV mask is compared with semiring.zero
+        mask = np.where(rand01(c.num_rows, 5) > 0, np.float32(zero), np.float32(0)).astype(np.float32)
+    else:
+        mask = rand01(c.num_rows, 5)
+    got, _ = _run(gpu, c, sem, mask_name, v, mask)
+    ref = O.spmspv(to_oracle(c), v, op, zero, mask, MASKS[mask_name])
+    assert_parity(got, ref, op, "gplus/%s/%s" % (sem, mask_name))
+
+
+def test_saturating_min_plus(gpu):
+    """(min,+) products saturate at FLOAT_INF (hw/float_pe.h:24-33, spmspv_module.h:482-491)."""
+    c = _csc("dense_1K")
+    c.adj_data[::3] = np.float32(2e9)
+    v = M.make_sparse_vec([0, 5, 9], [np.float32(3e9), 1.0, np.float32(9.9e8)])
+    zero = 999999999.0
+    got, _ = _run(gpu, c, "TropicalFloatInf", "NoMask", v, np.zeros(c.num_rows, np.float32))
+    ref = O.spmspv(to_oracle(c), v, O.ADDMIN, zero)
+    assert_parity(got, ref, 2, "saturation")
+
+
+def test_repeated_runs_and_empty_frontier(gpu):
+    """The accumulator is restored by every run; an empty frontier gives an empty result; changing the
+    semiring zero between runs re-initialises it."""
+    c = io.csr2csc(named_matrix("uniform_10K_10"))
+    oc = to_oracle(c)
+    mod = M.SpMSpVModule(512)
+    mod.set_up_runtime()
+    mod.load_and_format_matrix(c)
+    mod.send_matrix_host_to_device()
+    mask = rand01(c.num_rows, 1)
+    mod.send_mask_host_to_device(mask)
+    for it, (sem, mk, sp) in enumerate([("Logical", "WriteToZero", 0.9), ("Tropical", "NoMask", 0.99),
+                                        ("Arithmetic", "WriteToOne", 0.5), ("Logical", "NoMask", 0.999)]):
+        op, zero = SEMIRINGS[sem]
+        mod.set_semiring(M.SemiringType(op, 1.0, zero))
+        mod.set_mask_type(MASKS[mk])
+        v = _strided_vector(c.num_cols, sp, it)
+        mod.send_vector_host_to_device(v)
+        mod.run()
+        got = M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), c.num_rows, zero)
+        assert_parity(got, O.spmspv(oc, v, op, zero, mask, MASKS[mk]), op, "run %d" % it)
+    mod.send_vector_host_to_device(M.make_sparse_vec([], []))
+    mod.run()
+    assert mod.get_results_nnz() == 0
+
+
+def test_row_shards_concatenate(gpu):
+    """Row-sharded plans produce disjoint ascending slices whose concatenation is the full result."""
+    c = io.csr2csc(named_matrix("rmat_20K"))
+    v = _strided_vector(c.num_cols, 0.95, 1)
+    mask = rand01(c.num_rows, 2)
+    full, _ = _run(gpu, c, "Logical", "WriteToZero", v, mask)
+    cut = 9984
+    a, _ = _run(gpu, c, "Logical", "WriteToZero", v, mask, shard=(0, cut))
+    b, _ = _run(gpu, c, "Logical", "WriteToZero", v, mask, shard=(cut, c.num_rows))
+    assert not a[cut:].any() and not b[:cut].any()
+    assert np.array_equal(a + b, full)
+
+
+def test_golden_known_answers(gpu, golden_dir):
+    G = json.load(open(os.path.join(golden_dir, "reference_known_answers.json")))
+    S = G["survey_8c"]["semiring_mask"]
+    m = io.load_csr_matrix_from_float_npz(os.path.join(golden_dir, "line_8_csr_float32.npz"))
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    m.adj_data[:] = 1
+    c = io.csr2csc(m)
+    mask = (np.arange(128) % 2).astype(np.float32)
+    v = M.make_sparse_vec([p[0] for p in S["spmspv_v"]], [p[1] for p in S["spmspv_v"]])
+    for on, sem in (("arith", "Arithmetic"), ("logical", "Logical"), ("tropical", "Tropical")):
+        for mn, mk in (("nomask", "NoMask"), ("wzero", "WriteToZero"), ("wone", "WriteToOne")):
+            got, _ = _run(gpu, c, sem, mk, v, mask)
+            assert got[:10].tolist() == S["spmspv"][on][mn], (on, mn)

@@ -1,0 +1,144 @@
+"""GPU parity: SpMVModule through the C ABI vs the CPU oracle.
+Cases follow the reference's TEST(SpMV, MultipleCases) (tests/test_module_spmv_spmspv.cpp:137-178):
+{Arithmetic, Logical} x {NoMask, WriteToZero, WriteToOne} x skip_empty_rows on dense_32, Arithmetic x 3
+masks on uniform_10K_10 -- widened with the Tropical semiring and power-law matrices (long rows, empty
+rows, non-contiguous tiles)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from graphlily_amd import io, module as M
+from oracle import oracle as O
+
+from helpers import MASKS, SEMIRINGS, assert_parity, rand01, spmv_prepare, to_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_spmv(gpu, m, sem, mask_name, x, mask, skip_empty_rows=True, shard=None):
+    op, zero = SEMIRINGS[sem]
+    mod = M.SpMVModule(M.num_hbm_channels, 1024, 256)
+    mod.set_semiring(M.SemiringType(op, 1.0, zero))
+    mod.set_mask_type(MASKS[mask_name])
+    mod.set_target("hw")
+    mod.set_up_runtime("unused.xclbin")
+    if shard:
+        mod.set_row_shard(*shard)
+    mod.load_and_format_matrix(m, skip_empty_rows)
+    mod.send_matrix_host_to_device()
+    mod.send_vector_host_to_device(x)
+    mod.send_mask_host_to_device(mask)
+    mod.run()
+    return mod.send_results_device_to_host()
+
+
+def _ref_spmv(m, sem, mask_name, x, mask):
+    op, zero = SEMIRINGS[sem]
+    om = to_oracle(m)
+    if MASKS[mask_name] == O.NOMASK:
+        return O.spmv(om, x, op, zero)
+    return O.spmv(om, x, op, zero, mask, MASKS[mask_name])
+
+
+@pytest.mark.parametrize("skip_empty_rows", [False, True])
+@pytest.mark.parametrize("mask_name", list(MASKS))
+@pytest.mark.parametrize("sem", ["Arithmetic", "Logical", "Tropical"])
+def test_dense_32(gpu, sem, mask_name, skip_empty_rows):
+    m = spmv_prepare("dense_32")
+    x, mask = rand01(m.num_cols, 1), rand01(m.num_rows, 2)
+    got = _run_spmv(gpu, m, sem, mask_name, x, mask, skip_empty_rows)
+    assert_parity(got, _ref_spmv(m, sem, mask_name, x, mask), SEMIRINGS[sem][0], "dense_32/%s/%s" % (sem, mask_name))
+
+
+@pytest.mark.parametrize("mask_name", list(MASKS))
+@pytest.mark.parametrize("sem", ["Arithmetic", "Logical", "Tropical", "TropicalFloatInf"])
+@pytest.mark.parametrize("name", ["uniform_10K_10", "rmat_20K", "rmat_sym_50K"])
+def test_matrices(gpu, name, sem, mask_name):
+    m = spmv_prepare(name)
+    if sem.startswith("Tropical"):
+        # distinct, non-trivial weights so (min,+) is not degenerate
+        m.adj_data = (np.random.default_rng(5).integers(1, 9, size=m.nnz)).astype(np.float32)
+        x = np.where(rand01(m.num_cols, 3) > 0, np.float32(SEMIRINGS[sem][1]),
+                     np.random.default_rng(4).integers(0, 50, size=m.num_cols).astype(np.float32)).astype(np.float32)
+    else:
+        x = rand01(m.num_cols, 3)
+    mask = rand01(m.num_rows, 4)
+    got = _run_spmv(gpu, m, sem, mask_name, x, mask)
+    assert_parity(got, _ref_spmv(m, sem, mask_name, x, mask), SEMIRINGS[sem][0], "%s/%s/%s" % (name, sem, mask_name))
+
+
+def test_float_values_random(gpu):
+    """Arbitrary float weights and a dense random x: the float (+,x) tolerance case."""
+    m = spmv_prepare("rmat_sym_50K")
+    rng = np.random.default_rng(9)
+    m.adj_data = rng.random(m.nnz, dtype=np.float32)
+    x = rng.random(m.num_cols, dtype=np.float32)
+    got = _run_spmv(gpu, m, "Arithmetic", "NoMask", x, rand01(m.num_rows, 1))
+    assert_parity(got, _ref_spmv(m, "Arithmetic", "NoMask", x, None), 0, "random floats")
+
+
+@pytest.mark.parametrize("tile", ["64", "256", "4096"])
+def test_tile_sizes(gpu, tile, monkeypatch):
+    """The tile size only changes the work decomposition (more / fewer LONG rows), never results."""
+    monkeypatch.setenv("GRAPHLILY_SPMV_TILE_NNZ", tile)
+    m = spmv_prepare("rmat_20K")
+    x, mask = rand01(m.num_cols, 7), rand01(m.num_rows, 8)
+    for sem in ("Logical", "Tropical", "Arithmetic"):
+        got = _run_spmv(gpu, m, sem, "WriteToZero", x, mask)
+        assert_parity(got, _ref_spmv(m, sem, "WriteToZero", x, mask), SEMIRINGS[sem][0], "tile %s %s" % (tile, sem))
+
+
+def test_edge_shapes(gpu):
+    # all rows empty
+    m = io.CSRMatrix(256, 64, [], [], np.zeros(257, np.uint32))
+    x, mask = rand01(64, 1), rand01(256, 2)
+    for sem in ("Arithmetic", "Tropical"):
+        for mk in MASKS:
+            got = _run_spmv(gpu, m, sem, mk, x, mask)
+            assert_parity(got, _ref_spmv(m, sem, mk, x, mask), 1, "empty %s %s" % (sem, mk))
+    # one row holds everything (a single very long row), ragged size
+    n = 100003
+    m = io.CSRMatrix(3, n, np.ones(n, np.float32), np.arange(n, dtype=np.uint32), [0, 0, n, n])
+    x = rand01(n, 3)
+    got = _run_spmv(gpu, m, "Arithmetic", "NoMask", x, np.zeros(3, np.float32))
+    assert_parity(got, _ref_spmv(m, "Arithmetic", "NoMask", x, None), 0, "one long row")
+    got = _run_spmv(gpu, m, "Logical", "WriteToOne", x, np.array([1, 1, 0], np.float32))
+    assert_parity(got, _ref_spmv(m, "Logical", "WriteToOne", x, np.array([1, 1, 0], np.float32)), 1, "one long row logical")
+
+
+def test_row_shards_compose(gpu):
+    """Two row shards write disjoint slices of one y: the multi-GPU decomposition on one device."""
+    m = spmv_prepare("rmat_20K")
+    x, mask = rand01(m.num_cols, 1), rand01(m.num_rows, 2)
+    ref = _ref_spmv(m, "Tropical", "WriteToZero", x, mask)
+    cut = 7040
+    a = _run_spmv(gpu, m, "Tropical", "WriteToZero", x, mask, shard=(0, cut))
+    b = _run_spmv(gpu, m, "Tropical", "WriteToZero", x, mask, shard=(cut, m.num_rows))
+    assert_parity(a[:cut], ref[:cut], 2, "shard 0")
+    assert_parity(b[cut:], ref[cut:], 2, "shard 1")
+    assert not a[cut:].any() and not b[:cut].any()   # untouched slices keep the zero fill
+
+
+def test_golden_known_answers(gpu, golden_dir):
+    """The reference outputs recorded in SURVEY 8(c), reproduced by the HIP path."""
+    G = json.load(open(os.path.join(golden_dir, "reference_known_answers.json")))
+    S = G["survey_8c"]["semiring_mask"]
+    m = io.load_csr_matrix_from_float_npz(os.path.join(golden_dir, "line_8_csr_float32.npz"))
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    m.adj_data[:] = 1
+    mask = (np.arange(128) % 2).astype(np.float32)
+    x = ((3 * np.arange(128)) % 5).astype(np.float32)
+    for on, sem in (("arith", "Arithmetic"), ("logical", "Logical"), ("tropical", "Tropical")):
+        for mn, mk in (("nomask", "NoMask"), ("wzero", "WriteToZero"), ("wone", "WriteToOne")):
+            got = _run_spmv(gpu, m, sem, mk, x, mask)
+            assert got[:10].tolist() == S["spmv"][on][mn], (on, mn)
+    for a in G["survey_8c"]["apps"]:
+        if a["call"] != "spmv_arith_nomask":
+            continue
+        m = io.load_csr_matrix_from_float_npz(os.path.join(golden_dir, a["matrix"] + "_csr_float32.npz"))
+        io.util_round_csr_matrix_dim(m, 128, 128)
+        got = _run_spmv(gpu, m, "Arithmetic", "NoMask", (np.arange(m.num_cols) % 7).astype(np.float32),
+                        np.zeros(m.num_rows, np.float32))
+        assert got[:len(a["first"])].tolist() == a["first"]
