@@ -1,0 +1,257 @@
+#!/usr/bin/env python
+"""bench.py -- the headline benchmark of the SpMV / SpMSpV-with-semiring hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Workload (BASELINE.json `metric`): float32 (+,x) SpMV on the orkut stand-in (3 072 441 vertices,
+~213 M edges, symmetrised R-MAT seed 6), prepared exactly as the reference's
+bench_spmv does (benchmark/bench_spmv.cpp:50-60): adj_data = 1/num_rows, rows padded to x128, cols to
+x8, x in {0,1} (seeded).  A "step" is one pass of the hot path over the whole matrix:
+  N = 1: one gl_spmv_run (the reference's SpMVModule::run, bench_spmv.cpp:96-104);
+  N > 1: the matrix is row-sharded (nnz-balanced ranges); a step is the shard's gl_spmv_run plus the
+         all-gather that rebuilds the full dense vector on every rank -- strong scaling.
+`value` = algorithmic bytes of ONE whole-matrix SpMV (8*nnz + 12*n + 4) x K / wall time,
+with the matrix, x and y resident in HBM before the timed region; wall time is bracketed by
+barrier + synchronize on both sides and MAX-reduced over ranks.
+
+Extra objects on the same JSON line:
+  roofline      HBM roofline of the dominant kernel (spmv_rseg_kernel): algorithmic bytes per launch /
+                its mean duration from HIP events recorded on the launch stream inside the timed region.
+  cpu_baseline  the oracle's single-thread restatement of SpMVModule::compute_reference_results timed
+                on this host (rank 0, N = 1 only), same byte formula.
+  bfs           BFS pull_push on the same graph (bench_bfs.cpp:68-89 definition: nnz * iters / t).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def spmv_bytes(nnz, n_rows, n_cols, masked=False):
+    """8 B per non-zero (index + value), indptr, x read once, y written once."""
+    return 8 * nnz + 4 * (n_rows + 1) + 4 * n_cols + 4 * n_rows + (4 * n_rows if masked else 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)      # bench_spmv.cpp:96 runs 100
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graph", default="orkut")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the stand-in (debug only)")
+    ap.add_argument("--no-bfs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bfs-runs", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from graphlily_amd import app, capi, datasets, io
+    from graphlily_amd.dist import Comm, partition_rows_by_nnz
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        comm = Comm(True)
+    else:
+        comm = Comm(None)
+
+    capi.init(local_rank)
+    capi.set_stream(torch.cuda.current_stream().cuda_stream)   # library kernels on torch's stream
+
+    # ------------------------------------------------------------------ workload
+    t0 = time.time()
+    g = datasets.PAPER_GRAPHS[args.graph]
+    csr = datasets.paper_graph(args.graph, args.scale, device=dev)
+    raw = csr.copy() if not args.no_bfs else None
+    csr.adj_data = np.full(csr.nnz, np.float32(1.0 / csr.num_rows), dtype=np.float32)   # bench_spmv.cpp:50
+    io.util_round_csr_matrix_dim(csr, 16 * 8, 8)                                        # bench_spmv.cpp:52-55
+    n_rows, n_cols, nnz = csr.num_rows, csr.num_cols, csr.nnz
+    t_gen = time.time() - t0
+    bounds = partition_rows_by_nnz(csr.adj_indptr, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    t0 = time.time()
+    plan = capi.SpMVPlan(n_rows, n_cols, csr.adj_indptr, csr.adj_indices, csr.adj_data, r0, r1)
+    t_plan = time.time() - t0
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42)
+    x = torch.randint(0, 2, (n_cols,), generator=gen, device=dev).float()              # bench_spmv.cpp:57-60
+    y = torch.zeros(max(n_rows, n_cols), device=dev)
+    bx, by = capi.DeviceBuffer.from_torch(x), capi.DeviceBuffer.from_torch(y)
+    alg_bytes = spmv_bytes(nnz, n_rows, n_cols)
+    shard_bytes = spmv_bytes(plan.info()["nnz"], r1 - r0, n_cols)
+
+    def step():
+        plan.run(bx, None, by, capi.GL_OP_MULADD, 0.0, capi.GL_NOMASK)
+        if world > 1:
+            comm.all_gather_slices(y, bounds)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    capi.prof_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    wall = time.perf_counter() - t0
+    kern_ms_total, launches = capi.prof_end()
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ms_per_step = wall * 1e3 / args.steps
+    value = alg_bytes * args.steps / wall / 1e9
+    kern_ms = kern_ms_total / max(launches, 1)
+    achieved = shard_bytes / (kern_ms * 1e-3) / 1e9
+
+    # quick self-check of the timed result against float64 on a row sample (rank-local rows)
+    yh = y[r0:r1].cpu().numpy()
+    xs = x.cpu().numpy().astype(np.float64)
+    rs = np.random.default_rng(0).integers(r0, max(r1, r0 + 1), size=min(2000, max(r1 - r0, 1)))
+    ip = csr.adj_indptr.astype(np.int64)
+    chk = np.array([np.dot(csr.adj_data[ip[r]:ip[r + 1]].astype(np.float64), xs[csr.adj_indices[ip[r]:ip[r + 1]]])
+                    for r in rs]) if r1 > r0 else np.zeros(0)
+    ok = bool(np.allclose(yh[rs - r0], chk, rtol=1e-5, atol=1e-12)) if r1 > r0 else True
+
+    out = {
+        "metric": "SpMV effective HBM GB/s (fp32 (+,x), %s stand-in); BFS GTEPS in `bfs`" % args.graph,
+        "value": round(value, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "float32 (+,x) SpMV on %s stand-in (R-MAT seed %d, n=%d, nnz=%d), "
+                               "row-sharded x%d%s" % (args.graph, g["seed"], n_rows, nnz, world,
+                                                      " + all-gather of y" if world > 1 else ""),
+                   "graph": args.graph, "n": n_rows, "nnz": nnz, "scale": args.scale,
+                   "algorithmic_bytes_per_step": alg_bytes},
+        "gteps": round(nnz * args.steps / wall / 1e9, 3),
+        "frac_hbm_peak": round(value / (HBM_PEAK_GBPS * world), 4),
+        "selfcheck_ok": ok,
+        "setup_s": {"graph": round(t_gen, 2), "plan": round(t_plan, 2)},
+        "roofline": {
+            "bound": "hbm", "kernel": "spmv_rseg_kernel<MULADD,NOMASK>",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": _pmc_traffic(),
+            "bytes_per_launch": shard_bytes, "kernel_ms": round(kern_ms, 5), "launches": launches,
+        },
+    }
+
+    # ------------------------------------------------------------------ BFS GTEPS (same graph)
+    if not args.no_bfs:
+        try:
+            out["bfs"] = _bench_bfs(app, capi, comm, raw, g["iters"], local_rank, args.bfs_runs, fence)
+        except Exception as e:  # never lose the SpMV line because the extra leg failed
+            out["bfs"] = {"error": repr(e)}
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = _cpu_baseline(csr, x.cpu().numpy(), alg_bytes)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written
+    by scripts/pmc_summary.py with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); null when
+    no counter run has been recorded for this build."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("spmv_rseg_kernel_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence):
+    """bench_bfs.cpp:55-89: 1 warm-up + timed whole-algorithm runs, pull_push threshold 0.001, source 0;
+    GTEPS = nnz * iters / t (nominal edges, independent of direction)."""
+    t0 = time.time()
+    bfs = app.BFS(16, 0, 0, 0, comm=comm, backend=app.HipBackend(device, use_torch=True))
+    bfs.set_up_runtime()
+    bfs.load_and_format_matrix(raw, True)
+    bfs.send_matrix_host_to_device()
+    setup = time.time() - t0
+    nnz = bfs.get_nnz()
+    res = {}
+    for mode in ("pull_push", "pull"):
+        fn = (lambda: bfs.pull_push(0, iters, 0.001)) if mode == "pull_push" else (lambda: bfs.pull(0, iters))
+        d = fn()
+        ts = []
+        for _ in range(runs):
+            fence()
+            t0 = time.perf_counter()
+            d = fn()
+            fence()
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        res[mode] = {"ms": round(t * 1e3, 4), "gteps": round(nnz * iters / t / 1e9, 3),
+                     "reached": int((d != 0).sum())}
+        if mode == "pull_push":
+            res[mode]["push_iterations"] = bfs.push_iterations_
+    res.update({"iters": iters, "nnz": nnz, "setup_s": round(setup, 2), "threshold": 0.001, "source": 0})
+    return res
+
+
+def _cpu_baseline(csr, x, alg_bytes):
+    """The oracle's C restatement of SpMVModule::compute_reference_results (module/spmv_module.h:478-510),
+    single thread like the reference, on this host; plus the row-parallel OpenMP variant on all cores.
+    Sample: whole-matrix passes for ~10 s each."""
+    from oracle import oracle as O
+    om = O.CSR(csr.num_rows, csr.num_cols, csr.adj_data, csr.adj_indices, csr.adj_indptr)
+    res = {}
+    for name, omp in (("single", False), ("omp", True)):
+        O.spmv(om, x, O.MULADD, 0.0, omp=omp)   # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.spmv(om, x, O.MULADD, 0.0, omp=omp)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > 10.0 or n >= 50:
+                break
+        res[name] = (alg_bytes * n / el / 1e9, n, el)
+    cores = os.cpu_count() or 1
+    return {"value": round(res["single"][0], 3), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "%d whole-matrix (+,x) SpMV passes of the timed workload in %.1f s, oracle C port, 1 thread"
+                      % (res["single"][1], res["single"][2]),
+            "gteps": round(res["single"][0] * 1e9 / alg_bytes * csr.nnz / 1e9, 4),
+            "omp": {"value": round(res["omp"][0], 3), "unit": "GB/s", "cores": cores,
+                    "sample": "%d passes in %.1f s, same loop row-parallel with OpenMP" % (res["omp"][1], res["omp"][2])}}
+
+
+if __name__ == "__main__":
+    main()

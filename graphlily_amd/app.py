@@ -1,0 +1,433 @@
+"""BFS / PageRank / SSSP drivers written against the module API (graphlily::app).
+
+Same public surface and the same module call sequences as the reference drivers
+  ModuleCollection  app/module_collection.h:13-114
+  BFS               app/bfs.h:20-361      (pull :106-126, push :129-157, pull_push :160-219)
+  PageRank          app/pagerank.h:17-160 (pull :80-90)
+  SSSP              app/sssp.h:70-254     (pull :152-166, push :169-194, pull_push :197-243)
+re-expressed for one process per GPU: every driver optionally takes a dist.Comm; the matrix is
+then row-sharded (nnz-balanced ranges), the element-wise steps run on the owned slice, and one
+all-gather per iteration rebuilds the dense vector.  With comm=None the sequence
+of module calls is exactly the reference's.
+
+Differences that do not change results:
+  * modules run non-blocking and the driver synchronises only where the host needs a value
+    (get_results_nnz, final read-back) -- the reference finishes the queue after every call;
+  * the push->pull switch converts the frontier on the device (gl_sparse_to_dense) instead of
+    round-tripping through the host (app/bfs.h:196-201);
+  * vectors are allocated by the driver and bound into the modules, so the same buffers can be
+    handed to the collective.
+"""
+import numpy as np
+
+from . import capi, io
+from . import module as M
+from .dist import Comm, partition_rows_by_nnz
+
+
+class HipBackend:
+    """Allocation / transfer hooks of the drivers.  The CPU tests substitute a stand-in with the
+    same methods to exercise the distributed control flow over gloo."""
+    SpMVModule = M.SpMVModule
+    SpMSpVModule = M.SpMSpVModule
+    eWiseAddModule = M.eWiseAddModule
+    AssignVectorDenseModule = M.AssignVectorDenseModule
+    AssignVectorSparseModule = M.AssignVectorSparseModule
+
+    def __init__(self, device=0, use_torch=False):
+        self.device = device
+        self.use_torch = use_torch
+
+    def init(self):
+        capi.init(self.device)
+        if self.use_torch:
+            import torch
+            torch.cuda.set_device(self.device)
+            capi.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def alloc(self, count, dtype):
+        """Device array of `count` elements; dtype is np.float32 or capi.IDX_VAL.  In torch mode the
+        buffer carries `.tensor` (float32, or int64 with one element per (index,val) pair)."""
+        itemsize = np.dtype(dtype).itemsize
+        if self.use_torch:
+            import torch
+            t = torch.zeros(count, dtype=torch.float32 if itemsize == 4 else torch.int64,
+                            device="cuda:%d" % self.device)
+            buf = capi.DeviceBuffer.from_torch(t)
+            buf.tensor = t
+            return buf
+        buf = capi.DeviceBuffer(count * itemsize)
+        buf.tensor = None
+        return buf
+
+    def view(self, buf, first, count, itemsize):
+        v = capi.DeviceBuffer(count * itemsize, ptr=buf.ptr + first * itemsize, keepalive=buf)
+        v.tensor = None
+        return v
+
+    def upload(self, buf, arr):
+        buf.write(np.ascontiguousarray(arr))
+
+    def download(self, buf, dtype, count):
+        return buf.read(dtype, count)
+
+    def copy(self, dst, src, nbytes):
+        capi.copy_d2d(dst, src, nbytes)
+
+    def sparse_to_dense(self, sparse, dense, rng, zero, max_entries):
+        capi.sparse_to_dense(sparse, dense, rng, zero, max_entries)
+
+    def sync(self):
+        capi.sync()
+
+
+class ModuleCollection:
+    def __init__(self):
+        self.modules_ = []
+        self.target_ = "hw"
+
+    def add_module(self, module):
+        self.modules_.append(module)
+
+    def set_target(self, target):
+        assert target in ("sw_emu", "hw_emu", "hw")  # module_collection.h:56-59
+        self.target_ = target
+
+    def set_up_runtime(self, xclbin_file_path=None):
+        """One device context for all modules (module_collection.h:69-114); the bitstream path is
+        accepted for signature parity and ignored."""
+        self.backend.init()
+        for m in self.modules_:
+            m.blocking = False
+
+
+class _GraphApp(ModuleCollection):
+    def __init__(self, num_channels, comm, backend):
+        super().__init__()
+        self.num_channels_ = num_channels
+        self.comm = comm if comm is not None else Comm(None)
+        self.backend = backend if backend is not None else HipBackend()
+        self.bounds_ = None
+
+    def _pad(self, csr):
+        d = self.num_channels_ * M.pack_size      # app/bfs.h:86-89
+        io.util_round_csr_matrix_dim(csr, d, d)
+
+    def _load(self, src):
+        return io.load_csr_matrix_from_float_npz(src) if isinstance(src, (str, bytes)) else src.copy()
+
+    def _shard(self, csr):
+        self.bounds_ = partition_rows_by_nnz(csr.adj_indptr, self.comm.world_size)
+        self.r0_, self.r1_ = self.bounds_[self.comm.rank], self.bounds_[self.comm.rank + 1]
+
+    def get_nnz(self):
+        return self.SpMV_.get_nnz()
+
+    # slice helpers -----------------------------------------------------------------------------
+    def _own(self, buf):
+        return self.backend.view(buf, self.r0_, self.r1_ - self.r0_, 4)
+
+    def _gather(self, buf):
+        if self.comm.distributed:
+            self.comm.all_gather_slices(buf.tensor, self.bounds_)
+
+    def _new_dense(self, host):
+        buf = self.backend.alloc(host.shape[0], np.float32)
+        self.backend.upload(buf, host.astype(np.float32))
+        return buf
+
+    def _gather_sparse(self, local_buf, out_buf, n, head_val):
+        """All ranks contribute their (ascending, disjoint) slice of a sparse vector; every rank ends
+        up with the concatenation, head {total, head_val} included.  Returns the total count."""
+        B = self.backend
+        cnt = self.comm_sparse_count(local_buf)
+        if not self.comm.distributed:
+            return cnt
+        total = self.comm.all_gather_sparse(local_buf.tensor[1:], cnt, n, out_buf.tensor[1:])
+        head = np.zeros(1, dtype=capi.IDX_VAL)
+        head["index"][0], head["val"][0] = total, head_val
+        B.upload(B.view(out_buf, 0, 1, 8), head)
+        return total
+
+    def comm_sparse_count(self, buf):
+        return int(self.backend.download(buf, capi.IDX_VAL, 1)["index"][0])
+
+
+class BFS(_GraphApp):
+    def __init__(self, num_channels=M.num_hbm_channels, spmv_out_buf_len=0, spmspv_out_buf_len=0, vec_buf_len=0,
+                 comm=None, backend=None):
+        super().__init__(num_channels, comm, backend)
+        B = self.backend
+        self.semiring_ = M.LogicalSemiring
+        self.SpMV_ = B.SpMVModule(num_channels, spmv_out_buf_len, vec_buf_len)
+        self.SpMV_.set_semiring(self.semiring_)
+        self.SpMV_.set_mask_type(M.kMaskWriteToZero)
+        self.DenseAssign_ = B.AssignVectorDenseModule()
+        self.DenseAssign_.set_mask_type(M.kMaskWriteToOne)
+        self.SpMSpV_ = B.SpMSpVModule(spmspv_out_buf_len)
+        self.SpMSpV_.set_semiring(self.semiring_)
+        self.SpMSpV_.set_mask_type(M.kMaskWriteToZero)
+        self.SparseAssign_ = B.AssignVectorSparseModule(False)
+        self.eWiseAdd_ = B.eWiseAddModule()
+        for m in (self.SpMV_, self.DenseAssign_, self.SpMSpV_, self.SparseAssign_, self.eWiseAdd_):
+            self.add_module(m)
+
+    def load_and_format_matrix(self, csr_float_npz_path, skip_empty_rows=True):
+        csr = self._load(csr_float_npz_path)
+        self._pad(csr)
+        csr.adj_data = np.ones(csr.nnz, dtype=np.float32)       # app/bfs.h:90
+        csc = io.csr2csc(csr)
+        self._shard(csr)
+        for m in (self.SpMV_, self.SpMSpV_):
+            m.set_row_shard(self.r0_, self.r1_)
+        self.SpMV_.load_and_format_matrix(csr, skip_empty_rows)
+        self.SpMSpV_.load_and_format_matrix(csc)
+        self.n_ = self.SpMV_.get_num_rows()
+        assert self.n_ == self.SpMV_.get_num_cols()
+
+    def send_matrix_host_to_device(self):
+        self.SpMV_.send_matrix_host_to_device()
+        self.SpMSpV_.send_matrix_host_to_device()
+
+    # -- pull ------------------------------------------------------------------------------------
+    def _bind_pull(self, vector, distance):
+        B, n = self.backend, self.n_
+        results = B.alloc(n, np.float32)
+        self.SpMV_.bind_vector_buf(vector)
+        self.SpMV_.bind_mask_buf(distance)
+        self.SpMV_.bind_results_buf(results)
+        self.DenseAssign_.bind_mask_buf(self._own(vector))
+        self.DenseAssign_.bind_inout_buf(self._own(distance))
+        self.eWiseAdd_.bind_in_buf(self._own(results))
+        self.eWiseAdd_.bind_out_buf(self._own(vector))
+
+    def _pull_iteration(self, vector, it):
+        own = self.r1_ - self.r0_
+        self.SpMV_.run()
+        self.eWiseAdd_.run(own, 0.0)                 # results -> vector (app/bfs.h:119-122)
+        self.DenseAssign_.run(own, float(it + 1))
+        self._gather(vector)
+
+    def _finish_distance(self, distance):
+        self._gather(distance)
+        self.backend.sync()
+        return self.backend.download(distance, np.float32, self.n_)
+
+    def pull(self, source, num_iterations):
+        n = self.n_
+        inp = np.full(n, self.semiring_.zero, dtype=np.float32)
+        dist = np.zeros(n, dtype=np.float32)
+        inp[source] = 1
+        dist[source] = 1
+        vector, distance = self._new_dense(inp), self._new_dense(dist)
+        self._bind_pull(vector, distance)
+        for it in range(1, num_iterations + 1):
+            self._pull_iteration(vector, it)
+        return self._finish_distance(distance)
+
+    # -- push ------------------------------------------------------------------------------------
+    def _start_push(self, source):
+        B, n = self.backend, self.n_
+        frontier = B.alloc(n + 1, capi.IDX_VAL)
+        B.upload(B.view(frontier, 0, 2, 8), M.make_sparse_vec([source], [1.0]))
+        dist = np.zeros(n, dtype=np.float32)
+        dist[source] = 1
+        distance = self._new_dense(dist)
+        local = B.alloc(n + 1, capi.IDX_VAL)        # this rank's slice of the next frontier
+        self.SpMSpV_.bind_vector_buf(frontier)
+        self.SpMSpV_.bind_mask_buf(distance)
+        self.SpMSpV_.results_buf = local
+        self.SparseAssign_.bind_mask_buf(local)
+        self.SparseAssign_.bind_inout_buf(distance)
+        return frontier, distance, local
+
+    def _push_iteration(self, frontier, local, it):
+        """SpMSpV on the shard, mark the newly reached vertices, publish the next frontier."""
+        self.SpMSpV_.run()
+        self.SparseAssign_.run(float(it + 1))
+        if self.comm.distributed:
+            return self._gather_sparse(local, frontier, self.n_, self.semiring_.zero)
+        nnz = self.SpMSpV_.get_results_nnz()
+        self.backend.copy(frontier, local, 8 * (1 + nnz))   # app/bfs.h:149-152
+        return nnz
+
+    def push(self, source, num_iterations):
+        frontier, distance, local = self._start_push(source)
+        for it in range(1, num_iterations + 1):
+            self._push_iteration(frontier, local, it)
+        return self._finish_distance(distance)
+
+    def pull_push(self, source, num_iterations, threshold=0.05):
+        n = self.n_
+        frontier, distance, local = self._start_push(source)
+        it = 1
+        while True:
+            nnz = self._push_iteration(frontier, local, it)
+            it += 1
+            if not (it < num_iterations and float(nnz) / n < threshold):
+                break
+        self.push_iterations_ = it - 1
+        # switch: the frontier becomes the dense SpMV input (app/bfs.h:195-205), on the device
+        vector = self.backend.alloc(n, np.float32)
+        self.backend.sparse_to_dense(frontier, vector, n, M.LogicalSemiring.zero, n)
+        self._bind_pull(vector, distance)
+        while it <= num_iterations:
+            self._pull_iteration(vector, it)
+            it += 1
+        return self._finish_distance(distance)
+
+
+class PageRank(_GraphApp):
+    def __init__(self, num_channels=M.num_hbm_channels, spmv_out_buf_len=0, vec_buf_len=0, comm=None, backend=None):
+        super().__init__(num_channels, comm, backend)
+        B = self.backend
+        self.semiring_ = M.ArithmeticSemiring
+        self.SpMV_ = B.SpMVModule(num_channels, spmv_out_buf_len, vec_buf_len)
+        self.SpMV_.set_semiring(self.semiring_)
+        self.SpMV_.set_mask_type(M.kNoMask)
+        self.eWiseAdd_ = B.eWiseAddModule()
+        self.add_module(self.SpMV_)
+        self.add_module(self.eWiseAdd_)
+
+    def load_and_format_matrix(self, csr_float_npz_path, damping, skip_empty_rows=True):
+        csr = self._load(csr_float_npz_path)
+        self._pad(csr)
+        io.util_normalize_csr_matrix_by_outdegree(csr)
+        csr.adj_data = (csr.adj_data * np.float32(damping)).astype(np.float32)   # app/pagerank.h:67
+        self._shard(csr)
+        self.SpMV_.set_row_shard(self.r0_, self.r1_)
+        self.SpMV_.load_and_format_matrix(csr, skip_empty_rows)
+        self.n_ = self.SpMV_.get_num_rows()
+        assert self.n_ == self.SpMV_.get_num_cols()
+
+    def send_matrix_host_to_device(self):
+        self.SpMV_.send_matrix_host_to_device()
+
+    def pull(self, damping, num_iterations):
+        B, n = self.backend, self.n_
+        # rank starts at float(1.0 / n) over the PADDED n (app/pagerank.h:81), teleport is the float
+        # expression (1 - damping) / n (:87)
+        vector = self._new_dense(np.full(n, np.float32(1.0 / n), dtype=np.float32))
+        teleport = np.float32(np.float32(1) - np.float32(damping)) / np.float32(n)
+        results = B.alloc(n, np.float32)
+        self.SpMV_.bind_vector_buf(vector)
+        self.SpMV_.bind_results_buf(results)
+        self.eWiseAdd_.bind_in_buf(self._own(results))
+        self.eWiseAdd_.bind_out_buf(self._own(vector))
+        own = self.r1_ - self.r0_
+        for _ in range(num_iterations):
+            self.SpMV_.run()
+            self.eWiseAdd_.run(own, float(teleport))
+            self._gather(vector)
+        B.sync()
+        return B.download(vector, np.float32, n)
+
+
+class SSSP(_GraphApp):
+    def __init__(self, num_channels=M.num_hbm_channels, spmv_out_buf_len=0, spmspv_out_buf_len=0, vec_buf_len=0,
+                 comm=None, backend=None, semiring=M.TropicalSemiring):
+        super().__init__(num_channels, comm, backend)
+        B = self.backend
+        self.semiring_ = semiring
+        self.SpMV_ = B.SpMVModule(num_channels, spmv_out_buf_len, vec_buf_len)
+        self.SpMV_.set_semiring(self.semiring_)
+        self.SpMV_.set_mask_type(M.kNoMask)
+        self.SpMSpV_ = B.SpMSpVModule(spmspv_out_buf_len)
+        self.SpMSpV_.set_semiring(self.semiring_)
+        self.SpMSpV_.set_mask_type(M.kNoMask)
+        self.SparseAssign_ = B.AssignVectorSparseModule(True)
+        self.eWiseAdd_ = B.eWiseAddModule()
+        for m in (self.SpMV_, self.SpMSpV_, self.SparseAssign_, self.eWiseAdd_):
+            self.add_module(m)
+
+    def load_and_format_matrix(self, csr_float_npz_path, skip_empty_rows=True):
+        csr = self._load(csr_float_npz_path)
+        io.sssp_add_self_edges(csr)                  # app/sssp.h:132 (_preprocess)
+        self._pad(csr)
+        csc = io.csr2csc(csr)
+        self._shard(csr)
+        for m in (self.SpMV_, self.SpMSpV_):
+            m.set_row_shard(self.r0_, self.r1_)
+        self.SpMV_.load_and_format_matrix(csr, skip_empty_rows)
+        self.SpMSpV_.load_and_format_matrix(csc)
+        self.n_ = self.SpMV_.get_num_rows()
+        assert self.n_ == self.SpMV_.get_num_cols()
+
+    def send_matrix_host_to_device(self):
+        self.SpMV_.send_matrix_host_to_device()
+        self.SpMSpV_.send_matrix_host_to_device()
+
+    def _initial_distance(self, source):
+        d = np.full(self.n_, self.semiring_.zero, dtype=np.float32)
+        d[source] = 0
+        return d
+
+    def _pull_loop(self, vector, first_it, num_iterations):
+        B, n = self.backend, self.n_
+        results = B.alloc(n, np.float32)
+        self.SpMV_.bind_vector_buf(vector)
+        self.SpMV_.bind_results_buf(results)
+        self.eWiseAdd_.bind_in_buf(self._own(results))
+        self.eWiseAdd_.bind_out_buf(self._own(vector))
+        own = self.r1_ - self.r0_
+        for _ in range(first_it, num_iterations + 1):
+            self.SpMV_.run()
+            self.eWiseAdd_.run(own, 0.0)             # results -> vector (app/sssp.h:163)
+            self._gather(vector)
+        B.sync()
+        return B.download(vector, np.float32, n)
+
+    def pull(self, source, num_iterations):
+        return self._pull_loop(self._new_dense(self._initial_distance(source)), 1, num_iterations)
+
+    def _start_push(self, source):
+        B, n = self.backend, self.n_
+        frontier = B.alloc(n + 1, capi.IDX_VAL)
+        B.upload(B.view(frontier, 0, 2, 8), M.make_sparse_vec([source], [0.0]))
+        distance = self._new_dense(self._initial_distance(source))
+        candidates = B.alloc(n + 1, capi.IDX_VAL)    # SpMSpV result of this shard
+        self.SpMSpV_.bind_vector_buf(frontier)
+        self.SpMSpV_.bind_mask_buf(distance)
+        self.SpMSpV_.results_buf = candidates
+        self.SparseAssign_.bind_mask_buf(candidates)
+        self.SparseAssign_.bind_inout_buf(distance)
+        if self.comm.distributed:
+            local = B.alloc(n + 1, capi.IDX_VAL)     # relaxed entries of this shard
+            self.SparseAssign_.bind_new_frontier_buf(local)
+        else:
+            local = None
+            self.SparseAssign_.bind_new_frontier_buf(frontier)   # app/sssp.h:185-187
+        return frontier, distance, candidates, local
+
+    def _push_iteration(self, frontier, local):
+        self.SpMSpV_.run()
+        self.SparseAssign_.run()
+        if self.comm.distributed:
+            self._gather_sparse(local, frontier, self.n_, 0.0)
+
+    def push(self, source, num_iterations):
+        frontier, distance, _, local = self._start_push(source)
+        for _ in range(num_iterations):
+            self._push_iteration(frontier, local)
+        self._gather(distance)
+        self.backend.sync()
+        return self.backend.download(distance, np.float32, self.n_)
+
+    def pull_push(self, source, num_iterations, threshold=0.05):
+        n = self.n_
+        frontier, distance, candidates, local = self._start_push(source)
+        it = 1
+        while True:
+            self._push_iteration(frontier, local)
+            nnz = self.comm_sparse_count(candidates)            # app/sssp.h:221 (SpMSpV result size)
+            if self.comm.distributed:
+                import torch
+                t = torch.tensor([nnz], dtype=torch.int64, device=distance.tensor.device)
+                self.comm.dist.all_reduce(t, group=self.comm.group)
+                nnz = int(t.item())
+            it += 1
+            if not (it < num_iterations and float(nnz) / n < threshold):
+                break
+        self.push_iterations_ = it - 1
+        self._gather(distance)
+        return self._pull_loop(distance, it, num_iterations)   # app/sssp.h:227-242

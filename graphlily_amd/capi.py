@@ -28,9 +28,10 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 
 # every symbol include/graphlily_hip.h declares (tests check the .so exports them all)
 EXPORTS = [
-    "gl_init", "gl_device_count", "gl_set_stream", "gl_sync", "gl_last_error", "gl_version",
+    "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32",
     "gl_spmv_plan_create", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_run",
+    "gl_prof_begin", "gl_prof_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
     "gl_assign_sparse_new_frontier", "gl_sparse_to_dense",
@@ -60,13 +61,14 @@ def lib():
     vp, u32, u64, f32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float, ctypes.c_int
     P = ctypes.POINTER
     sigs = {
-        "gl_init": [i32], "gl_device_count": [P(i32)], "gl_set_stream": [vp], "gl_sync": [],
+        "gl_init": [i32], "gl_device_count": [P(i32)], "gl_set_stream": [vp], "gl_reset_stream": [], "gl_sync": [],
         "gl_buf_alloc": [P(vp), ctypes.c_size_t], "gl_buf_free": [vp],
         "gl_buf_h2d": [vp, vp, ctypes.c_size_t], "gl_buf_d2h": [vp, vp, ctypes.c_size_t],
         "gl_buf_d2d": [vp, vp, ctypes.c_size_t], "gl_buf_fill_f32": [vp, f32, ctypes.c_size_t],
         "gl_spmv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmv_plan_destroy": [vp], "gl_spmv_plan_info": [vp, P(u64), P(u64), P(u32)],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
+        "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)],
         "gl_spmspv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmspv_plan_destroy": [vp], "gl_spmspv_plan_info": [vp, P(u64), P(u64)],
         "gl_spmspv_run": [vp, vp, vp, vp, i32, f32, i32],
@@ -110,6 +112,10 @@ def device_count():
 
 def set_stream(hip_stream):
     check(lib().gl_set_stream(ctypes.c_void_p(hip_stream or 0)))
+
+
+def reset_stream():
+    check(lib().gl_reset_stream())
 
 
 def sync():
@@ -245,6 +251,17 @@ class SpMSpVPlan:
             self.destroy()
         except Exception:
             pass
+
+
+def prof_begin(max_launches):
+    check(lib().gl_prof_begin(int(max_launches)))
+
+
+def prof_end():
+    """-> (summed kernel milliseconds, launches) of the dominant SpMV kernel since prof_begin."""
+    ms, n = ctypes.c_double(0.0), ctypes.c_uint32(0)
+    check(lib().gl_prof_end(ctypes.byref(ms), ctypes.byref(n)))
+    return ms.value, n.value
 
 
 def sparse_nnz(buf):

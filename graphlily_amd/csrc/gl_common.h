@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <vector>
 
 #include "graphlily_hip.h"
 
@@ -27,6 +28,14 @@ struct Context {
 };
 
 Context &ctx();
+
+// bench.py's per-kernel HIP-event timing (gl_prof_begin / gl_prof_end)
+struct Profiler {
+    bool on = false;
+    uint32_t used = 0;
+    std::vector<hipEvent_t> events;  // pairs: start, stop
+};
+Profiler &prof();
 
 int set_error(int code, const char *fmt, ...);
 

@@ -12,6 +12,11 @@ Context &ctx() {
     return c;
 }
 
+Profiler &prof() {
+    static Profiler p;
+    return p;
+}
+
 static thread_local char g_err[512] = "";
 
 int set_error(int code, const char *fmt, ...) {
@@ -75,7 +80,42 @@ int gl_init(int device) {
 int gl_set_stream(void *hip_stream) {
     GL_REQUIRE_INIT();
     gl::Context &c = gl::ctx();
-    c.stream = hip_stream ? (hipStream_t)hip_stream : c.own_stream;
+    c.stream = (hipStream_t)hip_stream;
+    return GL_OK;
+}
+
+int gl_reset_stream(void) {
+    GL_REQUIRE_INIT();
+    gl::ctx().stream = gl::ctx().own_stream;
+    return GL_OK;
+}
+
+int gl_prof_begin(uint32_t max_launches) {
+    GL_REQUIRE_INIT();
+    gl::Profiler &p = gl::prof();
+    while (p.events.size() < 2ull * max_launches) {
+        hipEvent_t e;
+        GL_HIP(hipEventCreate(&e));
+        p.events.push_back(e);
+    }
+    p.used = 0;
+    p.on = true;
+    return GL_OK;
+}
+
+int gl_prof_end(double *total_ms, uint32_t *launches) {
+    GL_REQUIRE_INIT();
+    gl::Profiler &p = gl::prof();
+    p.on = false;
+    GL_HIP(hipStreamSynchronize(gl::ctx().stream));
+    double sum = 0.0;
+    for (uint32_t i = 0; i < p.used; i++) {
+        float ms = 0.0f;
+        GL_HIP(hipEventElapsedTime(&ms, p.events[2 * i], p.events[2 * i + 1]));
+        sum += ms;
+    }
+    if (total_ms) *total_ms = sum;
+    if (launches) *launches = p.used;
     return GL_OK;
 }
 

@@ -192,8 +192,15 @@ static int launch_spmv(const SpmvArgs &a, const LongRowArgs &l, hipStream_t s) {
     constexpr int U = 4;
     unsigned blocks = a.tile_blocks + cdiv(a.nempty, 256);
     if (blocks) {
+        Profiler &pf = prof();
+        const bool timed = pf.on && 2ull * (pf.used + 1) <= pf.events.size();
+        if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
         spmv_rseg_kernel<OP, MASK, U><<<blocks, 256, 0, s>>>(a);
         GL_LAUNCH_CHECK();
+        if (timed) {
+            GL_HIP(hipEventRecord(pf.events[2 * pf.used + 1], s));
+            pf.used++;
+        }
     }
     if (l.nlong) {
         spmv_long_rows_kernel<OP, MASK><<<cdiv(l.nlong, 4), 256, 0, s>>>(l);

@@ -1,0 +1,105 @@
+"""Row-range partitioning and the one exchange step of the multi-GPU path.
+
+The reference is single-device; SURVEY.md 8(e) defines the multi-GPU decomposition this build
+adds: the matrix is cut into contiguous, nnz-balanced ROW RANGES (the axis the FPGA already tiles
+on: out_buf_len row partitions, module/spmv_module.h:287), one range per GPU / process.  Each
+iteration a rank produces y[r0:r1) and applies the element-wise ops on that slice; ONE all-gather
+(RCCL over xGMI on the GPU box; gloo in the CPU tests) then rebuilds the full dense vector that is
+the next iteration's x.  No reduction collectives are needed.
+
+Everything here works on torch tensors of either device, so the control flow is testable with
+world_size-2 gloo runs.
+"""
+import numpy as np
+
+
+def partition_rows_by_nnz(indptr, world_size, align=64):
+    """Boundaries b[0..world_size] with b[0]=0, b[-1]=num_rows, balancing non-zeros per range and
+    rounding interior cuts to a multiple of `align` rows (64 = one wavefront of dense-vector
+    elements, keeps slices 256-byte aligned for the all-gather)."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    n = indptr.shape[0] - 1
+    nnz = int(indptr[n])
+    bounds = [0]
+    for k in range(1, world_size):
+        target = nnz * k // world_size
+        r = int(np.searchsorted(indptr, target, side="left"))
+        r = min(n, max(bounds[-1], (r + align // 2) // align * align))
+        bounds.append(r)
+    bounds.append(n)
+    return bounds
+
+
+class Comm:
+    """Thin wrapper around a torch.distributed process group (None = single process)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        if group is None:
+            self.rank, self.world_size = 0, 1
+        else:
+            import torch.distributed as dist
+            self.dist = dist
+            self.rank = dist.get_rank(group) if group is not True else dist.get_rank()
+            self.world_size = dist.get_world_size(group) if group is not True else dist.get_world_size()
+            if group is True:
+                self.group = None  # default group
+
+    @property
+    def distributed(self):
+        return self.world_size > 1
+
+    def all_gather_slices(self, full, bounds):
+        """`full` is a 1-D tensor over the whole vertex range whose slice
+        [bounds[rank], bounds[rank+1]) is valid on this rank; afterwards all of it is valid on every
+        rank.  Ranges are nnz-balanced, hence of different lengths: each rank pads its slice to the
+        longest one, ONE all_gather_into_tensor moves everything (the same call on RCCL and gloo),
+        and one concatenation writes the received slices back in place."""
+        if not self.distributed:
+            return
+        import torch
+        W = self.world_size
+        lens = [bounds[r + 1] - bounds[r] for r in range(W)]
+        mx = max(lens)
+        if mx == 0:
+            return
+        key = (full.device, full.dtype, W * mx)
+        if getattr(self, "_stage_key", None) != key:
+            self._stage = torch.empty(W * mx, dtype=full.dtype, device=full.device)
+            self._send = torch.zeros(mx, dtype=full.dtype, device=full.device)
+            self._stage_key = key
+        self._send[:lens[self.rank]].copy_(full[bounds[self.rank]:bounds[self.rank + 1]])
+        self.dist.all_gather_into_tensor(self._stage, self._send, group=self.group)
+        torch.cat([self._stage[r * mx:r * mx + lens[r]] for r in range(W)], out=full[bounds[0]:bounds[W]])
+
+    def all_gather_sparse(self, local, count, capacity_full, out):
+        """Concatenate per-rank sparse lists ((index,val) pairs as an int64-viewable [k,2] float/int
+        tensor) in rank order.  `local` holds this rank's entries (without a head), `count` their
+        number.  Returns the total count; `out` receives the concatenation."""
+        import torch
+        if not self.distributed:
+            out[:count] = local[:count]
+            return int(count)
+        cnt = torch.tensor([count], dtype=torch.int64, device=local.device)
+        counts = [torch.zeros_like(cnt) for _ in range(self.world_size)]
+        self.dist.all_gather(counts, cnt, group=self.group)
+        counts = [int(c.item()) for c in counts]
+        total = sum(counts)
+        assert total <= capacity_full
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        pieces = [out[int(offs[r]):int(offs[r + 1])] for r in range(self.world_size)]
+        mx = max(counts)
+        if mx == 0:
+            return 0
+        # pad to a common length so one all_gather_into_tensor moves everything
+        send = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[:count] = local[:count]
+        recv = torch.empty((self.world_size * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        for r in range(self.world_size):
+            pieces[r].copy_(recv[r * mx:r * mx + counts[r]])
+        return total
+
+    def barrier(self):
+        if self.distributed:
+            self.dist.barrier(group=self.group)

@@ -59,7 +59,8 @@ typedef struct gl_spmspv_plan_s *gl_spmspv_plan; /* formatted matrix for SpMSpV 
  * discovery, context, command queue.  No bitstream to load. */
 int gl_init(int device);                /* hipSetDevice + library stream        */
 int gl_device_count(int *count);
-int gl_set_stream(void *hip_stream);    /* adopt a caller-owned hipStream_t (NULL = library stream) */
+int gl_set_stream(void *hip_stream);    /* adopt a caller-owned hipStream_t; NULL is HIP's default (null) stream */
+int gl_reset_stream(void);              /* go back to the library-owned stream  */
 int gl_sync(void);                      /* command_queue_.finish()              */
 const char *gl_last_error(void);
 const char *gl_version(void);
@@ -100,6 +101,12 @@ int gl_spmv_plan_info(gl_spmv_plan plan, uint64_t *nnz, uint64_t *device_bytes, 
  * spmv_module.h:518-530). */
 int gl_spmv_run(gl_spmv_plan plan, const float *d_x, const float *d_mask, float *d_y,
                 int op, float zero, int mask_type);
+
+/* Measurement hook (bench.py roofline): between gl_prof_begin and gl_prof_end every launch of the
+ * dominant SpMV kernel is bracketed by HIP events recorded on the stream it is launched on.
+ * gl_prof_end synchronises and returns the summed kernel time and the number of launches. */
+int gl_prof_begin(uint32_t max_launches);
+int gl_prof_end(double *total_ms, uint32_t *launches);
 
 /* ------------------------------------------------------------------- SpMSpV
  * gl_spmspv_plan_create replaces SpMSpVModule::load_and_format_matrix +

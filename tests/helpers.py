@@ -45,9 +45,49 @@ SEMIRINGS = {"Arithmetic": (0, 0.0), "Logical": (1, 0.0), "Tropical": (2, 255.0)
 MASKS = {"NoMask": 0, "WriteToZero": 1, "WriteToOne": 2}
 
 
+U32 = 2.0 ** -24   # fp32 unit roundoff
+
+
+def arith_exact(m, x, rows=None):
+    """float64 evaluation of the (+,x) product and the per-row data the float tolerance needs:
+    exact[r] = sum a_i x_i, abs_sum[r] = sum |a_i x_i|, length[r]."""
+    n = m.nnz
+    prod = m.adj_data[:n].astype(np.float64) * np.asarray(x, np.float64)[m.adj_indices[:n]]
+    lens = np.diff(m.adj_indptr.astype(np.int64))
+    row_of = np.repeat(np.arange(m.num_rows), lens)
+    exact = np.bincount(row_of, weights=prod, minlength=m.num_rows)
+    abs_sum = np.bincount(row_of, weights=np.abs(prod), minlength=m.num_rows)
+    return exact, abs_sum, lens
+
+
+def assert_arith_parity(got, ref, exact, abs_sum, lens, what="", keep=None):
+    """Float (+,x) tolerance, stated in full:
+      (1) |got - exact| <= 1e-5 |exact| (+ 4u abs_sum for cancellation): the HIP result is within the
+          north_star's 1e-5 relative of the exactly evaluated product;
+      (2) |got - ref| <= 1e-5 |ref| + L u abs_sum: against the fp32 oracle, whose sequential
+          accumulation (spmv_module.h:495) itself carries the classical forward error (L-1) u sum|a_i x_i|
+          -- on rows with thousands of entries that alone exceeds 1e-5, whatever order the device uses.
+    `keep` selects the rows that were not masked off (masked rows must be exactly 0)."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    if keep is None:
+        keep = np.ones(got.shape[0], bool)
+    if np.any(got[~keep] != 0):
+        raise AssertionError("%s: masked-off rows must be exactly 0" % what)
+    e1 = np.abs(got - exact) - (1e-5 * np.abs(exact) + 4 * U32 * abs_sum)
+    e2 = np.abs(got - ref) - (1e-5 * np.abs(ref) + np.maximum(lens, 1) * U32 * abs_sum)
+    for name, e in (("vs exact", e1), ("vs oracle", e2)):
+        bad = np.nonzero((e > 0) & keep)[0]
+        if bad.size:
+            i = bad[0]
+            raise AssertionError("%s %s: %d rows out of tolerance, first row %d (len %d): got %r ref %r exact %r" %
+                                 (what, name, bad.size, i, lens[i], got[i], ref[i], exact[i]))
+
+
 def assert_parity(got, ref, op, what=""):
-    """Bit-exact for the boolean and (min,+) semirings; 1e-5 relative for float (+,x)
-    (BASELINE.json north_star).  The tiny atol only absorbs sums that are exactly 0 in one order."""
+    """Bit-exact for the boolean and (min,+) semirings.  For float (+,x) this short form is the
+    1e-5 relative bar of the north_star and is only used where rows are short; long-row cases go
+    through assert_arith_parity."""
     got = np.asarray(got, dtype=np.float32)
     ref = np.asarray(ref, dtype=np.float32)
     assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, got.shape, ref.shape)

@@ -1,0 +1,189 @@
+"""CPU suite, part 3: the N>1 path over gloo, world_size 2 -- row partitioning, the padded slice
+all-gather, the sparse-frontier all-gather, and the drivers' distributed control flow (BFS pull /
+pull_push, PageRank, SSSP pull / push / pull_push) with a CPU stand-in for the device modules."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from graphlily_amd import datasets, io
+from graphlily_amd.dist import Comm, partition_rows_by_nnz
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn_name, out_q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = globals()[fn_name](Comm(True))
+        out_q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn_name, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    # drain the queue BEFORE joining: a worker blocks in put() until its payload has been read
+    import time
+    deadline = time.time() + 240
+    while len(out) < world and time.time() < deadline:
+        if not q.empty():
+            r, res = q.get()
+            out[r] = res
+        elif any(p.exitcode not in (None, 0) for p in procs):
+            break
+        else:
+            time.sleep(0.05)
+    for p in procs:
+        p.join(30)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0, "worker failed (exit code %s)" % p.exitcode
+    assert len(out) == world
+    return out
+
+
+def test_partition_balances_nnz():
+    m = datasets.rmat(20000, 400000, seed=11)
+    for w in (1, 2, 4, 8):
+        b = partition_rows_by_nnz(m.adj_indptr, w)
+        assert b[0] == 0 and b[-1] == m.num_rows and len(b) == w + 1
+        assert all(b[i] <= b[i + 1] for i in range(w))
+        assert all(x % 64 == 0 for x in b[1:-1])
+        per = np.diff(m.adj_indptr.astype(np.int64)[b])
+        assert per.sum() == m.nnz
+        if w > 1:
+            # balanced up to the granularity imposed by the alignment and the heaviest row
+            slack = np.diff(m.adj_indptr.astype(np.int64)).max() * 64
+            assert per.max() <= m.nnz / w + slack
+
+
+# ------------------------------------------------------------------ worker bodies (module level)
+def _body_gather_slices(comm):
+    n = 1000
+    bounds = [0, 384, n]          # uneven on purpose
+    full = torch.full((n,), -1.0)
+    full[bounds[comm.rank]:bounds[comm.rank + 1]] = torch.arange(bounds[comm.rank], bounds[comm.rank + 1],
+                                                                 dtype=torch.float32)
+    comm.all_gather_slices(full, bounds)
+    return bool(torch.equal(full, torch.arange(n, dtype=torch.float32)))
+
+
+def _body_gather_sparse(comm):
+    cap = 64
+    local = torch.arange(10 * comm.rank, 10 * comm.rank + (3 if comm.rank == 0 else 5), dtype=torch.int64)
+    out = torch.zeros(cap, dtype=torch.int64)
+    total = comm.all_gather_sparse(local, local.numel(), cap, out)
+    return total, out[:total].tolist()
+
+
+def _graph():
+    m = datasets.rmat(3000, 30000, seed=21, symmetric=True)
+    return m
+
+
+def _apps(comm, which):
+    from cpu_backend import CpuBackend
+    from graphlily_amd import app, module as M
+    m = _graph()
+    if which == "bfs":
+        a = app.BFS(16, 1024, 512, 256, comm=comm, backend=CpuBackend())
+        a.set_up_runtime()
+        a.load_and_format_matrix(m, True)
+        a.send_matrix_host_to_device()
+        return [a.pull(0, 6), a.pull_push(0, 6, 0.05), a.push(0, 6)]
+    if which == "pagerank":
+        a = app.PageRank(16, 1024, 256, comm=comm, backend=CpuBackend())
+        a.set_up_runtime()
+        a.load_and_format_matrix(m, 0.9, True)
+        a.send_matrix_host_to_device()
+        return [a.pull(0.9, 5)]
+    a = app.SSSP(16, 1024, 512, 256, comm=comm, backend=CpuBackend(), semiring=M.TropicalSemiringUfixed)
+    a.set_up_runtime()
+    a.load_and_format_matrix(m, True)
+    a.send_matrix_host_to_device()
+    return [a.pull(0, 6), a.pull_push(0, 6, 0.05), a.push(0, 6)]
+
+
+def _body_bfs(comm):
+    return _apps(comm, "bfs")
+
+
+def _body_pagerank(comm):
+    return _apps(comm, "pagerank")
+
+
+def _body_sssp(comm):
+    return _apps(comm, "sssp")
+
+
+# ------------------------------------------------------------------ tests
+def test_all_gather_slices_uneven():
+    assert all(_spawn("_body_gather_slices").values())
+
+
+def test_all_gather_sparse():
+    out = _spawn("_body_gather_sparse")
+    for r in (0, 1):
+        assert out[r] == (8, [0, 1, 2, 10, 11, 12, 13, 14])
+
+
+def _oracle_graph(sssp=False, pagerank=False):
+    m = _graph()
+    om = O.CSR(m.num_rows, m.num_cols, m.adj_data, m.adj_indices, m.adj_indptr)
+    if sssp:
+        O.sssp_preprocess(om)
+    O.util_round_csr_matrix_dim(om, 128, 128)
+    if pagerank:
+        O.util_normalize_csr_matrix_by_outdegree(om)
+        om.adj_data = (om.adj_data * np.float32(0.9)).astype(np.float32)
+    elif not sssp:
+        om.adj_data[:] = 1
+    return om
+
+
+def test_distributed_bfs_matches_oracle():
+    ref = O.bfs(_oracle_graph(), 0, 6)
+    out = _spawn("_body_bfs")
+    for r in (0, 1):
+        for got in out[r]:
+            assert np.array_equal(got, ref)
+
+
+def test_distributed_pagerank_matches_oracle():
+    ref = O.pagerank(_oracle_graph(pagerank=True), 0.9, 5)
+    out = _spawn("_body_pagerank")
+    for r in (0, 1):
+        assert np.array_equal(out[r][0], ref)     # same per-row order on the stand-in => bit-equal
+
+
+def test_distributed_sssp_matches_oracle():
+    ref = O.sssp(_oracle_graph(sssp=True), 0, 6, 255.0)
+    out = _spawn("_body_sssp")
+    for r in (0, 1):
+        for got in out[r]:
+            assert np.array_equal(got, ref)

@@ -12,7 +12,8 @@ import pytest
 from graphlily_amd import io, module as M
 from oracle import oracle as O
 
-from helpers import MASKS, SEMIRINGS, assert_parity, rand01, spmv_prepare, to_oracle
+from helpers import (MASKS, SEMIRINGS, arith_exact, assert_arith_parity, assert_parity, rand01, spmv_prepare,
+                     to_oracle)
 
 pytestmark = pytest.mark.gpu
 
@@ -32,6 +33,20 @@ def _run_spmv(gpu, m, sem, mask_name, x, mask, skip_empty_rows=True, shard=None)
     mod.send_mask_host_to_device(mask)
     mod.run()
     return mod.send_results_device_to_host()
+
+
+def _check(got, m, sem, mask_name, x, mask, what):
+    ref = _ref_spmv(m, sem, mask_name, x, mask)
+    op = SEMIRINGS[sem][0]
+    if op != 0:
+        return assert_parity(got, ref, op, what)
+    exact, abs_sum, lens = arith_exact(m, x)
+    keep = None
+    if MASKS[mask_name] == O.WRITETOZERO:
+        keep = np.asarray(mask) == 0
+    elif MASKS[mask_name] == O.WRITETOONE:
+        keep = np.asarray(mask) != 0
+    assert_arith_parity(got, ref, exact, abs_sum, lens, what, keep)
 
 
 def _ref_spmv(m, sem, mask_name, x, mask):
@@ -66,7 +81,7 @@ def test_matrices(gpu, name, sem, mask_name):
         x = rand01(m.num_cols, 3)
     mask = rand01(m.num_rows, 4)
     got = _run_spmv(gpu, m, sem, mask_name, x, mask)
-    assert_parity(got, _ref_spmv(m, sem, mask_name, x, mask), SEMIRINGS[sem][0], "%s/%s/%s" % (name, sem, mask_name))
+    _check(got, m, sem, mask_name, x, mask, "%s/%s/%s" % (name, sem, mask_name))
 
 
 def test_float_values_random(gpu):
@@ -76,7 +91,7 @@ def test_float_values_random(gpu):
     m.adj_data = rng.random(m.nnz, dtype=np.float32)
     x = rng.random(m.num_cols, dtype=np.float32)
     got = _run_spmv(gpu, m, "Arithmetic", "NoMask", x, rand01(m.num_rows, 1))
-    assert_parity(got, _ref_spmv(m, "Arithmetic", "NoMask", x, None), 0, "random floats")
+    _check(got, m, "Arithmetic", "NoMask", x, None, "random floats")
 
 
 @pytest.mark.parametrize("tile", ["64", "256", "4096"])
@@ -87,7 +102,7 @@ def test_tile_sizes(gpu, tile, monkeypatch):
     x, mask = rand01(m.num_cols, 7), rand01(m.num_rows, 8)
     for sem in ("Logical", "Tropical", "Arithmetic"):
         got = _run_spmv(gpu, m, sem, "WriteToZero", x, mask)
-        assert_parity(got, _ref_spmv(m, sem, "WriteToZero", x, mask), SEMIRINGS[sem][0], "tile %s %s" % (tile, sem))
+        _check(got, m, sem, "WriteToZero", x, mask, "tile %s %s" % (tile, sem))
 
 
 def test_edge_shapes(gpu):
@@ -103,7 +118,7 @@ def test_edge_shapes(gpu):
     m = io.CSRMatrix(3, n, np.ones(n, np.float32), np.arange(n, dtype=np.uint32), [0, 0, n, n])
     x = rand01(n, 3)
     got = _run_spmv(gpu, m, "Arithmetic", "NoMask", x, np.zeros(3, np.float32))
-    assert_parity(got, _ref_spmv(m, "Arithmetic", "NoMask", x, None), 0, "one long row")
+    _check(got, m, "Arithmetic", "NoMask", x, None, "one long row")
     got = _run_spmv(gpu, m, "Logical", "WriteToOne", x, np.array([1, 1, 0], np.float32))
     assert_parity(got, _ref_spmv(m, "Logical", "WriteToOne", x, np.array([1, 1, 0], np.float32)), 1, "one long row logical")
 
