@@ -57,6 +57,12 @@ def lib():
         raise GraphLilyError(GL_ERR_NOT_INITIALIZED,
                              "%s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(there is no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7; if torch is going to be used
+    # at all (bench.py, multi-GPU) it must be the first to load it, or its device discovery fails.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, u32, u64, f32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float, ctypes.c_int
     P = ctypes.POINTER

@@ -87,24 +87,49 @@ __global__ __launch_bounds__(256) void spmv_rseg_kernel(SpmvArgs a) {
     const uint2 *__restrict__ sp = a.stream + off;
     const float ident = S::ident(a.zero);
 
+    // Software pipeline, three stages deep, so that a wave always has stream loads AND gathers in
+    // flight while it reduces:   stream(i+2)  |  gather x(i+1)  |  reduce(i).
+    // c0/x0 = entries and gathered x of the iteration being reduced, c1 = entries of the next one.
+    const uint32_t kStep = 64u * U;
+    uint2 c0[U], c1[U];
+    float x0[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        uint32_t k = u * 64u + lane;
+        c0[u] = (k < cnt) ? load_stream_nt(sp + k) : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        uint32_t k = kStep + u * 64u + lane;
+        c1[u] = (k < cnt) ? load_stream_nt(sp + k) : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) x0[u] = a.x[c0[u].x & 0x7fffffffu];
+
     if (flags & kTileLong) {
         // slice of one long row: plain per-lane accumulation, one wave reduction at the end
         float acc = ident;
-        for (uint32_t base = 0; base < cnt; base += 64u * U) {
-            uint2 cv[U];
+        for (uint32_t base = 0; base < cnt; base += kStep) {
+            uint2 c2[U];
+            float x1[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                uint32_t k = base + u * 64u + lane;
-                cv[u] = (k < cnt) ? load_stream_nt(sp + k) : make_uint2(0u, 0u);
+                uint32_t k = base + 2u * kStep + u * 64u + lane;
+                c2[u] = (k < cnt) ? load_stream_nt(sp + k) : make_uint2(0u, 0u);
             }
-            float xv[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) xv[u] = a.x[cv[u].x & 0x7fffffffu];
+            for (int u = 0; u < U; u++) x1[u] = a.x[c1[u].x & 0x7fffffffu];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 uint32_t k = base + u * 64u + lane;
-                float p = (k < cnt) ? S::mul(__uint_as_float(cv[u].y), xv[u]) : ident;
+                float p = (k < cnt) ? S::mul(__uint_as_float(c0[u].y), x0[u]) : ident;
                 acc = S::add(acc, p);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                c0[u] = c1[u];
+                c1[u] = c2[u];
+                x0[u] = x1[u];
             }
         }
 #pragma unroll
@@ -117,24 +142,24 @@ __global__ __launch_bounds__(256) void spmv_rseg_kernel(SpmvArgs a) {
     uint32_t rows_done = 0;  // rows of this tile already written
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-    for (uint32_t base = 0; base < cnt; base += 64u * U) {
-        uint2 cv[U];
+    for (uint32_t base = 0; base < cnt; base += kStep) {
+        uint2 c2[U];
+        float x1[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            uint32_t k = base + u * 64u + lane;
-            cv[u] = (k < cnt) ? load_stream_nt(sp + k) : make_uint2(0u, 0u);
+            uint32_t k = base + 2u * kStep + u * 64u + lane;
+            c2[u] = (k < cnt) ? load_stream_nt(sp + k) : make_uint2(0u, 0u);
         }
-        float xv[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) xv[u] = a.x[cv[u].x & 0x7fffffffu];
+        for (int u = 0; u < U; u++) x1[u] = a.x[c1[u].x & 0x7fffffffu];
 
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (base + u * 64u >= cnt) break;  // wave-uniform
             const uint32_t k = base + u * 64u + lane;
             const bool valid = k < cnt;
-            float p = valid ? S::mul(__uint_as_float(cv[u].y), xv[u]) : ident;
-            const bool e = valid && (cv[u].x >> 31);
+            float p = valid ? S::mul(__uint_as_float(c0[u].y), x0[u]) : ident;
+            const bool e = valid && (c0[u].x >> 31);
             const uint64_t me = __ballot(e);
             const uint64_t below = me & lt_mask;
             // first lane of the segment this lane belongs to
@@ -153,6 +178,12 @@ __global__ __launch_bounds__(256) void spmv_rseg_kernel(SpmvArgs a) {
             rows_done += (uint32_t)__popcll(me);
             const float last = __shfl(v, 63);
             carry = (me >> 63) ? ident : last;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            c0[u] = c1[u];
+            c1[u] = c2[u];
+            x0[u] = x1[u];
         }
     }
 }
@@ -187,15 +218,28 @@ __global__ __launch_bounds__(256) void spmv_long_rows_kernel(LongRowArgs a) {
     }
 }
 
+static int unroll_setting() {
+    static int u = [] {
+        const char *e = getenv("GRAPHLILY_SPMV_UNROLL");
+        int v = e ? atoi(e) : 4;
+        return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4;
+    }();
+    return u;
+}
+
 template <int OP, int MASK>
 static int launch_spmv(const SpmvArgs &a, const LongRowArgs &l, hipStream_t s) {
-    constexpr int U = 4;
     unsigned blocks = a.tile_blocks + cdiv(a.nempty, 256);
     if (blocks) {
         Profiler &pf = prof();
         const bool timed = pf.on && 2ull * (pf.used + 1) <= pf.events.size();
         if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
-        spmv_rseg_kernel<OP, MASK, U><<<blocks, 256, 0, s>>>(a);
+        switch (unroll_setting()) {
+            case 1: spmv_rseg_kernel<OP, MASK, 1><<<blocks, 256, 0, s>>>(a); break;
+            case 2: spmv_rseg_kernel<OP, MASK, 2><<<blocks, 256, 0, s>>>(a); break;
+            case 8: spmv_rseg_kernel<OP, MASK, 8><<<blocks, 256, 0, s>>>(a); break;
+            default: spmv_rseg_kernel<OP, MASK, 4><<<blocks, 256, 0, s>>>(a); break;
+        }
         GL_LAUNCH_CHECK();
         if (timed) {
             GL_HIP(hipEventRecord(pf.events[2 * pf.used + 1], s));
@@ -239,7 +283,7 @@ namespace gl {
 static uint32_t tile_nnz_setting() {
     // tuning knob; the reference passes (out_buf_len, vec_buf_len) hints for the same purpose
     const char *e = getenv("GRAPHLILY_SPMV_TILE_NNZ");
-    long v = e ? atol(e) : 512;
+    long v = e ? atol(e) : 2048;
     if (v < 64) v = 64;
     if (v > 32768) v = 32768;
     return (uint32_t)v;
