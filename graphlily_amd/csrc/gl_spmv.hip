@@ -4,262 +4,178 @@
 // (module/spmv_module.h:281-370, io/data_formatter.h:456-534) and
 // kernel_spmv (hw/kernel_spmv_impl.h:392-819).
 //
-// Layout ("row-segment stream", the CDNA4 counterpart of the FPGA's cyclic
-// packed streams with in-band end-of-row markers, io/data_formatter.h:54-81):
-//   stream[k] = { col | row_end << 31 , val }   8 bytes per non-zero, CSR order,
-//               so a wavefront step reads 64 x 8 = 512 contiguous bytes;
-//   tiles[t]  = { stream offset, first row, nnz | flags << 16, aux }
-//               one wavefront per tile; tiles are cut at row boundaries
-//               (<= tile_nnz non-zeros) so no partial sums cross tiles, except
-//               for rows longer than a tile, which become runs of LONG tiles
-//               whose partials are combined by a second, tiny kernel;
-//   empty rows are listed separately and written by trailing blocks of the
-//   same launch (the reference's skip_empty_rows idea, spmv_module.h:199).
-// Per step a lane gathers x[col] through L1/L2, multiplies, and the wave does
-// a segmented scan keyed by the ballot of row_end flags; lanes holding a
-// row_end write y (mask fused into the epilogue like write_to_out_ddr,
-// hw/kernel_spmv_impl.h:339-389).
+// What the hardware dictates (measured on MI355X, scripts/ubench_*.hip):
+//   * the packed 8-byte (index,value) stream reads at 5.5-7 TB/s, but a random 4-byte gather of x
+//     costs a whole cache line: ~100 G gathers/s from a 10 MB vector = 0.8 TB/s of matrix stream;
+//   * the same gather runs at >500 G/s when the lanes of a wavefront read NEIGHBOURING columns;
+//   * LDS atomics on 4/8-byte integers and on f64 run at full rate, ds_add_f32 at a third of it.
+// Hence the layout -- the CDNA4 counterpart of the FPGA's "dense-vector tile in URAM + output buffer
+// in URAM" partitioning (kernel_spmv_impl.h:470-495), with the roles swapped:
+//   row block   <= 16383 consecutive rows whose accumulators live in LDS for the whole sweep
+//               (f64 for (+,x), so ds_add_f64; 32-bit ordered-int min for (min,+); plain store for (||,&&));
+//   entries     of a row block are stored COLUMN-SORTED, 8 bytes each:
+//               { (col - group_base) << 14 | row_in_block , val },  64 entries = one 512-byte group with
+//               one base column, so a wavefront step is one coalesced 512-byte read and its 64 gathers
+//               of x fall into a handful of adjacent cache lines;
+//   segments    a row block's stream is cut into S equal pieces ("units", one workgroup each) so that
+//               about 256*k equally sized units exist (256 CUs); units are numbered segment-major so
+//               concurrently running workgroups sweep the same column window of x (L2 resident).
+// S == 1: the workgroup writes y for its rows directly, mask and semiring finish fused (the
+// write_to_out_ddr epilogue, kernel_spmv_impl.h:339-389).  S > 1: y is initialised by a small kernel
+// and the units fold their tiles in with device atomics (float add / ordered-int min / store).
 #include "gl_common.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
 namespace gl {
 
-constexpr uint32_t kTileLong = 1u;       // tile is a slice of one long row (no row_end flags inside)
-constexpr uint32_t kTileNonContig = 2u;  // rows of the tile are not consecutive: go through rowmap[aux + k]
+constexpr uint32_t kRowBits = 14;
+constexpr uint32_t kRowPad = (1u << kRowBits) - 1u;   // row_in_block value of a padding entry
+constexpr uint32_t kMaxBlockRows = kRowPad;            // 16383
+constexpr uint32_t kColOffBits = 32 - kRowBits;        // 18
+constexpr uint32_t kThreads = 1024;                    // one workgroup per CU: 16 wavefronts share the tile
+constexpr uint32_t kWaves = kThreads / 64;
 
 struct SpmvArgs {
-    const uint2 *stream;
-    const uint4 *tiles;
-    const uint32_t *rowmap;
-    const uint32_t *empty_rows;
+    const uint2 *entries;     // groups of 64
+    const uint32_t *bases;    // one base column per group
+    const uint4 *units;       // {first group, #groups, first row, #rows | direct << 31}
     const float *x;
     const float *mask;
     float *y;
-    float *long_partials;
-    uint32_t ntiles;
-    uint32_t tile_blocks;
-    uint32_t nempty;
     float zero;
 };
-
-template <int OP, int MASK>
-__device__ __forceinline__ void store_row(const SpmvArgs &a, uint32_t row, float acc) {
-    using S = Semiring<OP>;
-    float out = S::finish(a.zero, acc);
-    if (MASK != GL_NOMASK) {
-        // masked-off rows are literal 0, and the mask is compared with 0 (spmv_module.h:518-530)
-        if (!mask_allows<MASK>(a.mask[row], 0.0f)) out = 0.0f;
-    }
-    a.y[row] = out;
-}
-
-template <int OP, int MASK, int U>
-__global__ __launch_bounds__(256) void spmv_rseg_kernel(SpmvArgs a) {
-    using S = Semiring<OP>;
-    const uint32_t lane = threadIdx.x & 63u;
-
-    if (blockIdx.x >= a.tile_blocks) {
-        // rows without any non-zero: y = semiring zero (accumulator never touched)
-        uint32_t i = (blockIdx.x - a.tile_blocks) * 256u + threadIdx.x;
-        if (i < a.nempty) {
-            uint32_t r = a.empty_rows[i];
-            float out = a.zero;
-            if (MASK != GL_NOMASK) {
-                if (!mask_allows<MASK>(a.mask[r], 0.0f)) out = 0.0f;
-            }
-            a.y[r] = out;
-        }
-        return;
-    }
-
-    const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (t >= a.ntiles) return;
-    const uint4 d = a.tiles[t];
-    const uint32_t off = __builtin_amdgcn_readfirstlane(d.x);
-    const uint32_t row0 = __builtin_amdgcn_readfirstlane(d.y);
-    const uint32_t cnt = __builtin_amdgcn_readfirstlane(d.z) & 0xffffu;
-    const uint32_t flags = __builtin_amdgcn_readfirstlane(d.z) >> 16;
-    const uint32_t aux = __builtin_amdgcn_readfirstlane(d.w);
-    const uint2 *__restrict__ sp = a.stream + off;
-    const float ident = S::ident(a.zero);
-
-    // Software pipeline, three stages deep, so that a wave always has stream loads AND gathers in
-    // flight while it reduces:   stream(i+2)  |  gather x(i+1)  |  reduce(i).
-    // c0/x0 = entries and gathered x of the iteration being reduced, c1 = entries of the next one.
-    const uint32_t kStep = 64u * U;
-    uint2 c0[U], c1[U];
-    float x0[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        uint32_t k = u * 64u + lane;
-        c0[u] = (k < cnt) ? load_stream_nt(sp + k) : make_uint2(0u, 0u);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        uint32_t k = kStep + u * 64u + lane;
-        c1[u] = (k < cnt) ? load_stream_nt(sp + k) : make_uint2(0u, 0u);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) x0[u] = a.x[c0[u].x & 0x7fffffffu];
-
-    if (flags & kTileLong) {
-        // slice of one long row: plain per-lane accumulation, one wave reduction at the end
-        float acc = ident;
-        for (uint32_t base = 0; base < cnt; base += kStep) {
-            uint2 c2[U];
-            float x1[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                uint32_t k = base + 2u * kStep + u * 64u + lane;
-                c2[u] = (k < cnt) ? load_stream_nt(sp + k) : make_uint2(0u, 0u);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) x1[u] = a.x[c1[u].x & 0x7fffffffu];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                uint32_t k = base + u * 64u + lane;
-                float p = (k < cnt) ? S::mul(__uint_as_float(c0[u].y), x0[u]) : ident;
-                acc = S::add(acc, p);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                c0[u] = c1[u];
-                c1[u] = c2[u];
-                x0[u] = x1[u];
-            }
-        }
-#pragma unroll
-        for (int dlt = 32; dlt >= 1; dlt >>= 1) acc = S::add(acc, __shfl_down(acc, dlt));
-        if (lane == 0) a.long_partials[aux] = acc;
-        return;
-    }
-
-    float carry = ident;     // partial sum of the row that is open at the start of the step
-    uint32_t rows_done = 0;  // rows of this tile already written
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-
-    for (uint32_t base = 0; base < cnt; base += kStep) {
-        uint2 c2[U];
-        float x1[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            uint32_t k = base + 2u * kStep + u * 64u + lane;
-            c2[u] = (k < cnt) ? load_stream_nt(sp + k) : make_uint2(0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) x1[u] = a.x[c1[u].x & 0x7fffffffu];
-
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (base + u * 64u >= cnt) break;  // wave-uniform
-            const uint32_t k = base + u * 64u + lane;
-            const bool valid = k < cnt;
-            float p = valid ? S::mul(__uint_as_float(c0[u].y), x0[u]) : ident;
-            const bool e = valid && (c0[u].x >> 31);
-            const uint64_t me = __ballot(e);
-            const uint64_t below = me & lt_mask;
-            // first lane of the segment this lane belongs to
-            const uint32_t seg_start = below ? (64u - (uint32_t)__clzll((long long)below)) : 0u;
-#pragma unroll
-            for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
-                float up = __shfl_up(p, dlt);
-                if (lane >= seg_start + dlt) p = S::add(p, up);
-            }
-            const float v = (seg_start == 0u) ? S::add(carry, p) : p;
-            if (e) {
-                uint32_t kr = rows_done + (uint32_t)__popcll(below);
-                uint32_t row = (flags & kTileNonContig) ? a.rowmap[aux + kr] : row0 + kr;
-                store_row<OP, MASK>(a, row, v);
-            }
-            rows_done += (uint32_t)__popcll(me);
-            const float last = __shfl(v, 63);
-            carry = (me >> 63) ? ident : last;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            c0[u] = c1[u];
-            c1[u] = c2[u];
-            x0[u] = x1[u];
-        }
-    }
-}
-
-struct LongRowArgs {
-    const uint4 *long_rows;  // {row, first partial, nparts, 0}
-    const float *partials;
-    const float *mask;
-    float *y;
-    uint32_t nlong;
-    float zero;
-};
-
-// one wavefront per long row; fixed combination order => deterministic result
-template <int OP, int MASK>
-__global__ __launch_bounds__(256) void spmv_long_rows_kernel(LongRowArgs a) {
-    using S = Semiring<OP>;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (i >= a.nlong) return;
-    const uint4 d = a.long_rows[i];
-    float acc = S::ident(a.zero);
-    for (uint32_t k = lane; k < d.z; k += 64u) acc = S::add(acc, a.partials[d.y + k]);
-#pragma unroll
-    for (int dlt = 32; dlt >= 1; dlt >>= 1) acc = S::add(acc, __shfl_down(acc, dlt));
-    if (lane == 0) {
-        float out = S::finish(a.zero, acc);
-        if (MASK != GL_NOMASK) {
-            if (!mask_allows<MASK>(a.mask[d.x], 0.0f)) out = 0.0f;
-        }
-        a.y[d.x] = out;
-    }
-}
-
-static int unroll_setting() {
-    static int u = [] {
-        const char *e = getenv("GRAPHLILY_SPMV_UNROLL");
-        int v = e ? atoi(e) : 4;
-        return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4;
-    }();
-    return u;
-}
-
-template <int OP, int MASK>
-static int launch_spmv(const SpmvArgs &a, const LongRowArgs &l, hipStream_t s) {
-    unsigned blocks = a.tile_blocks + cdiv(a.nempty, 256);
-    if (blocks) {
-        Profiler &pf = prof();
-        const bool timed = pf.on && 2ull * (pf.used + 1) <= pf.events.size();
-        if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
-        switch (unroll_setting()) {
-            case 1: spmv_rseg_kernel<OP, MASK, 1><<<blocks, 256, 0, s>>>(a); break;
-            case 2: spmv_rseg_kernel<OP, MASK, 2><<<blocks, 256, 0, s>>>(a); break;
-            case 8: spmv_rseg_kernel<OP, MASK, 8><<<blocks, 256, 0, s>>>(a); break;
-            default: spmv_rseg_kernel<OP, MASK, 4><<<blocks, 256, 0, s>>>(a); break;
-        }
-        GL_LAUNCH_CHECK();
-        if (timed) {
-            GL_HIP(hipEventRecord(pf.events[2 * pf.used + 1], s));
-            pf.used++;
-        }
-    }
-    if (l.nlong) {
-        spmv_long_rows_kernel<OP, MASK><<<cdiv(l.nlong, 4), 256, 0, s>>>(l);
-        GL_LAUNCH_CHECK();
-    }
-    return GL_OK;
-}
 
 template <int OP>
-static int dispatch_mask(int mask_type, const SpmvArgs &a, const LongRowArgs &l, hipStream_t s) {
-    switch (mask_type) {
-        case GL_NOMASK: return launch_spmv<OP, GL_NOMASK>(a, l, s);
-        case GL_MASK_WRITETOZERO: return launch_spmv<OP, GL_MASK_WRITETOZERO>(a, l, s);
-        case GL_MASK_WRITETOONE: return launch_spmv<OP, GL_MASK_WRITETOONE>(a, l, s);
-        default: return set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid mask type %d", mask_type);
+struct Tile;  // LDS accumulator policy
+
+template <>
+struct Tile<GL_OP_MULADD> {
+    using T = double;
+    __device__ static T ident() { return 0.0; }
+    __device__ static void acc(T *t, uint32_t r, float a, float xv) {
+        // float product as in the reference (spmv_module.h:495), f64 accumulation
+        __hip_atomic_fetch_add(&t[r], (double)(a * xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ static float get(const T *t, uint32_t r) { return (float)t[r]; }
+    __device__ static bool touched(float s) { return s != 0.0f; }
+    __device__ static void fold(float *y, float s) { unsafeAtomicAdd(y, s); }
+    __device__ static float init(float zero) { return zero; }
+    __device__ static float finish(float zero, float s) { return zero + s; }
+};
+
+template <>
+struct Tile<GL_OP_ANDOR> {
+    using T = float;
+    __device__ static T ident() { return 0.0f; }
+    __device__ static void acc(T *t, uint32_t r, float a, float xv) {
+        if (a != 0.0f && xv != 0.0f) t[r] = 1.0f;   // every writer stores the same value
+    }
+    __device__ static float get(const T *t, uint32_t r) { return t[r]; }
+    __device__ static bool touched(float s) { return s != 0.0f; }
+    __device__ static void fold(float *y, float) { *y = 1.0f; }
+    __device__ static float init(float zero) { return zero != 0.0f ? 1.0f : 0.0f; }
+    __device__ static float finish(float zero, float s) { return (zero != 0.0f || s != 0.0f) ? 1.0f : 0.0f; }
+};
+
+// ordered-integer min: floats >= 0 compare like int, floats < 0 like reversed uint
+__device__ __forceinline__ void atomic_min_f32_as_int(float *addr, float v) {
+    if (v >= 0.0f)
+        atomicMin((int *)addr, __float_as_int(v));
+    else
+        atomicMax((unsigned int *)addr, __float_as_uint(v));
+}
+
+template <>
+struct Tile<GL_OP_ADDMIN> {
+    using T = float;
+    __device__ static T ident() { return __builtin_inff(); }
+    __device__ static void acc(T *t, uint32_t r, float a, float xv) { atomic_min_f32_as_int(&t[r], a + xv); }
+    __device__ static float get(const T *t, uint32_t r) { return t[r]; }
+    __device__ static bool touched(float s) { return s != __builtin_inff(); }
+    __device__ static void fold(float *y, float s) { atomic_min_f32_as_int(y, s); }
+    __device__ static float init(float zero) { return zero; }
+    __device__ static float finish(float zero, float s) { return (s < zero) ? s : zero; }
+};
+
+template <int OP, int MASK, int U>
+__global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
+    using TL = Tile<OP>;
+    using T = typename TL::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *tile = reinterpret_cast<T *>(__builtin_assume_aligned(lds_raw, 16));
+
+    const uint4 d = a.units[blockIdx.x];
+    const uint32_t g0 = d.x, ngroups = d.y, row0 = d.z;
+    const uint32_t nrows = d.w & 0xffffu;
+    const bool direct = (d.w >> 31) != 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    // wave id as a scalar so that group indices, and with them the base-column loads, stay in SGPRs
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) tile[i] = TL::ident();
+    __syncthreads();
+
+    // wave w takes groups w, w+16, ...: the workgroup reads 8 KB of contiguous stream per round and all
+    // of its wavefronts sweep the columns together
+    for (uint32_t g = wave; g < ngroups; g += kWaves * U) {
+        uint2 e[U];
+        uint32_t b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t gi = g + u * kWaves;
+            const bool in = gi < ngroups;
+            e[u] = in ? load_stream_nt(a.entries + (size_t)(g0 + gi) * 64u + lane) : make_uint2(kRowPad, 0u);
+            b[u] = in ? a.bases[g0 + gi] : 0u;
+        }
+        float xv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) xv[u] = a.x[b[u] + (e[u].x >> kRowBits)];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t r = e[u].x & kRowPad;
+            if (r != kRowPad) TL::acc(tile, r, __uint_as_float(e[u].y), xv[u]);
+        }
+    }
+    __syncthreads();
+
+    if (direct) {
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
+            const uint32_t row = row0 + i;
+            float out = TL::finish(a.zero, TL::get(tile, i));
+            if (MASK != GL_NOMASK) {
+                // masked-off rows are literal 0, and the mask is compared with 0 (spmv_module.h:518-530)
+                if (!mask_allows<MASK>(a.mask[row], 0.0f)) out = 0.0f;
+            }
+            a.y[row] = out;
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
+            const float s = TL::get(tile, i);
+            if (!TL::touched(s)) continue;
+            const uint32_t row = row0 + i;
+            if (MASK != GL_NOMASK) {
+                if (!mask_allows<MASK>(a.mask[row], 0.0f)) continue;
+            }
+            TL::fold(&a.y[row], s);
+        }
+    }
+}
+
+// y initialisation for the rows of blocks that are split into several units
+template <int OP, int MASK>
+__global__ __launch_bounds__(256) void spmv_init_kernel(uint32_t r0, uint32_t r1, const float *__restrict__ mask,
+                                                        float *__restrict__ y, float zero) {
+    for (uint32_t r = r0 + blockIdx.x * 256u + threadIdx.x; r < r1; r += gridDim.x * 256u) {
+        float out = Tile<OP>::init(zero);
+        if (MASK != GL_NOMASK) {
+            if (!mask_allows<MASK>(mask[r], 0.0f)) out = 0.0f;
+        }
+        y[r] = out;
     }
 }
 
@@ -268,34 +184,131 @@ static int dispatch_mask(int mask_type, const SpmvArgs &a, const LongRowArgs &l,
 struct gl_spmv_plan_s {
     uint32_t num_rows = 0, num_cols = 0, row_begin = 0, row_end = 0;
     uint64_t nnz = 0;
-    uint32_t ntiles = 0, nempty = 0, nlong = 0, nparts = 0;
-    uint2 *d_stream = nullptr;
-    uint4 *d_tiles = nullptr;
-    uint32_t *d_rowmap = nullptr;
-    uint32_t *d_empty = nullptr;
-    uint4 *d_long_rows = nullptr;
-    float *d_long_partials = nullptr;
+    uint32_t nunits = 0, nblocks = 0, segments = 1, max_block_rows = 0;
+    uint64_t ngroups = 0;
+    uint2 *d_entries = nullptr;
+    uint32_t *d_bases = nullptr;
+    uint4 *d_units = nullptr;
     uint64_t device_bytes = 0;
 };
 
 namespace gl {
 
-static uint32_t tile_nnz_setting() {
-    // tuning knob; the reference passes (out_buf_len, vec_buf_len) hints for the same purpose
-    const char *e = getenv("GRAPHLILY_SPMV_TILE_NNZ");
-    long v = e ? atol(e) : 2048;
-    if (v < 64) v = 64;
-    if (v > 32768) v = 32768;
-    return (uint32_t)v;
+template <int OP, int MASK>
+static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
+    constexpr int U = 4;
+    const uint32_t rows = p->row_end - p->row_begin;
+    if (rows == 0) return GL_OK;
+    if (p->segments > 1 || p->nunits == 0) {
+        unsigned grid = std::min<unsigned>(cdiv(rows, 256), (unsigned)ctx().num_cus * 8u);
+        spmv_init_kernel<OP, MASK><<<grid, 256, 0, s>>>(p->row_begin, p->row_end, a.mask, a.y, a.zero);
+        GL_LAUNCH_CHECK();
+    }
+    if (!p->nunits) return GL_OK;
+    const size_t lds = (size_t)p->max_block_rows * sizeof(typename Tile<OP>::T);
+    static bool attr_set = false;  // one flag per template instantiation
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_kernel<OP, MASK, U>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxBlockRows * sizeof(double))));
+        attr_set = true;
+    }
+    Profiler &pf = prof();
+    const bool timed = pf.on && 2ull * (pf.used + 1) <= pf.events.size();
+    if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
+    spmv_rbcs_kernel<OP, MASK, U><<<p->nunits, kThreads, lds, s>>>(a);
+    GL_LAUNCH_CHECK();
+    if (timed) {
+        GL_HIP(hipEventRecord(pf.events[2 * pf.used + 1], s));
+        pf.used++;
+    }
+    return GL_OK;
 }
 
-template <typename T>
-static int upload(T **d, const std::vector<T> &h, uint64_t *bytes) {
-    size_t n = h.size() * sizeof(T);
-    GL_HIP(hipMalloc((void **)d, n ? n : 16));
-    if (n) GL_HIP(hipMemcpy(*d, h.data(), n, hipMemcpyHostToDevice));
-    *bytes += n;
-    return GL_OK;
+template <int OP>
+static int dispatch_mask(int mask_type, gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
+    switch (mask_type) {
+        case GL_NOMASK: return launch_spmv<OP, GL_NOMASK>(p, a, s);
+        case GL_MASK_WRITETOZERO: return launch_spmv<OP, GL_MASK_WRITETOZERO>(p, a, s);
+        case GL_MASK_WRITETOONE: return launch_spmv<OP, GL_MASK_WRITETOONE>(p, a, s);
+        default: return set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid mask type %d", mask_type);
+    }
+}
+
+// ------------------------------------------------------------------------------------- planner
+// matrix-stream rate (TB/s) sustained by the inner loop as a function of the mean column distance
+// between consecutive entries of a unit (scripts/ubench_gap.hip, shared x window)
+static double stream_rate(double gap) {
+    static const double gx[] = {1.5, 3.0, 6.0, 12.0, 24.0, 48.0, 96.0};
+    static const double gy[] = {4.4, 4.35, 3.4, 2.4, 1.5, 1.0, 0.7};
+    if (gap <= gx[0]) return gy[0];
+    for (int i = 1; i < 7; i++)
+        if (gap <= gx[i]) {
+            double t = (std::log(gap) - std::log(gx[i - 1])) / (std::log(gx[i]) - std::log(gx[i - 1]));
+            return gy[i - 1] + t * (gy[i] - gy[i - 1]);
+        }
+    return gy[6];
+}
+
+struct Shape {
+    uint32_t blocks, segments;
+};
+
+static long env_long(const char *name, long dflt) {
+    const char *e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+
+// choose (#row blocks, #segments per block): blocks*segments ~ 256*k equal units, rows per block as
+// large as LDS allows (dense column sweep => coalesced gathers) unless splitting costs more than it buys
+static Shape choose_shape(uint64_t rows, uint64_t cols, uint64_t nnz, int num_cus) {
+    Shape best{1, 1};
+    if (rows == 0 || nnz == 0) return best;
+    const double deg = (double)nnz / (double)rows;
+    const uint64_t rmax = kMaxBlockRows - 64;   // slack: blocks are cut by nnz, not by row count
+    double best_cost = 1e300;
+    for (int k = 1; k <= 16 && best_cost > 1e299; k *= 2) {
+        for (uint32_t S = 1; S <= 64; S++) {
+            uint64_t B = (uint64_t)num_cus * k / S;
+            if (B == 0) break;
+            if (B > rows) B = rows;
+            const uint64_t R = (rows + B - 1) / B;
+            if (R > rmax) continue;
+            const double gap = (double)cols / ((double)R * deg);
+            const double flush = (S == 1) ? 0.0 : ((double)S * rows * 4.0 * 1.5 + rows * 8.0) / (8.0 * nnz);
+            const double util = (double)B * S / ((double)num_cus * k);
+            const double t = (8.0 * nnz * (1.0 + flush)) / (stream_rate(gap) * 1e12) / util + 3.0e-6 * k;
+            if (t < best_cost) {
+                best_cost = t;
+                best = Shape{(uint32_t)B, S};
+            }
+        }
+    }
+    if (best_cost > 1e299) best = Shape{(uint32_t)((rows + rmax - 1) / rmax), 1};  // taller than 16 rounds of CUs
+    const long fb = env_long("GRAPHLILY_SPMV_BLOCKS", 0), fs = env_long("GRAPHLILY_SPMV_SEGMENTS", 0);
+    if (fb > 0) best.blocks = (uint32_t)std::min<uint64_t>((uint64_t)fb, rows);
+    if (fs > 0) best.segments = (uint32_t)std::min<long>(fs, 4096);
+    return best;
+}
+
+struct Rec {
+    uint32_t col, row_local, val;
+};
+
+// stable LSD radix sort of a block's records by column
+static void sort_by_col(std::vector<Rec> &a, std::vector<Rec> &tmp, uint32_t num_cols) {
+    const size_t n = a.size();
+    tmp.resize(n);
+    int bits = 1;
+    while ((1ull << bits) < num_cols) bits++;
+    const int passes = (bits + 10) / 11;
+    for (int p = 0; p < passes; p++) {
+        const int sh = 11 * p;
+        size_t cnt[2049] = {0};
+        for (size_t i = 0; i < n; i++) cnt[((a[i].col >> sh) & 2047u) + 1]++;
+        for (int i = 0; i < 2048; i++) cnt[i + 1] += cnt[i];
+        for (size_t i = 0; i < n; i++) tmp[cnt[(a[i].col >> sh) & 2047u]++] = a[i];
+        a.swap(tmp);
+    }
 }
 
 }  // namespace gl
@@ -313,83 +326,107 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
     GL_ARG(nz1 >= nz0);
     const uint64_t nnz = nz1 - nz0;
     GL_ARG(nnz == 0 || (h_indices != nullptr && h_data != nullptr));
+    const uint32_t rows = row_end - row_begin;
+    for (uint32_t r = row_begin; r < row_end; r++) GL_ARG(h_indptr[r + 1] >= h_indptr[r]);
 
-    const uint32_t tile_nnz = gl::tile_nnz_setting();
-    std::vector<uint4> tiles;
-    std::vector<uint32_t> rowmap, empty;
-    std::vector<uint4> long_rows;
-    std::vector<uint2> stream(nnz);
-    tiles.reserve(nnz / tile_nnz * 5 / 4 + 16);
-    bool any_noncontig = false;
-
-    // open tile state
-    uint32_t cur_cnt = 0, cur_off = 0, cur_row0 = 0, cur_last = 0, cur_map0 = 0;
-    bool cur_noncontig = false;
-    auto flush = [&]() {
-        if (!cur_cnt) return;
-        uint32_t flags = cur_noncontig ? gl::kTileNonContig : 0u;
-        any_noncontig |= cur_noncontig;
-        tiles.push_back(make_uint4(cur_off, cur_row0, cur_cnt | (flags << 16), cur_map0));
-        cur_cnt = 0;
-        cur_noncontig = false;
-    };
-    uint32_t nparts = 0;
-    for (uint32_t r = row_begin; r < row_end; r++) {
-        const uint64_t s = h_indptr[r], e = h_indptr[r + 1];
-        GL_ARG(e >= s && e <= nz1);
-        const uint64_t len = e - s;
-        if (len == 0) {
-            empty.push_back(r);
-            continue;
-        }
-        if (len > tile_nnz) {
-            flush();
-            uint32_t parts = (uint32_t)((len + tile_nnz - 1) / tile_nnz);
-            long_rows.push_back(make_uint4(r, nparts, parts, 0u));
-            for (uint32_t p = 0; p < parts; p++) {
-                uint64_t ps = s + (uint64_t)p * tile_nnz;
-                uint32_t pc = (uint32_t)std::min<uint64_t>(tile_nnz, e - ps);
-                tiles.push_back(make_uint4((uint32_t)(ps - nz0), r, pc | (gl::kTileLong << 16), nparts + p));
+    // ---- row blocks: nnz-balanced boundaries, at most kMaxBlockRows rows each
+    const gl::Shape shape = gl::choose_shape(rows, num_cols, nnz, gl::ctx().num_cus);
+    std::vector<uint32_t> bstart;
+    bstart.push_back(row_begin);
+    if (nnz > 0) {
+        const double target = (double)nnz / (double)shape.blocks;
+        uint32_t r = row_begin, made = 0;
+        while (r < row_end) {
+            made++;
+            const uint32_t hi = (uint32_t)std::min<uint64_t>(row_end, (uint64_t)r + gl::kMaxBlockRows);
+            uint32_t e;
+            if (made >= shape.blocks && hi == row_end) {
+                e = row_end;   // the last planned block takes what is left if it fits
+            } else {
+                const uint64_t want64 = nz0 + (uint64_t)std::llround(target * made);
+                const uint32_t want = (uint32_t)std::min<uint64_t>(want64, nz1);
+                // last e in [r+1, hi] with indptr[e] <= want, at least one row
+                const uint32_t *ub = std::upper_bound(h_indptr + r + 1, h_indptr + hi + 1, want);
+                e = (uint32_t)(ub - h_indptr) - 1u;
+                if (e < r + 1) e = r + 1;
             }
-            nparts += parts;
-            continue;
+            bstart.push_back(e);
+            r = e;
         }
-        if (cur_cnt && cur_cnt + len > tile_nnz) flush();
-        if (!cur_cnt) {
-            cur_off = (uint32_t)(s - nz0);
-            cur_row0 = r;
-            cur_map0 = (uint32_t)rowmap.size();
-        } else if (r != cur_last + 1) {
-            cur_noncontig = true;
-        }
-        rowmap.push_back(r);
-        cur_last = r;
-        cur_cnt += (uint32_t)len;
     }
-    flush();
+    const uint32_t nblocks = (uint32_t)bstart.size() - 1;
+    const uint32_t S = nblocks ? shape.segments : 1;
+    const uint32_t jump_slack = (num_cols >> gl::kColOffBits) + 2;
 
-    // fill the stream: CSR order, row_end flag on the last entry of every short row
+    // ---- group budget per unit (upper bound), so every block can be emitted independently;
+    //      units are numbered segment-major: u = s * nblocks + b
+    std::vector<uint64_t> unit_goff((size_t)nblocks * S + 1, 0);
+    for (uint32_t b = 0; b < nblocks; b++) {
+        const uint64_t m = (uint64_t)h_indptr[bstart[b + 1]] - h_indptr[bstart[b]];
+        for (uint32_t s = 0; s < S; s++) {
+            const uint64_t c0 = m * s / S, c1 = m * (s + 1) / S;
+            unit_goff[(size_t)s * nblocks + b + 1] = (c1 > c0) ? (c1 - c0 + 63) / 64 + jump_slack : 0;
+        }
+    }
+    for (size_t i = 0; i < (size_t)nblocks * S; i++) unit_goff[i + 1] += unit_goff[i];
+    const uint64_t total_groups = unit_goff[(size_t)nblocks * S];
+    GL_ARG(total_groups < 0xffffffffull);
+
+    std::vector<uint2> entries(total_groups * 64);
+    std::vector<uint32_t> bases(total_groups);
+    std::vector<uint4> units((size_t)nblocks * S);
+    uint32_t max_rows = 0;
+    int bad_col = 0;
+
+#pragma omp parallel
     {
-        std::vector<uint8_t> is_long;  // only consulted when long rows exist
-        const bool have_long = !long_rows.empty();
-        if (have_long) {
-            is_long.assign(row_end - row_begin, 0);
-            for (const uint4 &lr : long_rows) is_long[lr.x - row_begin] = 1;
-        }
-#pragma omp parallel for schedule(static, 4096)
-        for (int64_t r = row_begin; r < (int64_t)row_end; r++) {
-            const uint64_t s = h_indptr[r], e = h_indptr[r + 1];
-            if (s == e) continue;
-            for (uint64_t i = s; i < e; i++) stream[i - nz0] = make_uint2(h_indices[i], __builtin_bit_cast(uint32_t, h_data[i]));
-            if (!(have_long && is_long[r - row_begin])) stream[e - 1 - nz0].x |= 0x80000000u;
+        std::vector<gl::Rec> recs, tmp;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)nblocks; b++) {
+            const uint32_t r0 = bstart[b], r1 = bstart[b + 1];
+            const uint64_t e0 = h_indptr[r0], e1 = h_indptr[r1];
+            recs.resize(e1 - e0);
+            bool bad = false;
+            for (uint32_t r = r0; r < r1; r++)
+                for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
+                    bad |= h_indices[i] >= num_cols;
+                    recs[i - e0] = gl::Rec{h_indices[i], r - r0, __builtin_bit_cast(uint32_t, h_data[i])};
+                }
+            if (bad) {
+#pragma omp atomic write
+                bad_col = 1;
+                continue;
+            }
+            gl::sort_by_col(recs, tmp, num_cols);
+            const uint64_t m = recs.size();
+            for (uint32_t s = 0; s < S; s++) {
+                const size_t u = (size_t)s * nblocks + b;
+                const uint64_t c0 = m * s / S, c1 = m * (s + 1) / S;
+                uint64_t g = unit_goff[u];     // groups [unit_goff[u], g) are complete or open
+                uint32_t fill = 64, base = 0;  // fill == 64: no open group
+                for (uint64_t i = c0; i < c1; i++) {
+                    const gl::Rec &rc = recs[i];
+                    if (fill == 64 || rc.col - base >= (1u << gl::kColOffBits)) {
+                        if (fill != 64)
+                            for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
+                        base = rc.col;
+                        bases[g] = base;
+                        g++;
+                        fill = 0;
+                    }
+                    entries[(g - 1) * 64 + fill] = make_uint2(((rc.col - base) << gl::kRowBits) | rc.row_local, rc.val);
+                    fill++;
+                }
+                if (g > unit_goff[u])
+                    for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
+                units[u] = make_uint4((uint32_t)unit_goff[u], (uint32_t)(g - unit_goff[u]), r0,
+                                      (r1 - r0) | (S == 1 ? 0x80000000u : 0u));
+            }
         }
     }
-    for (uint64_t i = 0; i < nnz; i++) {
-        if ((stream[i].x & 0x7fffffffu) >= num_cols)
-            return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index %u out of range (num_cols %u)",
-                                 stream[i].x & 0x7fffffffu, num_cols);
-    }
-    if (!any_noncontig) rowmap.clear();
+    if (bad_col)
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", num_cols);
+    for (uint32_t b = 0; b < nblocks; b++) max_rows = std::max(max_rows, bstart[b + 1] - bstart[b]);
 
     gl_spmv_plan p = new gl_spmv_plan_s();
     p->num_rows = num_rows;
@@ -397,46 +434,52 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
     p->row_begin = row_begin;
     p->row_end = row_end;
     p->nnz = nnz;
-    p->ntiles = (uint32_t)tiles.size();
-    p->nempty = (uint32_t)empty.size();
-    p->nlong = (uint32_t)long_rows.size();
-    p->nparts = nparts;
+    p->nblocks = nblocks;
+    p->segments = S;
+    p->nunits = nblocks * S;
+    p->ngroups = total_groups;
+    p->max_block_rows = max_rows;
+    auto up = [&](void **d, const void *h, size_t bytes) -> int {
+        GL_HIP(hipMalloc(d, bytes ? bytes : 16));
+        if (bytes) GL_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+        p->device_bytes += bytes;
+        return GL_OK;
+    };
     int rc;
-    if ((rc = gl::upload(&p->d_stream, stream, &p->device_bytes)) != GL_OK ||
-        (rc = gl::upload(&p->d_tiles, tiles, &p->device_bytes)) != GL_OK ||
-        (rc = gl::upload(&p->d_rowmap, rowmap, &p->device_bytes)) != GL_OK ||
-        (rc = gl::upload(&p->d_empty, empty, &p->device_bytes)) != GL_OK ||
-        (rc = gl::upload(&p->d_long_rows, long_rows, &p->device_bytes)) != GL_OK) {
+    if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * sizeof(uint2))) != GL_OK ||
+        (rc = up((void **)&p->d_bases, bases.data(), bases.size() * sizeof(uint32_t))) != GL_OK ||
+        (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK) {
         gl_spmv_plan_destroy(p);
         return rc;
     }
-    hipError_t he = hipMalloc((void **)&p->d_long_partials, (nparts ? nparts : 4) * sizeof(float));
-    if (he != hipSuccess) {
-        gl_spmv_plan_destroy(p);
-        return gl::set_error(GL_ERR_HIP, "hipMalloc(long partials): %s", hipGetErrorString(he));
-    }
-    p->device_bytes += (uint64_t)nparts * sizeof(float);
     *plan = p;
     return GL_OK;
 }
 
 int gl_spmv_plan_destroy(gl_spmv_plan p) {
     if (!p) return GL_OK;
-    (void)hipFree(p->d_stream);
-    (void)hipFree(p->d_tiles);
-    (void)hipFree(p->d_rowmap);
-    (void)hipFree(p->d_empty);
-    (void)hipFree(p->d_long_rows);
-    (void)hipFree(p->d_long_partials);
+    (void)hipFree(p->d_entries);
+    (void)hipFree(p->d_bases);
+    (void)hipFree(p->d_units);
     delete p;
     return GL_OK;
 }
 
-int gl_spmv_plan_info(gl_spmv_plan p, uint64_t *nnz, uint64_t *device_bytes, uint32_t *num_tiles) {
+int gl_spmv_plan_info(gl_spmv_plan p, uint64_t *nnz, uint64_t *device_bytes, uint32_t *num_units) {
     GL_ARG(p != nullptr);
     if (nnz) *nnz = p->nnz;
     if (device_bytes) *device_bytes = p->device_bytes;
-    if (num_tiles) *num_tiles = p->ntiles;
+    if (num_units) *num_units = p->nunits;
+    return GL_OK;
+}
+
+int gl_spmv_plan_shape(gl_spmv_plan p, uint32_t *blocks, uint32_t *segments, uint32_t *max_block_rows,
+                       uint64_t *groups) {
+    GL_ARG(p != nullptr);
+    if (blocks) *blocks = p->nblocks;
+    if (segments) *segments = p->segments;
+    if (max_block_rows) *max_block_rows = p->max_block_rows;
+    if (groups) *groups = p->ngroups;
     return GL_OK;
 }
 
@@ -447,30 +490,18 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     GL_ARG(d_x != nullptr || p->nnz == 0);
     GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
     gl::SpmvArgs a;
-    a.stream = p->d_stream;
-    a.tiles = p->d_tiles;
-    a.rowmap = p->d_rowmap;
-    a.empty_rows = p->d_empty;
+    a.entries = p->d_entries;
+    a.bases = p->d_bases;
+    a.units = p->d_units;
     a.x = d_x;
     a.mask = d_mask;
     a.y = d_y;
-    a.long_partials = p->d_long_partials;
-    a.ntiles = p->ntiles;
-    a.tile_blocks = gl::cdiv(p->ntiles, 4);
-    a.nempty = p->nempty;
     a.zero = zero;
-    gl::LongRowArgs l;
-    l.long_rows = p->d_long_rows;
-    l.partials = p->d_long_partials;
-    l.mask = d_mask;
-    l.y = d_y;
-    l.nlong = p->nlong;
-    l.zero = zero;
     hipStream_t s = gl::ctx().stream;
     switch (op) {
-        case GL_OP_MULADD: return gl::dispatch_mask<GL_OP_MULADD>(mask_type, a, l, s);
-        case GL_OP_ANDOR: return gl::dispatch_mask<GL_OP_ANDOR>(mask_type, a, l, s);
-        case GL_OP_ADDMIN: return gl::dispatch_mask<GL_OP_ADDMIN>(mask_type, a, l, s);
+        case GL_OP_MULADD: return gl::dispatch_mask<GL_OP_MULADD>(mask_type, p, a, s);
+        case GL_OP_ANDOR: return gl::dispatch_mask<GL_OP_ANDOR>(mask_type, p, a, s);
+        case GL_OP_ADDMIN: return gl::dispatch_mask<GL_OP_ADDMIN>(mask_type, p, a, s);
         default: return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid semiring op %d", op);
     }
 }

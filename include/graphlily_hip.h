@@ -79,8 +79,8 @@ int gl_buf_fill_f32(float *d_dst, float value, size_t count);   /* async    */
 /* --------------------------------------------------------------------- SpMV
  * gl_spmv_plan_create replaces SpMVModule::load_and_format_matrix +
  * send_matrix_host_to_device (module/spmv_module.h:281-420): it re-lays the
- * host CSR (io/data_loader.h:18-30) out as the CDNA4 row-segment stream and
- * uploads it.  [row_begin,row_end) selects the row shard this device owns
+ * host CSR (io/data_loader.h:18-30) out as the CDNA4 row-block / column-sorted
+ * stream (gl_spmv.hip) and uploads it.  [row_begin,row_end) selects the row shard this device owns
  * (0,num_rows = whole matrix); x is always indexed by global column and y by
  * global row, so a shard writes y[row_begin..row_end) of a full-length y. */
 int gl_spmv_plan_create(gl_spmv_plan *plan,
@@ -88,8 +88,11 @@ int gl_spmv_plan_create(gl_spmv_plan *plan,
                         const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
                         uint32_t row_begin, uint32_t row_end);
 int gl_spmv_plan_destroy(gl_spmv_plan plan);
-/* nnz held by this plan (its shard) and device bytes of the formatted matrix */
-int gl_spmv_plan_info(gl_spmv_plan plan, uint64_t *nnz, uint64_t *device_bytes, uint32_t *num_tiles);
+/* nnz held by this plan (its shard), device bytes of the formatted matrix, number of work units */
+int gl_spmv_plan_info(gl_spmv_plan plan, uint64_t *nnz, uint64_t *device_bytes, uint32_t *num_units);
+/* decomposition chosen by the planner: row blocks x column segments, tallest block, 64-entry groups */
+int gl_spmv_plan_shape(gl_spmv_plan plan, uint32_t *blocks, uint32_t *segments, uint32_t *max_block_rows,
+                       uint64_t *groups);
 
 /* gl_spmv_run replaces enqueueTask(overlay, mode = 1) (module/spmv_module.h:471-475,
  * hw/overlay.cpp:308-330 -> hw/kernel_spmv_impl.h:392-819):

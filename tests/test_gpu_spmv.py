@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from graphlily_amd import io, module as M
+from graphlily_amd import datasets, io, module as M
 from oracle import oracle as O
 
 from helpers import (MASKS, SEMIRINGS, arith_exact, assert_arith_parity, assert_parity, rand01, spmv_prepare,
@@ -94,15 +94,52 @@ def test_float_values_random(gpu):
     _check(got, m, "Arithmetic", "NoMask", x, None, "random floats")
 
 
-@pytest.mark.parametrize("tile", ["64", "256", "4096"])
-def test_tile_sizes(gpu, tile, monkeypatch):
-    """The tile size only changes the work decomposition (more / fewer LONG rows), never results."""
-    monkeypatch.setenv("GRAPHLILY_SPMV_TILE_NNZ", tile)
+@pytest.mark.parametrize("blocks,segments", [(1, 1), (3, 1), (2, 5), (7, 3), (64, 4), (300, 1)])
+def test_decompositions(gpu, blocks, segments, monkeypatch):
+    """The planner's (row blocks x column segments) choice only changes the work decomposition -- and,
+    for segments > 1, switches the epilogue from direct stores to init + atomic folds -- never results."""
+    monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(blocks))
+    monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(segments))
     m = spmv_prepare("rmat_20K")
     x, mask = rand01(m.num_cols, 7), rand01(m.num_rows, 8)
     for sem in ("Logical", "Tropical", "Arithmetic"):
-        got = _run_spmv(gpu, m, sem, "WriteToZero", x, mask)
-        _check(got, m, sem, "WriteToZero", x, mask, "tile %s %s" % (tile, sem))
+        for mk in ("WriteToZero", "NoMask"):
+            got = _run_spmv(gpu, m, sem, mk, x, mask)
+            _check(got, m, sem, mk, x, mask, "shape %dx%d %s %s" % (blocks, segments, sem, mk))
+
+
+def test_wide_column_jumps(gpu):
+    """Columns further apart than the 18-bit in-group offset force early group cuts and padding."""
+    n_cols = 3_000_000
+    rng = np.random.default_rng(3)
+    rows = 300
+    cols = np.sort(rng.choice(n_cols, size=(rows, 5), replace=False), axis=1).astype(np.uint32)
+    m = io.CSRMatrix(rows, n_cols, rng.random(rows * 5, dtype=np.float32), cols.reshape(-1),
+                     np.arange(0, rows * 5 + 1, 5, dtype=np.uint32))
+    x = rng.random(n_cols, dtype=np.float32)
+    for sem in ("Arithmetic", "Tropical"):
+        got = _run_spmv(gpu, m, sem, "NoMask", x, np.zeros(rows, np.float32))
+        _check(got, m, sem, "NoMask", x, None, "wide jumps " + sem)
+
+
+def test_tall_matrix_many_blocks(gpu):
+    """More rows than 256 full-height blocks can hold is not needed to hit the row cap: force it."""
+    m = spmv_prepare("uniform_10K_10")
+    x, mask = rand01(m.num_cols, 1), rand01(m.num_rows, 2)
+    import os
+    os.environ["GRAPHLILY_SPMV_BLOCKS"] = "1"      # one planned block, but 10112 rows fit; fine
+    try:
+        got = _run_spmv(gpu, m, "Arithmetic", "WriteToOne", x, mask)
+    finally:
+        del os.environ["GRAPHLILY_SPMV_BLOCKS"]
+    _check(got, m, "Arithmetic", "WriteToOne", x, mask, "single block")
+    big = datasets.uniform(40000, 3, seed=2)        # 40000 rows > 16383: the row cap must split blocks
+    os.environ["GRAPHLILY_SPMV_BLOCKS"] = "1"
+    try:
+        got = _run_spmv(gpu, big, "Tropical", "NoMask", rand01(big.num_cols, 5), rand01(big.num_rows, 6))
+    finally:
+        del os.environ["GRAPHLILY_SPMV_BLOCKS"]
+    assert_parity(got, _ref_spmv(big, "Tropical", "NoMask", rand01(big.num_cols, 5), None), 2, "row cap")
 
 
 def test_edge_shapes(gpu):
