@@ -16,7 +16,7 @@ with the matrix, x and y resident in HBM before the timed region; wall time is b
 barrier + synchronize on both sides and MAX-reduced over ranks.
 
 Extra objects on the same JSON line:
-  roofline      HBM roofline of the dominant kernel (spmv_rseg_kernel): algorithmic bytes per launch /
+  roofline      HBM roofline of the dominant kernel (spmv_rbcs_kernel): algorithmic bytes per launch /
                 its mean duration from HIP events recorded on the launch stream inside the timed region.
   cpu_baseline  the oracle's single-thread restatement of SpMVModule::compute_reference_results timed
                 on this host (rank 0, N = 1 only), same byte formula.
@@ -159,7 +159,7 @@ def main():
         "selfcheck_ok": ok,
         "setup_s": {"graph": round(t_gen, 2), "plan": round(t_plan, 2)},
         "roofline": {
-            "bound": "hbm", "kernel": "spmv_rseg_kernel<MULADD,NOMASK>",
+            "bound": "hbm", "kernel": "spmv_rbcs_kernel<MULADD,NOMASK>",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": _pmc_traffic(),
@@ -192,7 +192,7 @@ def _pmc_traffic():
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get("spmv_rseg_kernel_bytes_per_launch")
+            return json.load(f).get("spmv_rbcs_kernel_bytes_per_launch")
     except Exception:
         return None
 
