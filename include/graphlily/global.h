@@ -1,0 +1,155 @@
+// graphlily/global.h -- MI355X build of GraphLily's global definitions.
+//
+// Drop-in for the reference's graphlily/global.h:57-164 as far as the SpMV / SpMSpV hot path and
+// its callers use it: element types, the three semirings, mask types, aligned host vectors and
+// convert_sparse_vec_to_dense_vec.  The FPGA plumbing of the reference header (HBM bank map,
+// find_device, makefile strings, :27-54, :110-146) has no counterpart: there is no bitstream.
+//
+// val_t is float here (the reference's third option, global.h:64; the shipped default is
+// ap_ufixed<32,8>, :63, which needs Xilinx ap_fixed.h).
+#ifndef GRAPHLILY_GLOBAL_H_
+#define GRAPHLILY_GLOBAL_H_
+
+#include <algorithm>
+#include <cassert>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "graphlily_hip.h"
+
+// Host vectors handed to the device are page aligned in the reference (xcl2.hpp:61-76,
+// aligned_allocator at global scope); kept so that caller code naming it compiles unchanged.
+template <typename T>
+struct aligned_allocator {
+    using value_type = T;
+    aligned_allocator() = default;
+    template <typename U>
+    aligned_allocator(const aligned_allocator<U> &) {}
+    T *allocate(std::size_t num) {
+        void *ptr = nullptr;
+        const std::size_t bytes = (num == 0 ? 1 : num) * sizeof(T);
+        if (posix_memalign(&ptr, 4096, bytes)) throw std::bad_alloc();
+        return reinterpret_cast<T *>(ptr);
+    }
+    void deallocate(T *p, std::size_t) { free(p); }
+    template <typename U>
+    bool operator==(const aligned_allocator<U> &) const { return true; }
+    template <typename U>
+    bool operator!=(const aligned_allocator<U> &) const { return false; }
+};
+
+namespace graphlily {
+
+inline std::string get_root_path_() {
+    const char *p = getenv("GRAPHLILY_ROOT_PATH");
+    return p ? std::string(p) : std::string();
+}
+const std::string root_path = get_root_path_();
+const std::string device_name = "AMD Instinct MI355X (gfx950)";
+
+// kept for callers that size things with them; they no longer describe hardware lanes
+const uint32_t pack_size = 8;
+const uint32_t spmv_row_interleave_factor = 1;
+const uint32_t num_hbm_channels = 16;
+
+using val_t = float;
+typedef uint32_t idx_t;
+const uint32_t idx_marker = 0xffffffff;
+typedef struct {idx_t data[pack_size];} packed_idx_t;
+
+typedef struct {idx_t index; val_t val;} idx_val_t;
+typedef struct {idx_t index; float val;} idx_float_t;
+static_assert(sizeof(idx_val_t) == sizeof(gl_idx_val), "idx_val_t must match the C ABI element");
+
+using aligned_dense_vec_t = std::vector<val_t, aligned_allocator<val_t>>;
+using aligned_sparse_vec_t = std::vector<idx_val_t, aligned_allocator<idx_val_t>>;
+using aligned_dense_float_vec_t = std::vector<float, aligned_allocator<float>>;
+using aligned_sparse_float_vec_t = std::vector<idx_float_t, aligned_allocator<idx_float_t>>;
+
+const val_t UINT_INF = 4294967295.0f;
+const val_t UFIXED_INF = 255;
+const val_t FLOAT_INF = 999999999;
+
+enum OperationType {
+    kMulAdd = 0,
+    kLogicalAndOr = 1,
+    kAddMin = 2,
+};
+
+struct SemiringType {
+    OperationType op;
+    val_t one;   // identity of <x>
+    val_t zero;  // identity of <+>; a RUNTIME value on this backend (the FPGA hard-codes it per op)
+};
+
+const SemiringType ArithmeticSemiring = {kMulAdd, 1, 0};
+const SemiringType LogicalSemiring = {kLogicalAndOr, 1, 0};
+// the float line of the reference (global.h:100); the ap_ufixed build uses UFIXED_INF (:99)
+const SemiringType TropicalSemiring = {kAddMin, 0, FLOAT_INF};
+
+enum MaskType {
+    kNoMask = 0,
+    kMaskWriteToZero = 1,
+    kMaskWriteToOne = 2,
+};
+
+const std::string proj_folder_name = "proj";
+
+template <typename sparse_vec_t, typename dense_vec_t, typename value_t>
+dense_vec_t convert_sparse_vec_to_dense_vec(const sparse_vec_t &sparse_vector, uint32_t range, value_t zero) {
+    dense_vec_t dense_vector(range);
+    std::fill(dense_vector.begin(), dense_vector.end(), zero);
+    const int nnz = sparse_vector[0].index;
+    for (int i = 1; i < nnz + 1; i++) dense_vector[sparse_vector[i].index] = sparse_vector[i].val;
+    return dense_vector;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Error convention of the reference (xcl2.hpp:40-46 OCL_CHECK): report and exit, never throw.
+#define GRAPHLILY_CHECK(call)                                                                      \
+    do {                                                                                           \
+        int gl_rc_ = (call);                                                                       \
+        if (gl_rc_ != GL_OK) {                                                                     \
+            printf("%s:%d Error calling " #call ", error code is: %d (%s)\n", __FILE__, __LINE__,  \
+                   gl_rc_, gl_last_error());                                                       \
+            exit(EXIT_FAILURE);                                                                    \
+        }                                                                                          \
+    } while (0)
+
+// A reference-counted device allocation: the role cl::Buffer plays in the reference's module API.
+// Copyable, shareable between modules through bind_*_buf, freed with its last owner.
+class DeviceBuffer {
+    struct Impl {
+        void *ptr = nullptr;
+        size_t bytes = 0;
+        ~Impl() { if (ptr) gl_buf_free(ptr); }
+    };
+    std::shared_ptr<Impl> impl_;
+
+public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t bytes) : impl_(std::make_shared<Impl>()) {
+        GRAPHLILY_CHECK(gl_buf_alloc(&impl_->ptr, bytes));
+        impl_->bytes = bytes;
+    }
+    void *ptr() const { return impl_ ? impl_->ptr : nullptr; }
+    size_t size() const { return impl_ ? impl_->bytes : 0; }
+    bool valid() const { return ptr() != nullptr; }
+    void upload(const void *host, size_t bytes) const {
+        assert(bytes <= size());
+        GRAPHLILY_CHECK(gl_buf_h2d(ptr(), host, bytes));
+    }
+    void download(void *host, size_t bytes) const {
+        assert(bytes <= size());
+        GRAPHLILY_CHECK(gl_buf_d2h(host, ptr(), bytes));
+    }
+};
+
+}  // namespace graphlily
+
+#endif  // GRAPHLILY_GLOBAL_H_

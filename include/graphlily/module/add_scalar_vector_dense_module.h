@@ -1,0 +1,61 @@
+// graphlily/module/add_scalar_vector_dense_module.h -- eWiseAddModule on MI355X (reference
+// module/add_scalar_vector_dense_module.h:19-204): out[i] = in[i] + val.
+#ifndef GRAPHLILY_EWISE_ADD_MODULE_H_
+#define GRAPHLILY_EWISE_ADD_MODULE_H_
+
+#include <type_traits>
+#include <vector>
+
+#include "graphlily/global.h"
+#include "graphlily/module/base_module.h"
+
+namespace graphlily {
+namespace module {
+
+template <typename vector_data_t>
+class eWiseAddModule : public BaseModule {
+    static_assert(std::is_same<vector_data_t, float>::value, "the MI355X backend computes in float");
+    using aligned_dense_vec_t = std::vector<vector_data_t, aligned_allocator<vector_data_t>>;
+    aligned_dense_vec_t in_, out_;
+
+public:
+    DeviceBuffer in_buf;
+    DeviceBuffer out_buf;
+
+    eWiseAddModule() : BaseModule("overlay") {}
+
+    void send_in_host_to_device(aligned_dense_vec_t &in) {
+        in_.assign(in.begin(), in.end());
+        in_buf = DeviceBuffer(sizeof(float) * in_.size());
+        in_buf.upload(in_.data(), sizeof(float) * in_.size());
+    }
+    void allocate_out_buf(uint32_t len) {
+        out_.resize(len);
+        out_buf = DeviceBuffer(sizeof(float) * len);
+    }
+    void bind_in_buf(DeviceBuffer src_buf) { in_buf = src_buf; }
+    void bind_out_buf(DeviceBuffer src_buf) { out_buf = src_buf; }
+
+    void run(uint32_t len, vector_data_t val) {
+        GRAPHLILY_CHECK(gl_ewise_add((const float *)in_buf.ptr(), (float *)out_buf.ptr(), len, val));
+        finish_();
+    }
+
+    aligned_dense_vec_t send_out_device_to_host() {
+        out_.resize(out_buf.size() / sizeof(float));
+        out_buf.download(out_.data(), sizeof(float) * out_.size());
+        return out_;
+    }
+
+    graphlily::aligned_dense_float_vec_t compute_reference_results(graphlily::aligned_dense_float_vec_t const &in,
+                                                                    uint32_t len, float val) {
+        graphlily::aligned_dense_float_vec_t out(len);
+        for (uint32_t i = 0; i < len; i++) out[i] = in[i] + val;
+        return out;
+    }
+};
+
+}  // namespace module
+}  // namespace graphlily
+
+#endif  // GRAPHLILY_EWISE_ADD_MODULE_H_

@@ -1,0 +1,64 @@
+// graphlily/module/base_module.h -- common part of the operator modules (reference
+// module/base_module.h:10-133) on the HIP C ABI: no OpenCL device/context/kernel/queue objects; the
+// "runtime" is the library's device + stream (gl_init / gl_sync).
+#ifndef GRAPHLILY_BASE_MODULE_H_
+#define GRAPHLILY_BASE_MODULE_H_
+
+#include <cassert>
+#include <string>
+
+#include "graphlily/global.h"
+
+namespace graphlily {
+namespace module {
+
+class BaseModule {
+protected:
+    std::string kernel_name_;
+    std::string target_ = "hw";
+    int device_ = 0;
+    bool blocking_ = true;  // every reference call ends in command_queue_.finish()
+
+    void finish_() {
+        if (blocking_) GRAPHLILY_CHECK(gl_sync());
+    }
+
+public:
+    explicit BaseModule(std::string kernel_name) : kernel_name_(kernel_name) {}
+    virtual ~BaseModule() {}
+
+    std::string get_kernel_name() { return kernel_name_; }
+
+    void set_target(std::string target) {
+        assert(target == "sw_emu" || target == "hw_emu" || target == "hw");
+        target_ = target;
+    }
+
+    // extension: which GPU this module's buffers and kernels live on (default 0)
+    void set_device(int device) { device_ = device; }
+
+    // extension: let a driver enqueue several module calls and synchronise once (gl_sync)
+    void set_blocking(bool blocking) { blocking_ = blocking; }
+
+    void copy_buffer_device_to_device(DeviceBuffer src, DeviceBuffer dst, size_t bytes) {
+        GRAPHLILY_CHECK(gl_buf_d2d(dst.ptr(), src.ptr(), bytes));
+        GRAPHLILY_CHECK(gl_sync());
+    }
+
+    // The fused overlay needed its unused ports tied off and a mode selected (reference :90-96);
+    // separate HIP kernels need neither.  Kept virtual so caller code that invokes them still links.
+    virtual void set_unused_args() {}
+    virtual void set_mode() {}
+
+    // The bitstream path is accepted and ignored.
+    void set_up_runtime(std::string /*xclbin_file_path*/) {
+        GRAPHLILY_CHECK(gl_init(device_));
+        set_unused_args();
+        set_mode();
+    }
+};
+
+}  // namespace module
+}  // namespace graphlily
+
+#endif  // GRAPHLILY_BASE_MODULE_H_

@@ -1,0 +1,160 @@
+// graphlily/module/spmspv_module.h -- SpMSpVModule on MI355X (reference module/spmspv_module.h:27-520).
+#ifndef GRAPHLILY_SPMSPV_MODULE_H_
+#define GRAPHLILY_SPMSPV_MODULE_H_
+
+#include <cstdint>
+#include <type_traits>
+#include <vector>
+
+#include "graphlily/global.h"
+#include "graphlily/io/data_formatter.h"
+#include "graphlily/io/data_loader.h"
+#include "graphlily/module/base_module.h"
+
+using graphlily::io::CSCMatrix;
+
+namespace graphlily {
+namespace module {
+
+template <typename matrix_data_t, typename vector_data_t, typename idx_val_t>
+class SpMSpVModule : public BaseModule {
+    static_assert(std::is_same<matrix_data_t, float>::value && std::is_same<vector_data_t, float>::value,
+                  "the MI355X backend computes in float (val_t = float)");
+    static_assert(sizeof(idx_val_t) == sizeof(gl_idx_val), "sparse element must be {uint32 index; float val}");
+    using aligned_dense_vec_t = std::vector<vector_data_t, aligned_allocator<vector_data_t>>;
+    using aligned_sparse_vec_t = std::vector<idx_val_t, aligned_allocator<idx_val_t>>;
+
+    MaskType mask_type_ = kNoMask;
+    SemiringType semiring_ = ArithmeticSemiring;
+    uint32_t out_buf_len_;
+    uint32_t row_begin_ = 0, row_end_ = 0;
+    bool sharded_ = false;
+    CSCMatrix<float> csc_matrix_float_;
+    gl_spmspv_plan plan_ = nullptr;
+    aligned_sparse_vec_t vector_, results_;
+    aligned_dense_vec_t mask_;
+
+public:
+    DeviceBuffer channel_packets_buf, channel_indptr_buf, channel_partptr_buf;  // unused: held by the plan
+    DeviceBuffer vector_buf;
+    DeviceBuffer mask_buf;
+    DeviceBuffer results_buf;
+    DeviceBuffer results_nnz_buf;  // unused: gl_sparse_nnz reads the head of results_buf directly
+
+    explicit SpMSpVModule(uint32_t out_buf_len) : BaseModule("overlay"), out_buf_len_(out_buf_len) {}
+    ~SpMSpVModule() override { gl_spmspv_plan_destroy(plan_); }
+
+    uint32_t get_num_rows() { return csc_matrix_float_.num_rows; }
+    uint32_t get_num_cols() { return csc_matrix_float_.num_cols; }
+    uint32_t get_nnz() { return csc_matrix_float_.adj_indptr[csc_matrix_float_.num_cols]; }
+
+    void set_semiring(SemiringType semiring) { semiring_ = semiring; }
+    void set_mask_type(MaskType mask_type) { mask_type_ = mask_type; }
+    void set_row_shard(uint32_t row_begin, uint32_t row_end) {
+        row_begin_ = row_begin;
+        row_end_ = row_end;
+        sharded_ = true;
+    }
+
+    void load_and_format_matrix(CSCMatrix<float> const &csc_matrix_float) {
+        csc_matrix_float_ = csc_matrix_float;
+        vector_.resize((size_t)get_num_cols() + 1);
+        results_.assign((size_t)get_num_rows() + 1, idx_val_t{0, 0});
+    }
+
+    void send_matrix_host_to_device() {
+        const CSCMatrix<float> &m = csc_matrix_float_;
+        gl_spmspv_plan_destroy(plan_);
+        plan_ = nullptr;
+        GRAPHLILY_CHECK(gl_spmspv_plan_create(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
+                                              m.adj_data.data(), sharded_ ? row_begin_ : 0, sharded_ ? row_end_ : m.num_rows));
+        results_buf = DeviceBuffer(sizeof(idx_val_t) * ((size_t)m.num_rows + 1));
+        results_buf.upload(results_.data(), sizeof(idx_val_t) * results_.size());
+    }
+
+    // the vector may be shorter than num_cols + 1; the device copy always has that many slots
+    void send_vector_host_to_device(aligned_sparse_vec_t &vector) {
+        std::copy(vector.begin(), vector.end(), vector_.begin());
+        vector_buf = DeviceBuffer(sizeof(idx_val_t) * vector_.size());
+        vector_buf.upload(vector_.data(), sizeof(idx_val_t) * vector_.size());
+    }
+
+    void send_mask_host_to_device(aligned_dense_vec_t &mask) {
+        mask_.assign(mask.begin(), mask.end());
+        mask_buf = DeviceBuffer(sizeof(float) * mask_.size());
+        mask_buf.upload(mask_.data(), sizeof(float) * mask_.size());
+    }
+
+    void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }      // extension
+    void bind_vector_buf(DeviceBuffer src_buf) { vector_buf = src_buf; }  // extension
+
+    void run() {
+        GRAPHLILY_CHECK(gl_spmspv_run(plan_, (const gl_idx_val *)vector_buf.ptr(),
+                                      mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
+                                      (gl_idx_val *)results_buf.ptr(), (int)semiring_.op, semiring_.zero, (int)mask_type_));
+        finish_();
+    }
+
+    aligned_sparse_vec_t send_vector_device_to_host() {
+        vector_buf.download(vector_.data(), sizeof(idx_val_t) * vector_.size());
+        return vector_;
+    }
+    aligned_dense_vec_t send_mask_device_to_host() {
+        mask_.resize(mask_buf.size() / sizeof(float));
+        mask_buf.download(mask_.data(), sizeof(float) * mask_.size());
+        return mask_;
+    }
+    aligned_sparse_vec_t send_results_device_to_host() {
+        results_buf.download(results_.data(), sizeof(idx_val_t) * results_.size());
+        return results_;
+    }
+
+    // the per-iteration device->host control read of the push loops (reference :239-242)
+    uint32_t get_results_nnz() {
+        uint32_t nnz = 0;
+        GRAPHLILY_CHECK(gl_sparse_nnz((const gl_idx_val *)results_buf.ptr(), &nnz));
+        return nnz;
+    }
+
+    // CPU reference (reference :445-520): dense result, (min,+) product saturating at FLOAT_INF, mask
+    // compared with semiring.zero and masked-off rows set to semiring.zero.
+    graphlily::aligned_dense_float_vec_t compute_reference_results(graphlily::aligned_sparse_float_vec_t &vector,
+                                                                    graphlily::aligned_dense_float_vec_t &mask) {
+        const CSCMatrix<float> &m = csc_matrix_float_;
+        const float zero = semiring_.zero;
+        graphlily::aligned_dense_float_vec_t y(m.num_rows, zero);
+        const uint32_t active = vector[0].index;
+        for (uint32_t k = 1; k <= active; k++) {
+            const float xv = vector[k].val;
+            const uint32_t col = vector[k].index;
+            for (uint32_t e = m.adj_indptr[col]; e < m.adj_indptr[col + 1]; e++) {
+                float &acc = y[m.adj_indices[e]];
+                const float a = m.adj_data[e];
+                if (semiring_.op == kMulAdd) {
+                    acc += a * xv;
+                } else if (semiring_.op == kLogicalAndOr) {
+                    acc = acc || (a && xv);
+                } else if (semiring_.op == kAddMin) {
+                    float t = (a > FLOAT_INF || xv > FLOAT_INF) ? FLOAT_INF : a + xv;
+                    if (t > FLOAT_INF) t = FLOAT_INF;
+                    acc = (acc < t) ? acc : t;
+                } else {
+                    std::cerr << "ERROR: [Module SpMSpV] Invalid semiring" << std::endl;
+                }
+            }
+        }
+        for (uint32_t i = 0; i < m.num_rows; i++) {
+            bool off = true;
+            if (mask_type_ == kNoMask) off = false;
+            else if (mask_type_ == kMaskWriteToOne) off = (mask[i] == zero);
+            else if (mask_type_ == kMaskWriteToZero) off = (mask[i] != zero);
+            if (off) y[i] = zero;
+        }
+        return y;
+    }
+};
+
+}  // namespace module
+}  // namespace graphlily
+
+#endif  // GRAPHLILY_SPMSPV_MODULE_H_

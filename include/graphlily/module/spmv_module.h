@@ -1,0 +1,152 @@
+// graphlily/module/spmv_module.h -- SpMVModule on MI355X (reference module/spmv_module.h:37-532).
+// Same public surface; load_and_format_matrix + send_matrix_host_to_device hand the CSR to
+// gl_spmv_plan_create (which builds the CDNA4 layout) and run() is gl_spmv_run.
+#ifndef GRAPHLILY_SPMV_MODULE_H_
+#define GRAPHLILY_SPMV_MODULE_H_
+
+#include <cstdint>
+#include <type_traits>
+#include <vector>
+
+#include "graphlily/global.h"
+#include "graphlily/io/data_formatter.h"
+#include "graphlily/io/data_loader.h"
+#include "graphlily/module/base_module.h"
+
+using graphlily::io::CSRMatrix;
+
+namespace graphlily {
+namespace module {
+
+template <typename matrix_data_t, typename vector_data_t>
+class SpMVModule : public BaseModule {
+    static_assert(std::is_same<matrix_data_t, float>::value && std::is_same<vector_data_t, float>::value,
+                  "the MI355X backend computes in float (val_t = float)");
+    using aligned_dense_vec_t = std::vector<vector_data_t, aligned_allocator<vector_data_t>>;
+
+    MaskType mask_type_ = kNoMask;
+    SemiringType semiring_ = ArithmeticSemiring;
+    uint32_t num_channels_, out_buf_len_, vec_buf_len_;  // FPGA geometry, accepted as hints
+    uint32_t row_begin_ = 0, row_end_ = 0;
+    bool sharded_ = false;
+    CSRMatrix<float> csr_matrix_float_;
+    gl_spmv_plan plan_ = nullptr;
+    aligned_dense_vec_t vector_, mask_, results_;
+
+public:
+    // device buffers (the reference's public cl::Buffer members, :83-86)
+    std::vector<DeviceBuffer> channel_packets_buf;  // unused: the formatted matrix lives in the plan
+    DeviceBuffer vector_buf;
+    DeviceBuffer mask_buf;
+    DeviceBuffer results_buf;
+
+    SpMVModule(uint32_t num_channels, uint32_t out_buf_len, uint32_t vec_buf_len)
+        : BaseModule("overlay"), num_channels_(num_channels), out_buf_len_(out_buf_len), vec_buf_len_(vec_buf_len) {}
+    ~SpMVModule() override { gl_spmv_plan_destroy(plan_); }
+
+    void set_semiring(SemiringType semiring) { semiring_ = semiring; }
+    void set_mask_type(MaskType mask_type) { mask_type_ = mask_type; }
+    // extension (multi-GPU): this device owns rows [row_begin, row_end)
+    void set_row_shard(uint32_t row_begin, uint32_t row_end) {
+        row_begin_ = row_begin;
+        row_end_ = row_end;
+        sharded_ = true;
+    }
+
+    uint32_t get_num_rows() { return csr_matrix_float_.num_rows; }
+    uint32_t get_num_cols() { return csr_matrix_float_.num_cols; }
+    uint32_t get_nnz() { return csr_matrix_float_.adj_indptr[csr_matrix_float_.num_rows]; }
+
+    void load_and_format_matrix(CSRMatrix<float> const &csr_matrix_float, bool /*skip_empty_rows*/) {
+        csr_matrix_float_ = csr_matrix_float;
+        vector_.resize(csr_matrix_float_.num_cols);
+        results_.assign(csr_matrix_float_.num_rows, 0);
+    }
+
+    void send_matrix_host_to_device() {
+        const CSRMatrix<float> &m = csr_matrix_float_;
+        gl_spmv_plan_destroy(plan_);
+        plan_ = nullptr;
+        GRAPHLILY_CHECK(gl_spmv_plan_create(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
+                                            m.adj_data.data(), sharded_ ? row_begin_ : 0, sharded_ ? row_end_ : m.num_rows));
+        results_buf = DeviceBuffer(sizeof(float) * m.num_rows);
+        GRAPHLILY_CHECK(gl_buf_fill_f32((float *)results_buf.ptr(), 0.0f, m.num_rows));
+        GRAPHLILY_CHECK(gl_sync());
+    }
+
+    void send_vector_host_to_device(aligned_dense_vec_t &vector) {
+        vector_.assign(vector.begin(), vector.end());
+        vector_.resize(get_num_cols());
+        vector_buf = DeviceBuffer(sizeof(float) * get_num_cols());
+        vector_buf.upload(vector_.data(), sizeof(float) * get_num_cols());
+    }
+
+    void send_mask_host_to_device(aligned_dense_vec_t &mask) {
+        mask_.assign(mask.begin(), mask.end());
+        mask_.resize(get_num_rows());
+        mask_buf = DeviceBuffer(sizeof(float) * get_num_rows());
+        mask_buf.upload(mask_.data(), sizeof(float) * get_num_rows());
+    }
+
+    void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }
+    void bind_vector_buf(DeviceBuffer src_buf) { vector_buf = src_buf; }    // extension
+    void bind_results_buf(DeviceBuffer src_buf) { results_buf = src_buf; }  // extension
+
+    void run() {
+        GRAPHLILY_CHECK(gl_spmv_run(plan_, (const float *)vector_buf.ptr(),
+                                    mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
+                                    (float *)results_buf.ptr(), (int)semiring_.op, semiring_.zero, (int)mask_type_));
+        finish_();
+    }
+
+    aligned_dense_vec_t send_vector_device_to_host() {
+        vector_.resize(get_num_cols());
+        vector_buf.download(vector_.data(), sizeof(float) * get_num_cols());
+        return vector_;
+    }
+    aligned_dense_vec_t send_mask_device_to_host() {
+        mask_.resize(get_num_rows());
+        mask_buf.download(mask_.data(), sizeof(float) * get_num_rows());
+        return mask_;
+    }
+    aligned_dense_vec_t send_results_device_to_host() {
+        results_.resize(get_num_rows());
+        results_buf.download(results_.data(), sizeof(float) * get_num_rows());
+        return results_;
+    }
+
+    // CPU reference the callers verify against (part of the reference's public API, :478-532).
+    // Sequential row loop with a float accumulator, like the reference.
+    graphlily::aligned_dense_float_vec_t compute_reference_results(graphlily::aligned_dense_float_vec_t &vector) {
+        const CSRMatrix<float> &m = csr_matrix_float_;
+        graphlily::aligned_dense_float_vec_t y(m.num_rows, semiring_.zero);
+        for (uint32_t r = 0; r < m.num_rows; r++) {
+            float acc = semiring_.zero;
+            for (uint32_t i = m.adj_indptr[r]; i < m.adj_indptr[r + 1]; i++) {
+                const float a = m.adj_data[i], b = vector[m.adj_indices[i]];
+                switch (semiring_.op) {
+                    case kMulAdd: acc += a * b; break;
+                    case kLogicalAndOr: acc = acc || (a && b); break;
+                    case kAddMin: acc = std::min(acc, a + b); break;
+                    default: std::cerr << "Invalid semiring" << std::endl; break;
+                }
+            }
+            y[r] = acc;
+        }
+        return y;
+    }
+
+    graphlily::aligned_dense_float_vec_t compute_reference_results(graphlily::aligned_dense_float_vec_t &vector,
+                                                                    graphlily::aligned_dense_float_vec_t &mask) {
+        graphlily::aligned_dense_float_vec_t y = compute_reference_results(vector);
+        const bool keep_zero = (mask_type_ == kMaskWriteToZero);   // every other type behaves as WriteToOne
+        for (size_t i = 0; i < y.size(); i++)
+            if ((mask[i] == 0) != keep_zero) y[i] = 0;
+        return y;
+    }
+};
+
+}  // namespace module
+}  // namespace graphlily
+
+#endif  // GRAPHLILY_SPMV_MODULE_H_

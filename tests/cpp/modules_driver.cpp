@@ -1,0 +1,174 @@
+// C++ parity driver for the header-only module layer (include/graphlily/module/*.h): every module is
+// run on the GPU through the C ABI and checked against its own compute_reference_results, following
+// the reference's tests/test_module_spmv_spmspv.cpp and tests/test_module_apply.cpp with seeded inputs.
+//   g++ -std=c++11 -I include tests/cpp/modules_driver.cpp -L graphlily_amd/lib -lgraphlily_hip
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "graphlily/app/module_collection.h"
+#include "graphlily/module/add_scalar_vector_dense_module.h"
+#include "graphlily/module/assign_vector_dense_module.h"
+#include "graphlily/module/assign_vector_sparse_module.h"
+#include "graphlily/module/spmspv_module.h"
+#include "graphlily/module/spmv_module.h"
+
+using namespace graphlily;
+typedef aligned_dense_float_vec_t fvec;
+
+static int failures = 0;
+
+static void verify(const fvec &ref, const fvec &got, const char *what, bool exact) {
+    bool ok = ref.size() == got.size();
+    for (size_t i = 0; ok && i < ref.size(); i++) {
+        if (exact) ok = ref[i] == got[i];
+        else ok = std::fabs(got[i] - ref[i]) <= 1e-4f * std::fmax(1.0f, std::fabs(ref[i]));   // reference eps, relative
+        if (!ok) printf("  %s: row %zu ref %g got %g\n", what, i, ref[i], got[i]);
+    }
+    printf("%-58s %s\n", what, ok ? "OK" : "FAIL");
+    failures += !ok;
+}
+
+static CSRMatrix<float> uniform_csr(uint32_t n, uint32_t deg, uint32_t seed) {
+    std::mt19937 rng(seed);
+    CSRMatrix<float> m;
+    m.num_rows = m.num_cols = n;
+    m.adj_indptr.push_back(0);
+    for (uint32_t r = 0; r < n; r++) {
+        std::vector<uint32_t> cols;
+        while (cols.size() < deg) {
+            uint32_t c = rng() % n;
+            if (std::find(cols.begin(), cols.end(), c) == cols.end()) cols.push_back(c);
+        }
+        std::sort(cols.begin(), cols.end());
+        for (uint32_t c : cols) { m.adj_indices.push_back(c); m.adj_data.push_back(1.0f / n); }
+        m.adj_indptr.push_back((uint32_t)m.adj_indices.size());
+    }
+    return m;
+}
+
+int main() {
+    std::mt19937 rng(42);
+    CSRMatrix<float> csr = uniform_csr(10000, 10, 7);
+    io::util_round_csr_matrix_dim(csr, num_hbm_channels * pack_size, pack_size);
+    const SemiringType tropical255 = {kAddMin, 0, UFIXED_INF};
+    const SemiringType sems[] = {ArithmeticSemiring, LogicalSemiring, tropical255, TropicalSemiring};
+    const char *sem_names[] = {"Arithmetic", "Logical", "Tropical(255)", "Tropical(FLOAT_INF)"};
+    const MaskType masks[] = {kNoMask, kMaskWriteToZero, kMaskWriteToOne};
+    const char *mask_names[] = {"NoMask", "WriteToZero", "WriteToOne"};
+    char name[128];
+
+    {   // SpMV
+        module::SpMVModule<val_t, val_t> spmv(num_hbm_channels, 1024, 256);
+        spmv.set_target("hw");
+        spmv.set_up_runtime("unused.xclbin");
+        spmv.load_and_format_matrix(csr, true);
+        spmv.send_matrix_host_to_device();
+        fvec x(csr.num_cols), mask(csr.num_rows);
+        for (auto &v : x) v = float(rng() % 2);
+        for (auto &v : mask) v = float(rng() % 2);
+        spmv.send_vector_host_to_device(x);
+        spmv.send_mask_host_to_device(mask);
+        for (int s = 0; s < 4; s++)
+            for (int k = 0; k < 3; k++) {
+                spmv.set_semiring(sems[s]);
+                spmv.set_mask_type(masks[k]);
+                spmv.run();
+                fvec ref = (masks[k] == kNoMask) ? spmv.compute_reference_results(x) : spmv.compute_reference_results(x, mask);
+                snprintf(name, sizeof name, "SpMV %s %s", sem_names[s], mask_names[k]);
+                verify(ref, spmv.send_results_device_to_host(), name, s != 0);
+            }
+    }
+    {   // SpMSpV
+        CSCMatrix<float> csc = io::csr2csc(csr);
+        module::SpMSpVModule<val_t, val_t, idx_val_t> sp(512);
+        sp.set_target("hw");
+        sp.set_up_runtime("unused.xclbin");
+        sp.load_and_format_matrix(csc);
+        sp.send_matrix_host_to_device();
+        const uint32_t nnz = csc.num_cols / 100;
+        aligned_sparse_float_vec_t vf(nnz + 1);
+        aligned_sparse_vec_t v(nnz + 1);
+        vf[0] = idx_float_t{nnz, 0};
+        for (uint32_t i = 0; i < nnz; i++) vf[i + 1] = idx_float_t{i * 100, float(rng() % 10) / 10};
+        for (uint32_t i = 0; i <= nnz; i++) v[i] = idx_val_t{vf[i].index, vf[i].val};
+        fvec mask(csc.num_rows);
+        for (auto &m : mask) m = float(rng() % 2);
+        sp.send_mask_host_to_device(mask);
+        sp.send_vector_host_to_device(v);
+        for (int s = 0; s < 3; s++)
+            for (int k = 0; k < 3; k++) {
+                sp.set_semiring(sems[s]);
+                sp.set_mask_type(masks[k]);
+                sp.run();
+                aligned_sparse_vec_t res = sp.send_results_device_to_host();
+                if (res[0].index != sp.get_results_nnz()) { printf("get_results_nnz mismatch\n"); failures++; }
+                fvec got = convert_sparse_vec_to_dense_vec<aligned_sparse_vec_t, fvec, float>(res, csc.num_rows, sems[s].zero);
+                snprintf(name, sizeof name, "SpMSpV %s %s", sem_names[s], mask_names[k]);
+                verify(sp.compute_reference_results(vf, mask), got, name, s != 0);
+            }
+    }
+    {   // apply modules
+        const uint32_t len = 128 * 100;
+        fvec in(len), mask(len), inout(len);
+        for (auto &v : in) v = float(rng() % 10) / 100;
+        for (auto &v : mask) v = float(rng() % 2);
+        for (auto &v : inout) v = float(rng() % 2);
+        module::eWiseAddModule<val_t> add;
+        add.set_up_runtime("unused.xclbin");
+        add.send_in_host_to_device(in);
+        add.allocate_out_buf(len);
+        add.run(len, 1);
+        verify(add.compute_reference_results(in, len, 1), add.send_out_device_to_host(), "eWiseAdd", true);
+
+        module::AssignVectorDenseModule<val_t> dense;
+        dense.set_up_runtime("unused.xclbin");
+        dense.set_mask_type(kMaskWriteToOne);
+        dense.send_mask_host_to_device(mask);
+        dense.send_inout_host_to_device(inout);
+        dense.run(len, 23);
+        fvec ref = inout;
+        dense.compute_reference_results(mask, ref, len, 23);
+        verify(ref, dense.send_inout_device_to_host(), "AssignVectorDense WriteToOne", true);
+
+        const uint32_t n = 8192, cnt = 819;
+        aligned_sparse_float_vec_t mf(cnt + 1);
+        aligned_sparse_vec_t ms(cnt + 1);
+        mf[0] = idx_float_t{cnt, 0};
+        for (uint32_t i = 0; i < cnt; i++) mf[i + 1] = idx_float_t{i * 10, float(rng() % 10)};
+        for (uint32_t i = 0; i <= cnt; i++) ms[i] = idx_val_t{mf[i].index, mf[i].val};
+        fvec io1(n), io2(n);
+        for (auto &v : io1) v = float(rng() % 10);
+        for (auto &v : io2) v = (rng() % 10 > 5) ? 5.0f : FLOAT_INF;
+        module::AssignVectorSparseModule<val_t, idx_val_t> bfs_mode(false);
+        bfs_mode.set_up_runtime("unused.xclbin");
+        bfs_mode.send_mask_host_to_device(ms);
+        bfs_mode.send_inout_host_to_device(io1);
+        bfs_mode.run(3);
+        ref = io1;
+        bfs_mode.compute_reference_results(mf, ref, 3.0f);
+        verify(ref, bfs_mode.send_inout_device_to_host(), "AssignVectorSparse (no new frontier)", true);
+
+        module::AssignVectorSparseModule<val_t, idx_val_t> sssp_mode(true);
+        sssp_mode.set_up_runtime("unused.xclbin");
+        sssp_mode.send_mask_host_to_device(ms);
+        sssp_mode.send_inout_host_to_device(io2);
+        sssp_mode.run();
+        ref = io2;
+        aligned_sparse_float_vec_t nf_ref;
+        sssp_mode.compute_reference_results(mf, ref, nf_ref);
+        verify(ref, sssp_mode.send_inout_device_to_host(), "AssignVectorSparse (new frontier) inout", true);
+        aligned_sparse_vec_t nf = sssp_mode.send_new_frontier_device_to_host();
+        fvec d_ref = convert_sparse_vec_to_dense_vec<aligned_sparse_float_vec_t, fvec, float>(nf_ref, n, 0);
+        fvec d_got = convert_sparse_vec_to_dense_vec<aligned_sparse_vec_t, fvec, float>(nf, n, 0);
+        verify(d_ref, d_got, "AssignVectorSparse (new frontier) frontier", true);
+
+        // copy_buffer_device_to_device + bind_* (reference TEST(CopyBufferBindBuffer, Basic))
+        dense.send_mask_host_to_device(mask);
+        dense.send_inout_host_to_device(inout);
+        dense.copy_buffer_device_to_device(dense.mask_buf, dense.inout_buf, sizeof(val_t) * len);
+        verify(mask, dense.send_inout_device_to_host(), "copy_buffer_device_to_device", true);
+    }
+    printf("%s\n", failures ? "SOME CHECKS FAILED" : "ALL CHECKS PASSED");
+    return failures ? 1 : 0;
+}
