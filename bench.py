@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--no-bfs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bfs-runs", type=int, default=5)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for debugging")
+    ap.add_argument("--same-gpu", action="store_true", help="debugging: put every rank on cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -64,11 +66,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
         comm = Comm(True)
     else:
         comm = Comm(None)
@@ -119,7 +126,7 @@ def main():
     wall = time.perf_counter() - t0
     kern_ms_total, launches = capi.prof_end()
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     ms_per_step = wall * 1e3 / args.steps
@@ -162,7 +169,7 @@ def main():
             "bound": "hbm", "kernel": "spmv_rbcs_kernel<MULADD,NOMASK>",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": _pmc_traffic(),
+            "traffic": _pmc_traffic(args.graph, world, args.scale),
             "bytes_per_launch": shard_bytes, "kernel_ms": round(kern_ms, 5), "launches": launches,
         },
     }
@@ -185,14 +192,18 @@ def main():
         dist.destroy_process_group()
 
 
-def _pmc_traffic():
+def _pmc_traffic(graph, world, scale):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written
-    by scripts/pmc_summary.py with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); null when
-    no counter run has been recorded for this build."""
+    by scripts/pmc_summary.py with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md).  Counters
+    cannot be read from inside the benchmark process, so this is the figure of the recorded run; it is
+    null unless that run was this workload (same graph, one GPU, full scale)."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get("spmv_rbcs_kernel_bytes_per_launch")
+            rec = json.load(f)
+        if rec.get("graph", "orkut") != graph or world != 1 or scale != 1.0:
+            return None
+        return rec.get("spmv_rbcs_kernel_bytes_per_launch")
     except Exception:
         return None
 
@@ -207,9 +218,13 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence):
     bfs.send_matrix_host_to_device()
     setup = time.time() - t0
     nnz = bfs.get_nnz()
+    # the reference starts from vertex 0 (bench_bfs.cpp:46); the stand-ins are randomly relabelled, so
+    # vertex 0 can be isolated -- then take the first vertex that has an edge
+    deg = np.diff(raw.adj_indptr.astype(np.int64))
+    source = 0 if deg[0] > 0 else int(np.argmax(deg > 0))
     res = {}
     for mode in ("pull_push", "pull"):
-        fn = (lambda: bfs.pull_push(0, iters, 0.001)) if mode == "pull_push" else (lambda: bfs.pull(0, iters))
+        fn = (lambda: bfs.pull_push(source, iters, 0.001)) if mode == "pull_push" else (lambda: bfs.pull(source, iters))
         d = fn()
         ts = []
         for _ in range(runs):
@@ -223,7 +238,7 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence):
                      "reached": int((d != 0).sum())}
         if mode == "pull_push":
             res[mode]["push_iterations"] = bfs.push_iterations_
-    res.update({"iters": iters, "nnz": nnz, "setup_s": round(setup, 2), "threshold": 0.001, "source": 0})
+    res.update({"iters": iters, "nnz": nnz, "setup_s": round(setup, 2), "threshold": 0.001, "source": source})
     return res
 
 

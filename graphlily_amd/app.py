@@ -422,7 +422,8 @@ class SSSP(_GraphApp):
             nnz = self.comm_sparse_count(candidates)            # app/sssp.h:221 (SpMSpV result size)
             if self.comm.distributed:
                 import torch
-                t = torch.tensor([nnz], dtype=torch.int64, device=distance.tensor.device)
+                gloo = self.comm.dist.get_backend(self.comm.group) == "gloo"
+                t = torch.tensor([nnz], dtype=torch.int64, device="cpu" if gloo else distance.tensor.device)
                 self.comm.dist.all_reduce(t, group=self.comm.group)
                 nnz = int(t.item())
             it += 1

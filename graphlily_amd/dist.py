@@ -69,7 +69,13 @@ class Comm:
             self._send = torch.zeros(mx, dtype=full.dtype, device=full.device)
             self._stage_key = key
         self._send[:lens[self.rank]].copy_(full[bounds[self.rank]:bounds[self.rank + 1]])
-        self.dist.all_gather_into_tensor(self._stage, self._send, group=self.group)
+        if full.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # debugging aid (two ranks on one GPU, no RCCL): stage the collective through the host
+            stage_h, send_h = self._stage.cpu(), self._send.cpu()
+            self.dist.all_gather_into_tensor(stage_h, send_h, group=self.group)
+            self._stage.copy_(stage_h)
+        else:
+            self.dist.all_gather_into_tensor(self._stage, self._send, group=self.group)
         torch.cat([self._stage[r * mx:r * mx + lens[r]] for r in range(W)], out=full[bounds[0]:bounds[W]])
 
     def all_gather_sparse(self, local, count, capacity_full, out):
@@ -80,7 +86,8 @@ class Comm:
         if not self.distributed:
             out[:count] = local[:count]
             return int(count)
-        cnt = torch.tensor([count], dtype=torch.int64, device=local.device)
+        cnt = torch.tensor([count], dtype=torch.int64,
+                           device="cpu" if self.dist.get_backend(self.group) == "gloo" else local.device)
         counts = [torch.zeros_like(cnt) for _ in range(self.world_size)]
         self.dist.all_gather(counts, cnt, group=self.group)
         counts = [int(c.item()) for c in counts]
@@ -92,9 +99,11 @@ class Comm:
         if mx == 0:
             return 0
         # pad to a common length so one all_gather_into_tensor moves everything
-        send = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        host = local.is_cuda and self.dist.get_backend(self.group) == "gloo"   # debugging aid, see above
+        cdev = "cpu" if host else local.device
+        send = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=cdev)
         send[:count] = local[:count]
-        recv = torch.empty((self.world_size * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        recv = torch.empty((self.world_size * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=cdev)
         self.dist.all_gather_into_tensor(recv, send, group=self.group)
         for r in range(self.world_size):
             pieces[r].copy_(recv[r * mx:r * mx + counts[r]])

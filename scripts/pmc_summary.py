@@ -34,7 +34,7 @@ def mean_counter(path, kernel_substr):
 
 def main():
     os.makedirs(DST, exist_ok=True)
-    out = {"tag": TAG}
+    out = {"tag": TAG, "graph": "orkut", "n_gpus": 1}
     stats = glob.glob(os.path.join(SRC, "*kernel_stats.csv")) + glob.glob(os.path.join(SRC, ".*kernel_stats.csv"))
     if stats:
         dst = os.path.join(DST, "%s_bench_kernel_stats.csv" % TAG)
