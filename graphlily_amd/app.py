@@ -74,6 +74,9 @@ class HipBackend:
     def copy(self, dst, src, nbytes):
         capi.copy_d2d(dst, src, nbytes)
 
+    def fill(self, buf, value, count):
+        capi.fill_f32(buf, value, count)
+
     def sparse_to_dense(self, sparse, dense, rng, zero, max_entries):
         capi.sparse_to_dense(sparse, dense, rng, zero, max_entries)
 
@@ -131,9 +134,14 @@ class _GraphApp(ModuleCollection):
         if self.comm.distributed:
             self.comm.all_gather_slices(buf.tensor, self.bounds_)
 
-    def _new_dense(self, host):
-        buf = self.backend.alloc(host.shape[0], np.float32)
-        self.backend.upload(buf, host.astype(np.float32))
+    def _new_dense(self, n, fill, source=None, source_value=None):
+        """Dense vector built on the device: a fill kernel plus (optionally) one 4-byte store, instead of
+        the reference's full host-side vector + upload (e.g. app/bfs.h:107-112)."""
+        B = self.backend
+        buf = B.alloc(n, np.float32)
+        B.fill(buf, float(fill), n)
+        if source is not None:
+            B.upload(B.view(buf, source, 1, 4), np.array([source_value], dtype=np.float32))
         return buf
 
     def _gather_sparse(self, local_buf, out_buf, n, head_val):
@@ -215,11 +223,8 @@ class BFS(_GraphApp):
 
     def pull(self, source, num_iterations):
         n = self.n_
-        inp = np.full(n, self.semiring_.zero, dtype=np.float32)
-        dist = np.zeros(n, dtype=np.float32)
-        inp[source] = 1
-        dist[source] = 1
-        vector, distance = self._new_dense(inp), self._new_dense(dist)
+        vector = self._new_dense(n, self.semiring_.zero, source, 1.0)
+        distance = self._new_dense(n, 0.0, source, 1.0)
         self._bind_pull(vector, distance)
         for it in range(1, num_iterations + 1):
             self._pull_iteration(vector, it)
@@ -230,9 +235,7 @@ class BFS(_GraphApp):
         B, n = self.backend, self.n_
         frontier = B.alloc(n + 1, capi.IDX_VAL)
         B.upload(B.view(frontier, 0, 2, 8), M.make_sparse_vec([source], [1.0]))
-        dist = np.zeros(n, dtype=np.float32)
-        dist[source] = 1
-        distance = self._new_dense(dist)
+        distance = self._new_dense(n, 0.0, source, 1.0)
         local = B.alloc(n + 1, capi.IDX_VAL)        # this rank's slice of the next frontier
         self.SpMSpV_.bind_vector_buf(frontier)
         self.SpMSpV_.bind_mask_buf(distance)
@@ -307,7 +310,7 @@ class PageRank(_GraphApp):
         B, n = self.backend, self.n_
         # rank starts at float(1.0 / n) over the PADDED n (app/pagerank.h:81), teleport is the float
         # expression (1 - damping) / n (:87)
-        vector = self._new_dense(np.full(n, np.float32(1.0 / n), dtype=np.float32))
+        vector = self._new_dense(n, np.float32(1.0 / n))
         teleport = np.float32(np.float32(1) - np.float32(damping)) / np.float32(n)
         results = B.alloc(n, np.float32)
         self.SpMV_.bind_vector_buf(vector)
@@ -358,9 +361,7 @@ class SSSP(_GraphApp):
         self.SpMSpV_.send_matrix_host_to_device()
 
     def _initial_distance(self, source):
-        d = np.full(self.n_, self.semiring_.zero, dtype=np.float32)
-        d[source] = 0
-        return d
+        return self._new_dense(self.n_, self.semiring_.zero, source, 0.0)
 
     def _pull_loop(self, vector, first_it, num_iterations):
         B, n = self.backend, self.n_
@@ -378,13 +379,13 @@ class SSSP(_GraphApp):
         return B.download(vector, np.float32, n)
 
     def pull(self, source, num_iterations):
-        return self._pull_loop(self._new_dense(self._initial_distance(source)), 1, num_iterations)
+        return self._pull_loop(self._initial_distance(source), 1, num_iterations)
 
     def _start_push(self, source):
         B, n = self.backend, self.n_
         frontier = B.alloc(n + 1, capi.IDX_VAL)
         B.upload(B.view(frontier, 0, 2, 8), M.make_sparse_vec([source], [0.0]))
-        distance = self._new_dense(self._initial_distance(source))
+        distance = self._initial_distance(source)
         candidates = B.alloc(n + 1, capi.IDX_VAL)    # SpMSpV result of this shard
         self.SpMSpV_.bind_vector_buf(frontier)
         self.SpMSpV_.bind_mask_buf(distance)

@@ -35,7 +35,7 @@ EXPORTS = [
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
     "gl_assign_sparse_new_frontier", "gl_sparse_to_dense",
-    "gl_npz_csr_open", "gl_npz_csr_read", "gl_npz_csr_close",
+    "gl_host_csr2csc", "gl_npz_csr_open", "gl_npz_csr_read", "gl_npz_csr_close",
 ]
 
 
@@ -83,6 +83,7 @@ def lib():
         "gl_ewise_add": [vp, vp, u32, f32], "gl_assign_dense": [vp, vp, u32, f32, i32],
         "gl_assign_sparse": [vp, vp, f32, u32], "gl_assign_sparse_new_frontier": [vp, vp, vp, u32],
         "gl_sparse_to_dense": [vp, vp, u32, f32, u32],
+        "gl_host_csr2csc": [u32, u32, vp, vp, vp, vp, vp, vp],
         "gl_npz_csr_open": [ctypes.c_char_p, P(vp), P(u32), P(u32), P(u64)],
         "gl_npz_csr_read": [vp, vp, vp, vp], "gl_npz_csr_close": [vp],
     }
@@ -303,6 +304,20 @@ def sparse_to_dense(sparse, dense, rng, zero, max_entries):
 
 def fill_f32(buf, value, count):
     check(lib().gl_buf_fill_f32(_p(buf), float(value), int(count)))
+
+
+def host_csr2csc(num_rows, num_cols, indptr, indices, data):
+    """-> (csc_indptr, csc_indices, csc_data); host only."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.uint32)
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    nnz = int(indptr[num_rows])
+    o_indptr = np.empty(num_cols + 1, dtype=np.uint32)
+    o_indices = np.empty(nnz, dtype=np.uint32)
+    o_data = np.empty(nnz, dtype=np.float32)
+    check(lib().gl_host_csr2csc(num_rows, num_cols, _np_ptr(indptr), _np_ptr(indices), _np_ptr(data),
+                                ctypes.c_void_p(o_indptr.ctypes.data), _np_ptr(o_indices), _np_ptr(o_data)))
+    return o_indptr, o_indices, o_data
 
 
 def npz_load_csr(path):

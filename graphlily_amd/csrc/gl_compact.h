@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void compact_count_kernel(Src src, uint32_t *_
 
 // single block: counts[] -> exclusive offsets in place; out[0] = {total, head_val}
 static __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__restrict__ counts, uint32_t nblocks,
-                                                            gl_idx_val *__restrict__ out, float head_val) {
+                                                            gl_idx_val *__restrict__ out, float head_val,
+                                                            uint32_t *__restrict__ reset_word) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -91,6 +92,7 @@ static __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__r
     if (threadIdx.x == 0) {
         out[0].index = carry_s;
         out[0].val = head_val;
+        if (reset_word) *reset_word = 0u;   // e.g. the SpMSpV chunk-queue counter, ready for the next run
     }
 }
 
@@ -121,12 +123,12 @@ __global__ __launch_bounds__(256) void compact_write_kernel(Src src, const uint3
 // Runs the three phases for at most `max_items` candidates (host-side bound for the grid).
 template <typename Src>
 static int run_compaction(Src src, uint32_t max_items, uint32_t *d_counts, gl_idx_val *d_out, float head_val,
-                          hipStream_t s) {
+                          hipStream_t s, uint32_t *d_reset_word = nullptr) {
     uint32_t nblocks = cdiv(max_items, kCompactChunk);
     if (nblocks == 0) nblocks = 1;
     compact_count_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts);
     GL_LAUNCH_CHECK();
-    compact_scan_kernel<<<1, 1024, 0, s>>>(d_counts, nblocks, d_out, head_val);
+    compact_scan_kernel<<<1, 1024, 0, s>>>(d_counts, nblocks, d_out, head_val, d_reset_word);
     GL_LAUNCH_CHECK();
     compact_write_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out);
     GL_LAUNCH_CHECK();

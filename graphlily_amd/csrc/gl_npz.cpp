@@ -8,6 +8,11 @@
 // int64 index arrays (scipy switches to them for very large matrices) and
 // float64 data by narrowing.
 #include <zlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include <algorithm>
 
 #include <cstdint>
 #include <cstdio>
@@ -215,6 +220,56 @@ static bool to_u32(const Npy &a, size_t n, uint32_t *dst, std::string &err) {
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// io::csr2csc (io/data_loader.h:108-144) as a parallel counting sort: threads own contiguous row
+// ranges, so inside a column entries keep ascending row order exactly like the reference's loop.
+extern "C" int gl_host_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices,
+                               const float *data, uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data) {
+    GL_ARG(indptr != nullptr && csc_indptr != nullptr);
+    const uint64_t nnz = indptr[num_rows];
+    GL_ARG(nnz == 0 || (indices != nullptr && data != nullptr && csc_indices != nullptr && csc_data != nullptr));
+    for (uint64_t i = 0; i < nnz; i++)
+        if (indices[i] >= num_cols)
+            return gl::set_error(GL_ERR_INVALID_ARG, "gl_host_csr2csc: column index %u out of range (num_cols %u)", indices[i], num_cols);
+    int T = 1;
+#ifdef _OPENMP
+    T = std::min(omp_get_max_threads(), 16);
+#endif
+    if (nnz < (1u << 20)) T = 1;
+    // row range of thread t: balanced by nnz
+    std::vector<uint32_t> rb(T + 1, num_rows);
+    rb[0] = 0;
+    for (int t = 1; t < T; t++) {
+        const uint64_t want = nnz * t / T;
+        rb[t] = (uint32_t)(std::lower_bound(indptr, indptr + num_rows + 1, (uint32_t)want) - indptr);
+        if (rb[t] < rb[t - 1]) rb[t] = rb[t - 1];
+    }
+    std::vector<std::vector<uint32_t>> cnt(T, std::vector<uint32_t>(num_cols, 0));
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+    for (int t = 0; t < T; t++)
+        for (uint64_t i = indptr[rb[t]]; i < indptr[rb[t + 1]]; i++) cnt[t][indices[i]]++;
+    // column-major prefix over (column, thread): thread t's entries of column c start at off[t][c]
+    uint64_t run = 0;
+    for (uint32_t c = 0; c < num_cols; c++) {
+        csc_indptr[c] = (uint32_t)run;
+        for (int t = 0; t < T; t++) {
+            const uint32_t k = cnt[t][c];
+            cnt[t][c] = (uint32_t)run;
+            run += k;
+        }
+    }
+    csc_indptr[num_cols] = (uint32_t)run;
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+    for (int t = 0; t < T; t++)
+        for (uint32_t r = rb[t]; r < rb[t + 1]; r++)
+            for (uint64_t i = indptr[r]; i < indptr[r + 1]; i++) {
+                const uint32_t dst = cnt[t][indices[i]]++;
+                csc_indices[dst] = r;
+                csc_data[dst] = data[i];
+            }
+    return GL_OK;
+}
 
 struct gl_npz_csr_s {
     std::map<std::string, Npy> arrays;

@@ -10,12 +10,15 @@
 // any contiguous run of a column coalesced).
 //
 // Kernels per run:
-//  1. scatter: a workgroup takes 256 entries of the sparse input vector, stages
-//     (column start, degree prefix, value) in LDS, and its threads then walk the
-//     concatenated work list -- a binary search in LDS maps a work item to its
-//     column -- so the non-zeros of the active columns are spread evenly over
-//     the lanes whatever the degree mix.  Columns above a degree threshold are
-//     parked in a hub list and processed by the whole grid (kernel 1b).
+//  1. scatter: a workgroup takes 256 entries of the sparse input vector and
+//     buckets them in LDS by column length:
+//       long columns (>= 4096 non-zeros) are cut into 4096-entry chunks that go
+//         to a device-wide work queue (kernel 1b spreads them over the grid, so
+//         one hub vertex in the frontier does not serialise a workgroup);
+//       the others become wave tasks of <= 64 consecutive entries; an exclusive
+//         prefix of the task counts lives in LDS and each wavefront maps a task
+//         to its column with a wave-uniform binary search -- one search per 64
+//         non-zeros, coalesced 512-byte reads of the column's {row,val} stream.
 //     Products go into a dense accumulator with atomics: float add for (+,*),
 //     plain store of 1 for (||,&&), ordered-integer min for (min,+).
 //  2. ordered compaction of the accumulator into the (index, value) list with
@@ -37,22 +40,25 @@ struct gl_spmspv_plan_s {
     float acc_fill = 0.0f;
     bool acc_valid = false;        // d_acc is known to be all == acc_fill
     uint32_t *d_counts = nullptr;  // compaction workspace
-    uint32_t *d_hub = nullptr;     // [0] = count, then hub entry slots (index into the input vector)
-    uint32_t hub_capacity = 0;
+    uint32_t *d_queue_count = nullptr;  // [0] = chunks queued by the current run
+    uint4 *d_queue = nullptr;           // chunk descriptors of long columns
+    uint32_t queue_capacity = 0;
     uint64_t device_bytes = 0;
 };
 
 namespace gl {
 
-constexpr uint32_t kHubDegree = 8192;  // columns at least this long are processed by the whole grid
+constexpr uint32_t kBigColumn = 4096;  // columns at least this long are cut into queue chunks
+constexpr uint32_t kChunk = 4096;      // entries per queue chunk (one workgroup pass in kernel 1b)
 
 struct ScatterArgs {
     const uint32_t *indptr;
     const uint2 *stream;
     const gl_idx_val *vec;
     float *acc;
-    uint32_t *hub;
-    uint32_t hub_capacity;
+    uint32_t *queue_count;   // [0] = number of queued chunks (reset by the compaction scan)
+    uint4 *queue;            // {first entry, count, value bits, -}
+    uint32_t queue_capacity;
     uint32_t row_begin;
     uint32_t num_cols;
 };
@@ -84,83 +90,109 @@ __device__ __forceinline__ void scatter_one(float *acc, uint32_t row, float a, f
     }
 }
 
+// exclusive prefix of v over the 256 threads of the block; total broadcast through s_tot
+__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t *s_wave, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
+        uint32_t up = __shfl_up(incl, dlt);
+        if (lane >= dlt) incl += up;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t c = s_wave[k];
+        if (k < w) before += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return before + incl - v;
+}
+
 template <int OP>
 __global__ __launch_bounds__(256) void spmspv_scatter_kernel(ScatterArgs a) {
     __shared__ uint32_t s_start[256];
-    __shared__ uint32_t s_off[257];  // exclusive degree prefix, s_off[256] = total
+    __shared__ uint32_t s_deg[256];
+    __shared__ uint32_t s_task[257];  // exclusive prefix of wave-task counts, s_task[256] = total
     __shared__ float s_val[256];
     __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_qbase;
     const uint32_t vnnz = a.vec[0].index;
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     for (uint32_t batch = blockIdx.x * 256u; batch < vnnz; batch += gridDim.x * 256u) {
         const uint32_t e = batch + threadIdx.x;
         uint32_t start = 0, deg = 0;
         float xv = 0.0f;
         if (e < vnnz) {
-            gl_idx_val iv = a.vec[1u + e];
+            const gl_idx_val iv = a.vec[1u + e];
             if (iv.index < a.num_cols) {
                 start = a.indptr[iv.index];
                 deg = a.indptr[iv.index + 1u] - start;
                 xv = iv.val;
-                if (deg >= kHubDegree) {
-                    uint32_t slot = atomicAdd(&a.hub[0], 1u);
-                    if (slot < a.hub_capacity) {
-                        a.hub[1u + slot] = e;
-                        deg = 0;  // handled by the hub kernel
-                    }
-                }
             }
         }
-        // block-wide exclusive scan of deg
-        uint32_t incl = deg;
-#pragma unroll
-        for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
-            uint32_t up = __shfl_up(incl, dlt);
-            if (lane >= dlt) incl += up;
+        const bool big = deg >= kBigColumn;
+        // long columns -> queue chunks (one atomic per workgroup reserves the slots)
+        uint32_t nchunks = big ? (deg + kChunk - 1u) / kChunk : 0u, qtotal;
+        const uint32_t qoff = block_exclusive_256(nchunks, s_wave, &qtotal);
+        if (qtotal) {
+            if (threadIdx.x == 0) s_qbase = atomicAdd(a.queue_count, qtotal);
+            __syncthreads();
+            const uint32_t qb = s_qbase + qoff;
+            for (uint32_t c = 0; c < nchunks; c++) {
+                if (qb + c < a.queue_capacity)
+                    a.queue[qb + c] = make_uint4(start + c * kChunk, min(kChunk, deg - c * kChunk), __float_as_uint(xv), 0u);
+            }
         }
-        if (lane == 63) s_wave[w] = incl;
-        __syncthreads();
-        uint32_t before = 0;
-        for (uint32_t k = 0; k < w; k++) before += s_wave[k];
+        // the rest -> wave tasks of <= 64 entries
+        const uint32_t ntasks = big ? 0u : (deg + 63u) >> 6;
+        uint32_t ttotal;
+        const uint32_t toff = block_exclusive_256(ntasks, s_wave, &ttotal);
         s_start[threadIdx.x] = start;
+        s_deg[threadIdx.x] = big ? 0u : deg;
         s_val[threadIdx.x] = xv;
-        s_off[threadIdx.x] = before + incl - deg;
-        if (threadIdx.x == 255) s_off[256] = before + incl;
+        s_task[threadIdx.x] = toff;
+        if (threadIdx.x == 255) s_task[256] = ttotal;
         __syncthreads();
-        const uint32_t total = s_off[256];
-        for (uint32_t wi = threadIdx.x; wi < total; wi += 256u) {
-            // largest j with s_off[j] <= wi
+        for (uint32_t t = wave; t < ttotal; t += 4u) {
+            // largest j with s_task[j] <= t (wave-uniform: every lane reads the same words)
             uint32_t lo = 0, hi = 255;
 #pragma unroll
             for (int it = 0; it < 8; it++) {
-                uint32_t mid = (lo + hi + 1u) >> 1;
-                if (s_off[mid] <= wi) lo = mid; else hi = mid - 1u;
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (s_task[mid] <= t) lo = mid; else hi = mid - 1u;
             }
-            const uint2 rv = a.stream[s_start[lo] + (wi - s_off[lo])];
-            scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), s_val[lo]);
+            const uint32_t j = __builtin_amdgcn_readfirstlane(lo);
+            const uint32_t item = ((t - s_task[j]) << 6) + lane;
+            if (item < s_deg[j]) {
+                const uint2 rv = load_stream_nt(a.stream + s_start[j] + item);
+                scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), s_val[j]);
+            }
         }
         __syncthreads();
     }
 }
 
-// hub columns: every block takes a strided share of each parked column
+// queued chunks of long columns: one workgroup pass (256 threads x 16 coalesced entries) per chunk
 template <int OP>
-__global__ __launch_bounds__(256) void spmspv_hub_kernel(ScatterArgs a) {
-    uint32_t nhub = a.hub[0];
-    if (nhub > a.hub_capacity) nhub = a.hub_capacity;
-    for (uint32_t h = 0; h < nhub; h++) {
-        const gl_idx_val iv = a.vec[1u + a.hub[1u + h]];
-        const uint32_t start = a.indptr[iv.index];
-        const uint32_t deg = a.indptr[iv.index + 1u] - start;
-        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < deg; k += gridDim.x * 256u) {
-            const uint2 rv = a.stream[start + k];
-            scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), iv.val);
+__global__ __launch_bounds__(256) void spmspv_queue_kernel(ScatterArgs a) {
+    uint32_t nq = a.queue_count[0];
+    if (nq > a.queue_capacity) nq = a.queue_capacity;
+    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+        const uint4 c = a.queue[q];
+        const float xv = __uint_as_float(c.z);
+        for (uint32_t k = threadIdx.x; k < c.y; k += 256u) {
+            const uint2 rv = load_stream_nt(a.stream + c.x + k);
+            scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), xv);
         }
     }
 }
-
-__global__ void hub_reset_kernel(uint32_t *hub) { hub[0] = 0; }
 
 // compaction source over the dense accumulator
 template <int MASK>
@@ -189,11 +221,9 @@ struct AccSource {
 
 template <int OP>
 static int launch_scatter(const ScatterArgs &a, uint32_t grid, hipStream_t s) {
-    hub_reset_kernel<<<1, 1, 0, s>>>(a.hub);
-    GL_LAUNCH_CHECK();
     spmspv_scatter_kernel<OP><<<grid, 256, 0, s>>>(a);
     GL_LAUNCH_CHECK();
-    spmspv_hub_kernel<OP><<<1024, 256, 0, s>>>(a);
+    spmspv_queue_kernel<OP><<<(unsigned)ctx().num_cus * 8u, 256, 0, s>>>(a);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
@@ -234,7 +264,8 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     p->row_end = row_end;
     p->nnz = stream.size();
     const uint32_t nrows = row_end - row_begin;
-    p->hub_capacity = 4096;
+    // every queued column has >= kBigColumn entries and yields ceil(deg / kChunk) chunks
+    p->queue_capacity = (uint32_t)(stream.size() / gl::kBigColumn + 1);
     auto fail = [&](hipError_t e) {
         gl_spmspv_plan_destroy(p);
         return gl::set_error(GL_ERR_HIP, "gl_spmspv_plan_create: %s", hipGetErrorString(e));
@@ -243,15 +274,17 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     size_t b_indptr = indptr.size() * sizeof(uint32_t), b_stream = stream.size() * sizeof(uint2);
     size_t b_acc = (size_t)(nrows ? nrows : 1) * sizeof(float);
     size_t b_counts = (size_t)(gl::cdiv(nrows, gl::kCompactChunk) + 1) * sizeof(uint32_t);
-    size_t b_hub = (size_t)(p->hub_capacity + 1) * sizeof(uint32_t);
+    size_t b_queue = (size_t)p->queue_capacity * sizeof(uint4);
     if ((e = hipMalloc((void **)&p->d_indptr, b_indptr)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_stream, b_stream ? b_stream : 16)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_acc, b_acc)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_counts, b_counts)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void **)&p->d_hub, b_hub)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_queue, b_queue)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_queue_count, 16)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(p->d_queue_count, 0, 16)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(p->d_indptr, indptr.data(), b_indptr, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if (b_stream && (e = hipMemcpy(p->d_stream, stream.data(), b_stream, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
-    p->device_bytes = b_indptr + b_stream + b_acc + b_counts + b_hub;
+    p->device_bytes = b_indptr + b_stream + b_acc + b_counts + b_queue;
     *plan = p;
     return GL_OK;
 }
@@ -262,7 +295,8 @@ int gl_spmspv_plan_destroy(gl_spmspv_plan p) {
     (void)hipFree(p->d_stream);
     (void)hipFree(p->d_acc);
     (void)hipFree(p->d_counts);
-    (void)hipFree(p->d_hub);
+    (void)hipFree(p->d_queue);
+    (void)hipFree(p->d_queue_count);
     delete p;
     return GL_OK;
 }
@@ -297,8 +331,9 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
     a.stream = p->d_stream;
     a.vec = d_vector;
     a.acc = p->d_acc;
-    a.hub = p->d_hub;
-    a.hub_capacity = p->hub_capacity;
+    a.queue_count = p->d_queue_count;
+    a.queue = p->d_queue;
+    a.queue_capacity = p->queue_capacity;
     a.row_begin = p->row_begin;
     a.num_cols = p->num_cols;
     uint32_t grid = gl::cdiv(p->num_cols, 256);
@@ -316,15 +351,15 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
     switch (mask_type) {
         case GL_NOMASK: {
             gl::AccSource<GL_NOMASK> src{p->d_acc, d_mask, nrows, p->row_begin, zero};
-            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s);
+            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count);
         }
         case GL_MASK_WRITETOZERO: {
             gl::AccSource<GL_MASK_WRITETOZERO> src{p->d_acc, d_mask, nrows, p->row_begin, zero};
-            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s);
+            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count);
         }
         default: {
             gl::AccSource<GL_MASK_WRITETOONE> src{p->d_acc, d_mask, nrows, p->row_begin, zero};
-            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s);
+            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count);
         }
     }
 }

@@ -48,18 +48,11 @@ def load_csr_matrix_from_float_npz(csr_float_npz_path):
 
 
 def csr2csc(csr_matrix):
-    """Transpose by a stable sort on the column index, so rows inside a column stay ascending --
-    the order the reference's counting sort produces (io/data_loader.h:131-139)."""
-    nnz = csr_matrix.nnz
-    indices = csr_matrix.adj_indices[:nnz]
-    order = np.argsort(indices, kind="stable")
-    row_of = np.repeat(np.arange(csr_matrix.num_rows, dtype=np.uint32),
-                       np.diff(csr_matrix.adj_indptr.astype(np.int64)))
-    counts = np.bincount(indices, minlength=csr_matrix.num_cols)
-    indptr = np.zeros(csr_matrix.num_cols + 1, dtype=np.uint32)
-    np.cumsum(counts, out=indptr[1:], dtype=np.uint64)
-    return CSCMatrix(csr_matrix.num_rows, csr_matrix.num_cols, csr_matrix.adj_data[:nnz][order],
-                     row_of[order], indptr)
+    """Transpose (io/data_loader.h:108-144); rows inside a column stay ascending.  Done natively
+    (gl_host_csr2csc, parallel counting sort): the numpy formulation took 18 s on 212 M non-zeros."""
+    indptr, indices, data = capi.host_csr2csc(csr_matrix.num_rows, csr_matrix.num_cols, csr_matrix.adj_indptr,
+                                              csr_matrix.adj_indices, csr_matrix.adj_data)
+    return CSCMatrix(csr_matrix.num_rows, csr_matrix.num_cols, data, indices, indptr)
 
 
 def util_round_csr_matrix_dim(csr_matrix, row_divisor, col_divisor):

@@ -167,6 +167,11 @@ int gl_assign_sparse_new_frontier(const gl_idx_val *d_mask, float *d_inout,
 int gl_sparse_to_dense(const gl_idx_val *d_sparse, float *d_dense, uint32_t range, float zero,
                        uint32_t max_entries);
 
+/* csr2csc (io/data_loader.h:108-144) on the host, parallel; rows inside a column stay ascending.
+ * Output arrays: csc_indptr[num_cols+1], csc_indices[nnz], csc_data[nnz].  Needs no GPU. */
+int gl_host_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices,
+                    const float *data, uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data);
+
 /* scipy-npz CSR loader: replaces cnpy::npz_load in
  * load_csr_matrix_from_float_npz (io/data_loader.h:51-70).  Two-call protocol:
  * gl_npz_csr_open parses the file and reports sizes, gl_npz_csr_read copies

@@ -189,6 +189,9 @@ class CpuBackend:
         k = nbytes // dst.tensor.element_size()
         dst.tensor[:k].copy_(src.tensor[:k])
 
+    def fill(self, buf, value, count):
+        buf.tensor[:count] = float(value)
+
     def sparse_to_dense(self, sparse, dense, rng, zero, max_entries):
         dense.np()[:rng] = O.convert_sparse_vec_to_dense_vec(sparse.np().copy(), rng, zero)
 

@@ -172,9 +172,12 @@ def test_sssp_preprocess_matches_literal_replay(seed):
 
 
 # ---------------------------------------------------------------- product host formatters vs oracle
-@pytest.mark.parametrize("gen", ["uniform", "rmat"])
+@pytest.mark.parametrize("gen", ["uniform", "rmat", "rmat_2M"])
 def test_product_formatters_match_oracle(gen):
-    m = datasets.uniform(500, 7, seed=3) if gen == "uniform" else datasets.rmat(3000, 40000, seed=5)
+    if gen == "rmat_2M":      # > 1 Mi non-zeros: the multi-threaded path of gl_host_csr2csc
+        m = datasets.rmat(100000, 2200000, seed=8)
+    else:
+        m = datasets.uniform(500, 7, seed=3) if gen == "uniform" else datasets.rmat(3000, 40000, seed=5)
     m.adj_data = np.random.default_rng(1).random(m.nnz, dtype=np.float32)
     om = to_oracle(m)
     io.util_round_csr_matrix_dim(m, 128, 128)
