@@ -30,6 +30,7 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32",
+    "gl_host_alloc", "gl_host_free",
     "gl_spmv_plan_create", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_run",
     "gl_prof_begin", "gl_prof_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
@@ -69,6 +70,7 @@ def lib():
     sigs = {
         "gl_init": [i32], "gl_device_count": [P(i32)], "gl_set_stream": [vp], "gl_reset_stream": [], "gl_sync": [],
         "gl_buf_alloc": [P(vp), ctypes.c_size_t], "gl_buf_free": [vp],
+        "gl_host_alloc": [P(vp), ctypes.c_size_t], "gl_host_free": [vp],
         "gl_buf_h2d": [vp, vp, ctypes.c_size_t], "gl_buf_d2h": [vp, vp, ctypes.c_size_t],
         "gl_buf_d2d": [vp, vp, ctypes.c_size_t], "gl_buf_fill_f32": [vp, f32, ctypes.c_size_t],
         "gl_spmv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
@@ -130,6 +132,42 @@ def sync():
     check(lib().gl_sync())
 
 
+class _PinnedBlock:
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p(0)
+        check(lib().gl_host_alloc(ctypes.byref(p), nbytes))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().gl_host_free(ctypes.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(count, dtype):
+    """numpy array in page-locked host memory (freed with the array): read-backs into it run at the
+    full PCIe rate instead of the pageable-memory rate."""
+    dtype = np.dtype(dtype)
+    blk = _PinnedBlock(max(count * dtype.itemsize, 4))
+    raw = (ctypes.c_char * blk.nbytes).from_address(blk.ptr)
+    arr = np.frombuffer(raw, dtype=dtype, count=count)
+    arr = arr.view(_OwnedArray)
+    arr._owner = (raw, blk)
+    return arr
+
+
+class _OwnedArray(np.ndarray):
+    """ndarray that keeps its pinned block alive (views inherit the reference through .base)."""
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        if obj is not None and getattr(obj, "_owner", None) is not None:
+            self._owner = obj._owner
+
+
+
 class DeviceBuffer:
     """A device allocation handle: the role cl::Buffer plays in the reference's module API
     (shareable between modules via bind_*_buf).  Either owns memory from gl_buf_alloc or
@@ -162,11 +200,17 @@ class DeviceBuffer:
         assert offset_bytes + arr.nbytes <= self.nbytes, "host array larger than device buffer"
         check(lib().gl_buf_h2d(ctypes.c_void_p(self.ptr + offset_bytes), _np_ptr(arr), arr.nbytes))
 
-    def read(self, dtype, count=None, offset_bytes=0):
+    def read(self, dtype, count=None, offset_bytes=0, out=None):
+        """Blocking device->host copy.  `out` may be a preallocated array (e.g. pinned_empty(), which
+        makes the copy run at the full PCIe rate; pinning is slow, so callers allocate it once)."""
         dtype = np.dtype(dtype)
         if count is None:
             count = (self.nbytes - offset_bytes) // dtype.itemsize
-        out = np.empty(count, dtype=dtype)
+        if out is None:
+            out = np.empty(count, dtype=dtype)
+        else:
+            assert out.dtype == dtype and out.shape[0] >= count and out.flags["C_CONTIGUOUS"]
+            out = out[:count]
         assert offset_bytes + out.nbytes <= self.nbytes
         check(lib().gl_buf_d2h(_np_ptr(out), ctypes.c_void_p(self.ptr + offset_bytes), out.nbytes))
         return out

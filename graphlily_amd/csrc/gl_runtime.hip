@@ -167,6 +167,20 @@ int gl_buf_d2d(void *d_dst, const void *d_src, size_t bytes) {
     return GL_OK;
 }
 
+int gl_host_alloc(void **h_ptr, size_t bytes) {
+    GL_REQUIRE_INIT();
+    GL_ARG(h_ptr != nullptr);
+    *h_ptr = nullptr;
+    GL_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 4, hipHostMallocDefault));
+    return GL_OK;
+}
+
+int gl_host_free(void *h_ptr) {
+    GL_REQUIRE_INIT();
+    if (h_ptr) GL_HIP(hipHostFree(h_ptr));
+    return GL_OK;
+}
+
 int gl_buf_fill_f32(float *d_dst, float value, size_t count) {
     GL_REQUIRE_INIT();
     if (count == 0) return GL_OK;

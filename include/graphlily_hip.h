@@ -75,6 +75,10 @@ int gl_buf_h2d(void *d_dst, const void *h_src, size_t bytes);   /* blocking */
 int gl_buf_d2h(void *h_dst, const void *d_src, size_t bytes);   /* blocking */
 int gl_buf_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async    */
 int gl_buf_fill_f32(float *d_dst, float value, size_t count);   /* async    */
+/* page-locked host memory for result read-back at full PCIe rate (the reference's host mirrors are
+ * 4 KiB-aligned for the same reason, xcl2.hpp:61-76) */
+int gl_host_alloc(void **h_ptr, size_t bytes);
+int gl_host_free(void *h_ptr);
 
 /* --------------------------------------------------------------------- SpMV
  * gl_spmv_plan_create replaces SpMVModule::load_and_format_matrix +

@@ -185,6 +185,9 @@ class CpuBackend:
     def download(self, buf, dtype, count):
         return buf.np()[:count].copy()
 
+    def download_result(self, buf, count):
+        return self.download(buf, np.float32, count)
+
     def copy(self, dst, src, nbytes):
         k = nbytes // dst.tensor.element_size()
         dst.tensor[:k].copy_(src.tensor[:k])

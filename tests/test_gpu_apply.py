@@ -122,3 +122,13 @@ def test_sparse_to_dense(gpu):
     capi.sparse_to_dense(cap, dense, n, 255.0, n)
     capi.sync()
     assert np.array_equal(dense.read(np.float32), O.convert_sparse_vec_to_dense_vec(sv, n, 255.0))
+
+
+def test_pinned_readback(gpu):
+    """gl_host_alloc: page-locked destination for device->host copies (DeviceBuffer.read(out=...))."""
+    n = 300000
+    src = np.arange(n, dtype=np.float32)
+    buf = capi.DeviceBuffer.from_host(src)
+    out = capi.pinned_empty(n, np.float32)
+    got = buf.read(np.float32, n, out=out)
+    assert np.array_equal(got, src) and np.shares_memory(got, out)
