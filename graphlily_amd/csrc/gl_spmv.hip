@@ -20,6 +20,10 @@
 //   segments    a row block's stream is cut into S equal pieces ("units", one workgroup each) so that
 //               about 256*k equally sized units exist (256 CUs); units are numbered segment-major so
 //               concurrently running workgroups sweep the same column window of x (L2 resident).
+//   hub rows    a row that owns more than ~1/48 of its block's entries would make many lanes of every
+//               wavefront step hit one LDS word; its entries are spread over 16 private slots (chosen
+//               by the entry's position in its group, i.e. at format time) that are summed before the
+//               epilogue.
 // S == 1: the workgroup writes y for its rows directly, mask and semiring finish fused (the
 // write_to_out_ddr epilogue, kernel_spmv_impl.h:339-389).  S > 1: y is initialised by a small kernel
 // and the units fold their tiles in with device atomics (float add / ordered-int min / store).
@@ -37,13 +41,17 @@ constexpr uint32_t kRowBits = 14;
 constexpr uint32_t kRowPad = (1u << kRowBits) - 1u;   // row_in_block value of a padding entry
 constexpr uint32_t kMaxBlockRows = kRowPad;            // 16383
 constexpr uint32_t kColOffBits = 32 - kRowBits;        // 18
+constexpr uint32_t kHubSlots = 16;                     // private accumulators per hub row
+constexpr uint32_t kMaxHubRows = 32;                   // per row block
+constexpr uint32_t kMaxPlainRows = kMaxBlockRows - kHubSlots * kMaxHubRows;
 constexpr uint32_t kThreads = 1024;                    // one workgroup per CU: 16 wavefronts share the tile
 constexpr uint32_t kWaves = kThreads / 64;
 
 struct SpmvArgs {
     const uint2 *entries;     // groups of 64
     const uint32_t *bases;    // one base column per group
-    const uint4 *units;       // {first group, #groups, first row, #rows | direct << 31}
+    const uint4 *units;       // 2 per unit: {first group, #groups, first row, #rows | direct << 31}, {hub offset, #hub rows,-,-}
+    const uint32_t *hub_rows; // row_in_block of every hub row, per block
     const float *x;
     const float *mask;
     float *y;
@@ -61,6 +69,7 @@ struct Tile<GL_OP_MULADD> {
         // float product as in the reference (spmv_module.h:495), f64 accumulation
         __hip_atomic_fetch_add(&t[r], (double)(a * xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    __device__ static T comb(T x, T y) { return x + y; }
     __device__ static float get(const T *t, uint32_t r) { return (float)t[r]; }
     __device__ static bool touched(float s) { return s != 0.0f; }
     __device__ static void fold(float *y, float s) { unsafeAtomicAdd(y, s); }
@@ -75,6 +84,7 @@ struct Tile<GL_OP_ANDOR> {
     __device__ static void acc(T *t, uint32_t r, float a, float xv) {
         if (a != 0.0f && xv != 0.0f) t[r] = 1.0f;   // every writer stores the same value
     }
+    __device__ static T comb(T x, T y) { return (x != 0.0f || y != 0.0f) ? 1.0f : 0.0f; }
     __device__ static float get(const T *t, uint32_t r) { return t[r]; }
     __device__ static bool touched(float s) { return s != 0.0f; }
     __device__ static void fold(float *y, float) { *y = 1.0f; }
@@ -95,6 +105,7 @@ struct Tile<GL_OP_ADDMIN> {
     using T = float;
     __device__ static T ident() { return __builtin_inff(); }
     __device__ static void acc(T *t, uint32_t r, float a, float xv) { atomic_min_f32_as_int(&t[r], a + xv); }
+    __device__ static T comb(T x, T y) { return (y < x) ? y : x; }
     __device__ static float get(const T *t, uint32_t r) { return t[r]; }
     __device__ static bool touched(float s) { return s != __builtin_inff(); }
     __device__ static void fold(float *y, float s) { atomic_min_f32_as_int(y, s); }
@@ -109,15 +120,17 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T *tile = reinterpret_cast<T *>(__builtin_assume_aligned(lds_raw, 16));
 
-    const uint4 d = a.units[blockIdx.x];
+    const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
     const uint32_t g0 = d.x, ngroups = d.y, row0 = d.z;
     const uint32_t nrows = d.w & 0xffffu;
     const bool direct = (d.w >> 31) != 0u;
+    const uint32_t hub_off = dh.x, nhub = dh.y;
+    const uint32_t nslots = nrows + kHubSlots * nhub;
     const uint32_t lane = threadIdx.x & 63u;
     // wave id as a scalar so that group indices, and with them the base-column loads, stay in SGPRs
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) tile[i] = TL::ident();
+    for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
     __syncthreads();
 
     // wave w takes groups w, w+16, ...: the workgroup reads 8 KB of contiguous stream per round and all
@@ -142,6 +155,17 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
         }
     }
     __syncthreads();
+
+    if (nhub) {   // fold the private slots of every hub row back into its row
+        if (threadIdx.x < nhub) {
+            const uint32_t r = a.hub_rows[hub_off + threadIdx.x];
+            T acc = tile[r];
+#pragma unroll
+            for (uint32_t k = 0; k < kHubSlots; k++) acc = TL::comb(acc, tile[nrows + kHubSlots * threadIdx.x + k]);
+            tile[r] = acc;
+        }
+        __syncthreads();
+    }
 
     if (direct) {
         for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
@@ -189,6 +213,8 @@ struct gl_spmv_plan_s {
     uint2 *d_entries = nullptr;
     uint32_t *d_bases = nullptr;
     uint4 *d_units = nullptr;
+    uint32_t *d_hub_rows = nullptr;
+    uint32_t hub_rows_total = 0;
     uint64_t device_bytes = 0;
 };
 
@@ -264,7 +290,7 @@ static Shape choose_shape(uint64_t rows, uint64_t cols, uint64_t nnz, int num_cu
     Shape best{1, 1};
     if (rows == 0 || nnz == 0) return best;
     const double deg = (double)nnz / (double)rows;
-    const uint64_t rmax = kMaxBlockRows - 64;   // slack: blocks are cut by nnz, not by row count
+    const uint64_t rmax = kMaxPlainRows - 64;   // slack: blocks are cut by nnz, not by row count
     double best_cost = 1e300;
     for (int k = 1; k <= 16 && best_cost > 1e299; k *= 2) {
         for (uint32_t S = 1; S <= 64; S++) {
@@ -338,7 +364,7 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
         uint32_t r = row_begin, made = 0;
         while (r < row_end) {
             made++;
-            const uint32_t hi = (uint32_t)std::min<uint64_t>(row_end, (uint64_t)r + gl::kMaxBlockRows);
+            const uint32_t hi = (uint32_t)std::min<uint64_t>(row_end, (uint64_t)r + gl::kMaxPlainRows);
             uint32_t e;
             if (made >= shape.blocks && hi == row_end) {
                 e = row_end;   // the last planned block takes what is left if it fits
@@ -374,7 +400,9 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
 
     std::vector<uint2> entries(total_groups * 64);
     std::vector<uint32_t> bases(total_groups);
-    std::vector<uint4> units((size_t)nblocks * S);
+    std::vector<uint4> units((size_t)nblocks * S * 2);
+    std::vector<uint32_t> hub_rows((size_t)nblocks * gl::kMaxHubRows, 0);   // slot b*kMaxHubRows + h
+    std::vector<uint32_t> hub_count(nblocks, 0);
     uint32_t max_rows = 0;
     int bad_col = 0;
 
@@ -399,6 +427,22 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
             }
             gl::sort_by_col(recs, tmp, num_cols);
             const uint64_t m = recs.size();
+            // hub rows: more than 1/48 of the block's entries (=> several lanes of every step on one LDS word)
+            std::vector<uint32_t> cnt(r1 - r0, 0);
+            for (const gl::Rec &rc : recs) cnt[rc.row_local]++;
+            std::vector<int> hub_of(r1 - r0, -1);
+            {
+                const uint64_t thr = std::max<uint64_t>(256, m / 48);
+                uint32_t nh = 0;
+                for (uint32_t i = 0; i < r1 - r0 && nh < gl::kMaxHubRows; i++)
+                    if (cnt[i] >= thr) {
+                        hub_of[i] = (int)nh;
+                        hub_rows[(size_t)b * gl::kMaxHubRows + nh] = i;
+                        nh++;
+                    }
+                hub_count[b] = nh;
+            }
+            const uint32_t nrows_b = r1 - r0;
             for (uint32_t s = 0; s < S; s++) {
                 const size_t u = (size_t)s * nblocks + b;
                 const uint64_t c0 = m * s / S, c1 = m * (s + 1) / S;
@@ -414,19 +458,23 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
                         g++;
                         fill = 0;
                     }
-                    entries[(g - 1) * 64 + fill] = make_uint2(((rc.col - base) << gl::kRowBits) | rc.row_local, rc.val);
+                    const int hb = hub_of[rc.row_local];
+                    const uint32_t slot = hb < 0 ? rc.row_local : nrows_b + gl::kHubSlots * (uint32_t)hb + (fill & (gl::kHubSlots - 1u));
+                    entries[(g - 1) * 64 + fill] = make_uint2(((rc.col - base) << gl::kRowBits) | slot, rc.val);
                     fill++;
                 }
                 if (g > unit_goff[u])
                     for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
-                units[u] = make_uint4((uint32_t)unit_goff[u], (uint32_t)(g - unit_goff[u]), r0,
-                                      (r1 - r0) | (S == 1 ? 0x80000000u : 0u));
+                units[2 * u] = make_uint4((uint32_t)unit_goff[u], (uint32_t)(g - unit_goff[u]), r0,
+                                          (r1 - r0) | (S == 1 ? 0x80000000u : 0u));
+                units[2 * u + 1] = make_uint4((uint32_t)((size_t)b * gl::kMaxHubRows), hub_count[b], 0u, 0u);
             }
         }
     }
     if (bad_col)
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", num_cols);
-    for (uint32_t b = 0; b < nblocks; b++) max_rows = std::max(max_rows, bstart[b + 1] - bstart[b]);
+    for (uint32_t b = 0; b < nblocks; b++)
+        max_rows = std::max(max_rows, bstart[b + 1] - bstart[b] + gl::kHubSlots * hub_count[b]);   // LDS slots
 
     gl_spmv_plan p = new gl_spmv_plan_s();
     p->num_rows = num_rows;
@@ -448,7 +496,8 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
     int rc;
     if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * sizeof(uint2))) != GL_OK ||
         (rc = up((void **)&p->d_bases, bases.data(), bases.size() * sizeof(uint32_t))) != GL_OK ||
-        (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK) {
+        (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK ||
+        (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK) {
         gl_spmv_plan_destroy(p);
         return rc;
     }
@@ -461,6 +510,7 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_entries);
     (void)hipFree(p->d_bases);
     (void)hipFree(p->d_units);
+    (void)hipFree(p->d_hub_rows);
     delete p;
     return GL_OK;
 }
@@ -493,6 +543,7 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     a.entries = p->d_entries;
     a.bases = p->d_bases;
     a.units = p->d_units;
+    a.hub_rows = p->d_hub_rows;
     a.x = d_x;
     a.mask = d_mask;
     a.y = d_y;
