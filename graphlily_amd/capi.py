@@ -31,7 +31,7 @@ EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32",
     "gl_host_alloc", "gl_host_free",
-    "gl_spmv_plan_create", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_run",
+    "gl_spmv_plan_create", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_run",
     "gl_prof_begin", "gl_prof_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
@@ -76,6 +76,7 @@ def lib():
         "gl_spmv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmv_plan_destroy": [vp], "gl_spmv_plan_info": [vp, P(u64), P(u64), P(u32)],
         "gl_spmv_plan_shape": [vp, P(u32), P(u32), P(u32), P(u64)],
+        "gl_spmv_plan_hot": [vp, P(u32), P(u64), P(i32)],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
         "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)],
         "gl_spmspv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
@@ -257,8 +258,12 @@ class SpMVPlan:
         b, sg, mr, g = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint64(0)
         check(lib().gl_spmv_plan_shape(ctypes.c_void_p(self.handle), ctypes.byref(b), ctypes.byref(sg),
                                        ctypes.byref(mr), ctypes.byref(g)))
+        hc, hn, mix = ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_int(0)
+        check(lib().gl_spmv_plan_hot(ctypes.c_void_p(self.handle), ctypes.byref(hc), ctypes.byref(hn),
+                                     ctypes.byref(mix)))
         return {"nnz": nnz.value, "device_bytes": nbytes.value, "num_units": ntiles.value, "blocks": b.value,
-                "segments": sg.value, "max_block_rows": mr.value, "groups": g.value}
+                "segments": sg.value, "max_block_rows": mr.value, "groups": g.value,
+                "hot_columns": hc.value, "hot_nnz": hn.value, "mix": mix.value}
 
     def run(self, x, mask, y, op, zero, mask_type):
         check(lib().gl_spmv_run(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero),

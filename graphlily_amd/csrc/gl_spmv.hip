@@ -20,6 +20,12 @@
 //   segments    a row block's stream is cut into S equal pieces ("units", one workgroup each) so that
 //               about 256*k equally sized units exist (256 CUs); units are numbered segment-major so
 //               concurrently running workgroups sweep the same column window of x (L2 resident).
+//   hot columns the H highest-degree columns of the shard (on power-law graphs 8K columns hold a third of
+//               the non-zeros) are cached per workgroup in an LDS table; their entries form separate
+//               "hot" groups { hot_slot << 14 | row_in_block , val } that need no vector-memory gather.
+//               Cold groups are bound by the texture addresser (one gather lane per clock per CU), hot
+//               groups by HBM; a wavefront processes UC cold and UH hot groups per iteration so that
+//               both limits are worked against at the same time.
 //   hub rows    a row that owns more than ~1/48 of its block's entries would make many lanes of every
 //               wavefront step hit one LDS word; its entries are spread over 16 private slots (chosen
 //               by the entry's position in its group, i.e. at format time) that are summed before the
@@ -42,8 +48,9 @@ constexpr uint32_t kRowPad = (1u << kRowBits) - 1u;   // row_in_block value of a
 constexpr uint32_t kMaxBlockRows = kRowPad;            // 16383
 constexpr uint32_t kColOffBits = 32 - kRowBits;        // 18
 constexpr uint32_t kHubSlots = 16;                     // private accumulators per hub row
-constexpr uint32_t kMaxHubRows = 32;                   // per row block
+constexpr uint32_t kMaxHubRows = 64;                   // per row block
 constexpr uint32_t kMaxPlainRows = kMaxBlockRows - kHubSlots * kMaxHubRows;
+constexpr uint32_t kLdsBudget = 160u * 1024u - 512u;   // per-CU LDS minus a little slack
 constexpr uint32_t kThreads = 1024;                    // one workgroup per CU: 16 wavefronts share the tile
 constexpr uint32_t kWaves = kThreads / 64;
 
@@ -52,6 +59,8 @@ struct SpmvArgs {
     const uint32_t *bases;    // one base column per group
     const uint4 *units;       // 2 per unit: {first group, #groups, first row, #rows | direct << 31}, {hub offset, #hub rows,-,-}
     const uint32_t *hub_rows; // row_in_block of every hub row, per block
+    const float *hot_x;       // x[hot_cols[k]], gathered once per run by spmv_hot_gather_kernel
+    uint32_t nhot;            // cached columns (LDS table length, multiple of 64)
     const float *x;
     const float *mask;
     float *y;
@@ -113,46 +122,65 @@ struct Tile<GL_OP_ADDMIN> {
     __device__ static float finish(float zero, float s) { return (s < zero) ? s : zero; }
 };
 
-template <int OP, int MASK, int U>
+template <int OP, int MASK, int UC, int UH>
 __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     using TL = Tile<OP>;
     using T = typename TL::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    T *tile = reinterpret_cast<T *>(__builtin_assume_aligned(lds_raw, 16));
+    float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
+    T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);   // nhot is a multiple of 64
 
     const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
-    const uint32_t g0 = d.x, ngroups = d.y, row0 = d.z;
+    const uint32_t g0 = d.x, ncold = d.y, row0 = d.z;
     const uint32_t nrows = d.w & 0xffffu;
     const bool direct = (d.w >> 31) != 0u;
-    const uint32_t hub_off = dh.x, nhub = dh.y;
+    const uint32_t hub_off = dh.x, nhub = dh.y, nhotg = dh.z;
     const uint32_t nslots = nrows + kHubSlots * nhub;
     const uint32_t lane = threadIdx.x & 63u;
     // wave id as a scalar so that group indices, and with them the base-column loads, stay in SGPRs
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
+    if (UH > 0)
+        for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];   // coalesced, L2 hits
     for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
     __syncthreads();
 
-    // wave w takes groups w, w+16, ...: the workgroup reads 8 KB of contiguous stream per round and all
-    // of its wavefronts sweep the columns together
-    for (uint32_t g = wave; g < ngroups; g += kWaves * U) {
-        uint2 e[U];
-        uint32_t b[U];
+    // Wave w takes cold groups w, w+16, ... and hot groups w, w+16, ...: the workgroup reads contiguous
+    // stream and its wavefronts sweep the columns together.  Per iteration UC cold groups (stream read +
+    // global gather) and UH hot groups (stream read + LDS lookup) are in flight.
+    const uint32_t gh0 = g0 + ncold;
+    uint32_t gc = wave, gh = wave;
+    while (gc < ncold || (UH > 0 && gh < nhotg)) {
+        uint2 ec[UC];
+        uint32_t bc[UC];
+        uint2 eh[UH > 0 ? UH : 1];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t gi = g + u * kWaves;
-            const bool in = gi < ngroups;
-            e[u] = in ? load_stream_nt(a.entries + (size_t)(g0 + gi) * 64u + lane) : make_uint2(kRowPad, 0u);
-            b[u] = in ? a.bases[g0 + gi] : 0u;
+        for (int u = 0; u < UC; u++) {
+            const uint32_t gi = gc + u * kWaves;
+            const bool in = gi < ncold;
+            ec[u] = in ? load_stream_nt(a.entries + (size_t)(g0 + gi) * 64u + lane) : make_uint2(kRowPad, 0u);
+            bc[u] = in ? a.bases[g0 + gi] : 0u;
         }
-        float xv[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) xv[u] = a.x[b[u] + (e[u].x >> kRowBits)];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t r = e[u].x & kRowPad;
-            if (r != kRowPad) TL::acc(tile, r, __uint_as_float(e[u].y), xv[u]);
+        for (int u = 0; u < UH; u++) {
+            const uint32_t gi = gh + u * kWaves;
+            eh[u] = (gi < nhotg) ? load_stream_nt(a.entries + (size_t)(gh0 + gi) * 64u + lane) : make_uint2(kRowPad, 0u);
         }
+        float xc[UC];
+#pragma unroll
+        for (int u = 0; u < UC; u++) xc[u] = a.x[bc[u] + (ec[u].x >> kRowBits)];
+#pragma unroll
+        for (int u = 0; u < UH; u++) {
+            const uint32_t r = eh[u].x & kRowPad;
+            if (r != kRowPad) TL::acc(tile, r, __uint_as_float(eh[u].y), hot_x[eh[u].x >> kRowBits]);
+        }
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const uint32_t r = ec[u].x & kRowPad;
+            if (r != kRowPad) TL::acc(tile, r, __uint_as_float(ec[u].y), xc[u]);
+        }
+        gc += kWaves * UC;
+        gh += kWaves * (UH > 0 ? UH : 1);
     }
     __syncthreads();
 
@@ -190,6 +218,13 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     }
 }
 
+// the one scattered read of the hot columns per run; the workgroups then copy the compact table
+__global__ __launch_bounds__(256) void spmv_hot_gather_kernel(const float *__restrict__ x, const uint32_t *__restrict__ hot_cols,
+                                                              float *__restrict__ hot_x, uint32_t nhot) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nhot) hot_x[i] = x[hot_cols[i]];
+}
+
 // y initialisation for the rows of blocks that are split into several units
 template <int OP, int MASK>
 __global__ __launch_bounds__(256) void spmv_init_kernel(uint32_t r0, uint32_t r1, const float *__restrict__ mask,
@@ -214,15 +249,30 @@ struct gl_spmv_plan_s {
     uint32_t *d_bases = nullptr;
     uint4 *d_units = nullptr;
     uint32_t *d_hub_rows = nullptr;
-    uint32_t hub_rows_total = 0;
+    uint32_t nhot = 0;         // cached ("hot") columns, multiple of 64
+    uint64_t hot_nnz = 0;      // non-zeros served from the LDS table
+    int mix = 0;               // cold/hot groups per iteration: 0 = (4,0) no hot table, 5 = (3,3) default; others for tuning
+    uint32_t *d_hot_cols = nullptr;
+    float *d_hot_x = nullptr;
     uint64_t device_bytes = 0;
 };
 
 namespace gl {
 
+template <int OP, int MASK, int UC, int UH>
+static int launch_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStream_t s) {
+    static bool attr_set = false;  // one flag per template instantiation
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_kernel<OP, MASK, UC, UH>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set = true;
+    }
+    spmv_rbcs_kernel<OP, MASK, UC, UH><<<p->nunits, kThreads, lds, s>>>(a);
+    return GL_OK;
+}
+
 template <int OP, int MASK>
 static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
-    constexpr int U = 4;
     const uint32_t rows = p->row_end - p->row_begin;
     if (rows == 0) return GL_OK;
     if (p->segments > 1 || p->nunits == 0) {
@@ -231,17 +281,25 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
         GL_LAUNCH_CHECK();
     }
     if (!p->nunits) return GL_OK;
-    const size_t lds = (size_t)p->max_block_rows * sizeof(typename Tile<OP>::T);
-    static bool attr_set = false;  // one flag per template instantiation
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_kernel<OP, MASK, U>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxBlockRows * sizeof(double))));
-        attr_set = true;
+    if (p->nhot) {
+        spmv_hot_gather_kernel<<<cdiv(p->nhot, 256), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot);
+        GL_LAUNCH_CHECK();
     }
+    const size_t lds = (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(typename Tile<OP>::T);
     Profiler &pf = prof();
     const bool timed = pf.on && 2ull * (pf.used + 1) <= pf.events.size();
     if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
-    spmv_rbcs_kernel<OP, MASK, U><<<p->nunits, kThreads, lds, s>>>(a);
+    int rc;
+    switch (p->mix) {
+        case 1: rc = launch_variant<OP, MASK, 3, 1>(p, a, lds, s); break;
+        case 2: rc = launch_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
+        case 3: rc = launch_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
+        case 4: rc = launch_variant<OP, MASK, 4, 2>(p, a, lds, s); break;
+        case 5: rc = launch_variant<OP, MASK, 3, 3>(p, a, lds, s); break;
+        case 6: rc = launch_variant<OP, MASK, 4, 1>(p, a, lds, s); break;
+        default: rc = launch_variant<OP, MASK, 4, 0>(p, a, lds, s); break;
+    }
+    if (rc != GL_OK) return rc;
     GL_LAUNCH_CHECK();
     if (timed) {
         GL_HIP(hipEventRecord(pf.events[2 * pf.used + 1], s));
@@ -382,7 +440,49 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
     }
     const uint32_t nblocks = (uint32_t)bstart.size() - 1;
     const uint32_t S = nblocks ? shape.segments : 1;
-    const uint32_t jump_slack = (num_cols >> gl::kColOffBits) + 2;
+    const uint32_t jump_slack = (num_cols >> gl::kColOffBits) + 5;   // early cuts + cold/hot rounding
+    uint32_t tallest = 0;
+    for (uint32_t b = 0; b < nblocks; b++) tallest = std::max(tallest, bstart[b + 1] - bstart[b]);
+
+    // ---- hot columns: the H highest-degree columns of the shard get an LDS-resident copy of x.
+    //      H = largest power of two that fits next to the tallest f64 tile (incl. worst-case hub slots).
+    std::vector<uint32_t> hot_cols, hot_slot;   // slot -> column, column -> slot (0xffffffff = cold)
+    if (nnz > 0 && gl::env_long("GRAPHLILY_SPMV_HOT", 1) != 0) {
+        const size_t tile_bytes = ((size_t)tallest + gl::kHubSlots * gl::kMaxHubRows) * sizeof(double);
+        uint32_t H = 0;
+        for (uint32_t h = 1u << 14; h >= 1024u; h >>= 1)
+            if (tile_bytes + (size_t)h * 4u <= gl::kLdsBudget) { H = h; break; }
+        const long forced = gl::env_long("GRAPHLILY_SPMV_HOT", 1);
+        if (forced > 1) H = std::min<uint32_t>(H, (uint32_t)forced);
+        if (H) {
+            std::vector<uint32_t> deg(num_cols, 0);
+            for (uint64_t i = nz0; i < nz1; i++) deg[h_indices[i]]++;
+            const uint32_t dmax = *std::max_element(deg.begin(), deg.end());
+            std::vector<uint32_t> hist((size_t)dmax + 2, 0);
+            for (uint32_t c = 0; c < num_cols; c++) hist[deg[c]]++;
+            // thr = smallest degree such that at most H columns have degree >= thr; a column must also
+            // appear often enough to be worth a slot (>= 4 entries per row block on average)
+            const uint32_t floor_deg = std::max<uint32_t>(8u, 4u * nblocks);
+            uint64_t seen = 0;
+            uint32_t thr = dmax + 1;
+            while (thr > floor_deg && seen + hist[thr - 1] <= H) { thr--; seen += hist[thr]; }
+            hot_slot.assign(num_cols, 0xffffffffu);
+            for (uint32_t c = 0; c < num_cols; c++)
+                if (deg[c] >= thr && hot_cols.size() < H) {
+                    hot_slot[c] = (uint32_t)hot_cols.size();
+                    hot_cols.push_back(c);
+                }
+            uint64_t hn = 0;
+            for (uint32_t c : hot_cols) hn += deg[c];
+            if (hot_cols.empty() || (double)hn < 0.05 * (double)nnz) {   // not worth the table
+                hot_cols.clear();
+                hot_slot.clear();
+            }
+        }
+    }
+    const bool have_hot = !hot_cols.empty();
+    const uint32_t nhot_table = have_hot ? (uint32_t)((hot_cols.size() + 63) / 64 * 64) : 0u;
+    if (have_hot) hot_cols.resize(nhot_table, hot_cols[0]);   // pad the table to whole wavefronts
 
     // ---- group budget per unit (upper bound), so every block can be emitted independently;
     //      units are numbered segment-major: u = s * nblocks + b
@@ -391,7 +491,7 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
         const uint64_t m = (uint64_t)h_indptr[bstart[b + 1]] - h_indptr[bstart[b]];
         for (uint32_t s = 0; s < S; s++) {
             const uint64_t c0 = m * s / S, c1 = m * (s + 1) / S;
-            unit_goff[(size_t)s * nblocks + b + 1] = (c1 > c0) ? (c1 - c0 + 63) / 64 + jump_slack : 0;
+            unit_goff[(size_t)s * nblocks + b + 1] = (c1 - c0 + 63) / 64 + jump_slack;
         }
     }
     for (size_t i = 0; i < (size_t)nblocks * S; i++) unit_goff[i + 1] += unit_goff[i];
@@ -405,20 +505,24 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
     std::vector<uint32_t> hub_count(nblocks, 0);
     uint32_t max_rows = 0;
     int bad_col = 0;
+    uint64_t hot_nnz = 0;
 
-#pragma omp parallel
+#pragma omp parallel reduction(+ : hot_nnz)
     {
-        std::vector<gl::Rec> recs, tmp;
+        std::vector<gl::Rec> recs, tmp, hot;
 #pragma omp for schedule(dynamic, 1)
         for (int64_t b = 0; b < (int64_t)nblocks; b++) {
             const uint32_t r0 = bstart[b], r1 = bstart[b + 1];
-            const uint64_t e0 = h_indptr[r0], e1 = h_indptr[r1];
-            recs.resize(e1 - e0);
+            recs.clear();
+            hot.clear();
             bool bad = false;
             for (uint32_t r = r0; r < r1; r++)
                 for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
-                    bad |= h_indices[i] >= num_cols;
-                    recs[i - e0] = gl::Rec{h_indices[i], r - r0, __builtin_bit_cast(uint32_t, h_data[i])};
+                    const uint32_t c = h_indices[i];
+                    if (c >= num_cols) { bad = true; continue; }
+                    const uint32_t v = __builtin_bit_cast(uint32_t, h_data[i]);
+                    if (have_hot && hot_slot[c] != 0xffffffffu) hot.push_back(gl::Rec{hot_slot[c], r - r0, v});
+                    else recs.push_back(gl::Rec{c, r - r0, v});
                 }
             if (bad) {
 #pragma omp atomic write
@@ -426,13 +530,16 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
                 continue;
             }
             gl::sort_by_col(recs, tmp, num_cols);
-            const uint64_t m = recs.size();
-            // hub rows: more than 1/48 of the block's entries (=> several lanes of every step on one LDS word)
+            gl::sort_by_col(hot, tmp, nhot_table ? nhot_table : 1u);   // by slot: neighbours share an LDS word
+            hot_nnz += hot.size();
+            const uint64_t mc = recs.size(), m = mc + hot.size();
+            // hub rows: a large share of the block's entries (=> several lanes of every step on one LDS word)
             std::vector<uint32_t> cnt(r1 - r0, 0);
             for (const gl::Rec &rc : recs) cnt[rc.row_local]++;
+            for (const gl::Rec &rc : hot) cnt[rc.row_local]++;
             std::vector<int> hub_of(r1 - r0, -1);
             {
-                const uint64_t thr = std::max<uint64_t>(256, m / 48);
+                const uint64_t thr = std::max<uint64_t>(256, m / (uint64_t)gl::env_long("GRAPHLILY_SPMV_HUB_DIV", 48));
                 uint32_t nh = 0;
                 for (uint32_t i = 0; i < r1 - r0 && nh < gl::kMaxHubRows; i++)
                     if (cnt[i] >= thr) {
@@ -443,12 +550,16 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
                 hub_count[b] = nh;
             }
             const uint32_t nrows_b = r1 - r0;
+            // the block's cold entries (column-sorted) and hot entries (slot-sorted) are each cut into S pieces
+            auto slot_of = [&](const gl::Rec &rc, uint32_t fill) -> uint32_t {
+                const int hb = hub_of[rc.row_local];
+                return hb < 0 ? rc.row_local : nrows_b + gl::kHubSlots * (uint32_t)hb + (fill & (gl::kHubSlots - 1u));
+            };
             for (uint32_t s = 0; s < S; s++) {
                 const size_t u = (size_t)s * nblocks + b;
-                const uint64_t c0 = m * s / S, c1 = m * (s + 1) / S;
                 uint64_t g = unit_goff[u];     // groups [unit_goff[u], g) are complete or open
                 uint32_t fill = 64, base = 0;  // fill == 64: no open group
-                for (uint64_t i = c0; i < c1; i++) {
+                for (uint64_t i = mc * s / S; i < mc * (s + 1) / S; i++) {
                     const gl::Rec &rc = recs[i];
                     if (fill == 64 || rc.col - base >= (1u << gl::kColOffBits)) {
                         if (fill != 64)
@@ -458,16 +569,27 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
                         g++;
                         fill = 0;
                     }
-                    const int hb = hub_of[rc.row_local];
-                    const uint32_t slot = hb < 0 ? rc.row_local : nrows_b + gl::kHubSlots * (uint32_t)hb + (fill & (gl::kHubSlots - 1u));
-                    entries[(g - 1) * 64 + fill] = make_uint2(((rc.col - base) << gl::kRowBits) | slot, rc.val);
+                    entries[(g - 1) * 64 + fill] = make_uint2(((rc.col - base) << gl::kRowBits) | slot_of(rc, fill), rc.val);
                     fill++;
                 }
                 if (g > unit_goff[u])
                     for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
-                units[2 * u] = make_uint4((uint32_t)unit_goff[u], (uint32_t)(g - unit_goff[u]), r0,
-                                          (r1 - r0) | (S == 1 ? 0x80000000u : 0u));
-                units[2 * u + 1] = make_uint4((uint32_t)((size_t)b * gl::kMaxHubRows), hub_count[b], 0u, 0u);
+                const uint32_t ncold = (uint32_t)(g - unit_goff[u]);
+                const uint64_t gh0 = g, mh = hot.size();
+                fill = 64;
+                for (uint64_t i = mh * s / S; i < mh * (s + 1) / S; i++) {
+                    if (fill == 64) {
+                        bases[g] = 0;
+                        g++;
+                        fill = 0;
+                    }
+                    entries[(g - 1) * 64 + fill] = make_uint2((hot[i].col << gl::kRowBits) | slot_of(hot[i], fill), hot[i].val);
+                    fill++;
+                }
+                if (g > gh0)
+                    for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
+                units[2 * u] = make_uint4((uint32_t)unit_goff[u], ncold, r0, (r1 - r0) | (S == 1 ? 0x80000000u : 0u));
+                units[2 * u + 1] = make_uint4((uint32_t)((size_t)b * gl::kMaxHubRows), hub_count[b], (uint32_t)(g - gh0), 0u);
             }
         }
     }
@@ -487,6 +609,14 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
     p->nunits = nblocks * S;
     p->ngroups = total_groups;
     p->max_block_rows = max_rows;
+    p->nhot = nhot_table;
+    p->hot_nnz = hot_nnz;
+    {
+        // measured (orkut / products / hollywood / pokec stand-ins): the balanced 3 cold + 3 hot groups per
+        // iteration is best or within noise of the best everywhere; lopsided mixes starve one stream
+        const long forced = gl::env_long("GRAPHLILY_SPMV_MIX", -1);
+        p->mix = !have_hot ? 0 : (forced >= 0 ? (int)forced : 5);
+    }
     auto up = [&](void **d, const void *h, size_t bytes) -> int {
         GL_HIP(hipMalloc(d, bytes ? bytes : 16));
         if (bytes) GL_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
@@ -497,9 +627,20 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
     if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * sizeof(uint2))) != GL_OK ||
         (rc = up((void **)&p->d_bases, bases.data(), bases.size() * sizeof(uint32_t))) != GL_OK ||
         (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK ||
-        (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK) {
+        (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK ||
+        (rc = up((void **)&p->d_hot_cols, hot_cols.data(), hot_cols.size() * sizeof(uint32_t))) != GL_OK ||
+        (rc = up((void **)&p->d_hot_x, nullptr, 0)) != GL_OK) {
         gl_spmv_plan_destroy(p);
         return rc;
+    }
+    if (nhot_table) {
+        (void)hipFree(p->d_hot_x);
+        p->d_hot_x = nullptr;
+        hipError_t he = hipMalloc((void **)&p->d_hot_x, (size_t)nhot_table * sizeof(float));
+        if (he != hipSuccess) {
+            gl_spmv_plan_destroy(p);
+            return gl::set_error(GL_ERR_HIP, "gl_spmv_plan_create: hipMalloc(hot_x): %s", hipGetErrorString(he));
+        }
     }
     *plan = p;
     return GL_OK;
@@ -511,6 +652,8 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_bases);
     (void)hipFree(p->d_units);
     (void)hipFree(p->d_hub_rows);
+    (void)hipFree(p->d_hot_cols);
+    (void)hipFree(p->d_hot_x);
     delete p;
     return GL_OK;
 }
@@ -520,6 +663,14 @@ int gl_spmv_plan_info(gl_spmv_plan p, uint64_t *nnz, uint64_t *device_bytes, uin
     if (nnz) *nnz = p->nnz;
     if (device_bytes) *device_bytes = p->device_bytes;
     if (num_units) *num_units = p->nunits;
+    return GL_OK;
+}
+
+int gl_spmv_plan_hot(gl_spmv_plan p, uint32_t *hot_columns, uint64_t *hot_nnz, int *mix) {
+    GL_ARG(p != nullptr);
+    if (hot_columns) *hot_columns = p->nhot;
+    if (hot_nnz) *hot_nnz = p->hot_nnz;
+    if (mix) *mix = p->mix;
     return GL_OK;
 }
 
@@ -544,6 +695,8 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     a.bases = p->d_bases;
     a.units = p->d_units;
     a.hub_rows = p->d_hub_rows;
+    a.hot_x = p->d_hot_x;
+    a.nhot = p->nhot;
     a.x = d_x;
     a.mask = d_mask;
     a.y = d_y;

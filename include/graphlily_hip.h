@@ -97,6 +97,9 @@ int gl_spmv_plan_info(gl_spmv_plan plan, uint64_t *nnz, uint64_t *device_bytes, 
 /* decomposition chosen by the planner: row blocks x column segments, tallest block, 64-entry groups */
 int gl_spmv_plan_shape(gl_spmv_plan plan, uint32_t *blocks, uint32_t *segments, uint32_t *max_block_rows,
                        uint64_t *groups);
+/* hot-column cache: columns whose x value is kept in LDS, the non-zeros they serve, and the cold/hot
+ * interleave in use (0 = no hot table, 5 = 3 cold + 3 hot groups per wavefront iteration) */
+int gl_spmv_plan_hot(gl_spmv_plan plan, uint32_t *hot_columns, uint64_t *hot_nnz, int *mix);
 
 /* gl_spmv_run replaces enqueueTask(overlay, mode = 1) (module/spmv_module.h:471-475,
  * hw/overlay.cpp:308-330 -> hw/kernel_spmv_impl.h:392-819):
