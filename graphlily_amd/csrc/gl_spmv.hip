@@ -439,7 +439,36 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
         }
     }
     const uint32_t nblocks = (uint32_t)bstart.size() - 1;
-    const uint32_t S = nblocks ? shape.segments : 1;
+    // ---- segments per block: the planner asked for shape.blocks x shape.segments units; the row cap
+    //      can have produced more blocks than planned, so the unit budget (a multiple of the CU count)
+    //      is re-distributed over the actual blocks in proportion to their non-zeros.
+    std::vector<uint32_t> seg(nblocks, 1), seg_first(nblocks + 1, 0);   // seg_first: unit index base per segment level
+    uint32_t Smax = 1;
+    if (nblocks && shape.segments > 1) {
+        const uint32_t cus = (uint32_t)gl::ctx().num_cus;
+        uint64_t budget = (uint64_t)shape.blocks * shape.segments;
+        budget = std::max<uint64_t>(cus, budget / cus * cus);           // whole rounds of workgroups
+        if (budget < nblocks) budget = nblocks;
+        const double per_unit = (double)nnz / (double)budget;
+        uint64_t used = 0;
+        std::vector<std::pair<double, uint32_t>> frac;
+        for (uint32_t b = 0; b < nblocks; b++) {
+            const double want = (double)((uint64_t)h_indptr[bstart[b + 1]] - h_indptr[bstart[b]]) / per_unit;
+            seg[b] = std::max<uint32_t>(1u, (uint32_t)want);
+            used += seg[b];
+            frac.push_back({want - (double)seg[b], b});
+        }
+        std::sort(frac.begin(), frac.end(), [](const std::pair<double, uint32_t> &x, const std::pair<double, uint32_t> &y) { return x.first > y.first; });
+        for (size_t i = 0; used < budget && i < frac.size(); i++, used++) seg[frac[i].second]++;
+        for (uint32_t b = 0; b < nblocks; b++) Smax = std::max(Smax, seg[b]);
+    }
+    const bool all_direct = (Smax == 1);
+    // unit numbering is segment-major: all blocks' piece 0, then every block's piece 1 (where it exists), ...
+    std::vector<std::vector<uint32_t>> unit_of(Smax, std::vector<uint32_t>(nblocks, 0xffffffffu));
+    uint32_t nunits = 0;
+    for (uint32_t sgm = 0; sgm < Smax; sgm++)
+        for (uint32_t b = 0; b < nblocks; b++)
+            if (seg[b] > sgm) unit_of[sgm][b] = nunits++;
     const uint32_t jump_slack = (num_cols >> gl::kColOffBits) + 5;   // early cuts + cold/hot rounding
     uint32_t tallest = 0;
     for (uint32_t b = 0; b < nblocks; b++) tallest = std::max(tallest, bstart[b + 1] - bstart[b]);
@@ -486,21 +515,22 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
 
     // ---- group budget per unit (upper bound), so every block can be emitted independently;
     //      units are numbered segment-major: u = s * nblocks + b
-    std::vector<uint64_t> unit_goff((size_t)nblocks * S + 1, 0);
+    std::vector<uint64_t> unit_goff((size_t)nunits + 1, 0);
     for (uint32_t b = 0; b < nblocks; b++) {
         const uint64_t m = (uint64_t)h_indptr[bstart[b + 1]] - h_indptr[bstart[b]];
+        const uint32_t S = seg[b];
         for (uint32_t s = 0; s < S; s++) {
             const uint64_t c0 = m * s / S, c1 = m * (s + 1) / S;
-            unit_goff[(size_t)s * nblocks + b + 1] = (c1 - c0 + 63) / 64 + jump_slack;
+            unit_goff[(size_t)unit_of[s][b] + 1] = (c1 - c0 + 63) / 64 + jump_slack;
         }
     }
-    for (size_t i = 0; i < (size_t)nblocks * S; i++) unit_goff[i + 1] += unit_goff[i];
-    const uint64_t total_groups = unit_goff[(size_t)nblocks * S];
+    for (size_t i = 0; i < (size_t)nunits; i++) unit_goff[i + 1] += unit_goff[i];
+    const uint64_t total_groups = unit_goff[nunits];
     GL_ARG(total_groups < 0xffffffffull);
 
     std::vector<uint2> entries(total_groups * 64);
     std::vector<uint32_t> bases(total_groups);
-    std::vector<uint4> units((size_t)nblocks * S * 2);
+    std::vector<uint4> units((size_t)nunits * 2);
     std::vector<uint32_t> hub_rows((size_t)nblocks * gl::kMaxHubRows, 0);   // slot b*kMaxHubRows + h
     std::vector<uint32_t> hub_count(nblocks, 0);
     uint32_t max_rows = 0;
@@ -555,8 +585,9 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
                 const int hb = hub_of[rc.row_local];
                 return hb < 0 ? rc.row_local : nrows_b + gl::kHubSlots * (uint32_t)hb + (fill & (gl::kHubSlots - 1u));
             };
+            const uint32_t S = seg[b];
             for (uint32_t s = 0; s < S; s++) {
-                const size_t u = (size_t)s * nblocks + b;
+                const size_t u = unit_of[s][b];
                 uint64_t g = unit_goff[u];     // groups [unit_goff[u], g) are complete or open
                 uint32_t fill = 64, base = 0;  // fill == 64: no open group
                 for (uint64_t i = mc * s / S; i < mc * (s + 1) / S; i++) {
@@ -588,7 +619,7 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
                 }
                 if (g > gh0)
                     for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
-                units[2 * u] = make_uint4((uint32_t)unit_goff[u], ncold, r0, (r1 - r0) | (S == 1 ? 0x80000000u : 0u));
+                units[2 * u] = make_uint4((uint32_t)unit_goff[u], ncold, r0, (r1 - r0) | (all_direct ? 0x80000000u : 0u));
                 units[2 * u + 1] = make_uint4((uint32_t)((size_t)b * gl::kMaxHubRows), hub_count[b], (uint32_t)(g - gh0), 0u);
             }
         }
@@ -605,8 +636,8 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
     p->row_end = row_end;
     p->nnz = nnz;
     p->nblocks = nblocks;
-    p->segments = S;
-    p->nunits = nblocks * S;
+    p->segments = Smax;
+    p->nunits = nunits;
     p->ngroups = total_groups;
     p->max_block_rows = max_rows;
     p->nhot = nhot_table;

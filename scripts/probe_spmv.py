@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--ops", default="0")
+    ap.add_argument("--shard", default="0/1", help="k/N: time only the k-th of N nnz-balanced row shards")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     capi.init(0)
@@ -30,13 +31,17 @@ def main():
     print("graph %s: n=%d nnz=%d gen %.1fs; deg max %d mean %.1f median %d empty %d" %
           (args.graph, m.num_rows, m.nnz, t1 - t0, lens.max(), lens.mean(), np.median(lens), (lens == 0).sum()),
           flush=True)
-    plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data)
+    from graphlily_amd.dist import partition_rows_by_nnz
+    k, N = (int(t) for t in args.shard.split("/"))
+    bounds = partition_rows_by_nnz(m.adj_indptr, N)
+    plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, bounds[k], bounds[k + 1])
     print("plan create %.1fs" % (time.time() - t1), plan.info(), flush=True)
     x = torch.randint(0, 2, (m.num_cols,), device=dev).float()
     mask = torch.randint(0, 2, (m.num_rows,), device=dev).float()
     y = torch.zeros(m.num_rows, device=dev)
     bx, bm, by = (capi.DeviceBuffer.from_torch(t) for t in (x, mask, y))
-    nbytes = 8 * m.nnz + 12 * m.num_rows + 4
+    snnz = plan.info()["nnz"]
+    nbytes = 8 * snnz + 8 * (bounds[k + 1] - bounds[k]) + 4 * m.num_cols + 4
     for op in [int(o) for o in args.ops.split(",")]:
         for mt in (0, 1):
             zero = 0.0 if op < 2 else 255.0
@@ -51,7 +56,7 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
             print("op %d mask %d: %.3f ms  %.1f GTEPS  %.0f GB/s effective (%.1f%% of 8 TB/s)" %
-                  (op, mt, ms, m.nnz / ms / 1e6, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80), flush=True)
+                  (op, mt, ms, snnz / ms / 1e6, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80), flush=True)
     # streaming ceiling for reference: float4 copy of a 2 GiB buffer
     a = torch.empty(1 << 29, device=dev)
     b = torch.empty_like(a)

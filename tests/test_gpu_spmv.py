@@ -108,6 +108,42 @@ def test_decompositions(gpu, blocks, segments, monkeypatch):
             _check(got, m, sem, mk, x, mask, "shape %dx%d %s %s" % (blocks, segments, sem, mk))
 
 
+@pytest.mark.parametrize("hot,mix", [("0", "-1"), ("1024", "5"), ("1", "3"), ("1", "6"), ("4096", "1")])
+def test_hot_column_cache_variants(gpu, hot, mix, monkeypatch):
+    """The LDS-cached hot columns and the cold/hot interleave are pure work re-arrangements: any table
+    size (0 = disabled) and any interleave must reproduce the same results, with and without segments."""
+    monkeypatch.setenv("GRAPHLILY_SPMV_HOT", hot)
+    monkeypatch.setenv("GRAPHLILY_SPMV_MIX", mix)
+    m = spmv_prepare("rmat_sym_50K")
+    x, mask = rand01(m.num_cols, 11), rand01(m.num_rows, 12)
+    for shape in ((0, 0), (5, 3)):
+        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
+        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        for sem in ("Arithmetic", "Logical", "Tropical"):
+            got = _run_spmv(gpu, m, sem, "WriteToOne", x, mask)
+            _check(got, m, sem, "WriteToOne", x, mask, "hot %s mix %s shape %s %s" % (hot, mix, shape, sem))
+
+
+def test_hub_row_spreading(gpu):
+    """A few rows holding most of a block's entries go through the 16 private LDS slots."""
+    rng = np.random.default_rng(5)
+    n = 4096
+    dense_rows = [7, 1000, 4095]
+    rows, cols = [], []
+    for r in range(n):
+        k = n // 2 if r in dense_rows else 3
+        rows.append(np.full(k, r))
+        cols.append(np.sort(rng.choice(n, size=k, replace=False)))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    indptr = np.zeros(n + 1, np.uint32)
+    np.cumsum(np.bincount(rows, minlength=n), out=indptr[1:])
+    m = io.CSRMatrix(n, n, rng.random(rows.shape[0], dtype=np.float32), cols.astype(np.uint32), indptr)
+    x, mask = rng.random(n, dtype=np.float32), rand01(n, 1)
+    for sem in ("Arithmetic", "Logical", "Tropical"):
+        got = _run_spmv(gpu, m, sem, "NoMask", x, mask)
+        _check(got, m, sem, "NoMask", x, None, "hub rows " + sem)
+
+
 def test_wide_column_jumps(gpu):
     """Columns further apart than the 18-bit in-group offset force early group cuts and padding."""
     n_cols = 3_000_000
