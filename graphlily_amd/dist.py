@@ -13,13 +13,22 @@ world_size-2 gloo runs.
 import numpy as np
 
 
-def partition_rows_by_nnz(indptr, world_size, align=64):
+def partition_rows_by_nnz(indptr, world_size, align=64, equal_rows_tolerance=0.03):
     """Boundaries b[0..world_size] with b[0]=0, b[-1]=num_rows, balancing non-zeros per range and
     rounding interior cuts to a multiple of `align` rows (64 = one wavefront of dense-vector
-    elements, keeps slices 256-byte aligned for the all-gather)."""
+    elements, keeps slices 256-byte aligned for the all-gather).
+
+    When plain equal-length ranges are already balanced to within `equal_rows_tolerance` (randomly
+    labelled graphs are), they are preferred: equal slices let the all-gather run in place, without
+    the pad / unpack copies uneven slices need."""
     indptr = np.asarray(indptr, dtype=np.int64)
     n = indptr.shape[0] - 1
     nnz = int(indptr[n])
+    if world_size > 1 and n % (world_size * align) == 0 and nnz > 0:
+        eq = [n // world_size * r for r in range(world_size + 1)]
+        per = np.diff(indptr[eq])
+        if per.max() <= (1.0 + equal_rows_tolerance) * nnz / world_size:
+            return eq
     bounds = [0]
     for k in range(1, world_size):
         target = nnz * k // world_size
@@ -62,6 +71,12 @@ class Comm:
         lens = [bounds[r + 1] - bounds[r] for r in range(W)]
         mx = max(lens)
         if mx == 0:
+            return
+        gloo_on_gpu = full.is_cuda and self.dist.get_backend(self.group) == "gloo"
+        if min(lens) == mx and bounds[0] == 0 and full.is_contiguous() and not gloo_on_gpu:
+            # equal slices: gather straight into the vector (the clone keeps input and output disjoint)
+            mine = full[bounds[self.rank]:bounds[self.rank + 1]].clone()
+            self.dist.all_gather_into_tensor(full[:bounds[W]], mine, group=self.group)
             return
         key = (full.device, full.dtype, W * mx)
         if getattr(self, "_stage_key", None) != key:

@@ -146,6 +146,28 @@ def test_all_gather_slices_uneven():
     assert all(_spawn("_body_gather_slices").values())
 
 
+def _body_gather_slices_equal(comm):
+    n = 1024
+    bounds = [0, 512, n]
+    full = torch.full((n,), -1.0)
+    full[bounds[comm.rank]:bounds[comm.rank + 1]] = torch.arange(bounds[comm.rank], bounds[comm.rank + 1],
+                                                                 dtype=torch.float32)
+    comm.all_gather_slices(full, bounds)
+    return bool(torch.equal(full, torch.arange(n, dtype=torch.float32)))
+
+
+def test_all_gather_slices_equal_in_place():
+    assert all(_spawn("_body_gather_slices_equal").values())
+
+
+def test_partition_prefers_equal_rows_when_balanced():
+    m = datasets.uniform(4096, 5, seed=1)           # perfectly uniform rows
+    assert partition_rows_by_nnz(m.adj_indptr, 4) == [0, 1024, 2048, 3072, 4096]
+    skew = datasets.rmat(4096, 60000, seed=3)       # a few hub rows: equal rows are NOT balanced
+    b = partition_rows_by_nnz(skew.adj_indptr, 4, equal_rows_tolerance=0.0)
+    assert b[0] == 0 and b[-1] == 4096
+
+
 def test_all_gather_sparse():
     out = _spawn("_body_gather_sparse")
     for r in (0, 1):
