@@ -1,0 +1,126 @@
+"""GPU parity at BASELINE.json's full sizes, through size-independent properties (the oracle would need
+minutes per case at 2e8 non-zeros):
+
+  * SpMV (+,x) linearity:  A(x1 + x2) == A x1 + A x2  (1e-5 relative) and a float64 check on a row sample;
+  * SpMSpV (||,&&) on a sparse v  ==  SpMV (||,&&) on densify(v), bit for bit -- two independent kernels
+    and two independent matrix layouts (column-sorted row blocks vs CSC stream) must agree;
+  * (min,+) SpMV with unit weights and a 0/inf indicator vector == 1 + (||,&&) reachability pattern;
+  * BFS: pull == push == pull_push, levels consistent with the edges (no edge skips a level);
+  * SSSP (unit weights) == BFS levels - 1 on the reached set.
+All on the orkut stand-in (3.07 M vertices, 212 M edges)."""
+import numpy as np
+import pytest
+
+from graphlily_amd import app, capi, datasets, io, module as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orkut(gpu):
+    torch = pytest.importorskip("torch")
+    m = datasets.paper_graph("orkut", 1.0, device=torch.device("cuda:0"))
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    return m
+
+
+def _spmv_module(m, sem, mask_type=M.kNoMask):
+    mod = M.SpMVModule(16, 0, 0)
+    mod.set_semiring(sem)
+    mod.set_mask_type(mask_type)
+    mod.set_up_runtime()
+    mod.load_and_format_matrix(m, True)
+    mod.send_matrix_host_to_device()
+    return mod
+
+
+def test_spmv_linearity_and_sample(orkut):
+    m = orkut.copy()
+    rng = np.random.default_rng(0)
+    m.adj_data = rng.random(m.nnz, dtype=np.float32)
+    mod = _spmv_module(m, M.ArithmeticSemiring)
+    x1, x2 = rng.random(m.num_cols, dtype=np.float32), rng.random(m.num_cols, dtype=np.float32)
+    ys = []
+    for x in (x1, x2, x1 + x2):
+        mod.send_vector_host_to_device(x)
+        mod.run()
+        ys.append(mod.send_results_device_to_host().astype(np.float64))
+    assert np.allclose(ys[2], ys[0] + ys[1], rtol=1e-5, atol=1e-30)
+    rows = rng.integers(0, m.num_rows, size=3000)
+    ip = m.adj_indptr.astype(np.int64)
+    exact = np.array([np.dot(m.adj_data[ip[r]:ip[r + 1]].astype(np.float64),
+                             x1.astype(np.float64)[m.adj_indices[ip[r]:ip[r + 1]]]) for r in rows])
+    assert np.allclose(ys[0][rows], exact, rtol=1e-5, atol=1e-30)
+
+
+def test_spmspv_equals_spmv_on_densified_vector(orkut):
+    m = orkut.copy()
+    m.adj_data = np.ones(m.nnz, dtype=np.float32)
+    csc = io.csr2csc(m)
+    n = m.num_cols
+    rng = np.random.default_rng(1)
+    idx = np.sort(rng.choice(n, size=n // 500, replace=False)).astype(np.uint32)
+    v = M.make_sparse_vec(idx, np.ones(idx.shape[0], np.float32))
+    mask = rng.integers(0, 2, size=n).astype(np.float32)
+    dense = M.convert_sparse_vec_to_dense_vec(v, n, 0.0)
+    for sem, zero in ((M.LogicalSemiring, 0.0), (M.TropicalSemiringUfixed, 255.0)):
+        sp = M.SpMSpVModule(0)
+        sp.set_semiring(sem)
+        sp.set_mask_type(M.kMaskWriteToZero if sem.op == M.kLogicalAndOr else M.kNoMask)
+        sp.set_up_runtime()
+        sp.load_and_format_matrix(csc)
+        sp.send_matrix_host_to_device()
+        sp.send_vector_host_to_device(v)
+        sp.send_mask_host_to_device(mask)
+        sp.run()
+        got = M.convert_sparse_vec_to_dense_vec(sp.send_results_device_to_host(), n, zero)
+        if sem.op == M.kLogicalAndOr:
+            mv = _spmv_module(m, sem, M.kMaskWriteToZero)
+            mv.send_mask_host_to_device(mask)
+            mv.send_vector_host_to_device(dense)
+            mv.run()
+            assert np.array_equal(got, mv.send_results_device_to_host())
+        else:
+            # (min,+): x = 1 on the frontier (the sparse values), `zero` elsewhere; unit weights
+            xd = np.where(dense != 0, np.float32(1.0), np.float32(zero)).astype(np.float32)
+            mv = _spmv_module(m, sem)
+            mv.send_vector_host_to_device(xd)
+            mv.run()
+            ref = mv.send_results_device_to_host()
+            # SpMV does not saturate: zero + 1 = 256 > zero collapses back to zero by the final min
+            assert np.array_equal(got, ref)
+            reach = got != zero
+            assert np.all(got[reach] == 2.0)      # weight 1 + value 1
+
+
+def test_bfs_and_sssp_forms_agree(orkut, gpu):
+    raw = orkut
+    deg = np.diff(raw.adj_indptr.astype(np.int64))
+    src = 0 if deg[0] > 0 else int(np.argmax(deg > 0))
+    bfs = app.BFS(16, 0, 0, 0)
+    bfs.set_up_runtime()
+    bfs.load_and_format_matrix(raw, True)
+    bfs.send_matrix_host_to_device()
+    d_pull = bfs.pull(src, 6)
+    assert np.array_equal(d_pull, bfs.pull_push(src, 6, 0.001))
+    assert np.array_equal(d_pull, bfs.push(src, 6))
+    # level consistency: every edge (u -> v stored as row v, col u) has level[v] <= level[u] + 1 when u is
+    # reached before the last iteration; checked on a sample of rows
+    rng = np.random.default_rng(2)
+    ip = raw.adj_indptr.astype(np.int64)
+    for r in rng.integers(0, raw.num_rows, size=2000):
+        nb = d_pull[raw.adj_indices[ip[r]:ip[r + 1]]]
+        nb = nb[(nb > 0) & (nb < 7)]
+        if nb.size:
+            assert d_pull[r] != 0 and d_pull[r] <= nb.min() + 1
+    assert d_pull[src] == 1 and (d_pull > 0).sum() > raw.num_rows // 2
+    del bfs
+    ss = app.SSSP(16, 0, 0, 0, semiring=M.TropicalSemiring)
+    ss.set_up_runtime()
+    ss.load_and_format_matrix(raw, True)
+    ss.send_matrix_host_to_device()
+    dist = ss.pull(src, 6)
+    assert np.array_equal(dist, ss.pull_push(src, 6, 0.001))
+    reached = d_pull > 0
+    assert np.array_equal(dist[reached], d_pull[reached] - 1)
+    assert np.all(dist[~reached] == np.float32(M.FLOAT_INF))
