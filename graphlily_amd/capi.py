@@ -31,7 +31,7 @@ EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32",
     "gl_host_alloc", "gl_host_free",
-    "gl_spmv_plan_create", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_run",
+    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_run",
     "gl_prof_begin", "gl_prof_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
@@ -74,6 +74,7 @@ def lib():
         "gl_buf_h2d": [vp, vp, ctypes.c_size_t], "gl_buf_d2h": [vp, vp, ctypes.c_size_t],
         "gl_buf_d2d": [vp, vp, ctypes.c_size_t], "gl_buf_fill_f32": [vp, f32, ctypes.c_size_t],
         "gl_spmv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
+        "gl_spmv_plan_create_ex": [P(vp), u32, u32, vp, vp, vp, u32, u32, u32],
         "gl_spmv_plan_destroy": [vp], "gl_spmv_plan_info": [vp, P(u64), P(u64), P(u32)],
         "gl_spmv_plan_shape": [vp, P(u32), P(u32), P(u32), P(u64)],
         "gl_spmv_plan_hot": [vp, P(u32), P(u64), P(i32)],
@@ -237,15 +238,21 @@ def _p(buf):
     return ctypes.c_void_p(buf.ptr if buf is not None else 0)
 
 
+GL_PLAN_NO_MULADD = 1
+GL_ERR_UNSUPPORTED = -5
+
+
 class SpMVPlan:
-    def __init__(self, num_rows, num_cols, indptr, indices, data, row_begin=0, row_end=None):
+    def __init__(self, num_rows, num_cols, indptr, indices, data, row_begin=0, row_end=None, flags=0):
         self.indptr = np.ascontiguousarray(indptr, dtype=np.uint32)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32)
         self.data = np.ascontiguousarray(data, dtype=np.float32)
         row_end = num_rows if row_end is None else row_end
         h = ctypes.c_void_p(0)
-        check(lib().gl_spmv_plan_create(ctypes.byref(h), num_rows, num_cols, _np_ptr(self.indptr),
-                                        _np_ptr(self.indices), _np_ptr(self.data), row_begin, row_end))
+        check(lib().gl_spmv_plan_create_ex(ctypes.byref(h), num_rows, num_cols, _np_ptr(self.indptr),
+                                           _np_ptr(self.indices), _np_ptr(self.data), row_begin, row_end,
+                                           int(flags)))
+        self.flags = int(flags)
         self.handle = h.value
         self.num_rows, self.num_cols, self.row_begin, self.row_end = num_rows, num_cols, row_begin, row_end
         # host CSR copies are only needed during creation

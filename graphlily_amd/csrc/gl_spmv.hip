@@ -249,6 +249,7 @@ struct gl_spmv_plan_s {
     uint32_t *d_bases = nullptr;
     uint4 *d_units = nullptr;
     uint32_t *d_hub_rows = nullptr;
+    uint32_t flags = 0;        // GL_PLAN_* given at creation
     uint32_t nhot = 0;         // cached ("hot") columns, multiple of 64
     uint64_t hot_nnz = 0;      // non-zeros served from the LDS table
     int mix = 0;               // cold/hot groups per iteration: 0 = (4,0) no hot table, 5 = (3,3) default; others for tuning
@@ -286,6 +287,9 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
         GL_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(typename Tile<OP>::T);
+    if (lds > kLdsBudget)
+        return set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_NO_MULADD "
+                         "(hot-column table sized for 4-byte accumulators); (+,x) needs a plan without it");
     Profiler &pf = prof();
     const bool timed = pf.on && 2ull * (pf.used + 1) <= pf.events.size();
     if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
@@ -402,6 +406,12 @@ extern "C" {
 int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols,
                         const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
                         uint32_t row_begin, uint32_t row_end) {
+    return gl_spmv_plan_create_ex(plan, num_rows, num_cols, h_indptr, h_indices, h_data, row_begin, row_end, 0u);
+}
+
+int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols,
+                           const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
+                           uint32_t row_begin, uint32_t row_end, uint32_t flags) {
     GL_REQUIRE_INIT();
     GL_ARG(plan != nullptr && h_indptr != nullptr);
     GL_ARG(row_begin <= row_end && row_end <= num_rows);
@@ -477,9 +487,11 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
     //      H = largest power of two that fits next to the tallest f64 tile (incl. worst-case hub slots).
     std::vector<uint32_t> hot_cols, hot_slot;   // slot -> column, column -> slot (0xffffffff = cold)
     if (nnz > 0 && gl::env_long("GRAPHLILY_SPMV_HOT", 1) != 0) {
-        const size_t tile_bytes = ((size_t)tallest + gl::kHubSlots * gl::kMaxHubRows) * sizeof(double);
+        // 8-byte accumulators unless the caller promised to run only the 4-byte-tile semirings
+        const size_t elem = (flags & GL_PLAN_NO_MULADD) ? sizeof(float) : sizeof(double);
+        const size_t tile_bytes = ((size_t)tallest + gl::kHubSlots * gl::kMaxHubRows) * elem;
         uint32_t H = 0;
-        for (uint32_t h = 1u << 14; h >= 1024u; h >>= 1)
+        for (uint32_t h = 1u << 15; h >= 1024u; h >>= 1)
             if (tile_bytes + (size_t)h * 4u <= gl::kLdsBudget) { H = h; break; }
         const long forced = gl::env_long("GRAPHLILY_SPMV_HOT", 1);
         if (forced > 1) H = std::min<uint32_t>(H, (uint32_t)forced);
@@ -642,6 +654,7 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
     p->max_block_rows = max_rows;
     p->nhot = nhot_table;
     p->hot_nnz = hot_nnz;
+    p->flags = flags;
     {
         // measured (orkut / products / hollywood / pokec stand-ins): the balanced 3 cold + 3 hot groups per
         // iteration is best or within noise of the best everywhere; lopsided mixes starve one stream

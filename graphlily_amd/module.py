@@ -132,11 +132,18 @@ class SpMVModule(BaseModule):
         self.csr_matrix_ = csr_matrix_float
         self.skip_empty_rows_ = skip_empty_rows
 
-    def send_matrix_host_to_device(self):
+    def _make_plan(self):
         m = self.csr_matrix_
         re = m.num_rows if self.row_end_ is None else self.row_end_
+        # the semiring known at upload time sizes the LDS split (accumulators vs hot-column table); a later
+        # switch to (+,x) on a plan built for the 4-byte semirings re-formats the matrix (see run())
+        flags = capi.GL_PLAN_NO_MULADD if self.semiring_.op != kMulAdd else 0
         self.plan_ = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data,
-                                   self.row_begin_, re)
+                                   self.row_begin_, re, flags)
+
+    def send_matrix_host_to_device(self):
+        m = self.csr_matrix_
+        self._make_plan()
         self.results_buf = capi.DeviceBuffer(4 * m.num_rows)
         capi.fill_f32(self.results_buf, 0.0, m.num_rows)  # spmv_module.h:368-369
 
@@ -161,6 +168,9 @@ class SpMVModule(BaseModule):
 
     def run(self):
         mask = self.mask_buf if self.mask_type_ != kNoMask else None
+        if self.semiring_.op == kMulAdd and (self.plan_.flags & capi.GL_PLAN_NO_MULADD):
+            capi.sync()
+            self._make_plan()
         self.plan_.run(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
                        self.mask_type_)
         self._finish()

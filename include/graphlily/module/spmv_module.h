@@ -31,7 +31,19 @@ class SpMVModule : public BaseModule {
     bool sharded_ = false;
     CSRMatrix<float> csr_matrix_float_;
     gl_spmv_plan plan_ = nullptr;
+    uint32_t plan_flags_ = 0;
     aligned_dense_vec_t vector_, mask_, results_;
+
+    // The semiring known at upload time sizes the LDS split (accumulators vs hot-column table).
+    void make_plan_() {
+        const CSRMatrix<float> &m = csr_matrix_float_;
+        gl_spmv_plan_destroy(plan_);
+        plan_ = nullptr;
+        plan_flags_ = (semiring_.op != kMulAdd) ? GL_PLAN_NO_MULADD : 0u;
+        GRAPHLILY_CHECK(gl_spmv_plan_create_ex(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
+                                               m.adj_data.data(), sharded_ ? row_begin_ : 0,
+                                               sharded_ ? row_end_ : m.num_rows, plan_flags_));
+    }
 
 public:
     // device buffers (the reference's public cl::Buffer members, :83-86)
@@ -65,10 +77,7 @@ public:
 
     void send_matrix_host_to_device() {
         const CSRMatrix<float> &m = csr_matrix_float_;
-        gl_spmv_plan_destroy(plan_);
-        plan_ = nullptr;
-        GRAPHLILY_CHECK(gl_spmv_plan_create(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
-                                            m.adj_data.data(), sharded_ ? row_begin_ : 0, sharded_ ? row_end_ : m.num_rows));
+        make_plan_();
         results_buf = DeviceBuffer(sizeof(float) * m.num_rows);
         GRAPHLILY_CHECK(gl_buf_fill_f32((float *)results_buf.ptr(), 0.0f, m.num_rows));
         GRAPHLILY_CHECK(gl_sync());
@@ -93,6 +102,10 @@ public:
     void bind_results_buf(DeviceBuffer src_buf) { results_buf = src_buf; }  // extension
 
     void run() {
+        if (semiring_.op == kMulAdd && (plan_flags_ & GL_PLAN_NO_MULADD)) {   // semiring switched after upload
+            GRAPHLILY_CHECK(gl_sync());
+            make_plan_();
+        }
         GRAPHLILY_CHECK(gl_spmv_run(plan_, (const float *)vector_buf.ptr(),
                                     mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
                                     (float *)results_buf.ptr(), (int)semiring_.op, semiring_.zero, (int)mask_type_));

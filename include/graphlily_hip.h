@@ -91,6 +91,14 @@ int gl_spmv_plan_create(gl_spmv_plan *plan,
                         uint32_t num_rows, uint32_t num_cols,
                         const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
                         uint32_t row_begin, uint32_t row_end);
+/* Same with planning hints.  GL_PLAN_NO_MULADD: the plan will only be run with the (||,&&) and (min,+)
+ * semirings, whose LDS accumulators are 4 bytes -- the freed LDS holds a larger hot-column table.
+ * Running such a plan with (+,x) returns GL_ERR_UNSUPPORTED. */
+#define GL_PLAN_NO_MULADD 1u
+int gl_spmv_plan_create_ex(gl_spmv_plan *plan,
+                           uint32_t num_rows, uint32_t num_cols,
+                           const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
+                           uint32_t row_begin, uint32_t row_end, uint32_t flags);
 int gl_spmv_plan_destroy(gl_spmv_plan plan);
 /* nnz held by this plan (its shard), device bytes of the formatted matrix, number of work units */
 int gl_spmv_plan_info(gl_spmv_plan plan, uint64_t *nnz, uint64_t *device_bytes, uint32_t *num_units);
