@@ -1,13 +1,16 @@
-// graphlily/io/data_loader.h -- CSR/CSC containers and the scipy-npz loader (reference
-// io/data_loader.h:18-157).  The npz parsing is done by libgraphlily_hip.so (gl_npz_csr_*), which
-// replaces the un-vendored cnpy dependency.
+// graphlily/io/data_loader.h -- sparse-matrix containers, the scipy-npz loader and the CSR->CSC
+// transpose of graphlily::io (reference io/data_loader.h:18-157), MI355X build.
+//
+// CSRMatrix<T> and CSCMatrix<T> are two instantiations of one compressed-storage aggregate; field names
+// and order are the reference's, so brace / designated initialisation in caller code keeps working.
+// npz parsing and the float transpose are done natively by libgraphlily_hip.so (gl_npz_csr_*,
+// gl_host_csr2csc), replacing the un-vendored cnpy dependency and the single-threaded counting sort.
 #ifndef GRAPHLILY_IO_DATA_LOADER_H_
 #define GRAPHLILY_IO_DATA_LOADER_H_
 
-#include <cassert>
 #include <cstdint>
-#include <iterator>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "graphlily/global.h"
@@ -15,8 +18,14 @@
 namespace graphlily {
 namespace io {
 
-template <typename data_type>
-struct CSRMatrix {
+namespace detail {
+struct by_row {};
+struct by_col {};
+
+// Compressed sparse storage.  For by_row: adj_indices are column ids, adj_indptr has num_rows + 1
+// entries.  For by_col: adj_indices are row ids, adj_indptr has num_cols + 1 entries.
+template <typename data_type, typename major>
+struct Compressed {
     uint32_t num_rows;
     uint32_t num_cols;
     std::vector<data_type> adj_data;
@@ -24,79 +33,79 @@ struct CSRMatrix {
     std::vector<uint32_t> adj_indptr;
 };
 
+template <typename To, typename major, typename From>
+Compressed<To, major> retype(Compressed<From, major> const &src) {
+    Compressed<To, major> dst;
+    dst.num_rows = src.num_rows;
+    dst.num_cols = src.num_cols;
+    dst.adj_data.reserve(src.adj_data.size());
+    for (From v : src.adj_data) dst.adj_data.push_back(static_cast<To>(v));
+    dst.adj_indices = src.adj_indices;
+    dst.adj_indptr = src.adj_indptr;
+    return dst;
+}
+}  // namespace detail
+
+template <typename data_type>
+using CSRMatrix = detail::Compressed<data_type, detail::by_row>;
+template <typename data_type>
+using CSCMatrix = detail::Compressed<data_type, detail::by_col>;
+
 template <typename data_type>
 CSRMatrix<data_type> create_csr_matrix(uint32_t num_rows, uint32_t num_cols,
                                        std::vector<data_type> const &adj_data,
                                        std::vector<uint32_t> const &adj_indices,
                                        std::vector<uint32_t> const &adj_indptr) {
-    return CSRMatrix<data_type>{num_rows, num_cols, adj_data, adj_indices, adj_indptr};
+    return {num_rows, num_cols, adj_data, adj_indices, adj_indptr};
 }
 
-// scipy.sparse.save_npz file with float32 data -> CSR (reference :51-70)
+// scipy.sparse.save_npz file (float data, 32- or 64-bit indices) -> CSR; reference :51-70
 inline CSRMatrix<float> load_csr_matrix_from_float_npz(std::string csr_float_npz_path) {
-    CSRMatrix<float> m;
-    gl_npz_csr h = nullptr;
+    gl_npz_csr file = nullptr;
+    uint32_t rows = 0, cols = 0;
     uint64_t nnz = 0;
-    GRAPHLILY_CHECK(gl_npz_csr_open(csr_float_npz_path.c_str(), &h, &m.num_rows, &m.num_cols, &nnz));
-    m.adj_data.resize(nnz);
-    m.adj_indices.resize(nnz);
-    m.adj_indptr.resize((size_t)m.num_rows + 1);
-    GRAPHLILY_CHECK(gl_npz_csr_read(h, m.adj_data.data(), m.adj_indices.data(), m.adj_indptr.data()));
+    GRAPHLILY_CHECK(gl_npz_csr_open(csr_float_npz_path.c_str(), &file, &rows, &cols, &nnz));
+    CSRMatrix<float> m{rows, cols, std::vector<float>(nnz), std::vector<uint32_t>(nnz),
+                       std::vector<uint32_t>((size_t)rows + 1)};
+    GRAPHLILY_CHECK(gl_npz_csr_read(file, m.adj_data.data(), m.adj_indices.data(), m.adj_indptr.data()));
     return m;
 }
 
 template <typename data_type>
 CSRMatrix<data_type> csr_matrix_convert_from_float(CSRMatrix<float> const &in) {
-    CSRMatrix<data_type> out;
-    out.num_rows = in.num_rows;
-    out.num_cols = in.num_cols;
-    out.adj_data.assign(in.adj_data.begin(), in.adj_data.end());
-    out.adj_indices = in.adj_indices;
-    out.adj_indptr = in.adj_indptr;
-    return out;
-}
-
-template <typename data_type>
-struct CSCMatrix {
-    uint32_t num_rows;
-    uint32_t num_cols;
-    std::vector<data_type> adj_data;
-    std::vector<uint32_t> adj_indices;  // row ids
-    std::vector<uint32_t> adj_indptr;   // num_cols + 1
-};
-
-// Transpose; rows inside a column stay ascending (reference :108-144).
-template <typename data_type>
-CSCMatrix<data_type> csr2csc(CSRMatrix<data_type> const &csr) {
-    CSCMatrix<data_type> csc;
-    csc.num_rows = csr.num_rows;
-    csc.num_cols = csr.num_cols;
-    const size_t nnz = csr.adj_indptr[csr.num_rows];
-    csc.adj_data.resize(nnz);
-    csc.adj_indices.resize(nnz);
-    csc.adj_indptr.assign((size_t)csr.num_cols + 1, 0);
-    for (size_t i = 0; i < nnz; i++) csc.adj_indptr[csr.adj_indices[i] + 1]++;
-    for (size_t c = 0; c < csr.num_cols; c++) csc.adj_indptr[c + 1] += csc.adj_indptr[c];
-    std::vector<uint32_t> cursor(csc.adj_indptr.begin(), csc.adj_indptr.end() - 1);
-    for (uint32_t r = 0; r < csr.num_rows; r++) {
-        for (size_t i = csr.adj_indptr[r]; i < csr.adj_indptr[r + 1]; i++) {
-            const uint32_t dst = cursor[csr.adj_indices[i]]++;
-            csc.adj_indices[dst] = r;
-            csc.adj_data[dst] = csr.adj_data[i];
-        }
-    }
-    return csc;
+    return detail::retype<data_type>(in);
 }
 
 template <typename data_type>
 CSCMatrix<data_type> csc_matrix_convert_from_float(CSCMatrix<float> const &in) {
-    CSCMatrix<data_type> out;
-    out.num_rows = in.num_rows;
-    out.num_cols = in.num_cols;
-    out.adj_data.assign(in.adj_data.begin(), in.adj_data.end());
-    out.adj_indices = in.adj_indices;
-    out.adj_indptr = in.adj_indptr;
-    return out;
+    return detail::retype<data_type>(in);
+}
+
+// Transpose.  Entries of one column come out in ascending row order (what the reference's row-by-row
+// counting sort produces, :131-139).
+template <typename data_type>
+CSCMatrix<data_type> csr2csc(CSRMatrix<data_type> const &a) {
+    const size_t nnz = a.adj_indptr[a.num_rows];
+    CSCMatrix<data_type> t{a.num_rows, a.num_cols, std::vector<data_type>(nnz), std::vector<uint32_t>(nnz),
+                           std::vector<uint32_t>((size_t)a.num_cols + 1, 0u)};
+    if (std::is_same<data_type, float>::value) {
+        GRAPHLILY_CHECK(gl_host_csr2csc(a.num_rows, a.num_cols, a.adj_indptr.data(), a.adj_indices.data(),
+                                        reinterpret_cast<const float *>(a.adj_data.data()), t.adj_indptr.data(),
+                                        t.adj_indices.data(), reinterpret_cast<float *>(t.adj_data.data())));
+        return t;
+    }
+    // other value types: histogram of the column ids, prefix sum, then a scatter pass over the rows
+    std::vector<uint32_t> &colptr = t.adj_indptr;
+    for (size_t k = 0; k < nnz; k++) colptr[a.adj_indices[k] + 1]++;
+    for (uint32_t c = 0; c < a.num_cols; c++) colptr[c + 1] += colptr[c];
+    std::vector<uint32_t> next(colptr.begin(), colptr.end() - 1);
+    for (uint32_t r = 0; r < a.num_rows; r++)
+        for (uint32_t k = a.adj_indptr[r]; k < a.adj_indptr[r + 1]; k++) {
+            const uint32_t at = next[a.adj_indices[k]]++;
+            t.adj_indices[at] = r;
+            t.adj_data[at] = a.adj_data[k];
+        }
+    return t;
 }
 
 }  // namespace io
