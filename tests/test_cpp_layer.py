@@ -63,3 +63,15 @@ def test_reference_app_drivers_run_on_hip_backend(gpu, tmp_path, golden_dir):
         print(r.stdout[-2000:])
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert r.stdout.count(" OK") == 7
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "bench_bfs_on_hip")),
+                    reason="prebuilt reference benchmark drivers did not travel")
+def test_reference_benchmark_drivers_run_on_hip_backend(gpu):
+    """benchmark/bench_{bfs,pagerank,sssp}.cpp of the reference, compiled unmodified, run end to end."""
+    r = subprocess.run(["python", os.path.join(ROOT, "benchmarks", "run_reference_benches.py"),
+                        "--graph", "googleplus", "--scale", "0.25"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("GTEPS") >= 5      # BFS pull + pull-push, PageRank, SSSP pull + pull-push
