@@ -239,6 +239,7 @@ def _p(buf):
 
 
 GL_PLAN_NO_MULADD = 1
+GL_PLAN_BOOLEAN = 2
 GL_ERR_UNSUPPORTED = -5
 
 

@@ -33,26 +33,9 @@
 // S == 1: the workgroup writes y for its rows directly, mask and semiring finish fused (the
 // write_to_out_ddr epilogue, kernel_spmv_impl.h:339-389).  S > 1: y is initialised by a small kernel
 // and the units fold their tiles in with device atomics (float add / ordered-int min / store).
-#include "gl_common.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <vector>
+#include "gl_spmv_plan.h"
 
 namespace gl {
-
-constexpr uint32_t kRowBits = 14;
-constexpr uint32_t kRowPad = (1u << kRowBits) - 1u;   // row_in_block value of a padding entry
-constexpr uint32_t kMaxBlockRows = kRowPad;            // 16383
-constexpr uint32_t kColOffBits = 32 - kRowBits;        // 18
-constexpr uint32_t kHubSlots = 16;                     // private accumulators per hub row
-constexpr uint32_t kMaxHubRows = 64;                   // per row block
-constexpr uint32_t kMaxPlainRows = kMaxBlockRows - kHubSlots * kMaxHubRows;
-constexpr uint32_t kLdsBudget = 160u * 1024u - 512u;   // per-CU LDS minus a little slack
-constexpr uint32_t kThreads = 1024;                    // one workgroup per CU: 16 wavefronts share the tile
-constexpr uint32_t kWaves = kThreads / 64;
 
 struct SpmvArgs {
     const uint2 *entries;     // groups of 64
@@ -240,24 +223,6 @@ __global__ __launch_bounds__(256) void spmv_init_kernel(uint32_t r0, uint32_t r1
 
 }  // namespace gl
 
-struct gl_spmv_plan_s {
-    uint32_t num_rows = 0, num_cols = 0, row_begin = 0, row_end = 0;
-    uint64_t nnz = 0;
-    uint32_t nunits = 0, nblocks = 0, segments = 1, max_block_rows = 0;
-    uint64_t ngroups = 0;
-    uint2 *d_entries = nullptr;
-    uint32_t *d_bases = nullptr;
-    uint4 *d_units = nullptr;
-    uint32_t *d_hub_rows = nullptr;
-    uint32_t flags = 0;        // GL_PLAN_* given at creation
-    uint32_t nhot = 0;         // cached ("hot") columns, multiple of 64
-    uint64_t hot_nnz = 0;      // non-zeros served from the LDS table
-    int mix = 0;               // cold/hot groups per iteration: 0 = (4,0) no hot table, 5 = (3,3) default; others for tuning
-    uint32_t *d_hot_cols = nullptr;
-    float *d_hot_x = nullptr;
-    uint64_t device_bytes = 0;
-};
-
 namespace gl {
 
 template <int OP, int MASK, int UC, int UH>
@@ -337,15 +302,6 @@ static double stream_rate(double gap) {
     return gy[6];
 }
 
-struct Shape {
-    uint32_t blocks, segments;
-};
-
-static long env_long(const char *name, long dflt) {
-    const char *e = getenv(name);
-    return e ? atol(e) : dflt;
-}
-
 // choose (#row blocks, #segments per block): blocks*segments ~ 256*k equal units, rows per block as
 // large as LDS allows (dense column sweep => coalesced gathers) unless splitting costs more than it buys
 static Shape choose_shape(uint64_t rows, uint64_t cols, uint64_t nnz, int num_cus) {
@@ -378,24 +334,85 @@ static Shape choose_shape(uint64_t rows, uint64_t cols, uint64_t nnz, int num_cu
     return best;
 }
 
-struct Rec {
-    uint32_t col, row_local, val;
-};
+// see gl_spmv_plan.h
+BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin, uint32_t row_end, uint32_t max_rows) {
+    BlockPlan bp;
+    const uint64_t nz0 = h_indptr[row_begin], nz1 = h_indptr[row_end], nnz = nz1 - nz0;
+    std::vector<uint32_t> &bstart = bp.bstart;
+    bstart.push_back(row_begin);
+    if (nnz > 0) {
+        const double target = (double)nnz / (double)shape.blocks;
+        uint32_t r = row_begin, made = 0;
+        while (r < row_end) {
+            made++;
+            const uint32_t hi = (uint32_t)std::min<uint64_t>(row_end, (uint64_t)r + max_rows);
+            uint32_t e;
+            if (made >= shape.blocks && hi == row_end) {
+                e = row_end;   // the last planned block takes what is left if it fits
+            } else {
+                const uint64_t want64 = nz0 + (uint64_t)std::llround(target * made);
+                const uint32_t want = (uint32_t)std::min<uint64_t>(want64, nz1);
+                // last e in [r+1, hi] with indptr[e] <= want, at least one row
+                const uint32_t *ub = std::upper_bound(h_indptr + r + 1, h_indptr + hi + 1, want);
+                e = (uint32_t)(ub - h_indptr) - 1u;
+                if (e < r + 1) e = r + 1;
+            }
+            bstart.push_back(e);
+            r = e;
+        }
+    }
+    const uint32_t nblocks = bp.nblocks = (uint32_t)bstart.size() - 1;
+    // The planner asked for shape.blocks x shape.segments units; the row cap can have produced more blocks
+    // than planned, so the unit budget (a multiple of the CU count) is re-distributed over the actual
+    // blocks in proportion to their non-zeros.
+    bp.seg.assign(nblocks, 1);
+    if (nblocks && shape.segments > 1) {
+        const uint32_t cus = (uint32_t)ctx().num_cus;
+        uint64_t budget = (uint64_t)shape.blocks * shape.segments;
+        budget = std::max<uint64_t>(cus, budget / cus * cus);           // whole rounds of workgroups
+        if (budget < nblocks) budget = nblocks;
+        const double per_unit = (double)nnz / (double)budget;
+        uint64_t used = 0;
+        std::vector<std::pair<double, uint32_t>> frac;
+        for (uint32_t b = 0; b < nblocks; b++) {
+            const double want = (double)((uint64_t)h_indptr[bstart[b + 1]] - h_indptr[bstart[b]]) / per_unit;
+            bp.seg[b] = std::max<uint32_t>(1u, (uint32_t)want);
+            used += bp.seg[b];
+            frac.push_back({want - (double)bp.seg[b], b});
+        }
+        std::sort(frac.begin(), frac.end(), [](const std::pair<double, uint32_t> &x, const std::pair<double, uint32_t> &y) { return x.first > y.first; });
+        for (size_t i = 0; used < budget && i < frac.size(); i++, used++) bp.seg[frac[i].second]++;
+        for (uint32_t b = 0; b < nblocks; b++) bp.Smax = std::max(bp.Smax, bp.seg[b]);
+    }
+    bp.all_direct = (bp.Smax == 1);
+    bp.unit_of.assign(bp.Smax, std::vector<uint32_t>(nblocks, 0xffffffffu));
+    for (uint32_t sgm = 0; sgm < bp.Smax; sgm++)
+        for (uint32_t b = 0; b < nblocks; b++)
+            if (bp.seg[b] > sgm) bp.unit_of[sgm][b] = bp.nunits++;
+    return bp;
+}
 
-// stable LSD radix sort of a block's records by column
-static void sort_by_col(std::vector<Rec> &a, std::vector<Rec> &tmp, uint32_t num_cols) {
-    const size_t n = a.size();
-    tmp.resize(n);
-    int bits = 1;
-    while ((1ull << bits) < num_cols) bits++;
-    const int passes = (bits + 10) / 11;
-    for (int p = 0; p < passes; p++) {
-        const int sh = 11 * p;
-        size_t cnt[2049] = {0};
-        for (size_t i = 0; i < n; i++) cnt[((a[i].col >> sh) & 2047u) + 1]++;
-        for (int i = 0; i < 2048; i++) cnt[i + 1] += cnt[i];
-        for (size_t i = 0; i < n; i++) tmp[cnt[(a[i].col >> sh) & 2047u]++] = a[i];
-        a.swap(tmp);
+// y initialisation for plans whose units fold into y (shared with gl_spmv_bool.hip)
+template <int OP>
+static int init_rows_mask(int mask_type, uint32_t r0, uint32_t r1, const float *mask, float *y, float zero, hipStream_t s) {
+    if (r1 <= r0) return GL_OK;
+    const unsigned grid = std::min<unsigned>(cdiv(r1 - r0, 256), (unsigned)ctx().num_cus * 8u);
+    switch (mask_type) {
+        case GL_NOMASK: spmv_init_kernel<OP, GL_NOMASK><<<grid, 256, 0, s>>>(r0, r1, mask, y, zero); break;
+        case GL_MASK_WRITETOZERO: spmv_init_kernel<OP, GL_MASK_WRITETOZERO><<<grid, 256, 0, s>>>(r0, r1, mask, y, zero); break;
+        case GL_MASK_WRITETOONE: spmv_init_kernel<OP, GL_MASK_WRITETOONE><<<grid, 256, 0, s>>>(r0, r1, mask, y, zero); break;
+        default: return set_error(GL_ERR_INVALID_ARG, "invalid mask type %d", mask_type);
+    }
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int spmv_init_rows(int op, int mask_type, uint32_t r0, uint32_t r1, const float *mask, float *y, float zero, hipStream_t s) {
+    switch (op) {
+        case GL_OP_MULADD: return init_rows_mask<GL_OP_MULADD>(mask_type, r0, r1, mask, y, zero, s);
+        case GL_OP_ANDOR: return init_rows_mask<GL_OP_ANDOR>(mask_type, r0, r1, mask, y, zero, s);
+        case GL_OP_ADDMIN: return init_rows_mask<GL_OP_ADDMIN>(mask_type, r0, r1, mask, y, zero, s);
+        default: return set_error(GL_ERR_INVALID_ARG, "invalid semiring op %d", op);
     }
 }
 
@@ -423,62 +440,32 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     const uint32_t rows = row_end - row_begin;
     for (uint32_t r = row_begin; r < row_end; r++) GL_ARG(h_indptr[r + 1] >= h_indptr[r]);
 
-    // ---- row blocks: nnz-balanced boundaries, at most kMaxBlockRows rows each
+    // ---- (||,&&)-only plans have their own layout (gl_spmv_bool.hip); very wide matrices keep the general one
+    if ((flags & GL_PLAN_BOOLEAN) && nnz > 0 && gl::cdiv(num_cols, gl::kBoolPhaseCols) <= 8u &&
+        gl::env_long("GRAPHLILY_SPMV_BOOL", 1) != 0) {
+        gl_spmv_plan p = new gl_spmv_plan_s();
+        p->num_rows = num_rows;
+        p->num_cols = num_cols;
+        p->row_begin = row_begin;
+        p->row_end = row_end;
+        p->nnz = nnz;
+        p->flags = flags;
+        const int rc = gl::bool_plan_build(p, h_indptr, h_indices, h_data);
+        if (rc != GL_OK) {
+            gl_spmv_plan_destroy(p);
+            return rc;
+        }
+        *plan = p;
+        return GL_OK;
+    }
+
+    // ---- row blocks and segments per block (gl_spmv_plan.h)
     const gl::Shape shape = gl::choose_shape(rows, num_cols, nnz, gl::ctx().num_cus);
-    std::vector<uint32_t> bstart;
-    bstart.push_back(row_begin);
-    if (nnz > 0) {
-        const double target = (double)nnz / (double)shape.blocks;
-        uint32_t r = row_begin, made = 0;
-        while (r < row_end) {
-            made++;
-            const uint32_t hi = (uint32_t)std::min<uint64_t>(row_end, (uint64_t)r + gl::kMaxPlainRows);
-            uint32_t e;
-            if (made >= shape.blocks && hi == row_end) {
-                e = row_end;   // the last planned block takes what is left if it fits
-            } else {
-                const uint64_t want64 = nz0 + (uint64_t)std::llround(target * made);
-                const uint32_t want = (uint32_t)std::min<uint64_t>(want64, nz1);
-                // last e in [r+1, hi] with indptr[e] <= want, at least one row
-                const uint32_t *ub = std::upper_bound(h_indptr + r + 1, h_indptr + hi + 1, want);
-                e = (uint32_t)(ub - h_indptr) - 1u;
-                if (e < r + 1) e = r + 1;
-            }
-            bstart.push_back(e);
-            r = e;
-        }
-    }
-    const uint32_t nblocks = (uint32_t)bstart.size() - 1;
-    // ---- segments per block: the planner asked for shape.blocks x shape.segments units; the row cap
-    //      can have produced more blocks than planned, so the unit budget (a multiple of the CU count)
-    //      is re-distributed over the actual blocks in proportion to their non-zeros.
-    std::vector<uint32_t> seg(nblocks, 1), seg_first(nblocks + 1, 0);   // seg_first: unit index base per segment level
-    uint32_t Smax = 1;
-    if (nblocks && shape.segments > 1) {
-        const uint32_t cus = (uint32_t)gl::ctx().num_cus;
-        uint64_t budget = (uint64_t)shape.blocks * shape.segments;
-        budget = std::max<uint64_t>(cus, budget / cus * cus);           // whole rounds of workgroups
-        if (budget < nblocks) budget = nblocks;
-        const double per_unit = (double)nnz / (double)budget;
-        uint64_t used = 0;
-        std::vector<std::pair<double, uint32_t>> frac;
-        for (uint32_t b = 0; b < nblocks; b++) {
-            const double want = (double)((uint64_t)h_indptr[bstart[b + 1]] - h_indptr[bstart[b]]) / per_unit;
-            seg[b] = std::max<uint32_t>(1u, (uint32_t)want);
-            used += seg[b];
-            frac.push_back({want - (double)seg[b], b});
-        }
-        std::sort(frac.begin(), frac.end(), [](const std::pair<double, uint32_t> &x, const std::pair<double, uint32_t> &y) { return x.first > y.first; });
-        for (size_t i = 0; used < budget && i < frac.size(); i++, used++) seg[frac[i].second]++;
-        for (uint32_t b = 0; b < nblocks; b++) Smax = std::max(Smax, seg[b]);
-    }
-    const bool all_direct = (Smax == 1);
-    // unit numbering is segment-major: all blocks' piece 0, then every block's piece 1 (where it exists), ...
-    std::vector<std::vector<uint32_t>> unit_of(Smax, std::vector<uint32_t>(nblocks, 0xffffffffu));
-    uint32_t nunits = 0;
-    for (uint32_t sgm = 0; sgm < Smax; sgm++)
-        for (uint32_t b = 0; b < nblocks; b++)
-            if (seg[b] > sgm) unit_of[sgm][b] = nunits++;
+    const gl::BlockPlan bp = gl::plan_blocks(shape, h_indptr, row_begin, row_end, gl::kMaxPlainRows);
+    const std::vector<uint32_t> &bstart = bp.bstart, &seg = bp.seg;
+    const std::vector<std::vector<uint32_t>> &unit_of = bp.unit_of;
+    const uint32_t nblocks = bp.nblocks, nunits = bp.nunits, Smax = bp.Smax;
+    const bool all_direct = bp.all_direct;
     const uint32_t jump_slack = (num_cols >> gl::kColOffBits) + 5;   // early cuts + cold/hot rounding
     uint32_t tallest = 0;
     for (uint32_t b = 0; b < nblocks; b++) tallest = std::max(tallest, bstart[b + 1] - bstart[b]);
@@ -488,7 +475,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     std::vector<uint32_t> hot_cols, hot_slot;   // slot -> column, column -> slot (0xffffffff = cold)
     if (nnz > 0 && gl::env_long("GRAPHLILY_SPMV_HOT", 1) != 0) {
         // 8-byte accumulators unless the caller promised to run only the 4-byte-tile semirings
-        const size_t elem = (flags & GL_PLAN_NO_MULADD) ? sizeof(float) : sizeof(double);
+        const size_t elem = (flags & (GL_PLAN_NO_MULADD | GL_PLAN_BOOLEAN)) ? sizeof(float) : sizeof(double);
         const size_t tile_bytes = ((size_t)tallest + gl::kHubSlots * gl::kMaxHubRows) * elem;
         uint32_t H = 0;
         for (uint32_t h = 1u << 15; h >= 1024u; h >>= 1)
@@ -698,6 +685,8 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_hub_rows);
     (void)hipFree(p->d_hot_cols);
     (void)hipFree(p->d_hot_x);
+    (void)hipFree(p->d_spans);
+    (void)hipFree(p->d_xbits);
     delete p;
     return GL_OK;
 }
@@ -734,6 +723,16 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     GL_ARG(p != nullptr && d_y != nullptr);
     GL_ARG(d_x != nullptr || p->nnz == 0);
     GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
+    if (p->boolean) {
+        if (op != GL_OP_ANDOR)
+            return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_BOOLEAN and "
+                                 "holds the sparsity pattern only; semiring op %d needs a plan without it", op);
+        return gl::bool_plan_run(p, d_x, d_mask, d_y, zero, mask_type, gl::ctx().stream);
+    }
+    if ((p->flags & (GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD)) && op == GL_OP_MULADD && p->nhot &&
+        (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(double) > gl::kLdsBudget)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_NO_MULADD "
+                             "(hot-column table sized for 4-byte accumulators); (+,x) needs a plan without it");
     gl::SpmvArgs a;
     a.entries = p->d_entries;
     a.bases = p->d_bases;

@@ -1,0 +1,332 @@
+// SpMV for the (||,&&) semiring only (GL_PLAN_BOOLEAN): y[r] = mask( zero || OR_c (A[r,c] && x[c]) ).
+//
+// This is the BFS pull step (app/bfs.h:107-128 -> SpMVModule::run with LogicalSemiring).  With boolean
+// algebra neither the matrix values nor the float vector have to travel:
+//   entries   4 bytes: (col - group_base) << 14 | row_in_block, column-sorted per row block like the general
+//             layout (gl_spmv.hip); entries whose value is 0 are dropped at format time (a && b is false).
+//             A group is 128 entries = 512 bytes, one coalesced 8-byte-per-lane read; half the HBM bytes.
+//   x         packed to one bit per column by spmv_bool_pack_kernel (12 MB read once per run), and a whole
+//             "phase" of 1 179 648 columns (144 KB) is LDS-resident while a workgroup sweeps it, so there is
+//             no vector-memory gather at all: the lookups are LDS reads.
+//   tile      one bit per row of the block (ds_or_b32).
+// What is left is the 4-byte stream at HBM speed.  Units, segment-major numbering, direct epilogue for
+// unsplit blocks and the init kernel + plain stores (1.0f, idempotent) for split ones are as in gl_spmv.hip.
+#include "gl_spmv_plan.h"
+
+namespace gl {
+
+struct BoolArgs {
+    const uint2 *entries;      // groups of 128: lane l holds entries 2l and 2l+1
+    const uint32_t *bases;     // per group: base column minus the first column of its phase
+    const uint4 *units;        // {first span, #spans, first row, #rows | direct << 31}
+    const uint4 *spans;        // {first xbits word of the phase, first group, end group, lo4 | hi4 << 16}
+    const uint32_t *xbits;
+    const float *mask;
+    float *y;
+    float zero;
+};
+
+// x != 0 packed little-endian, 64 columns per wavefront step; words past num_cols are zero
+__global__ __launch_bounds__(256) void spmv_bool_pack_kernel(const float *__restrict__ x, uint32_t num_cols,
+                                                             uint64_t *__restrict__ bits, uint32_t nwords64) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nwaves = gridDim.x * 4u;
+    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < nwords64; w += nwaves) {
+        const uint32_t c = w * 64u + lane;
+        const bool set = (c < num_cols) && (x[c] != 0.0f);
+        const uint64_t m = __ballot(set);
+        if (lane == 0) bits[w] = m;
+    }
+}
+
+template <int MASK, int U>
+__global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
+    uint32_t *xw = lds_words;                       // kBoolPhaseWords
+    uint32_t *tile = lds_words + kBoolPhaseWords;   // kMaxBlockRows / 32 + 1 words
+
+    const uint4 d = a.units[blockIdx.x];
+    const uint32_t span0 = d.x, nspans = d.y, row0 = d.z;
+    const uint32_t nrows = d.w & 0xffffu;
+    const bool direct = (d.w >> 31) != 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    for (uint32_t i = threadIdx.x; i < (nrows + 31u) / 32u; i += kThreads) tile[i] = 0u;
+
+    for (uint32_t sp = 0; sp < nspans; sp++) {
+        const uint4 s = a.spans[span0 + sp];
+        __syncthreads();   // the previous phase's lookups are done (first pass: tile is zeroed)
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.xbits + s.x);
+            uint4 *dst = reinterpret_cast<uint4 *>(xw);
+            for (uint32_t i = (s.w & 0xffffu) + threadIdx.x; i < (s.w >> 16); i += kThreads) dst[i] = src[i];
+        }
+        __syncthreads();
+        for (uint32_t g = s.y + wave; g < s.z; g += kWaves * U) {
+            uint2 e[U];
+            uint32_t b[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t gi = g + u * kWaves;
+                const bool in = gi < s.z;
+                e[u] = in ? load_stream_nt(a.entries + (size_t)gi * 64u + lane) : make_uint2(kRowPad, kRowPad);
+                b[u] = in ? a.bases[gi] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t v = h ? e[u].y : e[u].x;
+                    const uint32_t r = v & kRowPad;
+                    if (r != kRowPad) {
+                        const uint32_t c = b[u] + (v >> kRowBits);
+                        if ((xw[c >> 5] >> (c & 31u)) & 1u) atomicOr(&tile[r >> 5], 1u << (r & 31u));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    if (direct) {
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
+            const uint32_t row = row0 + i;
+            const bool hit = (tile[i >> 5] >> (i & 31u)) & 1u;
+            float out = (a.zero != 0.0f || hit) ? 1.0f : 0.0f;
+            if (MASK != GL_NOMASK) {
+                if (!mask_allows<MASK>(a.mask[row], 0.0f)) out = 0.0f;   // spmv_module.h:518-530
+            }
+            a.y[row] = out;
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
+            if (!((tile[i >> 5] >> (i & 31u)) & 1u)) continue;
+            const uint32_t row = row0 + i;
+            if (MASK != GL_NOMASK) {
+                if (!mask_allows<MASK>(a.mask[row], 0.0f)) continue;
+            }
+            a.y[row] = 1.0f;   // every writer stores the same value
+        }
+    }
+}
+
+constexpr int kBoolUnroll = 6;
+constexpr size_t kBoolLds = ((size_t)kBoolPhaseWords + kMaxBlockRows / 32u + 1u) * 4u;
+
+template <int MASK>
+static int launch_bool(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute((const void *)spmv_bool_kernel<MASK, kBoolUnroll>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBoolLds));
+        attr_set = true;
+    }
+    Profiler &pf = prof();
+    const bool timed = pf.on && 2ull * (pf.used + 1) <= pf.events.size();
+    if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
+    spmv_bool_kernel<MASK, kBoolUnroll><<<p->nunits, kThreads, kBoolLds, s>>>(a);
+    GL_LAUNCH_CHECK();
+    if (timed) {
+        GL_HIP(hipEventRecord(pf.events[2 * pf.used + 1], s));
+        pf.used++;
+    }
+    return GL_OK;
+}
+
+int bool_plan_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, float zero, int mask_type, hipStream_t s) {
+    const uint32_t rows = p->row_end - p->row_begin;
+    if (rows == 0) return GL_OK;
+    if (p->segments > 1 || p->nunits == 0) {
+        const int rc = spmv_init_rows(GL_OP_ANDOR, mask_type, p->row_begin, p->row_end, d_mask, d_y, zero, s);
+        if (rc != GL_OK) return rc;
+    }
+    if (!p->nunits) return GL_OK;
+    const uint32_t nwords64 = p->nphases * (kBoolPhaseWords / 2u);
+    spmv_bool_pack_kernel<<<std::min<unsigned>(cdiv(nwords64, 4), (unsigned)ctx().num_cus * 16u), 256, 0, s>>>(
+        d_x, p->num_cols, reinterpret_cast<uint64_t *>(p->d_xbits), nwords64);
+    GL_LAUNCH_CHECK();
+    BoolArgs a;
+    a.entries = p->d_entries;
+    a.bases = p->d_bases;
+    a.units = p->d_units;
+    a.spans = p->d_spans;
+    a.xbits = p->d_xbits;
+    a.mask = d_mask;
+    a.y = d_y;
+    a.zero = zero;
+    switch (mask_type) {
+        case GL_NOMASK: return launch_bool<GL_NOMASK>(p, a, s);
+        case GL_MASK_WRITETOZERO: return launch_bool<GL_MASK_WRITETOZERO>(p, a, s);
+        case GL_MASK_WRITETOONE: return launch_bool<GL_MASK_WRITETOONE>(p, a, s);
+        default: return set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid mask type %d", mask_type);
+    }
+}
+
+// ------------------------------------------------------------------------------------- planner
+// Units of 256*k; tall blocks (the tile is only bits) cut into column segments, because a unit copies every
+// x phase it touches into LDS: B blocks x S segments costs about B * (nphases + S - 1) phase copies.
+static Shape choose_shape_bool(uint64_t rows, uint64_t cols, uint64_t nnz, int num_cus) {
+    Shape best{1, 1};
+    if (rows == 0 || nnz == 0) return best;
+    const double nph = (double)cdiv(cols, kBoolPhaseCols);
+    const double phase_bytes = std::min<double>((double)kBoolPhaseWords * 4.0, (double)cols / 8.0);
+    const uint64_t rmax = kMaxBlockRows - 64;
+    double best_cost = 1e300;
+    for (int k = 1; k <= 16 && best_cost > 1e299; k *= 2) {
+        for (uint32_t S = 1; S <= 64; S++) {
+            uint64_t B = (uint64_t)num_cus * k / S;
+            if (B == 0) break;
+            if (B > rows) B = rows;
+            const uint64_t R = (rows + B - 1) / B;
+            if (R > rmax) continue;
+            const double util = (double)B * S / ((double)num_cus * k);
+            const double t_stream = 4.0 * (double)nnz / 6.5e12 / util;
+            const double copies = (S == 1) ? nph : (nph + S - 1) / S;          // per unit
+            const double t_bits = k * copies * phase_bytes / 45e9;              // one CU copies ~45 GB/s from L2
+            const double t_fold = (S == 1) ? 0.0 : (double)rows * 8.0 / 4e12 + 3e-6;
+            const double t = t_stream + t_bits + t_fold + 3.0e-6 * k;
+            if (t < best_cost) {
+                best_cost = t;
+                best = Shape{(uint32_t)B, S};
+            }
+        }
+    }
+    if (best_cost > 1e299) best = Shape{(uint32_t)((rows + rmax - 1) / rmax), 1};
+    const long fb = env_long("GRAPHLILY_SPMV_BLOCKS", 0), fs = env_long("GRAPHLILY_SPMV_SEGMENTS", 0);
+    if (fb > 0) best.blocks = (uint32_t)std::min<uint64_t>((uint64_t)fb, rows);
+    if (fs > 0) best.segments = (uint32_t)std::min<long>(fs, 4096);
+    return best;
+}
+
+int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data) {
+    const uint32_t num_cols = p->num_cols, row_begin = p->row_begin, row_end = p->row_end;
+    const uint32_t rows = row_end - row_begin;
+    const Shape shape = choose_shape_bool(rows, num_cols, p->nnz, ctx().num_cus);
+    const BlockPlan bp = plan_blocks(shape, h_indptr, row_begin, row_end, kMaxBlockRows - 1u);
+    const uint32_t nblocks = bp.nblocks, nunits = bp.nunits;
+    const uint32_t nphases = cdiv(num_cols, kBoolPhaseCols);
+
+    // every unit is emitted on its own (groups, bases, spans), then the pieces are laid out in unit order
+    struct UnitOut {
+        std::vector<uint32_t> ent;     // 128 per group
+        std::vector<uint32_t> bases;   // per group
+        std::vector<uint4> spans;      // group indices are unit-local until the final pass
+    };
+    std::vector<UnitOut> out(nunits);
+    std::vector<uint4> units(nunits);
+    int bad_col = 0;
+    uint32_t max_rows = 0;
+#pragma omp parallel
+    {
+        std::vector<Rec> recs, tmp;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)nblocks; b++) {
+            const uint32_t r0 = bp.bstart[b], r1 = bp.bstart[b + 1];
+            recs.clear();
+            bool bad = false;
+            for (uint32_t r = r0; r < r1; r++)
+                for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
+                    const uint32_t c = h_indices[i];
+                    if (c >= num_cols) { bad = true; continue; }
+                    if (h_data[i] != 0.0f) recs.push_back(Rec{c, r - r0, 0u});   // a && b is false for a == 0
+                }
+            if (bad) {
+#pragma omp atomic write
+                bad_col = 1;
+                continue;
+            }
+            sort_by_col(recs, tmp, num_cols);
+            const uint64_t m = recs.size();
+            const uint32_t S = bp.seg[b];
+            for (uint32_t s = 0; s < S; s++) {
+                const size_t u = bp.unit_of[s][b];
+                UnitOut &o = out[u];
+                uint32_t fill = kBoolGroup, base = 0, phase = 0xffffffffu, lo = 0, hi = 0;
+                auto close_span = [&]() {
+                    if (phase == 0xffffffffu) return;
+                    for (; fill < kBoolGroup; fill++) o.ent.push_back(kRowPad);
+                    uint4 &sp = o.spans.back();
+                    sp.z = (uint32_t)o.bases.size();
+                    sp.w = (lo / 128u) | (((hi / 128u) + 1u) << 16);   // uint4 (128-column) granules of the phase
+                };
+                for (uint64_t i = m * s / S; i < m * (s + 1) / S; i++) {
+                    const Rec &rc = recs[i];
+                    const uint32_t ph = rc.col / kBoolPhaseCols, cin = rc.col - ph * kBoolPhaseCols;
+                    if (ph != phase) {
+                        close_span();
+                        phase = ph;
+                        o.spans.push_back(make_uint4(ph * kBoolPhaseWords, (uint32_t)o.bases.size(), 0u, 0u));
+                        fill = kBoolGroup;
+                        lo = cin;
+                    }
+                    if (fill == kBoolGroup || cin - base >= (1u << kColOffBits)) {
+                        for (; fill < kBoolGroup; fill++) o.ent.push_back(kRowPad);
+                        base = cin;
+                        o.bases.push_back(base);
+                        fill = 0;
+                    }
+                    o.ent.push_back(((cin - base) << kRowBits) | rc.row_local);
+                    fill++;
+                    hi = cin;
+                }
+                close_span();
+                units[u] = make_uint4(0u, (uint32_t)o.spans.size(), r0, (r1 - r0) | (bp.all_direct ? 0x80000000u : 0u));
+            }
+        }
+    }
+    if (bad_col)
+        return set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", num_cols);
+    for (uint32_t b = 0; b < nblocks; b++) max_rows = std::max(max_rows, bp.bstart[b + 1] - bp.bstart[b]);
+
+    std::vector<uint64_t> goff((size_t)nunits + 1, 0), soff((size_t)nunits + 1, 0);
+    for (size_t u = 0; u < nunits; u++) {
+        goff[u + 1] = goff[u] + out[u].bases.size();
+        soff[u + 1] = soff[u] + out[u].spans.size();
+    }
+    const uint64_t total_groups = goff[nunits];
+    if (total_groups >= 0xffffffffull) return set_error(GL_ERR_UNSUPPORTED, "gl_spmv_plan_create: too many groups");
+    std::vector<uint32_t> entries(total_groups * kBoolGroup), bases(total_groups);
+    std::vector<uint4> spans(soff[nunits]);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t u = 0; u < (int64_t)nunits; u++) {
+        UnitOut &o = out[u];
+        if (!o.bases.empty()) {
+            memcpy(&entries[goff[u] * kBoolGroup], o.ent.data(), o.ent.size() * 4u);
+            memcpy(&bases[goff[u]], o.bases.data(), o.bases.size() * 4u);
+        }
+        for (size_t k = 0; k < o.spans.size(); k++) {
+            uint4 sp = o.spans[k];
+            sp.y += (uint32_t)goff[u];
+            sp.z += (uint32_t)goff[u];
+            spans[soff[u] + k] = sp;
+        }
+        units[u].x = (uint32_t)soff[u];
+        UnitOut().ent.swap(o.ent);
+    }
+
+    p->boolean = true;
+    p->nblocks = nblocks;
+    p->segments = bp.Smax;
+    p->nunits = nunits;
+    p->ngroups = total_groups;
+    p->max_block_rows = max_rows;
+    p->nphases = nphases;
+    auto up = [&](void **d, const void *h, size_t bytes) -> int {
+        GL_HIP(hipMalloc(d, bytes ? bytes : 16));
+        if (bytes) GL_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+        p->device_bytes += bytes;
+        return GL_OK;
+    };
+    int rc;
+    if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * 4u)) != GL_OK ||
+        (rc = up((void **)&p->d_bases, bases.data(), bases.size() * 4u)) != GL_OK ||
+        (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK ||
+        (rc = up((void **)&p->d_spans, spans.data(), spans.size() * sizeof(uint4))) != GL_OK)
+        return rc;
+    GL_HIP(hipMalloc((void **)&p->d_xbits, (size_t)nphases * kBoolPhaseWords * 4u));
+    p->device_bytes += (size_t)nphases * kBoolPhaseWords * 4u;
+    return GL_OK;
+}
+
+}  // namespace gl

@@ -1,0 +1,109 @@
+// Shared by gl_spmv.hip (general semiring SpMV) and gl_spmv_bool.hip ((||,&&)-only SpMV): the plan object,
+// the row-block / segment planner and the host-side sorting helpers.
+#ifndef GL_SPMV_PLAN_H_
+#define GL_SPMV_PLAN_H_
+
+#include "gl_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace gl {
+
+constexpr uint32_t kRowBits = 14;
+constexpr uint32_t kRowPad = (1u << kRowBits) - 1u;   // row_in_block value of a padding entry
+constexpr uint32_t kMaxBlockRows = kRowPad;            // 16383
+constexpr uint32_t kColOffBits = 32 - kRowBits;        // 18
+constexpr uint32_t kHubSlots = 16;                     // private accumulators per hub row
+constexpr uint32_t kMaxHubRows = 64;                   // per row block
+constexpr uint32_t kMaxPlainRows = kMaxBlockRows - kHubSlots * kMaxHubRows;
+constexpr uint32_t kLdsBudget = 160u * 1024u - 512u;   // per-CU LDS minus a little slack
+constexpr uint32_t kThreads = 1024;                    // one workgroup per CU: 16 wavefronts share the tile
+constexpr uint32_t kWaves = kThreads / 64;
+
+// (||,&&)-only layout: x as a bitmap, one LDS-resident slice ("phase") of it at a time
+constexpr uint32_t kBoolPhaseWords = 36864;                   // 144 KB of x bits
+constexpr uint32_t kBoolPhaseCols = kBoolPhaseWords * 32u;    // 1 179 648 columns
+constexpr uint32_t kBoolGroup = 128;                          // entries per group: 8 bytes per lane
+
+static inline long env_long(const char *name, long dflt) {
+    const char *e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+
+struct Shape {
+    uint32_t blocks, segments;
+};
+
+struct Rec {
+    uint32_t col, row_local, val;
+};
+
+// stable LSD radix sort of a block's records by column
+static inline void sort_by_col(std::vector<Rec> &a, std::vector<Rec> &tmp, uint32_t num_cols) {
+    const size_t n = a.size();
+    tmp.resize(n);
+    int bits = 1;
+    while ((1ull << bits) < num_cols) bits++;
+    const int passes = (bits + 10) / 11;
+    for (int p = 0; p < passes; p++) {
+        const int sh = 11 * p;
+        size_t cnt[2049] = {0};
+        for (size_t i = 0; i < n; i++) cnt[((a[i].col >> sh) & 2047u) + 1]++;
+        for (int i = 0; i < 2048; i++) cnt[i + 1] += cnt[i];
+        for (size_t i = 0; i < n; i++) tmp[cnt[(a[i].col >> sh) & 2047u]++] = a[i];
+        a.swap(tmp);
+    }
+}
+
+// Row blocks (nnz-balanced boundaries, at most max_rows rows each) and the number of column segments
+// ("units", one workgroup each) every block is cut into.  Units are numbered segment-major: all blocks'
+// piece 0, then every block's piece 1 (where it exists), ... so that concurrently running workgroups sweep
+// the same column window of x.
+struct BlockPlan {
+    std::vector<uint32_t> bstart;                  // nblocks + 1 row boundaries
+    std::vector<uint32_t> seg;                     // segments per block
+    std::vector<std::vector<uint32_t>> unit_of;    // [segment][block] -> unit index (0xffffffff: none)
+    uint32_t nblocks = 0, nunits = 0, Smax = 1;
+    bool all_direct = true;
+};
+
+BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin, uint32_t row_end, uint32_t max_rows);
+
+}  // namespace gl
+
+struct gl_spmv_plan_s {
+    uint32_t num_rows = 0, num_cols = 0, row_begin = 0, row_end = 0;
+    uint64_t nnz = 0;
+    uint32_t nunits = 0, nblocks = 0, segments = 1, max_block_rows = 0;
+    uint64_t ngroups = 0;
+    uint2 *d_entries = nullptr;
+    uint32_t *d_bases = nullptr;
+    uint4 *d_units = nullptr;
+    uint32_t *d_hub_rows = nullptr;
+    uint32_t flags = 0;        // GL_PLAN_* given at creation
+    uint32_t nhot = 0;         // cached ("hot") columns, multiple of 64
+    uint64_t hot_nnz = 0;      // non-zeros served from the LDS table
+    int mix = 0;               // cold/hot groups per iteration: 0 = (4,0) no hot table, 5 = (3,3) default; others for tuning
+    uint32_t *d_hot_cols = nullptr;
+    float *d_hot_x = nullptr;
+    // (||,&&)-only layout (GL_PLAN_BOOLEAN): 4-byte pattern entries, x packed to bits once per run
+    bool boolean = false;
+    uint32_t nphases = 0;
+    uint4 *d_spans = nullptr;      // {first word of the phase in xbits, first group, end group, lo4 | hi4 << 16}
+    uint32_t *d_xbits = nullptr;   // nphases * kBoolPhaseWords words
+    uint64_t device_bytes = 0;
+};
+
+namespace gl {
+// gl_spmv_bool.hip
+int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data);
+int bool_plan_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, float zero, int mask_type, hipStream_t s);
+// gl_spmv.hip: y initialisation for plans whose units fold into y
+int spmv_init_rows(int op, int mask_type, uint32_t r0, uint32_t r1, const float *mask, float *y, float zero, hipStream_t s);
+}  // namespace gl
+
+#endif  // GL_SPMV_PLAN_H_

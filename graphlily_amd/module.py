@@ -132,12 +132,24 @@ class SpMVModule(BaseModule):
         self.csr_matrix_ = csr_matrix_float
         self.skip_empty_rows_ = skip_empty_rows
 
+    @staticmethod
+    def _plan_flags(op):
+        if op == kLogicalAndOr:     # pattern-only entries, x as bits (gl_spmv_bool.hip)
+            return capi.GL_PLAN_BOOLEAN | capi.GL_PLAN_NO_MULADD
+        return capi.GL_PLAN_NO_MULADD if op != kMulAdd else 0
+
+    def _plan_serves(self, op):
+        f = self.plan_.flags
+        if (f & capi.GL_PLAN_BOOLEAN) and op != kLogicalAndOr:
+            return False
+        return not ((f & capi.GL_PLAN_NO_MULADD) and op == kMulAdd)
+
     def _make_plan(self):
         m = self.csr_matrix_
         re = m.num_rows if self.row_end_ is None else self.row_end_
         # the semiring known at upload time sizes the LDS split (accumulators vs hot-column table); a later
         # switch to (+,x) on a plan built for the 4-byte semirings re-formats the matrix (see run())
-        flags = capi.GL_PLAN_NO_MULADD if self.semiring_.op != kMulAdd else 0
+        flags = self._plan_flags(self.semiring_.op)
         self.plan_ = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data,
                                    self.row_begin_, re, flags)
 
@@ -168,7 +180,7 @@ class SpMVModule(BaseModule):
 
     def run(self):
         mask = self.mask_buf if self.mask_type_ != kNoMask else None
-        if self.semiring_.op == kMulAdd and (self.plan_.flags & capi.GL_PLAN_NO_MULADD):
+        if not self._plan_serves(self.semiring_.op):   # semiring switched after upload: re-format
             capi.sync()
             self._make_plan()
         self.plan_.run(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,

@@ -34,12 +34,21 @@ class SpMVModule : public BaseModule {
     uint32_t plan_flags_ = 0;
     aligned_dense_vec_t vector_, mask_, results_;
 
-    // The semiring known at upload time sizes the LDS split (accumulators vs hot-column table).
+    // The semiring known at upload time picks the layout: pattern-only entries and a bit vector for (||,&&),
+    // a larger hot-column table for (min,+), 8-byte accumulators for (+,x).
+    static uint32_t flags_for_(OperationType op) {
+        if (op == kLogicalAndOr) return GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD;
+        return (op != kMulAdd) ? GL_PLAN_NO_MULADD : 0u;
+    }
+    bool plan_serves_(OperationType op) const {
+        if ((plan_flags_ & GL_PLAN_BOOLEAN) && op != kLogicalAndOr) return false;
+        return !((plan_flags_ & GL_PLAN_NO_MULADD) && op == kMulAdd);
+    }
     void make_plan_() {
         const CSRMatrix<float> &m = csr_matrix_float_;
         gl_spmv_plan_destroy(plan_);
         plan_ = nullptr;
-        plan_flags_ = (semiring_.op != kMulAdd) ? GL_PLAN_NO_MULADD : 0u;
+        plan_flags_ = flags_for_(semiring_.op);
         GRAPHLILY_CHECK(gl_spmv_plan_create_ex(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
                                                m.adj_data.data(), sharded_ ? row_begin_ : 0,
                                                sharded_ ? row_end_ : m.num_rows, plan_flags_));
@@ -102,7 +111,7 @@ public:
     void bind_results_buf(DeviceBuffer src_buf) { results_buf = src_buf; }  // extension
 
     void run() {
-        if (semiring_.op == kMulAdd && (plan_flags_ & GL_PLAN_NO_MULADD)) {   // semiring switched after upload
+        if (!plan_serves_(semiring_.op)) {   // semiring switched after upload: re-format
             GRAPHLILY_CHECK(gl_sync());
             make_plan_();
         }

@@ -95,6 +95,12 @@ int gl_spmv_plan_create(gl_spmv_plan *plan,
  * semirings, whose LDS accumulators are 4 bytes -- the freed LDS holds a larger hot-column table.
  * Running such a plan with (+,x) returns GL_ERR_UNSUPPORTED. */
 #define GL_PLAN_NO_MULADD 1u
+/* GL_PLAN_BOOLEAN: the plan will only be run with the (||,&&) semiring.  Only the sparsity pattern of the
+ * non-zero-valued entries is kept (4 bytes per entry; `a && b` is false for a == 0), x is packed to one
+ * bit per column once per run and kept in LDS, the row accumulators are bits.  Results are identical to the
+ * general plan's.  Running such a plan with another semiring returns GL_ERR_UNSUPPORTED.  Implies
+ * GL_PLAN_NO_MULADD when the general layout has to be used (more than 8 x 1 179 648 columns). */
+#define GL_PLAN_BOOLEAN 2u
 int gl_spmv_plan_create_ex(gl_spmv_plan *plan,
                            uint32_t num_rows, uint32_t num_cols,
                            const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--ops", default="0")
     ap.add_argument("--shard", default="0/1", help="k/N: time only the k-th of N nnz-balanced row shards")
+    ap.add_argument("--flags", type=int, default=0, help="GL_PLAN_* flags (1 NO_MULADD, 2 BOOLEAN)")
+    ap.add_argument("--no-copy", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     capi.init(0)
@@ -34,7 +36,7 @@ def main():
     from graphlily_amd.dist import partition_rows_by_nnz
     k, N = (int(t) for t in args.shard.split("/"))
     bounds = partition_rows_by_nnz(m.adj_indptr, N)
-    plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, bounds[k], bounds[k + 1])
+    plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, bounds[k], bounds[k + 1], args.flags)
     print("plan create %.1fs" % (time.time() - t1), plan.info(), flush=True)
     x = torch.randint(0, 2, (m.num_cols,), device=dev).float()
     mask = torch.randint(0, 2, (m.num_rows,), device=dev).float()
@@ -57,6 +59,8 @@ def main():
             ms = e0.elapsed_time(e1) / args.iters
             print("op %d mask %d: %.3f ms  %.1f GTEPS  %.0f GB/s effective (%.1f%% of 8 TB/s)" %
                   (op, mt, ms, snnz / ms / 1e6, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80), flush=True)
+    if args.no_copy:
+        return
     # streaming ceiling for reference: float4 copy of a 2 GiB buffer
     a = torch.empty(1 << 29, device=dev)
     b = torch.empty_like(a)

@@ -196,6 +196,46 @@ def test_edge_shapes(gpu):
     assert_parity(got, _ref_spmv(m, "Logical", "WriteToOne", x, np.array([1, 1, 0], np.float32)), 1, "one long row logical")
 
 
+def test_boolean_plan_phases_and_odd_values(gpu, monkeypatch):
+    """(||,&&) runs on the pattern-only layout (GL_PLAN_BOOLEAN): x packed to bits, 1 179 648-column phases
+    kept in LDS.  Three phases, explicit zeros / -0.0 / NaN / negative weights (a && b on floats), an x
+    with the same oddities, every mask, split and unsplit blocks, and a non-zero semiring `zero`."""
+    from graphlily_amd import capi
+    rng = np.random.default_rng(21)
+    n_rows, n_cols, per_row = 20000, 2_600_000, 24
+    cols = np.sort(rng.integers(0, n_cols, size=(n_rows, per_row)), axis=1).astype(np.uint32)
+    cols[:, -1] = n_cols - 1 - (np.arange(n_rows) % 7)          # touch the last phase's tail
+    vals = rng.choice(np.array([1.0, 0.0, -0.0, -3.5, np.nan, 2.0], np.float32), size=n_rows * per_row)
+    m = io.CSRMatrix(n_rows, n_cols, vals, cols.reshape(-1), np.arange(0, n_rows * per_row + 1, per_row, dtype=np.uint32))
+    x = rng.choice(np.array([0.0, 0.0, 0.0, 1.0, -0.0, np.nan, -2.0], np.float32), size=n_cols)
+    mask = rand01(n_rows, 4)
+    for shape in ((0, 0), (3, 4)):
+        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
+        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        for mk in MASKS:
+            got = _run_spmv(gpu, m, "Logical", mk, x, mask)
+            assert_parity(got, _ref_spmv(m, "Logical", mk, x, mask), 1, "boolean plan %s %s" % (shape, mk))
+    monkeypatch.delenv("GRAPHLILY_SPMV_BLOCKS")
+    monkeypatch.delenv("GRAPHLILY_SPMV_SEGMENTS")
+    # the same through the C ABI: layout is boolean, zero = 1 turns every allowed row on, (+,x) is refused
+    plan = capi.SpMVPlan(n_rows, n_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=capi.GL_PLAN_BOOLEAN)
+    dx, dm, dy = capi.DeviceBuffer(4 * n_cols), capi.DeviceBuffer(4 * n_rows), capi.DeviceBuffer(4 * n_rows)
+    dx.write(x)
+    dm.write(mask)
+    plan.run(dx, dm, dy, 1, 1.0, O.WRITETOZERO)
+    got = dy.read(np.float32, n_rows)
+    assert_parity(got, O.spmv(to_oracle(m), x, 1, 1.0, mask, O.WRITETOZERO), 1, "boolean plan, zero = 1")
+    with pytest.raises(capi.GraphLilyError) as ei:
+        plan.run(dx, dm, dy, 0, 0.0, O.NOMASK)
+    assert ei.value.code == capi.GL_ERR_UNSUPPORTED
+    # and the general layout gives the same answer for the same semiring
+    general = capi.SpMVPlan(n_rows, n_cols, m.adj_indptr, m.adj_indices, m.adj_data)
+    dy2 = capi.DeviceBuffer(4 * n_rows)
+    plan.run(dx, dm, dy, 1, 0.0, O.WRITETOONE)
+    general.run(dx, dm, dy2, 1, 0.0, O.WRITETOONE)
+    assert np.array_equal(dy.read(np.float32, n_rows), dy2.read(np.float32, n_rows))
+
+
 def test_row_shards_compose(gpu):
     """Two row shards write disjoint slices of one y: the multi-GPU decomposition on one device."""
     m = spmv_prepare("rmat_20K")
