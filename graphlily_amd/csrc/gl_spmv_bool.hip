@@ -39,11 +39,23 @@ __global__ __launch_bounds__(256) void spmv_bool_pack_kernel(const float *__rest
     }
 }
 
+// Plan metadata is read-only for the whole launch: loading it through the constant address space lets the
+// compiler keep wave-uniform loads on the scalar unit even though the span loop contains barriers
+// (a fence makes ordinary global loads "clobbered", which turns them into vector loads + vmcnt(0) waits).
+__device__ __forceinline__ uint32_t load_const(const uint32_t *p) {
+    return *(const __attribute__((address_space(4))) uint32_t *)(p);
+}
+__device__ __forceinline__ uint4 load_const(const uint4 *p) {
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+    return make_uint4(load_const(q), load_const(q + 1), load_const(q + 2), load_const(q + 3));
+}
+
 template <int MASK, int U>
 __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
-    uint32_t *xw = lds_words;                       // kBoolPhaseWords
-    uint32_t *tile = lds_words + kBoolPhaseWords;   // kMaxBlockRows / 32 + 1 words
+    // tile first: its byte offsets fit the 16-bit immediate of the LDS instructions either way
+    uint32_t *tile = lds_words;                     // kBoolTileWords: one bit per row slot, slot 16383 = padding
+    uint32_t *xw = lds_words + kBoolTileWords;      // kBoolPhaseWords
 
     const uint4 d = a.units[blockIdx.x];
     const uint32_t span0 = d.x, nspans = d.y, row0 = d.z;
@@ -52,10 +64,27 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    for (uint32_t i = threadIdx.x; i < (nrows + 31u) / 32u; i += kThreads) tile[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < kBoolTileWords; i += kThreads) tile[i] = 0u;
 
     for (uint32_t sp = 0; sp < nspans; sp++) {
-        const uint4 s = a.spans[span0 + sp];
+        const uint4 s = load_const(a.spans + span0 + sp);
+        // Register ring: U groups per wavefront are always in flight.  A slot is refilled right after it has
+        // been consumed, every load is unconditional (indices clamp to the span's last group) so that the
+        // compiler's s_waitcnt vmcnt(N) stay exact -- a batch "load U, wait, process U" loop leaves the
+        // memory pipe empty for the whole processing phase and is latency-bound at ~2/3 of HBM speed.
+        // The ring is primed BEFORE the x bits of the phase are copied: the copy hides the HBM latency.
+        const uint32_t gend = s.z, glast = s.z - 1u;
+        uint2 e[U];
+        uint32_t b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t gi = min(s.y + wave + u * kWaves, glast);
+            e[u] = load_stream_nt(a.entries + (size_t)gi * 64u + lane);
+            b[u] = load_const(a.bases + gi);
+            // keep slot order = issue order: if the scheduler reverses these loads, slot 0 becomes the youngest
+            // and the loop header needs vmcnt(0), which empties the ring once per iteration
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();   // the previous phase's lookups are done (first pass: tile is zeroed)
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(a.xbits + s.x);
@@ -63,29 +92,28 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
             for (uint32_t i = (s.w & 0xffffu) + threadIdx.x; i < (s.w >> 16); i += kThreads) dst[i] = src[i];
         }
         __syncthreads();
-        for (uint32_t g = s.y + wave; g < s.z; g += kWaves * U) {
-            uint2 e[U];
-            uint32_t b[U];
+        for (uint32_t g = s.y + wave; g < gend; g += kWaves * U) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t gi = g + u * kWaves;
-                const bool in = gi < s.z;
-                e[u] = in ? load_stream_nt(a.entries + (size_t)gi * 64u + lane) : make_uint2(kRowPad, kRowPad);
-                b[u] = in ? a.bases[gi] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const uint32_t v = h ? e[u].y : e[u].x;
-                    const uint32_t r = v & kRowPad;
-                    if (r != kRowPad) {
-                        const uint32_t c = b[u] + (v >> kRowBits);
-                        if ((xw[c >> 5] >> (c & 31u)) & 1u) atomicOr(&tile[r >> 5], 1u << (r & 31u));
-                    }
+                if (gi < gend) {   // wave-uniform
+                    // Per entry: bit index = base + offset, one LDS word read, bit test; hits OR the row's bit
+                    // into the tile.  Padding entries are ordinary entries of the ghost row slot 16383, which
+                    // the epilogue never reads -- no per-entry validity test.  16-lane SIMDs make every VALU
+                    // instruction cost 4 clocks per wavefront, so this path is kept to ~6 of them per entry.
+                    const uint32_t v0 = e[u].x, v1 = e[u].y;
+                    const uint32_t c0 = b[u] + (v0 >> kRowBits), c1 = b[u] + (v1 >> kRowBits);
+                    const uint32_t w0 = xw[c0 >> 5], w1 = xw[c1 >> 5];   // both lookups in flight before the tests
+                    if (__builtin_amdgcn_ubfe(w0, c0, 1u)) atomicOr(&tile[(v0 & kRowPad) >> 5], 1u << (v0 & 31u));
+                    if (__builtin_amdgcn_ubfe(w1, c1, 1u)) atomicOr(&tile[(v1 & kRowPad) >> 5], 1u << (v1 & 31u));
                 }
+                const uint32_t gn = min(gi + kWaves * U, glast);
+                e[u] = load_stream_nt(a.entries + (size_t)gn * 64u + lane);
+                b[u] = load_const(a.bases + gn);
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; u++) asm volatile("" : : "v"(e[u].x), "v"(e[u].y));   // retire the clamped tail loads
     }
     __syncthreads();
 
@@ -112,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
 }
 
 constexpr int kBoolUnroll = 6;
-constexpr size_t kBoolLds = ((size_t)kBoolPhaseWords + kMaxBlockRows / 32u + 1u) * 4u;
+constexpr size_t kBoolLds = ((size_t)kBoolPhaseWords + kBoolTileWords) * 4u;
 
 template <int MASK>
 static int launch_bool(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
@@ -242,10 +270,16 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
             for (uint32_t s = 0; s < S; s++) {
                 const size_t u = bp.unit_of[s][b];
                 UnitOut &o = out[u];
-                uint32_t fill = kBoolGroup, base = 0, phase = 0xffffffffu, lo = 0, hi = 0;
+                uint32_t fill = 0, base = 0, phase = 0xffffffffu, lo = 0, hi = 0;   // hi: column of the last entry
+                bool open = false;
+                auto seal_group = [&]() {   // pad the open group with entries of the ghost row slot, column = base
+                    if (!open) return;
+                    for (; fill < kBoolGroup; fill++) o.ent.push_back(kRowPad);
+                    open = false;
+                };
                 auto close_span = [&]() {
                     if (phase == 0xffffffffu) return;
-                    for (; fill < kBoolGroup; fill++) o.ent.push_back(kRowPad);
+                    seal_group();
                     uint4 &sp = o.spans.back();
                     sp.z = (uint32_t)o.bases.size();
                     sp.w = (lo / 128u) | (((hi / 128u) + 1u) << 16);   // uint4 (128-column) granules of the phase
@@ -257,14 +291,14 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
                         close_span();
                         phase = ph;
                         o.spans.push_back(make_uint4(ph * kBoolPhaseWords, (uint32_t)o.bases.size(), 0u, 0u));
-                        fill = kBoolGroup;
                         lo = cin;
                     }
-                    if (fill == kBoolGroup || cin - base >= (1u << kColOffBits)) {
-                        for (; fill < kBoolGroup; fill++) o.ent.push_back(kRowPad);
+                    if (!open || fill == kBoolGroup || cin - base >= (1u << kColOffBits)) {
+                        seal_group();
                         base = cin;
                         o.bases.push_back(base);
                         fill = 0;
+                        open = true;
                     }
                     o.ent.push_back(((cin - base) << kRowBits) | rc.row_local);
                     fill++;

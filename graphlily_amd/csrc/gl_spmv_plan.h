@@ -28,6 +28,7 @@ constexpr uint32_t kWaves = kThreads / 64;
 constexpr uint32_t kBoolPhaseWords = 36864;                   // 144 KB of x bits
 constexpr uint32_t kBoolPhaseCols = kBoolPhaseWords * 32u;    // 1 179 648 columns
 constexpr uint32_t kBoolGroup = 128;                          // entries per group: 8 bytes per lane
+constexpr uint32_t kBoolTileWords = (kMaxBlockRows + 1u) / 32u;  // 512: one bit per row slot incl. the padding slot
 
 static inline long env_long(const char *name, long dflt) {
     const char *e = getenv(name);

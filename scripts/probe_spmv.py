@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--shard", default="0/1", help="k/N: time only the k-th of N nnz-balanced row shards")
     ap.add_argument("--flags", type=int, default=0, help="GL_PLAN_* flags (1 NO_MULADD, 2 BOOLEAN)")
     ap.add_argument("--no-copy", action="store_true")
+    ap.add_argument("--density", type=float, default=0.5, help="fraction of non-zeros in x")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     capi.init(0)
@@ -38,7 +39,7 @@ def main():
     bounds = partition_rows_by_nnz(m.adj_indptr, N)
     plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, bounds[k], bounds[k + 1], args.flags)
     print("plan create %.1fs" % (time.time() - t1), plan.info(), flush=True)
-    x = torch.randint(0, 2, (m.num_cols,), device=dev).float()
+    x = (torch.rand(m.num_cols, device=dev) < args.density).float()
     mask = torch.randint(0, 2, (m.num_rows,), device=dev).float()
     y = torch.zeros(m.num_rows, device=dev)
     bx, bm, by = (capi.DeviceBuffer.from_torch(t) for t in (x, mask, y))

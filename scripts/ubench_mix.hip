@@ -10,6 +10,7 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int THREADS = 1024, U = 4;
 
 template <int SRC_S, int SRC_X>
@@ -50,6 +51,43 @@ __global__ __launch_bounds__(THREADS) void k(const uint2 *__restrict__ s, const 
     if (acc == 123.456f || accu == 0x12345u) y[0] = acc + accu;
 }
 
+
+// 16-byte-per-lane stream: one load instruction carries two groups (lane l gets entry l of group A and of group B)
+template <int SRC_X, int NT>
+__global__ __launch_bounds__(THREADS) void k4(const uint4 *__restrict__ s, const float *__restrict__ x, const uint32_t *__restrict__ offs,
+                                              float *__restrict__ y, uint32_t pairs_per_block, uint32_t xn) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t o[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) o[u] = offs[u * 64 + lane];
+    const size_t p0 = (size_t)blockIdx.x * pairs_per_block;
+    const double colstep = (double)(xn - 4096) / (pairs_per_block * 2);
+    float acc = 0.f;
+    uint32_t accu = 0;
+    constexpr int UP = U / 2;
+    for (uint32_t p = wave; p < pairs_per_block; p += 16 * UP) {
+        u32x4 e[UP];
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < UP; u++) {
+            const size_t pi = p0 + p + u * 16;
+            e[u] = NT ? __builtin_nontemporal_load((const u32x4 *)(s + pi * 64 + lane)) : *(const u32x4 *)(s + pi * 64 + lane);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint32_t base = (uint32_t)(((p + (u / 2) * 16) * 2 + (u & 1)) * colstep);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (SRC_X) v[u] = x[(size_t)base + o[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < UP; u++) accu += e[u].x ^ e[u].y ^ e[u].z ^ e[u].w;
+#pragma unroll
+        for (int u = 0; u < U; u++) if (SRC_X) acc += v[u];
+    }
+    if (acc == 123.456f || accu == 0x12345u) y[0] = acc + accu;
+}
+
 template <typename F> static double time_ms(F f, int iters) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); f(); CK(hipDeviceSynchronize());
     CK(hipEventRecord(a)); for (int i = 0; i < iters; i++) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
@@ -78,5 +116,11 @@ int main() {
     RUN(2, 1, "stream L2 + gather sweeping x (L2)");
     RUN(1, 2, "stream HBM nt + gather in 16 KB window (L1)");
     RUN(2, 2, "stream L2 + gather L1");
+#define RUN4(X, NT, name) { double t = time_ms([&] { k4<X, NT><<<256, THREADS>>>((const uint4 *)s, x, offs, y, gpb / 2, xn); }, 5); \
+        printf("%-58s %.3f ms  (%.0f GB/s of 8-B entries)\n", name, t, n * 8 / 1e9 / t * 1e3); }
+    RUN4(0, 1, "16-B/lane stream HBM nt only");
+    RUN4(0, 0, "16-B/lane stream HBM only");
+    RUN4(1, 1, "16-B/lane stream HBM nt + gather sweeping x (L2)");
+    RUN4(1, 0, "16-B/lane stream HBM + gather sweeping x (L2)");
     return 0;
 }
