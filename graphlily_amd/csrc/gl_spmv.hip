@@ -31,8 +31,9 @@
 //               by the entry's position in its group, i.e. at format time) that are summed before the
 //               epilogue.
 // S == 1: the workgroup writes y for its rows directly, mask and semiring finish fused (the
-// write_to_out_ddr epilogue, kernel_spmv_impl.h:339-389).  S > 1: y is initialised by a small kernel
-// and the units fold their tiles in with device atomics (float add / ordered-int min / store).
+// write_to_out_ddr epilogue, kernel_spmv_impl.h:339-389).  S > 1: every unit stores its tile to its
+// segment's plane of a scratch buffer and spmv_combine_kernel folds the planes in segment order --
+// deterministic, no atomics, 4*(2S+1) bytes per row.
 #include "gl_spmv_plan.h"
 
 namespace gl {
@@ -40,7 +41,7 @@ namespace gl {
 struct SpmvArgs {
     const uint2 *entries;     // groups of 64
     const uint32_t *bases;    // one base column per group
-    const uint4 *units;       // 2 per unit: {first group, #groups, first row, #rows | direct << 31}, {hub offset, #hub rows,-,-}
+    const uint4 *units;       // 2 per unit: {first group, #cold groups, first row, #rows | direct << 31}, {hub offset, #hub rows, #hot groups, segment}
     const uint32_t *hub_rows; // row_in_block of every hub row, per block
     const float *hot_x;       // x[hot_cols[k]], gathered once per run by spmv_hot_gather_kernel
     uint32_t nhot;            // cached columns (LDS table length, multiple of 64)
@@ -48,6 +49,9 @@ struct SpmvArgs {
     const float *mask;
     float *y;
     float zero;
+    float *partials;          // [segment][row - row_begin] per-unit tiles of split blocks (combined by spmv_combine_kernel)
+    uint32_t prow;            // rows per segment plane
+    uint32_t row_begin;
 };
 
 template <int OP>
@@ -63,8 +67,6 @@ struct Tile<GL_OP_MULADD> {
     }
     __device__ static T comb(T x, T y) { return x + y; }
     __device__ static float get(const T *t, uint32_t r) { return (float)t[r]; }
-    __device__ static bool touched(float s) { return s != 0.0f; }
-    __device__ static void fold(float *y, float s) { unsafeAtomicAdd(y, s); }
     __device__ static float init(float zero) { return zero; }
     __device__ static float finish(float zero, float s) { return zero + s; }
 };
@@ -78,8 +80,6 @@ struct Tile<GL_OP_ANDOR> {
     }
     __device__ static T comb(T x, T y) { return (x != 0.0f || y != 0.0f) ? 1.0f : 0.0f; }
     __device__ static float get(const T *t, uint32_t r) { return t[r]; }
-    __device__ static bool touched(float s) { return s != 0.0f; }
-    __device__ static void fold(float *y, float) { *y = 1.0f; }
     __device__ static float init(float zero) { return zero != 0.0f ? 1.0f : 0.0f; }
     __device__ static float finish(float zero, float s) { return (zero != 0.0f || s != 0.0f) ? 1.0f : 0.0f; }
 };
@@ -99,8 +99,6 @@ struct Tile<GL_OP_ADDMIN> {
     __device__ static void acc(T *t, uint32_t r, float a, float xv) { atomic_min_f32_as_int(&t[r], a + xv); }
     __device__ static T comb(T x, T y) { return (y < x) ? y : x; }
     __device__ static float get(const T *t, uint32_t r) { return t[r]; }
-    __device__ static bool touched(float s) { return s != __builtin_inff(); }
-    __device__ static void fold(float *y, float s) { atomic_min_f32_as_int(y, s); }
     __device__ static float init(float zero) { return zero; }
     __device__ static float finish(float zero, float s) { return (s < zero) ? s : zero; }
 };
@@ -189,15 +187,10 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
             a.y[row] = out;
         }
     } else {
-        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
-            const float s = TL::get(tile, i);
-            if (!TL::touched(s)) continue;
-            const uint32_t row = row0 + i;
-            if (MASK != GL_NOMASK) {
-                if (!mask_allows<MASK>(a.mask[row], 0.0f)) continue;
-            }
-            TL::fold(&a.y[row], s);
-        }
+        // split block: this unit's tile goes to its segment plane; spmv_combine_kernel folds the planes in
+        // segment order (deterministic, no atomics) and applies zero / mask
+        float *plane = a.partials + (size_t)dh.w * a.prow + (row0 - a.row_begin);
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) plane[i] = TL::get(tile, i);
     }
 }
 
@@ -221,6 +214,34 @@ __global__ __launch_bounds__(256) void spmv_init_kernel(uint32_t r0, uint32_t r1
     }
 }
 
+// second pass of split plans: y[r] = mask( zero (+) plane_0[r] (+) ... (+) plane_{S-1}[r] ), one workgroup per
+// 256 rows of a block; (+,x) sums the float planes in double
+template <int OP, int MASK>
+__global__ __launch_bounds__(256) void spmv_combine_kernel(const uint4 *__restrict__ blocks, const float *__restrict__ partials,
+                                                           uint32_t prow, uint32_t row_begin, const float *__restrict__ mask,
+                                                           float *__restrict__ y, float zero) {
+    const uint4 b = blocks[blockIdx.y];   // {first row, #rows, #segments, -}
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < b.y; i += gridDim.x * 256u) {
+        const uint32_t row = b.x + i;
+        const float *p = partials + (row - row_begin);
+        float s;
+        if (OP == GL_OP_MULADD) {
+            double acc = 0.0;
+            for (uint32_t k = 0; k < b.z; k++) acc += (double)p[(size_t)k * prow];
+            s = (float)acc;
+        } else {
+            float acc = Semiring<OP>::ident(zero);
+            for (uint32_t k = 0; k < b.z; k++) acc = Semiring<OP>::add(acc, p[(size_t)k * prow]);
+            s = acc;
+        }
+        float out = Tile<OP>::finish(zero, s);
+        if (MASK != GL_NOMASK) {
+            if (!mask_allows<MASK>(mask[row], 0.0f)) out = 0.0f;
+        }
+        y[row] = out;
+    }
+}
+
 }  // namespace gl
 
 namespace gl {
@@ -241,12 +262,12 @@ template <int OP, int MASK>
 static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     const uint32_t rows = p->row_end - p->row_begin;
     if (rows == 0) return GL_OK;
-    if (p->segments > 1 || p->nunits == 0) {
+    if (p->nunits == 0) {   // no stored entries in this shard: y = mask(zero)
         unsigned grid = std::min<unsigned>(cdiv(rows, 256), (unsigned)ctx().num_cus * 8u);
         spmv_init_kernel<OP, MASK><<<grid, 256, 0, s>>>(p->row_begin, p->row_end, a.mask, a.y, a.zero);
         GL_LAUNCH_CHECK();
+        return GL_OK;
     }
-    if (!p->nunits) return GL_OK;
     if (p->nhot) {
         spmv_hot_gather_kernel<<<cdiv(p->nhot, 256), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot);
         GL_LAUNCH_CHECK();
@@ -273,6 +294,11 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     if (timed) {
         GL_HIP(hipEventRecord(pf.events[2 * pf.used + 1], s));
         pf.used++;
+    }
+    if (p->segments > 1) {
+        const dim3 grid(std::max<unsigned>(1u, std::min<unsigned>(cdiv(p->max_plain_rows, 256), 64u)), p->nblocks);
+        spmv_combine_kernel<OP, MASK><<<grid, 256, 0, s>>>(p->d_blocks, p->d_partials, rows, p->row_begin, a.mask, a.y, a.zero);
+        GL_LAUNCH_CHECK();
     }
     return GL_OK;
 }
@@ -318,9 +344,9 @@ static Shape choose_shape(uint64_t rows, uint64_t cols, uint64_t nnz, int num_cu
             const uint64_t R = (rows + B - 1) / B;
             if (R > rmax) continue;
             const double gap = (double)cols / ((double)R * deg);
-            const double flush = (S == 1) ? 0.0 : ((double)S * rows * 4.0 * 1.5 + rows * 8.0) / (8.0 * nnz);
+            const double flush = (S == 1) ? 0.0 : (double)rows * 4.0 * (2.0 * S + 1.0) / (8.0 * nnz);   // planes out + in, y
             const double util = (double)B * S / ((double)num_cus * k);
-            const double t = (8.0 * nnz * (1.0 + flush)) / (stream_rate(gap) * 1e12) / util + 3.0e-6 * k;
+            const double t = (8.0 * nnz * (1.0 + flush)) / (stream_rate(gap) * 1e12) / util + 3.0e-6 * k + (S == 1 ? 0.0 : 3.0e-6);
             if (t < best_cost) {
                 best_cost = t;
                 best = Shape{(uint32_t)B, S};
@@ -619,7 +645,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
                 if (g > gh0)
                     for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
                 units[2 * u] = make_uint4((uint32_t)unit_goff[u], ncold, r0, (r1 - r0) | (all_direct ? 0x80000000u : 0u));
-                units[2 * u + 1] = make_uint4((uint32_t)((size_t)b * gl::kMaxHubRows), hub_count[b], (uint32_t)(g - gh0), 0u);
+                units[2 * u + 1] = make_uint4((uint32_t)((size_t)b * gl::kMaxHubRows), hub_count[b], (uint32_t)(g - gh0), s);
             }
         }
     }
@@ -641,6 +667,11 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     p->max_block_rows = max_rows;
     p->nhot = nhot_table;
     p->hot_nnz = hot_nnz;
+    std::vector<uint4> blocks(nblocks);
+    for (uint32_t b = 0; b < nblocks; b++) {
+        blocks[b] = make_uint4(bstart[b], bstart[b + 1] - bstart[b], seg[b], 0u);
+        p->max_plain_rows = std::max(p->max_plain_rows, bstart[b + 1] - bstart[b]);
+    }
     p->flags = flags;
     {
         // measured (orkut / products / hollywood / pokec stand-ins): the balanced 3 cold + 3 hot groups per
@@ -660,9 +691,19 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK ||
         (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK ||
         (rc = up((void **)&p->d_hot_cols, hot_cols.data(), hot_cols.size() * sizeof(uint32_t))) != GL_OK ||
+        (rc = up((void **)&p->d_blocks, blocks.data(), blocks.size() * sizeof(uint4))) != GL_OK ||
         (rc = up((void **)&p->d_hot_x, nullptr, 0)) != GL_OK) {
         gl_spmv_plan_destroy(p);
         return rc;
+    }
+    if (Smax > 1) {
+        const size_t bytes = (size_t)Smax * rows * sizeof(float);
+        hipError_t he = hipMalloc((void **)&p->d_partials, bytes);
+        if (he != hipSuccess) {
+            gl_spmv_plan_destroy(p);
+            return gl::set_error(GL_ERR_HIP, "gl_spmv_plan_create: hipMalloc(partials): %s", hipGetErrorString(he));
+        }
+        p->device_bytes += bytes;
     }
     if (nhot_table) {
         (void)hipFree(p->d_hot_x);
@@ -686,6 +727,8 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_hot_cols);
     (void)hipFree(p->d_hot_x);
     (void)hipFree(p->d_spans);
+    (void)hipFree(p->d_blocks);
+    (void)hipFree(p->d_partials);
     (void)hipFree(p->d_xbits);
     delete p;
     return GL_OK;
@@ -744,6 +787,9 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     a.mask = d_mask;
     a.y = d_y;
     a.zero = zero;
+    a.partials = p->d_partials;
+    a.prow = p->row_end - p->row_begin;
+    a.row_begin = p->row_begin;
     hipStream_t s = gl::ctx().stream;
     switch (op) {
         case GL_OP_MULADD: return gl::dispatch_mask<GL_OP_MULADD>(mask_type, p, a, s);

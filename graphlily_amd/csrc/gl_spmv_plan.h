@@ -91,6 +91,9 @@ struct gl_spmv_plan_s {
     int mix = 0;               // cold/hot groups per iteration: 0 = (4,0) no hot table, 5 = (3,3) default; others for tuning
     uint32_t *d_hot_cols = nullptr;
     float *d_hot_x = nullptr;
+    uint4 *d_blocks = nullptr;       // {first row, #rows, #segments, -} per row block
+    float *d_partials = nullptr;     // split plans: segments x rows planes of per-unit tiles
+    uint32_t max_plain_rows = 0;     // tallest block without hub slots
     // (||,&&)-only layout (GL_PLAN_BOOLEAN): 4-byte pattern entries, x packed to bits once per run
     bool boolean = false;
     uint32_t nphases = 0;
