@@ -31,7 +31,7 @@ EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32",
     "gl_host_alloc", "gl_host_free",
-    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_run",
+    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_run",
     "gl_prof_begin", "gl_prof_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
@@ -78,6 +78,7 @@ def lib():
         "gl_spmv_plan_destroy": [vp], "gl_spmv_plan_info": [vp, P(u64), P(u64), P(u32)],
         "gl_spmv_plan_shape": [vp, P(u32), P(u32), P(u32), P(u64)],
         "gl_spmv_plan_hot": [vp, P(u32), P(u64), P(i32)],
+        "gl_spmv_plan_layout": [vp, P(i32)],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
         "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)],
         "gl_spmspv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
@@ -240,6 +241,7 @@ def _p(buf):
 
 GL_PLAN_NO_MULADD = 1
 GL_PLAN_BOOLEAN = 2
+GL_PLAN_KEEP_VALUES = 4
 GL_ERR_UNSUPPORTED = -5
 
 
@@ -269,9 +271,12 @@ class SpMVPlan:
         hc, hn, mix = ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_int(0)
         check(lib().gl_spmv_plan_hot(ctypes.c_void_p(self.handle), ctypes.byref(hc), ctypes.byref(hn),
                                      ctypes.byref(mix)))
+        lay = ctypes.c_int(0)
+        check(lib().gl_spmv_plan_layout(ctypes.c_void_p(self.handle), ctypes.byref(lay)))
         return {"nnz": nnz.value, "device_bytes": nbytes.value, "num_units": ntiles.value, "blocks": b.value,
                 "segments": sg.value, "max_block_rows": mr.value, "groups": g.value,
-                "hot_columns": hc.value, "hot_nnz": hn.value, "mix": mix.value}
+                "hot_columns": hc.value, "hot_nnz": hn.value, "mix": mix.value,
+                "layout": ("general", "pattern", "boolean")[lay.value]}
 
     def run(self, x, mask, y, op, zero, mask_type):
         check(lib().gl_spmv_run(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero),

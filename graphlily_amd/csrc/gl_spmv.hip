@@ -49,6 +49,7 @@ struct SpmvArgs {
     const float *mask;
     float *y;
     float zero;
+    const float *z;           // pattern plans: colval (x) x, written by spmv_prescale_kernel
     float *partials;          // [segment][row - row_begin] per-unit tiles of split blocks (combined by spmv_combine_kernel)
     uint32_t prow;            // rows per segment plane
     uint32_t row_begin;
@@ -65,6 +66,9 @@ struct Tile<GL_OP_MULADD> {
         // float product as in the reference (spmv_module.h:495), f64 accumulation
         __hip_atomic_fetch_add(&t[r], (double)(a * xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    __device__ static void accz(T *t, uint32_t r, float z) {   // z = a (x) x already formed (pattern plans)
+        __hip_atomic_fetch_add(&t[r], (double)z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     __device__ static T comb(T x, T y) { return x + y; }
     __device__ static float get(const T *t, uint32_t r) { return (float)t[r]; }
     __device__ static float init(float zero) { return zero; }
@@ -77,6 +81,9 @@ struct Tile<GL_OP_ANDOR> {
     __device__ static T ident() { return 0.0f; }
     __device__ static void acc(T *t, uint32_t r, float a, float xv) {
         if (a != 0.0f && xv != 0.0f) t[r] = 1.0f;   // every writer stores the same value
+    }
+    __device__ static void accz(T *t, uint32_t r, float z) {
+        if (z != 0.0f) t[r] = 1.0f;
     }
     __device__ static T comb(T x, T y) { return (x != 0.0f || y != 0.0f) ? 1.0f : 0.0f; }
     __device__ static float get(const T *t, uint32_t r) { return t[r]; }
@@ -97,11 +104,51 @@ struct Tile<GL_OP_ADDMIN> {
     using T = float;
     __device__ static T ident() { return __builtin_inff(); }
     __device__ static void acc(T *t, uint32_t r, float a, float xv) { atomic_min_f32_as_int(&t[r], a + xv); }
+    __device__ static void accz(T *t, uint32_t r, float z) { atomic_min_f32_as_int(&t[r], z); }
     __device__ static T comb(T x, T y) { return (y < x) ? y : x; }
     __device__ static float get(const T *t, uint32_t r) { return t[r]; }
     __device__ static float init(float zero) { return zero; }
     __device__ static float finish(float zero, float s) { return (s < zero) ? s : zero; }
 };
+
+// after the sweep: hub slots -> rows, then y (unsplit blocks) or this unit's plane (split blocks)
+template <int OP, int MASK>
+__device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename Tile<OP>::T *tile, const uint4 d, const uint4 dh) {
+    using TL = Tile<OP>;
+    using T = typename TL::T;
+    const uint32_t row0 = d.z, nrows = d.w & 0xffffu;
+    const bool direct = (d.w >> 31) != 0u;
+    const uint32_t hub_off = dh.x, nhub = dh.y;
+    __syncthreads();
+    if (nhub) {   // fold the private slots of every hub row back into its row
+        if (threadIdx.x < nhub) {
+            const uint32_t r = a.hub_rows[hub_off + threadIdx.x];
+            T acc = tile[r];
+#pragma unroll
+            for (uint32_t k = 0; k < kHubSlots; k++) acc = TL::comb(acc, tile[nrows + kHubSlots * threadIdx.x + k]);
+            tile[r] = acc;
+        }
+        __syncthreads();
+    }
+
+    if (direct) {
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
+            const uint32_t row = row0 + i;
+            float out = TL::finish(a.zero, TL::get(tile, i));
+            if (MASK != GL_NOMASK) {
+                // masked-off rows are literal 0, and the mask is compared with 0 (spmv_module.h:518-530)
+                if (!mask_allows<MASK>(a.mask[row], 0.0f)) out = 0.0f;
+            }
+            a.y[row] = out;
+        }
+    } else {
+        // split block: this unit's tile goes to its segment plane; spmv_combine_kernel folds the planes in
+        // segment order (deterministic, no atomics) and applies zero / mask
+        float *plane = a.partials + (size_t)dh.w * a.prow + (row0 - a.row_begin);
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) plane[i] = TL::get(tile, i);
+    }
+}
+
 
 template <int OP, int MASK, int UC, int UH>
 __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
@@ -163,34 +210,88 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
         gc += kWaves * UC;
         gh += kWaves * (UH > 0 ? UH : 1);
     }
+    spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
+}
+
+// Pattern plans (every column's stored values are equal): the stream carries 4 bytes per entry,
+// { (col - group_base) << 14 | slot }, the value is folded into z[c] = colval[c] (x) x[c] once per run.
+// Two consecutive groups are stored lane-interleaved so that one 8-byte-per-lane read fetches both
+// (.x = entry `lane` of the even group, .y = of the odd group); group counts per unit are even.
+template <int OP, int MASK, int UC, int UH>   // UC cold PAIRS and UH hot PAIRS per wavefront iteration
+__global__ __launch_bounds__(kThreads) void spmv_rbcs_pat_kernel(SpmvArgs a) {
+    using TL = Tile<OP>;
+    using T = typename TL::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
+    T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);
+
+    const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
+    const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
+    const uint32_t nhub = dh.y, nhotg = dh.z;
+    const uint32_t nslots = nrows + kHubSlots * nhub;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    if (UH > 0)
+        for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];
+    for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
     __syncthreads();
 
-    if (nhub) {   // fold the private slots of every hub row back into its row
-        if (threadIdx.x < nhub) {
-            const uint32_t r = a.hub_rows[hub_off + threadIdx.x];
-            T acc = tile[r];
+    const uint2 *pairs = a.entries;                  // pair P = groups 2P, 2P+1; g0, ncold, nhotg are even
+    const uint32_t pc0 = g0 >> 1, npc = ncold >> 1, ph0 = (g0 + ncold) >> 1, nph = nhotg >> 1;
+    uint32_t pc = wave, ph = wave;
+    while (pc < npc || (UH > 0 && ph < nph)) {
+        uint2 ec[UC];
+        uint32_t bc[UC][2];
+        uint2 eh[UH > 0 ? UH : 1];
 #pragma unroll
-            for (uint32_t k = 0; k < kHubSlots; k++) acc = TL::comb(acc, tile[nrows + kHubSlots * threadIdx.x + k]);
-            tile[r] = acc;
+        for (int u = 0; u < UC; u++) {
+            const uint32_t pi = pc + u * kWaves;
+            const bool in = pi < npc;
+            ec[u] = in ? load_stream_nt(pairs + (size_t)(pc0 + pi) * 64u + lane) : make_uint2(kRowPad, kRowPad);
+            bc[u][0] = in ? a.bases[g0 + 2u * pi] : 0u;
+            bc[u][1] = in ? a.bases[g0 + 2u * pi + 1u] : 0u;
         }
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UH; u++) {
+            const uint32_t pi = ph + u * kWaves;
+            eh[u] = (pi < nph) ? load_stream_nt(pairs + (size_t)(ph0 + pi) * 64u + lane) : make_uint2(kRowPad, kRowPad);
+        }
+        float xc[UC][2];
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            xc[u][0] = a.z[bc[u][0] + (ec[u].x >> kRowBits)];
+            xc[u][1] = a.z[bc[u][1] + (ec[u].y >> kRowBits)];
+        }
+#pragma unroll
+        for (int u = 0; u < UH; u++) {
+            const uint32_t r0 = eh[u].x & kRowPad, r1 = eh[u].y & kRowPad;
+            if (r0 != kRowPad) TL::accz(tile, r0, hot_x[eh[u].x >> kRowBits]);
+            if (r1 != kRowPad) TL::accz(tile, r1, hot_x[eh[u].y >> kRowBits]);
+        }
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const uint32_t r0 = ec[u].x & kRowPad, r1 = ec[u].y & kRowPad;
+            if (r0 != kRowPad) TL::accz(tile, r0, xc[u][0]);
+            if (r1 != kRowPad) TL::accz(tile, r1, xc[u][1]);
+        }
+        pc += kWaves * UC;
+        ph += kWaves * (UH > 0 ? UH : 1);
     }
+    spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
+}
 
-    if (direct) {
-        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
-            const uint32_t row = row0 + i;
-            float out = TL::finish(a.zero, TL::get(tile, i));
-            if (MASK != GL_NOMASK) {
-                // masked-off rows are literal 0, and the mask is compared with 0 (spmv_module.h:518-530)
-                if (!mask_allows<MASK>(a.mask[row], 0.0f)) out = 0.0f;
-            }
-            a.y[row] = out;
-        }
-    } else {
-        // split block: this unit's tile goes to its segment plane; spmv_combine_kernel folds the planes in
-        // segment order (deterministic, no atomics) and applies zero / mask
-        float *plane = a.partials + (size_t)dh.w * a.prow + (row0 - a.row_begin);
-        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) plane[i] = TL::get(tile, i);
+// z = colval (x) x for every column, and the hot table from the same products
+template <int OP>
+__global__ __launch_bounds__(256) void spmv_prescale_kernel(const float *__restrict__ x, const float *__restrict__ colval,
+                                                            float *__restrict__ z, uint32_t num_cols,
+                                                            const uint32_t *__restrict__ hot_cols, float *__restrict__ hot_x,
+                                                            uint32_t nhot) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < num_cols) z[i] = Semiring<OP>::mul(colval[i], x[i]);
+    if (i < nhot) {
+        const uint32_t c = hot_cols[i];
+        hot_x[i] = Semiring<OP>::mul(colval[c], x[c]);
     }
 }
 
@@ -258,6 +359,18 @@ static int launch_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStre
     return GL_OK;
 }
 
+template <int OP, int MASK, int UC, int UH>
+static int launch_pat_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_pat_kernel<OP, MASK, UC, UH>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set = true;
+    }
+    spmv_rbcs_pat_kernel<OP, MASK, UC, UH><<<p->nunits, kThreads, lds, s>>>(a);
+    return GL_OK;
+}
+
 template <int OP, int MASK>
 static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     const uint32_t rows = p->row_end - p->row_begin;
@@ -268,7 +381,11 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
         GL_LAUNCH_CHECK();
         return GL_OK;
     }
-    if (p->nhot) {
+    if (p->pattern) {
+        spmv_prescale_kernel<OP><<<cdiv(std::max(p->num_cols, p->nhot), 256), 256, 0, s>>>(a.x, p->d_colval, p->d_z, p->num_cols,
+                                                                                            p->d_hot_cols, p->d_hot_x, p->nhot);
+        GL_LAUNCH_CHECK();
+    } else if (p->nhot) {
         spmv_hot_gather_kernel<<<cdiv(p->nhot, 256), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot);
         GL_LAUNCH_CHECK();
     }
@@ -280,6 +397,15 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     const bool timed = pf.on && 2ull * (pf.used + 1) <= pf.events.size();
     if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
     int rc;
+    if (p->pattern) {
+        switch (p->mix) {   // cold pairs, hot pairs per iteration
+            case 0: rc = launch_pat_variant<OP, MASK, 3, 0>(p, a, lds, s); break;
+            case 2: rc = launch_pat_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
+            case 3: rc = launch_pat_variant<OP, MASK, 3, 1>(p, a, lds, s); break;
+            case 4: rc = launch_pat_variant<OP, MASK, 1, 1>(p, a, lds, s); break;
+            default: rc = launch_pat_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
+        }
+    } else
     switch (p->mix) {
         case 1: rc = launch_variant<OP, MASK, 3, 1>(p, a, lds, s); break;
         case 2: rc = launch_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
@@ -538,6 +664,26 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     const uint32_t nhot_table = have_hot ? (uint32_t)((hot_cols.size() + 63) / 64 * 64) : 0u;
     if (have_hot) hot_cols.resize(nhot_table, hot_cols[0]);   // pad the table to whole wavefronts
 
+    // ---- pattern plan?  every column's stored values are bitwise equal (unweighted graphs, out-degree
+    //      normalised PageRank matrices, bench_spmv's 1/num_rows): the stream then carries no values
+    std::vector<uint32_t> colbits;
+    bool pattern = false;
+    if (nnz > 0 && !(flags & GL_PLAN_KEEP_VALUES) && gl::env_long("GRAPHLILY_SPMV_PATTERN", 1) != 0) {
+        colbits.assign(num_cols, 0u);
+        int mismatch = 0, oob = 0;
+        // pass 1: any writer wins (all of a column's writers agree if the column is constant); pass 2 verifies
+#pragma omp parallel for schedule(static) reduction(| : oob)
+        for (int64_t i = (int64_t)nz0; i < (int64_t)nz1; i++) {
+            if (h_indices[i] >= num_cols) { oob = 1; continue; }
+            __atomic_store_n(&colbits[h_indices[i]], __builtin_bit_cast(uint32_t, h_data[i]), __ATOMIC_RELAXED);
+        }
+#pragma omp parallel for schedule(static) reduction(| : mismatch)
+        for (int64_t i = (int64_t)nz0; i < (int64_t)nz1; i++)
+            if (h_indices[i] < num_cols && colbits[h_indices[i]] != __builtin_bit_cast(uint32_t, h_data[i])) mismatch = 1;
+        pattern = !mismatch && !oob;
+    }
+    const uint32_t group_mult = pattern ? 2u : 1u;   // pattern units hold whole PAIRS of groups
+
     // ---- group budget per unit (upper bound), so every block can be emitted independently;
     //      units are numbered segment-major: u = s * nblocks + b
     std::vector<uint64_t> unit_goff((size_t)nunits + 1, 0);
@@ -546,7 +692,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         const uint32_t S = seg[b];
         for (uint32_t s = 0; s < S; s++) {
             const uint64_t c0 = m * s / S, c1 = m * (s + 1) / S;
-            unit_goff[(size_t)unit_of[s][b] + 1] = (c1 - c0 + 63) / 64 + jump_slack;
+            unit_goff[(size_t)unit_of[s][b] + 1] = ((c1 - c0 + 63) / 64 + jump_slack + 3u) / 2u * 2u;   // even
         }
     }
     for (size_t i = 0; i < (size_t)nunits; i++) unit_goff[i + 1] += unit_goff[i];
@@ -630,6 +776,12 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
                 }
                 if (g > unit_goff[u])
                     for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
+                auto pad_group = [&]() {   // an all-padding group keeps the count a multiple of group_mult
+                    bases[g] = 0;
+                    for (uint32_t k = 0; k < 64; k++) entries[g * 64 + k] = make_uint2(gl::kRowPad, 0u);
+                    g++;
+                };
+                while ((g - unit_goff[u]) % group_mult) pad_group();
                 const uint32_t ncold = (uint32_t)(g - unit_goff[u]);
                 const uint64_t gh0 = g, mh = hot.size();
                 fill = 64;
@@ -644,6 +796,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
                 }
                 if (g > gh0)
                     for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
+                while ((g - gh0) % group_mult) pad_group();
                 units[2 * u] = make_uint4((uint32_t)unit_goff[u], ncold, r0, (r1 - r0) | (all_direct ? 0x80000000u : 0u));
                 units[2 * u + 1] = make_uint4((uint32_t)((size_t)b * gl::kMaxHubRows), hub_count[b], (uint32_t)(g - gh0), s);
             }
@@ -677,7 +830,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         // measured (orkut / products / hollywood / pokec stand-ins): the balanced 3 cold + 3 hot groups per
         // iteration is best or within noise of the best everywhere; lopsided mixes starve one stream
         const long forced = gl::env_long("GRAPHLILY_SPMV_MIX", -1);
-        p->mix = !have_hot ? 0 : (forced >= 0 ? (int)forced : 5);
+        p->mix = !have_hot ? 0 : (forced >= 0 ? (int)forced : (pattern ? 1 : 5));
     }
     auto up = [&](void **d, const void *h, size_t bytes) -> int {
         GL_HIP(hipMalloc(d, bytes ? bytes : 16));
@@ -685,6 +838,16 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         p->device_bytes += bytes;
         return GL_OK;
     };
+    p->pattern = pattern;
+    if (pattern) {
+        // 4-byte entries; pair P = groups 2P (-> .x) and 2P+1 (-> .y), lane-interleaved.  In place: the pair's
+        // 128 uint2 shrink into the first 64 uint2 slots of the array (reads stay ahead of writes).
+        const uint64_t npairs = total_groups / 2;
+        for (uint64_t P = 0; P < npairs; P++)
+            for (uint32_t l = 0; l < 64; l++)
+                entries[P * 64 + l] = make_uint2(entries[(2 * P) * 64 + l].x, entries[(2 * P + 1) * 64 + l].x);
+        entries.resize(npairs * 64);
+    }
     int rc;
     if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * sizeof(uint2))) != GL_OK ||
         (rc = up((void **)&p->d_bases, bases.data(), bases.size() * sizeof(uint32_t))) != GL_OK ||
@@ -695,6 +858,20 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         (rc = up((void **)&p->d_hot_x, nullptr, 0)) != GL_OK) {
         gl_spmv_plan_destroy(p);
         return rc;
+    }
+    if (pattern) {
+        std::vector<float> colval(num_cols);
+        memcpy(colval.data(), colbits.data(), (size_t)num_cols * 4u);
+        if ((rc = up((void **)&p->d_colval, colval.data(), (size_t)num_cols * 4u)) != GL_OK) {
+            gl_spmv_plan_destroy(p);
+            return rc;
+        }
+        hipError_t he = hipMalloc((void **)&p->d_z, (size_t)std::max<uint32_t>(num_cols, 1u) * sizeof(float));
+        if (he != hipSuccess) {
+            gl_spmv_plan_destroy(p);
+            return gl::set_error(GL_ERR_HIP, "gl_spmv_plan_create: hipMalloc(z): %s", hipGetErrorString(he));
+        }
+        p->device_bytes += (size_t)num_cols * sizeof(float);
     }
     if (Smax > 1) {
         const size_t bytes = (size_t)Smax * rows * sizeof(float);
@@ -728,6 +905,8 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_hot_x);
     (void)hipFree(p->d_spans);
     (void)hipFree(p->d_blocks);
+    (void)hipFree(p->d_colval);
+    (void)hipFree(p->d_z);
     (void)hipFree(p->d_partials);
     (void)hipFree(p->d_xbits);
     delete p;
@@ -747,6 +926,12 @@ int gl_spmv_plan_hot(gl_spmv_plan p, uint32_t *hot_columns, uint64_t *hot_nnz, i
     if (hot_columns) *hot_columns = p->nhot;
     if (hot_nnz) *hot_nnz = p->hot_nnz;
     if (mix) *mix = p->mix;
+    return GL_OK;
+}
+
+int gl_spmv_plan_layout(gl_spmv_plan p, int *layout) {
+    GL_ARG(p != nullptr && layout != nullptr);
+    *layout = p->boolean ? GL_LAYOUT_BOOLEAN : (p->pattern ? GL_LAYOUT_PATTERN : GL_LAYOUT_GENERAL);
     return GL_OK;
 }
 
@@ -787,6 +972,7 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     a.mask = d_mask;
     a.y = d_y;
     a.zero = zero;
+    a.z = p->d_z;
     a.partials = p->d_partials;
     a.prow = p->row_end - p->row_begin;
     a.row_begin = p->row_begin;

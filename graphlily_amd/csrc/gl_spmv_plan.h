@@ -91,6 +91,8 @@ struct gl_spmv_plan_s {
     int mix = 0;               // cold/hot groups per iteration: 0 = (4,0) no hot table, 5 = (3,3) default; others for tuning
     uint32_t *d_hot_cols = nullptr;
     float *d_hot_x = nullptr;
+    bool pattern = false;            // every column's values are equal: 4-byte entries, z = colval (x) x per run
+    float *d_colval = nullptr, *d_z = nullptr;
     uint4 *d_blocks = nullptr;       // {first row, #rows, #segments, -} per row block
     float *d_partials = nullptr;     // split plans: segments x rows planes of per-unit tiles
     uint32_t max_plain_rows = 0;     // tallest block without hub slots

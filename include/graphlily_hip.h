@@ -101,6 +101,12 @@ int gl_spmv_plan_create(gl_spmv_plan *plan,
  * general plan's.  Running such a plan with another semiring returns GL_ERR_UNSUPPORTED.  Implies
  * GL_PLAN_NO_MULADD when the general layout has to be used (more than 8 x 1 179 648 columns). */
 #define GL_PLAN_BOOLEAN 2u
+/* Matrices whose stored values are equal within every column (unweighted graphs, out-degree-normalised
+ * PageRank matrices, bench_spmv's constant 1/num_rows) are detected at plan creation and kept as a
+ * "pattern plan": 4 bytes per entry, the column value is folded into z[c] = colval[c] (x) x[c] by one
+ * extra pass over x per run -- the same float products as the general layout, hence the same results.
+ * GL_PLAN_KEEP_VALUES switches the detection off (8-byte {index,value} entries whatever the values are). */
+#define GL_PLAN_KEEP_VALUES 4u
 int gl_spmv_plan_create_ex(gl_spmv_plan *plan,
                            uint32_t num_rows, uint32_t num_cols,
                            const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
@@ -111,6 +117,12 @@ int gl_spmv_plan_info(gl_spmv_plan plan, uint64_t *nnz, uint64_t *device_bytes, 
 /* decomposition chosen by the planner: row blocks x column segments, tallest block, 64-entry groups */
 int gl_spmv_plan_shape(gl_spmv_plan plan, uint32_t *blocks, uint32_t *segments, uint32_t *max_block_rows,
                        uint64_t *groups);
+/* which device layout the plan holds: 8-byte {index,value} entries, 4-byte pattern entries with per-column
+ * values, or the (||,&&)-only bit layout */
+#define GL_LAYOUT_GENERAL 0
+#define GL_LAYOUT_PATTERN 1
+#define GL_LAYOUT_BOOLEAN 2
+int gl_spmv_plan_layout(gl_spmv_plan plan, int *layout);
 /* hot-column cache: columns whose x value is kept in LDS, the non-zeros they serve, and the cold/hot
  * interleave in use (0 = no hot table, 5 = 3 cold + 3 hot groups per wavefront iteration) */
 int gl_spmv_plan_hot(gl_spmv_plan plan, uint32_t *hot_columns, uint64_t *hot_nnz, int *mix);

@@ -236,6 +236,53 @@ def test_boolean_plan_phases_and_odd_values(gpu, monkeypatch):
     assert np.array_equal(dy.read(np.float32, n_rows), dy2.read(np.float32, n_rows))
 
 
+@pytest.mark.parametrize("kind", ["uniform", "per_column", "per_column_with_zeros"])
+def test_pattern_plan_matches_general_layout(gpu, kind, monkeypatch):
+    """Matrices whose values are equal within every column are kept as 4-byte pattern entries and
+    z = colval (x) x is formed once per run.  The products are the same floats as in the general layout
+    (GL_PLAN_KEEP_VALUES), so (min,+) and (||,&&) must agree bit for bit and (+,x) within the usual
+    accumulation-order tolerance; all of them must match the oracle."""
+    from graphlily_amd import capi
+    m = spmv_prepare("rmat_sym_50K")
+    rng = np.random.default_rng(17)
+    if kind == "uniform":
+        m.adj_data = np.full(m.nnz, np.float32(1.0 / m.num_rows), np.float32)
+    else:
+        colval = (rng.integers(1, 40, size=m.num_cols) / np.float32(7)).astype(np.float32)
+        if kind == "per_column_with_zeros":
+            colval[rng.integers(0, m.num_cols, size=m.num_cols // 10)] = 0.0
+        m.adj_data = colval[m.adj_indices[:m.nnz]]
+    x = np.where(rand01(m.num_cols, 2) > 0, rng.random(m.num_cols, dtype=np.float32) + np.float32(0.5), 0).astype(np.float32)
+    mask = rand01(m.num_rows, 3)
+    dx, dm = capi.DeviceBuffer(4 * m.num_cols), capi.DeviceBuffer(4 * m.num_rows)
+    dx.write(x)
+    dm.write(mask)
+    for shape in ((0, 0), (6, 3)):
+        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
+        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        pat = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data)
+        gen = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=capi.GL_PLAN_KEEP_VALUES)
+        assert pat.info()["layout"] == "pattern" and gen.info()["layout"] == "general"
+        assert pat.info()["device_bytes"] < 0.8 * gen.info()["device_bytes"]
+        for sem in ("Arithmetic", "Logical", "Tropical"):
+            op, zero = SEMIRINGS[sem]
+            for mk in MASKS:
+                a, b = capi.DeviceBuffer(4 * m.num_rows), capi.DeviceBuffer(4 * m.num_rows)
+                pat.run(dx, dm, a, op, zero, MASKS[mk])
+                gen.run(dx, dm, b, op, zero, MASKS[mk])
+                ya, yb = a.read(np.float32, m.num_rows), b.read(np.float32, m.num_rows)
+                what = "pattern %s %s %s %s" % (kind, shape, sem, mk)
+                if op != 0:
+                    assert np.array_equal(ya, yb), what
+                else:
+                    np.testing.assert_allclose(ya, yb, rtol=2e-6, atol=0, err_msg=what)
+                _check(ya, m, sem, mk, x, mask, what)
+    # a single differing entry inside one column turns the detection off
+    m.adj_data = m.adj_data.copy()
+    m.adj_data[m.nnz // 2] += np.float32(1.0)
+    assert capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data).info()["layout"] == "general"
+
+
 def test_row_shards_compose(gpu):
     """Two row shards write disjoint slices of one y: the multi-GPU decomposition on one device."""
     m = spmv_prepare("rmat_20K")
