@@ -56,29 +56,44 @@ def main():
         m = raw.copy()
         m.adj_data = np.full(m.nnz, np.float32(1.0 / m.num_rows), dtype=np.float32)
         io.util_round_csr_matrix_dim(m, 128, 8)
-        plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data)
         x = torch.randint(0, 2, (m.num_cols,), device=dev).float()
+        mask = torch.randint(0, 2, (m.num_rows,), device=dev).float()
         y = torch.zeros(m.num_rows, device=dev)
-        bx, by = capi.DeviceBuffer.from_torch(x), capi.DeviceBuffer.from_torch(y)
-        for _ in range(2):
-            plan.run(bx, None, by, 0, 0.0, 0)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(100):
-            plan.run(bx, None, by, 0, 0.0, 0)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 100
+        bx, bm, by = (capi.DeviceBuffer.from_torch(t) for t in (x, mask, y))
         nbytes = 8 * m.nnz + 4 * (m.num_rows + 1) + 4 * m.num_cols + 4 * m.num_rows
         rs = np.random.default_rng(0).integers(0, m.num_rows, size=1000)
         ip = m.adj_indptr.astype(np.int64)
         xs = x.cpu().numpy().astype(np.float64)
         chk = np.array([np.dot(m.adj_data[ip[r]:ip[r + 1]].astype(np.float64), xs[m.adj_indices[ip[r]:ip[r + 1]]]) for r in rs])
-        rec["spmv"] = {"ms": round(ms, 4), "gteps": round(m.nnz / ms / 1e6, 1), "eff_gbps": round(nbytes / ms / 1e6, 1),
-                       "frac_hbm_peak": round(nbytes / ms / 1e6 / 8000, 4), "shape": plan.info(),
-                       "ok": bool(np.allclose(y.cpu().numpy()[rs], chk, rtol=1e-5, atol=1e-12))}
-        del plan, bx, by, x, y, m
+
+        def spmv_line(flags, op, zero, mask_type):
+            plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=flags)
+            mk = bm if mask_type else None
+            for _ in range(2):
+                plan.run(bx, mk, by, op, zero, mask_type)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100):
+                plan.run(bx, mk, by, op, zero, mask_type)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 100
+            line = {"ms": round(ms, 4), "gteps": round(m.nnz / ms / 1e6, 1), "layout": plan.info()["layout"],
+                    "device_bytes": plan.info()["device_bytes"]}
+            if op == 0:
+                line["ok"] = bool(np.allclose(y.cpu().numpy()[rs], chk, rtol=1e-5, atol=1e-12))
+            return line, plan.info()
+
+        # headline: the general layout (values streamed), 8 B/nnz algorithmic bytes against the HBM peak
+        line, shape = spmv_line(capi.GL_PLAN_KEEP_VALUES, 0, 0.0, 0)
+        line.update({"eff_gbps": round(nbytes / line["ms"] / 1e6, 1), "frac_hbm_peak": round(nbytes / line["ms"] / 1e6 / 8000, 4),
+                     "shape": shape})
+        rec["spmv"] = line
+        # what the default plan does with this constant-valued matrix, and the (||,&&) layout BFS pulls with
+        rec["spmv_pattern"] = spmv_line(0, 0, 0.0, 0)[0]
+        rec["spmv_boolean_masked"] = spmv_line(capi.GL_PLAN_BOOLEAN, 1, 0.0, 1)[0]
+        del bx, bm, by, x, mask, y, m
         # ---- BFS
         deg = np.diff(raw.adj_indptr.astype(np.int64))
         src = 0 if deg[0] > 0 else int(np.argmax(deg > 0))

@@ -403,6 +403,10 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
             case 2: rc = launch_pat_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
             case 3: rc = launch_pat_variant<OP, MASK, 3, 1>(p, a, lds, s); break;
             case 4: rc = launch_pat_variant<OP, MASK, 1, 1>(p, a, lds, s); break;
+            case 5: rc = launch_pat_variant<OP, MASK, 4, 2>(p, a, lds, s); break;
+            case 6: rc = launch_pat_variant<OP, MASK, 3, 2>(p, a, lds, s); break;
+            case 7: rc = launch_pat_variant<OP, MASK, 4, 1>(p, a, lds, s); break;
+            case 8: rc = launch_pat_variant<OP, MASK, 6, 0>(p, a, lds, s); break;
             default: rc = launch_pat_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
         }
     } else
@@ -830,7 +834,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         // measured (orkut / products / hollywood / pokec stand-ins): the balanced 3 cold + 3 hot groups per
         // iteration is best or within noise of the best everywhere; lopsided mixes starve one stream
         const long forced = gl::env_long("GRAPHLILY_SPMV_MIX", -1);
-        p->mix = !have_hot ? 0 : (forced >= 0 ? (int)forced : (pattern ? 1 : 5));
+        p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : (pattern ? 1 : 5));   // 0 would skip the hot groups
     }
     auto up = [&](void **d, const void *h, size_t bytes) -> int {
         GL_HIP(hipMalloc(d, bytes ? bytes : 16));
