@@ -50,6 +50,8 @@ struct SpmvArgs {
     float *y;
     float zero;
     const float *z;           // pattern plans: colval (x) x, written by spmv_prescale_kernel
+    const float *diag;        // pattern plans with diagonal exceptions: A[r][r] per local row, folded in by the epilogue
+    const uint32_t *diag_has; // bit per local row: the row has a diagonal entry that differs from its column's value
     float *partials;          // [segment][row - row_begin] per-unit tiles of split blocks (combined by spmv_combine_kernel)
     uint32_t prow;            // rows per segment plane
     uint32_t row_begin;
@@ -66,6 +68,7 @@ struct Tile<GL_OP_MULADD> {
         // float product as in the reference (spmv_module.h:495), f64 accumulation
         __hip_atomic_fetch_add(&t[r], (double)(a * xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    __device__ static T lift(float z) { return (double)z; }
     __device__ static void accz(T *t, uint32_t r, float z) {   // z = a (x) x already formed (pattern plans)
         __hip_atomic_fetch_add(&t[r], (double)z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -82,6 +85,7 @@ struct Tile<GL_OP_ANDOR> {
     __device__ static void acc(T *t, uint32_t r, float a, float xv) {
         if (a != 0.0f && xv != 0.0f) t[r] = 1.0f;   // every writer stores the same value
     }
+    __device__ static T lift(float z) { return z != 0.0f ? 1.0f : 0.0f; }
     __device__ static void accz(T *t, uint32_t r, float z) {
         if (z != 0.0f) t[r] = 1.0f;
     }
@@ -104,6 +108,7 @@ struct Tile<GL_OP_ADDMIN> {
     using T = float;
     __device__ static T ident() { return __builtin_inff(); }
     __device__ static void acc(T *t, uint32_t r, float a, float xv) { atomic_min_f32_as_int(&t[r], a + xv); }
+    __device__ static T lift(float z) { return z; }
     __device__ static void accz(T *t, uint32_t r, float z) { atomic_min_f32_as_int(&t[r], z); }
     __device__ static T comb(T x, T y) { return (y < x) ? y : x; }
     __device__ static float get(const T *t, uint32_t r) { return t[r]; }
@@ -134,6 +139,11 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
     if (direct) {
         for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
             const uint32_t row = row0 + i;
+            if (a.diag_has) {   // diagonal entries kept out of the stream (pattern plans, e.g. SSSP's zero self edges)
+                const uint32_t lr = row - a.row_begin;
+                if ((a.diag_has[lr >> 5] >> (lr & 31u)) & 1u)
+                    tile[i] = TL::comb(tile[i], TL::lift(Semiring<OP>::mul(a.diag[lr], a.x[row])));
+            }
             float out = TL::finish(a.zero, TL::get(tile, i));
             if (MASK != GL_NOMASK) {
                 // masked-off rows are literal 0, and the mask is compared with 0 (spmv_module.h:518-530)
@@ -320,19 +330,24 @@ __global__ __launch_bounds__(256) void spmv_init_kernel(uint32_t r0, uint32_t r1
 template <int OP, int MASK>
 __global__ __launch_bounds__(256) void spmv_combine_kernel(const uint4 *__restrict__ blocks, const float *__restrict__ partials,
                                                            uint32_t prow, uint32_t row_begin, const float *__restrict__ mask,
-                                                           float *__restrict__ y, float zero) {
+                                                           float *__restrict__ y, float zero, const float *__restrict__ x,
+                                                           const float *__restrict__ diag, const uint32_t *__restrict__ diag_has) {
     const uint4 b = blocks[blockIdx.y];   // {first row, #rows, #segments, -}
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < b.y; i += gridDim.x * 256u) {
         const uint32_t row = b.x + i;
         const float *p = partials + (row - row_begin);
+        const uint32_t lr = row - row_begin;
+        const bool has_diag = diag_has && ((diag_has[lr >> 5] >> (lr & 31u)) & 1u);
         float s;
         if (OP == GL_OP_MULADD) {
             double acc = 0.0;
             for (uint32_t k = 0; k < b.z; k++) acc += (double)p[(size_t)k * prow];
+            if (has_diag) acc += (double)(diag[lr] * x[row]);
             s = (float)acc;
         } else {
             float acc = Semiring<OP>::ident(zero);
             for (uint32_t k = 0; k < b.z; k++) acc = Semiring<OP>::add(acc, p[(size_t)k * prow]);
+            if (has_diag) acc = Semiring<OP>::add(acc, Semiring<OP>::mul(diag[lr], x[row]));
             s = acc;
         }
         float out = Tile<OP>::finish(zero, s);
@@ -427,7 +442,8 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     }
     if (p->segments > 1) {
         const dim3 grid(std::max<unsigned>(1u, std::min<unsigned>(cdiv(p->max_plain_rows, 256), 64u)), p->nblocks);
-        spmv_combine_kernel<OP, MASK><<<grid, 256, 0, s>>>(p->d_blocks, p->d_partials, rows, p->row_begin, a.mask, a.y, a.zero);
+        spmv_combine_kernel<OP, MASK><<<grid, 256, 0, s>>>(p->d_blocks, p->d_partials, rows, p->row_begin, a.mask, a.y, a.zero, a.x,
+                                                             a.diag, a.diag_has);
         GL_LAUNCH_CHECK();
     }
     return GL_OK;
@@ -640,8 +656,9 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         if (forced > 1) H = std::min<uint32_t>(H, (uint32_t)forced);
         if (H) {
             std::vector<uint32_t> deg(num_cols, 0);
-            for (uint64_t i = nz0; i < nz1; i++) deg[h_indices[i]]++;
-            const uint32_t dmax = *std::max_element(deg.begin(), deg.end());
+            for (uint64_t i = nz0; i < nz1; i++)
+                if (h_indices[i] < num_cols) deg[h_indices[i]]++;   // out-of-range columns are reported below
+            const uint32_t dmax = num_cols ? *std::max_element(deg.begin(), deg.end()) : 0u;
             std::vector<uint32_t> hist((size_t)dmax + 2, 0);
             for (uint32_t c = 0; c < num_cols; c++) hist[deg[c]]++;
             // thr = smallest degree such that at most H columns have degree >= thr; a column must also
@@ -670,21 +687,43 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
 
     // ---- pattern plan?  every column's stored values are bitwise equal (unweighted graphs, out-degree
     //      normalised PageRank matrices, bench_spmv's 1/num_rows): the stream then carries no values
-    std::vector<uint32_t> colbits;
-    bool pattern = false;
+    std::vector<uint32_t> colbits, diag_has;
+    std::vector<float> diag_val;
+    bool pattern = false, diag_mode = false;
     if (nnz > 0 && !(flags & GL_PLAN_KEEP_VALUES) && gl::env_long("GRAPHLILY_SPMV_PATTERN", 1) != 0) {
+        // Diagonal entries are looked at separately: a matrix that is column-constant apart from its diagonal
+        // (SSSP's unit weights + zero self edges, app/sssp.h:16-62) keeps the pattern layout, the diagonal goes
+        // into a per-row array that the epilogue folds in.
         colbits.assign(num_cols, 0u);
-        int mismatch = 0, oob = 0;
+        diag_has.assign((size_t)(rows + 31) / 32, 0u);
+        diag_val.assign(rows, 0.0f);
+        int mismatch = 0;
+        uint64_t exceptions = 0;
         // pass 1: any writer wins (all of a column's writers agree if the column is constant); pass 2 verifies
-#pragma omp parallel for schedule(static) reduction(| : oob)
-        for (int64_t i = (int64_t)nz0; i < (int64_t)nz1; i++) {
-            if (h_indices[i] >= num_cols) { oob = 1; continue; }
-            __atomic_store_n(&colbits[h_indices[i]], __builtin_bit_cast(uint32_t, h_data[i]), __ATOMIC_RELAXED);
+#pragma omp parallel for schedule(static, 4096)
+        for (int64_t r = row_begin; r < (int64_t)row_end; r++)
+            for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
+                const uint32_t c = h_indices[i];
+                if (c < num_cols && c != (uint32_t)r)
+                    __atomic_store_n(&colbits[c], __builtin_bit_cast(uint32_t, h_data[i]), __ATOMIC_RELAXED);
+            }
+#pragma omp parallel for schedule(static, 4096) reduction(| : mismatch) reduction(+ : exceptions)
+        for (int64_t r = row_begin; r < (int64_t)row_end; r++) {   // 4096 rows = whole diag_has words per thread
+            uint32_t nexc = 0;
+            for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
+                const uint32_t c = h_indices[i], bits = __builtin_bit_cast(uint32_t, h_data[i]);
+                if (c >= num_cols) { mismatch = 1; continue; }
+                if (colbits[c] == bits) continue;             // a regular entry of its column (diagonal or not)
+                if (c != (uint32_t)r) { mismatch = 1; continue; }
+                nexc++;                                        // diagonal entry that differs from its column's value
+                diag_val[r - row_begin] = h_data[i];
+                diag_has[(r - row_begin) >> 5] |= 1u << ((r - row_begin) & 31);
+            }
+            if (nexc > 1) mismatch = 1;   // several different diagonal values in one row: keep the general layout
+            exceptions += nexc;
         }
-#pragma omp parallel for schedule(static) reduction(| : mismatch)
-        for (int64_t i = (int64_t)nz0; i < (int64_t)nz1; i++)
-            if (h_indices[i] < num_cols && colbits[h_indices[i]] != __builtin_bit_cast(uint32_t, h_data[i])) mismatch = 1;
-        pattern = !mismatch && !oob;
+        pattern = !mismatch;
+        diag_mode = pattern && exceptions > 0;
     }
     const uint32_t group_mult = pattern ? 2u : 1u;   // pattern units hold whole PAIRS of groups
 
@@ -726,6 +765,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
                     const uint32_t c = h_indices[i];
                     if (c >= num_cols) { bad = true; continue; }
                     const uint32_t v = __builtin_bit_cast(uint32_t, h_data[i]);
+                    if (diag_mode && c == r && v != colbits[c]) continue;   // the row's diagonal exception lives in diag_val
                     if (have_hot && hot_slot[c] != 0xffffffffu) hot.push_back(gl::Rec{hot_slot[c], r - r0, v});
                     else recs.push_back(gl::Rec{c, r - r0, v});
                 }
@@ -877,6 +917,13 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         }
         p->device_bytes += (size_t)num_cols * sizeof(float);
     }
+    if (diag_mode) {
+        if ((rc = up((void **)&p->d_diag, diag_val.data(), diag_val.size() * sizeof(float))) != GL_OK ||
+            (rc = up((void **)&p->d_diag_has, diag_has.data(), diag_has.size() * sizeof(uint32_t))) != GL_OK) {
+            gl_spmv_plan_destroy(p);
+            return rc;
+        }
+    }
     if (Smax > 1) {
         const size_t bytes = (size_t)Smax * rows * sizeof(float);
         hipError_t he = hipMalloc((void **)&p->d_partials, bytes);
@@ -910,6 +957,8 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_spans);
     (void)hipFree(p->d_blocks);
     (void)hipFree(p->d_colval);
+    (void)hipFree(p->d_diag);
+    (void)hipFree(p->d_diag_has);
     (void)hipFree(p->d_z);
     (void)hipFree(p->d_partials);
     (void)hipFree(p->d_xbits);
@@ -977,6 +1026,8 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     a.y = d_y;
     a.zero = zero;
     a.z = p->d_z;
+    a.diag = p->d_diag;
+    a.diag_has = p->d_diag_has;
     a.partials = p->d_partials;
     a.prow = p->row_end - p->row_begin;
     a.row_begin = p->row_begin;

@@ -93,6 +93,8 @@ struct gl_spmv_plan_s {
     float *d_hot_x = nullptr;
     bool pattern = false;            // every column's values are equal: 4-byte entries, z = colval (x) x per run
     float *d_colval = nullptr, *d_z = nullptr;
+    float *d_diag = nullptr;         // pattern plans whose diagonal differs from the column values: A[r][r] per local row
+    uint32_t *d_diag_has = nullptr;
     uint4 *d_blocks = nullptr;       // {first row, #rows, #segments, -} per row block
     float *d_partials = nullptr;     // split plans: segments x rows planes of per-unit tiles
     uint32_t max_plain_rows = 0;     // tallest block without hub slots

@@ -236,7 +236,7 @@ def test_boolean_plan_phases_and_odd_values(gpu, monkeypatch):
     assert np.array_equal(dy.read(np.float32, n_rows), dy2.read(np.float32, n_rows))
 
 
-@pytest.mark.parametrize("kind", ["uniform", "per_column", "per_column_with_zeros"])
+@pytest.mark.parametrize("kind", ["uniform", "per_column", "per_column_with_zeros", "sssp_self_edges", "diagonal_only_columns"])
 def test_pattern_plan_matches_general_layout(gpu, kind, monkeypatch):
     """Matrices whose values are equal within every column are kept as 4-byte pattern entries and
     z = colval (x) x is formed once per run.  The products are the same floats as in the general layout
@@ -247,6 +247,20 @@ def test_pattern_plan_matches_general_layout(gpu, kind, monkeypatch):
     rng = np.random.default_rng(17)
     if kind == "uniform":
         m.adj_data = np.full(m.nnz, np.float32(1.0 / m.num_rows), np.float32)
+    elif kind == "sssp_self_edges":
+        # unit weights + weight-0 self edges (app/sssp.h:16-62): column-constant apart from the diagonal, which the
+        # plan keeps per row and folds in after the sweep
+        io.sssp_add_self_edges(m)
+        assert (m.adj_data == 0).any() and (m.adj_data == 1).any()
+    elif kind == "diagonal_only_columns":
+        # an identity block (columns whose only entry is the diagonal) next to constant columns
+        import scipy.sparse as sp
+        n = m.num_rows
+        a = sp.csr_matrix((np.full(m.nnz, np.float32(0.25)), m.adj_indices[:m.nnz].astype(np.int64), m.adj_indptr.astype(np.int64)), shape=(n, m.num_cols)).tolil()
+        a.setdiag(np.float32(3.0))
+        a = a.tocsr()
+        a.sort_indices()
+        m = io.CSRMatrix(n, m.num_cols, a.data.astype(np.float32), a.indices.astype(np.uint32), a.indptr.astype(np.uint32))
     else:
         colval = (rng.integers(1, 40, size=m.num_cols) / np.float32(7)).astype(np.float32)
         if kind == "per_column_with_zeros":
