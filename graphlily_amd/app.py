@@ -203,6 +203,8 @@ class BFS(_GraphApp):
     def send_matrix_host_to_device(self):
         self.SpMV_.send_matrix_host_to_device()
         self.SpMSpV_.send_matrix_host_to_device()
+        if hasattr(self.SpMSpV_, "attach_pull"):
+            self.SpMSpV_.attach_pull(self.SpMV_)     # heavy frontiers of a push iteration go row-wise
 
     # -- pull ------------------------------------------------------------------------------------
     def _bind_pull(self, vector, distance):
@@ -242,6 +244,7 @@ class BFS(_GraphApp):
         B, n = self.backend, self.n_
         frontier = B.alloc(n + 1, capi.IDX_VAL)
         B.upload(B.view(frontier, 0, 2, 8), M.make_sparse_vec([source], [1.0]))
+        self._hint_frontier(1)
         distance = self._new_dense(n, 0.0, source, 1.0)
         local = B.alloc(n + 1, capi.IDX_VAL)        # this rank's slice of the next frontier
         self.SpMSpV_.bind_vector_buf(frontier)
@@ -251,14 +254,21 @@ class BFS(_GraphApp):
         self.SparseAssign_.bind_inout_buf(distance)
         return frontier, distance, local
 
+    def _hint_frontier(self, nnz):
+        if hasattr(self.SpMSpV_, "hint_vector_nnz"):
+            self.SpMSpV_.hint_vector_nnz(nnz)
+
     def _push_iteration(self, frontier, local, it):
         """SpMSpV on the shard, mark the newly reached vertices, publish the next frontier."""
         self.SpMSpV_.run()
         self.SparseAssign_.run(float(it + 1))
         if self.comm.distributed:
-            return self._gather_sparse(local, frontier, self.n_, self.semiring_.zero)
+            total = self._gather_sparse(local, frontier, self.n_, self.semiring_.zero)
+            self._hint_frontier(total)
+            return total
         nnz = self.SpMSpV_.get_results_nnz()
         self.backend.copy(frontier, local, 8 * (1 + nnz))   # app/bfs.h:149-152
+        self._hint_frontier(nnz)
         return nnz
 
     def push(self, source, num_iterations):

@@ -34,6 +34,7 @@ EXPORTS = [
     "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_run",
     "gl_prof_begin", "gl_prof_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
+    "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_last_direction",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
     "gl_assign_sparse_new_frontier", "gl_sparse_to_dense",
     "gl_host_csr2csc", "gl_npz_csr_open", "gl_npz_csr_read", "gl_npz_csr_close",
@@ -84,6 +85,7 @@ def lib():
         "gl_spmspv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmspv_plan_destroy": [vp], "gl_spmspv_plan_info": [vp, P(u64), P(u64)],
         "gl_spmspv_run": [vp, vp, vp, vp, i32, f32, i32],
+        "gl_spmspv_plan_attach_pull": [vp, vp], "gl_spmspv_plan_hint": [vp, u32], "gl_spmspv_last_direction": [vp, P(i32)],
         "gl_sparse_nnz": [vp, P(u32)],
         "gl_ewise_add": [vp, vp, u32, f32], "gl_assign_dense": [vp, vp, u32, f32, i32],
         "gl_assign_sparse": [vp, vp, f32, u32], "gl_assign_sparse_new_frontier": [vp, vp, vp, u32],
@@ -310,6 +312,20 @@ class SpMSpVPlan:
         nnz, nbytes = ctypes.c_uint64(0), ctypes.c_uint64(0)
         check(lib().gl_spmspv_plan_info(ctypes.c_void_p(self.handle), ctypes.byref(nnz), ctypes.byref(nbytes)))
         return {"nnz": nnz.value, "device_bytes": nbytes.value}
+
+    def attach_pull(self, spmv_plan):
+        """Let heavy (||,&&) frontiers run row-wise on a GL_PLAN_BOOLEAN SpMV plan of the same matrix."""
+        check(lib().gl_spmspv_plan_attach_pull(ctypes.c_void_p(self.handle),
+                                               ctypes.c_void_p(spmv_plan.handle) if spmv_plan is not None else None))
+        self._pull_keepalive = spmv_plan
+
+    def hint(self, vector_nnz_upper_bound):
+        check(lib().gl_spmspv_plan_hint(ctypes.c_void_p(self.handle), int(vector_nnz_upper_bound)))
+
+    def last_direction(self):
+        v = ctypes.c_int(0)
+        check(lib().gl_spmspv_last_direction(ctypes.c_void_p(self.handle), ctypes.byref(v)))
+        return "row-wise" if v.value else "scatter"
 
     def run(self, vector, mask, result, op, zero, mask_type):
         check(lib().gl_spmspv_run(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op),

@@ -27,7 +27,9 @@
 //     output buffer per call instead, kernel_spmspv_impl.h:505-516).
 #include "gl_common.h"
 #include "gl_compact.h"
+#include "gl_spmv_plan.h"
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -43,6 +45,12 @@ struct gl_spmspv_plan_s {
     uint32_t *d_queue_count = nullptr;  // [0] = chunks queued by the current run
     uint4 *d_queue = nullptr;           // chunk descriptors of long columns
     uint32_t queue_capacity = 0;
+    // direction switch inside the operator ((||,&&) only): a frontier whose columns hold more than 1/32 of the
+    // matrix is cheaper to apply row-wise with the attached boolean SpMV plan than to scatter
+    gl_spmv_plan pull = nullptr;        // not owned
+    uint32_t max_col_len = 0;           // longest column of the shard
+    uint64_t frontier_hint = ~0ull;     // caller's upper bound on the next run's vector nnz (~0 = unknown)
+    uint32_t *d_mode = nullptr;         // [0] 1 = this run goes row-wise, [1] block ticket, [2..3] work counter
     uint64_t device_bytes = 0;
 };
 
@@ -61,6 +69,7 @@ struct ScatterArgs {
     uint32_t queue_capacity;
     uint32_t row_begin;
     uint32_t num_cols;
+    const uint32_t *mode;    // non-null: skip the scatter when mode[0] != 0 (the run goes row-wise instead)
 };
 
 // ordered-integer trick: for IEEE floats, a >= 0 compares like int, a < 0 like reversed uint
@@ -121,6 +130,7 @@ __global__ __launch_bounds__(256) void spmspv_scatter_kernel(ScatterArgs a) {
     __shared__ float s_val[256];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_qbase;
+    if (a.mode && a.mode[0]) return;
     const uint32_t vnnz = a.vec[0].index;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(256) void spmspv_scatter_kernel(ScatterArgs a) {
 // queued chunks of long columns: one workgroup pass (256 threads x 16 coalesced entries) per chunk
 template <int OP>
 __global__ __launch_bounds__(256) void spmspv_queue_kernel(ScatterArgs a) {
+    if (a.mode && a.mode[0]) return;
     uint32_t nq = a.queue_count[0];
     if (nq > a.queue_capacity) nq = a.queue_capacity;
     for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
@@ -191,6 +202,45 @@ __global__ __launch_bounds__(256) void spmspv_queue_kernel(ScatterArgs a) {
             const uint2 rv = load_stream_nt(a.stream + c.x + k);
             scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), xv);
         }
+    }
+}
+
+// work of this run = sum of the lengths of the frontier's columns; the last block to finish sets the mode
+__global__ __launch_bounds__(256) void spmspv_work_kernel(const gl_idx_val *__restrict__ vec, const uint32_t *__restrict__ indptr,
+                                                          uint32_t num_cols, uint32_t *__restrict__ mode, uint64_t threshold) {
+    __shared__ unsigned long long s_sum[4];
+    const uint32_t vnnz = vec[0].index;
+    unsigned long long w = 0;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < vnnz; e += gridDim.x * 256u) {
+        const gl_idx_val iv = vec[1u + e];
+        if (iv.index < num_cols && iv.val != 0.0f) w += indptr[iv.index + 1u] - indptr[iv.index];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) w += __shfl_down(w, d);
+    if ((threadIdx.x & 63u) == 0) s_sum[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *total = reinterpret_cast<unsigned long long *>(mode + 2);
+        const unsigned long long mine = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        if (mine) atomicAdd(total, mine);
+        __threadfence();
+        if (atomicAdd(&mode[1], 1u) == gridDim.x - 1u) {   // last block: every partial sum has landed
+            const unsigned long long t = atomicAdd(total, 0ull);
+            mode[0] = t > threshold ? 1u : 0u;
+            mode[1] = 0u;
+            *total = 0ull;
+        }
+    }
+}
+
+// row-wise path: the frontier as a bit vector (the caller has zeroed `bits`)
+__global__ __launch_bounds__(256) void spmspv_frontier_bits_kernel(const gl_idx_val *__restrict__ vec, uint32_t num_cols,
+                                                                   uint32_t *__restrict__ bits, const uint32_t *__restrict__ mode) {
+    if (!mode[0]) return;
+    const uint32_t vnnz = vec[0].index;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < vnnz; e += gridDim.x * 256u) {
+        const gl_idx_val iv = vec[1u + e];
+        if (iv.index < num_cols && iv.val != 0.0f) atomicOr(&bits[iv.index >> 5], 1u << (iv.index & 31u));
     }
 }
 
@@ -256,8 +306,11 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
         }
     }
     indptr[num_cols] = (uint32_t)stream.size();
+    uint32_t max_col_len = 0;
+    for (uint32_t c = 0; c < num_cols; c++) max_col_len = std::max(max_col_len, indptr[c + 1] - indptr[c]);
 
     gl_spmspv_plan p = new gl_spmspv_plan_s();
+    p->max_col_len = max_col_len;
     p->num_rows = num_rows;
     p->num_cols = num_cols;
     p->row_begin = row_begin;
@@ -282,6 +335,8 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     if ((e = hipMalloc((void **)&p->d_queue, b_queue)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_queue_count, 16)) != hipSuccess) return fail(e);
     if ((e = hipMemset(p->d_queue_count, 0, 16)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_mode, 16)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(p->d_mode, 0, 16)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(p->d_indptr, indptr.data(), b_indptr, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if (b_stream && (e = hipMemcpy(p->d_stream, stream.data(), b_stream, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     p->device_bytes = b_indptr + b_stream + b_acc + b_counts + b_queue;
@@ -297,6 +352,7 @@ int gl_spmspv_plan_destroy(gl_spmspv_plan p) {
     (void)hipFree(p->d_counts);
     (void)hipFree(p->d_queue);
     (void)hipFree(p->d_queue_count);
+    (void)hipFree(p->d_mode);
     delete p;
     return GL_OK;
 }
@@ -326,7 +382,25 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
         p->acc_valid = true;
     }
 
+    // (||,&&) with an attached boolean SpMV plan: decide on the device which way this run goes
+    const long div = gl::env_long("GRAPHLILY_SPMSPV_PULL_DIV", 32);
+    const uint64_t threshold = div > 0 ? p->nnz / (uint64_t)div : 0ull;
+    bool may_pull = p->pull != nullptr && op == GL_OP_ANDOR && zero == 0.0f && nrows > 0 &&
+                    gl::env_long("GRAPHLILY_SPMSPV_PULL", 1) != 0;
+    // a caller that knows how many entries the vector holds (gl_spmspv_plan_hint) spares tiny frontiers the
+    // decision kernels: they cannot reach the threshold whatever their columns are
+    if (may_pull && p->frontier_hint != ~0ull && p->frontier_hint * (uint64_t)p->max_col_len <= threshold) may_pull = false;
+    p->frontier_hint = ~0ull;
+    if (may_pull) {
+        uint32_t wgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 4u);
+        gl::spmspv_work_kernel<<<wgrid ? wgrid : 1u, 256, 0, s>>>(d_vector, p->d_indptr, p->num_cols, p->d_mode, threshold);
+        GL_LAUNCH_CHECK();
+    } else if (p->pull != nullptr) {
+        GL_HIP(hipMemsetAsync(p->d_mode, 0, sizeof(uint32_t), s));   // gl_spmspv_last_direction: scatter
+    }
+
     gl::ScatterArgs a;
+    a.mode = may_pull ? p->d_mode : nullptr;
     a.indptr = p->d_indptr;
     a.stream = p->d_stream;
     a.vec = d_vector;
@@ -347,6 +421,17 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
         default: rc = gl::launch_scatter<GL_OP_ADDMIN>(a, grid, s); break;
     }
     if (rc != GL_OK) return rc;
+    if (may_pull) {
+        // row-wise: frontier -> bit vector -> boolean SpMV into the (all-zero) accumulator; both kernels return
+        // at once when the run is a scatter run
+        uint32_t *bits = gl::bool_plan_xbits(p->pull);
+        GL_HIP(hipMemsetAsync(bits, 0, gl::bool_plan_xbits_bytes(p->pull), s));
+        uint32_t bgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 8u);
+        gl::spmspv_frontier_bits_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(d_vector, p->num_cols, bits, p->d_mode);
+        GL_LAUNCH_CHECK();
+        rc = gl::bool_plan_run_bits(p->pull, p->d_acc - p->row_begin, p->d_mode, s);
+        if (rc != GL_OK) return rc;
+    }
 
     switch (mask_type) {
         case GL_NOMASK: {
@@ -362,6 +447,38 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
             return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count);
         }
     }
+}
+
+int gl_spmspv_plan_attach_pull(gl_spmspv_plan p, gl_spmv_plan pull) {
+    GL_ARG(p != nullptr);
+    if (pull == nullptr) {
+        p->pull = nullptr;
+        return GL_OK;
+    }
+    if (!pull->boolean)
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_attach_pull: the SpMV plan must hold the GL_PLAN_BOOLEAN layout");
+    if (pull->num_rows != p->num_rows || pull->num_cols != p->num_cols || pull->row_begin != p->row_begin ||
+        pull->row_end != p->row_end)
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_attach_pull: the two plans hold different matrices or row shards");
+    p->pull = pull;
+    return GL_OK;
+}
+
+int gl_spmspv_plan_hint(gl_spmspv_plan p, uint32_t vector_nnz_upper_bound) {
+    GL_ARG(p != nullptr);
+    p->frontier_hint = vector_nnz_upper_bound;
+    return GL_OK;
+}
+
+int gl_spmspv_last_direction(gl_spmspv_plan p, int *row_wise) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && row_wise != nullptr);
+    uint32_t m = 0;
+    hipStream_t s = gl::ctx().stream;
+    GL_HIP(hipMemcpyAsync(&m, p->d_mode, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+    *row_wise = (p->pull != nullptr && m != 0u) ? 1 : 0;
+    return GL_OK;
 }
 
 int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz) {

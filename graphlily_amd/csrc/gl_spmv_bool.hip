@@ -24,6 +24,7 @@ struct BoolArgs {
     const float *mask;
     float *y;
     float zero;
+    const uint32_t *run_flag;  // non-null: the launch is a no-op unless run_flag[0] != 0 (gl_spmspv_run's direction switch)
 };
 
 // x != 0 packed little-endian, 64 columns per wavefront step; words past num_cols are zero
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     uint32_t *tile = lds_words;                     // kBoolTileWords: one bit per row slot, slot 16383 = padding
     uint32_t *xw = lds_words + kBoolTileWords;      // kBoolPhaseWords
 
+    if (a.run_flag && load_const(a.run_flag) == 0u) return;
     const uint4 d = a.units[blockIdx.x];
     const uint32_t span0 = d.x, nspans = d.y, row0 = d.z;
     const uint32_t nrows = d.w & 0xffffu;
@@ -183,12 +185,33 @@ int bool_plan_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *
     a.mask = d_mask;
     a.y = d_y;
     a.zero = zero;
+    a.run_flag = nullptr;
     switch (mask_type) {
         case GL_NOMASK: return launch_bool<GL_NOMASK>(p, a, s);
         case GL_MASK_WRITETOZERO: return launch_bool<GL_MASK_WRITETOZERO>(p, a, s);
         case GL_MASK_WRITETOONE: return launch_bool<GL_MASK_WRITETOONE>(p, a, s);
         default: return set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid mask type %d", mask_type);
     }
+}
+
+uint32_t *bool_plan_xbits(gl_spmv_plan p) { return p->d_xbits; }
+size_t bool_plan_xbits_bytes(gl_spmv_plan p) { return (size_t)p->nphases * kBoolPhaseWords * 4u; }
+
+// gl_spmspv_run's row-wise path: x bits are already in place, no mask, zero = 0, output rows y[row_begin..row_end);
+// the kernels do nothing unless run_flag[0] != 0.  Split plans rely on y being all zero on entry.
+int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s) {
+    if (p->row_end == p->row_begin || !p->nunits) return GL_OK;
+    BoolArgs a;
+    a.entries = p->d_entries;
+    a.bases = p->d_bases;
+    a.units = p->d_units;
+    a.spans = p->d_spans;
+    a.xbits = p->d_xbits;
+    a.mask = nullptr;
+    a.y = d_y;
+    a.zero = 0.0f;
+    a.run_flag = run_flag;
+    return launch_bool<GL_NOMASK>(p, a, s);
 }
 
 // ------------------------------------------------------------------------------------- planner

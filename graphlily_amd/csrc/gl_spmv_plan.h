@@ -110,6 +110,9 @@ namespace gl {
 // gl_spmv_bool.hip
 int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data);
 int bool_plan_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, float zero, int mask_type, hipStream_t s);
+int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s);
+uint32_t *bool_plan_xbits(gl_spmv_plan p);
+size_t bool_plan_xbits_bytes(gl_spmv_plan p);
 // gl_spmv.hip: y initialisation for plans whose units fold into y
 int spmv_init_rows(int op, int mask_type, uint32_t r0, uint32_t r1, const float *mask, float *y, float zero, hipStream_t s);
 }  // namespace gl

@@ -150,8 +150,12 @@ class SpMVModule(BaseModule):
         # the semiring known at upload time sizes the LDS split (accumulators vs hot-column table); a later
         # switch to (+,x) on a plan built for the 4-byte semirings re-formats the matrix (see run())
         flags = self._plan_flags(self.semiring_.op)
+        for client in getattr(self, "pull_clients_", ()):   # the old plan is about to go away
+            client._attach(None)
         self.plan_ = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data,
                                    self.row_begin_, re, flags)
+        for client in getattr(self, "pull_clients_", ()):
+            client._attach(self)
 
     def send_matrix_host_to_device(self):
         m = self.csr_matrix_
@@ -238,10 +242,37 @@ class SpMSpVModule(BaseModule):
         self.results_buf = capi.DeviceBuffer(8 * (m.num_rows + 1))
         self.results_buf.write(np.zeros(m.num_rows + 1, dtype=IDX_VAL))
 
+        self._attach(getattr(self, "pull_module_", None))
+
+    def attach_pull(self, spmv_module):
+        """Extension (no counterpart in the reference): let heavy (||,&&) frontiers run row-wise on the boolean
+        plan of an SpMVModule that holds the same matrix and row shard (gl_spmspv_plan_attach_pull)."""
+        self.pull_module_ = spmv_module
+        if not hasattr(spmv_module, "pull_clients_"):
+            spmv_module.pull_clients_ = []
+        if self not in spmv_module.pull_clients_:
+            spmv_module.pull_clients_.append(self)
+        self._attach(spmv_module)
+
+    def hint_vector_nnz(self, nnz):
+        """Extension: the caller knows the next run's vector holds at most `nnz` entries (gl_spmspv_plan_hint)."""
+        if self.plan_ is not None:
+            self.plan_.hint(nnz)
+
+    def _attach(self, spmv_module):
+        if self.plan_ is None:
+            return
+        plan = getattr(spmv_module, "plan_", None) if spmv_module is not None else None
+        if plan is not None and plan.info()["layout"] == "boolean":
+            self.plan_.attach_pull(plan)
+        else:
+            self.plan_.attach_pull(None)
+
     def send_vector_host_to_device(self, vector):
         """The vector may be shorter than num_cols + 1; the device copy is always that long
         (spmspv_module.h:280, :379)."""
         vector = np.ascontiguousarray(vector, dtype=IDX_VAL)
+        self.hint_vector_nnz(int(vector["index"][0]) if vector.shape[0] else 0)
         self.vector_buf = capi.DeviceBuffer(8 * (self.get_num_cols() + 1))
         self.vector_buf.write(vector[:self.get_num_cols() + 1])
 

@@ -167,6 +167,19 @@ int gl_spmspv_plan_info(gl_spmspv_plan plan, uint64_t *nnz, uint64_t *device_byt
 int gl_spmspv_run(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask,
                   gl_idx_val *d_result, int op, float zero, int mask_type);
 
+/* Extension: direction switch inside the operator.  `pull` is a GL_PLAN_BOOLEAN SpMV plan over the same
+ * matrix and row shard (BFS holds both, app/bfs.h:83-99).  A (||,&&) run with zero == 0 whose frontier columns
+ * hold more than 1/32 of the matrix's non-zeros is then computed row-wise (frontier -> bit vector -> boolean
+ * SpMV into the dense accumulator) instead of being scattered; the decision is taken on the device, results
+ * are identical.  The SpMV plan is not owned and must outlive the attachment; NULL detaches. */
+int gl_spmspv_plan_attach_pull(gl_spmspv_plan plan, gl_spmv_plan pull);
+/* Optional: an upper bound on the number of entries of the NEXT run's input vector (the drivers know it from
+ * the previous iteration's gl_sparse_nnz).  Frontiers too small to reach the threshold whatever their columns
+ * are then skip the decision kernels.  One-shot: consumed by the next gl_spmspv_run. */
+int gl_spmspv_plan_hint(gl_spmspv_plan plan, uint32_t vector_nnz_upper_bound);
+/* which way the last run went (1 = row-wise).  Blocking; for tests and reports. */
+int gl_spmspv_last_direction(gl_spmspv_plan plan, int *row_wise);
+
 /* SpMSpVModule::get_results_nnz (module/spmspv_module.h:239-242): the one
  * device->host control read per push iteration.  Blocking. */
 int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz);

@@ -160,3 +160,46 @@ def test_golden_known_answers(gpu, golden_dir):
         for mn, mk in (("nomask", "NoMask"), ("wzero", "WriteToZero"), ("wone", "WriteToOne")):
             got, _ = _run(gpu, c, sem, mk, v, mask)
             assert got[:10].tolist() == S["spmspv"][on][mn], (on, mn)
+
+
+@pytest.mark.parametrize("shape", [(0, 0), (4, 3)])
+def test_direction_switch_inside_the_operator(gpu, shape, monkeypatch):
+    """With a boolean SpMV plan of the same matrix attached, a (||,&&) run whose frontier columns hold more
+    than 1/32 of the non-zeros goes row-wise (frontier -> bits -> boolean SpMV -> compaction) instead of being
+    scattered.  Both directions must give the oracle's result for every mask; zero-valued frontier entries
+    and zero-valued matrix entries take part in neither."""
+    monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
+    monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+    csr = named_matrix("rmat_sym_50K")
+    rng = np.random.default_rng(3)
+    csr.adj_data = rng.choice(np.array([1.0, 1.0, 0.0, 2.5], np.float32), size=csr.nnz)
+    csc = io.csr2csc(csr)
+    spmv = M.SpMVModule(16, 0, 0)
+    spmv.set_semiring(M.LogicalSemiring)
+    spmv.set_up_runtime()
+    spmv.load_and_format_matrix(csr, True)
+    spmv.send_matrix_host_to_device()
+    mask = rand01(csc.num_rows, 5)
+    for density, expect in ((0.0005, "scatter"), (0.3, "row-wise")):
+        idx = np.flatnonzero(rng.random(csc.num_cols) < density).astype(np.uint32)
+        vals = rng.choice(np.array([1.0, 0.0, 3.0], np.float32), size=idx.size)
+        v = M.make_sparse_vec(idx, vals)
+        for mk in MASKS:
+            mod = M.SpMSpVModule(0)
+            mod.set_semiring(M.LogicalSemiring)
+            mod.set_mask_type(MASKS[mk])
+            mod.set_up_runtime()
+            mod.load_and_format_matrix(csc)
+            mod.send_matrix_host_to_device()
+            mod.attach_pull(spmv)
+            mod.send_mask_host_to_device(mask)
+            mod.send_vector_host_to_device(v)
+            for rep in range(2):   # the second run finds the accumulator reset by the first
+                mod.run()
+                assert mod.plan_.last_direction() == expect
+                res = mod.send_results_device_to_host()
+                nnz = mod.get_results_nnz()
+                got = M.convert_sparse_vec_to_dense_vec(res, csc.num_rows, 0.0)
+                assert np.all(np.diff(res["index"][1:nnz + 1].astype(np.int64)) > 0)
+                ref = O.spmspv(to_oracle(csc), v, 1, 0.0, mask, MASKS[mk])
+                assert_parity(got, ref, 1, "direction %s %s run %d" % (expect, mk, rep))
