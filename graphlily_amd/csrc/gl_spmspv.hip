@@ -135,11 +135,14 @@ __global__ __launch_bounds__(256) void spmspv_scatter_kernel(ScatterArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    for (uint32_t batch = blockIdx.x * 256u; batch < vnnz; batch += gridDim.x * 256u) {
+    // a small frontier is spread over the whole grid (E entries per workgroup, down to one) -- a few hundred
+    // hub vertices would otherwise be served by one or two workgroups
+    const uint32_t E = min(256u, max(1u, (vnnz + gridDim.x - 1u) / gridDim.x));
+    for (uint32_t batch = blockIdx.x * E; batch < vnnz; batch += gridDim.x * E) {
         const uint32_t e = batch + threadIdx.x;
         uint32_t start = 0, deg = 0;
         float xv = 0.0f;
-        if (e < vnnz) {
+        if (threadIdx.x < E && e < vnnz) {
             const gl_idx_val iv = a.vec[1u + e];
             if (iv.index < a.num_cols) {
                 start = a.indptr[iv.index];
