@@ -395,7 +395,8 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
     if (may_pull && p->frontier_hint != ~0ull && p->frontier_hint * (uint64_t)p->max_col_len <= threshold) may_pull = false;
     p->frontier_hint = ~0ull;
     if (may_pull) {
-        uint32_t wgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 4u);
+        // few blocks: each ends with one atomic on the same ticket word
+        uint32_t wgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), 64u);
         gl::spmspv_work_kernel<<<wgrid ? wgrid : 1u, 256, 0, s>>>(d_vector, p->d_indptr, p->num_cols, p->d_mode, threshold);
         GL_LAUNCH_CHECK();
     } else if (p->pull != nullptr) {

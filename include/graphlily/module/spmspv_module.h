@@ -75,6 +75,7 @@ public:
     // the vector may be shorter than num_cols + 1; the device copy always has that many slots
     void send_vector_host_to_device(aligned_sparse_vec_t &vector) {
         std::copy(vector.begin(), vector.end(), vector_.begin());
+        if (!vector.empty()) hint_vector_nnz((uint32_t)vector[0].index);
         vector_buf = DeviceBuffer(sizeof(idx_val_t) * vector_.size());
         vector_buf.upload(vector_.data(), sizeof(idx_val_t) * vector_.size());
     }
@@ -87,6 +88,14 @@ public:
 
     void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }      // extension
     void bind_vector_buf(DeviceBuffer src_buf) { vector_buf = src_buf; }  // extension
+
+    // extensions (gl_spmspv_plan_attach_pull / gl_spmspv_plan_hint): a driver that also holds the matrix as a
+    // (||,&&) SpMVModule lets heavy frontiers run row-wise; pass SpMVModule::plan_handle() after BOTH modules
+    // have sent their matrices, and again if the SpMV module re-formats (semiring change).  nullptr detaches.
+    void attach_pull_plan(gl_spmv_plan spmv_plan) { GRAPHLILY_CHECK(gl_spmspv_plan_attach_pull(plan_, spmv_plan)); }
+    void hint_vector_nnz(uint32_t nnz) {
+        if (plan_) GRAPHLILY_CHECK(gl_spmspv_plan_hint(plan_, nnz));
+    }
 
     void run() {
         GRAPHLILY_CHECK(gl_spmspv_run(plan_, (const gl_idx_val *)vector_buf.ptr(),

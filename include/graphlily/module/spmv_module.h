@@ -74,6 +74,7 @@ public:
         sharded_ = true;
     }
 
+    gl_spmv_plan plan_handle() const { return plan_; }   // extension: for SpMSpVModule::attach_pull_plan
     uint32_t get_num_rows() { return csr_matrix_float_.num_rows; }
     uint32_t get_num_cols() { return csr_matrix_float_.num_cols; }
     uint32_t get_nnz() { return csr_matrix_float_.adj_indptr[csr_matrix_float_.num_rows]; }

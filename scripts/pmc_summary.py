@@ -56,9 +56,33 @@ def main():
     out.update({"FETCH_SIZE_KiB_mean": fetch, "WRITE_SIZE_KiB_mean": write, "launches_averaged": [nf, nw],
                 "fetch_correction": 2.0,
                 "spmv_rbcs_kernel_bytes_per_launch": int((2.0 * fetch + write) * 1024)})
+    # the other SpMV kernels of the same run (pattern leg, BFS leg), same correction
+    fs, ws = os.path.join(SRC, "pmc_fetch_spmv.csv"), os.path.join(SRC, "pmc_write_spmv.csv")
+    if os.path.exists(fs) and os.path.exists(ws):
+        shutil.copy(fs, os.path.join(DST, "%s_pmc_fetch_spmv.csv" % TAG))
+        shutil.copy(ws, os.path.join(DST, "%s_pmc_write_spmv.csv" % TAG))
+        other = {}
+        for k in ("spmv_rbcs_pat_kernel", "spmv_bool_kernel<1", "spmv_prescale_kernel", "spmv_bool_pack_kernel"):
+            try:
+                f_, n1 = mean_counter(fs, k)
+                w_, n2 = mean_counter(ws, k)
+                other[k] = {"FETCH_SIZE_KiB_mean": f_, "WRITE_SIZE_KiB_mean": w_, "launches_averaged": [n1, n2],
+                            "bytes_per_launch": int((2.0 * f_ + w_) * 1024)}
+            except ZeroDivisionError:
+                pass
+        out["other_kernels"] = other
+    if stats:
+        with open(stats[0]) as f:
+            rows = {}
+            for row in csv.DictReader(f):
+                for k in ("spmv_rbcs_pat_kernel", "spmv_bool_kernel<1", "spmv_bool_kernel<0", "spmv_prescale_kernel", "spmv_bool_pack_kernel",
+                          "spmv_hot_gather_kernel", "spmspv_scatter_kernel", "spmspv_queue_kernel", "spmspv_work_kernel"):
+                    if k in row["Name"]:
+                        rows[k] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
+            out["kernel_avg_ns"] = rows
     calib = os.path.join(SRC, "pmc_fetch_calib.csv")
     if os.path.exists(calib):
-        c, n = mean_counter(calib, "k_stream")
+        c, n = mean_counter(calib, "k_stream<0, 4>")
         out["calibration"] = {"kernel": "ubench k_stream<0,4> (8 B/lane nt loads of exactly 1 GiB)",
                               "FETCH_SIZE_KiB_mean": c, "expected_KiB": 1 << 20,
                               "measured_over_expected": c / float(1 << 20)}
