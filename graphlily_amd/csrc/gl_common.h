@@ -106,6 +106,12 @@ __device__ __forceinline__ uint2 load_stream_nt(const uint2 *p) {
     return make_uint2(v.x, v.y);
 }
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_stream_nt16(const uint4 *p) {
+    u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // mask test shared by SpMV epilogue and dense assign: "does the mask allow a write here?"
 template <int MASK>
 __device__ __forceinline__ bool mask_allows(float m, float ref) {

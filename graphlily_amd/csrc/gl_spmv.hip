@@ -223,6 +223,73 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
 }
 
+// The general layout with two consecutive groups stored lane-interleaved (16 bytes per lane and load:
+// { A.index, A.value, B.index, B.value }): half as many stream instructions per byte (scripts/ubench_mix:
+// -5 % on the stream + gather loop).  UC cold PAIRS and UH hot PAIRS per wavefront iteration.
+template <int OP, int MASK, int UC, int UH>
+__global__ __launch_bounds__(kThreads) void spmv_rbcs_wide_kernel(SpmvArgs a) {
+    using TL = Tile<OP>;
+    using T = typename TL::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
+    T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);
+
+    const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
+    const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
+    const uint32_t nhub = dh.y, nhotg = dh.z;
+    const uint32_t nslots = nrows + kHubSlots * nhub;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    if (UH > 0)
+        for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];
+    for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
+    __syncthreads();
+
+    const uint4 *pairs = reinterpret_cast<const uint4 *>(a.entries);   // pair P = groups 2P, 2P+1
+    const uint32_t pc0 = g0 >> 1, npc = ncold >> 1, ph0 = (g0 + ncold) >> 1, nph = nhotg >> 1;
+    uint32_t pc = wave, ph = wave;
+    while (pc < npc || (UH > 0 && ph < nph)) {
+        uint4 ec[UC];
+        uint32_t bc[UC][2];
+        uint4 eh[UH > 0 ? UH : 1];
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const uint32_t pi = pc + u * kWaves;
+            const bool in = pi < npc;
+            ec[u] = in ? load_stream_nt16(pairs + (size_t)(pc0 + pi) * 64u + lane) : make_uint4(kRowPad, 0u, kRowPad, 0u);
+            bc[u][0] = in ? a.bases[g0 + 2u * pi] : 0u;
+            bc[u][1] = in ? a.bases[g0 + 2u * pi + 1u] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < UH; u++) {
+            const uint32_t pi = ph + u * kWaves;
+            eh[u] = (pi < nph) ? load_stream_nt16(pairs + (size_t)(ph0 + pi) * 64u + lane) : make_uint4(kRowPad, 0u, kRowPad, 0u);
+        }
+        float xc[UC][2];
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            xc[u][0] = a.x[bc[u][0] + (ec[u].x >> kRowBits)];
+            xc[u][1] = a.x[bc[u][1] + (ec[u].z >> kRowBits)];
+        }
+#pragma unroll
+        for (int u = 0; u < UH; u++) {
+            const uint32_t r0 = eh[u].x & kRowPad, r1 = eh[u].z & kRowPad;
+            if (r0 != kRowPad) TL::acc(tile, r0, __uint_as_float(eh[u].y), hot_x[eh[u].x >> kRowBits]);
+            if (r1 != kRowPad) TL::acc(tile, r1, __uint_as_float(eh[u].w), hot_x[eh[u].z >> kRowBits]);
+        }
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const uint32_t r0 = ec[u].x & kRowPad, r1 = ec[u].z & kRowPad;
+            if (r0 != kRowPad) TL::acc(tile, r0, __uint_as_float(ec[u].y), xc[u][0]);
+            if (r1 != kRowPad) TL::acc(tile, r1, __uint_as_float(ec[u].w), xc[u][1]);
+        }
+        pc += kWaves * UC;
+        ph += kWaves * (UH > 0 ? UH : 1);
+    }
+    spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
+}
+
 // Pattern plans (every column's stored values are equal): the stream carries 4 bytes per entry,
 // { (col - group_base) << 14 | slot }, the value is folded into z[c] = colval[c] (x) x[c] once per run.
 // Two consecutive groups are stored lane-interleaved so that one 8-byte-per-lane read fetches both
@@ -375,6 +442,18 @@ static int launch_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStre
 }
 
 template <int OP, int MASK, int UC, int UH>
+static int launch_wide_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_wide_kernel<OP, MASK, UC, UH>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set = true;
+    }
+    spmv_rbcs_wide_kernel<OP, MASK, UC, UH><<<p->nunits, kThreads, lds, s>>>(a);
+    return GL_OK;
+}
+
+template <int OP, int MASK, int UC, int UH>
 static int launch_pat_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -423,6 +502,16 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
             case 7: rc = launch_pat_variant<OP, MASK, 4, 1>(p, a, lds, s); break;
             case 8: rc = launch_pat_variant<OP, MASK, 6, 0>(p, a, lds, s); break;
             default: rc = launch_pat_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
+        }
+    } else if (p->wide) {
+        switch (p->mix) {   // cold pairs, hot pairs per iteration
+            case 0: rc = launch_wide_variant<OP, MASK, 2, 0>(p, a, lds, s); break;
+            case 1: rc = launch_wide_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
+            case 2: rc = launch_wide_variant<OP, MASK, 1, 1>(p, a, lds, s); break;
+            case 3: rc = launch_wide_variant<OP, MASK, 3, 1>(p, a, lds, s); break;
+            case 6: rc = launch_wide_variant<OP, MASK, 3, 2>(p, a, lds, s); break;
+            case 7: rc = launch_wide_variant<OP, MASK, 3, 3>(p, a, lds, s); break;
+            default: rc = launch_wide_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
         }
     } else
     switch (p->mix) {
@@ -725,7 +814,8 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         pattern = !mismatch;
         diag_mode = pattern && exceptions > 0;
     }
-    const uint32_t group_mult = pattern ? 2u : 1u;   // pattern units hold whole PAIRS of groups
+    const bool wide = !pattern && gl::env_long("GRAPHLILY_SPMV_WIDE", 1) != 0;   // 16-byte stream loads: pairs of groups
+    const uint32_t group_mult = (pattern || wide) ? 2u : 1u;   // such units hold whole PAIRS of groups
 
     // ---- group budget per unit (upper bound), so every block can be emitted independently;
     //      units are numbered segment-major: u = s * nblocks + b
@@ -871,10 +961,15 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     }
     p->flags = flags;
     {
-        // measured (orkut / products / hollywood / pokec stand-ins): the balanced 3 cold + 3 hot groups per
-        // iteration is best or within noise of the best everywhere; lopsided mixes starve one stream
+        // cold : hot groups per wavefront iteration follow the share of non-zeros the hot table serves
+        // (measured on the stand-ins: orkut / products, 34-36 % hot, are best at 3 cold + 2 hot pairs;
+        // hollywood / ppa / googleplus, > 50 %, at 2 + 2; lopsided mixes starve one stream)
         const long forced = gl::env_long("GRAPHLILY_SPMV_MIX", -1);
-        p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : (pattern ? 1 : 5));   // 0 would skip the hot groups
+        const double hot_frac = nnz ? (double)hot_nnz / (double)nnz : 0.0;
+        int mix = 5;                                   // wide: 2 + 2 pairs; narrow: 3 + 3 groups
+        if (pattern) mix = 1;                          // 2 + 1 pairs
+        else if (wide && hot_frac < 0.40) mix = 6;     // 3 + 2 pairs
+        p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : mix);   // 0 would skip the hot groups
     }
     auto up = [&](void **d, const void *h, size_t bytes) -> int {
         GL_HIP(hipMalloc(d, bytes ? bytes : 16));
@@ -883,6 +978,20 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         return GL_OK;
     };
     p->pattern = pattern;
+    p->wide = wide;
+    if (wide) {
+        // pair P = groups 2P, 2P+1 -> lane l holds { A[l], B[l] } (two uint2 = one 16-byte load)
+        const uint64_t npairs = total_groups / 2;
+#pragma omp parallel for schedule(static)
+        for (int64_t P = 0; P < (int64_t)npairs; P++) {
+            uint2 tmp[128];
+            memcpy(tmp, &entries[(size_t)P * 128], sizeof(tmp));
+            for (uint32_t l = 0; l < 64; l++) {
+                entries[(size_t)P * 128 + 2 * l] = tmp[l];
+                entries[(size_t)P * 128 + 2 * l + 1] = tmp[64 + l];
+            }
+        }
+    }
     if (pattern) {
         // 4-byte entries; pair P = groups 2P (-> .x) and 2P+1 (-> .y), lane-interleaved.  In place: the pair's
         // 128 uint2 shrink into the first 64 uint2 slots of the array (reads stay ahead of writes).

@@ -91,6 +91,7 @@ struct gl_spmv_plan_s {
     int mix = 0;               // cold/hot groups per iteration: 0 = (4,0) no hot table, 5 = (3,3) default; others for tuning
     uint32_t *d_hot_cols = nullptr;
     float *d_hot_x = nullptr;
+    bool wide = false;               // general layout with lane-interleaved group pairs (16-byte stream loads)
     bool pattern = false;            // every column's values are equal: 4-byte entries, z = colval (x) x per run
     float *d_colval = nullptr, *d_z = nullptr;
     float *d_diag = nullptr;         // pattern plans whose diagonal differs from the column values: A[r][r] per local row
