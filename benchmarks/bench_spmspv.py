@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""SpMSpV sparsity sweep of the reference (benchmark/bench_spmspv.cpp), one GPU.
+
+Same protocol: matrix values 1/num_rows (:153), every k-th column active with values (rand() % 99 + 1) / 100
+(:157-185), Arithmetic semiring, kNoMask (:283, :323), vector sparsity 90 ... 99.99 % (:270-276), one warm-up
+run that is VERIFIED (here against an f64 evaluation of the same product on the host, the benchmark does not
+import the oracle) and 20 timed blocking runs (:228-236); bytes = 8 x sum nnz(active columns) (:61-76),
+GTEPS = GB/s / 8 (:238-239).  The two `uniform_conflict_free` matrices of the reference's list are FPGA
+bank-conflict probes and have no stand-in here.
+
+    python benchmarks/bench_spmspv.py [--graphs googleplus,pokec] [--semirings Arithmetic,Logical] [--out profiles/rNN_spmspv_sweep.jsonl]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SPARSITIES = (0.90, 0.95, 0.99, 0.995, 0.999, 0.9995, 0.9999)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graphs", default="googleplus,ogbl_ppa,hollywood,pokec,ogbn_products")
+    ap.add_argument("--semirings", default="Arithmetic")
+    ap.add_argument("--runs", type=int, default=20)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    import scipy.sparse as sp
+    import torch
+    from graphlily_amd import capi, datasets, io, module as M
+    dev = torch.device("cuda:0")
+    capi.init(0)
+    sems = {"Arithmetic": M.ArithmeticSemiring, "Logical": M.LogicalSemiring}
+    lines = []
+    for name in args.graphs.split(","):
+        csr = datasets.paper_graph(name, 1.0, device=dev)
+        csr.adj_data = np.full(csr.nnz, np.float32(1.0 / csr.num_rows), np.float32)
+        csc = io.csr2csc(csr)
+        coldeg = np.diff(csc.adj_indptr.astype(np.int64))
+        A = sp.csc_matrix((csc.adj_data.astype(np.float64), csc.adj_indices.astype(np.int64), csc.adj_indptr.astype(np.int64)),
+                          shape=(csc.num_rows, csc.num_cols))
+        for sname in args.semirings.split(","):
+            mod = M.SpMSpVModule(512 * 1024)
+            mod.set_semiring(sems[sname])
+            mod.set_mask_type(M.kNoMask)
+            mod.set_up_runtime("unused.xclbin")
+            mod.load_and_format_matrix(csc)
+            mod.send_matrix_host_to_device()
+            mod.send_mask_host_to_device(np.zeros(csc.num_rows, np.float32))
+            rng = np.random.default_rng(1)
+            for sparsity in SPARSITIES:
+                cnt = int(np.floor((1 - sparsity) * csc.num_cols))
+                if cnt == 0:
+                    continue
+                idx = (np.arange(cnt, dtype=np.int64) * (csc.num_cols // cnt)).astype(np.uint32)
+                vals = ((rng.integers(0, 99, size=cnt) + 1) / 100.0).astype(np.float32) if sname == "Arithmetic" else np.ones(cnt, np.float32)
+                mod.send_vector_host_to_device(M.make_sparse_vec(idx, vals))
+                mod.run()                                   # warm-up, verified
+                res = mod.send_results_device_to_host()
+                got = M.convert_sparse_vec_to_dense_vec(res, csc.num_rows, 0.0).astype(np.float64)
+                x = np.zeros(csc.num_cols)
+                x[idx] = vals.astype(np.float64)
+                ref = A @ x
+                if sname == "Logical":
+                    ref = (ref != 0).astype(np.float64)
+                ok = bool(np.allclose(got, ref, rtol=1e-5, atol=1e-12))
+                ts = []
+                for _ in range(args.runs):
+                    t0 = time.perf_counter()
+                    mod.run()                               # blocking, like the reference's run()
+                    ts.append(time.perf_counter() - t0)
+                ms = float(np.mean(ts)) * 1e3
+                active = int(coldeg[idx].sum())
+                rec = {"graph": name, "semiring": sname, "vector_sparsity": sparsity, "vector_nnz": cnt,
+                       "active_nnz": active, "result_nnz": int(res["index"][0]), "ms": round(ms, 4),
+                       "gbps": round(8 * active / ms / 1e6, 2), "gteps": round(active / ms / 1e6, 3), "verified": ok}
+                print(json.dumps(rec), flush=True)
+                lines.append(rec)
+            del mod
+    if args.out:
+        with open(args.out, "w") as f:
+            for rec in lines:
+                f.write(json.dumps(rec) + "\n")
+
+
+if __name__ == "__main__":
+    main()

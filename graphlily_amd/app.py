@@ -18,6 +18,8 @@ Differences that do not change results:
   * vectors are allocated by the driver and bound into the modules, so the same buffers can be
     handed to the collective.
 """
+import time
+
 import numpy as np
 
 from . import capi, io
@@ -297,6 +299,58 @@ class BFS(_GraphApp):
         return self._finish_distance(distance)
 
 
+    def pull_push_time_breakdown(self, source, num_iterations, threshold=0.05):
+        """app/bfs.h:222-347: pull_push with the reference's four wall-clock buckets.  Every step is followed by
+        a device sync (the reference's module calls are blocking), so the total is larger than pull_push's.
+        Returns the same distance vector; the buckets (ms) are left in `time_breakdown_` and printed."""
+        B, n = self.backend, self.n_
+        tb = {"spmv_spmspv": 0.0, "assign": 0.0, "data_transfer": 0.0}
+
+        def timed(bucket, fn):
+            B.sync()
+            t0 = time.perf_counter()
+            r = fn()
+            B.sync()
+            tb[bucket] += (time.perf_counter() - t0) * 1e3
+            return r
+
+        B.sync()
+        t_start = time.perf_counter()
+        frontier, distance, local = timed("data_transfer", lambda: self._start_push(source))
+        it = 1
+        while True:
+            timed("spmv_spmspv", self.SpMSpV_.run)
+            timed("assign", lambda: self.SparseAssign_.run(float(it + 1)))
+            if self.comm.distributed:
+                nnz = timed("data_transfer", lambda: self._gather_sparse(local, frontier, n, self.semiring_.zero))
+            else:
+                nnz = self.SpMSpV_.get_results_nnz()
+                timed("data_transfer", lambda: B.copy(frontier, local, 8 * (1 + nnz)))
+            self._hint_frontier(nnz)
+            it += 1
+            if not (it < num_iterations and float(nnz) / n < threshold):
+                break
+        self.push_iterations_ = it - 1
+        print("SpMSpV runs for %d iterations" % (it - 1))
+        vector = B.alloc(n, np.float32)
+        timed("data_transfer", lambda: B.sparse_to_dense(frontier, vector, n, M.LogicalSemiring.zero, n))
+        self._bind_pull(vector, distance)
+        own = self.r1_ - self.r0_
+        while it <= num_iterations:
+            timed("spmv_spmspv", self.SpMV_.run)
+            timed("data_transfer", lambda: (self.eWiseAdd_.run(own, 0.0), self._gather(vector)))
+            timed("assign", lambda: self.DenseAssign_.run(own, float(it + 1)))
+            it += 1
+        result = timed("data_transfer", lambda: self._finish_distance(distance))
+        total = (time.perf_counter() - t_start) * 1e3
+        tb["total"] = total
+        tb["overhead"] = total - tb["spmv_spmspv"] - tb["assign"] - tb["data_transfer"]
+        self.time_breakdown_ = tb
+        for k in ("total", "spmv_spmspv", "assign", "data_transfer", "overhead"):
+            print("%s_time_ms: %.4f" % (k, tb[k]))
+        return result
+
+
 class PageRank(_GraphApp):
     def __init__(self, num_channels=M.num_hbm_channels, spmv_out_buf_len=0, vec_buf_len=0, comm=None, backend=None):
         super().__init__(num_channels, comm, backend)
@@ -341,6 +395,43 @@ class PageRank(_GraphApp):
             self._gather(vector)
         B.sync()
         return B.download_result(vector, n)
+
+
+    def pull_time_breakdown(self, damping, num_iterations):
+        """app/pagerank.h:93-147: pull with per-iteration wall-clock buckets (spmv, ewise, data transfer); every
+        step is followed by a device sync.  Returns the rank vector (the reference returns the wrong buffer
+        there); the buckets (ms per iteration) are left in `time_breakdown_` and printed."""
+        B, n = self.backend, self.n_
+        tb = {"spmv": 0.0, "ewise": 0.0, "data_transfer": 0.0}
+
+        def timed(bucket, fn):
+            B.sync()
+            t0 = time.perf_counter()
+            r = fn()
+            B.sync()
+            tb[bucket] += (time.perf_counter() - t0) * 1e3
+            return r
+
+        B.sync()
+        t_start = time.perf_counter()
+        vector = timed("data_transfer", lambda: self._new_dense(n, np.float32(1.0 / n)))
+        teleport = np.float32(np.float32(1) - np.float32(damping)) / np.float32(n)
+        results = B.alloc(n, np.float32)
+        self.SpMV_.bind_vector_buf(vector)
+        self.SpMV_.bind_results_buf(results)
+        self.eWiseAdd_.bind_in_buf(self._own(results))
+        self.eWiseAdd_.bind_out_buf(self._own(vector))
+        own = self.r1_ - self.r0_
+        for _ in range(num_iterations):
+            timed("spmv", self.SpMV_.run)
+            timed("ewise", lambda: self.eWiseAdd_.run(own, float(teleport)))
+            timed("data_transfer", lambda: self._gather(vector))
+        result = timed("data_transfer", lambda: B.download_result(vector, n))
+        tb["total"] = (time.perf_counter() - t_start) * 1e3
+        self.time_breakdown_ = {k: v / num_iterations for k, v in tb.items()}
+        for k in ("total", "spmv", "ewise", "data_transfer"):
+            print("%s_time_ms per iteration: %.4f" % (k, self.time_breakdown_[k]))
+        return result
 
 
 class SSSP(_GraphApp):

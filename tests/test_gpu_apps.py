@@ -132,3 +132,28 @@ def test_golden_apps(gpu, golden_dir):
             d.load_and_format_matrix(path, True)
             d.send_matrix_host_to_device()
             assert d.pull(a["source"], a["iters"])[:len(exp)].tolist() == exp.tolist(), a
+
+
+def test_time_breakdown_variants(gpu, capsys):
+    """app/bfs.h:222-347 and app/pagerank.h:93-147: same results as the plain drivers, buckets reported."""
+    raw = datasets.rmat(20000, 300000, 11, True)
+    bfs = app.BFS(16, 0, 0, 0)
+    bfs.set_up_runtime()
+    bfs.load_and_format_matrix(raw.copy(), True)
+    bfs.send_matrix_host_to_device()
+    src = int(np.argmax(np.diff(raw.adj_indptr.astype(np.int64)) > 0))
+    d0 = bfs.pull_push(src, 8, 0.001)
+    d1 = bfs.pull_push_time_breakdown(src, 8, 0.001)
+    assert np.array_equal(d0, d1)
+    tb = bfs.time_breakdown_
+    assert tb["total"] > 0 and abs(tb["total"] - tb["spmv_spmspv"] - tb["assign"] - tb["data_transfer"] - tb["overhead"]) < 1e-6
+    pr = app.PageRank(16, 0, 0)
+    pr.set_up_runtime()
+    pr.load_and_format_matrix(raw.copy(), 0.9, True)
+    pr.send_matrix_host_to_device()
+    r0 = pr.pull(0.9, 5)
+    r1 = pr.pull_time_breakdown(0.9, 5)
+    assert np.array_equal(r0, r1)
+    assert pr.time_breakdown_["spmv"] > 0
+    out = capsys.readouterr().out
+    assert "spmv_spmspv_time_ms" in out and "spmv_time_ms per iteration" in out
