@@ -219,13 +219,27 @@ class BFS(_GraphApp):
         self.DenseAssign_.bind_inout_buf(self._own(distance))
         self.eWiseAdd_.bind_in_buf(self._own(results))
         self.eWiseAdd_.bind_out_buf(self._own(vector))
+        # Row-sharded runs exchange the frontier as BITS (n/8 bytes per iteration instead of 4n): the boolean
+        # SpMV layout reads a bit vector anyway.  Slices are whole 64-bit words (shard bounds are 64-aligned).
+        self.bits_ = None
+        words = self.SpMV_.bits_words() if (self.comm.distributed and hasattr(self.SpMV_, "bits_words")) else 0
+        if words and all(b % 64 == 0 for b in self.bounds_):
+            self.bits_ = B.alloc(words, np.float32)          # opaque 32-bit words
+            capi.pack_bits(vector, n, self.bits_)
 
     def _pull_iteration(self, vector, it):
-        own = self.r1_ - self.r0_
-        self.SpMV_.run()
+        B, own = self.backend, self.r1_ - self.r0_
+        if self.bits_ is not None:
+            self.SpMV_.run_bits(self.bits_)
+        else:
+            self.SpMV_.run()
         self.eWiseAdd_.run(own, 0.0)                 # results -> vector (app/bfs.h:119-122)
         self.DenseAssign_.run(own, float(it + 1))
-        self._gather(vector)
+        if self.bits_ is not None:
+            capi.pack_bits(self._own(vector), own, B.view(self.bits_, self.r0_ // 32, own // 32, 4))
+            self.comm.all_gather_slices(self.bits_.tensor, [b // 32 for b in self.bounds_])
+        else:
+            self._gather(vector)
 
     def _finish_distance(self, distance):
         self._gather(distance)

@@ -1091,6 +1091,29 @@ int gl_spmv_plan_hot(gl_spmv_plan p, uint32_t *hot_columns, uint64_t *hot_nnz, i
     return GL_OK;
 }
 
+int gl_spmv_plan_bits_words(gl_spmv_plan p, uint64_t *words) {
+    GL_ARG(p != nullptr && words != nullptr);
+    *words = p->boolean ? (uint64_t)p->nphases * gl::kBoolPhaseWords : 0ull;
+    return GL_OK;
+}
+
+int gl_pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits) {
+    GL_REQUIRE_INIT();
+    GL_ARG(n == 0 || (d_x != nullptr && d_bits != nullptr));
+    GL_ARG(((uintptr_t)d_bits & 7u) == 0);
+    return gl::pack_bits(d_x, n, d_bits, gl::ctx().stream);
+}
+
+int gl_spmv_run_bits(gl_spmv_plan p, const uint32_t *d_bits, const float *d_mask, float *d_y, float zero, int mask_type) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && d_y != nullptr && d_bits != nullptr);
+    GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
+    GL_ARG(((uintptr_t)d_bits & 15u) == 0);
+    if (!p->boolean)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run_bits: the plan does not hold the GL_PLAN_BOOLEAN layout");
+    return gl::bool_plan_run(p, nullptr, d_bits, d_mask, d_y, zero, mask_type, gl::ctx().stream);
+}
+
 int gl_spmv_plan_layout(gl_spmv_plan p, int *layout) {
     GL_ARG(p != nullptr && layout != nullptr);
     *layout = p->boolean ? GL_LAYOUT_BOOLEAN : (p->pattern ? GL_LAYOUT_PATTERN : GL_LAYOUT_GENERAL);
@@ -1117,7 +1140,7 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
         if (op != GL_OP_ANDOR)
             return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_BOOLEAN and "
                                  "holds the sparsity pattern only; semiring op %d needs a plan without it", op);
-        return gl::bool_plan_run(p, d_x, d_mask, d_y, zero, mask_type, gl::ctx().stream);
+        return gl::bool_plan_run(p, d_x, nullptr, d_mask, d_y, zero, mask_type, gl::ctx().stream);
     }
     if ((p->flags & (GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD)) && op == GL_OP_MULADD && p->nhot &&
         (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(double) > gl::kLdsBudget)

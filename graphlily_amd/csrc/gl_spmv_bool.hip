@@ -164,7 +164,10 @@ static int launch_bool(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
     return GL_OK;
 }
 
-int bool_plan_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, float zero, int mask_type, hipStream_t s) {
+// d_x != nullptr: pack it into the plan's bit vector first; else run on `bits` as the caller prepared them
+// (gl_spmv_run_bits: the bit vector of a row-sharded run is all-gathered instead of the float vector)
+int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const float *d_mask, float *d_y, float zero,
+                  int mask_type, hipStream_t s) {
     const uint32_t rows = p->row_end - p->row_begin;
     if (rows == 0) return GL_OK;
     if (p->segments > 1 || p->nunits == 0) {
@@ -172,16 +175,19 @@ int bool_plan_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *
         if (rc != GL_OK) return rc;
     }
     if (!p->nunits) return GL_OK;
-    const uint32_t nwords64 = p->nphases * (kBoolPhaseWords / 2u);
-    spmv_bool_pack_kernel<<<std::min<unsigned>(cdiv(nwords64, 4), (unsigned)ctx().num_cus * 16u), 256, 0, s>>>(
-        d_x, p->num_cols, reinterpret_cast<uint64_t *>(p->d_xbits), nwords64);
-    GL_LAUNCH_CHECK();
+    if (d_x != nullptr) {
+        const uint32_t nwords64 = p->nphases * (kBoolPhaseWords / 2u);
+        spmv_bool_pack_kernel<<<std::min<unsigned>(cdiv(nwords64, 4), (unsigned)ctx().num_cus * 16u), 256, 0, s>>>(
+            d_x, p->num_cols, reinterpret_cast<uint64_t *>(p->d_xbits), nwords64);
+        GL_LAUNCH_CHECK();
+        bits = p->d_xbits;
+    }
     BoolArgs a;
     a.entries = p->d_entries;
     a.bases = p->d_bases;
     a.units = p->d_units;
     a.spans = p->d_spans;
-    a.xbits = p->d_xbits;
+    a.xbits = bits;
     a.mask = d_mask;
     a.y = d_y;
     a.zero = zero;
@@ -192,6 +198,15 @@ int bool_plan_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *
         case GL_MASK_WRITETOONE: return launch_bool<GL_MASK_WRITETOONE>(p, a, s);
         default: return set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid mask type %d", mask_type);
     }
+}
+
+int pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits, hipStream_t s) {
+    const uint32_t nwords64 = cdiv(n, 64);
+    if (!nwords64) return GL_OK;
+    spmv_bool_pack_kernel<<<std::min<unsigned>(cdiv(nwords64, 4), (unsigned)ctx().num_cus * 16u), 256, 0, s>>>(
+        d_x, n, reinterpret_cast<uint64_t *>(d_bits), nwords64);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
 }
 
 uint32_t *bool_plan_xbits(gl_spmv_plan p) { return p->d_xbits; }

@@ -110,7 +110,9 @@ struct gl_spmv_plan_s {
 namespace gl {
 // gl_spmv_bool.hip
 int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data);
-int bool_plan_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, float zero, int mask_type, hipStream_t s);
+int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const float *d_mask, float *d_y, float zero,
+                  int mask_type, hipStream_t s);
+int pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits, hipStream_t s);
 int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s);
 uint32_t *bool_plan_xbits(gl_spmv_plan p);
 size_t bool_plan_xbits_bytes(gl_spmv_plan p);

@@ -191,6 +191,15 @@ class SpMVModule(BaseModule):
                        self.mask_type_)
         self._finish()
 
+    # extensions for row-sharded (||,&&) runs: x as a bit vector (gl_spmv_plan_bits_words / gl_spmv_run_bits)
+    def bits_words(self):
+        return self.plan_.bits_words() if self.plan_ is not None and self._plan_serves(self.semiring_.op) else 0
+
+    def run_bits(self, bits_buf):
+        mask = self.mask_buf if self.mask_type_ != kNoMask else None
+        self.plan_.run_bits(bits_buf, mask, self.results_buf, self.semiring_.zero, self.mask_type_)
+        self._finish()
+
     def send_vector_device_to_host(self):
         return self.vector_buf.read(np.float32, self.get_num_cols())
 

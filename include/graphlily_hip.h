@@ -123,6 +123,16 @@ int gl_spmv_plan_shape(gl_spmv_plan plan, uint32_t *blocks, uint32_t *segments, 
 #define GL_LAYOUT_PATTERN 1
 #define GL_LAYOUT_BOOLEAN 2
 int gl_spmv_plan_layout(gl_spmv_plan plan, int *layout);
+/* Extension for row-sharded (||,&&) runs: x as a bit vector supplied by the caller, so that ranks exchange
+ * n/8 bytes per iteration instead of 4n (multi-GPU).  gl_spmv_plan_bits_words: length in 32-bit words
+ * of the bit vector the boolean layout reads (whole 144 KB phases, 0 for the other layouts; bits past num_cols
+ * must be 0).  gl_pack_bits: bits[i / 32] bit (i % 32) = (x[i] != 0) for i < n, whole 64-bit words are written
+ * (d_bits 8-byte aligned).  gl_spmv_run_bits: gl_spmv_run of a GL_PLAN_BOOLEAN plan with op (||,&&) on that
+ * bit vector (16-byte aligned) instead of a float x. */
+int gl_spmv_plan_bits_words(gl_spmv_plan plan, uint64_t *words);
+int gl_pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits);
+int gl_spmv_run_bits(gl_spmv_plan plan, const uint32_t *d_bits, const float *d_mask, float *d_y, float zero,
+                     int mask_type);
 /* hot-column cache: columns whose x value is kept in LDS, the non-zeros they serve, and the cold/hot
  * interleave in use (0 = no hot table, 5 = 3 cold + 3 hot groups per wavefront iteration) */
 int gl_spmv_plan_hot(gl_spmv_plan plan, uint32_t *hot_columns, uint64_t *hot_nnz, int *mix);

@@ -1,0 +1,133 @@
+"""GPU suite: the N > 1 path with the REAL device modules.  Two ranks over gloo share cuda:0 (the GPU box has one
+device; RCCL needs one device per rank), so the collectives are host-staged by Comm, everything else -- row-shard
+plans, bit-vector frontier exchange of the BFS pull, sparse frontier all-gather of the push, on-device direction
+switch, split-plan combine -- is the code an 8-GPU run executes.  Results must equal the oracle's on every rank."""
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from graphlily_amd import datasets
+from graphlily_amd.dist import Comm
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _graph():
+    return datasets.rmat(40000, 900000, seed=23, symmetric=True)
+
+
+def _run_apps(comm, which):
+    from graphlily_amd import app, module as M
+    m = _graph()
+    B = app.HipBackend(0, use_torch=True)
+    if which == "bfs":
+        a = app.BFS(16, 0, 0, 0, comm=comm, backend=B)
+        a.set_up_runtime()
+        a.load_and_format_matrix(m, True)
+        a.send_matrix_host_to_device()
+        out = [a.pull(0, 7), a.pull_push(0, 7, 0.001), a.pull_push(0, 7, 0.5)]
+        assert a.bits_ is not None, "the pull iterations of a sharded BFS exchange bit vectors"
+        return out
+    if which == "pagerank":
+        a = app.PageRank(16, 0, 0, comm=comm, backend=B)
+        a.set_up_runtime()
+        a.load_and_format_matrix(m, 0.9, True)
+        a.send_matrix_host_to_device()
+        return [a.pull(0.9, 6)]
+    a = app.SSSP(16, 0, 0, 0, comm=comm, backend=B, semiring=M.TropicalSemiringUfixed)
+    a.set_up_runtime()
+    a.load_and_format_matrix(m, True)
+    a.send_matrix_host_to_device()
+    return [a.pull(0, 7), a.pull_push(0, 7, 0.01)]
+
+
+def _worker(rank, world, port, which, out_q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out_q.put((rank, _run_apps(Comm(True), which)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(which, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, which, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    deadline = time.time() + 300
+    while len(out) < world and time.time() < deadline:   # drain before joining (a put() blocks until read)
+        if not q.empty():
+            r, res = q.get()
+            out[r] = res
+        elif any(p.exitcode not in (None, 0) for p in procs):
+            break
+        else:
+            time.sleep(0.05)
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0, "worker failed (exit code %s)" % p.exitcode
+    assert len(out) == world
+    return out
+
+
+def _oracle_graph(sssp=False, pagerank=False):
+    m = _graph()
+    om = O.CSR(m.num_rows, m.num_cols, m.adj_data, m.adj_indices, m.adj_indptr)
+    if sssp:
+        O.sssp_preprocess(om)
+    O.util_round_csr_matrix_dim(om, 128, 128)
+    if pagerank:
+        O.util_normalize_csr_matrix_by_outdegree(om)
+        om.adj_data = (om.adj_data * np.float32(0.9)).astype(np.float32)
+    elif not sssp:
+        om.adj_data[:] = 1
+    return om
+
+
+def test_two_ranks_bfs(gpu):
+    ref = O.bfs(_oracle_graph(), 0, 7)
+    out = _spawn("bfs")
+    for r in (0, 1):
+        for got in out[r]:
+            assert np.array_equal(got, ref)
+
+
+def test_two_ranks_pagerank(gpu):
+    ref = O.pagerank(_oracle_graph(pagerank=True), 0.9, 6)
+    out = _spawn("pagerank")
+    for r in (0, 1):
+        np.testing.assert_allclose(out[r][0], ref, rtol=1e-4, atol=1e-9)
+    assert np.array_equal(out[0][0], out[1][0])
+
+
+def test_two_ranks_sssp(gpu):
+    ref = O.sssp(_oracle_graph(sssp=True), 0, 7, 255.0)
+    out = _spawn("sssp")
+    for r in (0, 1):
+        for got in out[r]:
+            assert np.array_equal(got, ref)
