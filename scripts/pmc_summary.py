@@ -44,15 +44,15 @@ def main():
                     g.write(line)
         with open(stats[0]) as f:
             for row in csv.DictReader(f):
-                if "spmv_rbcs_kernel" in row["Name"]:
+                if "spmv_rbcs_wide_kernel" in row["Name"]:
                     out["spmv_rbcs_kernel_avg_ns"] = float(row["AverageNs"])
                     out["spmv_rbcs_kernel_calls"] = int(row["Calls"])
     for name in ("pmc_fetch_rbcs.csv", "pmc_write_rbcs.csv"):
         p = os.path.join(SRC, name)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(DST, "%s_%s" % (TAG, name)))
-    fetch, nf = mean_counter(os.path.join(SRC, "pmc_fetch_rbcs.csv"), "spmv_rbcs_kernel")
-    write, nw = mean_counter(os.path.join(SRC, "pmc_write_rbcs.csv"), "spmv_rbcs_kernel")
+    fetch, nf = mean_counter(os.path.join(SRC, "pmc_fetch_rbcs.csv"), "spmv_rbcs_wide_kernel")
+    write, nw = mean_counter(os.path.join(SRC, "pmc_write_rbcs.csv"), "spmv_rbcs_wide_kernel")
     out.update({"FETCH_SIZE_KiB_mean": fetch, "WRITE_SIZE_KiB_mean": write, "launches_averaged": [nf, nw],
                 "fetch_correction": 2.0,
                 "spmv_rbcs_kernel_bytes_per_launch": int((2.0 * fetch + write) * 1024)})

@@ -124,6 +124,22 @@ def test_hot_column_cache_variants(gpu, hot, mix, monkeypatch):
             _check(got, m, sem, "WriteToOne", x, mask, "hot %s mix %s shape %s %s" % (hot, mix, shape, sem))
 
 
+def test_narrow_general_layout(gpu, monkeypatch):
+    """GRAPHLILY_SPMV_WIDE=0 keeps the 8-byte-per-lane stream (one group per load) -- the fallback of the default
+    lane-interleaved group pairs; same results."""
+    monkeypatch.setenv("GRAPHLILY_SPMV_WIDE", "0")
+    m = spmv_prepare("rmat_sym_50K")
+    rng = np.random.default_rng(31)
+    m.adj_data = rng.random(m.nnz, dtype=np.float32)
+    x, mask = rng.random(m.num_cols, dtype=np.float32), rand01(m.num_rows, 4)
+    for shape in ((0, 0), (3, 4)):
+        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
+        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        for sem in ("Arithmetic", "Tropical"):
+            got = _run_spmv(gpu, m, sem, "WriteToZero", x, mask)
+            _check(got, m, sem, "WriteToZero", x, mask, "narrow %s %s" % (shape, sem))
+
+
 def test_hub_row_spreading(gpu):
     """A few rows holding most of a block's entries go through the 16 private LDS slots."""
     rng = np.random.default_rng(5)
