@@ -18,7 +18,8 @@ namespace gl {
 struct BoolArgs {
     const uint2 *entries;      // groups of 128: lane l holds entries 2l and 2l+1
     const uint32_t *bases;     // per group: base column minus the first column of its phase
-    const uint4 *units;        // {first span, #spans, first row, #rows | direct << 31}
+    const uint4 *units;        // 2 per unit: {first span, #spans, first row, #rows | direct << 31}, {hub offset, #hub rows, -, -}
+    const uint32_t *hub_rows;  // row_in_block of every hub row, per block
     const uint4 *spans;        // {first xbits word of the phase, first group, end group, lo4 | hi4 << 16}
     const uint32_t *xbits;
     const float *mask;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     uint32_t *xw = lds_words + kBoolTileWords;      // kBoolPhaseWords
 
     if (a.run_flag && load_const(a.run_flag) == 0u) return;
-    const uint4 d = a.units[blockIdx.x];
+    const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
     const uint32_t span0 = d.x, nspans = d.y, row0 = d.z;
     const uint32_t nrows = d.w & 0xffffu;
     const bool direct = (d.w >> 31) != 0u;
@@ -118,6 +119,19 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         for (int u = 0; u < U; u++) asm volatile("" : : "v"(e[u].x), "v"(e[u].y));   // retire the clamped tail loads
     }
     __syncthreads();
+
+    if (dh.y) {   // hub rows: OR their 32 private bits (one per tile word 480..511) back into the row's bit
+        if (threadIdx.x < dh.y) {
+            uint32_t any = 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < kBoolHubSlots; j++) any |= tile[kBoolHubBit0 / 32u + j] >> threadIdx.x;
+            if (any & 1u) {
+                const uint32_t r = a.hub_rows[dh.x + threadIdx.x];
+                atomicOr(&tile[r >> 5], 1u << (r & 31u));
+            }
+        }
+        __syncthreads();
+    }
 
     if (direct) {
         for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
@@ -186,6 +200,7 @@ int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const 
     a.entries = p->d_entries;
     a.bases = p->d_bases;
     a.units = p->d_units;
+    a.hub_rows = p->d_hub_rows;
     a.spans = p->d_spans;
     a.xbits = bits;
     a.mask = d_mask;
@@ -220,6 +235,7 @@ int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hip
     a.entries = p->d_entries;
     a.bases = p->d_bases;
     a.units = p->d_units;
+    a.hub_rows = p->d_hub_rows;
     a.spans = p->d_spans;
     a.xbits = p->d_xbits;
     a.mask = nullptr;
@@ -237,7 +253,7 @@ static Shape choose_shape_bool(uint64_t rows, uint64_t cols, uint64_t nnz, int n
     if (rows == 0 || nnz == 0) return best;
     const double nph = (double)cdiv(cols, kBoolPhaseCols);
     const double phase_bytes = std::min<double>((double)kBoolPhaseWords * 4.0, (double)cols / 8.0);
-    const uint64_t rmax = kMaxBlockRows - 64;
+    const uint64_t rmax = kBoolHubBit0 - 64;
     double best_cost = 1e300;
     for (int k = 1; k <= 16 && best_cost > 1e299; k *= 2) {
         for (uint32_t S = 1; S <= 64; S++) {
@@ -269,7 +285,7 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
     const uint32_t num_cols = p->num_cols, row_begin = p->row_begin, row_end = p->row_end;
     const uint32_t rows = row_end - row_begin;
     const Shape shape = choose_shape_bool(rows, num_cols, p->nnz, ctx().num_cus);
-    const BlockPlan bp = plan_blocks(shape, h_indptr, row_begin, row_end, kMaxBlockRows - 1u);
+    const BlockPlan bp = plan_blocks(shape, h_indptr, row_begin, row_end, kBoolHubBit0);
     const uint32_t nblocks = bp.nblocks, nunits = bp.nunits;
     const uint32_t nphases = cdiv(num_cols, kBoolPhaseCols);
 
@@ -280,7 +296,8 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
         std::vector<uint4> spans;      // group indices are unit-local until the final pass
     };
     std::vector<UnitOut> out(nunits);
-    std::vector<uint4> units(nunits);
+    std::vector<uint4> units((size_t)nunits * 2);
+    std::vector<uint32_t> hub_rows((size_t)nblocks * kBoolHubMax, 0u);
     int bad_col = 0;
     uint32_t max_rows = 0;
 #pragma omp parallel
@@ -304,6 +321,26 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
             }
             sort_by_col(recs, tmp, num_cols);
             const uint64_t m = recs.size();
+            // hub rows: rows that own a large share of the block's entries receive most of the hits of a BFS
+            // step; their bit is spread over 32 private bits in 32 different tile words (picked by the entry's
+            // position in its group) so that the ds_or of one wavefront step do not pile up on one word
+            std::vector<uint32_t> cnt(r1 - r0, 0u);
+            for (const Rec &rc : recs) cnt[rc.row_local]++;
+            std::vector<int> hub_of(r1 - r0, -1);
+            uint32_t nhub = 0;
+            {
+                const uint64_t thr = std::max<uint64_t>(256, m / 48);
+                for (uint32_t i = 0; i < r1 - r0 && nhub < kBoolHubMax; i++)
+                    if (cnt[i] >= thr) {
+                        hub_of[i] = (int)nhub;
+                        hub_rows[(size_t)b * kBoolHubMax + nhub] = i;
+                        nhub++;
+                    }
+            }
+            auto slot_of = [&](const Rec &rc, uint32_t fill) -> uint32_t {
+                const int hb = hub_of[rc.row_local];
+                return hb < 0 ? rc.row_local : kBoolHubBit0 + (fill & (kBoolHubSlots - 1u)) * 32u + (uint32_t)hb;
+            };
             const uint32_t S = bp.seg[b];
             for (uint32_t s = 0; s < S; s++) {
                 const size_t u = bp.unit_of[s][b];
@@ -338,12 +375,13 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
                         fill = 0;
                         open = true;
                     }
-                    o.ent.push_back(((cin - base) << kRowBits) | rc.row_local);
+                    o.ent.push_back(((cin - base) << kRowBits) | slot_of(rc, fill));
                     fill++;
                     hi = cin;
                 }
                 close_span();
-                units[u] = make_uint4(0u, (uint32_t)o.spans.size(), r0, (r1 - r0) | (bp.all_direct ? 0x80000000u : 0u));
+                units[2 * u] = make_uint4(0u, (uint32_t)o.spans.size(), r0, (r1 - r0) | (bp.all_direct ? 0x80000000u : 0u));
+                units[2 * u + 1] = make_uint4((uint32_t)((size_t)b * kBoolHubMax), nhub, 0u, 0u);
             }
         }
     }
@@ -373,7 +411,7 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
             sp.z += (uint32_t)goff[u];
             spans[soff[u] + k] = sp;
         }
-        units[u].x = (uint32_t)soff[u];
+        units[2 * u].x = (uint32_t)soff[u];
         UnitOut().ent.swap(o.ent);
     }
 
@@ -394,6 +432,7 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
     if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * 4u)) != GL_OK ||
         (rc = up((void **)&p->d_bases, bases.data(), bases.size() * 4u)) != GL_OK ||
         (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK ||
+        (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK ||
         (rc = up((void **)&p->d_spans, spans.data(), spans.size() * sizeof(uint4))) != GL_OK)
         return rc;
     GL_HIP(hipMalloc((void **)&p->d_xbits, (size_t)nphases * kBoolPhaseWords * 4u));

@@ -29,6 +29,9 @@ constexpr uint32_t kBoolPhaseWords = 36864;                   // 144 KB of x bit
 constexpr uint32_t kBoolPhaseCols = kBoolPhaseWords * 32u;    // 1 179 648 columns
 constexpr uint32_t kBoolGroup = 128;                          // entries per group: 8 bytes per lane
 constexpr uint32_t kBoolTileWords = (kMaxBlockRows + 1u) / 32u;  // 512: one bit per row slot incl. the padding slot
+constexpr uint32_t kBoolHubSlots = 32;                        // private bits per hub row, one per tile word 480..511
+constexpr uint32_t kBoolHubMax = 31;                          // hub rows per block (bit 31 of word 511 is the padding slot)
+constexpr uint32_t kBoolHubBit0 = (kBoolTileWords - kBoolHubSlots) * 32u;   // 15360: plain rows use the bits below
 
 static inline long env_long(const char *name, long dflt) {
     const char *e = getenv(name);
