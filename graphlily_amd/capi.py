@@ -33,7 +33,7 @@ EXPORTS = [
     "gl_host_alloc", "gl_host_free",
     "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_run",
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits",
-    "gl_prof_begin", "gl_prof_end",
+    "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
     "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_last_direction",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
@@ -83,7 +83,7 @@ def lib():
         "gl_spmv_plan_layout": [vp, P(i32)],
         "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
-        "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)],
+        "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)], "gl_prof_sample_every": [u32],
         "gl_spmspv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmspv_plan_destroy": [vp], "gl_spmspv_plan_info": [vp, P(u64), P(u64)],
         "gl_spmspv_run": [vp, vp, vp, vp, i32, f32, i32],
@@ -358,7 +358,8 @@ def pack_bits(x, n, bits):
     check(lib().gl_pack_bits(_p(x), int(n), _p(bits)))
 
 
-def prof_begin(max_launches):
+def prof_begin(max_launches, every=1):
+    check(lib().gl_prof_sample_every(int(every)))
     check(lib().gl_prof_begin(int(max_launches)))
 
 

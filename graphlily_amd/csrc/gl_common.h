@@ -33,9 +33,15 @@ Context &ctx();
 struct Profiler {
     bool on = false;
     uint32_t used = 0;
+    uint32_t every = 1, seen = 0;    // bracket every `every`-th launch (gl_prof_sample_every)
     std::vector<hipEvent_t> events;  // pairs: start, stop
 };
 Profiler &prof();
+// should this launch of the dominant kernel be bracketed by an event pair?
+inline bool prof_take(Profiler &pf) {
+    if (!pf.on) return false;
+    return (pf.seen++ % pf.every) == 0u && 2ull * (pf.used + 1) <= pf.events.size();
+}
 
 int set_error(int code, const char *fmt, ...);
 

@@ -99,7 +99,13 @@ int gl_prof_begin(uint32_t max_launches) {
         p.events.push_back(e);
     }
     p.used = 0;
+    p.seen = 0;
     p.on = true;
+    return GL_OK;
+}
+
+int gl_prof_sample_every(uint32_t n) {
+    gl::prof().every = n ? n : 1u;
     return GL_OK;
 }
 

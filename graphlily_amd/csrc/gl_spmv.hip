@@ -488,7 +488,7 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
         return set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_NO_MULADD "
                          "(hot-column table sized for 4-byte accumulators); (+,x) needs a plan without it");
     Profiler &pf = prof();
-    const bool timed = pf.on && 2ull * (pf.used + 1) <= pf.events.size();
+    const bool timed = prof_take(pf);
     if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
     int rc;
     if (p->pattern) {

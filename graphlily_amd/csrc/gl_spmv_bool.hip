@@ -167,7 +167,7 @@ static int launch_bool(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
         attr_set = true;
     }
     Profiler &pf = prof();
-    const bool timed = pf.on && 2ull * (pf.used + 1) <= pf.events.size();
+    const bool timed = prof_take(pf);
     if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
     spmv_bool_kernel<MASK, kBoolUnroll><<<p->nunits, kThreads, kBoolLds, s>>>(a);
     GL_LAUNCH_CHECK();

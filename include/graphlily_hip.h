@@ -153,6 +153,10 @@ int gl_spmv_run(gl_spmv_plan plan, const float *d_x, const float *d_mask, float 
  * gl_prof_end synchronises and returns the summed kernel time and the number of launches. */
 int gl_prof_begin(uint32_t max_launches);
 int gl_prof_end(double *total_ms, uint32_t *launches);
+/* Bracket only every n-th launch (default 1 = all).  An event pair keeps the neighbouring launches from
+ * overlapping the kernel's first and last workgroups, so bracketing every launch slows a back-to-back sequence
+ * by ~5 %; sampling keeps the timed region close to what it is without the profiler. */
+int gl_prof_sample_every(uint32_t n);
 
 /* ------------------------------------------------------------------- SpMSpV
  * gl_spmspv_plan_create replaces SpMSpVModule::load_and_format_matrix +
