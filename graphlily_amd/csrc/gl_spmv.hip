@@ -967,7 +967,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         const long forced = gl::env_long("GRAPHLILY_SPMV_MIX", -1);
         const double hot_frac = nnz ? (double)hot_nnz / (double)nnz : 0.0;
         int mix = 5;                                   // wide: 2 + 2 pairs; narrow: 3 + 3 groups
-        if (pattern) mix = 1;                          // 2 + 1 pairs
+        if (pattern) mix = 2;                          // 2 + 2 pairs: best or equal on all six stand-ins
         else if (wide && hot_frac < 0.40) mix = 6;     // 3 + 2 pairs
         p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : mix);   // 0 would skip the hot groups
     }
