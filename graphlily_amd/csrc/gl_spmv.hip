@@ -500,7 +500,8 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
             case 5: rc = launch_pat_variant<OP, MASK, 4, 2>(p, a, lds, s); break;
             case 6: rc = launch_pat_variant<OP, MASK, 3, 2>(p, a, lds, s); break;
             case 7: rc = launch_pat_variant<OP, MASK, 4, 1>(p, a, lds, s); break;
-            case 8: rc = launch_pat_variant<OP, MASK, 6, 0>(p, a, lds, s); break;
+            case 8: rc = launch_pat_variant<OP, MASK, 1, 2>(p, a, lds, s); break;
+            case 9: rc = launch_pat_variant<OP, MASK, 2, 3>(p, a, lds, s); break;
             default: rc = launch_pat_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
         }
     } else if (p->wide) {
@@ -511,6 +512,8 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
             case 3: rc = launch_wide_variant<OP, MASK, 3, 1>(p, a, lds, s); break;
             case 6: rc = launch_wide_variant<OP, MASK, 3, 2>(p, a, lds, s); break;
             case 7: rc = launch_wide_variant<OP, MASK, 3, 3>(p, a, lds, s); break;
+            case 8: rc = launch_wide_variant<OP, MASK, 1, 2>(p, a, lds, s); break;
+            case 9: rc = launch_wide_variant<OP, MASK, 2, 3>(p, a, lds, s); break;
             default: rc = launch_wide_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
         }
     } else
@@ -967,8 +970,9 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         const long forced = gl::env_long("GRAPHLILY_SPMV_MIX", -1);
         const double hot_frac = nnz ? (double)hot_nnz / (double)nnz : 0.0;
         int mix = 5;                                   // wide: 2 + 2 pairs; narrow: 3 + 3 groups
-        if (pattern) mix = 2;                          // 2 + 2 pairs: best or equal on all six stand-ins
+        if (pattern) mix = hot_frac >= 0.60 ? 9 : 2;   // 2 + 2 pairs, 2 + 3 when the hot table serves most
         else if (wide && hot_frac < 0.40) mix = 6;     // 3 + 2 pairs
+        else if (wide && hot_frac >= 0.60) mix = 9;    // 2 + 3 pairs
         p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : mix);   // 0 would skip the hot groups
     }
     auto up = [&](void **d, const void *h, size_t bytes) -> int {
