@@ -42,7 +42,7 @@ def test_reference_app_drivers_compile_unmodified():
 @pytest.mark.gpu
 def test_cpp_module_layer_parity(gpu):
     _build_driver()
-    r = subprocess.run([DRIVER], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([DRIVER], capture_output=True, text=True, timeout=90)
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL CHECKS PASSED" in r.stdout
