@@ -4,14 +4,19 @@
 // (module/spmv_module.h:281-370, io/data_formatter.h:456-534) and
 // kernel_spmv (hw/kernel_spmv_impl.h:392-819).
 //
-// What the hardware dictates (measured on MI355X, scripts/ubench_*.hip, DESIGN.md):
-//   * the packed 8-byte (index,value) stream reads at 5.5-7 TB/s, but a random 4-byte gather of x
-//     costs a whole cache line: ~100 G gathers/s from a 10 MB vector = 0.8 TB/s of matrix stream;
-//   * the same gather runs at >500 G/s when the lanes of a wavefront read NEIGHBOURING columns;
+// What the hardware dictates (measured on MI355X, scripts/ubench_*.hip, DESIGN.md section 3):
+//   * the packed 8-byte (index,value) stream reads at ~7 TB/s (45 clocks of a CU's vector-memory pipe per 512 B);
+//   * a random 4-byte gather of x costs a whole cache line (~100 G/s from a 10 MB vector), but a gather whose
+//     64 lanes read NEIGHBOURING columns costs ~20 clocks, from L1 and L2 alike -- and that cost ADDS to the
+//     stream's: only fewer bytes per entry or fewer gather instructions (x values served from LDS) make
+//     the loop faster; unrolling, software pipelining and LDS window staging were measured and do not;
 //   * LDS atomics on 4/8-byte integers and on f64 run at full rate, ds_add_f32 at a third of it.
+// This file holds the GENERAL layout (8-byte entries; spmv_rbcs_wide_kernel, spmv_rbcs_kernel as the
+// GRAPHLILY_SPMV_WIDE=0 fallback) and the PATTERN layout (4-byte entries for column-constant matrices,
+// spmv_rbcs_pat_kernel); the (||,&&)-only bit layout lives in gl_spmv_bool.hip.
 // Hence the layout -- the CDNA4 counterpart of the FPGA's "dense-vector tile in URAM + output buffer
 // in URAM" partitioning (kernel_spmv_impl.h:470-495), with the roles swapped:
-//   row block   <= 16383 consecutive rows whose accumulators live in LDS for the whole sweep
+//   row block   <= 15359 consecutive rows whose accumulators live in LDS for the whole sweep
 //               (f64 for (+,x), so ds_add_f64; 32-bit ordered-int min for (min,+); plain store for (||,&&));
 //   entries     of a row block are stored COLUMN-SORTED, 8 bytes each:
 //               { (col - group_base) << 14 | row_in_block , val },  64 entries = one 512-byte group with
@@ -735,15 +740,16 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     for (uint32_t b = 0; b < nblocks; b++) tallest = std::max(tallest, bstart[b + 1] - bstart[b]);
 
     // ---- hot columns: the H highest-degree columns of the shard get an LDS-resident copy of x.
-    //      H = largest power of two that fits next to the tallest f64 tile (incl. worst-case hub slots).
+    //      H = what fits next to the tallest f64 tile (incl. worst-case hub slots).
     std::vector<uint32_t> hot_cols, hot_slot;   // slot -> column, column -> slot (0xffffffff = cold)
     if (nnz > 0 && gl::env_long("GRAPHLILY_SPMV_HOT", 1) != 0) {
         // 8-byte accumulators unless the caller promised to run only the 4-byte-tile semirings
         const size_t elem = (flags & (GL_PLAN_NO_MULADD | GL_PLAN_BOOLEAN)) ? sizeof(float) : sizeof(double);
         const size_t tile_bytes = ((size_t)tallest + gl::kHubSlots * gl::kMaxHubRows) * elem;
+        // as many columns as fit next to the tallest tile, in steps of 1024, at most 32 K
         uint32_t H = 0;
-        for (uint32_t h = 1u << 15; h >= 1024u; h >>= 1)
-            if (tile_bytes + (size_t)h * 4u <= gl::kLdsBudget) { H = h; break; }
+        if (tile_bytes + 4096u <= gl::kLdsBudget)
+            H = std::min<uint32_t>(1u << 15, (uint32_t)((gl::kLdsBudget - tile_bytes) / 4u / 1024u * 1024u));
         const long forced = gl::env_long("GRAPHLILY_SPMV_HOT", 1);
         if (forced > 1) H = std::min<uint32_t>(H, (uint32_t)forced);
         if (H) {
