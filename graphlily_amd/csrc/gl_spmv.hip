@@ -754,6 +754,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         if (forced > 1) H = std::min<uint32_t>(H, (uint32_t)forced);
         if (H) {
             std::vector<uint32_t> deg(num_cols, 0);
+            // sequential on purpose: atomics from all cores pile up on the hub columns' counters (measured slower)
             for (uint64_t i = nz0; i < nz1; i++)
                 if (h_indices[i] < num_cols) deg[h_indices[i]]++;   // out-of-range columns are reported below
             const uint32_t dmax = num_cols ? *std::max_element(deg.begin(), deg.end()) : 0u;
@@ -802,8 +803,12 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         for (int64_t r = row_begin; r < (int64_t)row_end; r++)
             for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
                 const uint32_t c = h_indices[i];
-                if (c < num_cols && c != (uint32_t)r)
-                    __atomic_store_n(&colbits[c], __builtin_bit_cast(uint32_t, h_data[i]), __ATOMIC_RELAXED);
+                // write only when it changes something: hub columns are written from every thread's row range, and
+                // unconditional stores would bounce their cache lines between all cores
+                if (c < num_cols && c != (uint32_t)r) {
+                    const uint32_t bits = __builtin_bit_cast(uint32_t, h_data[i]);
+                    if (__atomic_load_n(&colbits[c], __ATOMIC_RELAXED) != bits) __atomic_store_n(&colbits[c], bits, __ATOMIC_RELAXED);
+                }
             }
 #pragma omp parallel for schedule(static, 4096) reduction(| : mismatch) reduction(+ : exceptions)
         for (int64_t r = row_begin; r < (int64_t)row_end; r++) {   // 4096 rows = whole diag_has words per thread
@@ -1003,13 +1008,14 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         }
     }
     if (pattern) {
-        // 4-byte entries; pair P = groups 2P (-> .x) and 2P+1 (-> .y), lane-interleaved.  In place: the pair's
-        // 128 uint2 shrink into the first 64 uint2 slots of the array (reads stay ahead of writes).
+        // 4-byte entries; pair P = groups 2P (-> .x) and 2P+1 (-> .y), lane-interleaved
         const uint64_t npairs = total_groups / 2;
-        for (uint64_t P = 0; P < npairs; P++)
+        std::vector<uint2> packed(npairs * 64);
+#pragma omp parallel for schedule(static)
+        for (int64_t P = 0; P < (int64_t)npairs; P++)
             for (uint32_t l = 0; l < 64; l++)
-                entries[P * 64 + l] = make_uint2(entries[(2 * P) * 64 + l].x, entries[(2 * P + 1) * 64 + l].x);
-        entries.resize(npairs * 64);
+                packed[(size_t)P * 64 + l] = make_uint2(entries[(size_t)(2 * P) * 64 + l].x, entries[(size_t)(2 * P + 1) * 64 + l].x);
+        entries.swap(packed);
     }
     int rc;
     if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * sizeof(uint2))) != GL_OK ||
