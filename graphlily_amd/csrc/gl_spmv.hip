@@ -57,6 +57,7 @@ struct SpmvArgs {
     const float *z;           // pattern plans: colval (x) x, written by spmv_prescale_kernel
     const float *diag;        // pattern plans with diagonal exceptions: A[r][r] per local row, folded in by the epilogue
     const uint32_t *diag_has; // bit per local row: the row has a diagonal entry that differs from its column's value
+    unsigned long long *clocks;  // debugging (GRAPHLILY_SPMV_CLOCKS): wall_clock64 at the start and end of every unit
     float *partials;          // [segment][row - row_begin] per-unit tiles of split blocks (combined by spmv_combine_kernel)
     uint32_t prow;            // rows per segment plane
     uint32_t row_begin;
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_wide_kernel(SpmvArgs a) {
     for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
     __syncthreads();
 
+    if (a.clocks && threadIdx.x == 0) a.clocks[2u * blockIdx.x] = wall_clock64();
     const uint4 *pairs = reinterpret_cast<const uint4 *>(a.entries);   // pair P = groups 2P, 2P+1
     const uint32_t pc0 = g0 >> 1, npc = ncold >> 1, ph0 = (g0 + ncold) >> 1, nph = nhotg >> 1;
     uint32_t pc = wave, ph = wave;
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_wide_kernel(SpmvArgs a) {
         ph += kWaves * (UH > 0 ? UH : 1);
     }
     spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
+    if (a.clocks && threadIdx.x == 0) a.clocks[2u * blockIdx.x + 1u] = wall_clock64();
 }
 
 // Pattern plans (every column's stored values are equal): the stream carries 4 bytes per entry,
@@ -731,13 +734,9 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     // ---- row blocks and segments per block (gl_spmv_plan.h)
     const gl::Shape shape = gl::choose_shape(rows, num_cols, nnz, gl::ctx().num_cus);
     const gl::BlockPlan bp = gl::plan_blocks(shape, h_indptr, row_begin, row_end, gl::kMaxPlainRows);
-    const std::vector<uint32_t> &bstart = bp.bstart, &seg = bp.seg;
-    const std::vector<std::vector<uint32_t>> &unit_of = bp.unit_of;
-    const uint32_t nblocks = bp.nblocks, nunits = bp.nunits, Smax = bp.Smax;
-    const bool all_direct = bp.all_direct;
     const uint32_t jump_slack = (num_cols >> gl::kColOffBits) + 5;   // early cuts + cold/hot rounding
     uint32_t tallest = 0;
-    for (uint32_t b = 0; b < nblocks; b++) tallest = std::max(tallest, bstart[b + 1] - bstart[b]);
+    for (uint32_t b = 0; b < bp.nblocks; b++) tallest = std::max(tallest, bp.bstart[b + 1] - bp.bstart[b]);
 
     // ---- hot columns: the H highest-degree columns of the shard get an LDS-resident copy of x.
     //      H = what fits next to the tallest f64 tile (incl. worst-case hub slots).
@@ -762,7 +761,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             for (uint32_t c = 0; c < num_cols; c++) hist[deg[c]]++;
             // thr = smallest degree such that at most H columns have degree >= thr; a column must also
             // appear often enough to be worth a slot (>= 4 entries per row block on average)
-            const uint32_t floor_deg = std::max<uint32_t>(8u, 4u * nblocks);
+            const uint32_t floor_deg = std::max<uint32_t>(8u, 4u * bp.nblocks);
             uint64_t seen = 0;
             uint32_t thr = dmax + 1;
             while (thr > floor_deg && seen + hist[thr - 1] <= H) { thr--; seen += hist[thr]; }
@@ -781,6 +780,10 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         }
     }
     const bool have_hot = !hot_cols.empty();
+    const std::vector<uint32_t> &bstart = bp.bstart, &seg = bp.seg;
+    const std::vector<std::vector<uint32_t>> &unit_of = bp.unit_of;
+    const uint32_t nblocks = bp.nblocks, nunits = bp.nunits, Smax = bp.Smax;
+    const bool all_direct = bp.all_direct;
     const uint32_t nhot_table = have_hot ? (uint32_t)((hot_cols.size() + 63) / 64 * 64) : 0u;
     if (have_hot) hot_cols.resize(nhot_table, hot_cols[0]);   // pad the table to whole wavefronts
 
@@ -1173,6 +1176,14 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     a.mask = d_mask;
     a.y = d_y;
     a.zero = zero;
+    a.clocks = nullptr;
+    static const char *clocks_path = getenv("GRAPHLILY_SPMV_CLOCKS");
+    unsigned long long *d_clocks = nullptr;
+    if (clocks_path && p->nunits) {
+        GL_HIP(hipMalloc((void **)&d_clocks, (size_t)p->nunits * 16u));
+        GL_HIP(hipMemset(d_clocks, 0, (size_t)p->nunits * 16u));
+        a.clocks = d_clocks;
+    }
     a.z = p->d_z;
     a.diag = p->d_diag;
     a.diag_has = p->d_diag_has;
@@ -1180,12 +1191,29 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     a.prow = p->row_end - p->row_begin;
     a.row_begin = p->row_begin;
     hipStream_t s = gl::ctx().stream;
+    int rc;
     switch (op) {
-        case GL_OP_MULADD: return gl::dispatch_mask<GL_OP_MULADD>(mask_type, p, a, s);
-        case GL_OP_ANDOR: return gl::dispatch_mask<GL_OP_ANDOR>(mask_type, p, a, s);
-        case GL_OP_ADDMIN: return gl::dispatch_mask<GL_OP_ADDMIN>(mask_type, p, a, s);
-        default: return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid semiring op %d", op);
+        case GL_OP_MULADD: rc = gl::dispatch_mask<GL_OP_MULADD>(mask_type, p, a, s); break;
+        case GL_OP_ANDOR: rc = gl::dispatch_mask<GL_OP_ANDOR>(mask_type, p, a, s); break;
+        case GL_OP_ADDMIN: rc = gl::dispatch_mask<GL_OP_ADDMIN>(mask_type, p, a, s); break;
+        default: rc = gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid semiring op %d", op); break;
     }
+    if (d_clocks) {   // debugging only: blocking dump "unit start end" (100 MHz ticks), last run wins
+        std::vector<unsigned long long> h((size_t)p->nunits * 2);
+        std::vector<uint4> un((size_t)p->nunits * 2);
+        if (hipStreamSynchronize(s) == hipSuccess &&
+            hipMemcpy(h.data(), d_clocks, h.size() * 8u, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(un.data(), p->d_units, un.size() * sizeof(uint4), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(clocks_path, "w")) {   // unit start end #cold-groups #hot-groups #rows #hub-rows
+                for (uint32_t u = 0; u < p->nunits; u++)
+                    fprintf(f, "%u %llu %llu %u %u %u %u\n", u, h[2 * u], h[2 * u + 1], un[2 * u].y, un[2 * u + 1].z,
+                            un[2 * u].w & 0xffffu, un[2 * u + 1].y);
+                fclose(f);
+            }
+        }
+        (void)hipFree(d_clocks);
+    }
+    return rc;
 }
 
 }  // extern "C"
