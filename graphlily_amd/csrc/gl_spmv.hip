@@ -366,6 +366,76 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_pat_kernel(SpmvArgs a) {
     spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
 }
 
+// Pattern layout with FOUR consecutive groups lane-interleaved (16 bytes per lane and load: entry `lane` of groups
+// 4Q .. 4Q+3); group counts per unit are multiples of four.  UC cold QUADS and UH hot QUADS per iteration.
+template <int OP, int MASK, int UC, int UH>
+__global__ __launch_bounds__(kThreads) void spmv_rbcs_pat4_kernel(SpmvArgs a) {
+    using TL = Tile<OP>;
+    using T = typename TL::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
+    T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);
+
+    const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
+    const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
+    const uint32_t nhub = dh.y, nhotg = dh.z;
+    const uint32_t nslots = nrows + kHubSlots * nhub;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    if (UH > 0)
+        for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];
+    for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
+    __syncthreads();
+
+    const uint4 *quads = reinterpret_cast<const uint4 *>(a.entries);
+    const uint32_t qc0 = g0 >> 2, nqc = ncold >> 2, qh0 = (g0 + ncold) >> 2, nqh = nhotg >> 2;
+    uint32_t qc = wave, qh = wave;
+    while (qc < nqc || (UH > 0 && qh < nqh)) {
+        uint4 ec[UC];
+        uint32_t bc[UC][4];
+        uint4 eh[UH > 0 ? UH : 1];
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const uint32_t qi = qc + u * kWaves;
+            const bool in = qi < nqc;
+            ec[u] = in ? load_stream_nt16(quads + (size_t)(qc0 + qi) * 64u + lane) : make_uint4(kRowPad, kRowPad, kRowPad, kRowPad);
+#pragma unroll
+            for (int k = 0; k < 4; k++) bc[u][k] = in ? a.bases[g0 + 4u * qi + k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < UH; u++) {
+            const uint32_t qi = qh + u * kWaves;
+            eh[u] = (qi < nqh) ? load_stream_nt16(quads + (size_t)(qh0 + qi) * 64u + lane) : make_uint4(kRowPad, kRowPad, kRowPad, kRowPad);
+        }
+        float xc[UC][4];
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            xc[u][0] = a.z[bc[u][0] + (ec[u].x >> kRowBits)];
+            xc[u][1] = a.z[bc[u][1] + (ec[u].y >> kRowBits)];
+            xc[u][2] = a.z[bc[u][2] + (ec[u].z >> kRowBits)];
+            xc[u][3] = a.z[bc[u][3] + (ec[u].w >> kRowBits)];
+        }
+#pragma unroll
+        for (int u = 0; u < UH; u++) {
+            const uint32_t v[4] = {eh[u].x, eh[u].y, eh[u].z, eh[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((v[k] & kRowPad) != kRowPad) TL::accz(tile, v[k] & kRowPad, hot_x[v[k] >> kRowBits]);
+        }
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const uint32_t v[4] = {ec[u].x, ec[u].y, ec[u].z, ec[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((v[k] & kRowPad) != kRowPad) TL::accz(tile, v[k] & kRowPad, xc[u][k]);
+        }
+        qc += kWaves * UC;
+        qh += kWaves * (UH > 0 ? UH : 1);
+    }
+    spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
+}
+
 // z = colval (x) x for every column, and the hot table from the same products
 template <int OP>
 __global__ __launch_bounds__(256) void spmv_prescale_kernel(const float *__restrict__ x, const float *__restrict__ colval,
@@ -473,6 +543,18 @@ static int launch_pat_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hip
     return GL_OK;
 }
 
+template <int OP, int MASK, int UC, int UH>
+static int launch_pat4_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_pat4_kernel<OP, MASK, UC, UH>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set = true;
+    }
+    spmv_rbcs_pat4_kernel<OP, MASK, UC, UH><<<p->nunits, kThreads, lds, s>>>(a);
+    return GL_OK;
+}
+
 template <int OP, int MASK>
 static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     const uint32_t rows = p->row_end - p->row_begin;
@@ -499,7 +581,15 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     const bool timed = prof_take(pf);
     if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
     int rc;
-    if (p->pattern) {
+    if (p->pattern && p->wide) {
+        switch (p->mix) {   // cold quads, hot quads per iteration
+            case 0: rc = launch_pat4_variant<OP, MASK, 2, 0>(p, a, lds, s); break;
+            case 1: rc = launch_pat4_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
+            case 9: rc = launch_pat4_variant<OP, MASK, 1, 2>(p, a, lds, s); break;
+            case 6: rc = launch_pat4_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
+            default: rc = launch_pat4_variant<OP, MASK, 1, 1>(p, a, lds, s); break;
+        }
+    } else if (p->pattern) {
         switch (p->mix) {   // cold pairs, hot pairs per iteration
             case 0: rc = launch_pat_variant<OP, MASK, 3, 0>(p, a, lds, s); break;
             case 2: rc = launch_pat_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
@@ -831,8 +921,9 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         pattern = !mismatch;
         diag_mode = pattern && exceptions > 0;
     }
-    const bool wide = !pattern && gl::env_long("GRAPHLILY_SPMV_WIDE", 1) != 0;   // 16-byte stream loads: pairs of groups
-    const uint32_t group_mult = (pattern || wide) ? 2u : 1u;   // such units hold whole PAIRS of groups
+    // 16-byte stream loads: lane-interleaved pairs of 8-byte groups, or quads of 4-byte (pattern) groups
+    const bool wide = pattern ? gl::env_long("GRAPHLILY_SPMV_PAT4", 1) != 0 : gl::env_long("GRAPHLILY_SPMV_WIDE", 1) != 0;
+    const uint32_t group_mult = pattern ? (wide ? 4u : 2u) : (wide ? 2u : 1u);   // units hold whole pairs / quads of groups
 
     // ---- group budget per unit (upper bound), so every block can be emitted independently;
     //      units are numbered segment-major: u = s * nblocks + b
@@ -842,7 +933,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         const uint32_t S = seg[b];
         for (uint32_t s = 0; s < S; s++) {
             const uint64_t c0 = m * s / S, c1 = m * (s + 1) / S;
-            unit_goff[(size_t)unit_of[s][b] + 1] = ((c1 - c0 + 63) / 64 + jump_slack + 3u) / 2u * 2u;   // even
+            unit_goff[(size_t)unit_of[s][b] + 1] = ((c1 - c0 + 63) / 64 + jump_slack + 9u) / 4u * 4u;   // multiple of 4
         }
     }
     for (size_t i = 0; i < (size_t)nunits; i++) unit_goff[i + 1] += unit_goff[i];
@@ -984,7 +1075,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         const long forced = gl::env_long("GRAPHLILY_SPMV_MIX", -1);
         const double hot_frac = nnz ? (double)hot_nnz / (double)nnz : 0.0;
         int mix = 5;                                   // wide: 2 + 2 pairs; narrow: 3 + 3 groups
-        if (pattern) mix = hot_frac >= 0.60 ? 9 : 2;   // 2 + 2 pairs, 2 + 3 when the hot table serves most
+        if (pattern) mix = hot_frac >= 0.60 ? 9 : 2;   // quads: 1 + 1 (1 + 2 when the hot table serves most); pairs: 2 + 2 / 2 + 3
         else if (wide && hot_frac < 0.40) mix = 6;     // 3 + 2 pairs
         else if (wide && hot_frac >= 0.60) mix = 9;    // 2 + 3 pairs
         p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : mix);   // 0 would skip the hot groups
@@ -997,7 +1088,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     };
     p->pattern = pattern;
     p->wide = wide;
-    if (wide) {
+    if (wide && !pattern) {
         // pair P = groups 2P, 2P+1 -> lane l holds { A[l], B[l] } (two uint2 = one 16-byte load)
         const uint64_t npairs = total_groups / 2;
 #pragma omp parallel for schedule(static)
@@ -1011,13 +1102,24 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         }
     }
     if (pattern) {
-        // 4-byte entries; pair P = groups 2P (-> .x) and 2P+1 (-> .y), lane-interleaved
+        // 4-byte entries, lane-interleaved: pair P = groups 2P (-> .x), 2P+1 (-> .y); or quad Q = groups 4Q .. 4Q+3
+        // (-> .x .y .z .w of one 16-byte element = two consecutive uint2)
         const uint64_t npairs = total_groups / 2;
         std::vector<uint2> packed(npairs * 64);
+        if (wide) {
 #pragma omp parallel for schedule(static)
-        for (int64_t P = 0; P < (int64_t)npairs; P++)
-            for (uint32_t l = 0; l < 64; l++)
-                packed[(size_t)P * 64 + l] = make_uint2(entries[(size_t)(2 * P) * 64 + l].x, entries[(size_t)(2 * P + 1) * 64 + l].x);
+            for (int64_t Q = 0; Q < (int64_t)(total_groups / 4); Q++)
+                for (uint32_t l = 0; l < 64; l++) {
+                    const size_t g = (size_t)Q * 4;
+                    packed[(size_t)Q * 128 + 2 * l] = make_uint2(entries[g * 64 + l].x, entries[(g + 1) * 64 + l].x);
+                    packed[(size_t)Q * 128 + 2 * l + 1] = make_uint2(entries[(g + 2) * 64 + l].x, entries[(g + 3) * 64 + l].x);
+                }
+        } else {
+#pragma omp parallel for schedule(static)
+            for (int64_t P = 0; P < (int64_t)npairs; P++)
+                for (uint32_t l = 0; l < 64; l++)
+                    packed[(size_t)P * 64 + l] = make_uint2(entries[(size_t)(2 * P) * 64 + l].x, entries[(size_t)(2 * P + 1) * 64 + l].x);
+        }
         entries.swap(packed);
     }
     int rc;
