@@ -124,3 +124,40 @@ def test_bfs_and_sssp_forms_agree(orkut, gpu):
     reached = d_pull > 0
     assert np.array_equal(dist[reached], d_pull[reached] - 1)
     assert np.all(dist[~reached] == np.float32(M.FLOAT_INF))
+
+
+def test_layouts_agree_at_full_size(orkut):
+    """The three device layouts are three independent formatters and kernels over the same matrix: with unit
+    weights the 4-byte pattern layout and the (||,&&) bit layout must reproduce what the 8-byte general layout
+    (GL_PLAN_KEEP_VALUES) computes -- bit for bit for (||,&&) and (min,+), to accumulation order for (+,x)."""
+    m = orkut
+    n = m.num_rows
+    ones = np.ones(m.nnz, dtype=np.float32)
+    rng = np.random.default_rng(5)
+    x = (rng.random(m.num_cols) < 0.05).astype(np.float32)
+    mask = rng.integers(0, 2, size=n).astype(np.float32)
+    dx, dm = capi.DeviceBuffer(4 * m.num_cols), capi.DeviceBuffer(4 * n)
+    dx.write(x)
+    dm.write(mask)
+    plans = {"general": capi.SpMVPlan(n, m.num_cols, m.adj_indptr, m.adj_indices, ones, flags=capi.GL_PLAN_KEEP_VALUES),
+             "pattern": capi.SpMVPlan(n, m.num_cols, m.adj_indptr, m.adj_indices, ones),
+             "boolean": capi.SpMVPlan(n, m.num_cols, m.adj_indptr, m.adj_indices, ones, flags=capi.GL_PLAN_BOOLEAN)}
+    assert {k: p.info()["layout"] for k, p in plans.items()} == {"general": "general", "pattern": "pattern", "boolean": "boolean"}
+
+    def run(name, op, zero, mask_type, xbuf=dx):
+        dy = capi.DeviceBuffer(4 * n)
+        plans[name].run(xbuf, dm, dy, op, zero, mask_type)
+        return dy.read(np.float32, n)
+
+    for mt in (0, 1, 2):
+        ref = run("general", 1, 0.0, mt)
+        assert np.array_equal(run("boolean", 1, 0.0, mt), ref)
+        assert np.array_equal(run("pattern", 1, 0.0, mt), ref)
+    xt = np.where(x != 0, np.float32(3.0), np.float32(255.0)).astype(np.float32)
+    dxt = capi.DeviceBuffer(4 * m.num_cols)
+    dxt.write(xt)
+    assert np.array_equal(run("pattern", 2, 255.0, 1, dxt), run("general", 2, 255.0, 1, dxt))
+    xa = rng.random(m.num_cols, dtype=np.float32)
+    dxa = capi.DeviceBuffer(4 * m.num_cols)
+    dxa.write(xa)
+    np.testing.assert_allclose(run("pattern", 0, 0.0, 0, dxa), run("general", 0, 0.0, 0, dxa), rtol=2e-6, atol=0)
