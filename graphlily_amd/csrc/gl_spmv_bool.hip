@@ -2,7 +2,8 @@
 //
 // This is the BFS pull step (app/bfs.h:107-128 -> SpMVModule::run with LogicalSemiring).  With boolean
 // algebra neither the matrix values nor the float vector have to travel:
-//   entries   4 bytes: (col - group_base) << 14 | row_in_block, column-sorted per row block like the general
+//   entries   4 bytes: x word offset from the group's base : 13 | row_in_block : 14 | bit in the word : 5,
+//             column-sorted per row block like the general
 //             layout (gl_spmv.hip); entries whose value is 0 are dropped at format time (a && b is false).
 //             A group is 128 entries = 512 bytes, one coalesced 8-byte-per-lane read; half the HBM bytes.
 //   x         packed to one bit per column by spmv_bool_pack_kernel (12 MB read once per run), and a whole
@@ -17,7 +18,7 @@ namespace gl {
 
 struct BoolArgs {
     const uint2 *entries;      // groups of 128: lane l holds entries 2l and 2l+1
-    const uint32_t *bases;     // per group: base column minus the first column of its phase
+    const uint32_t *bases;     // per group: first x word (of its phase) the group's word offsets count from
     const uint4 *units;        // 2 per unit: {first span, #spans, first row, #rows | direct << 31}, {hub offset, #hub rows, -, -}
     const uint32_t *hub_rows;  // row_in_block of every hub row, per block
     const uint4 *spans;        // {first xbits word of the phase, first group, end group, lo4 | hi4 << 16}
@@ -51,6 +52,8 @@ __device__ __forceinline__ uint4 load_const(const uint4 *p) {
     const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
     return make_uint4(load_const(q), load_const(q + 1), load_const(q + 2), load_const(q + 3));
 }
+
+constexpr int kBoolStep = 2;   // ring slots processed together (divides the ring depth)
 
 template <int MASK, int U>
 __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
@@ -97,22 +100,33 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         __syncthreads();
         for (uint32_t g = s.y + wave; g < gend; g += kWaves * U) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t gi = g + u * kWaves;
-                if (gi < gend) {   // wave-uniform
-                    // Per entry: bit index = base + offset, one LDS word read, bit test; hits OR the row's bit
-                    // into the tile.  Padding entries are ordinary entries of the ghost row slot 16383, which
-                    // the epilogue never reads -- no per-entry validity test.  16-lane SIMDs make every VALU
-                    // instruction cost 4 clocks per wavefront, so this path is kept to ~6 of them per entry.
-                    const uint32_t v0 = e[u].x, v1 = e[u].y;
-                    const uint32_t c0 = b[u] + (v0 >> kRowBits), c1 = b[u] + (v1 >> kRowBits);
-                    const uint32_t w0 = xw[c0 >> 5], w1 = xw[c1 >> 5];   // both lookups in flight before the tests
-                    if (__builtin_amdgcn_ubfe(w0, c0, 1u)) atomicOr(&tile[(v0 & kRowPad) >> 5], 1u << (v0 & 31u));
-                    if (__builtin_amdgcn_ubfe(w1, c1, 1u)) atomicOr(&tile[(v1 & kRowPad) >> 5], 1u << (v1 & 31u));
+            for (int u = 0; u < U; u += kBoolStep) {
+                // Per entry: bit index = base + offset, one LDS word read, bit test; hits OR the row's bit into the
+                // tile.  Padding entries are ordinary entries of the ghost row slot 16383, which the epilogue never
+                // reads, and a slot past the span's end holds the span's last group again (clamped index), which
+                // is harmless to apply twice -- so there is no validity test at all.  16-lane SIMDs make every VALU
+                // instruction cost 4 clocks per wavefront: the path is kept to ~6 of them per entry, and kBoolStep ring
+                // slots are processed together so that 2 * kBoolStep LDS lookups are in flight before the first test.
+                // entry = word offset : 13 | row slot : 14 | bit : 5 (v_bfe takes the bit number from the low 5 bits
+                // of its operand, so the entry itself is the bit selector); b = first x word of the group
+                constexpr int NE = 2 * kBoolStep;
+                uint32_t v[NE], w[NE];
+#pragma unroll
+                for (int k = 0; k < NE; k++) v[k] = (k & 1) ? e[u + (k >> 1)].y : e[u + (k >> 1)].x;
+#pragma unroll
+                for (int k = 0; k < NE; k++) w[k] = xw[b[u + (k >> 1)] + (v[k] >> 19)];
+#pragma unroll
+                for (int k = 0; k < NE; k++)
+                    if (__builtin_amdgcn_ubfe(w[k], v[k], 1u)) {
+                        const uint32_t r = (v[k] >> 5) & kRowPad;
+                        atomicOr(&tile[r >> 5], 1u << (r & 31u));
+                    }
+#pragma unroll
+                for (int k = 0; k < kBoolStep; k++) {
+                    const uint32_t gn = min(g + (u + k) * kWaves + kWaves * U, glast);
+                    e[u + k] = load_stream_nt(a.entries + (size_t)gn * 64u + lane);
+                    b[u + k] = load_const(a.bases + gn);
                 }
-                const uint32_t gn = min(gi + kWaves * U, glast);
-                e[u] = load_stream_nt(a.entries + (size_t)gn * 64u + lane);
-                b[u] = load_const(a.bases + gn);
             }
         }
 #pragma unroll
@@ -349,7 +363,7 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
                 bool open = false;
                 auto seal_group = [&]() {   // pad the open group with entries of the ghost row slot, column = base
                     if (!open) return;
-                    for (; fill < kBoolGroup; fill++) o.ent.push_back(kRowPad);
+                    for (; fill < kBoolGroup; fill++) o.ent.push_back(kRowPad << 5);
                     open = false;
                 };
                 auto close_span = [&]() {
@@ -370,12 +384,12 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
                     }
                     if (!open || fill == kBoolGroup || cin - base >= (1u << kColOffBits)) {
                         seal_group();
-                        base = cin;
-                        o.bases.push_back(base);
+                        base = cin & ~31u;                 // groups start on an x word
+                        o.bases.push_back(base >> 5);
                         fill = 0;
                         open = true;
                     }
-                    o.ent.push_back(((cin - base) << kRowBits) | slot_of(rc, fill));
+                    o.ent.push_back((((cin - base) >> 5) << 19) | (slot_of(rc, fill) << 5) | (cin & 31u));
                     fill++;
                     hi = cin;
                 }
