@@ -18,6 +18,7 @@ Differences that do not change results:
   * vectors are allocated by the driver and bound into the modules, so the same buffers can be
     handed to the collective.
 """
+import os
 import time
 
 import numpy as np
@@ -150,7 +151,7 @@ class _GraphApp(ModuleCollection):
         buf = B.alloc(n, np.float32)
         B.fill(buf, float(fill), n)
         if source is not None:
-            B.upload(B.view(buf, source, 1, 4), np.array([source_value], dtype=np.float32))
+            B.fill(B.view(buf, source, 1, 4), float(source_value), 1)   # a 1-element fill kernel: no blocking copy
         return buf
 
     def _gather_sparse(self, local_buf, out_buf, n, head_val):
@@ -207,11 +208,14 @@ class BFS(_GraphApp):
         self.SpMSpV_.send_matrix_host_to_device()
         if hasattr(self.SpMSpV_, "attach_pull"):
             self.SpMSpV_.attach_pull(self.SpMV_)     # heavy frontiers of a push iteration go row-wise
+        self.results_ = self.bits_a_ = self.bits_b_ = None   # per-matrix scratch of the pull loop
 
     # -- pull ------------------------------------------------------------------------------------
     def _bind_pull(self, vector, distance):
         B, n = self.backend, self.n_
-        results = B.alloc(n, np.float32)
+        results = getattr(self, "results_", None)     # scratch of the unfused path, kept across calls
+        if results is None:
+            results = self.results_ = B.alloc(n, np.float32)
         self.SpMV_.bind_vector_buf(vector)
         self.SpMV_.bind_mask_buf(distance)
         self.SpMV_.bind_results_buf(results)
@@ -219,16 +223,38 @@ class BFS(_GraphApp):
         self.DenseAssign_.bind_inout_buf(self._own(distance))
         self.eWiseAdd_.bind_in_buf(self._own(results))
         self.eWiseAdd_.bind_out_buf(self._own(vector))
-        # Row-sharded runs exchange the frontier as BITS (n/8 bytes per iteration instead of 4n): the boolean
-        # SpMV layout reads a bit vector anyway.  Slices are whole 64-bit words (shard bounds are 64-aligned).
-        self.bits_ = None
-        words = self.SpMV_.bits_words() if (self.comm.distributed and hasattr(self.SpMV_, "bits_words")) else 0
-        if words and all(b % 64 == 0 for b in self.bounds_):
-            self.bits_ = B.alloc(words, np.float32)          # opaque 32-bit words
-            capi.pack_bits(vector, n, self.bits_)
+        # The frontier lives as BITS wherever the boolean SpMV layout allows it: row-sharded runs then exchange n/8
+        # bytes per iteration instead of 4n, and on unsplit plans the whole pull iteration (masked SpMV, eWiseAdd,
+        # dense assign, packing of the next frontier) is ONE launch (gl_bfs_pull_step).  Slices are whole 64-bit
+        # words (shard bounds are 64-aligned).
+        self.bits_ = self.bits_next_ = None
+        self.fused_ = False
+        self.distance_ = distance
+        words = self.SpMV_.bits_words() if hasattr(self.SpMV_, "bits_words") else 0
+        aligned = (not self.comm.distributed) or all(b % 64 == 0 for b in self.bounds_)
+        if words and aligned:
+            self.fused_ = (os.environ.get("GRAPHLILY_BFS_FUSED", "1") != "0" and hasattr(self.SpMV_, "fused_bfs_ok")
+                           and self.SpMV_.fused_bfs_ok())
+            if self.fused_ or self.comm.distributed:
+                # opaque 32-bit words, kept across calls: pack_bits / the fused step rewrite every word of the row
+                # range, words past it stay 0 from the allocation
+                if getattr(self, "bits_a_", None) is None:
+                    self.bits_a_, self.bits_b_ = B.alloc(words, np.float32), B.alloc(words, np.float32)
+                    B.fill(self.bits_a_, 0.0, words)
+                    B.fill(self.bits_b_, 0.0, words)
+                self.bits_ = self.bits_a_
+                capi.pack_bits(vector, n, self.bits_)
+            if self.fused_:
+                self.bits_next_ = self.bits_b_
 
     def _pull_iteration(self, vector, it):
         B, own = self.backend, self.r1_ - self.r0_
+        if self.fused_:
+            self.SpMV_.bfs_pull_step(self.bits_, self.bits_next_, self.distance_, float(it + 1))
+            self.bits_, self.bits_next_ = self.bits_next_, self.bits_
+            if self.comm.distributed:
+                self.comm.all_gather_slices(self.bits_.tensor, [b // 32 for b in self.bounds_])
+            return
         if self.bits_ is not None:
             self.SpMV_.run_bits(self.bits_)
         else:

@@ -32,7 +32,7 @@ EXPORTS = [
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32",
     "gl_host_alloc", "gl_host_free",
     "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_run",
-    "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits",
+    "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits", "gl_bfs_pull_step",
     "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
     "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_last_direction",
@@ -82,6 +82,7 @@ def lib():
         "gl_spmv_plan_hot": [vp, P(u32), P(u64), P(i32)],
         "gl_spmv_plan_layout": [vp, P(i32)],
         "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
+        "gl_bfs_pull_step": [vp, vp, vp, vp, f32],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
         "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)], "gl_prof_sample_every": [u32],
         "gl_spmspv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
@@ -290,6 +291,9 @@ class SpMVPlan:
         v = ctypes.c_uint64(0)
         check(lib().gl_spmv_plan_bits_words(ctypes.c_void_p(self.handle), ctypes.byref(v)))
         return v.value
+
+    def bfs_pull_step(self, bits_in, bits_out, distance, level):
+        check(lib().gl_bfs_pull_step(ctypes.c_void_p(self.handle), _p(bits_in), _p(bits_out), _p(distance), float(level)))
 
     def run_bits(self, bits, mask, y, zero, mask_type):
         check(lib().gl_spmv_run_bits(ctypes.c_void_p(self.handle), _p(bits), _p(mask), _p(y), float(zero), int(mask_type)))

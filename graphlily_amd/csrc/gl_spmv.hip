@@ -697,7 +697,8 @@ static Shape choose_shape(uint64_t rows, uint64_t cols, uint64_t nnz, int num_cu
 }
 
 // see gl_spmv_plan.h
-BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin, uint32_t row_end, uint32_t max_rows) {
+BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin, uint32_t row_end, uint32_t max_rows,
+                      uint32_t align) {
     BlockPlan bp;
     const uint64_t nz0 = h_indptr[row_begin], nz1 = h_indptr[row_end], nnz = nz1 - nz0;
     std::vector<uint32_t> &bstart = bp.bstart;
@@ -718,6 +719,12 @@ BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin,
                 const uint32_t *ub = std::upper_bound(h_indptr + r + 1, h_indptr + hi + 1, want);
                 e = (uint32_t)(ub - h_indptr) - 1u;
                 if (e < r + 1) e = r + 1;
+                if (align > 1u) {   // interior boundaries on multiples of `align` rows (row_begin and max_rows are)
+                    uint32_t ea = (e + align / 2u) / align * align;
+                    if (ea <= r) ea = r - r % align + align;
+                    if (ea >= hi) ea = (hi == row_end) ? row_end : hi / align * align;
+                    e = ea;
+                }
             }
             bstart.push_back(e);
             r = e;
@@ -1233,6 +1240,16 @@ int gl_spmv_run_bits(gl_spmv_plan p, const uint32_t *d_bits, const float *d_mask
     if (!p->boolean)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run_bits: the plan does not hold the GL_PLAN_BOOLEAN layout");
     return gl::bool_plan_run(p, nullptr, d_bits, d_mask, d_y, zero, mask_type, gl::ctx().stream);
+}
+
+int gl_bfs_pull_step(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && d_bits_in != nullptr && d_bits_out != nullptr && d_distance != nullptr);
+    GL_ARG(d_bits_in != d_bits_out);
+    GL_ARG((((uintptr_t)d_bits_in | (uintptr_t)d_bits_out) & 15u) == 0);
+    if (!p->boolean)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step: the plan does not hold the GL_PLAN_BOOLEAN layout");
+    return gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, gl::ctx().stream);
 }
 
 int gl_spmv_plan_layout(gl_spmv_plan p, int *layout) {

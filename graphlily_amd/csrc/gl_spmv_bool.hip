@@ -27,6 +27,11 @@ struct BoolArgs {
     float *y;
     float zero;
     const uint32_t *run_flag;  // non-null: the launch is a no-op unless run_flag[0] != 0 (gl_spmspv_run's direction switch)
+    // fused BFS pull step (gl_bfs_pull_step): rows reached now and not visited before get `level` and form the next
+    // frontier, written as bits
+    uint32_t *bits_out;
+    float *dist;
+    float level;
 };
 
 // x != 0 packed little-endian, 64 columns per wavefront step; words past num_cols are zero
@@ -55,7 +60,7 @@ __device__ __forceinline__ uint4 load_const(const uint4 *p) {
 
 constexpr int kBoolStep = 2;   // ring slots processed together (divides the ring depth)
 
-template <int MASK, int U>
+template <int MASK, int U, int FUSED>
 __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
     // tile first: its byte offsets fit the 16-bit immediate of the LDS instructions either way
@@ -147,7 +152,21 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         __syncthreads();
     }
 
-    if (direct) {
+    if (FUSED) {
+        // SpMV masked by `distance == 0`, eWiseAdd(+0), assign(level) where the result is set, and the packing of
+        // the next frontier (app/bfs.h:118-123) in one epilogue: 64 rows per wavefront step, one 64-bit word out.
+        // Blocks of boolean plans start on multiples of 64 rows, so every word has exactly one writer.
+        for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < nrows; i0 += kThreads) {
+            const uint32_t i = i0 + lane, row = row0 + i;
+            bool fresh = false;
+            if (i < nrows && ((tile[i >> 5] >> (i & 31u)) & 1u) && a.dist[row] == 0.0f) {
+                a.dist[row] = a.level;
+                fresh = true;
+            }
+            const uint64_t m = __ballot(fresh);
+            if (lane == 0) reinterpret_cast<uint64_t *>(a.bits_out)[(row0 + i0) >> 6] = m;
+        }
+    } else if (direct) {
         for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
             const uint32_t row = row0 + i;
             const bool hit = (tile[i >> 5] >> (i & 31u)) & 1u;
@@ -172,24 +191,52 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
 constexpr int kBoolUnroll = 6;
 constexpr size_t kBoolLds = ((size_t)kBoolPhaseWords + kBoolTileWords) * 4u;
 
-template <int MASK>
-static int launch_bool(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
+template <int MASK, int FUSED>
+static int launch_bool_variant(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute((const void *)spmv_bool_kernel<MASK, kBoolUnroll>,
+        GL_HIP(hipFuncSetAttribute((const void *)spmv_bool_kernel<MASK, kBoolUnroll, FUSED>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBoolLds));
         attr_set = true;
     }
     Profiler &pf = prof();
     const bool timed = prof_take(pf);
     if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
-    spmv_bool_kernel<MASK, kBoolUnroll><<<p->nunits, kThreads, kBoolLds, s>>>(a);
+    spmv_bool_kernel<MASK, kBoolUnroll, FUSED><<<p->nunits, kThreads, kBoolLds, s>>>(a);
     GL_LAUNCH_CHECK();
     if (timed) {
         GL_HIP(hipEventRecord(pf.events[2 * pf.used + 1], s));
         pf.used++;
     }
     return GL_OK;
+}
+
+template <int MASK>
+static int launch_bool(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
+    return launch_bool_variant<MASK, 0>(p, a, s);
+}
+
+// One BFS pull iteration on the bit layout (see the FUSED epilogue).  Unsplit plans whose shard starts on a
+// multiple of 64 rows only; bits_out must not alias bits_in.
+int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s) {
+    if (p->row_end == p->row_begin) return GL_OK;
+    if (p->segments > 1 || (p->row_begin & 63u) || !p->nunits)
+        return set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step: needs an unsplit boolean plan whose shard starts on a multiple of 64 rows");
+    BoolArgs a;
+    a.entries = p->d_entries;
+    a.bases = p->d_bases;
+    a.units = p->d_units;
+    a.hub_rows = p->d_hub_rows;
+    a.spans = p->d_spans;
+    a.xbits = bits_in;
+    a.mask = nullptr;
+    a.y = nullptr;
+    a.zero = 0.0f;
+    a.run_flag = nullptr;
+    a.bits_out = bits_out;
+    a.dist = d_distance;
+    a.level = level;
+    return launch_bool_variant<GL_NOMASK, 1>(p, a, s);
 }
 
 // d_x != nullptr: pack it into the plan's bit vector first; else run on `bits` as the caller prepared them
@@ -221,6 +268,9 @@ int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const 
     a.y = d_y;
     a.zero = zero;
     a.run_flag = nullptr;
+    a.bits_out = nullptr;
+    a.dist = nullptr;
+    a.level = 0.0f;
     switch (mask_type) {
         case GL_NOMASK: return launch_bool<GL_NOMASK>(p, a, s);
         case GL_MASK_WRITETOZERO: return launch_bool<GL_MASK_WRITETOZERO>(p, a, s);
@@ -256,6 +306,9 @@ int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hip
     a.y = d_y;
     a.zero = 0.0f;
     a.run_flag = run_flag;
+    a.bits_out = nullptr;
+    a.dist = nullptr;
+    a.level = 0.0f;
     return launch_bool<GL_NOMASK>(p, a, s);
 }
 
@@ -299,7 +352,8 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
     const uint32_t num_cols = p->num_cols, row_begin = p->row_begin, row_end = p->row_end;
     const uint32_t rows = row_end - row_begin;
     const Shape shape = choose_shape_bool(rows, num_cols, p->nnz, ctx().num_cus);
-    const BlockPlan bp = plan_blocks(shape, h_indptr, row_begin, row_end, kBoolHubBit0);
+    // block boundaries on multiples of 64 rows: the fused BFS epilogue writes whole 64-bit frontier words
+    const BlockPlan bp = plan_blocks(shape, h_indptr, row_begin, row_end, kBoolHubBit0 / 64u * 64u, 64u);
     const uint32_t nblocks = bp.nblocks, nunits = bp.nunits;
     const uint32_t nphases = cdiv(num_cols, kBoolPhaseCols);
 

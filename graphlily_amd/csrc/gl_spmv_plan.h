@@ -75,7 +75,8 @@ struct BlockPlan {
     bool all_direct = true;
 };
 
-BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin, uint32_t row_end, uint32_t max_rows);
+BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin, uint32_t row_end, uint32_t max_rows,
+                      uint32_t align = 1);
 
 }  // namespace gl
 
@@ -116,6 +117,7 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
 int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const float *d_mask, float *d_y, float zero,
                   int mask_type, hipStream_t s);
 int pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits, hipStream_t s);
+int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s);
 int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s);
 uint32_t *bool_plan_xbits(gl_spmv_plan p);
 size_t bool_plan_xbits_bytes(gl_spmv_plan p);

@@ -195,6 +195,19 @@ class SpMVModule(BaseModule):
     def bits_words(self):
         return self.plan_.bits_words() if self.plan_ is not None and self._plan_serves(self.semiring_.op) else 0
 
+    def bfs_pull_step(self, bits_in, bits_out, distance_buf, level):
+        """Extension (gl_bfs_pull_step): this module's masked (||,&&) run + eWiseAdd(+0) + dense assign(level) of a
+        BFS pull iteration in one launch, frontier in and out as bit vectors.  Raises GraphLilyError
+        (GL_ERR_UNSUPPORTED) for split plans."""
+        self.plan_.bfs_pull_step(bits_in, bits_out, distance_buf, level)
+        self._finish()
+
+    def fused_bfs_ok(self):
+        if self.plan_ is None or not self._plan_serves(self.semiring_.op) or self.semiring_.zero != 0.0:
+            return False
+        info = self.plan_.info()
+        return info["layout"] == "boolean" and info["segments"] == 1 and self.row_begin_ % 64 == 0
+
     def run_bits(self, bits_buf):
         mask = self.mask_buf if self.mask_type_ != kNoMask else None
         self.plan_.run_bits(bits_buf, mask, self.results_buf, self.semiring_.zero, self.mask_type_)

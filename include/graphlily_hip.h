@@ -133,6 +133,14 @@ int gl_spmv_plan_bits_words(gl_spmv_plan plan, uint64_t *words);
 int gl_pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits);
 int gl_spmv_run_bits(gl_spmv_plan plan, const uint32_t *d_bits, const float *d_mask, float *d_y, float zero,
                      int mask_type);
+/* Extension: one BFS pull iteration fused into one launch.  Equivalent to SpMVModule::run with the (||,&&) semiring
+ * masked WriteToZero by `distance`, eWiseAddModule::run(+0) into the frontier vector and
+ * AssignVectorDenseModule::run(level) WriteToOne by that vector (app/bfs.h:118-123), with the frontier kept as
+ * bits: rows with an edge from the frontier `bits_in` whose distance is still 0 get distance = level and their bit
+ * in `bits_out` (every word of the plan's row range is written).  Needs an unsplit GL_PLAN_BOOLEAN plan whose
+ * row range starts on a multiple of 64 (GL_ERR_UNSUPPORTED otherwise: use the three calls).  Both bit vectors
+ * have gl_spmv_plan_bits_words words, are 16-byte aligned and distinct. */
+int gl_bfs_pull_step(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level);
 /* hot-column cache: columns whose x value is kept in LDS, the non-zeros they serve, and the cold/hot
  * interleave in use (0 = no hot table, 5 = 3 cold + 3 hot groups per wavefront iteration) */
 int gl_spmv_plan_hot(gl_spmv_plan plan, uint32_t *hot_columns, uint64_t *hot_nnz, int *mix);

@@ -157,3 +157,55 @@ def test_time_breakdown_variants(gpu, capsys):
     assert pr.time_breakdown_["spmv"] > 0
     out = capsys.readouterr().out
     assert "spmv_spmspv_time_ms" in out and "spmv_time_ms per iteration" in out
+
+
+def test_fused_bfs_pull_step_equals_the_three_calls(gpu, monkeypatch):
+    """gl_bfs_pull_step = masked (||,&&) SpMV + eWiseAdd(+0) + dense assign(level) + packing of the next frontier
+    (app/bfs.h:118-123) in one launch.  Whole BFS runs with and without it must give the same levels (and the
+    oracle's), and one step through the C ABI must leave the same distance vector and frontier as the module calls."""
+    from graphlily_amd import capi
+    raw = datasets.rmat(30000, 500000, 17, True)
+    src = int(np.argmax(np.diff(raw.adj_indptr.astype(np.int64)) > 0))
+    runs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("GRAPHLILY_BFS_FUSED", fused)
+        bfs = app.BFS(16, 0, 0, 0)
+        bfs.set_up_runtime()
+        bfs.load_and_format_matrix(raw.copy(), True)
+        bfs.send_matrix_host_to_device()
+        runs[fused] = [bfs.pull(src, 8), bfs.pull_push(src, 8, 0.01)]
+        assert bfs.fused_ == (fused == "1")
+    for a, b in zip(runs["1"], runs["0"]):
+        assert np.array_equal(a, b)
+    om = to_oracle(raw)
+    O.util_round_csr_matrix_dim(om, 128, 128)
+    om.adj_data[:] = 1
+    assert np.array_equal(runs["1"][0], O.bfs(om, src, 8))
+    # one step, C ABI against the oracle's three operators
+    m = raw.copy()
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    n = m.num_rows
+    plan = capi.SpMVPlan(n, n, m.adj_indptr, m.adj_indices, np.ones(m.nnz, np.float32), flags=capi.GL_PLAN_BOOLEAN)
+    rng = np.random.default_rng(2)
+    x = (rng.random(n) < 0.02).astype(np.float32)
+    dist = np.where(rng.random(n) < 0.3, np.float32(2.0), np.float32(0.0)).astype(np.float32)
+    words = plan.bits_words()
+    dx, dd = capi.DeviceBuffer(4 * n), capi.DeviceBuffer(4 * n)
+    b_in, b_out = capi.DeviceBuffer(4 * words), capi.DeviceBuffer(4 * words)
+    dx.write(x)
+    dd.write(dist)
+    b_in.write(np.zeros(words, np.uint32))
+    b_out.write(np.full(words, 0xFFFFFFFF, np.uint32))     # every word of the row range must be overwritten
+    capi.pack_bits(dx, n, b_in)
+    plan.bfs_pull_step(b_in, b_out, dd, 5.0)
+    y = O.spmv(to_oracle(m), x, 1, 0.0, dist, O.WRITETOZERO)   # a_ij are 1 in `m`? use unit weights
+    om2 = to_oracle(m)
+    om2.adj_data[:] = 1
+    y = O.spmv(om2, x, 1, 0.0, dist, O.WRITETOZERO)
+    want_dist = dist.copy()
+    want_dist[y != 0] = 5.0
+    assert np.array_equal(dd.read(np.float32, n), want_dist)
+    bits = b_out.read(np.uint32, words)
+    got_front = ((bits[np.arange(n) >> 5] >> (np.arange(n) & 31).astype(np.uint32)) & 1).astype(np.float32)
+    assert np.array_equal(got_front, y)
+    assert not bits[(n + 31) // 32:].any() or np.all(bits[(n + 31) // 32:] == 0xFFFFFFFF)   # words past the rows untouched
