@@ -424,15 +424,21 @@ class PageRank(_GraphApp):
         vector = self._new_dense(n, np.float32(1.0 / n))
         teleport = np.float32(np.float32(1) - np.float32(damping)) / np.float32(n)
         results = B.alloc(n, np.float32)
-        self.SpMV_.bind_vector_buf(vector)
-        self.SpMV_.bind_results_buf(results)
-        self.eWiseAdd_.bind_in_buf(self._own(results))
-        self.eWiseAdd_.bind_out_buf(self._own(vector))
-        own = self.r1_ - self.r0_
-        for _ in range(num_iterations):
-            self.SpMV_.run()
-            self.eWiseAdd_.run(own, float(teleport))
-            self._gather(vector)
+        # The reference runs SpMV with zero = 0 and then eWiseAdd(results, teleport) -> vector (app/pagerank.h:84-88).
+        # The device epilogue computes zero + sum in float, so passing the teleport term AS the semiring's zero gives
+        # the same float (a + b == b + a), and the two buffers swap roles instead of being copied: one launch and
+        # 8n bytes less per iteration.
+        saved = self.SpMV_.semiring_
+        self.SpMV_.set_semiring(M.SemiringType(M.kMulAdd, 1.0, float(teleport)))
+        try:
+            for _ in range(num_iterations):
+                self.SpMV_.bind_vector_buf(vector)
+                self.SpMV_.bind_results_buf(results)
+                self.SpMV_.run()
+                self._gather(results)
+                vector, results = results, vector
+        finally:
+            self.SpMV_.set_semiring(saved)
         B.sync()
         return B.download_result(vector, n)
 
@@ -514,15 +520,14 @@ class SSSP(_GraphApp):
     def _pull_loop(self, vector, first_it, num_iterations):
         B, n = self.backend, self.n_
         results = B.alloc(n, np.float32)
-        self.SpMV_.bind_vector_buf(vector)
-        self.SpMV_.bind_results_buf(results)
-        self.eWiseAdd_.bind_in_buf(self._own(results))
-        self.eWiseAdd_.bind_out_buf(self._own(vector))
-        own = self.r1_ - self.r0_
+        # The reference copies results -> vector after every SpMV (eWiseAdd with 0, app/sssp.h:163); here the two
+        # buffers swap roles instead: same values, one launch and 8n bytes less per iteration.
         for _ in range(first_it, num_iterations + 1):
+            self.SpMV_.bind_vector_buf(vector)
+            self.SpMV_.bind_results_buf(results)
             self.SpMV_.run()
-            self.eWiseAdd_.run(own, 0.0)             # results -> vector (app/sssp.h:163)
-            self._gather(vector)
+            self._gather(results)
+            vector, results = results, vector
         B.sync()
         return B.download_result(vector, n)
 

@@ -71,10 +71,19 @@ class SpMVModule(_Mod):
     def run(self):
         s = self.semiring_
         x = self.vector_buf.np()
+        # (+,x) with a non-zero `zero` (PageRank passes its teleport term there): the device adds it to the finished
+        # row sum -- zero + sum, one float add, like the reference's eWiseAdd after the SpMV -- not in front of it
+        late = s.op == M.kMulAdd and s.zero != 0.0
+        zero = 0.0 if late else s.zero
         if self.mask_type_ == M.kNoMask:
-            y = O.spmv(self.sub, x, s.op, s.zero)
+            y = O.spmv(self.sub, x, s.op, zero)
+            allowed = np.ones(y.shape[0], bool)
         else:
-            y = O.spmv(self.sub, x, s.op, s.zero, self.mask_buf.np()[self.r0:self.r1].copy(), self.mask_type_)
+            mask = self.mask_buf.np()[self.r0:self.r1].copy()
+            y = O.spmv(self.sub, x, s.op, zero, mask, self.mask_type_)
+            allowed = (mask == 0) if self.mask_type_ == M.kMaskWriteToZero else (mask != 0)
+        if late:
+            y = np.where(allowed, np.float32(s.zero) + y, np.float32(0)).astype(np.float32)
         self.results_buf.np()[self.r0:self.r1] = y
 
 
