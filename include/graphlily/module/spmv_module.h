@@ -75,6 +75,32 @@ public:
     }
 
     gl_spmv_plan plan_handle() const { return plan_; }   // extension: for SpMSpVModule::attach_pull_plan
+
+    // extensions for (||,&&) loops that keep the frontier as a bit vector (gl_spmv_plan_bits_words, gl_pack_bits,
+    // gl_spmv_run_bits, gl_bfs_pull_step): bits_words() is 0 unless the plan holds the boolean layout
+    uint64_t bits_words() {
+        uint64_t w = 0;
+        if (plan_ && plan_serves_(semiring_.op)) GRAPHLILY_CHECK(gl_spmv_plan_bits_words(plan_, &w));
+        return w;
+    }
+    static void pack_bits(DeviceBuffer x, uint32_t n, DeviceBuffer bits) {
+        GRAPHLILY_CHECK(gl_pack_bits((const float *)x.ptr(), n, (uint32_t *)bits.ptr()));
+    }
+    void run_bits(DeviceBuffer bits) {
+        GRAPHLILY_CHECK(gl_spmv_run_bits(plan_, (const uint32_t *)bits.ptr(),
+                                         mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
+                                         (float *)results_buf.ptr(), semiring_.zero, (int)mask_type_));
+        finish_();
+    }
+    // one BFS pull iteration (app/bfs.h:118-123) in one launch; false if the plan is split: use the three calls
+    bool bfs_pull_step(DeviceBuffer bits_in, DeviceBuffer bits_out, DeviceBuffer distance, float level) {
+        const int rc = gl_bfs_pull_step(plan_, (const uint32_t *)bits_in.ptr(), (uint32_t *)bits_out.ptr(),
+                                        (float *)distance.ptr(), level);
+        if (rc == GL_ERR_UNSUPPORTED) return false;
+        GRAPHLILY_CHECK(rc);
+        finish_();
+        return true;
+    }
     uint32_t get_num_rows() { return csr_matrix_float_.num_rows; }
     uint32_t get_num_cols() { return csr_matrix_float_.num_cols; }
     uint32_t get_nnz() { return csr_matrix_float_.adj_indptr[csr_matrix_float_.num_rows]; }

@@ -79,6 +79,39 @@ int main() {
                 verify(ref, spmv.send_results_device_to_host(), name, s != 0);
             }
     }
+    {   // extensions: frontier as bits, fused BFS pull step == SpMV(WriteToZero by distance) + eWiseAdd(0) + assign(level)
+        module::SpMVModule<val_t, val_t> spmv(num_hbm_channels, 1024, 256);
+        spmv.set_semiring(LogicalSemiring);
+        spmv.set_mask_type(kMaskWriteToZero);
+        spmv.set_up_runtime("unused.xclbin");
+        spmv.load_and_format_matrix(csr, true);
+        spmv.send_matrix_host_to_device();
+        const uint32_t n = csr.num_rows;
+        fvec x(csr.num_cols), dist(n);
+        for (auto &v : x) v = float(rng() % 8 == 0);
+        for (auto &v : dist) v = (rng() % 3 == 0) ? 2.0f : 0.0f;
+        spmv.send_vector_host_to_device(x);
+        spmv.send_mask_host_to_device(dist);
+        const uint64_t words = spmv.bits_words();
+        if (words == 0) { printf("boolean layout expected\n"); failures++; }
+        DeviceBuffer bits_in(4 * words), bits_out(4 * words);
+        std::vector<uint32_t> zero_words(words, 0u);
+        bits_in.upload(zero_words.data(), 4 * words);
+        bits_out.upload(zero_words.data(), 4 * words);
+        module::SpMVModule<val_t, val_t>::pack_bits(spmv.vector_buf, csr.num_cols, bits_in);
+        spmv.run_bits(bits_in);
+        fvec y = spmv.send_results_device_to_host();
+        verify(spmv.compute_reference_results(x, dist), y, "SpMV run_bits Logical WriteToZero", true);
+        fvec want = dist;
+        for (uint32_t r = 0; r < n; r++) if (y[r] != 0) want[r] = 5.0f;
+        if (!spmv.bfs_pull_step(bits_in, bits_out, spmv.mask_buf, 5.0f)) { printf("bfs_pull_step unsupported\n"); failures++; }
+        verify(want, spmv.send_mask_device_to_host(), "fused BFS pull step: distance", true);
+        std::vector<uint32_t> got_bits(words);
+        bits_out.download(got_bits.data(), 4 * words);
+        fvec front(n);
+        for (uint32_t r = 0; r < n; r++) front[r] = float((got_bits[r >> 5] >> (r & 31)) & 1u);
+        verify(y, front, "fused BFS pull step: next frontier bits", true);
+    }
     {   // SpMSpV
         CSCMatrix<float> csc = io::csr2csc(csr);
         module::SpMSpVModule<val_t, val_t, idx_val_t> sp(512);
