@@ -124,6 +124,20 @@ def test_hot_column_cache_variants(gpu, hot, mix, monkeypatch):
             _check(got, m, sem, "WriteToOne", x, mask, "hot %s mix %s shape %s %s" % (hot, mix, shape, sem))
 
 
+def test_pattern_pair_layout_fallback(gpu, monkeypatch):
+    """GRAPHLILY_SPMV_PAT4=0 keeps two pattern groups per 8-byte load instead of four per 16-byte load."""
+    monkeypatch.setenv("GRAPHLILY_SPMV_PAT4", "0")
+    m = spmv_prepare("rmat_sym_50K")
+    m.adj_data = np.full(m.nnz, np.float32(0.5), np.float32)
+    x, mask = rand01(m.num_cols, 8), rand01(m.num_rows, 9)
+    for shape in ((0, 0), (5, 2)):
+        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
+        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        for sem in ("Arithmetic", "Tropical"):
+            got = _run_spmv(gpu, m, sem, "WriteToOne", x, mask)
+            _check(got, m, sem, "WriteToOne", x, mask, "pattern pairs %s %s" % (shape, sem))
+
+
 def test_narrow_general_layout(gpu, monkeypatch):
     """GRAPHLILY_SPMV_WIDE=0 keeps the 8-byte-per-lane stream (one group per load) -- the fallback of the default
     lane-interleaved group pairs; same results."""
