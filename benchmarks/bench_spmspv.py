@@ -5,7 +5,9 @@ Same protocol: matrix values 1/num_rows (:153), every k-th column active with va
 (:157-185), Arithmetic semiring, kNoMask (:283, :323), vector sparsity 90 ... 99.99 % (:270-276), one warm-up
 run that is VERIFIED (here against an f64 evaluation of the same product on the host, the benchmark does not
 import the oracle) and 20 timed blocking runs (:228-236); bytes = 8 x sum nnz(active columns) (:61-76),
-GTEPS = GB/s / 8 (:238-239).  The two `uniform_conflict_free` matrices of the reference's list are FPGA
+GTEPS = GB/s / 8 (:238-239).  By default the module gets a row-wise plan of its own matrix, so vectors whose
+columns hold more than 1/32 of the non-zeros are applied row-wise (`direction` in the output); --no-own-pull
+measures the scatter alone.  The two `uniform_conflict_free` matrices of the reference's list are FPGA
 bank-conflict probes and have no stand-in here.
 
     python benchmarks/bench_spmspv.py [--graphs googleplus,pokec] [--semirings Arithmetic,Logical] [--out profiles/rNN_spmspv_sweep.jsonl]
@@ -30,6 +32,8 @@ def main():
     ap.add_argument("--semirings", default="Arithmetic")
     ap.add_argument("--runs", type=int, default=20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--no-own-pull", action="store_true",
+                    help="scatter only: do not give the module a row-wise plan of its matrix for heavy vectors")
     args = ap.parse_args()
     import scipy.sparse as sp
     import torch
@@ -52,6 +56,8 @@ def main():
             mod.set_up_runtime("unused.xclbin")
             mod.load_and_format_matrix(csc)
             mod.send_matrix_host_to_device()
+            if not args.no_own_pull:
+                mod.enable_own_pull()       # direction switch inside the operator (gl_spmspv_plan_attach_pull)
             mod.send_mask_host_to_device(np.zeros(csc.num_rows, np.float32))
             rng = np.random.default_rng(1)
             for sparsity in SPARSITIES:
@@ -79,7 +85,8 @@ def main():
                 active = int(coldeg[idx].sum())
                 rec = {"graph": name, "semiring": sname, "vector_sparsity": sparsity, "vector_nnz": cnt,
                        "active_nnz": active, "result_nnz": int(res["index"][0]), "ms": round(ms, 4),
-                       "gbps": round(8 * active / ms / 1e6, 2), "gteps": round(active / ms / 1e6, 3), "verified": ok}
+                       "gbps": round(8 * active / ms / 1e6, 2), "gteps": round(active / ms / 1e6, 3), "verified": ok,
+                       "direction": mod.plan_.last_direction()}
                 print(json.dumps(rec), flush=True)
                 lines.append(rec)
             del mod

@@ -47,7 +47,9 @@ struct gl_spmspv_plan_s {
     uint32_t queue_capacity = 0;
     // direction switch inside the operator ((||,&&) only): a frontier whose columns hold more than 1/32 of the
     // matrix is cheaper to apply row-wise with the attached boolean SpMV plan than to scatter
-    gl_spmv_plan pull = nullptr;        // not owned
+    gl_spmv_plan pull = nullptr;        // not owned; boolean layout, serves (||,&&)
+    gl_spmv_plan pull_arith = nullptr;  // not owned; general / pattern layout of the same matrix, serves (+,x)
+    float *d_xdense = nullptr;          // the frontier as a dense vector for pull_arith (num_cols floats)
     uint32_t max_col_len = 0;           // longest column of the shard
     uint64_t frontier_hint = ~0ull;     // caller's upper bound on the next run's vector nnz (~0 = unknown)
     uint32_t *d_mode = nullptr;         // [0] 1 = this run goes row-wise, [1] block ticket, [2..3] work counter
@@ -247,6 +249,17 @@ __global__ __launch_bounds__(256) void spmspv_frontier_bits_kernel(const gl_idx_
     }
 }
 
+// row-wise (+,x) path: the frontier scattered into a zeroed dense vector
+__global__ __launch_bounds__(256) void spmspv_frontier_dense_kernel(const gl_idx_val *__restrict__ vec, uint32_t num_cols,
+                                                                    float *__restrict__ dense, const uint32_t *__restrict__ mode) {
+    if (!mode[0]) return;
+    const uint32_t vnnz = vec[0].index;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < vnnz; e += gridDim.x * 256u) {
+        const gl_idx_val iv = vec[1u + e];
+        if (iv.index < num_cols) dense[iv.index] = iv.val;
+    }
+}
+
 // compaction source over the dense accumulator
 template <int MASK>
 struct AccSource {
@@ -356,6 +369,7 @@ int gl_spmspv_plan_destroy(gl_spmspv_plan p) {
     (void)hipFree(p->d_queue);
     (void)hipFree(p->d_queue_count);
     (void)hipFree(p->d_mode);
+    (void)hipFree(p->d_xdense);
     delete p;
     return GL_OK;
 }
@@ -388,8 +402,8 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
     // (||,&&) with an attached boolean SpMV plan: decide on the device which way this run goes
     const long div = gl::env_long("GRAPHLILY_SPMSPV_PULL_DIV", 32);
     const uint64_t threshold = div > 0 ? p->nnz / (uint64_t)div : 0ull;
-    bool may_pull = p->pull != nullptr && op == GL_OP_ANDOR && zero == 0.0f && nrows > 0 &&
-                    gl::env_long("GRAPHLILY_SPMSPV_PULL", 1) != 0;
+    gl_spmv_plan pull_plan = op == GL_OP_ANDOR ? p->pull : (op == GL_OP_MULADD ? p->pull_arith : nullptr);
+    bool may_pull = pull_plan != nullptr && zero == 0.0f && nrows > 0 && gl::env_long("GRAPHLILY_SPMSPV_PULL", 1) != 0;
     // a caller that knows how many entries the vector holds (gl_spmspv_plan_hint) spares tiny frontiers the
     // decision kernels: they cannot reach the threshold whatever their columns are
     if (may_pull && p->frontier_hint != ~0ull && p->frontier_hint * (uint64_t)p->max_col_len <= threshold) may_pull = false;
@@ -399,7 +413,7 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
         uint32_t wgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), 64u);
         gl::spmspv_work_kernel<<<wgrid ? wgrid : 1u, 256, 0, s>>>(d_vector, p->d_indptr, p->num_cols, p->d_mode, threshold);
         GL_LAUNCH_CHECK();
-    } else if (p->pull != nullptr) {
+    } else if (p->pull != nullptr || p->pull_arith != nullptr) {
         GL_HIP(hipMemsetAsync(p->d_mode, 0, sizeof(uint32_t), s));   // gl_spmspv_last_direction: scatter
     }
 
@@ -425,7 +439,17 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
         default: rc = gl::launch_scatter<GL_OP_ADDMIN>(a, grid, s); break;
     }
     if (rc != GL_OK) return rc;
-    if (may_pull) {
+    if (may_pull && op == GL_OP_MULADD) {
+        // row-wise (+,x): frontier -> dense x -> SpMV on the attached general / pattern plan into the accumulator
+        // (zero = 0, no mask: the compaction applies the mask); its kernels return at once on a scatter run
+        GL_HIP(hipMemsetAsync(p->d_xdense, 0, (size_t)p->num_cols * sizeof(float), s));
+        uint32_t bgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 8u);
+        gl::spmspv_frontier_dense_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(d_vector, p->num_cols, p->d_xdense, p->d_mode);
+        GL_LAUNCH_CHECK();
+        rc = gl::spmv_run_general(p->pull_arith, p->d_xdense, nullptr, p->d_acc - p->row_begin, GL_OP_MULADD, 0.0f, GL_NOMASK,
+                                  p->d_mode);
+        if (rc != GL_OK) return rc;
+    } else if (may_pull) {
         // row-wise: frontier -> bit vector -> boolean SpMV into the (all-zero) accumulator; both kernels return
         // at once when the run is a scatter run
         uint32_t *bits = gl::bool_plan_xbits(p->pull);
@@ -456,15 +480,23 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
 int gl_spmspv_plan_attach_pull(gl_spmspv_plan p, gl_spmv_plan pull) {
     GL_ARG(p != nullptr);
     if (pull == nullptr) {
-        p->pull = nullptr;
+        p->pull = p->pull_arith = nullptr;
         return GL_OK;
     }
-    if (!pull->boolean)
-        return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_attach_pull: the SpMV plan must hold the GL_PLAN_BOOLEAN layout");
     if (pull->num_rows != p->num_rows || pull->num_cols != p->num_cols || pull->row_begin != p->row_begin ||
         pull->row_end != p->row_end)
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_attach_pull: the two plans hold different matrices or row shards");
-    p->pull = pull;
+    if (pull->boolean) {
+        p->pull = pull;
+        return GL_OK;
+    }
+    if (pull->flags & GL_PLAN_NO_MULADD)
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_attach_pull: a plan created with GL_PLAN_NO_MULADD cannot serve (+,x)");
+    if (!p->d_xdense) {
+        GL_HIP(hipMalloc((void **)&p->d_xdense, (size_t)std::max<uint32_t>(p->num_cols, 1u) * sizeof(float)));
+        p->device_bytes += (size_t)p->num_cols * sizeof(float);
+    }
+    p->pull_arith = pull;
     return GL_OK;
 }
 
@@ -481,7 +513,7 @@ int gl_spmspv_last_direction(gl_spmspv_plan p, int *row_wise) {
     hipStream_t s = gl::ctx().stream;
     GL_HIP(hipMemcpyAsync(&m, p->d_mode, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GL_HIP(hipStreamSynchronize(s));
-    *row_wise = (p->pull != nullptr && m != 0u) ? 1 : 0;
+    *row_wise = ((p->pull != nullptr || p->pull_arith != nullptr) && m != 0u) ? 1 : 0;
     return GL_OK;
 }
 

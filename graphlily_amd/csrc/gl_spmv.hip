@@ -57,6 +57,7 @@ struct SpmvArgs {
     const float *z;           // pattern plans: colval (x) x, written by spmv_prescale_kernel
     const float *diag;        // pattern plans with diagonal exceptions: A[r][r] per local row, folded in by the epilogue
     const uint32_t *diag_has; // bit per local row: the row has a diagonal entry that differs from its column's value
+    const uint32_t *run_flag;    // non-null: the launch is a no-op unless run_flag[0] != 0 (gl_spmspv_run's direction switch)
     unsigned long long *clocks;  // debugging (GRAPHLILY_SPMV_CLOCKS): wall_clock64 at the start and end of every unit
     float *partials;          // [segment][row - row_begin] per-unit tiles of split blocks (combined by spmv_combine_kernel)
     uint32_t prow;            // rows per segment plane
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
     T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);   // nhot is a multiple of 64
 
+    if (a.run_flag && *a.run_flag == 0u) return;
     const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
     const uint32_t g0 = d.x, ncold = d.y, row0 = d.z;
     const uint32_t nrows = d.w & 0xffffu;
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_wide_kernel(SpmvArgs a) {
     float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
     T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);
 
+    if (a.run_flag && *a.run_flag == 0u) return;
     const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
     const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
     const uint32_t nhub = dh.y, nhotg = dh.z;
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_pat_kernel(SpmvArgs a) {
     float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
     T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);
 
+    if (a.run_flag && *a.run_flag == 0u) return;
     const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
     const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
     const uint32_t nhub = dh.y, nhotg = dh.z;
@@ -376,6 +380,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_pat4_kernel(SpmvArgs a) {
     float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
     T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);
 
+    if (a.run_flag && *a.run_flag == 0u) return;
     const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
     const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
     const uint32_t nhub = dh.y, nhotg = dh.z;
@@ -476,7 +481,9 @@ template <int OP, int MASK>
 __global__ __launch_bounds__(256) void spmv_combine_kernel(const uint4 *__restrict__ blocks, const float *__restrict__ partials,
                                                            uint32_t prow, uint32_t row_begin, const float *__restrict__ mask,
                                                            float *__restrict__ y, float zero, const float *__restrict__ x,
-                                                           const float *__restrict__ diag, const uint32_t *__restrict__ diag_has) {
+                                                           const float *__restrict__ diag, const uint32_t *__restrict__ diag_has,
+                                                           const uint32_t *__restrict__ run_flag) {
+    if (run_flag && *run_flag == 0u) return;
     const uint4 b = blocks[blockIdx.y];   // {first row, #rows, #segments, -}
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < b.y; i += gridDim.x * 256u) {
         const uint32_t row = b.x + i;
@@ -633,7 +640,7 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     if (p->segments > 1) {
         const dim3 grid(std::max<unsigned>(1u, std::min<unsigned>(cdiv(p->max_plain_rows, 256), 64u)), p->nblocks);
         spmv_combine_kernel<OP, MASK><<<grid, 256, 0, s>>>(p->d_blocks, p->d_partials, rows, p->row_begin, a.mask, a.y, a.zero, a.x,
-                                                             a.diag, a.diag_has);
+                                                             a.diag, a.diag_has, a.run_flag);
         GL_LAUNCH_CHECK();
     }
     return GL_OK;
@@ -1280,6 +1287,16 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
                                  "holds the sparsity pattern only; semiring op %d needs a plan without it", op);
         return gl::bool_plan_run(p, d_x, nullptr, d_mask, d_y, zero, mask_type, gl::ctx().stream);
     }
+    return gl::spmv_run_general(p, d_x, d_mask, d_y, op, zero, mask_type, nullptr);
+}
+
+}  // extern "C"
+
+namespace gl {
+// the general / pattern layouts; run_flag as in SpmvArgs
+int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
+                     const uint32_t *run_flag) {
+    if (p->boolean) return set_error(GL_ERR_UNSUPPORTED, "spmv_run_general: boolean layout");
     if ((p->flags & (GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD)) && op == GL_OP_MULADD && p->nhot &&
         (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(double) > gl::kLdsBudget)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_NO_MULADD "
@@ -1295,6 +1312,7 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     a.mask = d_mask;
     a.y = d_y;
     a.zero = zero;
+    a.run_flag = run_flag;
     a.clocks = nullptr;
     static const char *clocks_path = getenv("GRAPHLILY_SPMV_CLOCKS");
     unsigned long long *d_clocks = nullptr;
@@ -1335,4 +1353,4 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     return rc;
 }
 
-}  // extern "C"
+}  // namespace gl

@@ -121,6 +121,8 @@ int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_o
 int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s);
 uint32_t *bool_plan_xbits(gl_spmv_plan p);
 size_t bool_plan_xbits_bytes(gl_spmv_plan p);
+int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
+                     const uint32_t *run_flag);
 // gl_spmv.hip: y initialisation for plans whose units fold into y
 int spmv_init_rows(int op, int mask_type, uint32_t r0, uint32_t r1, const float *mask, float *y, float zero, hipStream_t s);
 }  // namespace gl

@@ -285,10 +285,31 @@ class SpMSpVModule(BaseModule):
         if self.plan_ is None:
             return
         plan = getattr(spmv_module, "plan_", None) if spmv_module is not None else None
-        if plan is not None and plan.info()["layout"] == "boolean":
+        self.plan_.attach_pull(None)
+        if plan is None:
+            return
+        # boolean layout -> serves (||,&&); general / pattern layout (not GL_PLAN_NO_MULADD) -> serves (+,x)
+        if plan.info()["layout"] == "boolean" or not (plan.flags & capi.GL_PLAN_NO_MULADD):
             self.plan_.attach_pull(plan)
-        else:
-            self.plan_.attach_pull(None)
+
+    def enable_own_pull(self):
+        """Extension for stand-alone use (no SpMVModule around, e.g. the bench_spmspv sweep): build a row-wise plan of
+        this module's own matrix for its current semiring and attach it.  Costs a second formatted copy of the matrix."""
+        from . import io as _io
+        c = self.csc_matrix_
+        # the CSC arrays of A are the CSR arrays of A^T; transposing that once more gives A by rows
+        at = _io.CSRMatrix(c.num_cols, c.num_rows, c.adj_data, c.adj_indices, c.adj_indptr)
+        a = _io.csr2csc(at)
+        csr = _io.CSRMatrix(c.num_rows, c.num_cols, a.adj_data, a.adj_indices, a.adj_indptr)
+        own = SpMVModule(num_hbm_channels, 0, 0)
+        own.set_semiring(self.semiring_)
+        own.set_mask_type(kNoMask)
+        if self.row_end_ is not None:
+            own.set_row_shard(self.row_begin_, self.row_end_)
+        own.load_and_format_matrix(csr, True)
+        own.send_matrix_host_to_device()
+        self.own_pull_ = own
+        self.attach_pull(own)
 
     def send_vector_host_to_device(self, vector):
         """The vector may be shorter than num_cols + 1; the device copy is always that long

@@ -189,11 +189,14 @@ int gl_spmspv_plan_info(gl_spmspv_plan plan, uint64_t *nnz, uint64_t *device_byt
 int gl_spmspv_run(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask,
                   gl_idx_val *d_result, int op, float zero, int mask_type);
 
-/* Extension: direction switch inside the operator.  `pull` is a GL_PLAN_BOOLEAN SpMV plan over the same
- * matrix and row shard (BFS holds both, app/bfs.h:83-99).  A (||,&&) run with zero == 0 whose frontier columns
- * hold more than 1/32 of the matrix's non-zeros is then computed row-wise (frontier -> bit vector -> boolean
- * SpMV into the dense accumulator) instead of being scattered; the decision is taken on the device, results
- * are identical.  The SpMV plan is not owned and must outlive the attachment; NULL detaches. */
+/* Extension: direction switch inside the operator.  `pull` is an SpMV plan over the same matrix and row shard
+ * (BFS holds both, app/bfs.h:83-99).  A run with zero == 0 whose frontier columns hold more than 1/32 of the
+ * matrix's non-zeros is then computed row-wise into the dense accumulator instead of being scattered: a
+ * GL_PLAN_BOOLEAN plan serves (||,&&) (frontier -> bit vector -> boolean SpMV; results identical), a general /
+ * pattern plan serves (+,x) (frontier -> dense vector -> SpMV; same values up to float accumulation order --
+ * the scatter adds float atomics in arrival order, the SpMV sums in f64).  One of each kind may be attached;
+ * the decision is taken on the device.  The SpMV plans are not owned and must outlive the attachment; NULL
+ * detaches both. */
 int gl_spmspv_plan_attach_pull(gl_spmspv_plan plan, gl_spmv_plan pull);
 /* Optional: an upper bound on the number of entries of the NEXT run's input vector (the drivers know it from
  * the previous iteration's gl_sparse_nnz).  Frontiers too small to reach the threshold whatever their columns

@@ -203,3 +203,38 @@ def test_direction_switch_inside_the_operator(gpu, shape, monkeypatch):
                 assert np.all(np.diff(res["index"][1:nnz + 1].astype(np.int64)) > 0)
                 ref = O.spmspv(to_oracle(csc), v, 1, 0.0, mask, MASKS[mk])
                 assert_parity(got, ref, 1, "direction %s %s run %d" % (expect, mk, rep))
+
+
+def test_arithmetic_direction_switch(gpu):
+    """(+,x) with a general / pattern SpMV plan of the same matrix attached: heavy frontiers are applied row-wise
+    (frontier -> dense x -> SpMV into the accumulator), light ones scattered; both match the oracle within the
+    float tolerance, for every mask, on a weighted (general layout) and a constant (pattern layout) matrix."""
+    csr0 = named_matrix("rmat_sym_50K")
+    rng = np.random.default_rng(8)
+    for layout in ("general", "pattern"):
+        csr = csr0.copy()
+        csr.adj_data = (rng.random(csr.nnz, dtype=np.float32) + np.float32(0.25)) if layout == "general" else np.full(csr.nnz, np.float32(0.125), np.float32)
+        csc = io.csr2csc(csr)
+        mask = rand01(csc.num_rows, 6)
+        for density, expect in ((0.0005, "scatter"), (0.25, "row-wise")):
+            idx = np.flatnonzero(rng.random(csc.num_cols) < density).astype(np.uint32)
+            vals = (rng.integers(1, 9, size=idx.size) / np.float32(8)).astype(np.float32)
+            v = M.make_sparse_vec(idx, vals)
+            for mk in MASKS:
+                mod = M.SpMSpVModule(0)
+                mod.set_semiring(M.ArithmeticSemiring)
+                mod.set_mask_type(MASKS[mk])
+                mod.set_up_runtime()
+                mod.load_and_format_matrix(csc)
+                mod.send_matrix_host_to_device()
+                mod.enable_own_pull()
+                assert mod.own_pull_.plan_.info()["layout"] == layout
+                mod.send_mask_host_to_device(mask)
+                mod.send_vector_host_to_device(v)
+                for rep in range(2):
+                    mod.run()
+                    assert mod.plan_.last_direction() == expect
+                    res = mod.send_results_device_to_host()
+                    got = M.convert_sparse_vec_to_dense_vec(res, csc.num_rows, 0.0)
+                    ref = O.spmspv(to_oracle(csc), v, 0, 0.0, mask, MASKS[mk])
+                    assert_parity(got, ref, 0, "arith direction %s %s %s run %d" % (layout, expect, mk, rep))
