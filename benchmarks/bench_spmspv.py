@@ -85,6 +85,7 @@ def main():
                 active = int(coldeg[idx].sum())
                 rec = {"graph": name, "semiring": sname, "vector_sparsity": sparsity, "vector_nnz": cnt,
                        "active_nnz": active, "result_nnz": int(res["index"][0]), "ms": round(ms, 4),
+                       "ms_median": round(float(np.median(ts)) * 1e3, 4), "ms_max": round(float(np.max(ts)) * 1e3, 4),
                        "gbps": round(8 * active / ms / 1e6, 2), "gteps": round(active / ms / 1e6, 3), "verified": ok,
                        "direction": mod.plan_.last_direction()}
                 print(json.dumps(rec), flush=True)

@@ -249,7 +249,13 @@ __global__ __launch_bounds__(256) void spmspv_frontier_bits_kernel(const gl_idx_
     }
 }
 
-// row-wise (+,x) path: the frontier scattered into a zeroed dense vector
+// row-wise (+,x) path: zero the dense vector (only when the run goes row-wise) ...
+__global__ __launch_bounds__(256) void spmspv_clear_dense_kernel(float4 *__restrict__ dense4, uint32_t n4, const uint32_t *__restrict__ mode) {
+    if (!mode[0]) return;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) dense4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ... and scatter the frontier into it
 __global__ __launch_bounds__(256) void spmspv_frontier_dense_kernel(const gl_idx_val *__restrict__ vec, uint32_t num_cols,
                                                                     float *__restrict__ dense, const uint32_t *__restrict__ mode) {
     if (!mode[0]) return;
@@ -442,8 +448,10 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
     if (may_pull && op == GL_OP_MULADD) {
         // row-wise (+,x): frontier -> dense x -> SpMV on the attached general / pattern plan into the accumulator
         // (zero = 0, no mask: the compaction applies the mask); its kernels return at once on a scatter run
-        GL_HIP(hipMemsetAsync(p->d_xdense, 0, (size_t)p->num_cols * sizeof(float), s));
         uint32_t bgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 8u);
+        gl::spmspv_clear_dense_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(reinterpret_cast<float4 *>(p->d_xdense), gl::cdiv(p->num_cols, 4),
+                                                                        p->d_mode);
+        GL_LAUNCH_CHECK();
         gl::spmspv_frontier_dense_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(d_vector, p->num_cols, p->d_xdense, p->d_mode);
         GL_LAUNCH_CHECK();
         rc = gl::spmv_run_general(p->pull_arith, p->d_xdense, nullptr, p->d_acc - p->row_begin, GL_OP_MULADD, 0.0f, GL_NOMASK,
@@ -493,7 +501,7 @@ int gl_spmspv_plan_attach_pull(gl_spmspv_plan p, gl_spmv_plan pull) {
     if (pull->flags & GL_PLAN_NO_MULADD)
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_attach_pull: a plan created with GL_PLAN_NO_MULADD cannot serve (+,x)");
     if (!p->d_xdense) {
-        GL_HIP(hipMalloc((void **)&p->d_xdense, (size_t)std::max<uint32_t>(p->num_cols, 1u) * sizeof(float)));
+        GL_HIP(hipMalloc((void **)&p->d_xdense, ((size_t)p->num_cols + 4u) * sizeof(float)));   // whole float4s
         p->device_bytes += (size_t)p->num_cols * sizeof(float);
     }
     p->pull_arith = pull;

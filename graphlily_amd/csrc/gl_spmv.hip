@@ -446,7 +446,8 @@ template <int OP>
 __global__ __launch_bounds__(256) void spmv_prescale_kernel(const float *__restrict__ x, const float *__restrict__ colval,
                                                             float *__restrict__ z, uint32_t num_cols,
                                                             const uint32_t *__restrict__ hot_cols, float *__restrict__ hot_x,
-                                                            uint32_t nhot) {
+                                                            uint32_t nhot, const uint32_t *__restrict__ run_flag) {
+    if (run_flag && *run_flag == 0u) return;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < num_cols) z[i] = Semiring<OP>::mul(colval[i], x[i]);
     if (i < nhot) {
@@ -457,7 +458,8 @@ __global__ __launch_bounds__(256) void spmv_prescale_kernel(const float *__restr
 
 // the one scattered read of the hot columns per run; the workgroups then copy the compact table
 __global__ __launch_bounds__(256) void spmv_hot_gather_kernel(const float *__restrict__ x, const uint32_t *__restrict__ hot_cols,
-                                                              float *__restrict__ hot_x, uint32_t nhot) {
+                                                              float *__restrict__ hot_x, uint32_t nhot, const uint32_t *__restrict__ run_flag) {
+    if (run_flag && *run_flag == 0u) return;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < nhot) hot_x[i] = x[hot_cols[i]];
 }
@@ -574,10 +576,10 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     }
     if (p->pattern) {
         spmv_prescale_kernel<OP><<<cdiv(std::max(p->num_cols, p->nhot), 256), 256, 0, s>>>(a.x, p->d_colval, p->d_z, p->num_cols,
-                                                                                            p->d_hot_cols, p->d_hot_x, p->nhot);
+                                                                                            p->d_hot_cols, p->d_hot_x, p->nhot, a.run_flag);
         GL_LAUNCH_CHECK();
     } else if (p->nhot) {
-        spmv_hot_gather_kernel<<<cdiv(p->nhot, 256), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot);
+        spmv_hot_gather_kernel<<<cdiv(p->nhot, 256), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot, a.run_flag);
         GL_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(typename Tile<OP>::T);
