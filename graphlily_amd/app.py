@@ -513,6 +513,8 @@ class SSSP(_GraphApp):
     def send_matrix_host_to_device(self):
         self.SpMV_.send_matrix_host_to_device()
         self.SpMSpV_.send_matrix_host_to_device()
+        if hasattr(self.SpMSpV_, "attach_pull"):
+            self.SpMSpV_.attach_pull(self.SpMV_)     # heavy frontiers of a push iteration go row-wise
 
     def _initial_distance(self, source):
         return self._new_dense(self.n_, self.semiring_.zero, source, 0.0)

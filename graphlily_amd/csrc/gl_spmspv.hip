@@ -250,9 +250,10 @@ __global__ __launch_bounds__(256) void spmspv_frontier_bits_kernel(const gl_idx_
 }
 
 // row-wise (+,x) path: zero the dense vector (only when the run goes row-wise) ...
-__global__ __launch_bounds__(256) void spmspv_clear_dense_kernel(float4 *__restrict__ dense4, uint32_t n4, const uint32_t *__restrict__ mode) {
+__global__ __launch_bounds__(256) void spmspv_clear_dense_kernel(float4 *__restrict__ dense4, uint32_t n4, float fill,
+                                                                 const uint32_t *__restrict__ mode) {
     if (!mode[0]) return;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) dense4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) dense4[i] = make_float4(fill, fill, fill, fill);
 }
 
 // ... and scatter the frontier into it
@@ -408,8 +409,14 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
     // (||,&&) with an attached boolean SpMV plan: decide on the device which way this run goes
     const long div = gl::env_long("GRAPHLILY_SPMSPV_PULL_DIV", 32);
     const uint64_t threshold = div > 0 ? p->nnz / (uint64_t)div : 0ull;
-    gl_spmv_plan pull_plan = op == GL_OP_ANDOR ? p->pull : (op == GL_OP_MULADD ? p->pull_arith : nullptr);
-    bool may_pull = pull_plan != nullptr && zero == 0.0f && nrows > 0 && gl::env_long("GRAPHLILY_SPMSPV_PULL", 1) != 0;
+    // which attached plan can stand in for the scatter: (||,&&) and (+,x) need zero == 0 (the accumulator starts
+    // at it); (min,+) needs zero <= FLOAT_INF -- the scatter's products saturate there, the SpMV's do not, and the
+    // final min with zero hides the difference -- and a plan that was not restricted to other semirings
+    gl_spmv_plan pull_plan = nullptr;
+    if (op == GL_OP_ANDOR && zero == 0.0f) pull_plan = p->pull;
+    else if (op == GL_OP_MULADD && zero == 0.0f && p->pull_arith && !(p->pull_arith->flags & GL_PLAN_NO_MULADD)) pull_plan = p->pull_arith;
+    else if (op == GL_OP_ADDMIN && zero <= gl::kFloatInf) pull_plan = p->pull_arith;
+    bool may_pull = pull_plan != nullptr && nrows > 0 && gl::env_long("GRAPHLILY_SPMSPV_PULL", 1) != 0;
     // a caller that knows how many entries the vector holds (gl_spmspv_plan_hint) spares tiny frontiers the
     // decision kernels: they cannot reach the threshold whatever their columns are
     if (may_pull && p->frontier_hint != ~0ull && p->frontier_hint * (uint64_t)p->max_col_len <= threshold) may_pull = false;
@@ -445,17 +452,17 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
         default: rc = gl::launch_scatter<GL_OP_ADDMIN>(a, grid, s); break;
     }
     if (rc != GL_OK) return rc;
-    if (may_pull && op == GL_OP_MULADD) {
-        // row-wise (+,x): frontier -> dense x -> SpMV on the attached general / pattern plan into the accumulator
-        // (zero = 0, no mask: the compaction applies the mask); its kernels return at once on a scatter run
+    if (may_pull && op != GL_OP_ANDOR) {
+        // row-wise (+,x) / (min,+): frontier -> dense x (0 / +inf elsewhere) -> SpMV on the attached general /
+        // pattern plan into the accumulator (same zero, no mask: the compaction applies the mask); its kernels
+        // return at once on a scatter run
         uint32_t bgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 8u);
         gl::spmspv_clear_dense_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(reinterpret_cast<float4 *>(p->d_xdense), gl::cdiv(p->num_cols, 4),
-                                                                        p->d_mode);
+                                                                        op == GL_OP_MULADD ? 0.0f : __builtin_inff(), p->d_mode);
         GL_LAUNCH_CHECK();
         gl::spmspv_frontier_dense_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(d_vector, p->num_cols, p->d_xdense, p->d_mode);
         GL_LAUNCH_CHECK();
-        rc = gl::spmv_run_general(p->pull_arith, p->d_xdense, nullptr, p->d_acc - p->row_begin, GL_OP_MULADD, 0.0f, GL_NOMASK,
-                                  p->d_mode);
+        rc = gl::spmv_run_general(p->pull_arith, p->d_xdense, nullptr, p->d_acc - p->row_begin, op, zero, GL_NOMASK, p->d_mode);
         if (rc != GL_OK) return rc;
     } else if (may_pull) {
         // row-wise: frontier -> bit vector -> boolean SpMV into the (all-zero) accumulator; both kernels return
@@ -498,8 +505,6 @@ int gl_spmspv_plan_attach_pull(gl_spmspv_plan p, gl_spmv_plan pull) {
         p->pull = pull;
         return GL_OK;
     }
-    if (pull->flags & GL_PLAN_NO_MULADD)
-        return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_attach_pull: a plan created with GL_PLAN_NO_MULADD cannot serve (+,x)");
     if (!p->d_xdense) {
         GL_HIP(hipMalloc((void **)&p->d_xdense, ((size_t)p->num_cols + 4u) * sizeof(float)));   // whole float4s
         p->device_bytes += (size_t)p->num_cols * sizeof(float);

@@ -288,9 +288,8 @@ class SpMSpVModule(BaseModule):
         self.plan_.attach_pull(None)
         if plan is None:
             return
-        # boolean layout -> serves (||,&&); general / pattern layout (not GL_PLAN_NO_MULADD) -> serves (+,x)
-        if plan.info()["layout"] == "boolean" or not (plan.flags & capi.GL_PLAN_NO_MULADD):
-            self.plan_.attach_pull(plan)
+        # boolean layout -> serves (||,&&); general / pattern layout -> (min,+) and, unless GL_PLAN_NO_MULADD, (+,x)
+        self.plan_.attach_pull(plan)
 
     def enable_own_pull(self):
         """Extension for stand-alone use (no SpMVModule around, e.g. the bench_spmspv sweep): build a row-wise plan of

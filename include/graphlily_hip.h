@@ -194,7 +194,9 @@ int gl_spmspv_run(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *
  * matrix's non-zeros is then computed row-wise into the dense accumulator instead of being scattered: a
  * GL_PLAN_BOOLEAN plan serves (||,&&) (frontier -> bit vector -> boolean SpMV; results identical), a general /
  * pattern plan serves (+,x) (frontier -> dense vector -> SpMV; same values up to float accumulation order --
- * the scatter adds float atomics in arrival order, the SpMV sums in f64).  One of each kind may be attached;
+ * the scatter adds float atomics in arrival order, the SpMV sums in f64; not a GL_PLAN_NO_MULADD plan) and
+ * (min,+) with zero <= FLOAT_INF (results identical: the scatter's saturation at FLOAT_INF is hidden by the
+ * final min with zero).  One of each kind may be attached;
  * the decision is taken on the device.  The SpMV plans are not owned and must outlive the attachment; NULL
  * detaches both. */
 int gl_spmspv_plan_attach_pull(gl_spmspv_plan plan, gl_spmv_plan pull);

@@ -238,3 +238,44 @@ def test_arithmetic_direction_switch(gpu):
                     got = M.convert_sparse_vec_to_dense_vec(res, csc.num_rows, 0.0)
                     ref = O.spmspv(to_oracle(csc), v, 0, 0.0, mask, MASKS[mk])
                     assert_parity(got, ref, 0, "arith direction %s %s %s run %d" % (layout, expect, mk, rep))
+
+
+@pytest.mark.parametrize("sem", ["Tropical", "TropicalFloatInf"])
+def test_tropical_direction_switch(gpu, sem):
+    """(min,+) goes row-wise on heavy frontiers too (x = +inf off the frontier); bit-equal to the oracle, with
+    negative weights, a diagonal that differs from its columns (pattern layout with exceptions) and every mask."""
+    op, zero = SEMIRINGS[sem]
+    csr = named_matrix("rmat_sym_50K")
+    rng = np.random.default_rng(12)
+    for layout in ("general", "pattern"):
+        m = csr.copy()
+        if layout == "general":
+            m.adj_data = rng.integers(-2, 9, size=m.nnz).astype(np.float32)
+        else:
+            io.sssp_add_self_edges(m)
+        csc = io.csr2csc(m)
+        spmv = M.SpMVModule(16, 0, 0)
+        spmv.set_semiring(M.SemiringType(op, 0.0, zero))
+        spmv.set_up_runtime()
+        spmv.load_and_format_matrix(m, True)
+        spmv.send_matrix_host_to_device()
+        assert spmv.plan_.info()["layout"] == layout
+        mask = np.where(rand01(csc.num_rows, 3) > 0, np.float32(zero), np.float32(4.0)).astype(np.float32)
+        for density, expect in ((0.0005, "scatter"), (0.3, "row-wise")):
+            idx = np.flatnonzero(rng.random(csc.num_cols) < density).astype(np.uint32)
+            v = M.make_sparse_vec(idx, rng.integers(0, 6, size=idx.size).astype(np.float32))
+            for mk in MASKS:
+                mod = M.SpMSpVModule(0)
+                mod.set_semiring(M.SemiringType(op, 0.0, zero))
+                mod.set_mask_type(MASKS[mk])
+                mod.set_up_runtime()
+                mod.load_and_format_matrix(csc)
+                mod.send_matrix_host_to_device()
+                mod.attach_pull(spmv)
+                mod.send_mask_host_to_device(mask)
+                mod.send_vector_host_to_device(v)
+                mod.run()
+                assert mod.plan_.last_direction() == expect
+                got = M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), csc.num_rows, zero)
+                ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS[mk])
+                assert_parity(got, ref, op, "tropical direction %s %s %s %s" % (sem, layout, expect, mk))
