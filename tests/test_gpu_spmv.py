@@ -327,6 +327,23 @@ def test_pattern_plan_matches_general_layout(gpu, kind, monkeypatch):
     assert capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data).info()["layout"] == "general"
 
 
+def test_boolean_flag_on_a_very_wide_matrix_uses_the_general_layout(gpu):
+    """More than 8 x 1 179 648 columns: the bit layout would copy too many x phases per workgroup, so a
+    GL_PLAN_BOOLEAN request is served by the general layout (4-byte tiles); results unchanged, no bit vector."""
+    from graphlily_amd import capi
+    rng = np.random.default_rng(4)
+    n_rows, n_cols, per_row = 3000, 10_000_000, 12
+    cols = np.sort(rng.integers(0, n_cols, size=(n_rows, per_row)), axis=1).astype(np.uint32)
+    m = io.CSRMatrix(n_rows, n_cols, np.ones(n_rows * per_row, np.float32), cols.reshape(-1),
+                     np.arange(0, n_rows * per_row + 1, per_row, dtype=np.uint32))
+    x = (rng.random(n_cols) < 0.2).astype(np.float32)
+    mask = rand01(n_rows, 2)
+    plan = capi.SpMVPlan(n_rows, n_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=capi.GL_PLAN_BOOLEAN)
+    assert plan.info()["layout"] != "boolean" and plan.bits_words() == 0
+    got = _run_spmv(gpu, m, "Logical", "WriteToOne", x, mask)
+    assert_parity(got, _ref_spmv(m, "Logical", "WriteToOne", x, mask), 1, "very wide boolean request")
+
+
 def test_row_shards_compose(gpu):
     """Two row shards write disjoint slices of one y: the multi-GPU decomposition on one device."""
     m = spmv_prepare("rmat_20K")
