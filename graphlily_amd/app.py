@@ -301,22 +301,27 @@ class BFS(_GraphApp):
             self.SpMSpV_.hint_vector_nnz(nnz)
 
     def _push_iteration(self, frontier, local, it):
-        """SpMSpV on the shard, mark the newly reached vertices, publish the next frontier."""
+        """SpMSpV on the shard, mark the newly reached vertices, publish the next frontier.  Returns
+        (frontier size, frontier buffer, result buffer) for the next iteration."""
         self.SpMSpV_.run()
         self.SparseAssign_.run(float(it + 1))
         if self.comm.distributed:
             total = self._gather_sparse(local, frontier, self.n_, self.semiring_.zero)
             self._hint_frontier(total)
-            return total
+            return total, frontier, local
         nnz = self.SpMSpV_.get_results_nnz()
-        self.backend.copy(frontier, local, 8 * (1 + nnz))   # app/bfs.h:149-152
+        # the reference copies results -> vector here (app/bfs.h:149-152); the two buffers swap roles instead
+        frontier, local = local, frontier
+        self.SpMSpV_.bind_vector_buf(frontier)
+        self.SpMSpV_.results_buf = local
+        self.SparseAssign_.bind_mask_buf(local)
         self._hint_frontier(nnz)
-        return nnz
+        return nnz, frontier, local
 
     def push(self, source, num_iterations):
         frontier, distance, local = self._start_push(source)
         for it in range(1, num_iterations + 1):
-            self._push_iteration(frontier, local, it)
+            _, frontier, local = self._push_iteration(frontier, local, it)
         return self._finish_distance(distance)
 
     def pull_push(self, source, num_iterations, threshold=0.05):
@@ -324,7 +329,7 @@ class BFS(_GraphApp):
         frontier, distance, local = self._start_push(source)
         it = 1
         while True:
-            nnz = self._push_iteration(frontier, local, it)
+            nnz, frontier, local = self._push_iteration(frontier, local, it)
             it += 1
             if not (it < num_iterations and float(nnz) / n < threshold):
                 break

@@ -25,6 +25,7 @@ struct Context {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // current stream (own or adopted)
     int num_cus = 256;
+    uint32_t *pinned_word = nullptr;   // page-locked staging word for small device->host control reads
 };
 
 Context &ctx();

@@ -534,10 +534,12 @@ int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz) {
     GL_REQUIRE_INIT();
     GL_ARG(d_sparse != nullptr && nnz != nullptr);
     hipStream_t s = gl::ctx().stream;
-    uint32_t v = 0;
-    GL_HIP(hipMemcpyAsync(&v, &d_sparse->index, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // a page-locked destination makes this one DMA + one wait (a pageable one goes through a staging copy)
+    uint32_t *&w = gl::ctx().pinned_word;
+    if (!w) GL_HIP(hipHostMalloc((void **)&w, 64, hipHostMallocDefault));
+    GL_HIP(hipMemcpyAsync(w, &d_sparse->index, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     GL_HIP(hipStreamSynchronize(s));
-    *nnz = v;
+    *nnz = *w;
     return GL_OK;
 }
 
