@@ -174,7 +174,7 @@ def main():
         "selfcheck_ok": ok,
         "setup_s": {"graph": round(t_gen, 2), "plan": round(t_plan, 2)},
         "roofline": {
-            "bound": "hbm", "kernel": "spmv_rbcs_wide_kernel<MULADD,NOMASK>",
+            "bound": "hbm", "kernel": "spmv_rbcs_kernel<MULADD,NOMASK,WIDE>",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": _pmc_traffic(args.graph, world, args.scale),

@@ -11,9 +11,9 @@
 //     stream's: only fewer bytes per entry or fewer gather instructions (x values served from LDS) make
 //     the loop faster; unrolling, software pipelining and LDS window staging were measured and do not;
 //   * LDS atomics on 4/8-byte integers and on f64 run at full rate, ds_add_f32 at a third of it.
-// This file holds the GENERAL layout (8-byte entries; spmv_rbcs_wide_kernel, spmv_rbcs_kernel as the
-// GRAPHLILY_SPMV_WIDE=0 fallback) and the PATTERN layout (4-byte entries for column-constant matrices,
-// spmv_rbcs_pat_kernel); the (||,&&)-only bit layout lives in gl_spmv_bool.hip.
+// This file holds the GENERAL layout (8-byte entries) and the PATTERN layout (4-byte entries for
+// column-constant matrices), both served by spmv_rbcs_kernel<OP, MASK, stream layout, UC, UH>; the
+// (||,&&)-only bit layout lives in gl_spmv_bool.hip.
 // Hence the layout -- the CDNA4 counterpart of the FPGA's "dense-vector tile in URAM + output buffer
 // in URAM" partitioning (kernel_spmv_impl.h:470-495), with the roles swapped:
 //   row block   <= 15359 consecutive rows whose accumulators live in LDS for the whole sweep
@@ -167,20 +167,83 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
 }
 
 
-template <int OP, int MASK, int UC, int UH>
+// ---------------------------------------------------------------- stream layouts
+// One kernel body serves the four stream layouts; a layout says what one lane reads per load instruction
+// (8 or 16 bytes), how many consecutive 64-entry groups that read covers (stored lane-interleaved: lane L's
+// element holds entry L of each of the G groups) and whether values travel with the indices.
+//   NARROW  8 B: { index, value }                        1 group   (GRAPHLILY_SPMV_WIDE=0)
+//   WIDE   16 B: { A.index, A.value, B.index, B.value }  2 groups  (default general layout; scripts/ubench_mix:
+//                                                        half as many stream instructions per byte, -5 %)
+//   PAIR    8 B: { A.index, B.index }                    2 groups  (pattern plans, GRAPHLILY_SPMV_PAT4=0)
+//   QUAD   16 B: { A.index .. D.index }                  4 groups  (default pattern layout)
+// index = (col - group_base) << 14 | slot.  Pattern plans (every column's stored values are equal) fold the
+// value into z[c] = colval[c] (x) x[c] once per run (spmv_prescale_kernel) and gather z instead of x.
+enum { kLayNarrow = 0, kLayWide = 1, kLayPair = 2, kLayQuad = 3 };
+
+template <int L>
+struct Lay;
+
+template <>
+struct Lay<kLayNarrow> {
+    using E = uint2;
+    static constexpr int G = 1;
+    static constexpr bool kValues = true;
+    __device__ static E load(const void *s, size_t i) { return load_stream_nt(static_cast<const uint2 *>(s) + i); }
+    __device__ static E pad() { return make_uint2(kRowPad, 0u); }
+    __device__ static uint32_t key(const E &e, int) { return e.x; }
+    __device__ static float val(const E &e, int) { return __uint_as_float(e.y); }
+};
+
+template <>
+struct Lay<kLayWide> {
+    using E = uint4;
+    static constexpr int G = 2;
+    static constexpr bool kValues = true;
+    __device__ static E load(const void *s, size_t i) { return load_stream_nt16(static_cast<const uint4 *>(s) + i); }
+    __device__ static E pad() { return make_uint4(kRowPad, 0u, kRowPad, 0u); }
+    __device__ static uint32_t key(const E &e, int k) { return k ? e.z : e.x; }
+    __device__ static float val(const E &e, int k) { return __uint_as_float(k ? e.w : e.y); }
+};
+
+template <>
+struct Lay<kLayPair> {
+    using E = uint2;
+    static constexpr int G = 2;
+    static constexpr bool kValues = false;
+    __device__ static E load(const void *s, size_t i) { return load_stream_nt(static_cast<const uint2 *>(s) + i); }
+    __device__ static E pad() { return make_uint2(kRowPad, kRowPad); }
+    __device__ static uint32_t key(const E &e, int k) { return k ? e.y : e.x; }
+    __device__ static float val(const E &, int) { return 0.0f; }
+};
+
+template <>
+struct Lay<kLayQuad> {
+    using E = uint4;
+    static constexpr int G = 4;
+    static constexpr bool kValues = false;
+    __device__ static E load(const void *s, size_t i) { return load_stream_nt16(static_cast<const uint4 *>(s) + i); }
+    __device__ static E pad() { return make_uint4(kRowPad, kRowPad, kRowPad, kRowPad); }
+    __device__ static uint32_t key(const E &e, int k) { return k == 0 ? e.x : k == 1 ? e.y : k == 2 ? e.z : e.w; }
+    __device__ static float val(const E &, int) { return 0.0f; }
+};
+
+// One workgroup per unit.  UC cold and UH hot stream ELEMENTS (Lay<L>::G groups each) per wavefront iteration;
+// group counts per unit are multiples of G.
+template <int OP, int MASK, int L, int UC, int UH>
 __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     using TL = Tile<OP>;
     using T = typename TL::T;
+    using LY = Lay<L>;
+    using E = typename LY::E;
+    constexpr int G = LY::G;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
     T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);   // nhot is a multiple of 64
 
     if (a.run_flag && *a.run_flag == 0u) return;
     const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
-    const uint32_t g0 = d.x, ncold = d.y, row0 = d.z;
-    const uint32_t nrows = d.w & 0xffffu;
-    const bool direct = (d.w >> 31) != 0u;
-    const uint32_t hub_off = dh.x, nhub = dh.y, nhotg = dh.z;
+    const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
+    const uint32_t nhub = dh.y, nhotg = dh.z;
     const uint32_t nslots = nrows + kHubSlots * nhub;
     const uint32_t lane = threadIdx.x & 63u;
     // wave id as a scalar so that group indices, and with them the base-column loads, stay in SGPRs
@@ -191,254 +254,60 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
     __syncthreads();
 
-    // Wave w takes cold groups w, w+16, ... and hot groups w, w+16, ...: the workgroup reads contiguous
-    // stream and its wavefronts sweep the columns together.  Per iteration UC cold groups (stream read +
-    // global gather) and UH hot groups (stream read + LDS lookup) are in flight.
-    const uint32_t gh0 = g0 + ncold;
-    uint32_t gc = wave, gh = wave;
-    while (gc < ncold || (UH > 0 && gh < nhotg)) {
-        uint2 ec[UC];
-        uint32_t bc[UC];
-        uint2 eh[UH > 0 ? UH : 1];
-#pragma unroll
-        for (int u = 0; u < UC; u++) {
-            const uint32_t gi = gc + u * kWaves;
-            const bool in = gi < ncold;
-            ec[u] = in ? load_stream_nt(a.entries + (size_t)(g0 + gi) * 64u + lane) : make_uint2(kRowPad, 0u);
-            bc[u] = in ? a.bases[g0 + gi] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < UH; u++) {
-            const uint32_t gi = gh + u * kWaves;
-            eh[u] = (gi < nhotg) ? load_stream_nt(a.entries + (size_t)(gh0 + gi) * 64u + lane) : make_uint2(kRowPad, 0u);
-        }
-        float xc[UC];
-#pragma unroll
-        for (int u = 0; u < UC; u++) xc[u] = a.x[bc[u] + (ec[u].x >> kRowBits)];
-#pragma unroll
-        for (int u = 0; u < UH; u++) {
-            const uint32_t r = eh[u].x & kRowPad;
-            if (r != kRowPad) TL::acc(tile, r, __uint_as_float(eh[u].y), hot_x[eh[u].x >> kRowBits]);
-        }
-#pragma unroll
-        for (int u = 0; u < UC; u++) {
-            const uint32_t r = ec[u].x & kRowPad;
-            if (r != kRowPad) TL::acc(tile, r, __uint_as_float(ec[u].y), xc[u]);
-        }
-        gc += kWaves * UC;
-        gh += kWaves * (UH > 0 ? UH : 1);
-    }
-    spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
-}
-
-// The general layout with two consecutive groups stored lane-interleaved (16 bytes per lane and load:
-// { A.index, A.value, B.index, B.value }): half as many stream instructions per byte (scripts/ubench_mix:
-// -5 % on the stream + gather loop).  UC cold PAIRS and UH hot PAIRS per wavefront iteration.
-template <int OP, int MASK, int UC, int UH>
-__global__ __launch_bounds__(kThreads) void spmv_rbcs_wide_kernel(SpmvArgs a) {
-    using TL = Tile<OP>;
-    using T = typename TL::T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
-    T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);
-
-    if (a.run_flag && *a.run_flag == 0u) return;
-    const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
-    const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
-    const uint32_t nhub = dh.y, nhotg = dh.z;
-    const uint32_t nslots = nrows + kHubSlots * nhub;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    if (UH > 0)
-        for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];
-    for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
-    __syncthreads();
-
     if (a.clocks && threadIdx.x == 0) a.clocks[2u * blockIdx.x] = wall_clock64();
-    const uint4 *pairs = reinterpret_cast<const uint4 *>(a.entries);   // pair P = groups 2P, 2P+1
-    const uint32_t pc0 = g0 >> 1, npc = ncold >> 1, ph0 = (g0 + ncold) >> 1, nph = nhotg >> 1;
-    uint32_t pc = wave, ph = wave;
-    while (pc < npc || (UH > 0 && ph < nph)) {
-        uint4 ec[UC];
-        uint32_t bc[UC][2];
-        uint4 eh[UH > 0 ? UH : 1];
+    // Wave w takes cold elements w, w+16, ... and hot elements w, w+16, ...: the workgroup reads contiguous
+    // stream and its wavefronts sweep the columns together.  Per iteration UC cold elements (stream read +
+    // global gather) and UH hot elements (stream read + LDS lookup) are in flight.
+    const float *xsrc = LY::kValues ? a.x : a.z;
+    const uint32_t c0 = g0 / G, nc = ncold / G, h0 = (g0 + ncold) / G, nh = nhotg / G;
+    uint32_t ic = wave, ih = wave;
+    while (ic < nc || (UH > 0 && ih < nh)) {
+        E ec[UC];
+        uint32_t bc[UC][G];
+        E eh[UH > 0 ? UH : 1];
 #pragma unroll
         for (int u = 0; u < UC; u++) {
-            const uint32_t pi = pc + u * kWaves;
-            const bool in = pi < npc;
-            ec[u] = in ? load_stream_nt16(pairs + (size_t)(pc0 + pi) * 64u + lane) : make_uint4(kRowPad, 0u, kRowPad, 0u);
-            bc[u][0] = in ? a.bases[g0 + 2u * pi] : 0u;
-            bc[u][1] = in ? a.bases[g0 + 2u * pi + 1u] : 0u;
+            const uint32_t ei = ic + u * kWaves;
+            const bool in = ei < nc;
+            ec[u] = in ? LY::load(a.entries, (size_t)(c0 + ei) * 64u + lane) : LY::pad();
+#pragma unroll
+            for (int k = 0; k < G; k++) bc[u][k] = in ? a.bases[g0 + G * ei + k] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < UH; u++) {
-            const uint32_t pi = ph + u * kWaves;
-            eh[u] = (pi < nph) ? load_stream_nt16(pairs + (size_t)(ph0 + pi) * 64u + lane) : make_uint4(kRowPad, 0u, kRowPad, 0u);
+            const uint32_t ei = ih + u * kWaves;
+            eh[u] = (ei < nh) ? LY::load(a.entries, (size_t)(h0 + ei) * 64u + lane) : LY::pad();
         }
-        float xc[UC][2];
+        float xc[UC][G];
 #pragma unroll
-        for (int u = 0; u < UC; u++) {
-            xc[u][0] = a.x[bc[u][0] + (ec[u].x >> kRowBits)];
-            xc[u][1] = a.x[bc[u][1] + (ec[u].z >> kRowBits)];
-        }
+        for (int u = 0; u < UC; u++)
 #pragma unroll
-        for (int u = 0; u < UH; u++) {
-            const uint32_t r0 = eh[u].x & kRowPad, r1 = eh[u].z & kRowPad;
-            if (r0 != kRowPad) TL::acc(tile, r0, __uint_as_float(eh[u].y), hot_x[eh[u].x >> kRowBits]);
-            if (r1 != kRowPad) TL::acc(tile, r1, __uint_as_float(eh[u].w), hot_x[eh[u].z >> kRowBits]);
-        }
+            for (int k = 0; k < G; k++) xc[u][k] = xsrc[bc[u][k] + (LY::key(ec[u], k) >> kRowBits)];
 #pragma unroll
-        for (int u = 0; u < UC; u++) {
-            const uint32_t r0 = ec[u].x & kRowPad, r1 = ec[u].z & kRowPad;
-            if (r0 != kRowPad) TL::acc(tile, r0, __uint_as_float(ec[u].y), xc[u][0]);
-            if (r1 != kRowPad) TL::acc(tile, r1, __uint_as_float(ec[u].w), xc[u][1]);
-        }
-        pc += kWaves * UC;
-        ph += kWaves * (UH > 0 ? UH : 1);
+        for (int u = 0; u < UH; u++)
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                const uint32_t key = LY::key(eh[u], k), r = key & kRowPad;
+                if (r != kRowPad) {
+                    if (LY::kValues) TL::acc(tile, r, LY::val(eh[u], k), hot_x[key >> kRowBits]);
+                    else TL::accz(tile, r, hot_x[key >> kRowBits]);
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < UC; u++)
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                const uint32_t r = LY::key(ec[u], k) & kRowPad;
+                if (r != kRowPad) {
+                    if (LY::kValues) TL::acc(tile, r, LY::val(ec[u], k), xc[u][k]);
+                    else TL::accz(tile, r, xc[u][k]);
+                }
+            }
+        ic += kWaves * UC;
+        ih += kWaves * (UH > 0 ? UH : 1);
     }
     spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
     if (a.clocks && threadIdx.x == 0) a.clocks[2u * blockIdx.x + 1u] = wall_clock64();
-}
-
-// Pattern plans (every column's stored values are equal): the stream carries 4 bytes per entry,
-// { (col - group_base) << 14 | slot }, the value is folded into z[c] = colval[c] (x) x[c] once per run.
-// Two consecutive groups are stored lane-interleaved so that one 8-byte-per-lane read fetches both
-// (.x = entry `lane` of the even group, .y = of the odd group); group counts per unit are even.
-template <int OP, int MASK, int UC, int UH>   // UC cold PAIRS and UH hot PAIRS per wavefront iteration
-__global__ __launch_bounds__(kThreads) void spmv_rbcs_pat_kernel(SpmvArgs a) {
-    using TL = Tile<OP>;
-    using T = typename TL::T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
-    T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);
-
-    if (a.run_flag && *a.run_flag == 0u) return;
-    const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
-    const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
-    const uint32_t nhub = dh.y, nhotg = dh.z;
-    const uint32_t nslots = nrows + kHubSlots * nhub;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    if (UH > 0)
-        for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];
-    for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
-    __syncthreads();
-
-    const uint2 *pairs = a.entries;                  // pair P = groups 2P, 2P+1; g0, ncold, nhotg are even
-    const uint32_t pc0 = g0 >> 1, npc = ncold >> 1, ph0 = (g0 + ncold) >> 1, nph = nhotg >> 1;
-    uint32_t pc = wave, ph = wave;
-    while (pc < npc || (UH > 0 && ph < nph)) {
-        uint2 ec[UC];
-        uint32_t bc[UC][2];
-        uint2 eh[UH > 0 ? UH : 1];
-#pragma unroll
-        for (int u = 0; u < UC; u++) {
-            const uint32_t pi = pc + u * kWaves;
-            const bool in = pi < npc;
-            ec[u] = in ? load_stream_nt(pairs + (size_t)(pc0 + pi) * 64u + lane) : make_uint2(kRowPad, kRowPad);
-            bc[u][0] = in ? a.bases[g0 + 2u * pi] : 0u;
-            bc[u][1] = in ? a.bases[g0 + 2u * pi + 1u] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < UH; u++) {
-            const uint32_t pi = ph + u * kWaves;
-            eh[u] = (pi < nph) ? load_stream_nt(pairs + (size_t)(ph0 + pi) * 64u + lane) : make_uint2(kRowPad, kRowPad);
-        }
-        float xc[UC][2];
-#pragma unroll
-        for (int u = 0; u < UC; u++) {
-            xc[u][0] = a.z[bc[u][0] + (ec[u].x >> kRowBits)];
-            xc[u][1] = a.z[bc[u][1] + (ec[u].y >> kRowBits)];
-        }
-#pragma unroll
-        for (int u = 0; u < UH; u++) {
-            const uint32_t r0 = eh[u].x & kRowPad, r1 = eh[u].y & kRowPad;
-            if (r0 != kRowPad) TL::accz(tile, r0, hot_x[eh[u].x >> kRowBits]);
-            if (r1 != kRowPad) TL::accz(tile, r1, hot_x[eh[u].y >> kRowBits]);
-        }
-#pragma unroll
-        for (int u = 0; u < UC; u++) {
-            const uint32_t r0 = ec[u].x & kRowPad, r1 = ec[u].y & kRowPad;
-            if (r0 != kRowPad) TL::accz(tile, r0, xc[u][0]);
-            if (r1 != kRowPad) TL::accz(tile, r1, xc[u][1]);
-        }
-        pc += kWaves * UC;
-        ph += kWaves * (UH > 0 ? UH : 1);
-    }
-    spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
-}
-
-// Pattern layout with FOUR consecutive groups lane-interleaved (16 bytes per lane and load: entry `lane` of groups
-// 4Q .. 4Q+3); group counts per unit are multiples of four.  UC cold QUADS and UH hot QUADS per iteration.
-template <int OP, int MASK, int UC, int UH>
-__global__ __launch_bounds__(kThreads) void spmv_rbcs_pat4_kernel(SpmvArgs a) {
-    using TL = Tile<OP>;
-    using T = typename TL::T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
-    T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);
-
-    if (a.run_flag && *a.run_flag == 0u) return;
-    const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
-    const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
-    const uint32_t nhub = dh.y, nhotg = dh.z;
-    const uint32_t nslots = nrows + kHubSlots * nhub;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    if (UH > 0)
-        for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];
-    for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
-    __syncthreads();
-
-    const uint4 *quads = reinterpret_cast<const uint4 *>(a.entries);
-    const uint32_t qc0 = g0 >> 2, nqc = ncold >> 2, qh0 = (g0 + ncold) >> 2, nqh = nhotg >> 2;
-    uint32_t qc = wave, qh = wave;
-    while (qc < nqc || (UH > 0 && qh < nqh)) {
-        uint4 ec[UC];
-        uint32_t bc[UC][4];
-        uint4 eh[UH > 0 ? UH : 1];
-#pragma unroll
-        for (int u = 0; u < UC; u++) {
-            const uint32_t qi = qc + u * kWaves;
-            const bool in = qi < nqc;
-            ec[u] = in ? load_stream_nt16(quads + (size_t)(qc0 + qi) * 64u + lane) : make_uint4(kRowPad, kRowPad, kRowPad, kRowPad);
-#pragma unroll
-            for (int k = 0; k < 4; k++) bc[u][k] = in ? a.bases[g0 + 4u * qi + k] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < UH; u++) {
-            const uint32_t qi = qh + u * kWaves;
-            eh[u] = (qi < nqh) ? load_stream_nt16(quads + (size_t)(qh0 + qi) * 64u + lane) : make_uint4(kRowPad, kRowPad, kRowPad, kRowPad);
-        }
-        float xc[UC][4];
-#pragma unroll
-        for (int u = 0; u < UC; u++) {
-            xc[u][0] = a.z[bc[u][0] + (ec[u].x >> kRowBits)];
-            xc[u][1] = a.z[bc[u][1] + (ec[u].y >> kRowBits)];
-            xc[u][2] = a.z[bc[u][2] + (ec[u].z >> kRowBits)];
-            xc[u][3] = a.z[bc[u][3] + (ec[u].w >> kRowBits)];
-        }
-#pragma unroll
-        for (int u = 0; u < UH; u++) {
-            const uint32_t v[4] = {eh[u].x, eh[u].y, eh[u].z, eh[u].w};
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if ((v[k] & kRowPad) != kRowPad) TL::accz(tile, v[k] & kRowPad, hot_x[v[k] >> kRowBits]);
-        }
-#pragma unroll
-        for (int u = 0; u < UC; u++) {
-            const uint32_t v[4] = {ec[u].x, ec[u].y, ec[u].z, ec[u].w};
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if ((v[k] & kRowPad) != kRowPad) TL::accz(tile, v[k] & kRowPad, xc[u][k]);
-        }
-        qc += kWaves * UC;
-        qh += kWaves * (UH > 0 ? UH : 1);
-    }
-    spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
 }
 
 // z = colval (x) x for every column, and the hot table from the same products
@@ -516,53 +385,18 @@ __global__ __launch_bounds__(256) void spmv_combine_kernel(const uint4 *__restri
 
 namespace gl {
 
-template <int OP, int MASK, int UC, int UH>
+template <int OP, int MASK, int L, int UC, int UH>
 static int launch_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStream_t s) {
     static bool attr_set = false;  // one flag per template instantiation
     if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_kernel<OP, MASK, UC, UH>,
+        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_kernel<OP, MASK, L, UC, UH>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         attr_set = true;
     }
-    spmv_rbcs_kernel<OP, MASK, UC, UH><<<p->nunits, kThreads, lds, s>>>(a);
+    spmv_rbcs_kernel<OP, MASK, L, UC, UH><<<p->nunits, kThreads, lds, s>>>(a);
     return GL_OK;
 }
 
-template <int OP, int MASK, int UC, int UH>
-static int launch_wide_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_wide_kernel<OP, MASK, UC, UH>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set = true;
-    }
-    spmv_rbcs_wide_kernel<OP, MASK, UC, UH><<<p->nunits, kThreads, lds, s>>>(a);
-    return GL_OK;
-}
-
-template <int OP, int MASK, int UC, int UH>
-static int launch_pat_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_pat_kernel<OP, MASK, UC, UH>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set = true;
-    }
-    spmv_rbcs_pat_kernel<OP, MASK, UC, UH><<<p->nunits, kThreads, lds, s>>>(a);
-    return GL_OK;
-}
-
-template <int OP, int MASK, int UC, int UH>
-static int launch_pat4_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_pat4_kernel<OP, MASK, UC, UH>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set = true;
-    }
-    spmv_rbcs_pat4_kernel<OP, MASK, UC, UH><<<p->nunits, kThreads, lds, s>>>(a);
-    return GL_OK;
-}
 
 template <int OP, int MASK>
 static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
@@ -592,46 +426,46 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     int rc;
     if (p->pattern && p->wide) {
         switch (p->mix) {   // cold quads, hot quads per iteration
-            case 0: rc = launch_pat4_variant<OP, MASK, 2, 0>(p, a, lds, s); break;
-            case 1: rc = launch_pat4_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
-            case 9: rc = launch_pat4_variant<OP, MASK, 1, 2>(p, a, lds, s); break;
-            case 6: rc = launch_pat4_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
-            default: rc = launch_pat4_variant<OP, MASK, 1, 1>(p, a, lds, s); break;
+            case 0: rc = launch_variant<OP, MASK, kLayQuad, 2, 0>(p, a, lds, s); break;
+            case 1: rc = launch_variant<OP, MASK, kLayQuad, 2, 1>(p, a, lds, s); break;
+            case 9: rc = launch_variant<OP, MASK, kLayQuad, 1, 2>(p, a, lds, s); break;
+            case 6: rc = launch_variant<OP, MASK, kLayQuad, 2, 2>(p, a, lds, s); break;
+            default: rc = launch_variant<OP, MASK, kLayQuad, 1, 1>(p, a, lds, s); break;
         }
     } else if (p->pattern) {
         switch (p->mix) {   // cold pairs, hot pairs per iteration
-            case 0: rc = launch_pat_variant<OP, MASK, 3, 0>(p, a, lds, s); break;
-            case 2: rc = launch_pat_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
-            case 3: rc = launch_pat_variant<OP, MASK, 3, 1>(p, a, lds, s); break;
-            case 4: rc = launch_pat_variant<OP, MASK, 1, 1>(p, a, lds, s); break;
-            case 5: rc = launch_pat_variant<OP, MASK, 4, 2>(p, a, lds, s); break;
-            case 6: rc = launch_pat_variant<OP, MASK, 3, 2>(p, a, lds, s); break;
-            case 7: rc = launch_pat_variant<OP, MASK, 4, 1>(p, a, lds, s); break;
-            case 8: rc = launch_pat_variant<OP, MASK, 1, 2>(p, a, lds, s); break;
-            case 9: rc = launch_pat_variant<OP, MASK, 2, 3>(p, a, lds, s); break;
-            default: rc = launch_pat_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
+            case 0: rc = launch_variant<OP, MASK, kLayPair, 3, 0>(p, a, lds, s); break;
+            case 2: rc = launch_variant<OP, MASK, kLayPair, 2, 2>(p, a, lds, s); break;
+            case 3: rc = launch_variant<OP, MASK, kLayPair, 3, 1>(p, a, lds, s); break;
+            case 4: rc = launch_variant<OP, MASK, kLayPair, 1, 1>(p, a, lds, s); break;
+            case 5: rc = launch_variant<OP, MASK, kLayPair, 4, 2>(p, a, lds, s); break;
+            case 6: rc = launch_variant<OP, MASK, kLayPair, 3, 2>(p, a, lds, s); break;
+            case 7: rc = launch_variant<OP, MASK, kLayPair, 4, 1>(p, a, lds, s); break;
+            case 8: rc = launch_variant<OP, MASK, kLayPair, 1, 2>(p, a, lds, s); break;
+            case 9: rc = launch_variant<OP, MASK, kLayPair, 2, 3>(p, a, lds, s); break;
+            default: rc = launch_variant<OP, MASK, kLayPair, 2, 1>(p, a, lds, s); break;
         }
     } else if (p->wide) {
         switch (p->mix) {   // cold pairs, hot pairs per iteration
-            case 0: rc = launch_wide_variant<OP, MASK, 2, 0>(p, a, lds, s); break;
-            case 1: rc = launch_wide_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
-            case 2: rc = launch_wide_variant<OP, MASK, 1, 1>(p, a, lds, s); break;
-            case 3: rc = launch_wide_variant<OP, MASK, 3, 1>(p, a, lds, s); break;
-            case 6: rc = launch_wide_variant<OP, MASK, 3, 2>(p, a, lds, s); break;
-            case 7: rc = launch_wide_variant<OP, MASK, 3, 3>(p, a, lds, s); break;
-            case 8: rc = launch_wide_variant<OP, MASK, 1, 2>(p, a, lds, s); break;
-            case 9: rc = launch_wide_variant<OP, MASK, 2, 3>(p, a, lds, s); break;
-            default: rc = launch_wide_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
+            case 0: rc = launch_variant<OP, MASK, kLayWide, 2, 0>(p, a, lds, s); break;
+            case 1: rc = launch_variant<OP, MASK, kLayWide, 2, 1>(p, a, lds, s); break;
+            case 2: rc = launch_variant<OP, MASK, kLayWide, 1, 1>(p, a, lds, s); break;
+            case 3: rc = launch_variant<OP, MASK, kLayWide, 3, 1>(p, a, lds, s); break;
+            case 6: rc = launch_variant<OP, MASK, kLayWide, 3, 2>(p, a, lds, s); break;
+            case 7: rc = launch_variant<OP, MASK, kLayWide, 3, 3>(p, a, lds, s); break;
+            case 8: rc = launch_variant<OP, MASK, kLayWide, 1, 2>(p, a, lds, s); break;
+            case 9: rc = launch_variant<OP, MASK, kLayWide, 2, 3>(p, a, lds, s); break;
+            default: rc = launch_variant<OP, MASK, kLayWide, 2, 2>(p, a, lds, s); break;
         }
     } else
     switch (p->mix) {
-        case 1: rc = launch_variant<OP, MASK, 3, 1>(p, a, lds, s); break;
-        case 2: rc = launch_variant<OP, MASK, 2, 1>(p, a, lds, s); break;
-        case 3: rc = launch_variant<OP, MASK, 2, 2>(p, a, lds, s); break;
-        case 4: rc = launch_variant<OP, MASK, 4, 2>(p, a, lds, s); break;
-        case 5: rc = launch_variant<OP, MASK, 3, 3>(p, a, lds, s); break;
-        case 6: rc = launch_variant<OP, MASK, 4, 1>(p, a, lds, s); break;
-        default: rc = launch_variant<OP, MASK, 4, 0>(p, a, lds, s); break;
+        case 1: rc = launch_variant<OP, MASK, kLayNarrow, 3, 1>(p, a, lds, s); break;
+        case 2: rc = launch_variant<OP, MASK, kLayNarrow, 2, 1>(p, a, lds, s); break;
+        case 3: rc = launch_variant<OP, MASK, kLayNarrow, 2, 2>(p, a, lds, s); break;
+        case 4: rc = launch_variant<OP, MASK, kLayNarrow, 4, 2>(p, a, lds, s); break;
+        case 5: rc = launch_variant<OP, MASK, kLayNarrow, 3, 3>(p, a, lds, s); break;
+        case 6: rc = launch_variant<OP, MASK, kLayNarrow, 4, 1>(p, a, lds, s); break;
+        default: rc = launch_variant<OP, MASK, kLayNarrow, 4, 0>(p, a, lds, s); break;
     }
     if (rc != GL_OK) return rc;
     GL_LAUNCH_CHECK();

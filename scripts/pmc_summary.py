@@ -44,15 +44,15 @@ def main():
                     g.write(line)
         with open(stats[0]) as f:
             for row in csv.DictReader(f):
-                if "spmv_rbcs_wide_kernel" in row["Name"]:
+                if "spmv_rbcs_kernel<0, 0, 1," in row["Name"]:
                     out["spmv_rbcs_kernel_avg_ns"] = float(row["AverageNs"])
                     out["spmv_rbcs_kernel_calls"] = int(row["Calls"])
     for name in ("pmc_fetch_rbcs.csv", "pmc_write_rbcs.csv"):
         p = os.path.join(SRC, name)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(DST, "%s_%s" % (TAG, name)))
-    fetch, nf = mean_counter(os.path.join(SRC, "pmc_fetch_rbcs.csv"), "spmv_rbcs_wide_kernel")
-    write, nw = mean_counter(os.path.join(SRC, "pmc_write_rbcs.csv"), "spmv_rbcs_wide_kernel")
+    fetch, nf = mean_counter(os.path.join(SRC, "pmc_fetch_rbcs.csv"), "spmv_rbcs_kernel<0, 0, 1,")
+    write, nw = mean_counter(os.path.join(SRC, "pmc_write_rbcs.csv"), "spmv_rbcs_kernel<0, 0, 1,")
     out.update({"FETCH_SIZE_KiB_mean": fetch, "WRITE_SIZE_KiB_mean": write, "launches_averaged": [nf, nw],
                 "fetch_correction": 2.0,
                 "spmv_rbcs_kernel_bytes_per_launch": int((2.0 * fetch + write) * 1024)})
@@ -62,7 +62,7 @@ def main():
         shutil.copy(fs, os.path.join(DST, "%s_pmc_fetch_spmv.csv" % TAG))
         shutil.copy(ws, os.path.join(DST, "%s_pmc_write_spmv.csv" % TAG))
         other = {}
-        for k in ("spmv_rbcs_pat4_kernel", "spmv_bool_kernel<0, 6, 1>", "spmv_bool_kernel<0, 6, 0>", "spmv_prescale_kernel", "spmv_bool_pack_kernel"):
+        for k in ("spmv_rbcs_kernel<0, 0, 3,", "spmv_bool_kernel<0, 6, 1>", "spmv_bool_kernel<0, 6, 0>", "spmv_prescale_kernel", "spmv_bool_pack_kernel"):
             try:
                 f_, n1 = mean_counter(fs, k)
                 w_, n2 = mean_counter(ws, k)
@@ -75,7 +75,7 @@ def main():
         with open(stats[0]) as f:
             rows = {}
             for row in csv.DictReader(f):
-                for k in ("spmv_rbcs_pat4_kernel", "spmv_bool_kernel<0, 6, 1>", "spmv_bool_kernel<0, 6, 0>", "spmv_prescale_kernel", "spmv_bool_pack_kernel",
+                for k in ("spmv_rbcs_kernel<0, 0, 3,", "spmv_bool_kernel<0, 6, 1>", "spmv_bool_kernel<0, 6, 0>", "spmv_prescale_kernel", "spmv_bool_pack_kernel",
                           "spmv_hot_gather_kernel", "spmspv_scatter_kernel", "spmspv_queue_kernel", "spmspv_work_kernel"):
                     if k in row["Name"]:
                         rows[k] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}

@@ -12,7 +12,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $C --output-format csv -d /tmp/prof/pmc_$C -- python $R/bench.py --steps 10 --no-cpu-baseline --bfs-runs 2 > /tmp/prof/pmc_$C.json 2> /tmp/prof/pmc_$C.err
   f=$(find /tmp/prof/pmc_$C -name "*counter_collection.csv" | head -1)
   n=$(echo $C | tr A-Z a-z | sed 's/_size//')
-  if [ -n "$f" ]; then head -1 "$f" > $OUT/pmc_${n}_spmv.csv; grep "spmv_" "$f" >> $OUT/pmc_${n}_spmv.csv; grep "spmv_rbcs_wide_kernel" $OUT/pmc_${n}_spmv.csv > /dev/null && { head -1 "$f" > $OUT/pmc_${n}_rbcs.csv; grep "spmv_rbcs_wide_kernel" "$f" >> $OUT/pmc_${n}_rbcs.csv; }; fi
+  if [ -n "$f" ]; then head -1 "$f" > $OUT/pmc_${n}_spmv.csv; grep "spmv_" "$f" >> $OUT/pmc_${n}_spmv.csv; grep "spmv_rbcs_kernel<0, 0, 1," $OUT/pmc_${n}_spmv.csv > /dev/null && { head -1 "$f" > $OUT/pmc_${n}_rbcs.csv; grep "spmv_rbcs_kernel<0, 0, 1," "$f" >> $OUT/pmc_${n}_rbcs.csv; }; fi
 done
 if [ -x $R/build/ubench_gather ]; then
   timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof/calib -- $R/build/ubench_gather > /tmp/prof/calib.log 2>&1
