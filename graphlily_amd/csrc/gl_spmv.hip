@@ -58,11 +58,24 @@ struct SpmvArgs {
     const float *diag;        // pattern plans with diagonal exceptions: A[r][r] per local row, folded in by the epilogue
     const uint32_t *diag_has; // bit per local row: the row has a diagonal entry that differs from its column's value
     const uint32_t *run_flag;    // non-null: the launch is a no-op unless run_flag[0] != 0 (gl_spmspv_run's direction switch)
-    unsigned long long *clocks;  // debugging (GRAPHLILY_SPMV_CLOCKS): wall_clock64 at the start and end of every unit
+    unsigned long long *clocks;  // debugging (GRAPHLILY_SPMV_CLOCKS): kClockStamps wall_clock64 stamps per unit
     float *partials;          // [segment][row - row_begin] per-unit tiles of split blocks (combined by spmv_combine_kernel)
     uint32_t prow;            // rows per segment plane
     uint32_t row_begin;
+    uint32_t tickets;         // 1: wavefronts draw iterations from the LDS ticket; 0: static split (GRAPHLILY_SPMV_TICKETS=0)
 };
+
+// debugging: stamp k of this unit (entry, prologue done, wave 0's loop done, all waves done, end)
+// and, as a sixth word, where the unit ran: HW_ID (se / sh / cu) | XCC_ID << 32
+constexpr uint32_t kClockStamps = 6;
+__device__ __forceinline__ void clock_stamp(const SpmvArgs &a, uint32_t k) {
+    if (a.clocks && threadIdx.x == 0) {
+        a.clocks[kClockStamps * blockIdx.x + k] = wall_clock64();
+        if (k == 0)   // s_getreg_b32 hwreg(HW_REG_HW_ID = 4, 0, 32) and hwreg(HW_REG_XCC_ID = 20, 0, 32)
+            a.clocks[kClockStamps * blockIdx.x + 5] =
+                (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+    }
+}
 
 template <int OP>
 struct Tile;  // LDS accumulator policy
@@ -132,6 +145,7 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
     const bool direct = (d.w >> 31) != 0u;
     const uint32_t hub_off = dh.x, nhub = dh.y;
     __syncthreads();
+    clock_stamp(a, 3);
     if (nhub) {   // fold the private slots of every hub row back into its row
         if (threadIdx.x < nhub) {
             const uint32_t r = a.hub_rows[hub_off + threadIdx.x];
@@ -227,6 +241,67 @@ struct Lay<kLayQuad> {
     __device__ static float val(const E &, int) { return 0.0f; }
 };
 
+// One slot's work: UC cold and UH hot stream elements (either may be 0).  Every load is unconditional -- indices clamp
+// to the stream's last element and the plan pads its arrays by one element -- because conditional loads make the
+// compiler serialise them with s_waitcnt vmcnt(0); out-of-range elements are dropped at the accumulate.
+struct StreamGeom {
+    uint32_t g0, c0, nc, nc_last, h0, nh, nh_last;
+};
+
+template <int OP, int L, int UC, int UH>
+__device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Tile<OP>::T *tile, const float *hot_x,
+                                                 const float *xsrc, const StreamGeom &sg, uint32_t lane, uint32_t ic, uint32_t ih,
+                                                 uint32_t *next_slot, uint32_t &ticket) {
+    using TL = Tile<OP>;
+    using LY = Lay<L>;
+    using E = typename LY::E;
+    constexpr int G = LY::G;
+    E ec[UC > 0 ? UC : 1];
+    uint32_t bc[UC > 0 ? UC : 1][G];
+    E eh[UH > 0 ? UH : 1];
+#pragma unroll
+    for (int u = 0; u < UC; u++) {
+        const uint32_t ei = min(ic + u * kWaves, sg.nc_last);
+        ec[u] = LY::load(a.entries, (size_t)(sg.c0 + ei) * 64u + lane);
+#pragma unroll
+        for (int k = 0; k < G; k++) bc[u][k] = load_const(a.bases + sg.g0 + G * ei + k);
+    }
+#pragma unroll
+    for (int u = 0; u < UH; u++) eh[u] = LY::load(a.entries, (size_t)(sg.h0 + min(ih + u * kWaves, sg.nh_last)) * 64u + lane);
+    // the next slot's ticket is drawn while the loads are in flight: at the end of the step it would have to wait for
+    // the step's own accumulates (LDS operations complete in order)
+    if (a.tickets && lane == 0) ticket = __hip_atomic_fetch_add(next_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    float xc[UC > 0 ? UC : 1][G];
+#pragma unroll
+    for (int u = 0; u < UC; u++)
+#pragma unroll
+        for (int k = 0; k < G; k++) xc[u][k] = xsrc[bc[u][k] + (LY::key(ec[u], k) >> kRowBits)];
+#pragma unroll
+    for (int u = 0; u < UH; u++) {
+        const bool in = ih + u * kWaves < sg.nh;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const uint32_t key = LY::key(eh[u], k), r = in ? (key & kRowPad) : kRowPad;
+            if (r != kRowPad) {
+                if (LY::kValues) TL::acc(tile, r, LY::val(eh[u], k), hot_x[key >> kRowBits]);
+                else TL::accz(tile, r, hot_x[key >> kRowBits]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UC; u++) {
+        const bool in = ic + u * kWaves < sg.nc;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const uint32_t r = in ? (LY::key(ec[u], k) & kRowPad) : kRowPad;
+            if (r != kRowPad) {
+                if (LY::kValues) TL::acc(tile, r, LY::val(ec[u], k), xc[u][k]);
+                else TL::accz(tile, r, xc[u][k]);
+            }
+        }
+    }
+}
+
 // One workgroup per unit.  UC cold and UH hot stream ELEMENTS (Lay<L>::G groups each) per wavefront iteration;
 // group counts per unit are multiples of G.
 template <int OP, int MASK, int L, int UC, int UH>
@@ -234,14 +309,14 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     using TL = Tile<OP>;
     using T = typename TL::T;
     using LY = Lay<L>;
-    using E = typename LY::E;
     constexpr int G = LY::G;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
     T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);   // nhot is a multiple of 64
 
     if (a.run_flag && *a.run_flag == 0u) return;
-    const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
+    clock_stamp(a, 0);
+    const uint4 d = load_const(a.units + 2u * blockIdx.x), dh = load_const(a.units + 2u * blockIdx.x + 1u);   // scalar loads
     const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
     const uint32_t nhub = dh.y, nhotg = dh.z;
     const uint32_t nslots = nrows + kHubSlots * nhub;
@@ -249,65 +324,46 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     // wave id as a scalar so that group indices, and with them the base-column loads, stay in SGPRs
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
+    __shared__ uint32_t next_iter;   // ticket: the first kWaves iterations are taken by wave number
+    if (threadIdx.x == 0) next_iter = kWaves;
     if (UH > 0)
         for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];   // coalesced, L2 hits
     for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
     __syncthreads();
 
-    if (a.clocks && threadIdx.x == 0) a.clocks[2u * blockIdx.x] = wall_clock64();
-    // Wave w takes cold elements w, w+16, ... and hot elements w, w+16, ...: the workgroup reads contiguous
-    // stream and its wavefronts sweep the columns together.  Per iteration UC cold elements (stream read +
-    // global gather) and UH hot elements (stream read + LDS lookup) are in flight.
+    clock_stamp(a, 1);
+    // The stream is consumed in rounds of kWaves slots: slot w of round j takes cold elements j*kWaves*UC + w + u*kWaves
+    // (u < UC) and the hot ones likewise, so the slots of a round read contiguous stream and sweep the same columns
+    // (stream read + global gather for cold, stream read + LDS lookup for hot).  Wavefronts draw slot numbers from an LDS
+    // ticket: with a static split the hardware's oldest-first issue lets the low wavefronts finish ~10 % early and the
+    // CU idles its memory pipe while the rest catch up.  Rounds past the end of the shorter stream touch only the other.
     const float *xsrc = LY::kValues ? a.x : a.z;
-    const uint32_t c0 = g0 / G, nc = ncold / G, h0 = (g0 + ncold) / G, nh = nhotg / G;
-    uint32_t ic = wave, ih = wave;
-    while (ic < nc || (UH > 0 && ih < nh)) {
-        E ec[UC];
-        uint32_t bc[UC][G];
-        E eh[UH > 0 ? UH : 1];
-#pragma unroll
-        for (int u = 0; u < UC; u++) {
-            const uint32_t ei = ic + u * kWaves;
-            const bool in = ei < nc;
-            ec[u] = in ? LY::load(a.entries, (size_t)(c0 + ei) * 64u + lane) : LY::pad();
-#pragma unroll
-            for (int k = 0; k < G; k++) bc[u][k] = in ? a.bases[g0 + G * ei + k] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < UH; u++) {
-            const uint32_t ei = ih + u * kWaves;
-            eh[u] = (ei < nh) ? LY::load(a.entries, (size_t)(h0 + ei) * 64u + lane) : LY::pad();
-        }
-        float xc[UC][G];
-#pragma unroll
-        for (int u = 0; u < UC; u++)
-#pragma unroll
-            for (int k = 0; k < G; k++) xc[u][k] = xsrc[bc[u][k] + (LY::key(ec[u], k) >> kRowBits)];
-#pragma unroll
-        for (int u = 0; u < UH; u++)
-#pragma unroll
-            for (int k = 0; k < G; k++) {
-                const uint32_t key = LY::key(eh[u], k), r = key & kRowPad;
-                if (r != kRowPad) {
-                    if (LY::kValues) TL::acc(tile, r, LY::val(eh[u], k), hot_x[key >> kRowBits]);
-                    else TL::accz(tile, r, hot_x[key >> kRowBits]);
-                }
-            }
-#pragma unroll
-        for (int u = 0; u < UC; u++)
-#pragma unroll
-            for (int k = 0; k < G; k++) {
-                const uint32_t r = LY::key(ec[u], k) & kRowPad;
-                if (r != kRowPad) {
-                    if (LY::kValues) TL::acc(tile, r, LY::val(ec[u], k), xc[u][k]);
-                    else TL::accz(tile, r, xc[u][k]);
-                }
-            }
-        ic += kWaves * UC;
-        ih += kWaves * (UH > 0 ? UH : 1);
+    StreamGeom sg;
+    sg.g0 = g0;
+    sg.c0 = g0 / G, sg.nc = ncold / G, sg.h0 = (g0 + ncold) / G, sg.nh = nhotg / G;
+    sg.nc_last = max(sg.nc, 1u) - 1u, sg.nh_last = max(sg.nh, 1u) - 1u;
+    const uint32_t rc = (sg.nc + kWaves * UC - 1) / (kWaves * UC), rh = UH > 0 ? (sg.nh + kWaves * UH - 1) / (kWaves * UH) : 0u;
+    const uint32_t n_both = min(rc, rh) * kWaves, n_all = max(rc, rh) * kWaves;
+    uint32_t it = wave, ticket = 0;
+    while (it < n_both) {
+        spmv_stream_step<OP, L, UC, UH>(a, tile, hot_x, xsrc, sg, lane, it / kWaves * (kWaves * UC) + it % kWaves,
+                                        it / kWaves * (kWaves * UH) + it % kWaves, &next_iter, ticket);
+        it = a.tickets ? __builtin_amdgcn_readfirstlane(ticket) : it + kWaves;
     }
+    if (rc > rh) {
+        while (it < n_all) {
+            spmv_stream_step<OP, L, UC, 0>(a, tile, hot_x, xsrc, sg, lane, it / kWaves * (kWaves * UC) + it % kWaves, 0u, &next_iter, ticket);
+            it = a.tickets ? __builtin_amdgcn_readfirstlane(ticket) : it + kWaves;
+        }
+    } else if (UH > 0) {
+        while (it < n_all) {
+            spmv_stream_step<OP, L, 0, UH>(a, tile, hot_x, xsrc, sg, lane, 0u, it / kWaves * (kWaves * UH) + it % kWaves, &next_iter, ticket);
+            it = a.tickets ? __builtin_amdgcn_readfirstlane(ticket) : it + kWaves;
+        }
+    }
+    clock_stamp(a, 2);
     spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
-    if (a.clocks && threadIdx.x == 0) a.clocks[2u * blockIdx.x + 1u] = wall_clock64();
+    clock_stamp(a, 4);
 }
 
 // z = colval (x) x for every column, and the hot table from the same products
@@ -972,6 +1028,10 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         }
         entries.swap(packed);
     }
+    // one element of slack: the kernel's loads are unconditional and clamp to a unit's last element, which for a unit
+    // without groups is the element that follows it
+    entries.insert(entries.end(), 128, make_uint2(gl::kRowPad, gl::kRowPad));
+    bases.insert(bases.end(), 4, 0u);
     int rc;
     if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * sizeof(uint2))) != GL_OK ||
         (rc = up((void **)&p->d_bases, bases.data(), bases.size() * sizeof(uint32_t))) != GL_OK ||
@@ -1153,8 +1213,8 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
     static const char *clocks_path = getenv("GRAPHLILY_SPMV_CLOCKS");
     unsigned long long *d_clocks = nullptr;
     if (clocks_path && p->nunits) {
-        GL_HIP(hipMalloc((void **)&d_clocks, (size_t)p->nunits * 16u));
-        GL_HIP(hipMemset(d_clocks, 0, (size_t)p->nunits * 16u));
+        GL_HIP(hipMalloc((void **)&d_clocks, (size_t)p->nunits * 8u * gl::kClockStamps));
+        GL_HIP(hipMemset(d_clocks, 0, (size_t)p->nunits * 8u * gl::kClockStamps));
         a.clocks = d_clocks;
     }
     a.z = p->d_z;
@@ -1163,6 +1223,8 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
     a.partials = p->d_partials;
     a.prow = p->row_end - p->row_begin;
     a.row_begin = p->row_begin;
+    static const uint32_t tickets = gl::env_long("GRAPHLILY_SPMV_TICKETS", 1) != 0;
+    a.tickets = tickets;
     hipStream_t s = gl::ctx().stream;
     int rc;
     switch (op) {
@@ -1171,16 +1233,18 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
         case GL_OP_ADDMIN: rc = gl::dispatch_mask<GL_OP_ADDMIN>(mask_type, p, a, s); break;
         default: rc = gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid semiring op %d", op); break;
     }
-    if (d_clocks) {   // debugging only: blocking dump "unit start end" (100 MHz ticks), last run wins
-        std::vector<unsigned long long> h((size_t)p->nunits * 2);
+    if (d_clocks) {   // debugging only: blocking dump (100 MHz ticks), last run wins
+        std::vector<unsigned long long> h((size_t)p->nunits * gl::kClockStamps);
         std::vector<uint4> un((size_t)p->nunits * 2);
         if (hipStreamSynchronize(s) == hipSuccess &&
             hipMemcpy(h.data(), d_clocks, h.size() * 8u, hipMemcpyDeviceToHost) == hipSuccess &&
             hipMemcpy(un.data(), p->d_units, un.size() * sizeof(uint4), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE *f = fopen(clocks_path, "w")) {   // unit start end #cold-groups #hot-groups #rows #hub-rows
-                for (uint32_t u = 0; u < p->nunits; u++)
-                    fprintf(f, "%u %llu %llu %u %u %u %u\n", u, h[2 * u], h[2 * u + 1], un[2 * u].y, un[2 * u + 1].z,
-                            un[2 * u].w & 0xffffu, un[2 * u + 1].y);
+            if (FILE *f = fopen(clocks_path, "w")) {   // unit, the stamps, #cold-groups #hot-groups #rows #hub-rows
+                for (uint32_t u = 0; u < p->nunits; u++) {
+                    fprintf(f, "%u", u);
+                    for (uint32_t k = 0; k < gl::kClockStamps; k++) fprintf(f, " %llu", h[gl::kClockStamps * u + k]);
+                    fprintf(f, " %u %u %u %u\n", un[2 * u].y, un[2 * u + 1].z, un[2 * u].w & 0xffffu, un[2 * u + 1].y);
+                }
                 fclose(f);
             }
         }

@@ -47,17 +47,6 @@ __global__ __launch_bounds__(256) void spmv_bool_pack_kernel(const float *__rest
     }
 }
 
-// Plan metadata is read-only for the whole launch: loading it through the constant address space lets the
-// compiler keep wave-uniform loads on the scalar unit even though the span loop contains barriers
-// (a fence makes ordinary global loads "clobbered", which turns them into vector loads + vmcnt(0) waits).
-__device__ __forceinline__ uint32_t load_const(const uint32_t *p) {
-    return *(const __attribute__((address_space(4))) uint32_t *)(p);
-}
-__device__ __forceinline__ uint4 load_const(const uint4 *p) {
-    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
-    return make_uint4(load_const(q), load_const(q + 1), load_const(q + 2), load_const(q + 3));
-}
-
 constexpr int kBoolStep = 2;   // ring slots processed together (divides the ring depth)
 
 template <int MASK, int U, int FUSED>

@@ -21,7 +21,10 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="GL_PLAN_* flags (1 NO_MULADD, 2 BOOLEAN)")
     ap.add_argument("--no-copy", action="store_true")
     ap.add_argument("--density", type=float, default=0.5, help="fraction of non-zeros in x")
+    ap.add_argument("--lib", default=None, help="load this build of libgraphlily_hip.so instead (A/B runs on one box)")
     args = ap.parse_args()
+    if args.lib:
+        capi.LIB_PATH = os.path.abspath(args.lib)
     dev = torch.device("cuda:0")
     capi.init(0)
     capi.set_stream(torch.cuda.current_stream().cuda_stream)
