@@ -709,7 +709,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     for (uint32_t r = row_begin; r < row_end; r++) GL_ARG(h_indptr[r + 1] >= h_indptr[r]);
 
     // ---- (||,&&)-only plans have their own layout (gl_spmv_bool.hip); very wide matrices keep the general one
-    if ((flags & GL_PLAN_BOOLEAN) && nnz > 0 && gl::cdiv(num_cols, gl::kBoolPhaseCols) <= 8u &&
+    if ((flags & GL_PLAN_BOOLEAN) && nnz > 0 && gl::cdiv(num_cols, gl::kBoolPhaseCols) <= gl::kBoolMaxPhases &&
         gl::env_long("GRAPHLILY_SPMV_BOOL", 1) != 0) {
         gl_spmv_plan p = new gl_spmv_plan_s();
         p->num_rows = num_rows;
@@ -977,11 +977,12 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     {
         // cold : hot groups per wavefront iteration follow the share of non-zeros the hot table serves
         // (measured on the stand-ins: orkut / products, 34-36 % hot, are best at 3 cold + 2 hot pairs;
-        // hollywood / ppa / googleplus, > 50 %, at 2 + 2; lopsided mixes starve one stream)
+        // hollywood / ppa / googleplus, > 50 %, at 2 + 2; since rounds past the end of the shorter stream touch only the
+        // other one, the choice is worth 2 % at most)
         const long forced = gl::env_long("GRAPHLILY_SPMV_MIX", -1);
         const double hot_frac = nnz ? (double)hot_nnz / (double)nnz : 0.0;
         int mix = 5;                                   // wide: 2 + 2 pairs; narrow: 3 + 3 groups
-        if (pattern) mix = hot_frac >= 0.60 ? 9 : 2;   // quads: 1 + 1 (1 + 2 when the hot table serves most); pairs: 2 + 2 / 2 + 3
+        if (pattern) mix = hot_frac >= 0.60 ? 9 : 6;   // quads: 2 + 2 (1 + 2 when the hot table serves most); pairs: 3 + 2 / 2 + 3
         else if (wide && hot_frac < 0.40) mix = 6;     // 3 + 2 pairs
         else if (wide && hot_frac >= 0.60) mix = 9;    // 2 + 3 pairs
         p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : mix);   // 0 would skip the hot groups

@@ -32,6 +32,7 @@ struct BoolArgs {
     uint32_t *bits_out;
     float *dist;
     float level;
+    uint32_t tickets;          // 1: ring slots are refilled from an LDS ticket per span; 0: static split (GRAPHLILY_SPMV_TICKETS=0)
 };
 
 // x != 0 packed little-endian, 64 columns per wavefront step; words past num_cols are zero
@@ -65,6 +66,11 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     for (uint32_t i = threadIdx.x; i < kBoolTileWords; i += kThreads) tile[i] = 0u;
+    // one ticket counter per span (a unit has at most kBoolMaxPhases of them): the first kWaves * U groups of a span are
+    // taken by wave and ring slot, the rest is drawn kBoolStep groups at a time, so that the wavefronts of a workgroup
+    // run out of work together (a static split lets the hardware's oldest-first issue finish the low wavefronts early)
+    __shared__ uint32_t next_group[kBoolMaxPhases];
+    if (threadIdx.x < kBoolMaxPhases) next_group[threadIdx.x] = kWaves * U;
 
     for (uint32_t sp = 0; sp < nspans; sp++) {
         const uint4 s = load_const(a.spans + span0 + sp);
@@ -73,12 +79,13 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         // compiler's s_waitcnt vmcnt(N) stay exact -- a batch "load U, wait, process U" loop leaves the
         // memory pipe empty for the whole processing phase and is latency-bound at ~2/3 of HBM speed.
         // The ring is primed BEFORE the x bits of the phase are copied: the copy hides the HBM latency.
-        const uint32_t gend = s.z, glast = s.z - 1u;
+        const uint32_t ngroups = s.z - s.y, glast = s.z - 1u;
         uint2 e[U];
-        uint32_t b[U];
+        uint32_t b[U], li[U];   // li: the slot's group, counted from the span's first
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t gi = min(s.y + wave + u * kWaves, glast);
+            li[u] = wave + u * kWaves;
+            const uint32_t gi = min(s.y + li[u], glast);
             e[u] = load_stream_nt(a.entries + (size_t)gi * 64u + lane);
             b[u] = load_const(a.bases + gi);
             // keep slot order = issue order: if the scheduler reverses these loads, slot 0 becomes the youngest
@@ -92,7 +99,9 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
             for (uint32_t i = (s.w & 0xffffu) + threadIdx.x; i < (s.w >> 16); i += kThreads) dst[i] = src[i];
         }
         __syncthreads();
-        for (uint32_t g = s.y + wave; g < gend; g += kWaves * U) {
+        uint32_t drawn = 0;   // lane 0: the ticket for the next refill, drawn one step ahead
+        if (a.tickets && lane == 0) drawn = __hip_atomic_fetch_add(&next_group[sp], (uint32_t)kBoolStep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (li[0] < ngroups) {   // slot 0 holds the oldest group; younger slots past the end re-apply the last group
 #pragma unroll
             for (int u = 0; u < U; u += kBoolStep) {
                 // Per entry: bit index = base + offset, one LDS word read, bit test; hits OR the row's bit into the
@@ -115,9 +124,12 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                         const uint32_t r = (v[k] >> 5) & kRowPad;
                         atomicOr(&tile[r >> 5], 1u << (r & 31u));
                     }
+                const uint32_t t = __builtin_amdgcn_readfirstlane(drawn);
+                if (a.tickets && lane == 0) drawn = __hip_atomic_fetch_add(&next_group[sp], (uint32_t)kBoolStep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
                 for (int k = 0; k < kBoolStep; k++) {
-                    const uint32_t gn = min(g + (u + k) * kWaves + kWaves * U, glast);
+                    li[u + k] = a.tickets ? t + k : li[u + k] + kWaves * U;
+                    const uint32_t gn = min(s.y + li[u + k], glast);
                     e[u + k] = load_stream_nt(a.entries + (size_t)gn * 64u + lane);
                     b[u + k] = load_const(a.bases + gn);
                 }
@@ -177,6 +189,11 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     }
 }
 
+static uint32_t bool_tickets() {
+    static const uint32_t t = env_long("GRAPHLILY_SPMV_TICKETS", 1) != 0;
+    return t;
+}
+
 constexpr int kBoolUnroll = 6;
 constexpr size_t kBoolLds = ((size_t)kBoolPhaseWords + kBoolTileWords) * 4u;
 
@@ -225,6 +242,7 @@ int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_o
     a.bits_out = bits_out;
     a.dist = d_distance;
     a.level = level;
+    a.tickets = bool_tickets();
     return launch_bool_variant<GL_NOMASK, 1>(p, a, s);
 }
 
@@ -260,6 +278,7 @@ int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const 
     a.bits_out = nullptr;
     a.dist = nullptr;
     a.level = 0.0f;
+    a.tickets = bool_tickets();
     switch (mask_type) {
         case GL_NOMASK: return launch_bool<GL_NOMASK>(p, a, s);
         case GL_MASK_WRITETOZERO: return launch_bool<GL_MASK_WRITETOZERO>(p, a, s);
@@ -298,6 +317,7 @@ int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hip
     a.bits_out = nullptr;
     a.dist = nullptr;
     a.level = 0.0f;
+    a.tickets = bool_tickets();
     return launch_bool<GL_NOMASK>(p, a, s);
 }
 

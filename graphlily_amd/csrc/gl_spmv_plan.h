@@ -20,6 +20,7 @@ constexpr uint32_t kColOffBits = 32 - kRowBits;        // 18
 constexpr uint32_t kHubSlots = 16;                     // private accumulators per hub row
 constexpr uint32_t kMaxHubRows = 64;                   // per row block
 constexpr uint32_t kMaxPlainRows = kMaxBlockRows - kHubSlots * kMaxHubRows;
+constexpr uint32_t kBoolMaxPhases = 8;                 // wider matrices keep the general layout
 constexpr uint32_t kLdsBudget = 160u * 1024u - 512u;   // per-CU LDS minus a little slack
 constexpr uint32_t kThreads = 1024;                    // one workgroup per CU: 16 wavefronts share the tile
 constexpr uint32_t kWaves = kThreads / 64;
