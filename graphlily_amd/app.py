@@ -303,8 +303,12 @@ class BFS(_GraphApp):
     def _push_iteration(self, frontier, local, it):
         """SpMSpV on the shard, mark the newly reached vertices, publish the next frontier.  Returns
         (frontier size, frontier buffer, result buffer) for the next iteration."""
-        self.SpMSpV_.run()
-        self.SparseAssign_.run(float(it + 1))
+        # SpMSpV, then distance[new] = level (app/bfs.h:146-148); the assign rides on the pass that writes the results
+        if hasattr(self.SpMSpV_, "run_assign") and os.environ.get("GRAPHLILY_BFS_FUSED_PUSH", "1") != "0":
+            self.SpMSpV_.run_assign(self.SparseAssign_.inout_buf, float(it + 1))
+        else:
+            self.SpMSpV_.run()
+            self.SparseAssign_.run(float(it + 1))
         if self.comm.distributed:
             total = self._gather_sparse(local, frontier, self.n_, self.semiring_.zero)
             self._hint_frontier(total)

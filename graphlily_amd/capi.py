@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgraphlily_hip.so")
+# GRAPHLILY_HIP_LIB: another build of the same library (same-box A/B runs of kernel changes, scripts/ab_variants.sh)
+LIB_PATH = os.environ.get("GRAPHLILY_HIP_LIB") or os.path.join(_HERE, "lib", "libgraphlily_hip.so")
 
 # graphlily/global.h:83-87, :103-107
 GL_OP_MULADD, GL_OP_ANDOR, GL_OP_ADDMIN = 0, 1, 2
@@ -34,7 +35,7 @@ EXPORTS = [
     "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_run",
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits", "gl_bfs_pull_step",
     "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every",
-    "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run",
+    "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run", "gl_spmspv_run_assign",
     "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_last_direction",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
     "gl_assign_sparse_new_frontier", "gl_sparse_to_dense",
@@ -88,6 +89,7 @@ def lib():
         "gl_spmspv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmspv_plan_destroy": [vp], "gl_spmspv_plan_info": [vp, P(u64), P(u64)],
         "gl_spmspv_run": [vp, vp, vp, vp, i32, f32, i32],
+        "gl_spmspv_run_assign": [vp, vp, vp, vp, i32, f32, i32, vp, f32],
         "gl_spmspv_plan_attach_pull": [vp, vp], "gl_spmspv_plan_hint": [vp, u32], "gl_spmspv_last_direction": [vp, P(i32)],
         "gl_sparse_nnz": [vp, P(u32)],
         "gl_ewise_add": [vp, vp, u32, f32], "gl_assign_dense": [vp, vp, u32, f32, i32],
@@ -98,6 +100,8 @@ def lib():
         "gl_npz_csr_read": [vp, vp, vp, vp], "gl_npz_csr_close": [vp],
     }
     for name, argtypes in sigs.items():
+        if os.environ.get("GRAPHLILY_HIP_LIB") and not hasattr(L, name):
+            continue   # an older build in an A/B run: entry points added since stay unbound
         fn = getattr(L, name)
         fn.argtypes = argtypes
         fn.restype = i32
@@ -344,6 +348,11 @@ class SpMSpVPlan:
     def run(self, vector, mask, result, op, zero, mask_type):
         check(lib().gl_spmspv_run(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op),
                                   float(zero), int(mask_type)))
+
+    def run_assign(self, vector, mask, result, op, zero, mask_type, inout, val):
+        """gl_spmspv_run_assign: run + gl_assign_sparse(result, inout, val) in the result-writing pass."""
+        check(lib().gl_spmspv_run_assign(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op),
+                                         float(zero), int(mask_type), _p(inout), float(val)))
 
     def destroy(self):
         if getattr(self, "handle", None):

@@ -19,6 +19,9 @@ int scratch_reserve(size_t bytes, void **d_ptr) {
         g_scratch_bytes = 0;
         size_t want = bytes < (1u << 16) ? (1u << 16) : bytes;
         GL_HIP(hipMalloc(&g_scratch, want));
+        // word 0 is the compaction's ticket (gl_compact.h); on the launch stream: the library's own stream does not
+        // synchronise with the null stream a plain hipMemset runs on
+        GL_HIP(hipMemsetAsync(g_scratch, 0, sizeof(uint32_t), ctx().stream));
         g_scratch_bytes = want;
     }
     *d_ptr = g_scratch;
@@ -84,6 +87,7 @@ struct RelaxSource {
         gl_idx_val m = mask[1u + i];
         if (inout[m.index] > m.val) inout[m.index] = m.val;
     }
+    __device__ void emitted(const gl_idx_val &) const {}
 };
 
 // graphlily/global.h:153-164

@@ -4,13 +4,16 @@
 // The reference emits its sparse outputs in an unspecified, lane-round-robin
 // order (hw/kernel_spmspv_impl.h:253-286).  This build emits them in candidate
 // order (ascending row for SpMSpV, mask order for the assign), so results are
-// reproducible run to run.  Three small launches: per-block counts, one-block
-// scan of the counts (+ head element), ordered write.
+// reproducible run to run.  Per-block counts, a scan of the counts (+ head element;
+// done by the last counting block for short lists, by a one-block launch for long
+// ones), ordered write.
 //
 // A "source" functor provides:
 //   __device__ uint32_t size() const;                       // number of candidates
 //   __device__ bool     get(uint32_t i, gl_idx_val &out);   // candidate i kept? payload
 //   __device__ void     consumed(uint32_t i);               // called once per candidate in the write pass
+//   __device__ void     emitted(const gl_idx_val &item);    // called once per kept candidate in the write pass
+// d_counts: cdiv(max_items, kCompactChunk) + 1 words, word 0 (the ticket) zero before the first run.
 #ifndef GL_COMPACT_H_
 #define GL_COMPACT_H_
 
@@ -21,6 +24,7 @@ namespace gl {
 constexpr uint32_t kCompactThreads = 256;
 constexpr uint32_t kCompactItems = 4;
 constexpr uint32_t kCompactChunk = kCompactThreads * kCompactItems;
+constexpr uint32_t kCompactFuseBlocks = 128;   // lists up to 128 K candidates scan their counts in the counting launch
 
 // exclusive prefix of `flag` over the 256 threads of a block, in thread order; total in *block_total
 __device__ __forceinline__ uint32_t block_rank_256(bool flag, uint32_t *lds4, uint32_t *block_total) {
@@ -41,9 +45,17 @@ __device__ __forceinline__ uint32_t block_rank_256(bool flag, uint32_t *lds4, ui
     return before + in_wave;
 }
 
+// Pass 1: per-block counts into counts[1 + block].  With `fused`, the block that finishes last (ticket in counts[0],
+// zero between runs) turns them into exclusive offsets in place and writes the head element out[0] = {total,
+// head_val}: one launch less (~30 us per BFS push iteration on googleplus).  Only for short lists: every block ends
+// with an atomic on the same word, and thousands of them (3 M rows = 3000 blocks) cost more than the launch saved
+// (orkut BFS pull-push 1.15 -> 1.30 ms when this was unconditional).
 template <typename Src>
-__global__ __launch_bounds__(256) void compact_count_kernel(Src src, uint32_t *__restrict__ counts) {
+__global__ __launch_bounds__(256) void compact_count_kernel(Src src, uint32_t *__restrict__ counts, gl_idx_val *__restrict__ out,
+                                                            float head_val, uint32_t *__restrict__ reset_word, bool fused) {
     __shared__ uint32_t lds4[4];
+    __shared__ uint32_t carry_s;
+    __shared__ bool last_s;
     const uint32_t n = src.size();
     const uint32_t base = blockIdx.x * kCompactChunk;
     uint32_t c = 0;
@@ -59,21 +71,58 @@ __global__ __launch_bounds__(256) void compact_count_kernel(Src src, uint32_t *_
     for (int dlt = 32; dlt >= 1; dlt >>= 1) c += __shfl_down(c, dlt);
     if ((threadIdx.x & 63u) == 0) lds4[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    if (!fused) {
+        if (threadIdx.x == 0) counts[1u + blockIdx.x] = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+        return;
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&counts[1u + blockIdx.x], lds4[0] + lds4[1] + lds4[2] + lds4[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last_s = atomicAdd(&counts[0], 1u) == gridDim.x - 1u;   // no block waits for another: the last one does the scan
+        carry_s = 0;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    const uint32_t nblocks = gridDim.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += kCompactThreads) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? __hip_atomic_load(&counts[1u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
+            uint32_t up = __shfl_up(incl, dlt);
+            if (lane >= dlt) incl += up;
+        }
+        if (lane == 63) lds4[w] = incl;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (uint32_t k = 0; k < w; k++) before += lds4[k];
+        if (i < nblocks) counts[1u + i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == kCompactThreads - 1u) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0].index = carry_s;
+        out[0].val = head_val;
+        counts[0] = 0u;                     // ticket ready for the next run
+        if (reset_word) *reset_word = 0u;   // e.g. the SpMSpV chunk-queue counter, ready for the next run
+    }
 }
 
-// single block: counts[] -> exclusive offsets in place; out[0] = {total, head_val}
+// long lists: counts[1..nblocks] -> exclusive offsets in place, one block; out[0] = {total, head_val}
 static __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__restrict__ counts, uint32_t nblocks,
-                                                            gl_idx_val *__restrict__ out, float head_val,
-                                                            uint32_t *__restrict__ reset_word) {
+                                                                   gl_idx_val *__restrict__ out, float head_val,
+                                                                   uint32_t *__restrict__ reset_word) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     for (uint32_t base = 0; base < nblocks; base += 1024u) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = (i < nblocks) ? counts[i] : 0u;
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? counts[1u + i] : 0u;
         uint32_t incl = v;
 #pragma unroll
         for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
@@ -84,7 +133,7 @@ static __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__r
         __syncthreads();
         uint32_t before = carry_s;
         for (uint32_t k = 0; k < w; k++) before += wave_tot[k];
-        if (i < nblocks) counts[i] = before + incl - v;
+        if (i < nblocks) counts[1u + i] = before + incl - v;
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = before + incl;
         __syncthreads();
@@ -92,7 +141,7 @@ static __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__r
     if (threadIdx.x == 0) {
         out[0].index = carry_s;
         out[0].val = head_val;
-        if (reset_word) *reset_word = 0u;   // e.g. the SpMSpV chunk-queue counter, ready for the next run
+        if (reset_word) *reset_word = 0u;
     }
 }
 
@@ -103,7 +152,7 @@ __global__ __launch_bounds__(256) void compact_write_kernel(Src src, const uint3
     const uint32_t n = src.size();
     const uint32_t base = blockIdx.x * kCompactChunk;
     if (base >= n) return;
-    uint32_t pos = offsets[blockIdx.x];
+    uint32_t pos = offsets[1u + blockIdx.x];
 #pragma unroll
     for (uint32_t j = 0; j < kCompactItems; j++) {
         uint32_t i = base + j * kCompactThreads + threadIdx.x;
@@ -115,21 +164,27 @@ __global__ __launch_bounds__(256) void compact_write_kernel(Src src, const uint3
         }
         uint32_t total;
         uint32_t rank = block_rank_256(keep, lds4, &total);
-        if (keep) out[1u + pos + rank] = item;
+        if (keep) {
+            out[1u + pos + rank] = item;
+            src.emitted(item);
+        }
         pos += total;
     }
 }
 
-// Runs the three phases for at most `max_items` candidates (host-side bound for the grid).
+// Runs the passes for at most `max_items` candidates (host-side bound for the grid).
 template <typename Src>
 static int run_compaction(Src src, uint32_t max_items, uint32_t *d_counts, gl_idx_val *d_out, float head_val,
                           hipStream_t s, uint32_t *d_reset_word = nullptr) {
     uint32_t nblocks = cdiv(max_items, kCompactChunk);
     if (nblocks == 0) nblocks = 1;
-    compact_count_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts);
+    const bool fused = nblocks <= kCompactFuseBlocks;
+    compact_count_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out, head_val, d_reset_word, fused);
     GL_LAUNCH_CHECK();
-    compact_scan_kernel<<<1, 1024, 0, s>>>(d_counts, nblocks, d_out, head_val, d_reset_word);
-    GL_LAUNCH_CHECK();
+    if (!fused) {
+        compact_scan_kernel<<<1, 1024, 0, s>>>(d_counts, nblocks, d_out, head_val, d_reset_word);
+        GL_LAUNCH_CHECK();
+    }
     compact_write_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out);
     GL_LAUNCH_CHECK();
     return GL_OK;

@@ -275,6 +275,8 @@ struct AccSource {
     uint32_t nrows;      // rows in the shard
     uint32_t row_begin;
     float zero;
+    float *assign;       // gl_spmspv_run_assign: assign[index] = assign_val for every emitted entry (or null)
+    float assign_val;
     __device__ uint32_t size() const { return nrows; }
     __device__ bool get(uint32_t i, gl_idx_val &out) const {
         float v = acc[i];
@@ -289,6 +291,10 @@ struct AccSource {
     }
     __device__ void consumed(uint32_t i) const {
         if (acc[i] != zero) acc[i] = zero;
+    }
+    // the entry's own row: no other thread reads or writes assign[item.index] in this pass
+    __device__ void emitted(const gl_idx_val &item) const {
+        if (assign) assign[item.index] = assign_val;
     }
 };
 
@@ -355,6 +361,7 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     if ((e = hipMalloc((void **)&p->d_stream, b_stream ? b_stream : 16)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_acc, b_acc)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_counts, b_counts)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(p->d_counts, 0, sizeof(uint32_t))) != hipSuccess) return fail(e);   // the compaction's ticket word
     if ((e = hipMalloc((void **)&p->d_queue, b_queue)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_queue_count, 16)) != hipSuccess) return fail(e);
     if ((e = hipMemset(p->d_queue_count, 0, 16)) != hipSuccess) return fail(e);
@@ -362,6 +369,7 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     if ((e = hipMemset(p->d_mode, 0, 16)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(p->d_indptr, indptr.data(), b_indptr, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if (b_stream && (e = hipMemcpy(p->d_stream, stream.data(), b_stream, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e);   // the memsets above ran on the null stream
     p->device_bytes = b_indptr + b_stream + b_acc + b_counts + b_queue;
     *plan = p;
     return GL_OK;
@@ -390,6 +398,11 @@ int gl_spmspv_plan_info(gl_spmspv_plan p, uint64_t *nnz, uint64_t *device_bytes)
 
 int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
                   int op, float zero, int mask_type) {
+    return gl_spmspv_run_assign(p, d_vector, d_mask, d_result, op, zero, mask_type, nullptr, 0.0f);
+}
+
+int gl_spmspv_run_assign(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
+                         int op, float zero, int mask_type, float *d_inout, float val) {
     GL_REQUIRE_INIT();
     GL_ARG(p != nullptr && d_vector != nullptr && d_result != nullptr);
     GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
@@ -478,15 +491,15 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
 
     switch (mask_type) {
         case GL_NOMASK: {
-            gl::AccSource<GL_NOMASK> src{p->d_acc, d_mask, nrows, p->row_begin, zero};
+            gl::AccSource<GL_NOMASK> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val};
             return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count);
         }
         case GL_MASK_WRITETOZERO: {
-            gl::AccSource<GL_MASK_WRITETOZERO> src{p->d_acc, d_mask, nrows, p->row_begin, zero};
+            gl::AccSource<GL_MASK_WRITETOZERO> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val};
             return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count);
         }
         default: {
-            gl::AccSource<GL_MASK_WRITETOONE> src{p->d_acc, d_mask, nrows, p->row_begin, zero};
+            gl::AccSource<GL_MASK_WRITETOONE> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val};
             return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count);
         }
     }

@@ -335,6 +335,14 @@ class SpMSpVModule(BaseModule):
                        self.mask_type_)
         self._finish()
 
+    def run_assign(self, inout_buf, val):
+        """Extension (gl_spmspv_run_assign): run() followed by AssignVectorSparseModule.run(val) with the results as
+        its mask and `inout_buf` as its inout -- BFS's push iteration (app/bfs.h:146-148) -- in one call."""
+        mask = self.mask_buf if self.mask_type_ != kNoMask else None
+        self.plan_.run_assign(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
+                              self.mask_type_, inout_buf, val)
+        self._finish()
+
     def get_results_nnz(self):
         return capi.sparse_nnz(self.results_buf)
 

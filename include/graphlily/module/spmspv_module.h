@@ -103,6 +103,15 @@ public:
                                       (gl_idx_val *)results_buf.ptr(), (int)semiring_.op, semiring_.zero, (int)mask_type_));
         finish_();
     }
+    // extension (gl_spmspv_run_assign): run() + AssignVectorSparseModule::run(val) with the results as its mask and
+    // `inout` as its inout (the push iteration of app/bfs.h:146-148) in one call
+    void run_assign(DeviceBuffer inout, float val) {
+        GRAPHLILY_CHECK(gl_spmspv_run_assign(plan_, (const gl_idx_val *)vector_buf.ptr(),
+                                             mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
+                                             (gl_idx_val *)results_buf.ptr(), (int)semiring_.op, semiring_.zero,
+                                             (int)mask_type_, (float *)inout.ptr(), val));
+        finish_();
+    }
 
     aligned_sparse_vec_t send_vector_device_to_host() {
         vector_buf.download(vector_.data(), sizeof(idx_val_t) * vector_.size());

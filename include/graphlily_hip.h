@@ -188,6 +188,13 @@ int gl_spmspv_plan_info(gl_spmspv_plan plan, uint64_t *nnz, uint64_t *device_byt
  * at FLOAT_INF = 999999999 (hw/float_pe.h:24-33). */
 int gl_spmspv_run(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask,
                   gl_idx_val *d_result, int op, float zero, int mask_type);
+/* Extension: gl_spmspv_run followed by gl_assign_sparse(d_result, d_inout, val) -- the push iteration of BFS
+ * (app/bfs.h:146-148: SpMSpV, then AssignVectorSparse::run(val) with the result as its mask) -- with the assign
+ * done by the pass that writes the result list (one launch and one read of the list less).  d_inout may be the
+ * vector d_mask points to (BFS masks with the distances it assigns): an entry's mask word is read before its
+ * own row is written and no other entry touches it.  d_inout == NULL is gl_spmspv_run. */
+int gl_spmspv_run_assign(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask,
+                         gl_idx_val *d_result, int op, float zero, int mask_type, float *d_inout, float val);
 
 /* Extension: direction switch inside the operator.  `pull` is an SpMV plan over the same matrix and row shard
  * (BFS holds both, app/bfs.h:83-99).  A run with zero == 0 whose frontier columns hold more than 1/32 of the

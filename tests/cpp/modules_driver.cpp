@@ -140,6 +140,19 @@ int main() {
                 snprintf(name, sizeof name, "SpMSpV %s %s", sem_names[s], mask_names[k]);
                 verify(sp.compute_reference_results(vf, mask), got, name, s != 0);
             }
+        {   // extension: run_assign == run + AssignVectorSparse::run(val), with the mask as the assigned vector (BFS)
+            sp.set_semiring(LogicalSemiring);
+            sp.set_mask_type(kMaskWriteToZero);
+            sp.send_mask_host_to_device(mask);
+            sp.run_assign(sp.mask_buf, 9.0f);
+            fvec y = sp.compute_reference_results(vf, mask), want = mask;
+            for (size_t i = 0; i < want.size(); i++)
+                if (y[i] != 0) want[i] = 9.0f;
+            verify(want, sp.send_mask_device_to_host(), "SpMSpV run_assign: assigned vector", true);
+            aligned_sparse_vec_t res = sp.send_results_device_to_host();
+            fvec got = convert_sparse_vec_to_dense_vec<aligned_sparse_vec_t, fvec, float>(res, csc.num_rows, 0.0f);
+            verify(y, got, "SpMSpV run_assign: results", true);
+        }
     }
     {   // apply modules
         const uint32_t len = 128 * 100;

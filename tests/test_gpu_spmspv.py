@@ -279,3 +279,45 @@ def test_tropical_direction_switch(gpu, sem):
                 got = M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), csc.num_rows, zero)
                 ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS[mk])
                 assert_parity(got, ref, op, "tropical direction %s %s %s %s" % (sem, layout, expect, mk))
+
+
+@pytest.mark.parametrize("sparsity", [0.5, 0.999])
+def test_run_assign_equals_run_then_assign(gpu, sparsity):
+    """gl_spmspv_run_assign = SpMSpV + AssignVectorSparse::run(val) (app/bfs.h:146-148), with the BFS aliasing:
+    the mask IS the distance vector the assign writes."""
+    csr = named_matrix("gplus_small")
+    csc = io.csr2csc(csr)
+    csc.adj_data = np.ones(csc.nnz, dtype=np.float32)
+    n = csc.num_rows
+    v = _strided_vector(csc.num_cols, sparsity, 3)
+    dist0 = (np.random.default_rng(5).random(n) < 0.4).astype(np.float32) * 2.0   # 0 = unvisited
+    outs = []
+    for fused in (False, True):
+        mod = M.SpMSpVModule(512)
+        mod.set_semiring(M.LogicalSemiring)
+        mod.set_mask_type(M.kMaskWriteToZero)
+        mod.set_up_runtime()
+        mod.load_and_format_matrix(csc)
+        mod.send_matrix_host_to_device()
+        mod.send_mask_host_to_device(dist0.copy())
+        mod.send_vector_host_to_device(v)
+        if fused:
+            mod.run_assign(mod.mask_buf, 7.0)
+        else:
+            mod.run()
+            asg = M.AssignVectorSparseModule(False)
+            asg.set_up_runtime()
+            asg.bind_mask_buf(mod.results_buf)
+            asg.bind_inout_buf(mod.mask_buf)
+            asg.run(7.0)
+        res = mod.send_results_device_to_host()
+        nnz = mod.get_results_nnz()
+        outs.append((res[:nnz + 1].copy(), mod.send_mask_device_to_host()[:n].copy()))
+    (r0, d0), (r1, d1) = outs
+    assert r0.tobytes() == r1.tobytes()
+    assert np.array_equal(d0, d1)
+    ref = O.spmspv(to_oracle(csc), v, 1, 0.0, dist0, M.kMaskWriteToZero)
+    want = dist0.copy()
+    want[ref != 0] = 7.0
+    assert np.array_equal(d1, want)
+    assert int(r1["index"][0]) == int((ref != 0).sum())
