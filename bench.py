@@ -21,6 +21,7 @@ Extra objects on the same JSON line:
   cpu_baseline  the oracle's single-thread restatement of SpMVModule::compute_reference_results timed
                 on this host (rank 0, N = 1 only), same byte formula.
   bfs           BFS pull_push on the same graph (bench_bfs.cpp:68-89 definition: nnz * iters / t).
+  host_buffers  the SpMV step with x uploaded and y downloaded over PCIe inside it (the module API's host vectors).
 """
 import argparse
 import json
@@ -190,6 +191,34 @@ def main():
             out["pattern_plan"] = _bench_pattern(capi, csr, r0, r1, bx, by, y, yh, args, fence, world, comm, bounds, dist, dev)
         except Exception as e:
             out["pattern_plan"] = {"error": repr(e)}
+
+    # ------------------------------------------------------------------ the same step with host buffers at the boundary
+    # (SpMVModule::send_vector_host_to_device + run + send_results_device_to_host, module/spmv_module.h:422-475):
+    # x uploaded and y downloaded over PCIe every step.  Reported beside the headline, never as `value`.
+    if world == 1:
+        try:
+            reps = max(3, min(20, args.steps))
+            hb = {"pcie_bytes_per_step": 4 * (n_cols + n_rows), "steps": reps,
+                  "note": "x host->device and y device->host inside every step"}
+            for kind in ("pageable", "pinned"):
+                if kind == "pinned":
+                    xh, yh2 = capi.pinned_empty(n_cols, np.float32), capi.pinned_empty(n_rows, np.float32)
+                    xh[:] = x.cpu().numpy()
+                else:
+                    xh, yh2 = x.cpu().numpy(), np.empty(n_rows, dtype=np.float32)
+                for i in range(2 + reps):
+                    if i == 2:
+                        fence()
+                        t0 = time.perf_counter()
+                    bx.write(xh)
+                    plan.run(bx, None, by, capi.GL_OP_MULADD, 0.0, capi.GL_NOMASK)
+                    by.read(np.float32, n_rows, out=yh2)
+                fence()
+                t = (time.perf_counter() - t0) / reps
+                hb[kind] = {"ms_per_step": round(t * 1e3, 4), "value": round(alg_bytes / t / 1e9, 1), "unit": "GB/s"}
+            out["host_buffers"] = hb
+        except Exception as e:
+            out["host_buffers"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ BFS GTEPS (same graph)
     if not args.no_bfs:
