@@ -54,7 +54,8 @@ struct SpmvArgs {
     const float *mask;
     float *y;
     float zero;
-    const float *z;           // pattern plans: colval (x) x, written by spmv_prescale_kernel
+    const float *xg;          // general plans: what the cold entries gather from (x, or the plan's packed copy of it)
+    const float *z;           // pattern plans: colval (x) x (packed like xg), written by spmv_prescale_kernel
     const float *diag;        // pattern plans with diagonal exceptions: A[r][r] per local row, folded in by the epilogue
     const uint32_t *diag_has; // bit per local row: the row has a diagonal entry that differs from its column's value
     const uint32_t *run_flag;    // non-null: the launch is a no-op unless run_flag[0] != 0 (gl_spmspv_run's direction switch)
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     // (stream read + global gather for cold, stream read + LDS lookup for hot).  Wavefronts draw slot numbers from an LDS
     // ticket: with a static split the hardware's oldest-first issue lets the low wavefronts finish ~10 % early and the
     // CU idles its memory pipe while the rest catch up.  Rounds past the end of the shorter stream touch only the other.
-    const float *xsrc = LY::kValues ? a.x : a.z;
+    const float *xsrc = LY::kValues ? a.xg : a.z;
     StreamGeom sg;
     sg.g0 = g0;
     sg.c0 = g0 / G, sg.nc = ncold / G, sg.h0 = (g0 + ncold) / G, sg.nh = nhotg / G;
@@ -366,27 +367,29 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     clock_stamp(a, 4);
 }
 
-// z = colval (x) x for every column, and the hot table from the same products
+// z[j] = colval (x) x of gathered column j (all columns, or the packed ones), and the hot table from the same products
 template <int OP>
-__global__ __launch_bounds__(256) void spmv_prescale_kernel(const float *__restrict__ x, const float *__restrict__ colval,
-                                                            float *__restrict__ z, uint32_t num_cols,
-                                                            const uint32_t *__restrict__ hot_cols, float *__restrict__ hot_x,
-                                                            uint32_t nhot, const uint32_t *__restrict__ run_flag) {
+__global__ __launch_bounds__(256) void spmv_prescale_kernel(const float *__restrict__ x, const uint32_t *__restrict__ zcols,
+                                                            const float *__restrict__ zcolval, float *__restrict__ z, uint32_t nz,
+                                                            const uint32_t *__restrict__ hot_cols, const float *__restrict__ hot_colval,
+                                                            float *__restrict__ hot_x, uint32_t nhot,
+                                                            const uint32_t *__restrict__ run_flag) {
     if (run_flag && *run_flag == 0u) return;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < num_cols) z[i] = Semiring<OP>::mul(colval[i], x[i]);
-    if (i < nhot) {
-        const uint32_t c = hot_cols[i];
-        hot_x[i] = Semiring<OP>::mul(colval[c], x[c]);
-    }
+    if (i < nz) z[i] = Semiring<OP>::mul(zcolval[i], x[zcols ? zcols[i] : i]);
+    if (i < nhot) hot_x[i] = Semiring<OP>::mul(hot_colval[i], x[hot_cols[i]]);
 }
 
-// the one scattered read of the hot columns per run; the workgroups then copy the compact table
+// the one scattered read of the hot columns per run (the workgroups then copy the compact table), and the packed copy
+// of the gathered columns if the plan has one
 __global__ __launch_bounds__(256) void spmv_hot_gather_kernel(const float *__restrict__ x, const uint32_t *__restrict__ hot_cols,
-                                                              float *__restrict__ hot_x, uint32_t nhot, const uint32_t *__restrict__ run_flag) {
+                                                              float *__restrict__ hot_x, uint32_t nhot,
+                                                              const uint32_t *__restrict__ ccols, float *__restrict__ xc, uint32_t ncompact,
+                                                              const uint32_t *__restrict__ run_flag) {
     if (run_flag && *run_flag == 0u) return;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < nhot) hot_x[i] = x[hot_cols[i]];
+    if (i < ncompact) xc[i] = x[ccols[i]];
 }
 
 // y initialisation for the rows of blocks that are split into several units
@@ -465,11 +468,13 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
         return GL_OK;
     }
     if (p->pattern) {
-        spmv_prescale_kernel<OP><<<cdiv(std::max(p->num_cols, p->nhot), 256), 256, 0, s>>>(a.x, p->d_colval, p->d_z, p->num_cols,
-                                                                                            p->d_hot_cols, p->d_hot_x, p->nhot, a.run_flag);
+        const uint32_t nz = p->ncompact ? p->ncompact : p->num_cols;
+        spmv_prescale_kernel<OP><<<cdiv(std::max(nz, p->nhot), 256), 256, 0, s>>>(a.x, p->ncompact ? p->d_ccols : nullptr, p->d_colval, p->d_z, nz,
+                                                                               p->d_hot_cols, p->d_hot_colval, p->d_hot_x, p->nhot, a.run_flag);
         GL_LAUNCH_CHECK();
-    } else if (p->nhot) {
-        spmv_hot_gather_kernel<<<cdiv(p->nhot, 256), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot, a.run_flag);
+    } else if (p->nhot || p->ncompact) {
+        spmv_hot_gather_kernel<<<cdiv(std::max(p->nhot, p->ncompact), 256), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot, p->d_ccols,
+                                                                                        p->d_xc, p->ncompact, a.run_flag);
         GL_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(typename Tile<OP>::T);
@@ -737,6 +742,13 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     // ---- hot columns: the H highest-degree columns of the shard get an LDS-resident copy of x.
     //      H = what fits next to the tallest f64 tile (incl. worst-case hub slots).
     std::vector<uint32_t> hot_cols, hot_slot;   // slot -> column, column -> slot (0xffffffff = cold)
+    std::vector<uint32_t> deg;                  // non-zeros per column within the shard
+    if (nnz > 0) {
+        deg.assign(num_cols, 0);
+        // sequential on purpose: atomics from all cores pile up on the hub columns' counters (measured slower)
+        for (uint64_t i = nz0; i < nz1; i++)
+            if (h_indices[i] < num_cols) deg[h_indices[i]]++;   // out-of-range columns are reported below
+    }
     if (nnz > 0 && gl::env_long("GRAPHLILY_SPMV_HOT", 1) != 0) {
         // 8-byte accumulators unless the caller promised to run only the 4-byte-tile semirings
         const size_t elem = (flags & (GL_PLAN_NO_MULADD | GL_PLAN_BOOLEAN)) ? sizeof(float) : sizeof(double);
@@ -748,10 +760,6 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         const long forced = gl::env_long("GRAPHLILY_SPMV_HOT", 1);
         if (forced > 1) H = std::min<uint32_t>(H, (uint32_t)forced);
         if (H) {
-            std::vector<uint32_t> deg(num_cols, 0);
-            // sequential on purpose: atomics from all cores pile up on the hub columns' counters (measured slower)
-            for (uint64_t i = nz0; i < nz1; i++)
-                if (h_indices[i] < num_cols) deg[h_indices[i]]++;   // out-of-range columns are reported below
             const uint32_t dmax = num_cols ? *std::max_element(deg.begin(), deg.end()) : 0u;
             std::vector<uint32_t> hist((size_t)dmax + 2, 0);
             for (uint32_t c = 0; c < num_cols; c++) hist[deg[c]]++;
@@ -776,6 +784,48 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         }
     }
     const bool have_hot = !hot_cols.empty();
+    // ---- packed gather vector.  Gathers cost per distinct 128-byte line a wavefront instruction touches (~2 clocks),
+    //      and a row block's sweep touches every line of x that holds one of its cold columns -- with arbitrary vertex
+    //      labels, all of them.  So the cold entries index a packed copy of x instead (general plans: xc[j] =
+    //      x[ccols[j]], filled by the per-run helper kernel; pattern plans: z is simply built in that order) which
+    //        - drops the columns that are never gathered: no entry in this shard (isolated vertices; most low-degree
+    //          columns of a 1/8 row shard) or served from the hot table;
+    //        - orders the rest by degree class (>= nblocks/4, /16, /64, below; ascending column inside a class, so
+    //          the helper's reads stay nearly sequential): a line of 32 rare columns is then touched by few row
+    //          blocks instead of riding along with a popular neighbour in every one.
+    //      Lines touched per block sweep on the ogbn-products stand-in: 68.7 K (x) -> 48.5 K (packed) -> 29.2 K
+    //      (classes); a full sort by degree gives 28.5 K.
+    std::vector<uint32_t> ccols, cmap;
+    if (nnz > 0 && gl::env_long("GRAPHLILY_SPMV_COMPACT", 1) != 0) {
+        const uint32_t nb = bp.nblocks;
+        const bool by_class = bp.Smax == 1 && gl::env_long("GRAPHLILY_SPMV_COMPACT", 1) != 2;
+        const uint32_t edge[3] = {std::max(nb / 4u, 1u), std::max(nb / 16u, 1u), std::max(nb / 64u, 1u)};
+        auto cls = [&](uint32_t c) -> int {
+            if (deg[c] == 0 || (have_hot && hot_slot[c] != 0xffffffffu)) return -1;   // never gathered
+            // split blocks keep one class: their segments cut the stream by position, and a segment of rare columns
+            // only would touch several times the lines of its siblings (1/8 orkut shard: 0.061 -> 0.082 ms with classes)
+            if (!by_class) return 0;
+            return deg[c] >= edge[0] ? 0 : deg[c] >= edge[1] ? 1 : deg[c] >= edge[2] ? 2 : 3;
+        };
+        uint32_t start[5] = {0, 0, 0, 0, 0};
+        for (uint32_t c = 0; c < num_cols; c++) {
+            const int k = cls(c);
+            if (k >= 0) start[k + 1]++;
+        }
+        for (int k = 0; k < 4; k++) start[k + 1] += start[k];
+        const uint32_t gathered = start[4];
+        cmap.assign(num_cols, 0xffffffffu);
+        ccols.assign(std::max(gathered, 1u), 0u);   // (every entry hot: keep the arrays non-empty)
+        for (uint32_t c = 0; c < num_cols; c++) {
+            const int k = cls(c);
+            if (k >= 0) {
+                cmap[c] = start[k];
+                ccols[start[k]++] = c;
+            }
+        }
+    }
+    const bool compact = !ccols.empty();
+    const uint32_t gather_cols = compact ? (uint32_t)ccols.size() : num_cols;
     const std::vector<uint32_t> &bstart = bp.bstart, &seg = bp.seg;
     const std::vector<std::vector<uint32_t>> &unit_of = bp.unit_of;
     const uint32_t nblocks = bp.nblocks, nunits = bp.nunits, Smax = bp.Smax;
@@ -871,14 +921,14 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
                     const uint32_t v = __builtin_bit_cast(uint32_t, h_data[i]);
                     if (diag_mode && c == r && v != colbits[c]) continue;   // the row's diagonal exception lives in diag_val
                     if (have_hot && hot_slot[c] != 0xffffffffu) hot.push_back(gl::Rec{hot_slot[c], r - r0, v});
-                    else recs.push_back(gl::Rec{c, r - r0, v});
+                    else recs.push_back(gl::Rec{compact ? cmap[c] : c, r - r0, v});
                 }
             if (bad) {
 #pragma omp atomic write
                 bad_col = 1;
                 continue;
             }
-            gl::sort_by_col(recs, tmp, num_cols);
+            gl::sort_by_col(recs, tmp, gather_cols);
             gl::sort_by_col(hot, tmp, nhot_table ? nhot_table : 1u);   // by slot: neighbours share an LDS word
             hot_nnz += hot.size();
             const uint64_t mc = recs.size(), m = mc + hot.size();
@@ -1045,18 +1095,35 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         return rc;
     }
     if (pattern) {
-        std::vector<float> colval(num_cols);
-        memcpy(colval.data(), colbits.data(), (size_t)num_cols * 4u);
-        if ((rc = up((void **)&p->d_colval, colval.data(), (size_t)num_cols * 4u)) != GL_OK) {
+        std::vector<uint32_t> zval(gather_cols), hval(hot_cols.size());   // value bits of the gathered / hot columns
+        for (uint32_t j = 0; j < gather_cols; j++) zval[j] = colbits[compact ? ccols[j] : j];
+        for (size_t j = 0; j < hot_cols.size(); j++) hval[j] = colbits[hot_cols[j]];
+        if ((rc = up((void **)&p->d_colval, zval.data(), (size_t)gather_cols * 4u)) != GL_OK ||
+            (rc = up((void **)&p->d_hot_colval, hval.data(), hval.size() * 4u)) != GL_OK) {
             gl_spmv_plan_destroy(p);
             return rc;
         }
-        hipError_t he = hipMalloc((void **)&p->d_z, (size_t)std::max<uint32_t>(num_cols, 1u) * sizeof(float));
+        hipError_t he = hipMalloc((void **)&p->d_z, (size_t)std::max<uint32_t>(gather_cols, 1u) * sizeof(float));
         if (he != hipSuccess) {
             gl_spmv_plan_destroy(p);
             return gl::set_error(GL_ERR_HIP, "gl_spmv_plan_create: hipMalloc(z): %s", hipGetErrorString(he));
         }
-        p->device_bytes += (size_t)num_cols * sizeof(float);
+        p->device_bytes += (size_t)gather_cols * sizeof(float);
+    }
+    if (compact) {
+        p->ncompact = gather_cols;
+        if ((rc = up((void **)&p->d_ccols, ccols.data(), ccols.size() * sizeof(uint32_t))) != GL_OK) {
+            gl_spmv_plan_destroy(p);
+            return rc;
+        }
+        if (!pattern) {
+            hipError_t he = hipMalloc((void **)&p->d_xc, (size_t)gather_cols * sizeof(float));
+            if (he != hipSuccess) {
+                gl_spmv_plan_destroy(p);
+                return gl::set_error(GL_ERR_HIP, "gl_spmv_plan_create: hipMalloc(xc): %s", hipGetErrorString(he));
+            }
+            p->device_bytes += (size_t)gather_cols * sizeof(float);
+        }
     }
     if (diag_mode) {
         if ((rc = up((void **)&p->d_diag, diag_val.data(), diag_val.size() * sizeof(float))) != GL_OK ||
@@ -1098,6 +1165,9 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_spans);
     (void)hipFree(p->d_blocks);
     (void)hipFree(p->d_colval);
+    (void)hipFree(p->d_hot_colval);
+    (void)hipFree(p->d_ccols);
+    (void)hipFree(p->d_xc);
     (void)hipFree(p->d_diag);
     (void)hipFree(p->d_diag_has);
     (void)hipFree(p->d_z);
@@ -1206,6 +1276,7 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
     a.hot_x = p->d_hot_x;
     a.nhot = p->nhot;
     a.x = d_x;
+    a.xg = p->ncompact ? p->d_xc : d_x;
     a.mask = d_mask;
     a.y = d_y;
     a.zero = zero;

@@ -96,6 +96,13 @@ struct gl_spmv_plan_s {
     int mix = 0;               // cold/hot groups per iteration: 0 = (4,0) no hot table, 5 = (3,3) default; others for tuning
     uint32_t *d_hot_cols = nullptr;
     float *d_hot_x = nullptr;
+    float *d_hot_colval = nullptr;   // pattern plans: the hot columns' values
+    // compact gather vector: when a tenth or more of the columns are never gathered (no entry in this shard, or hot),
+    // the cold entries index a packed copy of x (pattern plans: of z) that a per-run kernel fills -- fewer lines
+    // per sweep of a row block
+    uint32_t ncompact = 0;           // 0: gather from x (z) directly
+    uint32_t *d_ccols = nullptr;     // packed index -> column, ascending
+    float *d_xc = nullptr;           // general plans: x[ccols[j]]
     bool wide = false;               // general layout with lane-interleaved group pairs (16-byte stream loads)
     bool pattern = false;            // every column's values are equal: 4-byte entries, z = colval (x) x per run
     float *d_colval = nullptr, *d_z = nullptr;
