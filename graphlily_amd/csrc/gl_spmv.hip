@@ -367,21 +367,35 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     clock_stamp(a, 4);
 }
 
-// z[j] = colval (x) x of gathered column j (all columns, or the packed ones), and the hot table from the same products
+// z[j] = colval (x) x of gathered column j (all columns, or the packed ones), four per thread, and the hot table from
+// the same products.  zcolval, zcols and z hold a multiple of four elements (the plan pads them).
 template <int OP>
 __global__ __launch_bounds__(256) void spmv_prescale_kernel(const float *__restrict__ x, const uint32_t *__restrict__ zcols,
                                                             const float *__restrict__ zcolval, float *__restrict__ z, uint32_t nz,
+                                                            uint32_t num_cols,
                                                             const uint32_t *__restrict__ hot_cols, const float *__restrict__ hot_colval,
                                                             float *__restrict__ hot_x, uint32_t nhot,
                                                             const uint32_t *__restrict__ run_flag) {
     if (run_flag && *run_flag == 0u) return;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < nz) z[i] = Semiring<OP>::mul(zcolval[i], x[zcols ? zcols[i] : i]);
+    if (4u * i < nz) {
+        const float4 v = reinterpret_cast<const float4 *>(zcolval)[i];
+        float4 xv;
+        if (zcols) {
+            const uint4 c = reinterpret_cast<const uint4 *>(zcols)[i];
+            xv = make_float4(x[c.x], x[c.y], x[c.z], x[c.w]);
+        } else {   // identity: x itself may end before the padded group of four does
+            const uint32_t c = 4u * i, last = num_cols - 1u;
+            xv = make_float4(x[c], x[min(c + 1u, last)], x[min(c + 2u, last)], x[min(c + 3u, last)]);
+        }
+        reinterpret_cast<float4 *>(z)[i] = make_float4(Semiring<OP>::mul(v.x, xv.x), Semiring<OP>::mul(v.y, xv.y),
+                                                       Semiring<OP>::mul(v.z, xv.z), Semiring<OP>::mul(v.w, xv.w));
+    }
     if (i < nhot) hot_x[i] = Semiring<OP>::mul(hot_colval[i], x[hot_cols[i]]);
 }
 
 // the one scattered read of the hot columns per run (the workgroups then copy the compact table), and the packed copy
-// of the gathered columns if the plan has one
+// of the gathered columns if the plan has one (four per thread; ccols and xc hold a multiple of four elements)
 __global__ __launch_bounds__(256) void spmv_hot_gather_kernel(const float *__restrict__ x, const uint32_t *__restrict__ hot_cols,
                                                               float *__restrict__ hot_x, uint32_t nhot,
                                                               const uint32_t *__restrict__ ccols, float *__restrict__ xc, uint32_t ncompact,
@@ -389,7 +403,10 @@ __global__ __launch_bounds__(256) void spmv_hot_gather_kernel(const float *__res
     if (run_flag && *run_flag == 0u) return;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < nhot) hot_x[i] = x[hot_cols[i]];
-    if (i < ncompact) xc[i] = x[ccols[i]];
+    if (4u * i < ncompact) {
+        const uint4 c = reinterpret_cast<const uint4 *>(ccols)[i];
+        reinterpret_cast<float4 *>(xc)[i] = make_float4(x[c.x], x[c.y], x[c.z], x[c.w]);
+    }
 }
 
 // y initialisation for the rows of blocks that are split into several units
@@ -469,12 +486,13 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     }
     if (p->pattern) {
         const uint32_t nz = p->ncompact ? p->ncompact : p->num_cols;
-        spmv_prescale_kernel<OP><<<cdiv(std::max(nz, p->nhot), 256), 256, 0, s>>>(a.x, p->ncompact ? p->d_ccols : nullptr, p->d_colval, p->d_z, nz,
-                                                                               p->d_hot_cols, p->d_hot_colval, p->d_hot_x, p->nhot, a.run_flag);
+        spmv_prescale_kernel<OP><<<cdiv(std::max(cdiv(nz, 4), p->nhot), 256), 256, 0, s>>>(a.x, p->ncompact ? p->d_ccols : nullptr, p->d_colval, p->d_z,
+                                                                                         nz, p->num_cols, p->d_hot_cols, p->d_hot_colval, p->d_hot_x,
+                                                                                         p->nhot, a.run_flag);
         GL_LAUNCH_CHECK();
     } else if (p->nhot || p->ncompact) {
-        spmv_hot_gather_kernel<<<cdiv(std::max(p->nhot, p->ncompact), 256), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot, p->d_ccols,
-                                                                                        p->d_xc, p->ncompact, a.run_flag);
+        spmv_hot_gather_kernel<<<cdiv(std::max(cdiv(p->ncompact, 4), p->nhot), 256), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot, p->d_ccols,
+                                                                                                p->d_xc, p->ncompact, a.run_flag);
         GL_LAUNCH_CHECK();
     }
     const size_t lds = (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(typename Tile<OP>::T);
@@ -1095,15 +1113,15 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         return rc;
     }
     if (pattern) {
-        std::vector<uint32_t> zval(gather_cols), hval(hot_cols.size());   // value bits of the gathered / hot columns
+        std::vector<uint32_t> zval(((size_t)gather_cols + 3) / 4 * 4, 0u), hval(hot_cols.size());   // value bits of the gathered / hot columns
         for (uint32_t j = 0; j < gather_cols; j++) zval[j] = colbits[compact ? ccols[j] : j];
         for (size_t j = 0; j < hot_cols.size(); j++) hval[j] = colbits[hot_cols[j]];
-        if ((rc = up((void **)&p->d_colval, zval.data(), (size_t)gather_cols * 4u)) != GL_OK ||
+        if ((rc = up((void **)&p->d_colval, zval.data(), zval.size() * 4u)) != GL_OK ||
             (rc = up((void **)&p->d_hot_colval, hval.data(), hval.size() * 4u)) != GL_OK) {
             gl_spmv_plan_destroy(p);
             return rc;
         }
-        hipError_t he = hipMalloc((void **)&p->d_z, (size_t)std::max<uint32_t>(gather_cols, 1u) * sizeof(float));
+        hipError_t he = hipMalloc((void **)&p->d_z, ((size_t)gather_cols + 4u) * sizeof(float));   // whole groups of four
         if (he != hipSuccess) {
             gl_spmv_plan_destroy(p);
             return gl::set_error(GL_ERR_HIP, "gl_spmv_plan_create: hipMalloc(z): %s", hipGetErrorString(he));
@@ -1112,12 +1130,13 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     }
     if (compact) {
         p->ncompact = gather_cols;
+        while (ccols.size() % 4u) ccols.push_back(ccols.back());   // the helper kernels move four at a time
         if ((rc = up((void **)&p->d_ccols, ccols.data(), ccols.size() * sizeof(uint32_t))) != GL_OK) {
             gl_spmv_plan_destroy(p);
             return rc;
         }
         if (!pattern) {
-            hipError_t he = hipMalloc((void **)&p->d_xc, (size_t)gather_cols * sizeof(float));
+            hipError_t he = hipMalloc((void **)&p->d_xc, ((size_t)gather_cols + 4u) * sizeof(float));
             if (he != hipSuccess) {
                 gl_spmv_plan_destroy(p);
                 return gl::set_error(GL_ERR_HIP, "gl_spmv_plan_create: hipMalloc(xc): %s", hipGetErrorString(he));
