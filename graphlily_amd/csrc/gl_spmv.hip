@@ -10,6 +10,9 @@
 //     64 lanes read NEIGHBOURING columns costs ~20 clocks, from L1 and L2 alike -- and that cost ADDS to the
 //     stream's: only fewer bytes per entry or fewer gather instructions (x values served from LDS) make
 //     the loop faster; unrolling, software pipelining and LDS window staging were measured and do not;
+//   * in the real stream a gather costs ~4 + 2.2 clocks per distinct 128-byte line it touches, and a row block's
+//     sweep touches every line of x that holds one of its columns -- so the cold entries index a PACKED copy of x
+//     (never-gathered columns dropped, rare ones clustered by degree class), refilled per run by a helper kernel;
 //   * LDS atomics on 4/8-byte integers and on f64 run at full rate, ds_add_f32 at a third of it.
 // This file holds the GENERAL layout (8-byte entries) and the PATTERN layout (4-byte entries for
 // column-constant matrices), both served by spmv_rbcs_kernel<OP, MASK, stream layout, UC, UH>; the
