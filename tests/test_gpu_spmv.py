@@ -378,3 +378,45 @@ def test_golden_known_answers(gpu, golden_dir):
         got = _run_spmv(gpu, m, "Arithmetic", "NoMask", (np.arange(m.num_cols) % 7).astype(np.float32),
                         np.zeros(m.num_rows, np.float32))
         assert got[:len(a["first"])].tolist() == a["first"]
+
+
+@pytest.mark.parametrize("keep_values", [True, False])
+def test_packed_gather_vector_changes_nothing(gpu, keep_values, monkeypatch):
+    """The cold entries gather from a packed copy of x (never-gathered columns dropped, the rest in degree-class
+    order, refilled per run); GRAPHLILY_SPMV_COMPACT=0 gathers from x itself, =2 packs without classes.  The
+    products and their order per row are the same, so all three must agree bit for bit for (min,+) / (||,&&) and
+    to accumulation-order tolerance for (+,x), on unsplit and split plans, with half of the columns empty."""
+    from graphlily_amd import capi
+    m = spmv_prepare("rmat_sym_50K")
+    rng = np.random.default_rng(23)
+    # empty every second column: relabel the entries into the even columns only
+    m.adj_indices = (m.adj_indices // 2 * 2).astype(np.uint32)
+    m.adj_data = (rng.integers(1, 9, size=m.nnz) / np.float32(8)).astype(np.float32) if keep_values else \
+        np.full(m.nnz, np.float32(0.5), np.float32)
+    x = np.where(rand01(m.num_cols, 5) > 0, rng.random(m.num_cols, dtype=np.float32) + np.float32(0.25), 0).astype(np.float32)
+    mask = rand01(m.num_rows, 6)
+    dx, dm, dy = capi.DeviceBuffer(4 * m.num_cols), capi.DeviceBuffer(4 * m.num_rows), capi.DeviceBuffer(4 * m.num_rows)
+    dx.write(x)
+    dm.write(mask)
+    flags = capi.GL_PLAN_KEEP_VALUES if keep_values else 0
+    for shape in ((0, 0), (5, 3)):
+        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
+        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        outs = {}
+        for mode in ("1", "0", "2"):
+            monkeypatch.setenv("GRAPHLILY_SPMV_COMPACT", mode)
+            plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=flags)
+            assert plan.info()["layout"] == ("general" if keep_values else "pattern")
+            for sem, (op, zero) in SEMIRINGS.items():
+                for mk, mt in MASKS.items():
+                    plan.run(dx, dm if mt else None, dy, op, zero, mt)
+                    outs[(mode, sem, mk)] = dy.read(np.float32, m.num_rows).copy()
+            plan.destroy()
+        for sem, (op, zero) in SEMIRINGS.items():
+            for mk, mt in MASKS.items():
+                _check(outs[("1", sem, mk)], m, sem, mk, x, mask, "%s/%s packed" % (sem, mk))
+                for mode in ("0", "2"):
+                    if op == O.MULADD:
+                        np.testing.assert_allclose(outs[(mode, sem, mk)], outs[("1", sem, mk)], rtol=2e-6, atol=0)
+                    else:
+                        assert np.array_equal(outs[(mode, sem, mk)], outs[("1", sem, mk)]), (mode, sem, mk, shape)
