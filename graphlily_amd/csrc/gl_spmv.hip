@@ -1053,8 +1053,9 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         const long forced = gl::env_long("GRAPHLILY_SPMV_MIX", -1);
         const double hot_frac = nnz ? (double)hot_nnz / (double)nnz : 0.0;
         int mix = 5;                                   // wide: 2 + 2 pairs; narrow: 3 + 3 groups
-        if (pattern) mix = hot_frac >= 0.60 ? 9 : 6;   // quads: 2 + 2 (1 + 2 when the hot table serves most); pairs: 3 + 2 / 2 + 3
-        else if (wide && hot_frac < 0.40) mix = 6;     // 3 + 2 pairs
+        // (re-swept with the packed gather vector: cold groups got cheaper, so a little more of them per slot)
+        if (pattern) mix = hot_frac >= 0.60 ? 9 : hot_frac < 0.45 ? 1 : 6;   // quads: 2 + 1 / 2 + 2 / 1 + 2; pairs: 2 + 1 / 3 + 2 / 2 + 3
+        else if (wide && hot_frac < 0.50) mix = 6;     // 3 + 2 pairs
         else if (wide && hot_frac >= 0.60) mix = 9;    // 2 + 3 pairs
         p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : mix);   // 0 would skip the hot groups
     }
