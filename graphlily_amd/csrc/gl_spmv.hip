@@ -406,10 +406,19 @@ __global__ __launch_bounds__(256) void spmv_hot_gather_kernel(const float *__res
     if (run_flag && *run_flag == 0u) return;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < nhot) hot_x[i] = x[hot_cols[i]];
-    if (4u * i < ncompact) {
-        const uint4 c = reinterpret_cast<const uint4 *>(ccols)[i];
-        reinterpret_cast<float4 *>(xc)[i] = make_float4(x[c.x], x[c.y], x[c.z], x[c.w]);
-    }
+    // four groups of four per thread, every load of a stage issued before the first use: the kernel is a chain of two
+    // dependent loads and a store, i.e. latency-bound unless several chains are in flight per thread
+    if (ncompact == 0u) return;
+    const uint32_t n4 = (ncompact + 3u) / 4u, base = blockIdx.x * 1024u + threadIdx.x;
+    uint4 c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[k] = reinterpret_cast<const uint4 *>(ccols)[min(base + k * 256u, n4 - 1u)];
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = make_float4(x[c[k].x], x[c[k].y], x[c[k].z], x[c[k].w]);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (base + k * 256u < n4) reinterpret_cast<float4 *>(xc)[base + k * 256u] = v[k];
 }
 
 // y initialisation for the rows of blocks that are split into several units
@@ -494,7 +503,7 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
                                                                                          p->nhot, a.run_flag);
         GL_LAUNCH_CHECK();
     } else if (p->nhot || p->ncompact) {
-        spmv_hot_gather_kernel<<<cdiv(std::max(cdiv(p->ncompact, 4), p->nhot), 256), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot, p->d_ccols,
+        spmv_hot_gather_kernel<<<std::max(cdiv(p->ncompact, 4096), cdiv(p->nhot, 256)), 256, 0, s>>>(a.x, p->d_hot_cols, p->d_hot_x, p->nhot, p->d_ccols,
                                                                                                 p->d_xc, p->ncompact, a.run_flag);
         GL_LAUNCH_CHECK();
     }
