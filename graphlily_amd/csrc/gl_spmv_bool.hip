@@ -5,7 +5,7 @@
 //   entries   4 bytes: x word offset from the group's base : 13 | row_in_block : 14 | bit in the word : 5,
 //             column-sorted per row block like the general
 //             layout (gl_spmv.hip); entries whose value is 0 are dropped at format time (a && b is false).
-//             A group is 128 entries = 512 bytes, one coalesced 8-byte-per-lane read; half the HBM bytes.
+//             A group is 256 entries = 1 KB, one coalesced 16-byte-per-lane read; half the HBM bytes.
 //   x         packed to one bit per column by spmv_bool_pack_kernel (12 MB read once per run), and a whole
 //             "phase" of 1 179 648 columns (144 KB) is LDS-resident while a workgroup sweeps it, so there is
 //             no vector-memory gather at all: the lookups are LDS reads.
@@ -17,7 +17,7 @@
 namespace gl {
 
 struct BoolArgs {
-    const uint2 *entries;      // groups of 128: lane l holds entries 2l and 2l+1
+    const void *entries;       // groups of kBoolGroup: lane l holds entries kBoolLane * l ... (one 8- or 16-byte load)
     const uint32_t *bases;     // per group: first x word (of its phase) the group's word offsets count from
     const uint4 *units;        // 2 per unit: {first span, #spans, first row, #rows | direct << 31}, {hub offset, #hub rows, -, -}
     const uint32_t *hub_rows;  // row_in_block of every hub row, per block
@@ -48,7 +48,25 @@ __global__ __launch_bounds__(256) void spmv_bool_pack_kernel(const float *__rest
     }
 }
 
-constexpr int kBoolStep = 2;   // ring slots processed together (divides the ring depth)
+#ifndef GL_BOOL_STEP
+#define GL_BOOL_STEP 2
+#endif
+constexpr int kBoolStep = GL_BOOL_STEP;   // ring slots processed together (divides the ring depth)
+constexpr int kBoolLane = kBoolGroup / 64;   // entries per lane and load
+struct BoolElem {   // one lane's share of a group
+    uint32_t v[kBoolLane];
+};
+__device__ __forceinline__ BoolElem bool_load(const void *entries, size_t group, uint32_t lane) {
+    BoolElem e;
+    if (kBoolLane == 4) {
+        const uint4 t = load_stream_nt16(static_cast<const uint4 *>(entries) + group * 64u + lane);
+        e.v[0] = t.x, e.v[1] = t.y, e.v[kBoolLane - 2] = t.z, e.v[kBoolLane - 1] = t.w;
+    } else {
+        const uint2 t = load_stream_nt(static_cast<const uint2 *>(entries) + group * 64u + lane);
+        e.v[0] = t.x, e.v[1] = t.y;
+    }
+    return e;
+}
 
 template <int MASK, int U, int FUSED>
 __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
@@ -80,13 +98,13 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         // memory pipe empty for the whole processing phase and is latency-bound at ~2/3 of HBM speed.
         // The ring is primed BEFORE the x bits of the phase are copied: the copy hides the HBM latency.
         const uint32_t ngroups = s.z - s.y, glast = s.z - 1u;
-        uint2 e[U];
+        BoolElem e[U];
         uint32_t b[U], li[U];   // li: the slot's group, counted from the span's first
 #pragma unroll
         for (int u = 0; u < U; u++) {
             li[u] = wave + u * kWaves;
             const uint32_t gi = min(s.y + li[u], glast);
-            e[u] = load_stream_nt(a.entries + (size_t)gi * 64u + lane);
+            e[u] = bool_load(a.entries, gi, lane);
             b[u] = load_const(a.bases + gi);
             // keep slot order = issue order: if the scheduler reverses these loads, slot 0 becomes the youngest
             // and the loop header needs vmcnt(0), which empties the ring once per iteration
@@ -109,15 +127,15 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                 // reads, and a slot past the span's end holds the span's last group again (clamped index), which
                 // is harmless to apply twice -- so there is no validity test at all.  16-lane SIMDs make every VALU
                 // instruction cost 4 clocks per wavefront: the path is kept to ~6 of them per entry, and kBoolStep ring
-                // slots are processed together so that 2 * kBoolStep LDS lookups are in flight before the first test.
+                // slots are processed together so that kBoolLane * kBoolStep LDS lookups are in flight before the first test.
                 // entry = word offset : 13 | row slot : 14 | bit : 5 (v_bfe takes the bit number from the low 5 bits
                 // of its operand, so the entry itself is the bit selector); b = first x word of the group
-                constexpr int NE = 2 * kBoolStep;
+                constexpr int NE = kBoolLane * kBoolStep;
                 uint32_t v[NE], w[NE];
 #pragma unroll
-                for (int k = 0; k < NE; k++) v[k] = (k & 1) ? e[u + (k >> 1)].y : e[u + (k >> 1)].x;
+                for (int k = 0; k < NE; k++) v[k] = e[u + k / kBoolLane].v[k % kBoolLane];
 #pragma unroll
-                for (int k = 0; k < NE; k++) w[k] = xw[b[u + (k >> 1)] + (v[k] >> 19)];
+                for (int k = 0; k < NE; k++) w[k] = xw[b[u + k / kBoolLane] + (v[k] >> 19)];
 #pragma unroll
                 for (int k = 0; k < NE; k++)
                     if (__builtin_amdgcn_ubfe(w[k], v[k], 1u)) {
@@ -130,13 +148,15 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                 for (int k = 0; k < kBoolStep; k++) {
                     li[u + k] = a.tickets ? t + k : li[u + k] + kWaves * U;
                     const uint32_t gn = min(s.y + li[u + k], glast);
-                    e[u + k] = load_stream_nt(a.entries + (size_t)gn * 64u + lane);
+                    e[u + k] = bool_load(a.entries, gn, lane);
                     b[u + k] = load_const(a.bases + gn);
                 }
             }
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) asm volatile("" : : "v"(e[u].x), "v"(e[u].y));   // retire the clamped tail loads
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < kBoolLane; k++) asm volatile("" : : "v"(e[u].v[k]));   // retire the clamped tail loads
     }
     __syncthreads();
 
@@ -194,7 +214,12 @@ static uint32_t bool_tickets() {
     return t;
 }
 
-constexpr int kBoolUnroll = 6;
+#ifndef GL_BOOL_U
+#define GL_BOOL_U 4
+#endif
+// ring depth.  Same-box sweep (orkut / products, masked, x density 0.5 and 0.02): groups of 256 entries (16-byte loads),
+// two slots per step, four slots deep 0.160 / 0.097 ms; 128-entry groups (8-byte loads), 2, 6: 0.170 / 0.102 ms.
+constexpr int kBoolUnroll = GL_BOOL_U;
 constexpr size_t kBoolLds = ((size_t)kBoolPhaseWords + kBoolTileWords) * 4u;
 
 template <int MASK, int FUSED>

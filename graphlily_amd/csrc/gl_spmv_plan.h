@@ -28,7 +28,10 @@ constexpr uint32_t kWaves = kThreads / 64;
 // (||,&&)-only layout: x as a bitmap, one LDS-resident slice ("phase") of it at a time
 constexpr uint32_t kBoolPhaseWords = 36864;                   // 144 KB of x bits
 constexpr uint32_t kBoolPhaseCols = kBoolPhaseWords * 32u;    // 1 179 648 columns
-constexpr uint32_t kBoolGroup = 128;                          // entries per group: 8 bytes per lane
+#ifndef GL_BOOL_GROUP
+#define GL_BOOL_GROUP 256
+#endif
+constexpr uint32_t kBoolGroup = GL_BOOL_GROUP;                  // entries per group: 16 (256) or 8 (128) bytes per lane and load
 constexpr uint32_t kBoolTileWords = (kMaxBlockRows + 1u) / 32u;  // 512: one bit per row slot incl. the padding slot
 constexpr uint32_t kBoolHubSlots = 32;                        // private bits per hub row, one per tile word 480..511
 constexpr uint32_t kBoolHubMax = 31;                          // hub rows per block (bit 31 of word 511 is the padding slot)

@@ -62,7 +62,7 @@ def main():
         shutil.copy(fs, os.path.join(DST, "%s_pmc_fetch_spmv.csv" % TAG))
         shutil.copy(ws, os.path.join(DST, "%s_pmc_write_spmv.csv" % TAG))
         other = {}
-        for k in ("spmv_rbcs_kernel<0, 0, 3,", "spmv_bool_kernel<0, 6, 1>", "spmv_bool_kernel<0, 6, 0>", "spmv_prescale_kernel", "spmv_bool_pack_kernel"):
+        for k in ("spmv_rbcs_kernel<0, 0, 3,", "spmv_bool_kernel<0, 4, 1>", "spmv_bool_kernel<0, 4, 0>", "spmv_prescale_kernel", "spmv_bool_pack_kernel"):
             try:
                 f_, n1 = mean_counter(fs, k)
                 w_, n2 = mean_counter(ws, k)
@@ -75,7 +75,7 @@ def main():
         with open(stats[0]) as f:
             rows = {}
             for row in csv.DictReader(f):
-                for k in ("spmv_rbcs_kernel<0, 0, 3,", "spmv_bool_kernel<0, 6, 1>", "spmv_bool_kernel<0, 6, 0>", "spmv_prescale_kernel", "spmv_bool_pack_kernel",
+                for k in ("spmv_rbcs_kernel<0, 0, 3,", "spmv_bool_kernel<0, 4, 1>", "spmv_bool_kernel<0, 4, 0>", "spmv_prescale_kernel", "spmv_bool_pack_kernel",
                           "spmv_hot_gather_kernel", "spmspv_scatter_kernel", "spmspv_queue_kernel", "spmspv_work_kernel"):
                     if k in row["Name"]:
                         rows[k] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
