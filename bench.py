@@ -58,14 +58,23 @@ def main():
     ap.add_argument("--same-gpu", action="store_true", help="debugging: put every rank on cuda:0")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` from a plain shell: start the N ranks ourselves (one process per GPU, the launch the
+    # driver would otherwise do) and hand back their exit code; under torch.distributed.run WORLD_SIZE is set.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # torch.distributed.run pins OMP_NUM_THREADS to 1; plan creation on the host is OpenMP code -- give every rank
+    # its share of the cores (set before the library and its OpenMP runtime are loaded)
+    if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))
+
     import torch
     import torch.distributed as dist
     from graphlily_amd import app, capi, datasets, io
     from graphlily_amd.dist import Comm, partition_rows_by_nnz
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
@@ -236,6 +245,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _self_launch(n):
+    """Re-run this command line as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <args>`
+    on a free local port; the ranks' output (rank 0 prints the JSON line) passes through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def _bench_pattern(capi, csr, r0, r1, bx, by, y, y_general, args, fence, world, comm, bounds, dist, dev):

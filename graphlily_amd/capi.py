@@ -31,7 +31,7 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32",
-    "gl_host_alloc", "gl_host_free",
+    "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim",
     "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_run",
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits", "gl_bfs_pull_step",
     "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every",
@@ -74,6 +74,7 @@ def lib():
         "gl_init": [i32], "gl_device_count": [P(i32)], "gl_set_stream": [vp], "gl_reset_stream": [], "gl_sync": [],
         "gl_buf_alloc": [P(vp), ctypes.c_size_t], "gl_buf_free": [vp],
         "gl_host_alloc": [P(vp), ctypes.c_size_t], "gl_host_free": [vp],
+        "gl_host_pool_alloc": [P(vp), ctypes.c_size_t], "gl_host_pool_free": [vp], "gl_pool_trim": [],
         "gl_buf_h2d": [vp, vp, ctypes.c_size_t], "gl_buf_d2h": [vp, vp, ctypes.c_size_t],
         "gl_buf_d2d": [vp, vp, ctypes.c_size_t], "gl_buf_fill_f32": [vp, f32, ctypes.c_size_t],
         "gl_spmv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],

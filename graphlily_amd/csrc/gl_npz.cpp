@@ -151,6 +151,7 @@ static bool load_npz(const char *path, std::map<std::string, Npy> &arrays, std::
     if (!read_file(path, f, err)) return false;
     // end of central directory
     size_t eocd = std::string::npos;
+    if (f.size() < 22) { err = "file too short to be a zip archive"; return false; }
     for (size_t i = f.size() - 22;; i--) {
         if (rd<uint32_t>(&f[i]) == 0x06054b50u) { eocd = i; break; }
         if (i == 0 || f.size() - i > 65557) break;
@@ -160,35 +161,43 @@ static bool load_npz(const char *path, std::map<std::string, Npy> &arrays, std::
     uint64_t cd_off = rd<uint32_t>(&f[eocd + 16]);
     if ((nent == 0xffff || cd_off == 0xffffffffu) && eocd >= 20 && rd<uint32_t>(&f[eocd - 20]) == 0x07064b50u) {
         uint64_t z64 = rd<uint64_t>(&f[eocd - 20 + 8]);
-        if (z64 + 56 <= f.size() && rd<uint32_t>(&f[z64]) == 0x06064b50u) {
+        if (z64 <= f.size() && z64 + 56 <= f.size() && rd<uint32_t>(&f[z64]) == 0x06064b50u) {
             nent = rd<uint64_t>(&f[z64 + 32]);
             cd_off = rd<uint64_t>(&f[z64 + 48]);
         }
     }
+    // every length below comes from the file: nothing is read or sized before it is checked against the file's end
+    if (cd_off > f.size()) { err = "zip central directory offset beyond the file"; return false; }
     size_t p = (size_t)cd_off;
     for (uint64_t e = 0; e < nent; e++) {
-        if (p + 46 > f.size() || rd<uint32_t>(&f[p]) != 0x02014b50u) { err = "bad zip central directory"; return false; }
+        if (p > f.size() || f.size() - p < 46 || rd<uint32_t>(&f[p]) != 0x02014b50u) { err = "bad zip central directory"; return false; }
         uint16_t method = rd<uint16_t>(&f[p + 10]);
         uint64_t csize = rd<uint32_t>(&f[p + 20]), usize = rd<uint32_t>(&f[p + 24]);
         uint16_t nlen = rd<uint16_t>(&f[p + 28]), xlen = rd<uint16_t>(&f[p + 30]), clen = rd<uint16_t>(&f[p + 32]);
         uint64_t lho = rd<uint32_t>(&f[p + 42]);
+        if (f.size() - p - 46 < (size_t)nlen + xlen + clen) { err = "truncated zip central directory entry"; return false; }
         std::string name((const char *)&f[p + 46], nlen);
         // zip64 extra field
-        size_t x = p + 46 + nlen, xend = x + xlen;
+        size_t x = p + 46 + nlen;
+        const size_t xend = x + xlen;   // <= f.size(), checked above
         while (x + 4 <= xend) {
             uint16_t id = rd<uint16_t>(&f[x]), sz = rd<uint16_t>(&f[x + 2]);
+            const size_t fend = std::min(x + 4 + (size_t)sz, xend);   // a field may not run past the extra block
             if (id == 0x0001) {
                 size_t y = x + 4;
-                if (usize == 0xffffffffu && y + 8 <= x + 4 + sz) { usize = rd<uint64_t>(&f[y]); y += 8; }
-                if (csize == 0xffffffffu && y + 8 <= x + 4 + sz) { csize = rd<uint64_t>(&f[y]); y += 8; }
-                if (lho == 0xffffffffu && y + 8 <= x + 4 + sz) { lho = rd<uint64_t>(&f[y]); y += 8; }
+                if (usize == 0xffffffffu && y + 8 <= fend) { usize = rd<uint64_t>(&f[y]); y += 8; }
+                if (csize == 0xffffffffu && y + 8 <= fend) { csize = rd<uint64_t>(&f[y]); y += 8; }
+                if (lho == 0xffffffffu && y + 8 <= fend) { lho = rd<uint64_t>(&f[y]); y += 8; }
             }
             x += 4 + (size_t)sz;
         }
         p = xend + clen;
-        if (lho + 30 > f.size() || rd<uint32_t>(&f[lho]) != 0x04034b50u) { err = "bad zip local header"; return false; }
-        size_t data = (size_t)lho + 30 + rd<uint16_t>(&f[lho + 26]) + rd<uint16_t>(&f[lho + 28]);
-        if (data + csize > f.size()) { err = "zip member exceeds file"; return false; }
+        if (lho > f.size() || f.size() - lho < 30 || rd<uint32_t>(&f[lho]) != 0x04034b50u) { err = "bad zip local header"; return false; }
+        const uint64_t data64 = lho + 30 + rd<uint16_t>(&f[lho + 26]) + rd<uint16_t>(&f[lho + 28]);
+        if (data64 > f.size() || csize > f.size() - data64) { err = "zip member exceeds file"; return false; }
+        const size_t data = (size_t)data64;
+        // deflate expands by at most ~1032x: a larger claim is not an array this file can hold
+        if (usize > (uint64_t)csize * 1032u + 65536u) { err = "zip member claims an impossible uncompressed size"; return false; }
         std::vector<uint8_t> blob;
         if (method == 0) {
             blob.assign(f.begin() + (long)data, f.begin() + (long)(data + csize));

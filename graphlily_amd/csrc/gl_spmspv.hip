@@ -58,6 +58,20 @@ struct gl_spmspv_plan_s {
 
 namespace gl {
 
+// Live SpMSpV plans, so that destroying an SpMV plan detaches it wherever it is attached (gl_spmspv_plan_attach_pull
+// does not own the plan; a module that re-formats or dies must not leave a dangling pointer behind).
+static std::vector<gl_spmspv_plan> &live_spmspv_plans() {
+    static std::vector<gl_spmspv_plan> v;
+    return v;
+}
+
+void spmspv_detach_everywhere(gl_spmv_plan dying) {
+    for (gl_spmspv_plan q : live_spmspv_plans()) {
+        if (q->pull == dying) q->pull = nullptr;
+        if (q->pull_arith == dying) q->pull_arith = nullptr;
+    }
+}
+
 constexpr uint32_t kBigColumn = 4096;  // columns at least this long are cut into queue chunks
 constexpr uint32_t kChunk = 4096;      // entries per queue chunk (one workgroup pass in kernel 1b)
 
@@ -76,7 +90,7 @@ struct ScatterArgs {
 
 // ordered-integer trick: for IEEE floats, a >= 0 compares like int, a < 0 like reversed uint
 __device__ __forceinline__ void atomic_min_float(float *addr, float v) {
-    if (v >= 0.0f)
+    if (!(__float_as_uint(v) >> 31))   // by sign bit, so that -0.0 takes the negative path (v >= 0 is true for it)
         atomicMin((int *)addr, __float_as_int(v));
     else
         atomicMax((unsigned int *)addr, __float_as_uint(v));
@@ -163,6 +177,27 @@ __global__ __launch_bounds__(256) void spmspv_scatter_kernel(ScatterArgs a) {
             for (uint32_t c = 0; c < nchunks; c++) {
                 if (qb + c < a.queue_capacity)
                     a.queue[qb + c] = make_uint4(start + c * kChunk, min(kChunk, deg - c * kChunk), __float_as_uint(xv), 0u);
+            }
+            // The queue holds one slot per chunk of every long column (exact, computed at plan creation), so it can
+            // only run out when the input vector names a column more than once.  Chunks without a slot are
+            // scattered right here by the whole workgroup: slow, never wrong.
+            if (s_qbase + qtotal > a.queue_capacity) {   // block-uniform
+                s_start[threadIdx.x] = start;
+                s_deg[threadIdx.x] = nchunks ? deg : 0u;
+                s_val[threadIdx.x] = xv;
+                s_task[threadIdx.x] = qb;
+                __syncthreads();
+                for (uint32_t j = 0; j < 256u; j++) {
+                    const uint32_t dj = s_deg[j];
+                    if (!dj) continue;
+                    const uint32_t nj = (dj + kChunk - 1u) / kChunk, qj = s_task[j];
+                    const uint32_t c0 = qj >= a.queue_capacity ? 0u : min(nj, a.queue_capacity - qj);   // first chunk without a slot
+                    for (uint32_t k = c0 * kChunk + threadIdx.x; k < dj; k += 256u) {
+                        const uint2 rv = load_stream_nt(a.stream + s_start[j] + k);
+                        scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), s_val[j]);
+                    }
+                }
+                __syncthreads();
             }
         }
         // the rest -> wave tasks of <= 64 entries
@@ -346,8 +381,15 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     p->row_end = row_end;
     p->nnz = stream.size();
     const uint32_t nrows = row_end - row_begin;
-    // every queued column has >= kBigColumn entries and yields ceil(deg / kChunk) chunks
-    p->queue_capacity = (uint32_t)(stream.size() / gl::kBigColumn + 1);
+    // one slot per chunk of every long column: a column of deg >= kBigColumn entries yields ceil(deg / kChunk) chunks
+    // (nnz / kChunk undercounts: two columns of 4097 entries need four slots).  A vector that lists a column twice
+    // can still exceed it; the scatter kernel then processes the surplus chunks itself.
+    uint64_t chunks = 0;
+    for (uint32_t c = 0; c < num_cols; c++) {
+        const uint32_t d = indptr[c + 1] - indptr[c];
+        if (d >= gl::kBigColumn) chunks += (d + gl::kChunk - 1u) / gl::kChunk;
+    }
+    p->queue_capacity = (uint32_t)std::min<uint64_t>(chunks + 1u, 0x7fffffffu);
     auto fail = [&](hipError_t e) {
         gl_spmspv_plan_destroy(p);
         return gl::set_error(GL_ERR_HIP, "gl_spmspv_plan_create: %s", hipGetErrorString(e));
@@ -371,12 +413,15 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     if (b_stream && (e = hipMemcpy(p->d_stream, stream.data(), b_stream, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e);   // the memsets above ran on the null stream
     p->device_bytes = b_indptr + b_stream + b_acc + b_counts + b_queue;
+    gl::live_spmspv_plans().push_back(p);
     *plan = p;
     return GL_OK;
 }
 
 int gl_spmspv_plan_destroy(gl_spmspv_plan p) {
     if (!p) return GL_OK;
+    std::vector<gl_spmspv_plan> &live = gl::live_spmspv_plans();
+    live.erase(std::remove(live.begin(), live.end(), p), live.end());
     (void)hipFree(p->d_indptr);
     (void)hipFree(p->d_stream);
     (void)hipFree(p->d_acc);

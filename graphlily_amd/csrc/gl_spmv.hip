@@ -121,7 +121,7 @@ struct Tile<GL_OP_ANDOR> {
 
 // ordered-integer min: floats >= 0 compare like int, floats < 0 like reversed uint
 __device__ __forceinline__ void atomic_min_f32_as_int(float *addr, float v) {
-    if (v >= 0.0f)
+    if (!(__float_as_uint(v) >> 31))   // by sign bit: -0.0 must take the negative path (v >= 0 is true for it)
         atomicMin((int *)addr, __float_as_int(v));
     else
         atomicMax((unsigned int *)addr, __float_as_uint(v));
@@ -475,11 +475,11 @@ namespace gl {
 
 template <int OP, int MASK, int L, int UC, int UH>
 static int launch_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStream_t s) {
-    static bool attr_set = false;  // one flag per template instantiation
-    if (!attr_set) {
+    static int attr_device = -1;  // per template instantiation; the opt-in is per device (gl_init may switch devices)
+    if (attr_device != ctx().device) {
         GL_HIP(hipFuncSetAttribute((const void *)spmv_rbcs_kernel<OP, MASK, L, UC, UH>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set = true;
+        attr_device = ctx().device;
     }
     spmv_rbcs_kernel<OP, MASK, L, UC, UH><<<p->nunits, kThreads, lds, s>>>(a);
     return GL_OK;
@@ -1188,6 +1188,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
 
 int gl_spmv_plan_destroy(gl_spmv_plan p) {
     if (!p) return GL_OK;
+    gl::spmspv_detach_everywhere(p);   // attachments do not own the plan; none may outlive it
     (void)hipFree(p->d_entries);
     (void)hipFree(p->d_bases);
     (void)hipFree(p->d_units);

@@ -224,11 +224,11 @@ constexpr size_t kBoolLds = ((size_t)kBoolPhaseWords + kBoolTileWords) * 4u;
 
 template <int MASK, int FUSED>
 static int launch_bool_variant(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_device = -1;   // the opt-in is per device (gl_init may switch devices)
+    if (attr_device != ctx().device) {
         GL_HIP(hipFuncSetAttribute((const void *)spmv_bool_kernel<MASK, kBoolUnroll, FUSED>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBoolLds));
-        attr_set = true;
+        attr_device = ctx().device;
     }
     Profiler &pf = prof();
     const bool timed = prof_take(pf);

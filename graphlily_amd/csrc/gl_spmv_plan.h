@@ -134,6 +134,8 @@ uint32_t *bool_plan_xbits(gl_spmv_plan p);
 size_t bool_plan_xbits_bytes(gl_spmv_plan p);
 int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
                      const uint32_t *run_flag);
+// gl_spmspv.hip: forget `dying` wherever gl_spmspv_plan_attach_pull attached it
+void spmspv_detach_everywhere(gl_spmv_plan dying);
 // gl_spmv.hip: y initialisation for plans whose units fold into y
 int spmv_init_rows(int op, int mask_type, uint32_t r0, uint32_t r1, const float *mask, float *y, float zero, hipStream_t s);
 }  // namespace gl

@@ -48,6 +48,9 @@ public:
             m->set_device(device_);
             m->set_unused_args();
             m->set_mode();
+            // one in-order stream serves all modules; host-visible calls synchronise (base_module.h).
+            // GRAPHLILY_BLOCKING=1 restores a finish() after every launch (time-breakdown style measurements).
+            m->set_blocking(getenv("GRAPHLILY_BLOCKING") != nullptr && atoi(getenv("GRAPHLILY_BLOCKING")) != 0);
         }
     }
 };

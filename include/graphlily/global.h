@@ -24,6 +24,9 @@
 
 // Host vectors handed to the device are page aligned in the reference (xcl2.hpp:61-76,
 // aligned_allocator at global scope); kept so that caller code naming it compiles unchanged.
+// Blocks come from the library's host pool (gl_host_pool_alloc): 4 KiB aligned like the reference's, and -- once
+// the runtime is up -- page-locked and recycled by size, so the n-element vectors the drivers build for every
+// pull() / push() call (app/bfs.h:107-113) cost neither page faults nor a staged pageable copy.
 template <typename T>
 struct aligned_allocator {
     using value_type = T;
@@ -32,11 +35,10 @@ struct aligned_allocator {
     aligned_allocator(const aligned_allocator<U> &) {}
     T *allocate(std::size_t num) {
         void *ptr = nullptr;
-        const std::size_t bytes = (num == 0 ? 1 : num) * sizeof(T);
-        if (posix_memalign(&ptr, 4096, bytes)) throw std::bad_alloc();
+        if (gl_host_pool_alloc(&ptr, (num == 0 ? 1 : num) * sizeof(T)) != GL_OK || !ptr) throw std::bad_alloc();
         return reinterpret_cast<T *>(ptr);
     }
-    void deallocate(T *p, std::size_t) { free(p); }
+    void deallocate(T *p, std::size_t) { gl_host_pool_free(p); }
     template <typename U>
     bool operator==(const aligned_allocator<U> &) const { return true; }
     template <typename U>

@@ -16,7 +16,7 @@ template <typename vector_data_t>
 class eWiseAddModule : public BaseModule {
     static_assert(std::is_same<vector_data_t, float>::value, "the MI355X backend computes in float");
     using aligned_dense_vec_t = std::vector<vector_data_t, aligned_allocator<vector_data_t>>;
-    aligned_dense_vec_t in_, out_;
+    aligned_dense_vec_t out_;   // host staging for send_out_device_to_host
 
 public:
     DeviceBuffer in_buf;
@@ -25,14 +25,10 @@ public:
     eWiseAddModule() : BaseModule("overlay") {}
 
     void send_in_host_to_device(aligned_dense_vec_t &in) {
-        in_.assign(in.begin(), in.end());
-        in_buf = DeviceBuffer(sizeof(float) * in_.size());
-        in_buf.upload(in_.data(), sizeof(float) * in_.size());
+        in_buf = DeviceBuffer(sizeof(float) * in.size());
+        in_buf.upload(in.data(), sizeof(float) * in.size());
     }
-    void allocate_out_buf(uint32_t len) {
-        out_.resize(len);
-        out_buf = DeviceBuffer(sizeof(float) * len);
-    }
+    void allocate_out_buf(uint32_t len) { out_buf = DeviceBuffer(sizeof(float) * len); }
     void bind_in_buf(DeviceBuffer src_buf) { in_buf = src_buf; }
     void bind_out_buf(DeviceBuffer src_buf) { out_buf = src_buf; }
 

@@ -34,14 +34,12 @@ public:
     }
 
     void send_mask_host_to_device(aligned_dense_vec_t &mask) {
-        mask_.assign(mask.begin(), mask.end());
-        mask_buf = DeviceBuffer(sizeof(float) * mask_.size());
-        mask_buf.upload(mask_.data(), sizeof(float) * mask_.size());
+        mask_buf = DeviceBuffer(sizeof(float) * mask.size());
+        mask_buf.upload(mask.data(), sizeof(float) * mask.size());
     }
     void send_inout_host_to_device(aligned_dense_vec_t &inout) {
-        inout_.assign(inout.begin(), inout.end());
-        inout_buf = DeviceBuffer(sizeof(float) * inout_.size());
-        inout_buf.upload(inout_.data(), sizeof(float) * inout_.size());
+        inout_buf = DeviceBuffer(sizeof(float) * inout.size());
+        inout_buf.upload(inout.data(), sizeof(float) * inout.size());
     }
     void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }
     void bind_inout_buf(DeviceBuffer src_buf) { inout_buf = src_buf; }

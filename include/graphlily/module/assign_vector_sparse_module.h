@@ -44,19 +44,17 @@ public:
         : BaseModule("overlay"), generate_new_frontier_(generate_new_frontier) {}
 
     void send_mask_host_to_device(aligned_mask_t &mask) {
-        mask_.assign(mask.begin(), mask.end());
-        mask_buf = DeviceBuffer(sizeof(gl_idx_val) * mask_.size());
-        mask_buf.upload(mask_.data(), sizeof(gl_idx_val) * mask_.size());
+        mask_buf = DeviceBuffer(sizeof(gl_idx_val) * mask.size());
+        mask_buf.upload(mask.data(), sizeof(gl_idx_val) * mask.size());
         if (generate_new_frontier_) {  // the new frontier can never be longer than the mask
-            new_frontier_.assign(mask_.size(), sparse_vector_data_t{0, 0});
-            new_frontier_buf = DeviceBuffer(sizeof(gl_idx_val) * new_frontier_.size());
-            new_frontier_buf.upload(new_frontier_.data(), sizeof(gl_idx_val) * new_frontier_.size());
+            new_frontier_buf = DeviceBuffer(sizeof(gl_idx_val) * mask.size());
+            const sparse_vector_data_t head{0, 0};
+            if (!mask.empty()) new_frontier_buf.upload(&head, sizeof(head));
         }
     }
     void send_inout_host_to_device(aligned_dense_vec_t &inout) {
-        inout_.assign(inout.begin(), inout.end());
-        inout_buf = DeviceBuffer(sizeof(float) * inout_.size());
-        inout_buf.upload(inout_.data(), sizeof(float) * inout_.size());
+        inout_buf = DeviceBuffer(sizeof(float) * inout.size());
+        inout_buf.upload(inout.data(), sizeof(float) * inout.size());
     }
     void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }
     void bind_inout_buf(DeviceBuffer src_buf) { inout_buf = src_buf; }

@@ -17,7 +17,11 @@ protected:
     std::string kernel_name_;
     std::string target_ = "hw";
     int device_ = 0;
-    bool blocking_ = true;  // every reference call ends in command_queue_.finish()
+    // Every reference call ends in command_queue_.finish().  A stand-alone module keeps that; modules owned by a
+    // ModuleCollection run non-blocking (module_collection.h): all work goes to one in-order stream and every call
+    // that hands data to the host (send_*_device_to_host, get_results_nnz, uploads) waits for it anyway, so the
+    // callers see the same values without a host round trip per launch.
+    bool blocking_ = true;
 
     void finish_() {
         if (blocking_) GRAPHLILY_CHECK(gl_sync());
@@ -42,7 +46,7 @@ public:
 
     void copy_buffer_device_to_device(DeviceBuffer src, DeviceBuffer dst, size_t bytes) {
         GRAPHLILY_CHECK(gl_buf_d2d(dst.ptr(), src.ptr(), bytes));
-        GRAPHLILY_CHECK(gl_sync());
+        finish_();
     }
 
     // The fused overlay needed its unused ports tied off and a mode selected (reference :90-96);

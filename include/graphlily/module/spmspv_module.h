@@ -2,6 +2,7 @@
 #ifndef GRAPHLILY_SPMSPV_MODULE_H_
 #define GRAPHLILY_SPMSPV_MODULE_H_
 
+#include <algorithm>
 #include <cstdint>
 #include <type_traits>
 #include <vector>
@@ -31,8 +32,19 @@ class SpMSpVModule : public BaseModule {
     bool sharded_ = false;
     CSCMatrix<float> csc_matrix_float_;
     gl_spmspv_plan plan_ = nullptr;
-    aligned_sparse_vec_t vector_, results_;
+    aligned_sparse_vec_t vector_, results_;   // host staging for the by-value returns
     aligned_dense_vec_t mask_;
+
+    static aligned_sparse_vec_t download_sparse_(const DeviceBuffer &buf, aligned_sparse_vec_t &stage) {
+        const size_t slots = buf.size() / sizeof(idx_val_t);
+        if (stage.size() != slots) stage.assign(slots, idx_val_t{0, 0});
+        if (!slots) return stage;
+        uint32_t nnz = 0;
+        GRAPHLILY_CHECK(gl_sparse_nnz((const gl_idx_val *)buf.ptr(), &nnz));
+        const size_t used = std::min(slots, (size_t)nnz + 1);
+        buf.download(stage.data(), sizeof(idx_val_t) * used);
+        return stage;
+    }
 
 public:
     DeviceBuffer channel_packets_buf, channel_indptr_buf, channel_partptr_buf;  // unused: held by the plan
@@ -56,11 +68,7 @@ public:
         sharded_ = true;
     }
 
-    void load_and_format_matrix(CSCMatrix<float> const &csc_matrix_float) {
-        csc_matrix_float_ = csc_matrix_float;
-        vector_.resize((size_t)get_num_cols() + 1);
-        results_.assign((size_t)get_num_rows() + 1, idx_val_t{0, 0});
-    }
+    void load_and_format_matrix(CSCMatrix<float> const &csc_matrix_float) { csc_matrix_float_ = csc_matrix_float; }
 
     void send_matrix_host_to_device() {
         const CSCMatrix<float> &m = csc_matrix_float_;
@@ -69,21 +77,29 @@ public:
         GRAPHLILY_CHECK(gl_spmspv_plan_create(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
                                               m.adj_data.data(), sharded_ ? row_begin_ : 0, sharded_ ? row_end_ : m.num_rows));
         results_buf = DeviceBuffer(sizeof(idx_val_t) * ((size_t)m.num_rows + 1));
-        results_buf.upload(results_.data(), sizeof(idx_val_t) * results_.size());
+        const idx_val_t head{0, 0};   // an empty result list until the first run
+        results_buf.upload(&head, sizeof(head));
     }
 
     // the vector may be shorter than num_cols + 1; the device copy always has that many slots
     void send_vector_host_to_device(aligned_sparse_vec_t &vector) {
-        std::copy(vector.begin(), vector.end(), vector_.begin());
-        if (!vector.empty()) hint_vector_nnz((uint32_t)vector[0].index);
-        vector_buf = DeviceBuffer(sizeof(idx_val_t) * vector_.size());
-        vector_buf.upload(vector_.data(), sizeof(idx_val_t) * vector_.size());
+        const size_t slots = (size_t)get_num_cols() + 1;   // reference :280,379
+        vector_buf = DeviceBuffer(sizeof(idx_val_t) * slots);
+        if (vector.empty()) {
+            const idx_val_t head{0, 0};
+            vector_buf.upload(&head, sizeof(head));
+            hint_vector_nnz(0);
+            return;
+        }
+        // only the head and the entries it counts are meaningful
+        const size_t used = std::min(std::min(vector.size(), slots), (size_t)vector[0].index + 1);
+        vector_buf.upload(vector.data(), sizeof(idx_val_t) * used);
+        hint_vector_nnz((uint32_t)vector[0].index);
     }
 
     void send_mask_host_to_device(aligned_dense_vec_t &mask) {
-        mask_.assign(mask.begin(), mask.end());
-        mask_buf = DeviceBuffer(sizeof(float) * mask_.size());
-        mask_buf.upload(mask_.data(), sizeof(float) * mask_.size());
+        mask_buf = DeviceBuffer(sizeof(float) * mask.size());
+        mask_buf.upload(mask.data(), sizeof(float) * mask.size());
     }
 
     void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }      // extension
@@ -113,19 +129,15 @@ public:
         finish_();
     }
 
-    aligned_sparse_vec_t send_vector_device_to_host() {
-        vector_buf.download(vector_.data(), sizeof(idx_val_t) * vector_.size());
-        return vector_;
-    }
+    // sparse vectors come back at their full capacity like the reference's mirrors, but only the head and the
+    // entries it counts are transferred (the rest of the staging vector keeps whatever it held)
+    aligned_sparse_vec_t send_vector_device_to_host() { return download_sparse_(vector_buf, vector_); }
     aligned_dense_vec_t send_mask_device_to_host() {
         mask_.resize(mask_buf.size() / sizeof(float));
         mask_buf.download(mask_.data(), sizeof(float) * mask_.size());
         return mask_;
     }
-    aligned_sparse_vec_t send_results_device_to_host() {
-        results_buf.download(results_.data(), sizeof(idx_val_t) * results_.size());
-        return results_;
-    }
+    aligned_sparse_vec_t send_results_device_to_host() { return download_sparse_(results_buf, results_); }
 
     // the per-iteration device->host control read of the push loops (reference :239-242)
     uint32_t get_results_nnz() {

@@ -4,6 +4,7 @@
 #ifndef GRAPHLILY_SPMV_MODULE_H_
 #define GRAPHLILY_SPMV_MODULE_H_
 
+#include <algorithm>
 #include <cstdint>
 #include <type_traits>
 #include <vector>
@@ -32,7 +33,23 @@ class SpMVModule : public BaseModule {
     CSRMatrix<float> csr_matrix_float_;
     gl_spmv_plan plan_ = nullptr;
     uint32_t plan_flags_ = 0;
+    // host staging for the by-value returns of send_*_device_to_host (the reference's host mirrors, :67-70; their
+    // contents are only ever observable after a download, so uploads go straight from the caller's vector)
     aligned_dense_vec_t vector_, mask_, results_;
+
+    // upload `n` floats taken from `src` (zero-padded if it is shorter) into a fresh buffer
+    static DeviceBuffer upload_dense_(aligned_dense_vec_t &src, size_t n) {
+        DeviceBuffer buf(sizeof(float) * n);
+        const size_t have = std::min(src.size(), n);
+        if (have) buf.upload(src.data(), sizeof(float) * have);
+        if (have < n) GRAPHLILY_CHECK(gl_buf_fill_f32((float *)buf.ptr() + have, 0.0f, n - have));
+        return buf;
+    }
+    static aligned_dense_vec_t download_dense_(const DeviceBuffer &buf, aligned_dense_vec_t &stage, size_t n) {
+        stage.resize(n);
+        buf.download(stage.data(), sizeof(float) * n);
+        return stage;
+    }
 
     // The semiring known at upload time picks the layout: pattern-only entries and a bit vector for (||,&&),
     // a larger hot-column table for (min,+), 8-byte accumulators for (+,x).
@@ -107,8 +124,6 @@ public:
 
     void load_and_format_matrix(CSRMatrix<float> const &csr_matrix_float, bool /*skip_empty_rows*/) {
         csr_matrix_float_ = csr_matrix_float;
-        vector_.resize(csr_matrix_float_.num_cols);
-        results_.assign(csr_matrix_float_.num_rows, 0);
     }
 
     void send_matrix_host_to_device() {
@@ -116,22 +131,12 @@ public:
         make_plan_();
         results_buf = DeviceBuffer(sizeof(float) * m.num_rows);
         GRAPHLILY_CHECK(gl_buf_fill_f32((float *)results_buf.ptr(), 0.0f, m.num_rows));
-        GRAPHLILY_CHECK(gl_sync());
+        finish_();
     }
 
-    void send_vector_host_to_device(aligned_dense_vec_t &vector) {
-        vector_.assign(vector.begin(), vector.end());
-        vector_.resize(get_num_cols());
-        vector_buf = DeviceBuffer(sizeof(float) * get_num_cols());
-        vector_buf.upload(vector_.data(), sizeof(float) * get_num_cols());
-    }
+    void send_vector_host_to_device(aligned_dense_vec_t &vector) { vector_buf = upload_dense_(vector, get_num_cols()); }
 
-    void send_mask_host_to_device(aligned_dense_vec_t &mask) {
-        mask_.assign(mask.begin(), mask.end());
-        mask_.resize(get_num_rows());
-        mask_buf = DeviceBuffer(sizeof(float) * get_num_rows());
-        mask_buf.upload(mask_.data(), sizeof(float) * get_num_rows());
-    }
+    void send_mask_host_to_device(aligned_dense_vec_t &mask) { mask_buf = upload_dense_(mask, get_num_rows()); }
 
     void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }
     void bind_vector_buf(DeviceBuffer src_buf) { vector_buf = src_buf; }    // extension
@@ -148,21 +153,9 @@ public:
         finish_();
     }
 
-    aligned_dense_vec_t send_vector_device_to_host() {
-        vector_.resize(get_num_cols());
-        vector_buf.download(vector_.data(), sizeof(float) * get_num_cols());
-        return vector_;
-    }
-    aligned_dense_vec_t send_mask_device_to_host() {
-        mask_.resize(get_num_rows());
-        mask_buf.download(mask_.data(), sizeof(float) * get_num_rows());
-        return mask_;
-    }
-    aligned_dense_vec_t send_results_device_to_host() {
-        results_.resize(get_num_rows());
-        results_buf.download(results_.data(), sizeof(float) * get_num_rows());
-        return results_;
-    }
+    aligned_dense_vec_t send_vector_device_to_host() { return download_dense_(vector_buf, vector_, get_num_cols()); }
+    aligned_dense_vec_t send_mask_device_to_host() { return download_dense_(mask_buf, mask_, get_num_rows()); }
+    aligned_dense_vec_t send_results_device_to_host() { return download_dense_(results_buf, results_, get_num_rows()); }
 
     // CPU reference the callers verify against (part of the reference's public API, :478-532).
     // Sequential row loop with a float accumulator, like the reference.

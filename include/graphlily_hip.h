@@ -79,6 +79,16 @@ int gl_buf_fill_f32(float *d_dst, float value, size_t count);   /* async    */
  * 4 KiB-aligned for the same reason, xcl2.hpp:61-76) */
 int gl_host_alloc(void **h_ptr, size_t bytes);
 int gl_host_free(void *h_ptr);
+/* Block recycling.  The reference's drivers make a fresh cl::Buffer and a fresh 4 KiB-aligned host vector for
+ * every send_*_host_to_device / send_*_device_to_host (app/bfs.h:107-113, xcl2.hpp:61-76); hipMalloc, hipFree and
+ * hipHostMalloc of 12 MB cost more than the SpMV they serve.  gl_buf_alloc / gl_buf_free therefore recycle device
+ * blocks by size (reuse is ordered by the library's stream), and gl_host_pool_alloc / gl_host_pool_free do the
+ * same for host blocks -- page-locked when >= 64 KiB and the runtime is up, plain 4 KiB-aligned pages otherwise
+ * (they work before gl_init: the C++ layer's aligned_allocator sits on them).  gl_pool_trim returns every cached
+ * block to the driver. */
+int gl_host_pool_alloc(void **h_ptr, size_t bytes);
+int gl_host_pool_free(void *h_ptr);
+int gl_pool_trim(void);
 
 /* --------------------------------------------------------------------- SpMV
  * gl_spmv_plan_create replaces SpMVModule::load_and_format_matrix +

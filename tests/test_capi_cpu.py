@@ -63,6 +63,48 @@ def test_npz_loader_errors(tmp_path):
         io.load_csr_matrix_from_float_npz(str(bad))
 
 
+def test_npz_loader_survives_truncated_and_corrupted_archives(tmp_path, golden_dir):
+    """Every length field of the zip / npy containers comes from the file; a damaged archive must be
+    rejected with GL_ERR_IO (or load, if the damage missed everything that matters) -- never read past
+    the file or allocate by a forged size.  Truncations at every 7th byte + seeded byte flips."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    A = sp.random(64, 64, density=0.1, format="csr", dtype=np.float32, random_state=rng)
+    blobs = []
+    for compressed in (True, False):
+        q = str(tmp_path / ("src%d.npz" % compressed))
+        sp.save_npz(q, A, compressed=compressed)
+        blobs.append(open(q, "rb").read())
+    blobs.append(open(os.path.join(golden_dir, "eye_10_csr_float32.npz"), "rb").read())
+    victim = tmp_path / "victim.npz"
+    outcomes = {"ok": 0, "rejected": 0}
+
+    def attempt(data):
+        victim.write_bytes(data)
+        try:
+            io.load_csr_matrix_from_float_npz(str(victim))
+            outcomes["ok"] += 1
+        except capi.GraphLilyError as e:
+            assert e.code in (capi.GL_ERR_IO, capi.GL_ERR_INVALID_ARG)
+            outcomes["rejected"] += 1
+
+    for blob in blobs:
+        for cut in range(0, len(blob), 7):
+            attempt(blob[:cut])
+        for _ in range(300):
+            b = bytearray(blob)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            attempt(bytes(b))
+        # forged sizes: every 32-bit field of the central directory / end record set to 0xffffffff in turn
+        cd = blob.rfind(b"PK\x01\x02")
+        for off in range(cd, len(blob) - 3, 2):
+            b = bytearray(blob)
+            b[off:off + 4] = b"\xff\xff\xff\xff"
+            attempt(bytes(b))
+    assert outcomes["rejected"] > 500
+
+
 @pytest.mark.skipif(capi.device_count() > 0, reason="checks the no-GPU failure mode")
 def test_compute_fails_loudly_without_gpu():
     with pytest.raises(capi.GraphLilyError):

@@ -131,3 +131,22 @@ def test_two_ranks_sssp(gpu):
     for r in (0, 1):
         for got in out[r]:
             assert np.array_equal(got, ref)
+
+
+def test_bench_self_launches_two_ranks(gpu):
+    """`python bench.py --gpus 2` from a plain shell (no torch.distributed.run around it, WORLD_SIZE unset) starts its
+    own ranks; here both share cuda:0 over gloo (the box has one GPU).  The JSON line must say n_gpus = 2."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-gpu",
+                        "--steps", "20", "--warmup", "2", "--scale", "0.1", "--bfs-runs", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["selfcheck_ok"] is True
+    assert rec["scaling"] == "strong" and "roofline" in rec
+    assert "error" not in rec.get("bfs", {}), rec["bfs"]
