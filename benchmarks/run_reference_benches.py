@@ -27,20 +27,26 @@ def main():
     ap.add_argument("--graph", default="googleplus")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--apps", default="bfs,pagerank,sssp")
+    ap.add_argument("--npz", default=None, help="an already written stand-in (skips generation)")
     args = ap.parse_args()
     import scipy.sparse as sp
     import torch
     from graphlily_amd import datasets
     g = datasets.PAPER_GRAPHS[args.graph]
     dev = torch.device("cuda:0") if torch.cuda.is_available() else None
-    m = datasets.paper_graph(args.graph, args.scale, device=dev)
-    A = sp.csr_matrix((m.adj_data, m.adj_indices.view(np.int32), m.adj_indptr.view(np.int32)),
-                      shape=(m.num_rows, m.num_cols), dtype=np.float32)
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-        path = os.path.join(tmp, "%s_csr_float32.npz" % args.graph)
-        t0 = time.time()
-        sp.save_npz(path, A, compressed=False)
-        print("# %s stand-in: n=%d nnz=%d, npz written in %.1f s" % (args.graph, m.num_rows, m.nnz, time.time() - t0), flush=True)
+        if args.npz:
+            path = args.npz
+            print("# %s stand-in from %s" % (args.graph, path), flush=True)
+        else:
+            m = datasets.paper_graph(args.graph, args.scale, device=dev)
+            A = sp.csr_matrix((m.adj_data, m.adj_indices.view(np.int32), m.adj_indptr.view(np.int32)),
+                              shape=(m.num_rows, m.num_cols), dtype=np.float32)
+            path = os.path.join(tmp, "%s_csr_float32.npz" % args.graph)
+            t0 = time.time()
+            sp.save_npz(path, A, compressed=False)
+            print("# %s stand-in: n=%d nnz=%d, npz written in %.1f s" % (args.graph, m.num_rows, m.nnz, time.time() - t0), flush=True)
+            del m, A
         rc = 0
         for a in args.apps.split(","):
             exe = os.path.join(ROOT, "oracle", "_ref", "bench_%s_on_hip" % a)

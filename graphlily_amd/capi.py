@@ -32,7 +32,7 @@ EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32",
     "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim",
-    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_run",
+    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_plan_export", "gl_spmv_run",
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits", "gl_bfs_pull_step",
     "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run", "gl_spmspv_run_assign",
@@ -83,6 +83,7 @@ def lib():
         "gl_spmv_plan_shape": [vp, P(u32), P(u32), P(u32), P(u64)],
         "gl_spmv_plan_hot": [vp, P(u32), P(u64), P(i32)],
         "gl_spmv_plan_layout": [vp, P(i32)],
+        "gl_spmv_plan_export": [vp, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)],
         "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
         "gl_bfs_pull_step": [vp, vp, vp, vp, f32],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
@@ -252,6 +253,9 @@ def _p(buf):
 GL_PLAN_NO_MULADD = 1
 GL_PLAN_BOOLEAN = 2
 GL_PLAN_KEEP_VALUES = 4
+GL_PLAN_HOST_FORMAT = 8
+GL_PLAN_DEVICE_FORMAT = 16
+PLAN_ARRAYS = {"entries": 0, "bases": 1, "units": 2, "hub_rows": 3, "spans": 4}
 GL_ERR_UNSUPPORTED = -5
 
 
@@ -291,6 +295,14 @@ class SpMVPlan:
     def run(self, x, mask, y, op, zero, mask_type):
         check(lib().gl_spmv_run(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero),
                                 int(mask_type)))
+
+    def export(self, name):
+        """One of the plan's formatted device arrays (PLAN_ARRAYS) as uint32 words (gl_spmv_plan_export)."""
+        n = ctypes.c_size_t(0)
+        check(lib().gl_spmv_plan_export(ctypes.c_void_p(self.handle), PLAN_ARRAYS[name], None, 0, ctypes.byref(n)))
+        out = np.empty(n.value // 4, dtype=np.uint32)
+        check(lib().gl_spmv_plan_export(ctypes.c_void_p(self.handle), PLAN_ARRAYS[name], _np_ptr(out), out.nbytes, ctypes.byref(n)))
+        return out
 
     def bits_words(self):
         v = ctypes.c_uint64(0)

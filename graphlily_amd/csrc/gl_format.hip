@@ -1,0 +1,556 @@
+// Plan creation on the GPU: the O(nnz) half of gl_spmv_plan_create_ex / bool_plan_build.
+//
+// The reference formats its matrices on the host, single-threaded (csr2cpsr, io/data_formatter.h:456-534: 6.8 s for
+// 16.7 M non-zeros); round 1 of this build did it with OpenMP (2.2 s for the 212 M non-zeros of the orkut
+// stand-in).  Here the host keeps only what is O(rows + columns) -- row blocks, hot columns, the packed gather
+// order, hub rows, group budgets: the same code for both formatters -- and the device does everything that touches
+// every non-zero:
+//   * column degrees                      one atomic per entry
+//   * column-constant ("pattern") test    two passes, wave per row
+//   * the per-block column sort           ONE stable radix sort of all entries by (block, hot?, gather index)
+//                                         (rocPRIM; the host sorts each block's records on its own)
+//   * group packing                       a wave per unit walks its sorted piece: a group ends after 64 entries or
+//                                         where the column offset would overflow its 18 bits (64 candidate groups
+//                                         are tested per step, so the walk costs ~1/64 step per group)
+//   * emission                            a wave per group writes the 64 entries in the stream's final
+//                                         lane-interleaved order
+// Both formatters produce byte-identical arrays (tests/test_gpu_format.py compares them through gl_spmv_plan_export).
+#include <cstring>   // rocPRIM's texture iterator calls memset from host code
+
+#include "gl_spmv_plan.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace gl {
+
+struct DevCsr {
+    uint32_t row_begin = 0, row_end = 0;
+    uint64_t nz0 = 0, nnz = 0;
+    uint32_t *d_indptr = nullptr;    // rows + 1 offsets, GLOBAL (subtract nz0)
+    uint32_t *d_indices = nullptr;   // nnz column ids of the shard
+    uint32_t *d_data = nullptr;      // nnz value bits
+    uint32_t *d_colbits = nullptr;   // per column value bits (left by fmt_detect_pattern for the emission's diagonal test)
+    uint32_t num_cols_colbits = 0;
+};
+
+namespace {
+
+struct DevMem {   // scratch that lives for one plan creation
+    void *p = nullptr;
+    ~DevMem() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        GL_HIP(hipMalloc(&p, bytes ? bytes : 16));
+        return GL_OK;
+    }
+    template <typename T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
+constexpr uint32_t kFmtThreads = 256;
+
+inline unsigned wave_grid(uint64_t rows) {   // wave-per-row kernels: 4 waves per workgroup
+    const uint64_t want = (rows + 3) / 4;
+    const uint64_t cap = (uint64_t)ctx().num_cus * 32u;
+    return (unsigned)std::max<uint64_t>(1, std::min(want, cap));
+}
+
+__global__ __launch_bounds__(kFmtThreads) void fmt_degree_kernel(const uint32_t *__restrict__ indices, uint64_t nnz, uint32_t num_cols,
+                                                                 uint32_t *__restrict__ deg, uint32_t *__restrict__ bad) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kFmtThreads + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * kFmtThreads) {
+        const uint32_t c = indices[i];
+        if (c < num_cols) atomicAdd(&deg[c], 1u);
+        else *bad = 1u;
+    }
+}
+
+// pass 1 of the column-constant test: any off-diagonal writer leaves its value bits (all writers of a constant
+// column agree; pass 2 finds out whether they did)
+__global__ __launch_bounds__(kFmtThreads) void fmt_pattern_pass1_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                                        const uint32_t *__restrict__ data, uint32_t row_begin, uint32_t rows,
+                                                                        uint64_t nz0, uint32_t num_cols, uint32_t *__restrict__ colbits) {
+    const uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * (kFmtThreads / 64u);
+    for (uint32_t row = blockIdx.x * (kFmtThreads / 64u) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+        const uint32_t r = row_begin + row;
+        const uint64_t s = indptr[row] - nz0, e = indptr[row + 1] - nz0;
+        for (uint64_t i = s + lane; i < e; i += 64u) {
+            const uint32_t c = indices[i];
+            if (c < num_cols && c != r) {
+                const uint32_t bits = data[i];
+                if (colbits[c] != bits) colbits[c] = bits;   // hub columns: do not hammer a line that already holds the value
+            }
+        }
+    }
+}
+
+// pass 2: every entry equals its column's value, or is the row's one diagonal exception
+__global__ __launch_bounds__(kFmtThreads) void fmt_pattern_pass2_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                                        const uint32_t *__restrict__ data, uint32_t row_begin, uint32_t rows,
+                                                                        uint64_t nz0, uint32_t num_cols, const uint32_t *__restrict__ colbits,
+                                                                        uint32_t *__restrict__ diag_has, uint32_t *__restrict__ diag_val,
+                                                                        uint32_t *__restrict__ mismatch, unsigned long long *__restrict__ exceptions) {
+    const uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * (kFmtThreads / 64u);
+    for (uint32_t row = blockIdx.x * (kFmtThreads / 64u) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+        const uint32_t r = row_begin + row;
+        const uint64_t s = indptr[row] - nz0, e = indptr[row + 1] - nz0;
+        uint32_t nexc = 0;
+        bool bad = false;
+        for (uint64_t i = s + lane; i < e; i += 64u) {
+            const uint32_t c = indices[i], bits = data[i];
+            if (c >= num_cols) { bad = true; continue; }
+            if (colbits[c] == bits) continue;
+            if (c != r) { bad = true; continue; }
+            nexc++;
+            diag_val[row] = bits;
+            atomicOr(&diag_has[row >> 5], 1u << (row & 31u));
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) nexc += __shfl_down(nexc, d);
+        nexc = __shfl(nexc, 0);
+        if (nexc > 1u) bad = true;
+        if (__ballot(bad) != 0ull && lane == 0) *mismatch = 1u;
+        if (nexc && lane == 0) atomicAdd(exceptions, (unsigned long long)nexc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ general / pattern layout
+// key = block << (cb + 1) | hot << cb | gather index;  dropped entries get the bit above the block field
+template <typename K>
+__global__ __launch_bounds__(kFmtThreads) void fmt_keys_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                               const uint32_t *__restrict__ data, uint32_t row_begin, uint32_t rows, uint64_t nz0,
+                                                               uint32_t num_cols, const uint32_t *__restrict__ bstart, uint32_t nblocks,
+                                                               const uint32_t *__restrict__ colmap, const uint32_t *__restrict__ colbits,
+                                                               uint32_t cb, uint32_t bb, K *__restrict__ keys, uint2 *__restrict__ payload) {
+    const uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * (kFmtThreads / 64u);
+    const K drop = (K)1 << (bb + cb + 1u);
+    for (uint32_t row = blockIdx.x * (kFmtThreads / 64u) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+        const uint32_t r = row_begin + row;
+        const uint64_t s = indptr[row] - nz0, e = indptr[row + 1] - nz0;
+        if (s == e) continue;
+        // block of this row: last b with bstart[b] <= r
+        uint32_t lo = 0, hi = nblocks - 1u;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (bstart[mid] <= r) lo = mid; else hi = mid - 1u;
+        }
+        const uint32_t b = lo, r0 = bstart[b];
+        for (uint64_t i = s + lane; i < e; i += 64u) {
+            const uint32_t c = indices[i], v = data[i];
+            K key;
+            if (c >= num_cols || (colbits && c == r && v != colbits[c])) {
+                key = drop;   // the row's diagonal exception lives in diag_val (out-of-range columns were reported earlier)
+            } else {
+                const uint32_t cm = colmap[c];
+                key = ((K)b << (cb + 1u)) | ((K)(cm >> 31) << cb) | (K)(cm & 0x7fffffffu);
+            }
+            keys[i] = key;
+            payload[i] = make_uint2(r - r0, v);
+        }
+    }
+}
+
+// off[i] = first sorted position whose (key >> cb) >= i, i = 2 * block + hot
+template <typename K>
+__global__ __launch_bounds__(kFmtThreads) void fmt_bounds_kernel(const K *__restrict__ keys, uint64_t n, uint32_t count, uint32_t cb,
+                                                                 unsigned long long *__restrict__ off) {
+    const uint32_t i = blockIdx.x * kFmtThreads + threadIdx.x;
+    if (i >= count) return;
+    const K target = (K)i << cb;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    off[i] = lo;
+}
+
+struct UnitDesc {
+    uint32_t cold_begin, cold_end, hot_begin, hot_end;   // positions in the sorted arrays
+    uint32_t goff, r0, nrows_direct, hub_off;            // first group; first row; #rows | direct << 31; first hub_rows slot of the block
+    uint32_t nhub, seg, pad0, pad1;
+};
+
+struct UnitGroups {
+    uint32_t ncold_raw, ncold, nhot_raw, nhot;   // groups with entries / after padding to the stream layout's multiple
+};
+
+// One wave per unit: cut the unit's cold piece into groups.  A group holds <= 64 consecutive entries whose gather
+// index is within 2^18 of its first entry's (the host formatter's rule, gl_spmv.hip).  64 candidate groups per step.
+template <typename K>
+__global__ __launch_bounds__(64) void fmt_group_kernel(const K *__restrict__ keys, const UnitDesc *__restrict__ units, uint32_t cb,
+                                                       uint32_t group_mult, uint32_t *__restrict__ gstart, uint32_t *__restrict__ gcount,
+                                                       UnitGroups *__restrict__ ug, uint4 *__restrict__ plan_units) {
+    const UnitDesc u = units[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const K cmask = ((K)1 << cb) - 1;
+    uint32_t cur = u.cold_begin, g = u.goff;
+    const uint32_t end = u.cold_end;
+    while (cur < end) {
+        const uint32_t p = cur + 64u * lane;
+        bool full = false;
+        if (p < end && end - p >= 64u)
+            full = (uint32_t)(keys[p + 63u] & cmask) - (uint32_t)(keys[p] & cmask) < (1u << kColOffBits);
+        const unsigned long long notfull = __ballot(!full);
+        const uint32_t f = notfull ? (uint32_t)__builtin_ctzll(notfull) : 64u;
+        if (lane < f) {
+            gstart[g + lane] = p;
+            gcount[g + lane] = 64u;
+        }
+        g += f;
+        if (f == 64u) {
+            cur += 64u * 64u;
+            continue;
+        }
+        const uint32_t pf = cur + 64u * f;
+        if (pf >= end) break;
+        const uint32_t j = pf + lane;
+        const bool viol = j < end && (uint32_t)(keys[j] & cmask) - (uint32_t)(keys[pf] & cmask) >= (1u << kColOffBits);
+        const unsigned long long vm = __ballot(viol);
+        const uint32_t cnt = vm ? (uint32_t)__builtin_ctzll(vm) : min(64u, end - pf);
+        if (lane == 0) {
+            gstart[g] = pf;
+            gcount[g] = cnt;
+        }
+        g++;
+        cur = pf + cnt;
+    }
+    const uint32_t ncold_raw = g - u.goff;
+    const uint32_t ncold = (ncold_raw + group_mult - 1u) / group_mult * group_mult;
+    for (uint32_t k = ncold_raw + lane; k < ncold; k += 64u) {   // all-padding groups
+        gstart[u.goff + k] = 0u;
+        gcount[u.goff + k] = 0u;
+    }
+    const uint32_t nhot_raw = (u.hot_end - u.hot_begin + 63u) / 64u;
+    const uint32_t nhot = (nhot_raw + group_mult - 1u) / group_mult * group_mult;
+    if (lane == 0) {
+        ug[blockIdx.x] = UnitGroups{ncold_raw, ncold, nhot_raw, nhot};
+        plan_units[2u * blockIdx.x] = make_uint4(u.goff, ncold, u.r0, u.nrows_direct);
+        plan_units[2u * blockIdx.x + 1u] = make_uint4(u.hub_off, u.nhub, nhot, u.seg);
+    }
+}
+
+// stream layouts as in gl_spmv.hip: 0 narrow (8 B), 1 wide (two 8-B groups lane-interleaved), 2 pair (two 4-B groups),
+// 3 quad (four 4-B groups)
+template <int LAYOUT>
+__device__ __forceinline__ void fmt_store(void *entries, uint32_t g, uint32_t lane, uint32_t ex, uint32_t ey) {
+    if (LAYOUT == 0) static_cast<uint2 *>(entries)[(size_t)g * 64u + lane] = make_uint2(ex, ey);
+    else if (LAYOUT == 1) static_cast<uint2 *>(entries)[(size_t)(g >> 1) * 128u + 2u * lane + (g & 1u)] = make_uint2(ex, ey);
+    else if (LAYOUT == 2) static_cast<uint32_t *>(entries)[(size_t)(g >> 1) * 128u + 2u * lane + (g & 1u)] = ex;
+    else static_cast<uint32_t *>(entries)[(size_t)(g >> 2) * 256u + 4u * lane + (g & 3u)] = ex;
+}
+
+// One workgroup per unit, one wave per group: entry = (gather index - base) << 14 | slot, value.  Hub rows (their list
+// is per block) spread over 16 private slots picked by the entry's position in its group.
+template <typename K, int LAYOUT>
+__global__ __launch_bounds__(kThreads) void fmt_emit_kernel(const K *__restrict__ keys, const uint2 *__restrict__ payload,
+                                                            const UnitDesc *__restrict__ units, const UnitGroups *__restrict__ ug,
+                                                            const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gcount,
+                                                            const uint32_t *__restrict__ hub_rows, uint32_t cb, void *__restrict__ entries,
+                                                            uint32_t *__restrict__ bases) {
+    __shared__ uint8_t hub_of[kMaxBlockRows + 1];
+    const UnitDesc u = units[blockIdx.x];
+    const UnitGroups n = ug[blockIdx.x];
+    const uint32_t nrows = u.nrows_direct & 0xffffu;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const K cmask = ((K)1 << cb) - 1;
+    if (u.nhub) {
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) hub_of[i] = 0xffu;
+        __syncthreads();
+        if (threadIdx.x < u.nhub) hub_of[hub_rows[u.hub_off + threadIdx.x]] = (uint8_t)threadIdx.x;
+        __syncthreads();
+    }
+    const uint32_t total = n.ncold + n.nhot;
+    for (uint32_t k = wave; k < total; k += kWaves) {
+        const uint32_t g = u.goff + k;
+        uint32_t st, cnt, base = 0u;
+        const bool cold = k < n.ncold;
+        if (cold) {
+            st = gstart[g];
+            cnt = gcount[g];
+            if (cnt) base = (uint32_t)(keys[st] & cmask);
+        } else {
+            const uint32_t kh = k - n.ncold;
+            st = u.hot_begin + kh * 64u;
+            cnt = kh < n.nhot_raw ? min(64u, u.hot_end - st) : 0u;
+        }
+        uint32_t ex = kRowPad, ey = 0u;
+        if (lane < cnt) {
+            const uint32_t idx = (uint32_t)(keys[st + lane] & cmask);
+            const uint2 pl = payload[st + lane];
+            uint32_t slot = pl.x;
+            if (u.nhub) {
+                const uint32_t hb = hub_of[pl.x];
+                if (hb != 0xffu) slot = nrows + kHubSlots * hb + (lane & (kHubSlots - 1u));
+            }
+            ex = ((idx - base) << kRowBits) | slot;
+            ey = pl.y;
+        }
+        fmt_store<LAYOUT>(entries, g, lane, ex, ey);
+        if (lane == 0) bases[g] = base;
+    }
+}
+
+__global__ void fmt_fill_u32_kernel(uint32_t *dst, uint32_t v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = v;
+}
+
+template <typename K>
+int sort_pairs(K *kin, K *kout, uint2 *vin, uint2 *vout, uint64_t n, uint32_t bits, hipStream_t s) {
+    size_t tmp_bytes = 0;
+    GL_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, bits, s));
+    DevMem tmp;
+    int rc = tmp.alloc(tmp_bytes);
+    if (rc != GL_OK) return rc;
+    GL_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, bits, s));
+    GL_HIP(hipStreamSynchronize(s));   // tmp dies here
+    return GL_OK;
+}
+
+template <typename K>
+int sort_keys_values_u32(K *kin, K *kout, uint32_t *vin, uint32_t *vout, uint64_t n, uint32_t bits, hipStream_t s) {
+    size_t tmp_bytes = 0;
+    GL_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, bits, s));
+    DevMem tmp;
+    int rc = tmp.alloc(tmp_bytes);
+    if (rc != GL_OK) return rc;
+    GL_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0u, bits, s));
+    GL_HIP(hipStreamSynchronize(s));
+    return GL_OK;
+}
+
+inline uint32_t bits_for(uint64_t count) {   // bits needed to hold values 0 .. count - 1
+    uint32_t b = 1;
+    while ((1ull << b) < count) b++;
+    return b;
+}
+
+template <typename K>
+int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vector<uint32_t> &hub_count, uint64_t *hot_nnz,
+                       uint32_t cb, uint32_t bb) {
+    hipStream_t s = ctx().stream;
+    const BlockPlan &bp = *e.bp;
+    const uint32_t nblocks = bp.nblocks, nunits = bp.nunits;
+    const uint32_t rows = c->row_end - c->row_begin;
+    const uint64_t nnz = c->nnz;
+    const uint64_t total_groups = e.unit_goff[nunits];
+
+    DevMem d_bstart, d_colmap, d_keys, d_keys2, d_pl, d_pl2, d_off;
+    int rc;
+    if ((rc = d_bstart.alloc((size_t)(nblocks + 1) * 4u)) != GL_OK || (rc = d_colmap.alloc((size_t)e.num_cols * 4u)) != GL_OK ||
+        (rc = d_keys.alloc(nnz * sizeof(K))) != GL_OK || (rc = d_keys2.alloc(nnz * sizeof(K))) != GL_OK ||
+        (rc = d_pl.alloc(nnz * 8u)) != GL_OK || (rc = d_pl2.alloc(nnz * 8u)) != GL_OK ||
+        (rc = d_off.alloc((size_t)(2u * nblocks + 1u) * 8u)) != GL_OK)
+        return rc;
+    GL_HIP(hipMemcpyAsync(d_bstart.p, bp.bstart.data(), (size_t)(nblocks + 1) * 4u, hipMemcpyHostToDevice, s));
+    GL_HIP(hipMemcpyAsync(d_colmap.p, e.colmap, (size_t)e.num_cols * 4u, hipMemcpyHostToDevice, s));
+    fmt_keys_kernel<K><<<wave_grid(rows), kFmtThreads, 0, s>>>(c->d_indptr, c->d_indices, c->d_data, c->row_begin, rows, c->nz0, e.num_cols,
+                                                               d_bstart.as<uint32_t>(), nblocks, d_colmap.as<uint32_t>(),
+                                                               e.diag_mode ? c->d_colbits : nullptr, cb, bb, d_keys.as<K>(), d_pl.as<uint2>());
+    GL_LAUNCH_CHECK();
+    if ((rc = sort_pairs<K>(d_keys.as<K>(), d_keys2.as<K>(), d_pl.as<uint2>(), d_pl2.as<uint2>(), nnz, bb + cb + 2u, s)) != GL_OK) return rc;
+    (void)hipFree(d_keys.p); d_keys.p = nullptr;
+    (void)hipFree(d_pl.p); d_pl.p = nullptr;
+    const K *keys = d_keys2.as<K>();
+    const uint2 *payload = d_pl2.as<uint2>();
+    fmt_bounds_kernel<K><<<cdiv(2u * nblocks + 1u, kFmtThreads), kFmtThreads, 0, s>>>(keys, nnz, 2u * nblocks + 1u, cb, d_off.as<unsigned long long>());
+    GL_LAUNCH_CHECK();
+    std::vector<unsigned long long> off(2u * nblocks + 1u);
+    GL_HIP(hipMemcpyAsync(off.data(), d_off.p, off.size() * 8u, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+
+    // ---- host, O(rows): hub rows of every block (same rule as the host formatter) and the unit table
+    std::vector<uint32_t> hub_rows((size_t)nblocks * kMaxHubRows, 0u);
+    hub_count.assign(nblocks, 0u);
+    std::vector<UnitDesc> units(nunits);
+    uint64_t hn = 0;
+    for (uint32_t b = 0; b < nblocks; b++) {
+        const uint32_t r0 = bp.bstart[b], r1 = bp.bstart[b + 1];
+        const uint64_t mc = off[2 * b + 1] - off[2 * b], mh = off[2 * b + 2] - off[2 * b + 1], m = mc + mh;
+        hn += mh;
+        const uint64_t thr = std::max<uint64_t>(256, m / (uint64_t)e.hub_div);
+        uint32_t nh = 0;
+        for (uint32_t r = r0; r < r1 && nh < kMaxHubRows; r++) {
+            uint64_t cnt = (uint64_t)e.h_indptr[r + 1] - e.h_indptr[r];
+            if (cnt < thr) continue;   // (a diagonal exception can only lower it)
+            if (e.diag_mode) {
+                const uint32_t lr = r - c->row_begin;
+                if ((e.diag_has[lr >> 5] >> (lr & 31u)) & 1u) cnt--;
+            }
+            if (cnt >= thr) hub_rows[(size_t)b * kMaxHubRows + nh++] = r - r0;
+        }
+        hub_count[b] = nh;
+        const uint32_t S = bp.seg[b];
+        for (uint32_t sg = 0; sg < S; sg++) {
+            UnitDesc &u = units[bp.unit_of[sg][b]];
+            u.cold_begin = (uint32_t)(off[2 * b] + mc * sg / S);
+            u.cold_end = (uint32_t)(off[2 * b] + mc * (sg + 1) / S);
+            u.hot_begin = (uint32_t)(off[2 * b + 1] + mh * sg / S);
+            u.hot_end = (uint32_t)(off[2 * b + 1] + mh * (sg + 1) / S);
+            u.goff = (uint32_t)e.unit_goff[bp.unit_of[sg][b]];
+            u.r0 = r0;
+            u.nrows_direct = (r1 - r0) | (bp.all_direct ? 0x80000000u : 0u);
+            u.hub_off = (uint32_t)((size_t)b * kMaxHubRows);
+            u.nhub = nh;
+            u.seg = sg;
+            u.pad0 = u.pad1 = 0u;
+        }
+    }
+    *hot_nnz = hn;
+
+    // ---- outputs, sized and padded exactly like the host formatter's vectors
+    const size_t entry_bytes = e.pattern ? (size_t)total_groups * 64u * 4u : (size_t)total_groups * 64u * 8u;
+    const size_t tail_bytes = 128u * 8u;                 // 128 x (kRowPad, kRowPad): the kernels' clamped loads land here
+    const size_t n_bases = (size_t)total_groups + 4u;
+    GL_HIP(hipMalloc((void **)&p->d_entries, entry_bytes + tail_bytes));
+    GL_HIP(hipMalloc((void **)&p->d_bases, n_bases * 4u));
+    GL_HIP(hipMalloc((void **)&p->d_units, (size_t)nunits * 2u * sizeof(uint4) + 16u));
+    GL_HIP(hipMalloc((void **)&p->d_hub_rows, hub_rows.size() * 4u + 16u));
+    p->device_bytes += entry_bytes + tail_bytes + n_bases * 4u + (size_t)nunits * 2u * sizeof(uint4) + hub_rows.size() * 4u;
+    p->b_entries = entry_bytes + tail_bytes;
+    p->b_bases = n_bases * 4u;
+    p->b_units = (size_t)nunits * 2u * sizeof(uint4);
+    p->b_hub_rows = hub_rows.size() * 4u;
+    GL_HIP(hipMemsetAsync(p->d_entries, 0, entry_bytes, s));
+    GL_HIP(hipMemsetAsync(p->d_bases, 0, n_bases * 4u, s));
+    fmt_fill_u32_kernel<<<1, 256, 0, s>>>(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(p->d_entries) + entry_bytes), kRowPad, tail_bytes / 4u);
+    GL_LAUNCH_CHECK();
+    GL_HIP(hipMemcpyAsync(p->d_hub_rows, hub_rows.data(), hub_rows.size() * 4u, hipMemcpyHostToDevice, s));
+
+    DevMem d_units, d_ug, d_gstart, d_gcount;
+    if ((rc = d_units.alloc((size_t)nunits * sizeof(UnitDesc))) != GL_OK || (rc = d_ug.alloc((size_t)nunits * sizeof(UnitGroups))) != GL_OK ||
+        (rc = d_gstart.alloc((size_t)total_groups * 4u)) != GL_OK || (rc = d_gcount.alloc((size_t)total_groups * 4u)) != GL_OK)
+        return rc;
+    GL_HIP(hipMemcpyAsync(d_units.p, units.data(), (size_t)nunits * sizeof(UnitDesc), hipMemcpyHostToDevice, s));
+    fmt_group_kernel<K><<<nunits, 64, 0, s>>>(keys, d_units.as<UnitDesc>(), cb, e.group_mult, d_gstart.as<uint32_t>(), d_gcount.as<uint32_t>(),
+                                              d_ug.as<UnitGroups>(), p->d_units);
+    GL_LAUNCH_CHECK();
+    const int layout = e.pattern ? (e.wide ? 3 : 2) : (e.wide ? 1 : 0);
+#define GL_FMT_EMIT(L)                                                                                                           \
+    fmt_emit_kernel<K, L><<<nunits, kThreads, 0, s>>>(keys, payload, d_units.as<UnitDesc>(), d_ug.as<UnitGroups>(),             \
+                                                      d_gstart.as<uint32_t>(), d_gcount.as<uint32_t>(), p->d_hub_rows, cb,      \
+                                                      (void *)p->d_entries, p->d_bases)
+    switch (layout) {
+        case 0: GL_FMT_EMIT(0); break;
+        case 1: GL_FMT_EMIT(1); break;
+        case 2: GL_FMT_EMIT(2); break;
+        default: GL_FMT_EMIT(3); break;
+    }
+#undef GL_FMT_EMIT
+    GL_LAUNCH_CHECK();
+    GL_HIP(hipStreamSynchronize(s));   // scratch and host vectors die here
+    return GL_OK;
+}
+
+}  // namespace
+
+bool format_on_device(uint32_t flags, uint64_t nnz) {
+    if (flags & GL_PLAN_HOST_FORMAT) return false;
+    if (flags & GL_PLAN_DEVICE_FORMAT) return true;
+    const long forced = env_long("GRAPHLILY_PLAN_DEVICE", -1);
+    if (forced >= 0) return forced != 0;
+    // below ~1 M entries the host formats faster than the device path's allocations and launches cost
+    return nnz >= (1u << 20);
+}
+
+int devcsr_stage(DevCsr **out, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data, uint32_t row_begin,
+                 uint32_t row_end) {
+    DevCsr *c = new DevCsr();
+    c->row_begin = row_begin;
+    c->row_end = row_end;
+    c->nz0 = h_indptr[row_begin];
+    c->nnz = (uint64_t)h_indptr[row_end] - c->nz0;
+    const size_t rows1 = (size_t)(row_end - row_begin) + 1u;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&c->d_indptr, rows1 * 4u)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_indices, c->nnz ? c->nnz * 4u : 16u)) != hipSuccess ||
+        (e = hipMalloc((void **)&c->d_data, c->nnz ? c->nnz * 4u : 16u)) != hipSuccess) {
+        devcsr_release(c);
+        return set_error(GL_ERR_HIP, "plan creation: staging the CSR on the device: %s", hipGetErrorString(e));
+    }
+    hipStream_t s = ctx().stream;
+    // pageable sources copy at PCIe rate on this platform (profiles/r02_ubench_host.txt: 56 GB/s)
+    if ((e = hipMemcpyAsync(c->d_indptr, h_indptr + row_begin, rows1 * 4u, hipMemcpyHostToDevice, s)) != hipSuccess ||
+        (c->nnz && (e = hipMemcpyAsync(c->d_indices, h_indices + c->nz0, c->nnz * 4u, hipMemcpyHostToDevice, s)) != hipSuccess) ||
+        (c->nnz && (e = hipMemcpyAsync(c->d_data, h_data + c->nz0, c->nnz * 4u, hipMemcpyHostToDevice, s)) != hipSuccess) ||
+        (e = hipStreamSynchronize(s)) != hipSuccess) {
+        devcsr_release(c);
+        return set_error(GL_ERR_HIP, "plan creation: uploading the CSR: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return GL_OK;
+}
+
+void devcsr_release(DevCsr *c) {
+    if (!c) return;
+    (void)hipFree(c->d_indptr);
+    (void)hipFree(c->d_indices);
+    (void)hipFree(c->d_data);
+    (void)hipFree(c->d_colbits);
+    delete c;
+}
+
+int fmt_column_degrees(DevCsr *c, uint32_t num_cols, std::vector<uint32_t> &deg, int *bad_col) {
+    hipStream_t s = ctx().stream;
+    DevMem d_deg, d_bad;
+    int rc;
+    if ((rc = d_deg.alloc((size_t)num_cols * 4u)) != GL_OK || (rc = d_bad.alloc(16)) != GL_OK) return rc;
+    GL_HIP(hipMemsetAsync(d_deg.p, 0, (size_t)num_cols * 4u, s));
+    GL_HIP(hipMemsetAsync(d_bad.p, 0, 16, s));
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((c->nnz + kFmtThreads - 1) / kFmtThreads, (uint64_t)ctx().num_cus * 16u));
+    fmt_degree_kernel<<<grid, kFmtThreads, 0, s>>>(c->d_indices, c->nnz, num_cols, d_deg.as<uint32_t>(), d_bad.as<uint32_t>());
+    GL_LAUNCH_CHECK();
+    deg.resize(num_cols);
+    uint32_t bad = 0;
+    GL_HIP(hipMemcpyAsync(deg.data(), d_deg.p, (size_t)num_cols * 4u, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+    *bad_col = bad ? 1 : 0;
+    return GL_OK;
+}
+
+int fmt_detect_pattern(DevCsr *c, uint32_t num_cols, std::vector<uint32_t> &colbits, std::vector<uint32_t> &diag_has,
+                       std::vector<float> &diag_val, int *mismatch, uint64_t *exceptions) {
+    hipStream_t s = ctx().stream;
+    const uint32_t rows = c->row_end - c->row_begin;
+    const size_t words = ((size_t)rows + 31u) / 32u;
+    if (!c->d_colbits) GL_HIP(hipMalloc((void **)&c->d_colbits, (size_t)std::max(num_cols, 1u) * 4u));
+    c->num_cols_colbits = num_cols;
+    DevMem d_has, d_val, d_flags;
+    int rc;
+    if ((rc = d_has.alloc(words * 4u)) != GL_OK || (rc = d_val.alloc((size_t)rows * 4u)) != GL_OK || (rc = d_flags.alloc(16)) != GL_OK) return rc;
+    GL_HIP(hipMemsetAsync(c->d_colbits, 0, (size_t)num_cols * 4u, s));
+    GL_HIP(hipMemsetAsync(d_has.p, 0, words * 4u, s));
+    GL_HIP(hipMemsetAsync(d_val.p, 0, (size_t)rows * 4u, s));
+    GL_HIP(hipMemsetAsync(d_flags.p, 0, 16, s));
+    fmt_pattern_pass1_kernel<<<wave_grid(rows), kFmtThreads, 0, s>>>(c->d_indptr, c->d_indices, c->d_data, c->row_begin, rows, c->nz0, num_cols, c->d_colbits);
+    GL_LAUNCH_CHECK();
+    fmt_pattern_pass2_kernel<<<wave_grid(rows), kFmtThreads, 0, s>>>(c->d_indptr, c->d_indices, c->d_data, c->row_begin, rows, c->nz0, num_cols,
+                                                                  c->d_colbits, d_has.as<uint32_t>(), d_val.as<uint32_t>(), d_flags.as<uint32_t>(),
+                                                                  reinterpret_cast<unsigned long long *>(d_flags.as<uint32_t>() + 2));
+    GL_LAUNCH_CHECK();
+    colbits.resize(num_cols);
+    diag_has.resize(words);
+    diag_val.resize(rows);
+    uint32_t flags[4] = {0, 0, 0, 0};
+    GL_HIP(hipMemcpyAsync(colbits.data(), c->d_colbits, (size_t)num_cols * 4u, hipMemcpyDeviceToHost, s));
+    if (words) GL_HIP(hipMemcpyAsync(diag_has.data(), d_has.p, words * 4u, hipMemcpyDeviceToHost, s));
+    if (rows) GL_HIP(hipMemcpyAsync(diag_val.data(), d_val.p, (size_t)rows * 4u, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipMemcpyAsync(flags, d_flags.p, 16, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+    *mismatch = flags[0] ? 1 : 0;
+    unsigned long long ex;
+    memcpy(&ex, &flags[2], 8);
+    *exceptions = ex;
+    return GL_OK;
+}
+
+int fmt_emit_general(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vector<uint32_t> &hub_count, uint64_t *hot_nnz) {
+    const uint32_t cb = bits_for(std::max<uint64_t>(std::max(e.gather_cols, e.nhot_table), 2u));
+    const uint32_t bb = bits_for(std::max<uint32_t>(e.bp->nblocks, 2u));
+    if (c->nnz >= 0xffffffffull) return set_error(GL_ERR_UNSUPPORTED, "plan creation on the device: more than 2^32 - 1 entries in a shard");
+    if (bb + cb + 2u <= 32u) return emit_general_typed<uint32_t>(c, e, p, hub_count, hot_nnz, cb, bb);
+    return emit_general_typed<unsigned long long>(c, e, p, hub_count, hot_nnz, cb, bb);
+}
+
+}  // namespace gl

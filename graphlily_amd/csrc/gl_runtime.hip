@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 namespace gl {
 
@@ -19,14 +20,31 @@ namespace gl {
 //   device blocks: gl_buf_alloc / gl_buf_free.  Reuse is ordered by the library's stream: a block freed while kernels
 //     that read it are still queued is only ever handed to work enqueued later on the same stream (switching
 //     streams drains the old one first, gl_set_stream).
-//   pinned host blocks: gl_host_pool_alloc / gl_host_pool_free, behind the C++ layer's aligned_allocator.  Large
-//     blocks are page-locked (uploads / downloads are then one DMA at PCIe rate instead of a staged pageable copy);
-//     small ones, and everything before gl_init, come from posix_memalign.
+//   host blocks: gl_host_pool_alloc / gl_host_pool_free, behind the C++ layer's aligned_allocator.  Blocks of
+//     64 KiB and more are recycled, so the drivers' per-call vectors are not mmap'ed and page-faulted in again every
+//     time (glibc gives a 12 MB vector fresh pages: ~3000 faults per fill).  They are NOT page-locked by default:
+//     measured on the MI355X box (scripts/ubench_host.hip, profiles/r02_ubench_host.txt) a 12 MB copy takes 0.23 ms
+//     in either direction from pageable and from page-locked memory alike (56 GB/s), while hipHostMalloc of 12 MB costs
+//     2-2.5 ms -- and a driver whose previous result is still alive needs a new block on its first calls.
+//     GRAPHLILY_HOST_PIN=1 page-locks them for platforms where pageable copies are staged slowly.
 // Cached bytes are capped (GRAPHLILY_POOL_MAX_MB, default 8192 device / 2048 host); gl_pool_trim releases them.
 struct BlockPool {
     std::mutex mu;
-    std::unordered_map<void *, size_t> live;             // block -> rounded size (pinned blocks only, for the host pool)
+    std::unordered_map<void *, size_t> live;             // block -> rounded size | pinned flag (bit 0, host pool)
     std::multimap<size_t, void *> cached;                // rounded size -> free block
+    std::unordered_map<void *, size_t> pinned_cached;    // host pool: cached blocks that are page-locked
+    std::unordered_map<size_t, bool> grown;              // host pool: sizes that got their one extra block (see gl_host_pool_alloc)
+    struct Slab {
+        char *base;
+        size_t size, used;
+    };
+    std::vector<Slab> slabs;                             // device pool: blocks are carved from these
+    size_t slab_live = 0;                                // carved blocks currently handed out
+    bool in_slab(const void *p) const {
+        for (const Slab &s : slabs)
+            if ((const char *)p >= s.base && (const char *)p < s.base + s.size) return true;
+        return false;
+    }
     size_t cached_bytes = 0, cap_bytes = 0;
 };
 
@@ -50,7 +68,17 @@ static inline size_t round_block(size_t bytes) {
     return (bytes + q - 1) / q * q;
 }
 
-constexpr size_t kPinThreshold = 64u << 10;   // host blocks below this are not worth a page-locked mapping
+constexpr size_t kHostPoolThreshold = 64u << 10;   // smaller host blocks go straight to the C library
+constexpr size_t kSpareThreshold = 1u << 20;       // a host-pool miss on a block this large also parks one spare
+constexpr size_t kSlabBytes = 256u << 20;          // device blocks up to a quarter of this are carved from slabs
+static bool pool_trace() {
+    static const bool on = getenv("GRAPHLILY_POOL_TRACE") && atoi(getenv("GRAPHLILY_POOL_TRACE")) != 0;
+    return on;
+}
+static bool spare_on_miss() {
+    static const bool on = !(getenv("GRAPHLILY_POOL_SPARE") && atoi(getenv("GRAPHLILY_POOL_SPARE")) == 0);
+    return on;
+}
 
 Context &ctx() {
     static Context c;
@@ -193,10 +221,31 @@ int gl_buf_alloc(void **d_ptr, size_t bytes) {
             *d_ptr = it->second;
             P.cached.erase(it);
             P.cached_bytes -= want;
-            P.live[*d_ptr] = want;
+            P.live[*d_ptr] = want | (P.in_slab(*d_ptr) ? 1u : 0u);
             return GL_OK;
         }
+        // Not cached: carve it from a slab.  A genuine hipMalloc costs 0.2 ms (rocprofv3 trace of the reference's
+        // bench_bfs on this backend) and a driver that re-sends its vectors on every call (app/bfs.h:107-113) holds
+        // the previous call's buffers while it allocates the new ones, so its first calls all miss the cache;
+        // carving makes a miss as cheap as a hit.  Blocks above a quarter slab get their own allocation.
+        if (want <= gl::kSlabBytes / 4) {
+            if (P.slabs.empty() || P.slabs.back().size - P.slabs.back().used < want) {
+                void *base = nullptr;
+                if (gl::pool_trace()) fprintf(stderr, "[pool] new device slab (%zu MB) for a %zu-byte block\n", gl::kSlabBytes >> 20, want);
+                if (hipMalloc(&base, gl::kSlabBytes) == hipSuccess) P.slabs.push_back(gl::BlockPool::Slab{(char *)base, gl::kSlabBytes, 0});
+                else (void)hipGetLastError();   // no room for a slab: plain allocation below
+            }
+            if (!P.slabs.empty() && P.slabs.back().size - P.slabs.back().used >= want) {
+                gl::BlockPool::Slab &sl = P.slabs.back();
+                *d_ptr = sl.base + sl.used;
+                sl.used += want;
+                P.live[*d_ptr] = want | 1u;
+                P.slab_live++;
+                return GL_OK;
+            }
+        }
     }
+    if (gl::pool_trace()) fprintf(stderr, "[pool] device miss %zu bytes\n", want);
     hipError_t e = hipMalloc(d_ptr, want);
     if (e != hipSuccess) {   // out of memory with blocks parked in the pool: release them and try once more
         (void)hipGetLastError();
@@ -213,15 +262,16 @@ int gl_buf_free(void *d_ptr) {
     GL_REQUIRE_INIT();
     if (!d_ptr) return GL_OK;
     gl::BlockPool &P = gl::device_pool();
-    size_t sz = 0;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         if (!P.cap_bytes) P.cap_bytes = gl::pool_cap("device", 8192);
         auto it = P.live.find(d_ptr);
         if (it != P.live.end()) {
-            sz = it->second;
+            const size_t sz = it->second & ~(size_t)1;
+            const bool slab = (it->second & 1u) != 0;
             P.live.erase(it);
-            if (P.cached_bytes + sz <= P.cap_bytes) {
+            if (slab) P.slab_live--;
+            if (slab || P.cached_bytes + sz <= P.cap_bytes) {   // slab blocks can only be recycled
                 P.cached.emplace(sz, d_ptr);
                 P.cached_bytes += sz;
                 return GL_OK;
@@ -236,17 +286,35 @@ int gl_pool_trim(void) {
     for (int host = 0; host < 2; host++) {
         gl::BlockPool &P = host ? gl::host_pool() : gl::device_pool();
         std::multimap<size_t, void *> drop;
+        std::unordered_map<void *, size_t> pinned;
+        std::vector<gl::BlockPool::Slab> slabs;
         {
             std::lock_guard<std::mutex> lk(P.mu);
-            drop.swap(P.cached);
-            P.cached_bytes = 0;
+            if (!host && P.slab_live) {   // carved blocks are still out: only the separately allocated ones can go
+                for (auto it = P.cached.begin(); it != P.cached.end();) {
+                    if (P.in_slab(it->second)) { ++it; continue; }
+                    drop.emplace(it->first, it->second);
+                    P.cached_bytes -= it->first;
+                    it = P.cached.erase(it);
+                }
+            } else {
+                drop.swap(P.cached);
+                pinned.swap(P.pinned_cached);
+                slabs.swap(P.slabs);
+                P.cached_bytes = 0;
+            }
         }
-        if (drop.empty()) continue;
+        if (drop.empty() && slabs.empty()) continue;
         if (!host && gl::ctx().initialized) (void)hipStreamSynchronize(gl::ctx().stream);   // queued work may still use them
         for (auto &kv : drop) {
-            if (host) (void)hipHostFree(kv.second);
-            else (void)hipFree(kv.second);
+            bool carved = false;
+            for (const gl::BlockPool::Slab &sl : slabs) carved = carved || ((char *)kv.second >= sl.base && (char *)kv.second < sl.base + sl.size);
+            if (carved) continue;
+            if (!host) (void)hipFree(kv.second);
+            else if (pinned.count(kv.second)) (void)hipHostFree(kv.second);
+            else free(kv.second);
         }
+        for (const gl::BlockPool::Slab &sl : slabs) (void)hipFree(sl.base);
     }
     return GL_OK;
 }
@@ -255,9 +323,10 @@ int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
     GL_ARG(h_ptr != nullptr);
     *h_ptr = nullptr;
     if (bytes == 0) bytes = 1;
-    if (bytes >= gl::kPinThreshold && gl::ctx().initialized) {
+    if (bytes >= gl::kHostPoolThreshold) {
         gl::BlockPool &P = gl::host_pool();
-        const size_t want = gl::round_block(bytes);
+        const size_t want = gl::round_block(bytes);   // multiple of 4096: bit 0 is free for the pinned flag
+        bool hit = false, grow = false;
         {
             std::lock_guard<std::mutex> lk(P.mu);
             auto it = P.cached.find(want);
@@ -265,17 +334,61 @@ int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
                 *h_ptr = it->second;
                 P.cached.erase(it);
                 P.cached_bytes -= want;
-                P.live[*h_ptr] = want;
-                return GL_OK;
+                P.live[*h_ptr] = want | P.pinned_cached[*h_ptr];
+                P.pinned_cached.erase(*h_ptr);
+                // A driver call needs one block more from its second call on: the previous call's result is still
+                // alive while the new one is allocated (kernel_results = bfs.pull(...), benchmark/bench_bfs.cpp:60).
+                // The first time a large size class runs empty it therefore gets one extra paged-in block -- once;
+                // the cost (a 12 MB block: ~2 ms of page faults) lands in the call that emptied it, not in the next.
+                grow = want >= gl::kSpareThreshold && gl::spare_on_miss() && P.cached.find(want) == P.cached.end() && !P.grown[want];
+                if (grow) P.grown[want] = true;
+                hit = true;
             }
         }
-        if (hipHostMalloc(h_ptr, want, hipHostMallocDefault) == hipSuccess) {
-            std::lock_guard<std::mutex> lk(P.mu);
-            P.live[*h_ptr] = want;
+        if (hit) {
+            void *extra = nullptr;
+            if (grow && posix_memalign(&extra, 4096, want) == 0) {
+                memset(extra, 0, want);
+                std::lock_guard<std::mutex> lk(P.mu);
+                P.cached.emplace(want, extra);
+                P.cached_bytes += want;
+            }
             return GL_OK;
         }
-        (void)hipGetLastError();   // cannot pin (limits): plain pages below
-        *h_ptr = nullptr;
+        if (gl::pool_trace()) fprintf(stderr, "[pool] host miss %zu bytes\n", want);
+        static const bool pin = getenv("GRAPHLILY_HOST_PIN") && atoi(getenv("GRAPHLILY_HOST_PIN")) != 0;
+        size_t pinned = 0;
+        if (pin && gl::ctx().initialized) {
+            if (hipHostMalloc(h_ptr, want, hipHostMallocDefault) == hipSuccess) pinned = 1;
+            else {
+                (void)hipGetLastError();   // cannot pin (limits): plain pages below
+                *h_ptr = nullptr;
+            }
+        }
+        if (!pinned && posix_memalign(h_ptr, 4096, want) != 0) {
+            *h_ptr = nullptr;
+            return gl::set_error(GL_ERR_INVALID_ARG, "gl_host_pool_alloc: out of host memory (%zu bytes)", want);
+        }
+        // a miss on a large block parks one spare, and both are paged in now (a fresh 12 MB block costs ~3000 page
+        // faults on first touch: 2 ms inside a 2 ms BFS, tests/cpp/api_breakdown.cpp)
+        void *spare = nullptr;
+        if (!pinned && want >= gl::kSpareThreshold && gl::spare_on_miss()) {
+            memset(*h_ptr, 0, want);
+            if (posix_memalign(&spare, 4096, want) == 0) memset(spare, 0, want);
+            else spare = nullptr;
+        }
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.live[*h_ptr] = want | pinned;
+        if (spare) {
+            if (!P.cap_bytes) P.cap_bytes = gl::pool_cap("host", 2048);
+            if (P.cached_bytes + want <= P.cap_bytes) {
+                P.cached.emplace(want, spare);
+                P.cached_bytes += want;
+            } else {
+                free(spare);
+            }
+        }
+        return GL_OK;
     }
     if (posix_memalign(h_ptr, 4096, bytes) != 0) {
         *h_ptr = nullptr;
@@ -287,23 +400,27 @@ int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
 int gl_host_pool_free(void *h_ptr) {
     if (!h_ptr) return GL_OK;
     gl::BlockPool &P = gl::host_pool();
+    size_t tag;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         if (!P.cap_bytes) P.cap_bytes = gl::pool_cap("host", 2048);
         auto it = P.live.find(h_ptr);
         if (it == P.live.end()) {
-            free(h_ptr);   // a posix_memalign block
+            free(h_ptr);   // a small block
             return GL_OK;
         }
-        const size_t sz = it->second;
+        tag = it->second;
         P.live.erase(it);
+        const size_t sz = tag & ~(size_t)1;
         if (P.cached_bytes + sz <= P.cap_bytes) {
             P.cached.emplace(sz, h_ptr);
+            if (tag & 1) P.pinned_cached[h_ptr] = 1;
             P.cached_bytes += sz;
             return GL_OK;
         }
     }
-    (void)hipHostFree(h_ptr);
+    if (tag & 1) (void)hipHostFree(h_ptr);
+    else free(h_ptr);
     return GL_OK;
 }
 

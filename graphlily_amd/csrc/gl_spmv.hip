@@ -762,6 +762,18 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         return GL_OK;
     }
 
+    // ---- where the O(nnz) steps run: on the device over a staged copy of the shard's CSR (gl_format.hip), or here
+    //      with OpenMP (small matrices, GL_PLAN_HOST_FORMAT; the two produce identical arrays)
+    struct Staged {
+        gl::DevCsr *c = nullptr;
+        ~Staged() { gl::devcsr_release(c); }
+    } staged;
+    const bool on_device = nnz > 0 && gl::format_on_device(flags, nnz);
+    if (on_device) {
+        const int src = gl::devcsr_stage(&staged.c, h_indptr, h_indices, h_data, row_begin, row_end);
+        if (src != GL_OK) return src;
+    }
+
     // ---- row blocks and segments per block (gl_spmv_plan.h)
     const gl::Shape shape = gl::choose_shape(rows, num_cols, nnz, gl::ctx().num_cus);
     const gl::BlockPlan bp = gl::plan_blocks(shape, h_indptr, row_begin, row_end, gl::kMaxPlainRows);
@@ -773,7 +785,13 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     //      H = what fits next to the tallest f64 tile (incl. worst-case hub slots).
     std::vector<uint32_t> hot_cols, hot_slot;   // slot -> column, column -> slot (0xffffffff = cold)
     std::vector<uint32_t> deg;                  // non-zeros per column within the shard
-    if (nnz > 0) {
+    if (on_device) {
+        int bad = 0;
+        const int drc = gl::fmt_column_degrees(staged.c, num_cols, deg, &bad);
+        if (drc != GL_OK) return drc;
+        if (bad)
+            return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", num_cols);
+    } else if (nnz > 0) {
         deg.assign(num_cols, 0);
         // sequential on purpose: atomics from all cores pile up on the hub columns' counters (measured slower)
         for (uint64_t i = nz0; i < nz1; i++)
@@ -872,11 +890,15 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         // Diagonal entries are looked at separately: a matrix that is column-constant apart from its diagonal
         // (SSSP's unit weights + zero self edges, app/sssp.h:16-62) keeps the pattern layout, the diagonal goes
         // into a per-row array that the epilogue folds in.
+        int mismatch = 0;
+        uint64_t exceptions = 0;
+        if (on_device) {
+            const int prc = gl::fmt_detect_pattern(staged.c, num_cols, colbits, diag_has, diag_val, &mismatch, &exceptions);
+            if (prc != GL_OK) return prc;
+        } else {
         colbits.assign(num_cols, 0u);
         diag_has.assign((size_t)(rows + 31) / 32, 0u);
         diag_val.assign(rows, 0.0f);
-        int mismatch = 0;
-        uint64_t exceptions = 0;
         // pass 1: any writer wins (all of a column's writers agree if the column is constant); pass 2 verifies
 #pragma omp parallel for schedule(static, 4096)
         for (int64_t r = row_begin; r < (int64_t)row_end; r++)
@@ -904,6 +926,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             if (nexc > 1) mismatch = 1;   // several different diagonal values in one row: keep the general layout
             exceptions += nexc;
         }
+        }
         pattern = !mismatch;
         diag_mode = pattern && exceptions > 0;
     }
@@ -926,15 +949,46 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     const uint64_t total_groups = unit_goff[nunits];
     GL_ARG(total_groups < 0xffffffffull);
 
-    std::vector<uint2> entries(total_groups * 64);
-    std::vector<uint32_t> bases(total_groups);
-    std::vector<uint4> units((size_t)nunits * 2);
-    std::vector<uint32_t> hub_rows((size_t)nblocks * gl::kMaxHubRows, 0);   // slot b*kMaxHubRows + h
+    std::vector<uint2> entries;
+    std::vector<uint32_t> bases;
+    std::vector<uint4> units;
+    std::vector<uint32_t> hub_rows;   // slot b*kMaxHubRows + h
     std::vector<uint32_t> hub_count(nblocks, 0);
     uint32_t max_rows = 0;
     int bad_col = 0;
     uint64_t hot_nnz = 0;
+    gl_spmv_plan p = new gl_spmv_plan_s();
 
+    if (on_device) {
+        // ---- the per-block column sort, group packing and emission on the device (gl_format.hip)
+        std::vector<uint32_t> colmap(num_cols);
+        for (uint32_t c = 0; c < num_cols; c++)
+            colmap[c] = (have_hot && hot_slot[c] != 0xffffffffu) ? (0x80000000u | hot_slot[c]) : (compact ? (cmap[c] & 0x7fffffffu) : c);
+        gl::EmitGeneral eg;
+        eg.bp = &bp;
+        eg.unit_goff = unit_goff.data();
+        eg.colmap = colmap.data();
+        eg.gather_cols = gather_cols;
+        eg.nhot_table = nhot_table;
+        eg.diag_mode = diag_mode;
+        eg.colbits = colbits.data();
+        eg.diag_has = diag_has.data();
+        eg.pattern = pattern;
+        eg.wide = wide;
+        eg.group_mult = group_mult;
+        eg.hub_div = (uint32_t)std::max<long>(1, gl::env_long("GRAPHLILY_SPMV_HUB_DIV", 48));
+        eg.h_indptr = h_indptr;
+        eg.num_cols = num_cols;
+        const int erc = gl::fmt_emit_general(staged.c, eg, p, hub_count, &hot_nnz);
+        if (erc != GL_OK) {
+            gl_spmv_plan_destroy(p);
+            return erc;
+        }
+    } else {
+    entries.resize(total_groups * 64);
+    bases.resize(total_groups);
+    units.resize((size_t)nunits * 2);
+    hub_rows.assign((size_t)nblocks * gl::kMaxHubRows, 0);
 #pragma omp parallel reduction(+ : hot_nnz)
     {
         std::vector<gl::Rec> recs, tmp, hot;
@@ -1030,12 +1084,14 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             }
         }
     }
-    if (bad_col)
+    }   // host emission
+    if (bad_col) {
+        gl_spmv_plan_destroy(p);
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", num_cols);
+    }
     for (uint32_t b = 0; b < nblocks; b++)
         max_rows = std::max(max_rows, bstart[b + 1] - bstart[b] + gl::kHubSlots * hub_count[b]);   // LDS slots
 
-    gl_spmv_plan p = new gl_spmv_plan_s();
     p->num_rows = num_rows;
     p->num_cols = num_cols;
     p->row_begin = row_begin;
@@ -1076,7 +1132,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     };
     p->pattern = pattern;
     p->wide = wide;
-    if (wide && !pattern) {
+    if (wide && !pattern && !on_device) {
         // pair P = groups 2P, 2P+1 -> lane l holds { A[l], B[l] } (two uint2 = one 16-byte load)
         const uint64_t npairs = total_groups / 2;
 #pragma omp parallel for schedule(static)
@@ -1089,7 +1145,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             }
         }
     }
-    if (pattern) {
+    if (pattern && !on_device) {
         // 4-byte entries, lane-interleaved: pair P = groups 2P (-> .x), 2P+1 (-> .y); or quad Q = groups 4Q .. 4Q+3
         // (-> .x .y .z .w of one 16-byte element = two consecutive uint2)
         const uint64_t npairs = total_groups / 2;
@@ -1112,14 +1168,23 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     }
     // one element of slack: the kernel's loads are unconditional and clamp to a unit's last element, which for a unit
     // without groups is the element that follows it
-    entries.insert(entries.end(), 128, make_uint2(gl::kRowPad, gl::kRowPad));
-    bases.insert(bases.end(), 4, 0u);
-    int rc;
-    if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * sizeof(uint2))) != GL_OK ||
-        (rc = up((void **)&p->d_bases, bases.data(), bases.size() * sizeof(uint32_t))) != GL_OK ||
-        (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK ||
-        (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK ||
-        (rc = up((void **)&p->d_hot_cols, hot_cols.data(), hot_cols.size() * sizeof(uint32_t))) != GL_OK ||
+    int rc = GL_OK;
+    if (!on_device) {   // (the device formatter wrote these four arrays in place)
+        entries.insert(entries.end(), 128, make_uint2(gl::kRowPad, gl::kRowPad));
+        bases.insert(bases.end(), 4, 0u);
+        if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * sizeof(uint2))) != GL_OK ||
+            (rc = up((void **)&p->d_bases, bases.data(), bases.size() * sizeof(uint32_t))) != GL_OK ||
+            (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK ||
+            (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK) {
+            gl_spmv_plan_destroy(p);
+            return rc;
+        }
+        p->b_entries = entries.size() * sizeof(uint2);
+        p->b_bases = bases.size() * sizeof(uint32_t);
+        p->b_units = units.size() * sizeof(uint4);
+        p->b_hub_rows = hub_rows.size() * sizeof(uint32_t);
+    }
+    if ((rc = up((void **)&p->d_hot_cols, hot_cols.data(), hot_cols.size() * sizeof(uint32_t))) != GL_OK ||
         (rc = up((void **)&p->d_blocks, blocks.data(), blocks.size() * sizeof(uint4))) != GL_OK ||
         (rc = up((void **)&p->d_hot_x, nullptr, 0)) != GL_OK) {
         gl_spmv_plan_destroy(p);
@@ -1257,6 +1322,29 @@ int gl_bfs_pull_step(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits
     if (!p->boolean)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step: the plan does not hold the GL_PLAN_BOOLEAN layout");
     return gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, gl::ctx().stream);
+}
+
+int gl_spmv_plan_export(gl_spmv_plan p, int array, void *h_dst, size_t capacity, size_t *bytes) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && bytes != nullptr);
+    const void *src = nullptr;
+    size_t n = 0;
+    switch (array) {
+        case GL_PLAN_ARRAY_ENTRIES: src = p->d_entries, n = p->b_entries; break;
+        case GL_PLAN_ARRAY_BASES: src = p->d_bases, n = p->b_bases; break;
+        case GL_PLAN_ARRAY_UNITS: src = p->d_units, n = p->b_units; break;
+        case GL_PLAN_ARRAY_HUB_ROWS: src = p->d_hub_rows, n = p->b_hub_rows; break;
+        case GL_PLAN_ARRAY_SPANS: src = p->d_spans, n = p->b_spans; break;
+        default: return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_export: unknown array %d", array);
+    }
+    *bytes = n;
+    if (!h_dst) return GL_OK;
+    GL_ARG(capacity >= n);
+    if (n) {
+        GL_HIP(hipStreamSynchronize(gl::ctx().stream));
+        GL_HIP(hipMemcpy(h_dst, src, n, hipMemcpyDeviceToHost));
+    }
+    return GL_OK;
 }
 
 int gl_spmv_plan_layout(gl_spmv_plan p, int *layout) {

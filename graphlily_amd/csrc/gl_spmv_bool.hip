@@ -537,6 +537,11 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
         (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK ||
         (rc = up((void **)&p->d_spans, spans.data(), spans.size() * sizeof(uint4))) != GL_OK)
         return rc;
+    p->b_entries = entries.size() * 4u;
+    p->b_bases = bases.size() * 4u;
+    p->b_units = units.size() * sizeof(uint4);
+    p->b_hub_rows = hub_rows.size() * sizeof(uint32_t);
+    p->b_spans = spans.size() * sizeof(uint4);
     GL_HIP(hipMalloc((void **)&p->d_xbits, (size_t)nphases * kBoolPhaseWords * 4u));
     p->device_bytes += (size_t)nphases * kBoolPhaseWords * 4u;
     return GL_OK;

@@ -120,9 +120,49 @@ struct gl_spmv_plan_s {
     uint4 *d_spans = nullptr;      // {first word of the phase in xbits, first group, end group, lo4 | hi4 << 16}
     uint32_t *d_xbits = nullptr;   // nphases * kBoolPhaseWords words
     uint64_t device_bytes = 0;
+    size_t b_entries = 0, b_bases = 0, b_units = 0, b_hub_rows = 0, b_spans = 0;   // sizes of the formatted arrays (gl_spmv_plan_export)
 };
 
 namespace gl {
+// ------------------------------------------------------------------------------------------ gl_format.hip
+// Plan creation on the GPU.  The O(rows + columns) decisions of a plan -- row blocks, hot columns,
+// packed gather order, hub rows, group budgets -- stay on the host and are shared with the host formatter; every
+// O(nnz) step runs on the device over a staged copy of the shard's CSR: column degrees, column-constant ("pattern")
+// detection, and the per-block column sort + group packing that produces the entry stream.  Both formatters
+// produce byte-identical device arrays (tests/test_gpu_format.py).
+struct DevCsr;   // the shard's indptr / indices / data on the device
+int devcsr_stage(DevCsr **out, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
+                 uint32_t row_begin, uint32_t row_end);
+void devcsr_release(DevCsr *c);
+bool format_on_device(uint32_t flags, uint64_t nnz);   // policy: GL_PLAN_HOST_FORMAT / GRAPHLILY_PLAN_DEVICE / size
+int fmt_column_degrees(DevCsr *c, uint32_t num_cols, std::vector<uint32_t> &deg, int *bad_col);
+int fmt_detect_pattern(DevCsr *c, uint32_t num_cols, std::vector<uint32_t> &colbits, std::vector<uint32_t> &diag_has,
+                       std::vector<float> &diag_val, int *mismatch, uint64_t *exceptions);
+
+struct EmitGeneral {   // what the host planner decided (gl_spmv_plan_create_ex)
+    const BlockPlan *bp;
+    const uint64_t *unit_goff;         // nunits + 1 group offsets (budgets)
+    const uint32_t *colmap;            // per column: 0x80000000 | hot slot, or the index the cold entry gathers from
+    uint32_t gather_cols, nhot_table;  // ranges of those two index spaces
+    bool diag_mode;                    // diagonal entries that differ from their column's value are dropped
+    const uint32_t *colbits;           // host copy of the column values (diag_mode)
+    const uint32_t *diag_has;          // host bitmap of the rows whose diagonal entry is an exception (diag_mode)
+    bool pattern, wide;
+    uint32_t group_mult;
+    uint32_t hub_div;
+    const uint32_t *h_indptr;          // host indptr (global), for the per-row counts
+    uint32_t num_cols;
+};
+// fills p->d_entries / d_bases / d_units / d_hub_rows (allocated here) and hub_count, hot_nnz
+int fmt_emit_general(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vector<uint32_t> &hub_count, uint64_t *hot_nnz);
+// (||,&&) layout: the device twin of bool_plan_build's record loop (gl_spmv_bool.hip)
+struct EmitBool {
+    const BlockPlan *bp;
+    const uint32_t *h_indptr;
+    uint32_t num_cols;
+};
+int fmt_emit_bool(DevCsr *c, const EmitBool &e, gl_spmv_plan p, uint32_t *max_rows);
+
 // gl_spmv_bool.hip
 int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data);
 int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const float *d_mask, float *d_y, float zero,

@@ -163,15 +163,23 @@ class SpMVModule(BaseModule):
         self.results_buf = capi.DeviceBuffer(4 * m.num_rows)
         capi.fill_f32(self.results_buf, 0.0, m.num_rows)  # spmv_module.h:368-369
 
+    @staticmethod
+    def _upload_dense(host, n):
+        """Fresh n-float buffer holding `host`, zero-padded when it is shorter (device blocks are recycled:
+        nothing may be assumed about what a new buffer holds)."""
+        host = np.ascontiguousarray(host, dtype=np.float32)[:n]
+        buf = capi.DeviceBuffer(4 * n)
+        buf.write(host)
+        if host.shape[0] < n:
+            tail = capi.DeviceBuffer(4 * (n - host.shape[0]), ptr=buf.ptr + 4 * host.shape[0], keepalive=buf)
+            capi.fill_f32(tail, 0.0, n - host.shape[0])
+        return buf
+
     def send_vector_host_to_device(self, vector):
-        vector = np.ascontiguousarray(vector, dtype=np.float32)
-        self.vector_buf = capi.DeviceBuffer(4 * self.get_num_cols())
-        self.vector_buf.write(vector[:self.get_num_cols()])
+        self.vector_buf = self._upload_dense(vector, self.get_num_cols())
 
     def send_mask_host_to_device(self, mask):
-        mask = np.ascontiguousarray(mask, dtype=np.float32)
-        self.mask_buf = capi.DeviceBuffer(4 * self.get_num_rows())
-        self.mask_buf.write(mask[:self.get_num_rows()])
+        self.mask_buf = self._upload_dense(mask, self.get_num_rows())
 
     def bind_mask_buf(self, src_buf):
         self.mask_buf = src_buf

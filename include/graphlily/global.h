@@ -24,9 +24,9 @@
 
 // Host vectors handed to the device are page aligned in the reference (xcl2.hpp:61-76,
 // aligned_allocator at global scope); kept so that caller code naming it compiles unchanged.
-// Blocks come from the library's host pool (gl_host_pool_alloc): 4 KiB aligned like the reference's, and -- once
-// the runtime is up -- page-locked and recycled by size, so the n-element vectors the drivers build for every
-// pull() / push() call (app/bfs.h:107-113) cost neither page faults nor a staged pageable copy.
+// Blocks come from the library's host pool (gl_host_pool_alloc): 4 KiB aligned like the reference's and recycled
+// by size, so the n-element vectors the drivers build for every pull() / push() call (app/bfs.h:107-113) are not
+// mapped and page-faulted in afresh each time.
 template <typename T>
 struct aligned_allocator {
     using value_type = T;

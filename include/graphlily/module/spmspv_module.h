@@ -32,18 +32,16 @@ class SpMSpVModule : public BaseModule {
     bool sharded_ = false;
     CSCMatrix<float> csc_matrix_float_;
     gl_spmspv_plan plan_ = nullptr;
-    aligned_sparse_vec_t vector_, results_;   // host staging for the by-value returns
-    aligned_dense_vec_t mask_;
-
-    static aligned_sparse_vec_t download_sparse_(const DeviceBuffer &buf, aligned_sparse_vec_t &stage) {
+    // sparse vectors come back at their full capacity like the reference's mirrors (:53-60), zero beyond the entries
+    // the head counts; only the head and those entries are transferred
+    static aligned_sparse_vec_t download_sparse_(const DeviceBuffer &buf) {
         const size_t slots = buf.size() / sizeof(idx_val_t);
-        if (stage.size() != slots) stage.assign(slots, idx_val_t{0, 0});
-        if (!slots) return stage;
+        aligned_sparse_vec_t out(slots, idx_val_t{0, 0});
+        if (!slots) return out;
         uint32_t nnz = 0;
         GRAPHLILY_CHECK(gl_sparse_nnz((const gl_idx_val *)buf.ptr(), &nnz));
-        const size_t used = std::min(slots, (size_t)nnz + 1);
-        buf.download(stage.data(), sizeof(idx_val_t) * used);
-        return stage;
+        buf.download(out.data(), sizeof(idx_val_t) * std::min(slots, (size_t)nnz + 1));
+        return out;
     }
 
 public:
@@ -129,15 +127,13 @@ public:
         finish_();
     }
 
-    // sparse vectors come back at their full capacity like the reference's mirrors, but only the head and the
-    // entries it counts are transferred (the rest of the staging vector keeps whatever it held)
-    aligned_sparse_vec_t send_vector_device_to_host() { return download_sparse_(vector_buf, vector_); }
+    aligned_sparse_vec_t send_vector_device_to_host() { return download_sparse_(vector_buf); }
     aligned_dense_vec_t send_mask_device_to_host() {
-        mask_.resize(mask_buf.size() / sizeof(float));
-        mask_buf.download(mask_.data(), sizeof(float) * mask_.size());
-        return mask_;
+        aligned_dense_vec_t out(mask_buf.size() / sizeof(float));
+        mask_buf.download(out.data(), sizeof(float) * out.size());
+        return out;
     }
-    aligned_sparse_vec_t send_results_device_to_host() { return download_sparse_(results_buf, results_); }
+    aligned_sparse_vec_t send_results_device_to_host() { return download_sparse_(results_buf); }
 
     // the per-iteration device->host control read of the push loops (reference :239-242)
     uint32_t get_results_nnz() {

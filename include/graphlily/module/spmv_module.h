@@ -33,9 +33,9 @@ class SpMVModule : public BaseModule {
     CSRMatrix<float> csr_matrix_float_;
     gl_spmv_plan plan_ = nullptr;
     uint32_t plan_flags_ = 0;
-    // host staging for the by-value returns of send_*_device_to_host (the reference's host mirrors, :67-70; their
-    // contents are only ever observable after a download, so uploads go straight from the caller's vector)
-    aligned_dense_vec_t vector_, mask_, results_;
+    // The reference keeps host mirrors of its three buffers (:67-70).  Their contents are only ever observable through
+    // send_*_device_to_host, i.e. after a download, so uploads go straight from the caller's vector and downloads
+    // straight into the vector that is returned.
 
     // upload `n` floats taken from `src` (zero-padded if it is shorter) into a fresh buffer
     static DeviceBuffer upload_dense_(aligned_dense_vec_t &src, size_t n) {
@@ -45,10 +45,10 @@ class SpMVModule : public BaseModule {
         if (have < n) GRAPHLILY_CHECK(gl_buf_fill_f32((float *)buf.ptr() + have, 0.0f, n - have));
         return buf;
     }
-    static aligned_dense_vec_t download_dense_(const DeviceBuffer &buf, aligned_dense_vec_t &stage, size_t n) {
-        stage.resize(n);
-        buf.download(stage.data(), sizeof(float) * n);
-        return stage;
+    static aligned_dense_vec_t download_dense_(const DeviceBuffer &buf, size_t n) {
+        aligned_dense_vec_t out(n);
+        buf.download(out.data(), sizeof(float) * n);
+        return out;
     }
 
     // The semiring known at upload time picks the layout: pattern-only entries and a bit vector for (||,&&),
@@ -153,9 +153,9 @@ public:
         finish_();
     }
 
-    aligned_dense_vec_t send_vector_device_to_host() { return download_dense_(vector_buf, vector_, get_num_cols()); }
-    aligned_dense_vec_t send_mask_device_to_host() { return download_dense_(mask_buf, mask_, get_num_rows()); }
-    aligned_dense_vec_t send_results_device_to_host() { return download_dense_(results_buf, results_, get_num_rows()); }
+    aligned_dense_vec_t send_vector_device_to_host() { return download_dense_(vector_buf, get_num_cols()); }
+    aligned_dense_vec_t send_mask_device_to_host() { return download_dense_(mask_buf, get_num_rows()); }
+    aligned_dense_vec_t send_results_device_to_host() { return download_dense_(results_buf, get_num_rows()); }
 
     // CPU reference the callers verify against (part of the reference's public API, :478-532).
     // Sequential row loop with a float accumulator, like the reference.

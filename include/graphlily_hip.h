@@ -83,9 +83,10 @@ int gl_host_free(void *h_ptr);
  * every send_*_host_to_device / send_*_device_to_host (app/bfs.h:107-113, xcl2.hpp:61-76); hipMalloc, hipFree and
  * hipHostMalloc of 12 MB cost more than the SpMV they serve.  gl_buf_alloc / gl_buf_free therefore recycle device
  * blocks by size (reuse is ordered by the library's stream), and gl_host_pool_alloc / gl_host_pool_free do the
- * same for host blocks -- page-locked when >= 64 KiB and the runtime is up, plain 4 KiB-aligned pages otherwise
- * (they work before gl_init: the C++ layer's aligned_allocator sits on them).  gl_pool_trim returns every cached
- * block to the driver. */
+ * same for 4 KiB-aligned host blocks of 64 KiB and more (no mmap + page faults per vector; they work before
+ * gl_init: the C++ layer's aligned_allocator sits on them).  Host blocks are plain pages -- on the MI355X box
+ * pageable and page-locked copies run at the same 56 GB/s while page-locking 12 MB costs 2.5 ms
+ * (profiles/r02_ubench_host.txt); GRAPHLILY_HOST_PIN=1 page-locks them.  gl_pool_trim returns every cached block. */
 int gl_host_pool_alloc(void **h_ptr, size_t bytes);
 int gl_host_pool_free(void *h_ptr);
 int gl_pool_trim(void);
@@ -117,6 +118,14 @@ int gl_spmv_plan_create(gl_spmv_plan *plan,
  * extra pass over x per run -- the same float products as the general layout, hence the same results.
  * GL_PLAN_KEEP_VALUES switches the detection off (8-byte {index,value} entries whatever the values are). */
 #define GL_PLAN_KEEP_VALUES 4u
+/* Where the plan is formatted.  By default matrices of a million non-zeros and more are formatted ON THE GPU
+ * (gl_format.hip: the shard's CSR is uploaded once; column degrees, the column-constant test, the per-block column
+ * sort -- one stable radix sort -- group packing and emission are kernels; the O(rows + columns) decisions stay on
+ * the host), smaller ones on the host with OpenMP.  The two formatters produce byte-identical device arrays
+ * (gl_spmv_plan_export, tests/test_gpu_format.py).  These two flags force one or the other; the environment
+ * variable GRAPHLILY_PLAN_DEVICE=0/1 does the same for plans created without them. */
+#define GL_PLAN_HOST_FORMAT 8u
+#define GL_PLAN_DEVICE_FORMAT 16u
 int gl_spmv_plan_create_ex(gl_spmv_plan *plan,
                            uint32_t num_rows, uint32_t num_cols,
                            const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
@@ -133,6 +142,15 @@ int gl_spmv_plan_shape(gl_spmv_plan plan, uint32_t *blocks, uint32_t *segments, 
 #define GL_LAYOUT_PATTERN 1
 #define GL_LAYOUT_BOOLEAN 2
 int gl_spmv_plan_layout(gl_spmv_plan plan, int *layout);
+/* Debugging / tests: copy one of the plan's device arrays to the host.  `array` is one of GL_PLAN_ARRAY_*; *bytes
+ * receives its size (also when h_dst is NULL or capacity is too small, in which case nothing is copied and
+ * GL_ERR_INVALID_ARG is returned for a non-NULL h_dst). */
+#define GL_PLAN_ARRAY_ENTRIES 0
+#define GL_PLAN_ARRAY_BASES 1
+#define GL_PLAN_ARRAY_UNITS 2
+#define GL_PLAN_ARRAY_HUB_ROWS 3
+#define GL_PLAN_ARRAY_SPANS 4
+int gl_spmv_plan_export(gl_spmv_plan plan, int array, void *h_dst, size_t capacity, size_t *bytes);
 /* Extension for row-sharded (||,&&) runs: x as a bit vector supplied by the caller, so that ranks exchange
  * n/8 bytes per iteration instead of 4n (multi-GPU).  gl_spmv_plan_bits_words: length in 32-bit words
  * of the bit vector the boolean layout reads (whole 144 KB phases, 0 for the other layouts; bits past num_cols

@@ -1,0 +1,138 @@
+"""GPU: plan creation on the device (csrc/gl_format.hip) produces the SAME device layout as the host
+formatter -- entries, bases, unit descriptors, hub rows (and phase spans for the boolean layout) compared byte for
+byte through gl_spmv_plan_export -- for every layout, for row shards and split plans, with hot columns and hub rows,
+and the plans it makes compute the oracle's results.  The full-size case also reports the two creation times."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from graphlily_amd import capi, datasets, io
+from oracle import oracle as O
+
+from helpers import named_matrix, to_oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HOST, DEV = capi.GL_PLAN_HOST_FORMAT, capi.GL_PLAN_DEVICE_FORMAT
+
+
+def _both(m, flags=0, r0=0, r1=None, data=None):
+    data = m.adj_data if data is None else data
+    r1 = m.num_rows if r1 is None else r1
+    a = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, data, r0, r1, flags=flags | HOST)
+    b = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, data, r0, r1, flags=flags | DEV)
+    return a, b
+
+
+def _assert_same_layout(a, b, what):
+    ia, ib = a.info(), b.info()
+    for k in ("nnz", "num_units", "blocks", "segments", "max_block_rows", "groups", "hot_columns", "hot_nnz", "mix", "layout",
+              "device_bytes"):
+        assert ia[k] == ib[k], "%s: plan.%s host %r device %r" % (what, k, ia[k], ib[k])
+    names = ["entries", "bases", "units", "hub_rows"] + (["spans"] if ia["layout"] == "boolean" else [])
+    for name in names:
+        ha, hb = a.export(name), b.export(name)
+        assert ha.shape == hb.shape, "%s: %s has %d words on the host, %d on the device" % (what, name, ha.size, hb.size)
+        if not np.array_equal(ha, hb):
+            bad = np.nonzero(ha != hb)[0]
+            raise AssertionError("%s: %s differs in %d of %d words, first at %d: host %#x device %#x" %
+                                 (what, name, bad.size, ha.size, bad[0], ha[bad[0]], hb[bad[0]]))
+    return ia
+
+
+CASES = [
+    ("uniform_10K_10", 0), ("rmat_20K", 0), ("rmat_sym_50K", 0), ("gplus_small", 0), ("dense_1K", 0),
+]
+
+
+@pytest.mark.parametrize("name,_", CASES)
+@pytest.mark.parametrize("kind", ["general", "pattern", "pattern_diag", "boolean"])
+def test_device_formatter_matches_host(gpu, name, _, kind):
+    m = named_matrix(name)
+    rng = np.random.default_rng(3)
+    if kind == "pattern_diag":
+        io.sssp_add_self_edges(m)            # unit weights + zero self edges: column-constant apart from the diagonal
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    if kind == "general":
+        data, flags = rng.random(m.nnz, dtype=np.float32), 0
+    elif kind == "boolean":
+        data, flags = (rng.random(m.nnz) < 0.9).astype(np.float32), capi.GL_PLAN_BOOLEAN   # zero-valued entries are dropped
+    else:
+        data, flags = m.adj_data, 0
+    a, b = _both(m, flags, data=data)
+    info = _assert_same_layout(a, b, "%s/%s" % (name, kind))
+    assert info["layout"] == {"general": "general", "pattern": "pattern", "pattern_diag": "pattern", "boolean": "boolean"}[kind]
+    # and the device-made plan computes the oracle's result
+    om = to_oracle(m)
+    om.adj_data = np.ascontiguousarray(data, np.float32)
+    x = rng.integers(0, 3, size=m.num_cols).astype(np.float32)
+    op, zero = (1, 0.0) if kind == "boolean" else (2, 255.0)
+    if op == 2:
+        x = np.where(x > 0, x, np.float32(zero)).astype(np.float32)
+    dx, dy = capi.DeviceBuffer.from_host(x), capi.DeviceBuffer(4 * m.num_rows)
+    b.run(dx, None, dy, op, zero, 0)
+    assert np.array_equal(dy.read(np.float32, m.num_rows), O.spmv(om, x, op, zero))
+
+
+@pytest.mark.parametrize("kind", ["general", "pattern", "boolean"])
+def test_device_formatter_matches_host_on_shards_and_split_plans(gpu, kind, monkeypatch):
+    m = named_matrix("rmat_sym_50K")
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    rng = np.random.default_rng(4)
+    data = rng.random(m.nnz, dtype=np.float32) if kind == "general" else m.adj_data
+    flags = capi.GL_PLAN_BOOLEAN if kind == "boolean" else 0
+    n = m.num_rows
+    for r0, r1 in ((0, n // 2), (n // 2, n), (n // 4 // 64 * 64, n // 4 // 64 * 64 + 4096), (0, 0)):
+        a, b = _both(m, flags, r0, r1, data=data)
+        _assert_same_layout(a, b, "%s shard [%d,%d)" % (kind, r0, r1))
+    monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", "16")
+    monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", "5")
+    a, b = _both(m, flags, data=data)
+    info = _assert_same_layout(a, b, kind + " split 16 x 5")
+    assert info["segments"] > 1
+    monkeypatch.setenv("GRAPHLILY_SPMV_COMPACT", "0")
+    monkeypatch.setenv("GRAPHLILY_SPMV_HOT", "0")
+    a, b = _both(m, flags, data=data)
+    _assert_same_layout(a, b, kind + " split, no hot table, no packed gather vector")
+
+
+def test_device_formatter_rejects_bad_columns_like_the_host(gpu):
+    m = named_matrix("uniform_10K_10")
+    bad = m.adj_indices.copy()
+    bad[12345] = m.num_cols + 7
+    for f in (HOST, DEV):
+        with pytest.raises(capi.GraphLilyError) as e:
+            capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, bad, m.adj_data, flags=f)
+        assert e.value.code == capi.GL_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("graph", ["pokec", "orkut"])
+def test_device_formatter_full_size(gpu, graph):
+    """The bench's matrix (and a short-row one): identical layouts, and how long each formatter takes."""
+    import torch
+    m = datasets.paper_graph(graph, 1.0, device=torch.device("cuda:0"))
+    m.adj_data = np.full(m.nnz, np.float32(1.0 / m.num_rows), dtype=np.float32)
+    io.util_round_csr_matrix_dim(m, 128, 8)
+    rec = {"graph": graph, "n": int(m.num_rows), "nnz": int(m.nnz)}
+    for kind, flags in (("general", capi.GL_PLAN_KEEP_VALUES), ("pattern", 0), ("boolean", capi.GL_PLAN_BOOLEAN)):
+        ts = {}
+        plans = {}
+        for where, f in (("device", DEV), ("host", HOST), ("device_again", DEV)):
+            t0 = time.perf_counter()
+            plans[where] = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=flags | f)
+            ts[where] = round(time.perf_counter() - t0, 3)
+        _assert_same_layout(plans["host"], plans["device"], "%s/%s" % (graph, kind))
+        rec[kind] = ts
+        for p in plans.values():
+            p.destroy()
+    print("FORMAT_SECONDS " + json.dumps(rec))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "format_seconds.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass

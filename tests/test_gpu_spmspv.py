@@ -321,3 +321,49 @@ def test_run_assign_equals_run_then_assign(gpu, sparsity):
     want[ref != 0] = 7.0
     assert np.array_equal(d1, want)
     assert int(r1["index"][0]) == int((ref != 0).sum())
+
+
+@pytest.mark.parametrize("sem", ["Arithmetic", "Logical", "Tropical"])
+def test_many_long_columns_fill_the_chunk_queue(gpu, sem):
+    """Columns just above a multiple of the 4096-entry chunk size need ceil(deg / 4096) queue slots each; nnz / 4096
+    undercounts that (two columns of 4097 entries: 3 slots for 4 chunks -- round 1 dropped the surplus silently).
+    24 columns of 4097..8191 entries, all in the frontier; then the same frontier with every column listed twice,
+    which exceeds even the exact capacity and must take the in-kernel overflow path."""
+    rng = np.random.default_rng(17)
+    n = 16384
+    degs = rng.integers(4097, 8192, size=24)
+    degs[:4] = 4097
+    cols = np.sort(rng.choice(n, size=24, replace=False))
+    indptr = np.zeros(n + 1, np.int64)
+    indptr[cols + 1] = degs
+    indptr = np.cumsum(indptr)
+    rows = np.concatenate([np.sort(rng.choice(n, size=int(d), replace=False)) for d in degs]).astype(np.uint32)
+    vals = rng.integers(1, 4, size=rows.shape[0]).astype(np.float32)
+    csc = io.CSCMatrix(n, n, vals, rows, indptr.astype(np.uint32))
+    op, zero = SEMIRINGS[sem]
+    mask = rand01(n, 9)
+    xv = rng.integers(1, 5, size=24).astype(np.float32)
+    v = M.make_sparse_vec(cols, xv)
+    got, _ = _run(gpu, csc, sem, "WriteToZero" if sem != "Tropical" else "NoMask", v, mask)
+    ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS["WriteToZero" if sem != "Tropical" else "NoMask"])
+    assert_parity(got, ref, op, "long columns " + sem)
+    assert (ref != zero).sum() > n // 4
+    # duplicates: the reference loop simply applies a column twice (spmspv_module.h:463-497)
+    v2 = M.make_sparse_vec(np.concatenate([cols, cols]), np.concatenate([xv, xv + 1]))
+    mod = M.SpMSpVModule(512)
+    mod.set_semiring(M.SemiringType(op, 1.0, zero))
+    mod.set_mask_type(M.kNoMask)
+    mod.set_up_runtime()
+    mod.load_and_format_matrix(csc)
+    mod.send_matrix_host_to_device()
+    mod.send_mask_host_to_device(mask)
+    mod.send_vector_host_to_device(v2)
+    mod.run()
+    got2 = M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), n, zero)
+    ref2 = O.spmspv(to_oracle(csc), v2, op, zero, mask, O.NOMASK)
+    assert_parity(got2, ref2, op, "long columns listed twice " + sem)
+    # and a clean run afterwards: the queue counter was reset although it overflowed
+    mod.send_vector_host_to_device(v)
+    mod.run()
+    got3 = M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), n, zero)
+    assert_parity(got3, O.spmspv(to_oracle(csc), v, op, zero, mask, O.NOMASK), op, "run after overflow " + sem)
