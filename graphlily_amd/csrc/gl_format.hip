@@ -442,6 +442,304 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     return GL_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------ (||,&&) layout
+// The device twin of bool_plan_build's record loop (gl_spmv_bool.hip): entries whose value is 0 are dropped, the rest
+// sorted by (block, column); a group is <= kBoolGroup consecutive entries of ONE x phase whose column stays within
+// 2^18 of the group's (word-aligned) base; a span is a run of groups of one phase.
+template <typename K>
+__global__ __launch_bounds__(kFmtThreads) void fmt_bool_keys_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                                    const uint32_t *__restrict__ data, uint32_t row_begin, uint32_t rows, uint64_t nz0,
+                                                                    uint32_t num_cols, const uint32_t *__restrict__ bstart, uint32_t nblocks,
+                                                                    uint32_t cb, uint32_t bb, K *__restrict__ keys, uint32_t *__restrict__ payload,
+                                                                    uint32_t *__restrict__ row_count, uint32_t *__restrict__ bad) {
+    const uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * (kFmtThreads / 64u);
+    const K drop = (K)1 << (bb + cb);
+    for (uint32_t row = blockIdx.x * (kFmtThreads / 64u) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+        const uint32_t r = row_begin + row;
+        const uint64_t s = indptr[row] - nz0, e = indptr[row + 1] - nz0;
+        uint32_t kept = 0;
+        if (s != e) {
+            uint32_t lo = 0, hi = nblocks - 1u;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (bstart[mid] <= r) lo = mid; else hi = mid - 1u;
+            }
+            const uint32_t b = lo, r0 = bstart[b];
+            for (uint64_t i = s + lane; i < e; i += 64u) {
+                const uint32_t c = indices[i];
+                if (c >= num_cols) *bad = 1u;
+                const bool keep = c < num_cols && __uint_as_float(data[i]) != 0.0f;   // a && b is false for a == 0
+                keys[i] = keep ? (((K)b << cb) | (K)c) : drop;
+                payload[i] = r - r0;
+                kept += keep ? 1u : 0u;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) kept += __shfl_down(kept, d);
+        }
+        if (lane == 0) row_count[row] = kept;   // entries the row keeps: decides the hub rows
+    }
+}
+
+struct BoolUnitDesc {
+    uint32_t begin, end;          // the unit's piece of the sorted arrays
+    uint32_t tmp_goff, tmp_soff;  // where pass A leaves its group / span records
+    uint32_t goff, soff;          // final offsets (pass B)
+    uint32_t r0, nrows_direct, hub_off, nhub;
+    uint32_t pad0, pad1;
+};
+
+__device__ __forceinline__ uint32_t bool_phase(uint32_t col) { return col / kBoolPhaseCols; }
+
+// pass A: one wave per unit walks its piece; group records (start, count) and, per group, whether it opens a span
+template <typename K>
+__global__ __launch_bounds__(64) void fmt_bool_group_kernel(const K *__restrict__ keys, const BoolUnitDesc *__restrict__ units, uint32_t cb,
+                                                            uint32_t *__restrict__ gstart, uint32_t *__restrict__ gcount,
+                                                            uint2 *__restrict__ counts) {
+    const BoolUnitDesc u = units[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const K cmask = ((K)1 << cb) - 1;
+    auto col = [&](uint32_t j) -> uint32_t { return (uint32_t)(keys[j] & cmask); };
+    uint32_t cur = u.begin, g = u.tmp_goff, nspans = 0;
+    const uint32_t end = u.end;
+    while (cur < end) {
+        const uint32_t p = cur + kBoolGroup * lane;
+        bool full = false;
+        uint32_t c0 = 0;
+        if (p < end) c0 = col(p);
+        if (p < end && end - p >= kBoolGroup) {
+            const uint32_t c1 = col(p + kBoolGroup - 1u);
+            const uint32_t ph = bool_phase(c0);
+            full = bool_phase(c1) == ph && (c1 - ph * kBoolPhaseCols) - ((c0 - ph * kBoolPhaseCols) & ~31u) < (1u << kColOffBits);
+        }
+        const unsigned long long notfull = __ballot(!full);
+        const uint32_t f = notfull ? (uint32_t)__builtin_ctzll(notfull) : 64u;
+        // a group opens a span when it is the unit's first or its phase differs from the previous entry's
+        const bool mine = lane < f || (lane == f && p < end);
+        bool opens = false;
+        if (mine) opens = (p == u.begin) || bool_phase(col(p - 1u)) != bool_phase(c0);
+        if (lane < f) {
+            gstart[g + lane] = p | (opens ? 0x80000000u : 0u);
+            gcount[g + lane] = kBoolGroup;
+        }
+        nspans += (uint32_t)__popcll(__ballot(opens && lane < f));
+        g += f;
+        if (f == 64u) {
+            cur += kBoolGroup * 64u;
+            continue;
+        }
+        const uint32_t pf = cur + kBoolGroup * f;
+        if (pf >= end) break;
+        const uint32_t cf = col(pf), phf = bool_phase(cf), basef = (cf - phf * kBoolPhaseCols) & ~31u;
+        uint32_t cnt = min((uint32_t)kBoolGroup, end - pf);
+        for (uint32_t t = 0; t < kBoolGroup / 64u; t++) {
+            const uint32_t j = pf + t * 64u + lane;
+            bool viol = false;
+            if (j < end && j - pf < cnt) {
+                const uint32_t cj = col(j);
+                viol = bool_phase(cj) != phf || (cj - phf * kBoolPhaseCols) - basef >= (1u << kColOffBits);
+            }
+            const unsigned long long vm = __ballot(viol);
+            if (vm) {
+                cnt = t * 64u + (uint32_t)__builtin_ctzll(vm);
+                break;
+            }
+        }
+        const bool opens_f = __shfl(opens ? 1 : 0, (int)f) != 0;
+        if (lane == 0) {
+            gstart[g] = pf | (opens_f ? 0x80000000u : 0u);
+            gcount[g] = cnt;
+        }
+        nspans += opens_f ? 1u : 0u;
+        g++;
+        cur = pf + cnt;
+    }
+    if (lane == 0) counts[blockIdx.x] = make_uint2(g - u.tmp_goff, nspans);
+}
+
+// pass B: one workgroup per unit; waves emit groups, wave 0 also writes the unit's spans and descriptor
+template <typename K>
+__global__ __launch_bounds__(kThreads) void fmt_bool_emit_kernel(const K *__restrict__ keys, const uint32_t *__restrict__ payload,
+                                                                 const BoolUnitDesc *__restrict__ units, const uint2 *__restrict__ counts,
+                                                                 const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gcount,
+                                                                 const uint32_t *__restrict__ hub_rows, uint32_t cb, uint32_t *__restrict__ entries,
+                                                                 uint32_t *__restrict__ bases, uint4 *__restrict__ spans, uint4 *__restrict__ plan_units) {
+    __shared__ uint8_t hub_of[kMaxBlockRows + 1];
+    __shared__ uint32_t s_span_first[kBoolMaxPhases];
+    const BoolUnitDesc u = units[blockIdx.x];
+    const uint32_t ngroups = counts[blockIdx.x].x, nspans = counts[blockIdx.x].y;
+    const uint32_t nrows = u.nrows_direct & 0xffffu;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const K cmask = ((K)1 << cb) - 1;
+    if (u.nhub) {
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) hub_of[i] = 0xffu;
+        __syncthreads();
+        if (threadIdx.x < u.nhub) hub_of[hub_rows[u.hub_off + threadIdx.x]] = (uint8_t)threadIdx.x;
+        __syncthreads();
+    }
+    for (uint32_t k = wave; k < ngroups; k += kWaves) {
+        const uint32_t st = gstart[u.tmp_goff + k] & 0x7fffffffu, cnt = gcount[u.tmp_goff + k];
+        const uint32_t c0 = (uint32_t)(keys[st] & cmask), ph = bool_phase(c0), base = (c0 - ph * kBoolPhaseCols) & ~31u;
+        const size_t g = (size_t)u.goff + k;
+        for (uint32_t i = lane; i < kBoolGroup; i += 64u) {
+            uint32_t e = kRowPad << 5;   // the ghost row slot, column = base
+            if (i < cnt) {
+                const uint32_t cin = (uint32_t)(keys[st + i] & cmask) - ph * kBoolPhaseCols;
+                const uint32_t rl = payload[st + i];
+                uint32_t slot = rl;
+                if (u.nhub) {
+                    const uint32_t hb = hub_of[rl];
+                    if (hb != 0xffu) slot = kBoolHubBit0 + (i & (kBoolHubSlots - 1u)) * 32u + hb;
+                }
+                e = (((cin - base) >> 5) << 19) | (slot << 5) | (cin & 31u);
+            }
+            entries[g * kBoolGroup + i] = e;
+        }
+        if (lane == 0) bases[g] = base >> 5;
+    }
+    if (wave == 0) {
+        // spans: the piece is column-sorted, so its phases ascend and it holds at most kBoolMaxPhases spans; collect
+        // the groups that open one (64 groups per step), then one lane per span writes it
+        volatile uint32_t *first = s_span_first;
+        uint32_t sidx = 0;
+        for (uint32_t k0 = 0; k0 < ngroups; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            const bool opens = k < ngroups && (gstart[u.tmp_goff + k] >> 31);
+            const unsigned long long om = __ballot(opens);
+            if (opens) {
+                const uint32_t my = sidx + (uint32_t)__popcll(om & ((1ull << lane) - 1ull));
+                if (my < kBoolMaxPhases) first[my] = k;
+            }
+            sidx += (uint32_t)__popcll(om);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // one wave: its LDS operations complete in order
+        if (lane < nspans && lane < kBoolMaxPhases) {
+            const uint32_t k = first[lane], kend = (lane + 1u < nspans) ? first[lane + 1u] : ngroups;
+            const uint32_t st = gstart[u.tmp_goff + k] & 0x7fffffffu;
+            const uint32_t c0 = (uint32_t)(keys[st] & cmask), ph = bool_phase(c0);
+            const uint32_t last_st = gstart[u.tmp_goff + kend - 1u] & 0x7fffffffu, last_cnt = gcount[u.tmp_goff + kend - 1u];
+            const uint32_t lo = c0 - ph * kBoolPhaseCols;
+            const uint32_t hi = (uint32_t)(keys[last_st + last_cnt - 1u] & cmask) - ph * kBoolPhaseCols;
+            spans[(size_t)u.soff + lane] = make_uint4(ph * kBoolPhaseWords, u.goff + k, u.goff + kend, (lo / 128u) | (((hi / 128u) + 1u) << 16));
+        }
+        if (lane == 0) {
+            plan_units[2u * blockIdx.x] = make_uint4(u.soff, nspans, u.r0, u.nrows_direct);
+            plan_units[2u * blockIdx.x + 1u] = make_uint4(u.hub_off, u.nhub, 0u, 0u);
+        }
+    }
+}
+
+template <typename K>
+int emit_bool_typed(DevCsr *c, const EmitBool &e, gl_spmv_plan p, uint32_t *max_rows_out, uint32_t cb, uint32_t bb) {
+    hipStream_t s = ctx().stream;
+    const BlockPlan &bp = *e.bp;
+    const uint32_t nblocks = bp.nblocks, nunits = bp.nunits;
+    const uint32_t rows = c->row_end - c->row_begin;
+    const uint64_t nnz = c->nnz;
+    const uint32_t nphases = cdiv(e.num_cols, kBoolPhaseCols);
+
+    DevMem d_bstart, d_keys, d_keys2, d_pl, d_pl2, d_off, d_rowcnt;
+    int rc;
+    if ((rc = d_bstart.alloc((size_t)(nblocks + 1) * 4u)) != GL_OK || (rc = d_keys.alloc(nnz * sizeof(K))) != GL_OK ||
+        (rc = d_keys2.alloc(nnz * sizeof(K))) != GL_OK || (rc = d_pl.alloc(nnz * 4u)) != GL_OK || (rc = d_pl2.alloc(nnz * 4u)) != GL_OK ||
+        (rc = d_off.alloc((size_t)(nblocks + 2u) * 8u)) != GL_OK || (rc = d_rowcnt.alloc((size_t)std::max(rows, 1u) * 4u)) != GL_OK)
+        return rc;
+    uint32_t *d_bad = reinterpret_cast<uint32_t *>(d_off.as<unsigned long long>() + nblocks + 1u);
+    GL_HIP(hipMemsetAsync(d_bad, 0, 8, s));
+    GL_HIP(hipMemcpyAsync(d_bstart.p, bp.bstart.data(), (size_t)(nblocks + 1) * 4u, hipMemcpyHostToDevice, s));
+    fmt_bool_keys_kernel<K><<<wave_grid(rows), kFmtThreads, 0, s>>>(c->d_indptr, c->d_indices, c->d_data, c->row_begin, rows, c->nz0, e.num_cols,
+                                                                    d_bstart.as<uint32_t>(), nblocks, cb, bb, d_keys.as<K>(), d_pl.as<uint32_t>(),
+                                                                    d_rowcnt.as<uint32_t>(), d_bad);
+    GL_LAUNCH_CHECK();
+    if ((rc = sort_keys_values_u32<K>(d_keys.as<K>(), d_keys2.as<K>(), d_pl.as<uint32_t>(), d_pl2.as<uint32_t>(), nnz, bb + cb + 1u, s)) != GL_OK) return rc;
+    (void)hipFree(d_keys.p); d_keys.p = nullptr;
+    (void)hipFree(d_pl.p); d_pl.p = nullptr;
+    const K *keys = d_keys2.as<K>();
+    fmt_bounds_kernel<K><<<cdiv(nblocks + 1u, kFmtThreads), kFmtThreads, 0, s>>>(keys, nnz, nblocks + 1u, cb, d_off.as<unsigned long long>());
+    GL_LAUNCH_CHECK();
+    std::vector<unsigned long long> off(nblocks + 2u);
+    std::vector<uint32_t> rowcnt(rows);
+    GL_HIP(hipMemcpyAsync(off.data(), d_off.p, off.size() * 8u, hipMemcpyDeviceToHost, s));
+    if (rows) GL_HIP(hipMemcpyAsync(rowcnt.data(), d_rowcnt.p, (size_t)rows * 4u, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+    if (off[nblocks + 1u] != 0ull)
+        return set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", e.num_cols);
+
+    // ---- host, O(rows): hub rows, unit table with scratch budgets
+    std::vector<uint32_t> hub_rows((size_t)nblocks * kBoolHubMax, 0u);
+    std::vector<BoolUnitDesc> units(nunits);
+    uint32_t max_rows = 0;
+    uint64_t tmp_g = 0;
+    const uint32_t extra = nphases + (e.num_cols >> kColOffBits) + 3u;   // groups a piece can have beyond len / kBoolGroup
+    for (uint32_t b = 0; b < nblocks; b++) {
+        const uint32_t r0 = bp.bstart[b], r1 = bp.bstart[b + 1];
+        max_rows = std::max(max_rows, r1 - r0);
+        const uint64_t m = off[b + 1] - off[b];
+        const uint64_t thr = std::max<uint64_t>(256, m / 48);
+        uint32_t nh = 0;
+        for (uint32_t r = r0; r < r1 && nh < kBoolHubMax; r++)
+            if (rowcnt[r - c->row_begin] >= thr) hub_rows[(size_t)b * kBoolHubMax + nh++] = r - r0;
+        const uint32_t S = bp.seg[b];
+        for (uint32_t sg = 0; sg < S; sg++) {
+            BoolUnitDesc &u = units[bp.unit_of[sg][b]];
+            u.begin = (uint32_t)(off[b] + m * sg / S);
+            u.end = (uint32_t)(off[b] + m * (sg + 1) / S);
+            u.r0 = r0;
+            u.nrows_direct = (r1 - r0) | (bp.all_direct ? 0x80000000u : 0u);
+            u.hub_off = (uint32_t)((size_t)b * kBoolHubMax);
+            u.nhub = nh;
+            u.goff = u.soff = u.tmp_soff = u.pad0 = u.pad1 = 0u;
+        }
+    }
+    for (uint32_t uidx = 0; uidx < nunits; uidx++) {   // scratch offsets in unit order
+        units[uidx].tmp_goff = (uint32_t)tmp_g;
+        tmp_g += (units[uidx].end - units[uidx].begin + kBoolGroup - 1u) / kBoolGroup + extra;
+    }
+    if (tmp_g >= 0x7fffffffull) return set_error(GL_ERR_UNSUPPORTED, "gl_spmv_plan_create: too many groups");
+    *max_rows_out = max_rows;
+
+    DevMem d_units, d_counts, d_gstart, d_gcount;
+    if ((rc = d_units.alloc((size_t)nunits * sizeof(BoolUnitDesc))) != GL_OK || (rc = d_counts.alloc((size_t)nunits * 8u)) != GL_OK ||
+        (rc = d_gstart.alloc((size_t)tmp_g * 4u)) != GL_OK || (rc = d_gcount.alloc((size_t)tmp_g * 4u)) != GL_OK)
+        return rc;
+    GL_HIP(hipMemcpyAsync(d_units.p, units.data(), (size_t)nunits * sizeof(BoolUnitDesc), hipMemcpyHostToDevice, s));
+    fmt_bool_group_kernel<K><<<nunits, 64, 0, s>>>(keys, d_units.as<BoolUnitDesc>(), cb, d_gstart.as<uint32_t>(), d_gcount.as<uint32_t>(),
+                                                   d_counts.as<uint2>());
+    GL_LAUNCH_CHECK();
+    std::vector<uint2> counts(nunits);
+    GL_HIP(hipMemcpyAsync(counts.data(), d_counts.p, (size_t)nunits * 8u, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+    uint64_t total_groups = 0, total_spans = 0;
+    for (uint32_t uidx = 0; uidx < nunits; uidx++) {
+        units[uidx].goff = (uint32_t)total_groups;
+        units[uidx].soff = (uint32_t)total_spans;
+        total_groups += counts[uidx].x;
+        total_spans += counts[uidx].y;
+    }
+    if (total_groups >= 0xffffffffull) return set_error(GL_ERR_UNSUPPORTED, "gl_spmv_plan_create: too many groups");
+    GL_HIP(hipMemcpyAsync(d_units.p, units.data(), (size_t)nunits * sizeof(BoolUnitDesc), hipMemcpyHostToDevice, s));
+
+    const size_t b_entries = (size_t)total_groups * kBoolGroup * 4u, b_bases = (size_t)total_groups * 4u;
+    const size_t b_units = (size_t)nunits * 2u * sizeof(uint4), b_hub = hub_rows.size() * 4u, b_spans = (size_t)total_spans * sizeof(uint4);
+    GL_HIP(hipMalloc((void **)&p->d_entries, b_entries ? b_entries : 16));
+    GL_HIP(hipMalloc((void **)&p->d_bases, b_bases ? b_bases : 16));
+    GL_HIP(hipMalloc((void **)&p->d_units, b_units ? b_units : 16));
+    GL_HIP(hipMalloc((void **)&p->d_hub_rows, b_hub ? b_hub : 16));
+    GL_HIP(hipMalloc((void **)&p->d_spans, b_spans ? b_spans : 16));
+    p->device_bytes += b_entries + b_bases + b_units + b_hub + b_spans;
+    p->b_entries = b_entries, p->b_bases = b_bases, p->b_units = b_units, p->b_hub_rows = b_hub, p->b_spans = b_spans;
+    if (b_hub) GL_HIP(hipMemcpyAsync(p->d_hub_rows, hub_rows.data(), b_hub, hipMemcpyHostToDevice, s));
+    if (nunits) {
+        fmt_bool_emit_kernel<K><<<nunits, kThreads, 0, s>>>(keys, d_pl2.as<uint32_t>(), d_units.as<BoolUnitDesc>(), d_counts.as<uint2>(),
+                                                            d_gstart.as<uint32_t>(), d_gcount.as<uint32_t>(), p->d_hub_rows, cb,
+                                                            reinterpret_cast<uint32_t *>(p->d_entries), p->d_bases, p->d_spans, p->d_units);
+        GL_LAUNCH_CHECK();
+    }
+    GL_HIP(hipStreamSynchronize(s));
+    p->ngroups = total_groups;
+    return GL_OK;
+}
+
 }  // namespace
 
 bool format_on_device(uint32_t flags, uint64_t nnz) {
@@ -551,6 +849,14 @@ int fmt_emit_general(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vecto
     if (c->nnz >= 0xffffffffull) return set_error(GL_ERR_UNSUPPORTED, "plan creation on the device: more than 2^32 - 1 entries in a shard");
     if (bb + cb + 2u <= 32u) return emit_general_typed<uint32_t>(c, e, p, hub_count, hot_nnz, cb, bb);
     return emit_general_typed<unsigned long long>(c, e, p, hub_count, hot_nnz, cb, bb);
+}
+
+int fmt_emit_bool(DevCsr *c, const EmitBool &e, gl_spmv_plan p, uint32_t *max_rows) {
+    const uint32_t cb = bits_for(std::max<uint64_t>(e.num_cols, 2u));
+    const uint32_t bb = bits_for(std::max<uint32_t>(e.bp->nblocks, 2u));
+    if (c->nnz >= 0x7fffffffull) return set_error(GL_ERR_UNSUPPORTED, "plan creation on the device: more than 2^31 - 1 entries in a shard");
+    if (bb + cb + 1u <= 32u) return emit_bool_typed<uint32_t>(c, e, p, max_rows, cb, bb);
+    return emit_bool_typed<unsigned long long>(c, e, p, max_rows, cb, bb);
 }
 
 }  // namespace gl

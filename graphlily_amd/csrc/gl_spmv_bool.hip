@@ -391,6 +391,31 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
     const uint32_t nblocks = bp.nblocks, nunits = bp.nunits;
     const uint32_t nphases = cdiv(num_cols, kBoolPhaseCols);
 
+    if (format_on_device(p->flags, p->nnz)) {
+        // the record loop below as kernels over a staged copy of the shard (gl_format.hip); identical arrays
+        struct Staged {
+            DevCsr *c = nullptr;
+            ~Staged() { devcsr_release(c); }
+        } staged;
+        int rc = devcsr_stage(&staged.c, h_indptr, h_indices, h_data, row_begin, row_end);
+        if (rc != GL_OK) return rc;
+        EmitBool eb;
+        eb.bp = &bp;
+        eb.h_indptr = h_indptr;
+        eb.num_cols = num_cols;
+        uint32_t tallest = 0;
+        if ((rc = fmt_emit_bool(staged.c, eb, p, &tallest)) != GL_OK) return rc;
+        p->boolean = true;
+        p->nblocks = nblocks;
+        p->segments = bp.Smax;
+        p->nunits = nunits;
+        p->max_block_rows = tallest;
+        p->nphases = nphases;
+        GL_HIP(hipMalloc((void **)&p->d_xbits, (size_t)nphases * kBoolPhaseWords * 4u));
+        p->device_bytes += (size_t)nphases * kBoolPhaseWords * 4u;
+        return GL_OK;
+    }
+
     // every unit is emitted on its own (groups, bases, spans), then the pieces are laid out in unit order
     struct UnitOut {
         std::vector<uint32_t> ent;     // 128 per group
