@@ -328,7 +328,72 @@ class BFS(_GraphApp):
             _, frontier, local = self._push_iteration(frontier, local, it)
         return self._finish_distance(distance)
 
+    # -- pull_push without the host in the loop -------------------------------------------------
+    def _device_loop_ok(self):
+        return (not self.comm.distributed and os.environ.get("GRAPHLILY_BFS_DEVICE_LOOP", "1") != "0"
+                and hasattr(self.SpMSpV_, "run_gated") and hasattr(self.SpMV_, "fused_bfs_ok") and self.SpMV_.fused_bfs_ok())
+
+    def _pull_push_device(self, source, num_iterations, threshold):
+        """The reference decides push vs pull on the host from a count it reads back every iteration
+        (app/bfs.h:180-190) and converts the frontier on the host at the switch (:195-205).  Here the WHOLE
+        schedule is enqueued up front: every iteration slot holds a pull step and a push step, a device-side mode
+        word (written by gl_bfs_direction_step from the result count, same float comparison) says which of the two
+        runs, and the push step's write pass leaves the next frontier as bits as well, so the switch is a flipped
+        word.  No synchronisation or device->host copy until the distances are read back.  The schedule depends
+        only on (num_iterations, threshold) -- the source is a device word -- so it is captured once as a hipGraph
+        and replayed (GRAPHLILY_BFS_GRAPH=0: enqueue it every time)."""
+        B, n = self.backend, self.n_
+        st = getattr(self, "dev_loop_", None)
+        if st is None:
+            words = self.SpMV_.bits_words()
+            both = B.alloc(n + 4, np.float32)     # distances, then the control words: one read-back fetches both
+            st = self.dev_loop_ = {
+                "both": both, "ctl": B.view(both, n, 4, 4), "distance": B.view(both, 0, n, 4),
+                "F": [B.alloc(n + 1, capi.IDX_VAL), B.alloc(n + 1, capi.IDX_VAL)],
+                "bits": [B.alloc(words, np.float32), B.alloc(words, np.float32)], "words": words, "graphs": {},
+                "src": np.zeros(1, np.uint32)}
+            for b in st["bits"]:
+                B.fill(b, 0.0, words)
+        ctl, distance, F, bits, words = st["ctl"], st["distance"], st["F"], st["bits"], st["words"]
+        self.SpMSpV_.bind_mask_buf(distance)
+
+        def schedule():
+            # slot `it`: frontier list F[it & 1] / bits[it & 1] in, F[(it + 1) & 1] / bits[(it + 1) & 1] out
+            capi.bfs_begin(ctl, distance, n, F[1], bits[1], words)
+            for it in range(1, num_iterations + 1):
+                cur, nxt = it & 1, (it + 1) & 1
+                # ctl[0] = first pull slot: slot `it` pulls if ctl[0] <= it, pushes if ctl[0] > it
+                self.SpMV_.bfs_pull_step_gated(bits[cur], bits[nxt], distance, float(it + 1), ctl, it, capi.GL_GATE_LE)
+                # the push step's counting pass clears the words of bits[nxt] that its write pass ORs the new frontier
+                # into, and its scan pass takes the reference's loop decision (threshold, iterations left)
+                self.SpMSpV_.run_gated(F[cur], F[nxt], distance, float(it + 1), bits[nxt], ctl, it, capi.GL_GATE_GT,
+                                       ctl=ctl, slot=it, threshold=threshold, may_continue=it + 1 < num_iterations)
+
+        st["src"][0] = source
+        B.upload(B.view(ctl, 2, 1, 4), st["src"])        # ctl[2] = source: the one host->device word per run
+        key = (num_iterations, float(threshold))
+        use_graph = os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0"
+        g = st["graphs"].get(key)
+        if g is None and use_graph and st.get("warm") == key:
+            try:
+                with capi.Graph.capture() as g:
+                    schedule()
+                st["graphs"][key] = g
+            except capi.GraphLilyError:
+                g = st["graphs"][key] = False              # capture not possible here: keep enqueueing
+        if g:
+            g.launch()
+        else:
+            schedule()
+            st["warm"] = key                              # buffers, attributes and scratch exist now: the next call captures
+        B.sync()
+        out = B.download_result(st["both"], n + 4)
+        self.push_iterations_ = int(out[n + 1:n + 2].view(np.uint32)[0])
+        return out[:n]
+
     def pull_push(self, source, num_iterations, threshold=0.05):
+        if self._device_loop_ok():
+            return self._pull_push_device(source, num_iterations, threshold)
         n = self.n_
         frontier, distance, local = self._start_push(source)
         it = 1

@@ -30,7 +30,9 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 # every symbol include/graphlily_hip.h declares (tests check the .so exports them all)
 EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
-    "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32",
+    "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
+    "gl_bfs_begin", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated",
+    "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32", "gl_buf_fill_u32_gated",
     "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim",
     "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_plan_export", "gl_spmv_run",
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits", "gl_bfs_pull_step",
@@ -39,7 +41,7 @@ EXPORTS = [
     "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_last_direction",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
     "gl_assign_sparse_new_frontier", "gl_sparse_to_dense",
-    "gl_host_csr2csc", "gl_npz_csr_open", "gl_npz_csr_read", "gl_npz_csr_close",
+    "gl_host_csr2csc", "gl_csr2csc", "gl_csr_normalize_by_outdegree", "gl_npz_csr_open", "gl_npz_csr_read", "gl_npz_csr_close",
 ]
 
 
@@ -71,12 +73,17 @@ def lib():
     vp, u32, u64, f32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_float, ctypes.c_int
     P = ctypes.POINTER
     sigs = {
+        "gl_graph_begin_capture": [], "gl_graph_end_capture": [P(vp)], "gl_graph_launch": [vp], "gl_graph_destroy": [vp],
+        "gl_bfs_begin": [vp, vp, u32, vp, vp, u32],
+        "gl_spmspv_run_gated": [vp, vp, vp, vp, i32, f32, i32, vp, f32, vp, vp, u32, i32, vp, u32, f32, i32],
+        "gl_bfs_pull_step_gated": [vp, vp, vp, vp, f32, vp, u32, i32],
         "gl_init": [i32], "gl_device_count": [P(i32)], "gl_set_stream": [vp], "gl_reset_stream": [], "gl_sync": [],
         "gl_buf_alloc": [P(vp), ctypes.c_size_t], "gl_buf_free": [vp],
         "gl_host_alloc": [P(vp), ctypes.c_size_t], "gl_host_free": [vp],
         "gl_host_pool_alloc": [P(vp), ctypes.c_size_t], "gl_host_pool_free": [vp], "gl_pool_trim": [],
         "gl_buf_h2d": [vp, vp, ctypes.c_size_t], "gl_buf_d2h": [vp, vp, ctypes.c_size_t],
         "gl_buf_d2d": [vp, vp, ctypes.c_size_t], "gl_buf_fill_f32": [vp, f32, ctypes.c_size_t],
+        "gl_buf_fill_u32_gated": [vp, u32, ctypes.c_size_t, vp, u32],
         "gl_spmv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmv_plan_create_ex": [P(vp), u32, u32, vp, vp, vp, u32, u32, u32],
         "gl_spmv_plan_destroy": [vp], "gl_spmv_plan_info": [vp, P(u64), P(u64), P(u32)],
@@ -98,6 +105,8 @@ def lib():
         "gl_assign_sparse": [vp, vp, f32, u32], "gl_assign_sparse_new_frontier": [vp, vp, vp, u32],
         "gl_sparse_to_dense": [vp, vp, u32, f32, u32],
         "gl_host_csr2csc": [u32, u32, vp, vp, vp, vp, vp, vp],
+        "gl_csr2csc": [u32, u32, vp, vp, vp, vp, vp, vp],
+        "gl_csr_normalize_by_outdegree": [u32, u32, vp, vp, vp],
         "gl_npz_csr_open": [ctypes.c_char_p, P(vp), P(u32), P(u32), P(u64)],
         "gl_npz_csr_read": [vp, vp, vp, vp], "gl_npz_csr_close": [vp],
     }
@@ -253,6 +262,7 @@ def _p(buf):
 GL_PLAN_NO_MULADD = 1
 GL_PLAN_BOOLEAN = 2
 GL_PLAN_KEEP_VALUES = 4
+GL_GATE_EQ, GL_GATE_GT, GL_GATE_LE = 0, 1, 2
 GL_PLAN_HOST_FORMAT = 8
 GL_PLAN_DEVICE_FORMAT = 16
 PLAN_ARRAYS = {"entries": 0, "bases": 1, "units": 2, "hub_rows": 3, "spans": 4}
@@ -309,6 +319,10 @@ class SpMVPlan:
         check(lib().gl_spmv_plan_bits_words(ctypes.c_void_p(self.handle), ctypes.byref(v)))
         return v.value
 
+    def bfs_pull_step_gated(self, bits_in, bits_out, distance, level, gate, gate_value, gate_op):
+        check(lib().gl_bfs_pull_step_gated(ctypes.c_void_p(self.handle), _p(bits_in), _p(bits_out), _p(distance), float(level),
+                                           _p(gate), int(gate_value), int(gate_op)))
+
     def bfs_pull_step(self, bits_in, bits_out, distance, level):
         check(lib().gl_bfs_pull_step(ctypes.c_void_p(self.handle), _p(bits_in), _p(bits_out), _p(distance), float(level)))
 
@@ -362,6 +376,12 @@ class SpMSpVPlan:
         check(lib().gl_spmspv_run(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op),
                                   float(zero), int(mask_type)))
 
+    def run_gated(self, vector, mask, result, op, zero, mask_type, inout, val, next_bits, gate, gate_value, gate_op,
+                  ctl=None, slot=0, threshold=0.0, may_continue=False):
+        check(lib().gl_spmspv_run_gated(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op), float(zero),
+                                        int(mask_type), _p(inout), float(val), _p(next_bits), _p(gate), int(gate_value),
+                                        int(gate_op), _p(ctl), int(slot), float(threshold), int(bool(may_continue))))
+
     def run_assign(self, vector, mask, result, op, zero, mask_type, inout, val):
         """gl_spmspv_run_assign: run + gl_assign_sparse(result, inout, val) in the result-writing pass."""
         check(lib().gl_spmspv_run_assign(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op),
@@ -377,6 +397,48 @@ class SpMSpVPlan:
             self.destroy()
         except Exception:
             pass
+
+
+class Graph:
+    """A recorded launch sequence (gl_graph_*): `with Graph.capture() as g: ...enqueue...`, then g.launch()."""
+
+    def __init__(self):
+        self.handle = None
+
+    @classmethod
+    def capture(cls):
+        g = cls()
+        check(lib().gl_graph_begin_capture())
+        return g
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        h = ctypes.c_void_p(0)
+        rc = lib().gl_graph_end_capture(ctypes.byref(h))
+        if exc_type is None:
+            check(rc)
+            self.handle = h.value
+        return False
+
+    def launch(self):
+        check(lib().gl_graph_launch(ctypes.c_void_p(self.handle)))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().gl_graph_destroy(ctypes.c_void_p(self.handle))
+        except Exception:
+            pass
+
+
+def fill_u32_gated(buf, value, count, gate, gate_value):
+    check(lib().gl_buf_fill_u32_gated(_p(buf), int(value), int(count), _p(gate), int(gate_value)))
+
+
+def bfs_begin(ctl, distance, n, frontier, bits, bits_words):
+    check(lib().gl_bfs_begin(_p(ctl), _p(distance), int(n), _p(frontier), _p(bits), int(bits_words)))
 
 
 def pack_bits(x, n, bits):
@@ -435,9 +497,19 @@ def host_csr2csc(num_rows, num_cols, indptr, indices, data):
     o_indptr = np.empty(num_cols + 1, dtype=np.uint32)
     o_indices = np.empty(nnz, dtype=np.uint32)
     o_data = np.empty(nnz, dtype=np.float32)
-    check(lib().gl_host_csr2csc(num_rows, num_cols, _np_ptr(indptr), _np_ptr(indices), _np_ptr(data),
-                                ctypes.c_void_p(o_indptr.ctypes.data), _np_ptr(o_indices), _np_ptr(o_data)))
+    # gl_csr2csc: on the GPU when the runtime is up and the matrix is large, on the host otherwise; same output
+    check(lib().gl_csr2csc(num_rows, num_cols, _np_ptr(indptr), _np_ptr(indices), _np_ptr(data),
+                           ctypes.c_void_p(o_indptr.ctypes.data), _np_ptr(o_indices), _np_ptr(o_data)))
     return o_indptr, o_indices, o_data
+
+
+def csr_normalize_by_outdegree(num_rows, num_cols, indptr, indices):
+    """-> adj_data with data[i] = float(1.0 / #entries in the column of i) (io/data_formatter.h:36-51)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.uint32)
+    indices = np.ascontiguousarray(indices, dtype=np.uint32)
+    out = np.empty(int(indptr[num_rows]), dtype=np.float32)
+    check(lib().gl_csr_normalize_by_outdegree(num_rows, num_cols, _np_ptr(indptr), _np_ptr(indices), _np_ptr(out)))
+    return out
 
 
 def npz_load_csr(path):

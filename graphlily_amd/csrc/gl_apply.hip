@@ -88,6 +88,7 @@ struct RelaxSource {
         if (inout[m.index] > m.val) inout[m.index] = m.val;
     }
     __device__ void emitted(const gl_idx_val &) const {}
+    __device__ void begin_chunk(uint32_t) const {}
 };
 
 // graphlily/global.h:153-164
@@ -101,9 +102,40 @@ __global__ __launch_bounds__(256) void sparse_scatter_kernel(const gl_idx_val *_
     }
 }
 
+// ---- device-side bookkeeping of a whole BFS (gl_bfs_begin, gl_spmspv_run_gated): ctl[0] = first pull slot (0xffffffff
+//      while pushing), ctl[1] = push iterations done, ctl[2] = source vertex (written by the host before the schedule)
+__global__ __launch_bounds__(256) void bfs_begin_kernel(uint32_t *__restrict__ ctl, float *__restrict__ distance, uint32_t n,
+                                                        gl_idx_val *__restrict__ frontier, uint32_t *__restrict__ bits, uint32_t words) {
+    const uint32_t src = ctl[2];
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    for (uint32_t i = tid; i < n; i += stride) distance[i] = (i == src) ? 1.0f : 0.0f;      // app/bfs.h:168-171
+    if (bits)
+        for (uint32_t w = tid; w < words; w += stride) bits[w] = (w == (src >> 5)) ? (1u << (src & 31u)) : 0u;
+    if (tid == 0) {
+        if (frontier) {
+            frontier[0].index = 1u;          // one source vertex (app/bfs.h:162-166)
+            frontier[0].val = 0.0f;
+            frontier[1].index = src;
+            frontier[1].val = 1.0f;
+        }
+        ctl[0] = frontier ? 0xffffffffu : 0u;   // first pull slot: none yet / every slot
+        ctl[1] = 0u;
+    }
+}
+
 }  // namespace gl
 
 extern "C" {
+
+int gl_bfs_begin(uint32_t *d_ctl, float *d_distance, uint32_t n, gl_idx_val *d_frontier, uint32_t *d_bits, uint32_t bits_words) {
+    GL_REQUIRE_INIT();
+    GL_ARG(d_ctl != nullptr && d_distance != nullptr && n > 0);
+    GL_ARG(d_frontier != nullptr || d_bits != nullptr);
+    gl::bfs_begin_kernel<<<gl::stream_grid(n), 256, 0, gl::ctx().stream>>>(d_ctl, d_distance, n, d_frontier, d_bits, bits_words);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 
 int gl_ewise_add(const float *d_in, float *d_out, uint32_t len, float val) {
     GL_REQUIRE_INIT();

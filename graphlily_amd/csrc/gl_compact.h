@@ -13,6 +13,7 @@
 //   __device__ bool     get(uint32_t i, gl_idx_val &out);   // candidate i kept? payload
 //   __device__ void     consumed(uint32_t i);               // called once per candidate in the write pass
 //   __device__ void     emitted(const gl_idx_val &item);    // called once per kept candidate in the write pass
+//   __device__ void     begin_chunk(uint32_t first);        // counting pass, once per block (all threads call it)
 // d_counts: cdiv(max_items, kCompactChunk) + 1 words, word 0 (the ticket) zero before the first run.
 #ifndef GL_COMPACT_H_
 #define GL_COMPACT_H_
@@ -25,6 +26,36 @@ constexpr uint32_t kCompactThreads = 256;
 constexpr uint32_t kCompactItems = 4;
 constexpr uint32_t kCompactChunk = kCompactThreads * kCompactItems;
 constexpr uint32_t kCompactFuseBlocks = 128;   // lists up to 128 K candidates scan their counts in the counting launch
+
+// Optional predicate of a launch: when `word` is set the kernels do nothing unless *word (op) value holds, op being
+// GL_GATE_EQ / GL_GATE_GT / GL_GATE_LE.  Drivers that enqueue a whole push / pull schedule without host round trips
+// (gl_bfs_*_gated) use it with a device-side word that holds the first pull slot.
+struct Gate {
+    const uint32_t *word = nullptr;
+    uint32_t value = 0;
+    int op = GL_GATE_EQ;
+    __device__ bool closed() const {
+        if (word == nullptr) return false;
+        const uint32_t w = *word;
+        return !(op == GL_GATE_EQ ? w == value : op == GL_GATE_GT ? w > value : w <= value);
+    }
+};
+
+// Optional epilogue of the scan: the push -> pull decision of a BFS, taken where the result count is produced
+// (do { push } while (iter < num_iterations && nnz / n < threshold), app/bfs.h:180-190).  ctl[0] = first pull slot
+// (0xffffffff while pushing), ctl[1] = push iterations done.  The push step of slot `slot` is gated on ctl[0] > slot,
+// so writing slot + 1 here does not close the gate of the write pass that follows in the same step.
+struct Direction {
+    uint32_t *ctl = nullptr;
+    uint32_t n = 1, slot = 0;
+    float threshold = 0.0f;
+    uint32_t may_continue = 0;
+    __device__ void decide(uint32_t nnz) const {
+        if (!ctl || ctl[0] != 0xffffffffu) return;
+        ctl[1] += 1u;
+        if (!(may_continue != 0u && ((float)nnz / (float)n < threshold))) ctl[0] = slot + 1u;
+    }
+};
 
 // exclusive prefix of `flag` over the 256 threads of a block, in thread order; total in *block_total
 __device__ __forceinline__ uint32_t block_rank_256(bool flag, uint32_t *lds4, uint32_t *block_total) {
@@ -52,12 +83,15 @@ __device__ __forceinline__ uint32_t block_rank_256(bool flag, uint32_t *lds4, ui
 // (orkut BFS pull-push 1.15 -> 1.30 ms when this was unconditional).
 template <typename Src>
 __global__ __launch_bounds__(256) void compact_count_kernel(Src src, uint32_t *__restrict__ counts, gl_idx_val *__restrict__ out,
-                                                            float head_val, uint32_t *__restrict__ reset_word, bool fused) {
+                                                            float head_val, uint32_t *__restrict__ reset_word, bool fused, Gate gate,
+                                                            Direction dir) {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t carry_s;
     __shared__ bool last_s;
+    if (gate.closed()) return;
     const uint32_t n = src.size();
     const uint32_t base = blockIdx.x * kCompactChunk;
+    src.begin_chunk(base);
     uint32_t c = 0;
     if (base < n) {
 #pragma unroll
@@ -108,15 +142,17 @@ __global__ __launch_bounds__(256) void compact_count_kernel(Src src, uint32_t *_
         out[0].val = head_val;
         counts[0] = 0u;                     // ticket ready for the next run
         if (reset_word) *reset_word = 0u;   // e.g. the SpMSpV chunk-queue counter, ready for the next run
+        dir.decide(carry_s);
     }
 }
 
 // long lists: counts[1..nblocks] -> exclusive offsets in place, one block; out[0] = {total, head_val}
 static __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__restrict__ counts, uint32_t nblocks,
                                                                    gl_idx_val *__restrict__ out, float head_val,
-                                                                   uint32_t *__restrict__ reset_word) {
+                                                                   uint32_t *__restrict__ reset_word, Gate gate, Direction dir) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
+    if (gate.closed()) return;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -142,13 +178,15 @@ static __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__r
         out[0].index = carry_s;
         out[0].val = head_val;
         if (reset_word) *reset_word = 0u;
+        dir.decide(carry_s);
     }
 }
 
 template <typename Src>
 __global__ __launch_bounds__(256) void compact_write_kernel(Src src, const uint32_t *__restrict__ offsets,
-                                                            gl_idx_val *__restrict__ out) {
+                                                            gl_idx_val *__restrict__ out, Gate gate) {
     __shared__ uint32_t lds4[4];
+    if (gate.closed()) return;
     const uint32_t n = src.size();
     const uint32_t base = blockIdx.x * kCompactChunk;
     if (base >= n) return;
@@ -175,17 +213,17 @@ __global__ __launch_bounds__(256) void compact_write_kernel(Src src, const uint3
 // Runs the passes for at most `max_items` candidates (host-side bound for the grid).
 template <typename Src>
 static int run_compaction(Src src, uint32_t max_items, uint32_t *d_counts, gl_idx_val *d_out, float head_val,
-                          hipStream_t s, uint32_t *d_reset_word = nullptr) {
+                          hipStream_t s, uint32_t *d_reset_word = nullptr, Gate gate = Gate(), Direction dir = Direction()) {
     uint32_t nblocks = cdiv(max_items, kCompactChunk);
     if (nblocks == 0) nblocks = 1;
     const bool fused = nblocks <= kCompactFuseBlocks;
-    compact_count_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out, head_val, d_reset_word, fused);
+    compact_count_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out, head_val, d_reset_word, fused, gate, dir);
     GL_LAUNCH_CHECK();
     if (!fused) {
-        compact_scan_kernel<<<1, 1024, 0, s>>>(d_counts, nblocks, d_out, head_val, d_reset_word);
+        compact_scan_kernel<<<1, 1024, 0, s>>>(d_counts, nblocks, d_out, head_val, d_reset_word, gate, dir);
         GL_LAUNCH_CHECK();
     }
-    compact_write_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out);
+    compact_write_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out, gate);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

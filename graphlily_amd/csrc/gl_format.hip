@@ -851,6 +851,235 @@ int fmt_emit_general(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vecto
     return emit_general_typed<unsigned long long>(c, e, p, hub_count, hot_nnz, cb, bb);
 }
 
+// ------------------------------------------------------------------------------------------ SpMSpV stream, csr2csc, normalise
+namespace {
+
+// whole matrix: the CSC arrays simply interleave into the {row, value} stream
+__global__ __launch_bounds__(kFmtThreads) void fmt_csc_interleave_kernel(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ vals, uint64_t nnz,
+                                                                         uint32_t num_rows, uint2 *__restrict__ stream, uint32_t *__restrict__ bad) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kFmtThreads + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * kFmtThreads) {
+        const uint32_t r = rows[i];
+        if (r >= num_rows) *bad = 1u;
+        stream[i] = make_uint2(r, vals[i]);
+    }
+}
+
+// row shard, pass 1: entries of each column whose row lies in [r0, r1)
+__global__ __launch_bounds__(kFmtThreads) void fmt_csc_count_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ rows, uint32_t num_cols,
+                                                                    uint32_t num_rows, uint32_t r0, uint32_t r1, uint32_t *__restrict__ cnt,
+                                                                    uint32_t *__restrict__ bad) {
+    const uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * (kFmtThreads / 64u);
+    for (uint32_t c = blockIdx.x * (kFmtThreads / 64u) + (threadIdx.x >> 6); c < num_cols; c += nwaves) {
+        uint32_t k = 0;
+        for (uint64_t i = (uint64_t)indptr[c] + lane; i < indptr[c + 1]; i += 64u) {
+            const uint32_t r = rows[i];
+            if (r >= num_rows) *bad = 1u;
+            k += (r >= r0 && r < r1) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) k += __shfl_down(k, d);
+        if (lane == 0) cnt[c] = k;
+    }
+}
+
+// pass 2: order-preserving write of the kept entries
+__global__ __launch_bounds__(kFmtThreads) void fmt_csc_filter_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ rows,
+                                                                     const uint32_t *__restrict__ vals, uint32_t num_cols, uint32_t r0, uint32_t r1,
+                                                                     const uint32_t *__restrict__ out_ptr, uint2 *__restrict__ stream) {
+    const uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * (kFmtThreads / 64u);
+    for (uint32_t c = blockIdx.x * (kFmtThreads / 64u) + (threadIdx.x >> 6); c < num_cols; c += nwaves) {
+        uint32_t at = out_ptr[c];
+        const uint64_t e = indptr[c + 1];
+        for (uint64_t i0 = indptr[c]; i0 < e; i0 += 64u) {
+            const uint64_t i = i0 + lane;
+            uint32_t r = 0;
+            bool keep = false;
+            if (i < e) {
+                r = rows[i];
+                keep = r >= r0 && r < r1;
+            }
+            const unsigned long long km = __ballot(keep);
+            if (keep) stream[at + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = make_uint2(r, vals[i]);
+            at += (uint32_t)__popcll(km);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kFmtThreads) void fmt_row_of_kernel(const uint32_t *__restrict__ indptr, uint32_t rows, uint32_t *__restrict__ row_of) {
+    const uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * (kFmtThreads / 64u);
+    for (uint32_t r = blockIdx.x * (kFmtThreads / 64u) + (threadIdx.x >> 6); r < rows; r += nwaves)
+        for (uint64_t i = (uint64_t)indptr[r] + lane; i < indptr[r + 1]; i += 64u) row_of[i] = r;
+}
+
+__global__ __launch_bounds__(kFmtThreads) void fmt_split_pairs_kernel(const uint2 *__restrict__ pairs, uint64_t nnz, uint32_t *__restrict__ a, uint32_t *__restrict__ b) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kFmtThreads + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * kFmtThreads) {
+        const uint2 p = pairs[i];
+        a[i] = p.x;
+        b[i] = p.y;
+    }
+}
+
+__global__ __launch_bounds__(kFmtThreads) void fmt_pack_pairs_kernel(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t nnz, uint2 *__restrict__ pairs) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kFmtThreads + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * kFmtThreads) pairs[i] = make_uint2(a[i], b[i]);
+}
+
+// adj_data[i] = 1.0 / count(column of i): double divide, float store (io/data_formatter.h:36-51)
+__global__ __launch_bounds__(kFmtThreads) void fmt_normalize_kernel(const uint32_t *__restrict__ cols, const uint32_t *__restrict__ deg, uint64_t nnz, float *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kFmtThreads + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * kFmtThreads)
+        out[i] = (float)(1.0 / (double)deg[cols[i]]);
+}
+
+inline unsigned flat_grid(uint64_t n) {
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kFmtThreads - 1) / kFmtThreads, (uint64_t)ctx().num_cus * 16u));
+}
+
+}  // namespace
+
+int fmt_spmspv_stream(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
+                      uint32_t r0, uint32_t r1, uint32_t **d_indptr_out, uint2 **d_stream_out, std::vector<uint32_t> &indptr_out) {
+    hipStream_t s = ctx().stream;
+    const uint64_t nnz_all = h_indptr[num_cols];
+    const bool whole = (r0 == 0 && r1 == num_rows);
+    DevMem d_rows, d_vals, d_ip, d_bad, d_cnt;
+    int rc;
+    if ((rc = d_rows.alloc(nnz_all * 4u)) != GL_OK || (rc = d_vals.alloc(nnz_all * 4u)) != GL_OK || (rc = d_bad.alloc(16)) != GL_OK ||
+        (rc = d_ip.alloc((size_t)(num_cols + 1ull) * 4u)) != GL_OK)
+        return rc;
+    GL_HIP(hipMemsetAsync(d_bad.p, 0, 16, s));
+    GL_HIP(hipMemcpyAsync(d_ip.p, h_indptr, (size_t)(num_cols + 1ull) * 4u, hipMemcpyHostToDevice, s));
+    if (nnz_all) {
+        GL_HIP(hipMemcpyAsync(d_rows.p, h_indices, nnz_all * 4u, hipMemcpyHostToDevice, s));
+        GL_HIP(hipMemcpyAsync(d_vals.p, h_data, nnz_all * 4u, hipMemcpyHostToDevice, s));
+    }
+    uint2 *stream = nullptr;
+    uint32_t *out_ip = nullptr;
+    indptr_out.resize((size_t)num_cols + 1u);
+    if (whole) {
+        GL_HIP(hipMalloc((void **)&stream, nnz_all ? nnz_all * 8u : 16u));
+        if (nnz_all) {
+            fmt_csc_interleave_kernel<<<flat_grid(nnz_all), kFmtThreads, 0, s>>>(d_rows.as<uint32_t>(), d_vals.as<uint32_t>(), nnz_all, num_rows, stream, d_bad.as<uint32_t>());
+            GL_LAUNCH_CHECK();
+        }
+        out_ip = d_ip.as<uint32_t>();
+        d_ip.p = nullptr;   // ownership moves to the caller
+        memcpy(indptr_out.data(), h_indptr, indptr_out.size() * 4u);
+    } else {
+        if ((rc = d_cnt.alloc((size_t)(num_cols + 1ull) * 4u)) != GL_OK) return rc;
+        GL_HIP(hipMemsetAsync(d_cnt.p, 0, (size_t)(num_cols + 1ull) * 4u, s));
+        fmt_csc_count_kernel<<<wave_grid(num_cols), kFmtThreads, 0, s>>>(d_ip.as<uint32_t>(), d_rows.as<uint32_t>(), num_cols, num_rows, r0, r1,
+                                                                     d_cnt.as<uint32_t>(), d_bad.as<uint32_t>());
+        GL_LAUNCH_CHECK();
+        GL_HIP(hipMalloc((void **)&out_ip, (size_t)(num_cols + 1ull) * 4u));
+        size_t tmp_bytes = 0;
+        hipError_t he = rocprim::exclusive_scan(nullptr, tmp_bytes, d_cnt.as<uint32_t>(), out_ip, 0u, (size_t)num_cols + 1u, rocprim::plus<uint32_t>(), s);
+        DevMem tmp;
+        if (he == hipSuccess && (rc = tmp.alloc(tmp_bytes)) == GL_OK)
+            he = rocprim::exclusive_scan(tmp.p, tmp_bytes, d_cnt.as<uint32_t>(), out_ip, 0u, (size_t)num_cols + 1u, rocprim::plus<uint32_t>(), s);
+        if (he != hipSuccess || rc != GL_OK) {
+            (void)hipFree(out_ip);
+            return rc != GL_OK ? rc : set_error(GL_ERR_HIP, "gl_spmspv_plan_create: scan: %s", hipGetErrorString(he));
+        }
+        GL_HIP(hipMemcpyAsync(indptr_out.data(), out_ip, indptr_out.size() * 4u, hipMemcpyDeviceToHost, s));
+        GL_HIP(hipStreamSynchronize(s));
+        const uint64_t kept = indptr_out[num_cols];
+        GL_HIP(hipMalloc((void **)&stream, kept ? kept * 8u : 16u));
+        fmt_csc_filter_kernel<<<wave_grid(num_cols), kFmtThreads, 0, s>>>(d_ip.as<uint32_t>(), d_rows.as<uint32_t>(), d_vals.as<uint32_t>(), num_cols, r0, r1,
+                                                                      out_ip, stream);
+        GL_LAUNCH_CHECK();
+    }
+    uint32_t bad = 0;
+    GL_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+    if (bad) {
+        (void)hipFree(stream);
+        (void)hipFree(out_ip);
+        return set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_create: row index out of range (num_rows %u)", num_rows);
+    }
+    *d_indptr_out = out_ip;
+    *d_stream_out = stream;
+    return GL_OK;
+}
+
+// io::csr2csc (io/data_loader.h:108-144) as ONE stable radix sort by column of (row, value) pairs: rows inside a column
+// stay ascending exactly like the reference's row-by-row counting sort
+int fmt_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
+                uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data) {
+    hipStream_t s = ctx().stream;
+    const uint64_t nnz = h_indptr[num_rows];
+    if (nnz >= 0xffffffffull) return set_error(GL_ERR_UNSUPPORTED, "gl_csr2csc: more than 2^32 - 1 entries");
+    DevMem d_ip, d_cols, d_cols2, d_rowof, d_vals, d_pairs, d_pairs2, d_deg, d_bad;
+    int rc;
+    if ((rc = d_ip.alloc((size_t)(num_rows + 1ull) * 4u)) != GL_OK || (rc = d_cols.alloc(nnz * 4u)) != GL_OK || (rc = d_cols2.alloc(nnz * 4u)) != GL_OK ||
+        (rc = d_rowof.alloc(nnz * 4u)) != GL_OK || (rc = d_vals.alloc(nnz * 4u)) != GL_OK || (rc = d_pairs.alloc(nnz * 8u)) != GL_OK ||
+        (rc = d_pairs2.alloc(nnz * 8u)) != GL_OK || (rc = d_deg.alloc((size_t)(num_cols + 1ull) * 4u)) != GL_OK || (rc = d_bad.alloc(16)) != GL_OK)
+        return rc;
+    GL_HIP(hipMemcpyAsync(d_ip.p, h_indptr, (size_t)(num_rows + 1ull) * 4u, hipMemcpyHostToDevice, s));
+    GL_HIP(hipMemsetAsync(d_deg.p, 0, (size_t)(num_cols + 1ull) * 4u, s));
+    GL_HIP(hipMemsetAsync(d_bad.p, 0, 16, s));
+    if (nnz) {
+        GL_HIP(hipMemcpyAsync(d_cols.p, h_indices, nnz * 4u, hipMemcpyHostToDevice, s));
+        GL_HIP(hipMemcpyAsync(d_vals.p, h_data, nnz * 4u, hipMemcpyHostToDevice, s));
+        fmt_row_of_kernel<<<wave_grid(num_rows), kFmtThreads, 0, s>>>(d_ip.as<uint32_t>(), num_rows, d_rowof.as<uint32_t>());
+        GL_LAUNCH_CHECK();
+        fmt_pack_pairs_kernel<<<flat_grid(nnz), kFmtThreads, 0, s>>>(d_rowof.as<uint32_t>(), d_vals.as<uint32_t>(), nnz, d_pairs.as<uint2>());
+        GL_LAUNCH_CHECK();
+        fmt_degree_kernel<<<flat_grid(nnz), kFmtThreads, 0, s>>>(d_cols.as<uint32_t>(), nnz, num_cols, d_deg.as<uint32_t>(), d_bad.as<uint32_t>());
+        GL_LAUNCH_CHECK();
+        if ((rc = sort_pairs<uint32_t>(d_cols.as<uint32_t>(), d_cols2.as<uint32_t>(), d_pairs.as<uint2>(), d_pairs2.as<uint2>(), nnz,
+                                       bits_for(std::max<uint64_t>(num_cols, 2u)), s)) != GL_OK)
+            return rc;
+        fmt_split_pairs_kernel<<<flat_grid(nnz), kFmtThreads, 0, s>>>(d_pairs2.as<uint2>(), nnz, d_rowof.as<uint32_t>(), d_vals.as<uint32_t>());
+        GL_LAUNCH_CHECK();
+    }
+    uint32_t bad = 0;
+    GL_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
+    // column pointers: exclusive scan of the degrees (num_cols + 1 entries, the last one being the total)
+    {
+        size_t tmp_bytes = 0;
+        DevMem d_cp;
+        if ((rc = d_cp.alloc((size_t)(num_cols + 1ull) * 4u)) != GL_OK) return rc;
+        uint32_t *out = d_cp.as<uint32_t>();
+        GL_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, d_deg.as<uint32_t>(), out, 0u, (size_t)num_cols + 1u, rocprim::plus<uint32_t>(), s));
+        DevMem tmp;
+        if ((rc = tmp.alloc(tmp_bytes)) != GL_OK) return rc;
+        GL_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, d_deg.as<uint32_t>(), out, 0u, (size_t)num_cols + 1u, rocprim::plus<uint32_t>(), s));
+        GL_HIP(hipMemcpyAsync(csc_indptr, out, (size_t)(num_cols + 1ull) * 4u, hipMemcpyDeviceToHost, s));
+        GL_HIP(hipStreamSynchronize(s));
+    }
+    if (bad) return set_error(GL_ERR_INVALID_ARG, "gl_csr2csc: column index out of range (num_cols %u)", num_cols);
+    if (nnz) {
+        GL_HIP(hipMemcpyAsync(csc_indices, d_rowof.p, nnz * 4u, hipMemcpyDeviceToHost, s));
+        GL_HIP(hipMemcpyAsync(csc_data, d_vals.p, nnz * 4u, hipMemcpyDeviceToHost, s));
+        GL_HIP(hipStreamSynchronize(s));
+    }
+    return GL_OK;
+}
+
+int fmt_normalize_by_outdegree(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_indptr, const uint32_t *h_indices, float *h_data) {
+    hipStream_t s = ctx().stream;
+    const uint64_t nnz = h_indptr[num_rows];
+    if (!nnz) return GL_OK;
+    DevMem d_cols, d_out, d_deg, d_bad;
+    int rc;
+    if ((rc = d_cols.alloc(nnz * 4u)) != GL_OK || (rc = d_out.alloc(nnz * 4u)) != GL_OK || (rc = d_deg.alloc((size_t)std::max(num_cols, 1u) * 4u)) != GL_OK ||
+        (rc = d_bad.alloc(16)) != GL_OK)
+        return rc;
+    GL_HIP(hipMemsetAsync(d_deg.p, 0, (size_t)num_cols * 4u, s));
+    GL_HIP(hipMemsetAsync(d_bad.p, 0, 16, s));
+    GL_HIP(hipMemcpyAsync(d_cols.p, h_indices, nnz * 4u, hipMemcpyHostToDevice, s));
+    fmt_degree_kernel<<<flat_grid(nnz), kFmtThreads, 0, s>>>(d_cols.as<uint32_t>(), nnz, num_cols, d_deg.as<uint32_t>(), d_bad.as<uint32_t>());
+    GL_LAUNCH_CHECK();
+    uint32_t bad = 0;
+    GL_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+    if (bad) return set_error(GL_ERR_INVALID_ARG, "gl_csr_normalize_by_outdegree: column index out of range (num_cols %u)", num_cols);
+    fmt_normalize_kernel<<<flat_grid(nnz), kFmtThreads, 0, s>>>(d_cols.as<uint32_t>(), d_deg.as<uint32_t>(), nnz, d_out.as<float>());
+    GL_LAUNCH_CHECK();
+    GL_HIP(hipMemcpyAsync(h_data, d_out.p, nnz * 4u, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+    return GL_OK;
+}
+
 int fmt_emit_bool(DevCsr *c, const EmitBool &e, gl_spmv_plan p, uint32_t *max_rows) {
     const uint32_t cb = bits_for(std::max<uint64_t>(e.num_cols, 2u));
     const uint32_t bb = bits_for(std::max<uint32_t>(e.bp->nblocks, 2u));
@@ -860,3 +1089,34 @@ int fmt_emit_bool(DevCsr *c, const EmitBool &e, gl_spmv_plan p, uint32_t *max_ro
 }
 
 }  // namespace gl
+
+extern "C" {
+
+int gl_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices, const float *data,
+               uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data) {
+    GL_ARG(indptr != nullptr && csc_indptr != nullptr);
+    const uint64_t nnz = indptr[num_rows];
+    GL_ARG(nnz == 0 || (indices != nullptr && data != nullptr && csc_indices != nullptr && csc_data != nullptr));
+    if (gl::ctx().initialized && gl::format_on_device(0u, nnz))
+        return gl::fmt_csr2csc(num_rows, num_cols, indptr, indices, data, csc_indptr, csc_indices, csc_data);
+    return gl_host_csr2csc(num_rows, num_cols, indptr, indices, data, csc_indptr, csc_indices, csc_data);
+}
+
+int gl_csr_normalize_by_outdegree(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices, float *data) {
+    GL_ARG(indptr != nullptr);
+    const uint64_t nnz = indptr[num_rows];
+    GL_ARG(nnz == 0 || (indices != nullptr && data != nullptr));
+    if (gl::ctx().initialized && gl::format_on_device(0u, nnz))
+        return gl::fmt_normalize_by_outdegree(num_rows, num_cols, indptr, indices, data);
+    std::vector<uint32_t> per_col(num_cols, 0u);
+    for (uint64_t i = 0; i < nnz; i++) {
+        if (indices[i] >= num_cols)
+            return gl::set_error(GL_ERR_INVALID_ARG, "gl_csr_normalize_by_outdegree: column index %u out of range (num_cols %u)", indices[i], num_cols);
+        per_col[indices[i]]++;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)nnz; i++) data[i] = (float)(1.0 / (double)per_col[indices[i]]);
+    return GL_OK;
+}
+
+}  // extern "C"

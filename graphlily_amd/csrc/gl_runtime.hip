@@ -106,6 +106,13 @@ __global__ void fill_f32_kernel(float *__restrict__ dst, float v, size_t n) {
     for (; i < n; i += stride) dst[i] = v;
 }
 
+__global__ void fill_u32_gated_kernel(uint32_t *__restrict__ dst, uint32_t v, size_t n, const uint32_t *__restrict__ gate, uint32_t gate_value) {
+    if (gate && *gate != gate_value) return;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = v;
+}
+
 }  // namespace gl
 
 extern "C" {
@@ -199,6 +206,39 @@ int gl_prof_end(double *total_ms, uint32_t *launches) {
     }
     if (total_ms) *total_ms = sum;
     if (launches) *launches = p.used;
+    return GL_OK;
+}
+
+// ---- hipGraph capture of a launch sequence on the library's stream
+int gl_graph_begin_capture(void) {
+    GL_REQUIRE_INIT();
+    GL_HIP(hipStreamBeginCapture(gl::ctx().stream, hipStreamCaptureModeThreadLocal));
+    return GL_OK;
+}
+
+int gl_graph_end_capture(gl_graph *graph) {
+    GL_REQUIRE_INIT();
+    GL_ARG(graph != nullptr);
+    *graph = nullptr;
+    hipGraph_t g = nullptr;
+    GL_HIP(hipStreamEndCapture(gl::ctx().stream, &g));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return gl::set_error(GL_ERR_HIP, "gl_graph_end_capture: hipGraphInstantiate: %s", hipGetErrorString(e));
+    *graph = reinterpret_cast<gl_graph>(exec);
+    return GL_OK;
+}
+
+int gl_graph_launch(gl_graph graph) {
+    GL_REQUIRE_INIT();
+    GL_ARG(graph != nullptr);
+    GL_HIP(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph), gl::ctx().stream));
+    return GL_OK;
+}
+
+int gl_graph_destroy(gl_graph graph) {
+    if (graph) GL_HIP(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph)));
     return GL_OK;
 }
 
@@ -463,6 +503,17 @@ int gl_host_alloc(void **h_ptr, size_t bytes) {
 int gl_host_free(void *h_ptr) {
     GL_REQUIRE_INIT();
     if (h_ptr) GL_HIP(hipHostFree(h_ptr));
+    return GL_OK;
+}
+
+int gl_buf_fill_u32_gated(uint32_t *d_dst, uint32_t value, size_t count, const uint32_t *d_gate, uint32_t gate_value) {
+    GL_REQUIRE_INIT();
+    if (count == 0) return GL_OK;
+    GL_ARG(d_dst != nullptr);
+    unsigned blocks = gl::cdiv(count, 256);
+    if (blocks > 2048) blocks = 2048;
+    gl::fill_u32_gated_kernel<<<blocks, 256, 0, gl::ctx().stream>>>(d_dst, value, count, d_gate, gate_value);
+    GL_LAUNCH_CHECK();
     return GL_OK;
 }
 

@@ -86,6 +86,7 @@ struct ScatterArgs {
     uint32_t row_begin;
     uint32_t num_cols;
     const uint32_t *mode;    // non-null: skip the scatter when mode[0] != 0 (the run goes row-wise instead)
+    Gate gate;               // driver-level predicate of the whole run (gl_spmspv_run_gated)
 };
 
 // ordered-integer trick: for IEEE floats, a >= 0 compares like int, a < 0 like reversed uint
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void spmspv_scatter_kernel(ScatterArgs a) {
     __shared__ float s_val[256];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_qbase;
+    if (a.gate.closed()) return;
     if (a.mode && a.mode[0]) return;
     const uint32_t vnnz = a.vec[0].index;
     const uint32_t lane = threadIdx.x & 63u;
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(256) void spmspv_scatter_kernel(ScatterArgs a) {
 // queued chunks of long columns: one workgroup pass (256 threads x 16 coalesced entries) per chunk
 template <int OP>
 __global__ __launch_bounds__(256) void spmspv_queue_kernel(ScatterArgs a) {
+    if (a.gate.closed()) return;
     if (a.mode && a.mode[0]) return;
     uint32_t nq = a.queue_count[0];
     if (nq > a.queue_capacity) nq = a.queue_capacity;
@@ -247,8 +250,12 @@ __global__ __launch_bounds__(256) void spmspv_queue_kernel(ScatterArgs a) {
 
 // work of this run = sum of the lengths of the frontier's columns; the last block to finish sets the mode
 __global__ __launch_bounds__(256) void spmspv_work_kernel(const gl_idx_val *__restrict__ vec, const uint32_t *__restrict__ indptr,
-                                                          uint32_t num_cols, uint32_t *__restrict__ mode, uint64_t threshold) {
+                                                          uint32_t num_cols, uint32_t *__restrict__ mode, uint64_t threshold, Gate gate) {
     __shared__ unsigned long long s_sum[4];
+    if (gate.closed()) {   // a run that does not happen goes neither way: the row-wise kernels look at mode[0]
+        if (blockIdx.x == 0 && threadIdx.x == 0) mode[0] = 0u;
+        return;
+    }
     const uint32_t vnnz = vec[0].index;
     unsigned long long w = 0;
     for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < vnnz; e += gridDim.x * 256u) {
@@ -312,6 +319,7 @@ struct AccSource {
     float zero;
     float *assign;       // gl_spmspv_run_assign: assign[index] = assign_val for every emitted entry (or null)
     float assign_val;
+    uint32_t *next_bits; // gl_spmspv_run_gated: the emitted rows also as a bit vector (zeroed by the caller), or null
     __device__ uint32_t size() const { return nrows; }
     __device__ bool get(uint32_t i, gl_idx_val &out) const {
         float v = acc[i];
@@ -330,6 +338,13 @@ struct AccSource {
     // the entry's own row: no other thread reads or writes assign[item.index] in this pass
     __device__ void emitted(const gl_idx_val &item) const {
         if (assign) assign[item.index] = assign_val;
+        if (next_bits) atomicOr(&next_bits[item.index >> 5], 1u << (item.index & 31u));
+    }
+    // counting pass: the words of next_bits that this chunk's rows own start from zero (row_begin is a multiple of 32
+    // and a chunk holds kCompactChunk = 1024 rows = 32 words; the write pass ORs into them in a later launch)
+    __device__ void begin_chunk(uint32_t first) const {
+        if (next_bits && threadIdx.x < kCompactChunk / 32u && first + 32u * threadIdx.x < nrows)
+            next_bits[((row_begin + first) >> 5) + threadIdx.x] = 0u;
     }
 };
 
@@ -356,12 +371,21 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     GL_ARG(nnz_all == 0 || (h_indices != nullptr && h_data != nullptr));
     const bool whole = (row_begin == 0 && row_end == num_rows);
 
+    for (uint32_t c = 0; c < num_cols; c++) GL_ARG(h_indptr[c + 1] >= h_indptr[c] && h_indptr[c + 1] <= nnz_all);
     std::vector<uint32_t> indptr(num_cols + 1ull);
     std::vector<uint2> stream;
+    // large matrices: the stream is built on the device from the uploaded CSC (gl_format.hip); the host loop below
+    // is the same thing, serially
+    const bool on_device = nnz_all > 0 && gl::format_on_device(0u, nnz_all);
+    uint32_t *dev_indptr = nullptr;
+    uint2 *dev_stream = nullptr;
+    if (on_device) {
+        const int frc = gl::fmt_spmspv_stream(num_rows, num_cols, h_indptr, h_indices, h_data, row_begin, row_end, &dev_indptr, &dev_stream, indptr);
+        if (frc != GL_OK) return frc;
+    } else {
     stream.reserve(whole ? nnz_all : nnz_all / 2);
     for (uint32_t c = 0; c < num_cols; c++) {
         indptr[c] = (uint32_t)stream.size();
-        GL_ARG(h_indptr[c + 1] >= h_indptr[c] && h_indptr[c + 1] <= nnz_all);
         for (uint64_t i = h_indptr[c]; i < h_indptr[c + 1]; i++) {
             uint32_t r = h_indices[i];
             if (r >= num_rows)
@@ -370,6 +394,8 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
         }
     }
     indptr[num_cols] = (uint32_t)stream.size();
+    }
+    const uint64_t kept = on_device ? (uint64_t)indptr[num_cols] : (uint64_t)stream.size();
     uint32_t max_col_len = 0;
     for (uint32_t c = 0; c < num_cols; c++) max_col_len = std::max(max_col_len, indptr[c + 1] - indptr[c]);
 
@@ -379,7 +405,9 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     p->num_cols = num_cols;
     p->row_begin = row_begin;
     p->row_end = row_end;
-    p->nnz = stream.size();
+    p->nnz = kept;
+    p->d_indptr = dev_indptr;   // (null unless the device built them)
+    p->d_stream = dev_stream;
     const uint32_t nrows = row_end - row_begin;
     // one slot per chunk of every long column: a column of deg >= kBigColumn entries yields ceil(deg / kChunk) chunks
     // (nnz / kChunk undercounts: two columns of 4097 entries need four slots).  A vector that lists a column twice
@@ -395,12 +423,12 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
         return gl::set_error(GL_ERR_HIP, "gl_spmspv_plan_create: %s", hipGetErrorString(e));
     };
     hipError_t e;
-    size_t b_indptr = indptr.size() * sizeof(uint32_t), b_stream = stream.size() * sizeof(uint2);
+    size_t b_indptr = indptr.size() * sizeof(uint32_t), b_stream = kept * sizeof(uint2);
     size_t b_acc = (size_t)(nrows ? nrows : 1) * sizeof(float);
     size_t b_counts = (size_t)(gl::cdiv(nrows, gl::kCompactChunk) + 1) * sizeof(uint32_t);
     size_t b_queue = (size_t)p->queue_capacity * sizeof(uint4);
-    if ((e = hipMalloc((void **)&p->d_indptr, b_indptr)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void **)&p->d_stream, b_stream ? b_stream : 16)) != hipSuccess) return fail(e);
+    if (!on_device && (e = hipMalloc((void **)&p->d_indptr, b_indptr)) != hipSuccess) return fail(e);
+    if (!on_device && (e = hipMalloc((void **)&p->d_stream, b_stream ? b_stream : 16)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_acc, b_acc)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_counts, b_counts)) != hipSuccess) return fail(e);
     if ((e = hipMemset(p->d_counts, 0, sizeof(uint32_t))) != hipSuccess) return fail(e);   // the compaction's ticket word
@@ -409,8 +437,8 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     if ((e = hipMemset(p->d_queue_count, 0, 16)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_mode, 16)) != hipSuccess) return fail(e);
     if ((e = hipMemset(p->d_mode, 0, 16)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpy(p->d_indptr, indptr.data(), b_indptr, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
-    if (b_stream && (e = hipMemcpy(p->d_stream, stream.data(), b_stream, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if (!on_device && (e = hipMemcpy(p->d_indptr, indptr.data(), b_indptr, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if (!on_device && b_stream && (e = hipMemcpy(p->d_stream, stream.data(), b_stream, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e);   // the memsets above ran on the null stream
     p->device_bytes = b_indptr + b_stream + b_acc + b_counts + b_queue;
     gl::live_spmspv_plans().push_back(p);
@@ -448,7 +476,27 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
 
 int gl_spmspv_run_assign(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
                          int op, float zero, int mask_type, float *d_inout, float val) {
+    return gl_spmspv_run_gated(p, d_vector, d_mask, d_result, op, zero, mask_type, d_inout, val, nullptr, nullptr, 0u, GL_GATE_EQ,
+                               nullptr, 0u, 0.0f, 0);
+}
+
+int gl_spmspv_run_gated(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
+                        int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
+                        const uint32_t *d_gate, uint32_t gate_value, int gate_op,
+                        uint32_t *d_ctl, uint32_t slot, float dir_threshold, int may_continue_push) {
     GL_REQUIRE_INIT();
+    GL_ARG(gate_op == GL_GATE_EQ || gate_op == GL_GATE_GT || gate_op == GL_GATE_LE);
+    GL_ARG(d_next_bits == nullptr || (p != nullptr && (p->row_begin & 31u) == 0u));
+    gl::Gate gate;
+    gate.word = d_gate;
+    gate.value = gate_value;
+    gate.op = gate_op;
+    gl::Direction dir;
+    dir.ctl = d_ctl;
+    dir.n = p ? p->num_rows : 1u;
+    dir.slot = slot;
+    dir.threshold = dir_threshold;
+    dir.may_continue = may_continue_push ? 1u : 0u;
     GL_ARG(p != nullptr && d_vector != nullptr && d_result != nullptr);
     GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
     GL_ARG(op == GL_OP_MULADD || op == GL_OP_ANDOR || op == GL_OP_ADDMIN);
@@ -482,13 +530,14 @@ int gl_spmspv_run_assign(gl_spmspv_plan p, const gl_idx_val *d_vector, const flo
     if (may_pull) {
         // few blocks: each ends with one atomic on the same ticket word
         uint32_t wgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), 64u);
-        gl::spmspv_work_kernel<<<wgrid ? wgrid : 1u, 256, 0, s>>>(d_vector, p->d_indptr, p->num_cols, p->d_mode, threshold);
+        gl::spmspv_work_kernel<<<wgrid ? wgrid : 1u, 256, 0, s>>>(d_vector, p->d_indptr, p->num_cols, p->d_mode, threshold, gate);
         GL_LAUNCH_CHECK();
     } else if (p->pull != nullptr || p->pull_arith != nullptr) {
         GL_HIP(hipMemsetAsync(p->d_mode, 0, sizeof(uint32_t), s));   // gl_spmspv_last_direction: scatter
     }
 
     gl::ScatterArgs a;
+    a.gate = gate;
     a.mode = may_pull ? p->d_mode : nullptr;
     a.indptr = p->d_indptr;
     a.stream = p->d_stream;
@@ -536,16 +585,16 @@ int gl_spmspv_run_assign(gl_spmspv_plan p, const gl_idx_val *d_vector, const flo
 
     switch (mask_type) {
         case GL_NOMASK: {
-            gl::AccSource<GL_NOMASK> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val};
-            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count);
+            gl::AccSource<GL_NOMASK> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
+            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
         }
         case GL_MASK_WRITETOZERO: {
-            gl::AccSource<GL_MASK_WRITETOZERO> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val};
-            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count);
+            gl::AccSource<GL_MASK_WRITETOZERO> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
+            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
         }
         default: {
-            gl::AccSource<GL_MASK_WRITETOONE> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val};
-            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count);
+            gl::AccSource<GL_MASK_WRITETOONE> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
+            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
         }
     }
 }

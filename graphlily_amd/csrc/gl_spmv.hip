@@ -1324,6 +1324,18 @@ int gl_bfs_pull_step(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits
     return gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, gl::ctx().stream);
 }
 
+int gl_bfs_pull_step_gated(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level,
+                           const uint32_t *d_gate, uint32_t gate_value, int gate_op) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && d_bits_in != nullptr && d_bits_out != nullptr && d_distance != nullptr);
+    GL_ARG(d_bits_in != d_bits_out);
+    GL_ARG((((uintptr_t)d_bits_in | (uintptr_t)d_bits_out) & 15u) == 0);
+    if (!p->boolean)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step: the plan does not hold the GL_PLAN_BOOLEAN layout");
+    GL_ARG(gate_op == GL_GATE_EQ || gate_op == GL_GATE_GT || gate_op == GL_GATE_LE);
+    return gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, gl::ctx().stream, d_gate, gate_value, gate_op);
+}
+
 int gl_spmv_plan_export(gl_spmv_plan p, int array, void *h_dst, size_t capacity, size_t *bytes) {
     GL_REQUIRE_INIT();
     GL_ARG(p != nullptr && bytes != nullptr);

@@ -33,6 +33,9 @@ struct BoolArgs {
     float *dist;
     float level;
     uint32_t tickets;          // 1: ring slots are refilled from an LDS ticket per span; 0: static split (GRAPHLILY_SPMV_TICKETS=0)
+    const uint32_t *gate = nullptr;   // non-null: the launch is a no-op unless gate[0] (gate_op) gate_value (gl_bfs_pull_step_gated)
+    uint32_t gate_value = 0;
+    int gate_op = GL_GATE_EQ;
 };
 
 // x != 0 packed little-endian, 64 columns per wavefront step; words past num_cols are zero
@@ -76,6 +79,10 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     uint32_t *xw = lds_words + kBoolTileWords;      // kBoolPhaseWords
 
     if (a.run_flag && load_const(a.run_flag) == 0u) return;
+    if (a.gate) {   // (a plain load: the word is written by kernels earlier in the stream)
+        const uint32_t w = *a.gate;
+        if (!(a.gate_op == GL_GATE_EQ ? w == a.gate_value : a.gate_op == GL_GATE_GT ? w > a.gate_value : w <= a.gate_value)) return;
+    }
     const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
     const uint32_t span0 = d.x, nspans = d.y, row0 = d.z;
     const uint32_t nrows = d.w & 0xffffu;
@@ -249,7 +256,8 @@ static int launch_bool(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
 
 // One BFS pull iteration on the bit layout (see the FUSED epilogue).  Unsplit plans whose shard starts on a
 // multiple of 64 rows only; bits_out must not alias bits_in.
-int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s) {
+int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s,
+                       const uint32_t *gate, uint32_t gate_value, int gate_op) {
     if (p->row_end == p->row_begin) return GL_OK;
     if (p->segments > 1 || (p->row_begin & 63u) || !p->nunits)
         return set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step: needs an unsplit boolean plan whose shard starts on a multiple of 64 rows");
@@ -267,6 +275,9 @@ int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_o
     a.bits_out = bits_out;
     a.dist = d_distance;
     a.level = level;
+    a.gate = gate;
+    a.gate_value = gate_value;
+    a.gate_op = gate_op;
     a.tickets = bool_tickets();
     return launch_bool_variant<GL_NOMASK, 1>(p, a, s);
 }

@@ -163,12 +163,21 @@ struct EmitBool {
 };
 int fmt_emit_bool(DevCsr *c, const EmitBool &e, gl_spmv_plan p, uint32_t *max_rows);
 
+// SpMSpV plans: the {row, value} stream and its column pointers for the rows of [r0, r1), built on the device from a
+// host CSC (replaces a serial host loop); indptr_out is the host copy of the new column pointers
+int fmt_spmspv_stream(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
+                      uint32_t r0, uint32_t r1, uint32_t **d_indptr_out, uint2 **d_stream_out, std::vector<uint32_t> &indptr_out);
+int fmt_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
+                uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data);
+int fmt_normalize_by_outdegree(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_indptr, const uint32_t *h_indices, float *h_data);
+
 // gl_spmv_bool.hip
 int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data);
 int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const float *d_mask, float *d_y, float zero,
                   int mask_type, hipStream_t s);
 int pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits, hipStream_t s);
-int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s);
+int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s,
+                       const uint32_t *gate = nullptr, uint32_t gate_value = 0, int gate_op = GL_GATE_EQ);
 int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s);
 uint32_t *bool_plan_xbits(gl_spmv_plan p);
 size_t bool_plan_xbits_bytes(gl_spmv_plan p);

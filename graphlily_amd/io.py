@@ -70,10 +70,8 @@ def util_round_csr_matrix_dim(csr_matrix, row_divisor, col_divisor):
 
 def util_normalize_csr_matrix_by_outdegree(csr_matrix):
     """adj_data[i] = 1.0 / (#non-zeros in column of i): double divide, float store."""
-    nnz = csr_matrix.nnz
-    cols = csr_matrix.adj_indices[:nnz]
-    per_col = np.bincount(cols, minlength=csr_matrix.num_cols)
-    csr_matrix.adj_data = (1.0 / per_col[cols].astype(np.float64)).astype(np.float32)
+    csr_matrix.adj_data = capi.csr_normalize_by_outdegree(csr_matrix.num_rows, csr_matrix.num_cols, csr_matrix.adj_indptr,
+                                                          csr_matrix.adj_indices)
 
 
 def sssp_add_self_edges(csr_matrix):

@@ -210,6 +210,9 @@ class SpMVModule(BaseModule):
         self.plan_.bfs_pull_step(bits_in, bits_out, distance_buf, level)
         self._finish()
 
+    def bfs_pull_step_gated(self, bits_in, bits_out, distance_buf, level, gate, gate_value, gate_op):
+        self.plan_.bfs_pull_step_gated(bits_in, bits_out, distance_buf, level, gate, gate_value, gate_op)
+
     def fused_bfs_ok(self):
         if self.plan_ is None or not self._plan_serves(self.semiring_.op) or self.semiring_.zero != 0.0:
             return False
@@ -350,6 +353,14 @@ class SpMSpVModule(BaseModule):
         self.plan_.run_assign(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
                               self.mask_type_, inout_buf, val)
         self._finish()
+
+    def run_gated(self, vector_buf, results_buf, inout_buf, val, next_bits, gate, gate_value, gate_op, ctl=None, slot=0,
+                  threshold=0.0, may_continue=False):
+        """Extension (gl_spmspv_run_gated): run_assign on explicit vector / result buffers under a device-side launch
+        predicate; leaves the emitted rows as bits in `next_bits` and, with `ctl`, takes the push -> pull decision."""
+        mask = self.mask_buf if self.mask_type_ != kNoMask else None
+        self.plan_.run_gated(vector_buf, mask, results_buf, self.semiring_.op, self.semiring_.zero, self.mask_type_,
+                             inout_buf, val, next_bits, gate, gate_value, gate_op, ctl, slot, threshold, may_continue)
 
     def get_results_nnz(self):
         return capi.sparse_nnz(self.results_buf)

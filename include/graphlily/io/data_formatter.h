@@ -5,6 +5,7 @@
 #define GRAPHLILY_IO_DATA_FORMATTER_H_
 
 #include <cstdint>
+#include <type_traits>
 #include <vector>
 
 #include "graphlily/global.h"
@@ -27,6 +28,11 @@ void util_round_csr_matrix_dim(CSRMatrix<data_type> &m, uint32_t row_divisor, ui
 // adj_data[i] = 1.0 / (non-zeros in the column of i): double divide, stored as data_type.
 template <typename data_type>
 void util_normalize_csr_matrix_by_outdegree(CSRMatrix<data_type> &m) {
+    if (std::is_same<data_type, float>::value) {   // natively (GPU when the runtime is up): same double divide, float store
+        GRAPHLILY_CHECK(gl_csr_normalize_by_outdegree(m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
+                                                      reinterpret_cast<float *>(m.adj_data.data())));
+        return;
+    }
     std::vector<uint32_t> per_col(m.num_cols, 0);
     for (uint32_t c : m.adj_indices) per_col[c]++;
     const size_t nnz = m.adj_indptr[m.num_rows];

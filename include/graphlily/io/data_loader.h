@@ -89,7 +89,7 @@ CSCMatrix<data_type> csr2csc(CSRMatrix<data_type> const &a) {
     CSCMatrix<data_type> t{a.num_rows, a.num_cols, std::vector<data_type>(nnz), std::vector<uint32_t>(nnz),
                            std::vector<uint32_t>((size_t)a.num_cols + 1, 0u)};
     if (std::is_same<data_type, float>::value) {
-        GRAPHLILY_CHECK(gl_host_csr2csc(a.num_rows, a.num_cols, a.adj_indptr.data(), a.adj_indices.data(),
+        GRAPHLILY_CHECK(gl_csr2csc(a.num_rows, a.num_cols, a.adj_indptr.data(), a.adj_indices.data(),
                                         reinterpret_cast<const float *>(a.adj_data.data()), t.adj_indptr.data(),
                                         t.adj_indices.data(), reinterpret_cast<float *>(t.adj_data.data())));
         return t;

@@ -62,6 +62,16 @@ int gl_device_count(int *count);
 int gl_set_stream(void *hip_stream);    /* adopt a caller-owned hipStream_t; NULL is HIP's default (null) stream */
 int gl_reset_stream(void);              /* go back to the library-owned stream  */
 int gl_sync(void);                      /* command_queue_.finish()              */
+/* A launch sequence of this library recorded once and replayed with one call (hipGraph): between
+ * gl_graph_begin_capture and gl_graph_end_capture the calls on the library's stream are recorded instead of executed
+ * (only asynchronous entry points may be used: no uploads / downloads / gl_sync / plan creation, and every buffer
+ * the sequence needs must exist already -- run it once eagerly first).  The iterative drivers are launch-bound on
+ * small frontiers (a BFS push iteration is ~10 launches of a few microseconds each). */
+typedef struct gl_graph_s *gl_graph;
+int gl_graph_begin_capture(void);
+int gl_graph_end_capture(gl_graph *graph);
+int gl_graph_launch(gl_graph graph);    /* async, on the library's stream */
+int gl_graph_destroy(gl_graph graph);
 const char *gl_last_error(void);
 const char *gl_version(void);
 
@@ -75,6 +85,8 @@ int gl_buf_h2d(void *d_dst, const void *h_src, size_t bytes);   /* blocking */
 int gl_buf_d2h(void *h_dst, const void *d_src, size_t bytes);   /* blocking */
 int gl_buf_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async    */
 int gl_buf_fill_f32(float *d_dst, float value, size_t count);   /* async    */
+/* 32-bit fill that does nothing unless *d_gate == gate_value (d_gate NULL: always) */
+int gl_buf_fill_u32_gated(uint32_t *d_dst, uint32_t value, size_t count, const uint32_t *d_gate, uint32_t gate_value);
 /* page-locked host memory for result read-back at full PCIe rate (the reference's host mirrors are
  * 4 KiB-aligned for the same reason, xcl2.hpp:61-76) */
 int gl_host_alloc(void **h_ptr, size_t bytes);
@@ -224,6 +236,34 @@ int gl_spmspv_run(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *
 int gl_spmspv_run_assign(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask,
                          gl_idx_val *d_result, int op, float zero, int mask_type, float *d_inout, float val);
 
+/* Extensions that take the host out of the BFS loop (the reference reads the result count back every
+ * push iteration to decide the direction, app/bfs.h:180-190, and converts the frontier on the host at the switch,
+ * :195-205).  A driver enqueues the WHOLE schedule -- for every iteration slot both a pull step and a push step --
+ * and a device-side word decides which of them runs:
+ *   d_ctl            three words: [0] first pull slot (0xffffffff while pushing), [1] push iterations done,
+ *                    [2] source vertex (written by the host before the schedule is enqueued).
+ *   gate             a launch predicate: the call does nothing unless *d_gate (gate_op) gate_value.  The pull step of
+ *                    slot s is gated GL_GATE_LE on d_ctl with value s, its push step GL_GATE_GT.
+ *   gl_bfs_begin     distance[i] = (i == source), the one-entry frontier list {1,(source,1)} (or, with d_frontier NULL,
+ *                    pull from slot 0 on), the frontier as bits, ctl[0..1].
+ *   gl_spmspv_run_gated   gl_spmspv_run_assign under a gate that also (a) leaves the emitted rows as bits in
+ *                    d_next_bits (may be NULL; the words of the plan's rows are rewritten, the shard must start on a
+ *                    multiple of 32 rows) -- so the push -> pull switch needs no conversion pass -- and (b) with d_ctl
+ *                    set, takes the reference's loop decision where the result count is produced: ctl[1]++, and
+ *                    ctl[0] = slot + 1 unless may_continue_push and float(count) / num_rows < threshold.
+ *   gl_bfs_pull_step_gated   gl_bfs_pull_step under a gate.
+ * No call of the schedule synchronises or copies to the host; it can be captured once (gl_graph_*) and replayed. */
+#define GL_GATE_EQ 0
+#define GL_GATE_GT 1
+#define GL_GATE_LE 2
+int gl_bfs_begin(uint32_t *d_ctl, float *d_distance, uint32_t n, gl_idx_val *d_frontier, uint32_t *d_bits, uint32_t bits_words);
+int gl_spmspv_run_gated(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
+                        int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
+                        const uint32_t *d_gate, uint32_t gate_value, int gate_op,
+                        uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue_push);
+int gl_bfs_pull_step_gated(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level,
+                           const uint32_t *d_gate, uint32_t gate_value, int gate_op);
+
 /* Extension: direction switch inside the operator.  `pull` is an SpMV plan over the same matrix and row shard
  * (BFS holds both, app/bfs.h:83-99).  A run with zero == 0 whose frontier columns hold more than 1/32 of the
  * matrix's non-zeros is then computed row-wise into the dense accumulator instead of being scattered: a
@@ -279,6 +319,14 @@ int gl_sparse_to_dense(const gl_idx_val *d_sparse, float *d_dense, uint32_t rang
  * Output arrays: csc_indptr[num_cols+1], csc_indices[nnz], csc_data[nnz].  Needs no GPU. */
 int gl_host_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices,
                     const float *data, uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data);
+/* The same transpose with host arrays in and out, done on the GPU when the runtime is up and the matrix is large (one
+ * stable radix sort of (row, value) pairs by column: identical output), on the host otherwise. */
+int gl_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices,
+               const float *data, uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data);
+/* util_normalize_csr_matrix_by_outdegree (io/data_formatter.h:36-51): data[i] = 1.0 / (entries in the column of i),
+ * double divide stored as float; host arrays, GPU when the runtime is up and the matrix is large. */
+int gl_csr_normalize_by_outdegree(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices,
+                                  float *data);
 
 /* scipy-npz CSR loader: replaces cnpy::npz_load in
  * load_csr_matrix_from_float_npz (io/data_loader.h:51-70).  Two-call protocol:

@@ -209,3 +209,33 @@ def test_fused_bfs_pull_step_equals_the_three_calls(gpu, monkeypatch):
     got_front = ((bits[np.arange(n) >> 5] >> (np.arange(n) & 31).astype(np.uint32)) & 1).astype(np.float32)
     assert np.array_equal(got_front, y)
     assert not bits[(n + 31) // 32:].any() or np.all(bits[(n + 31) // 32:] == 0xFFFFFFFF)   # words past the rows untouched
+
+
+@pytest.mark.parametrize("name", ["rmat_sym_50K", "uniform_10K_10"])
+def test_bfs_pull_push_device_loop_equals_host_loop(gpu, name, monkeypatch):
+    """pull_push with the direction decided on the device (no read-back per iteration; the schedule is
+    captured as a hipGraph from the second call on) gives the oracle's distances and switches direction after the same
+    number of push iterations as the host-driven loop of the reference (app/bfs.h:180-190), for several sources and
+    thresholds, eagerly and replayed."""
+    m = named_matrix(name)
+    om = _oracle_prepared(m, "bfs")
+    bfs = app.BFS(M.num_hbm_channels, 0, 0, 0)
+    bfs.set_up_runtime()
+    bfs.load_and_format_matrix(m, True)
+    bfs.send_matrix_host_to_device()
+    assert bfs._device_loop_ok()
+    deg = np.diff(m.adj_indptr.astype(np.int64))
+    sources = [0, int(np.argmax(deg)), int(np.nonzero(deg > 0)[0][-1])]
+    for thr in (0.001, 0.05, 1.0):
+        for rep in range(3):                       # eager, capture, replay
+            for src in sources:
+                monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "1")
+                got = bfs.pull_push(src, 8, thr)
+                pushes = bfs.push_iterations_
+                assert np.array_equal(got, O.bfs(om, src, 8)), "thr %g rep %d src %d" % (thr, rep, src)
+                monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "0")
+                ref = bfs.pull_push(src, 8, thr)
+                assert np.array_equal(ref, got)
+                assert bfs.push_iterations_ == pushes, "thr %g src %d: device %d vs host %d push iterations" % (
+                    thr, src, pushes, bfs.push_iterations_)
+    assert any(bfs.dev_loop_["graphs"].values()), "the schedule was captured as a graph"

@@ -136,3 +136,55 @@ def test_device_formatter_full_size(gpu, graph):
             f.write(json.dumps(rec) + "\n")
     except OSError:
         pass
+
+
+def test_csr2csc_and_normalise_on_device_equal_host(gpu, monkeypatch):
+    """gl_csr2csc / gl_csr_normalize_by_outdegree: the GPU versions (forced for a small matrix) against the host ones
+    and against the oracle's restatement of io/data_loader.h:108-144 and io/data_formatter.h:36-51."""
+    m = named_matrix("rmat_sym_50K")
+    m.adj_data = np.random.default_rng(8).random(m.nnz, dtype=np.float32)
+    ref = O.csr2csc(to_oracle(m))
+    outs = {}
+    for where in ("0", "1"):
+        monkeypatch.setenv("GRAPHLILY_PLAN_DEVICE", where)
+        c = io.csr2csc(m)
+        outs[where] = c
+        assert np.array_equal(c.adj_indptr, ref.adj_indptr) and np.array_equal(c.adj_indices, ref.adj_indices)
+        assert np.array_equal(c.adj_data, ref.adj_data)
+        n = m.copy()
+        io.util_normalize_csr_matrix_by_outdegree(n)
+        on = to_oracle(m.copy())     # (the oracle normalises in place and shares the arrays it is given)
+        O.util_normalize_csr_matrix_by_outdegree(on)
+        assert np.array_equal(n.adj_data, on.adj_data)
+
+
+@pytest.mark.parametrize("shard", [None, (0, 25088), (25088, 50048)])
+def test_spmspv_plan_built_on_device(gpu, monkeypatch, shard):
+    """The SpMSpV plan's {row, value} stream built by the device path (forced) gives the oracle's results, whole and sharded."""
+    from graphlily_amd import module as M
+    m = named_matrix("rmat_sym_50K")
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    m.adj_data = np.random.default_rng(9).integers(1, 4, size=m.nnz).astype(np.float32)
+    csc = io.csr2csc(m)
+    rng = np.random.default_rng(10)
+    idx = np.sort(rng.choice(m.num_cols, size=700, replace=False)).astype(np.uint32)
+    v = M.make_sparse_vec(idx, rng.integers(1, 5, size=idx.shape[0]).astype(np.float32))
+    mask = rng.integers(0, 2, size=m.num_rows).astype(np.float32)
+    monkeypatch.setenv("GRAPHLILY_PLAN_DEVICE", "1")
+    for sem, op, zero in ((M.ArithmeticSemiring, 0, 0.0), (M.LogicalSemiring, 1, 0.0), (M.TropicalSemiringUfixed, 2, 255.0)):
+        mod = M.SpMSpVModule(0)
+        mod.set_semiring(sem)
+        mod.set_mask_type(M.kMaskWriteToZero if op != 2 else M.kNoMask)
+        mod.set_up_runtime()
+        if shard:
+            mod.set_row_shard(*shard)
+        mod.load_and_format_matrix(csc)
+        mod.send_matrix_host_to_device()
+        mod.send_vector_host_to_device(v)
+        mod.send_mask_host_to_device(mask)
+        mod.run()
+        got = M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), m.num_rows, zero)
+        ref = O.spmspv(to_oracle(csc), v, op, zero, mask, O.WRITETOZERO if op != 2 else O.NOMASK)
+        lo, hi = shard if shard else (0, m.num_rows)
+        assert np.array_equal(got[lo:hi], ref[lo:hi])
+        assert np.all(got[:lo] == zero) and np.all(got[hi:] == zero)
