@@ -32,6 +32,10 @@ EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
     "gl_bfs_begin", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated",
+    "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32", "gl_dist_all_gather_bits",
+    "gl_dist_all_gather_sparse",
+    "gl_spmv_run_typed", "gl_spmspv_run_typed", "gl_ewise_add_typed", "gl_assign_dense_typed", "gl_assign_sparse_typed",
+    "gl_assign_sparse_new_frontier_typed", "gl_sparse_to_dense_typed",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32", "gl_buf_fill_u32_gated",
     "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim",
     "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_plan_export", "gl_spmv_run",
@@ -77,6 +81,13 @@ def lib():
         "gl_bfs_begin": [vp, vp, u32, vp, vp, u32],
         "gl_spmspv_run_gated": [vp, vp, vp, vp, i32, f32, i32, vp, f32, vp, vp, u32, i32, vp, u32, f32, i32],
         "gl_bfs_pull_step_gated": [vp, vp, vp, vp, f32, vp, u32, i32],
+        "gl_dist_unique_id": [vp], "gl_dist_init": [P(vp), i32, i32, vp], "gl_dist_destroy": [vp], "gl_dist_rank": [vp, P(i32), P(i32)],
+        "gl_dist_all_gather_f32": [vp, vp, vp], "gl_dist_all_gather_bits": [vp, vp, vp],
+        "gl_dist_all_gather_sparse": [vp, vp, vp, u32, f32, P(u32)],
+        "gl_spmv_run_typed": [vp, vp, vp, vp, i32, u32, i32, i32], "gl_spmspv_run_typed": [vp, vp, vp, vp, i32, u32, i32, i32],
+        "gl_ewise_add_typed": [vp, vp, u32, u32, i32], "gl_assign_dense_typed": [vp, vp, u32, u32, i32, i32],
+        "gl_assign_sparse_typed": [vp, vp, u32, u32], "gl_assign_sparse_new_frontier_typed": [vp, vp, vp, u32, i32],
+        "gl_sparse_to_dense_typed": [vp, vp, u32, u32, u32],
         "gl_init": [i32], "gl_device_count": [P(i32)], "gl_set_stream": [vp], "gl_reset_stream": [], "gl_sync": [],
         "gl_buf_alloc": [P(vp), ctypes.c_size_t], "gl_buf_free": [vp],
         "gl_host_alloc": [P(vp), ctypes.c_size_t], "gl_host_free": [vp],
@@ -263,6 +274,7 @@ GL_PLAN_NO_MULADD = 1
 GL_PLAN_BOOLEAN = 2
 GL_PLAN_KEEP_VALUES = 4
 GL_GATE_EQ, GL_GATE_GT, GL_GATE_LE = 0, 1, 2
+GL_VAL_FLOAT, GL_VAL_UNSIGNED, GL_VAL_UFIXED_32_8 = 0, 1, 2
 GL_PLAN_HOST_FORMAT = 8
 GL_PLAN_DEVICE_FORMAT = 16
 PLAN_ARRAYS = {"entries": 0, "bases": 1, "units": 2, "hub_rows": 3, "spans": 4}
@@ -305,6 +317,11 @@ class SpMVPlan:
     def run(self, x, mask, y, op, zero, mask_type):
         check(lib().gl_spmv_run(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero),
                                 int(mask_type)))
+
+    def run_typed(self, x, mask, y, op, zero_bits, mask_type, val_type):
+        """gl_spmv_run_typed: the buffers hold 32-bit value words of `val_type` (GL_VAL_*)."""
+        check(lib().gl_spmv_run_typed(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), int(zero_bits), int(mask_type),
+                                      int(val_type)))
 
     def export(self, name):
         """One of the plan's formatted device arrays (PLAN_ARRAYS) as uint32 words (gl_spmv_plan_export)."""
@@ -382,6 +399,10 @@ class SpMSpVPlan:
                                         int(mask_type), _p(inout), float(val), _p(next_bits), _p(gate), int(gate_value),
                                         int(gate_op), _p(ctl), int(slot), float(threshold), int(bool(may_continue))))
 
+    def run_typed(self, vector, mask, result, op, zero_bits, mask_type, val_type):
+        check(lib().gl_spmspv_run_typed(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op), int(zero_bits),
+                                        int(mask_type), int(val_type)))
+
     def run_assign(self, vector, mask, result, op, zero, mask_type, inout, val):
         """gl_spmspv_run_assign: run + gl_assign_sparse(result, inout, val) in the result-writing pass."""
         check(lib().gl_spmspv_run_assign(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op),
@@ -429,6 +450,46 @@ class Graph:
         try:
             if self.handle:
                 lib().gl_graph_destroy(ctypes.c_void_p(self.handle))
+        except Exception:
+            pass
+
+
+class Dist:
+    """gl_dist_*: the RCCL exchange step of the row-sharded path through the C ABI (one communicator per process)."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        check(lib().gl_dist_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, rank, world_size, unique_id):
+        h = ctypes.c_void_p(0)
+        check(lib().gl_dist_init(ctypes.byref(h), int(rank), int(world_size), ctypes.c_char_p(unique_id)))
+        self.handle, self.rank, self.world_size = h.value, int(rank), int(world_size)
+
+    def all_gather_f32(self, full, bounds):
+        b = np.ascontiguousarray(bounds, dtype=np.uint32)
+        check(lib().gl_dist_all_gather_f32(ctypes.c_void_p(self.handle), _p(full), _np_ptr(b)))
+
+    def all_gather_bits(self, bits, row_bounds):
+        b = np.ascontiguousarray(row_bounds, dtype=np.uint32)
+        check(lib().gl_dist_all_gather_bits(ctypes.c_void_p(self.handle), _p(bits), _np_ptr(b)))
+
+    def all_gather_sparse(self, local, full, capacity, head_val):
+        n = ctypes.c_uint32(0)
+        check(lib().gl_dist_all_gather_sparse(ctypes.c_void_p(self.handle), _p(local), _p(full), int(capacity), float(head_val),
+                                              ctypes.byref(n)))
+        return n.value
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            lib().gl_dist_destroy(ctypes.c_void_p(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
         except Exception:
             pass
 
@@ -482,6 +543,48 @@ def assign_sparse_new_frontier(mask, inout, new_frontier, max_entries):
 
 def sparse_to_dense(sparse, dense, rng, zero, max_entries):
     check(lib().gl_sparse_to_dense(_p(sparse), _p(dense), int(rng), float(zero), int(max_entries)))
+
+
+def ewise_add_typed(inp, out, length, val_bits, val_type):
+    check(lib().gl_ewise_add_typed(_p(inp), _p(out), int(length), int(val_bits), int(val_type)))
+
+
+def assign_dense_typed(mask, inout, length, val_bits, mask_type, val_type):
+    check(lib().gl_assign_dense_typed(_p(mask), _p(inout), int(length), int(val_bits), int(mask_type), int(val_type)))
+
+
+def assign_sparse_typed(mask, inout, val_bits, max_entries):
+    check(lib().gl_assign_sparse_typed(_p(mask), _p(inout), int(val_bits), int(max_entries)))
+
+
+def assign_sparse_new_frontier_typed(mask, inout, new_frontier, max_entries, val_type):
+    check(lib().gl_assign_sparse_new_frontier_typed(_p(mask), _p(inout), _p(new_frontier), int(max_entries), int(val_type)))
+
+
+def sparse_to_dense_typed(sparse, dense, rng, zero_bits, max_entries):
+    check(lib().gl_sparse_to_dense_typed(_p(sparse), _p(dense), int(rng), int(zero_bits), int(max_entries)))
+
+
+IDX_WORD = np.dtype([("index", np.uint32), ("val", np.uint32)])   # sparse element of the integer value types
+UFIXED_ONE = 1 << 24                                                 # 1.0 in ap_ufixed<32, 8>
+
+
+def words_from_float(val_type, values):
+    """float -> 32-bit value words, what the reference's csr_matrix_convert_from_float<val_t> does to the float matrix
+    (io/data_loader.h:75-84): `unsigned` truncates toward zero, ap_ufixed<32,8,AP_RND,AP_SAT> rounds half up to 24
+    fraction bits and saturates to [0, 2^32 - 1]."""
+    v = np.asarray(values, dtype=np.float32).astype(np.float64)
+    if val_type == GL_VAL_UNSIGNED:
+        return np.clip(np.trunc(v), 0, 4294967295.0).astype(np.uint64).astype(np.uint32)
+    if val_type == GL_VAL_UFIXED_32_8:
+        q = np.floor(np.where(v > 0, v, 0.0) * 16777216.0 + 0.5)
+        return np.clip(q, 0, 4294967295.0).astype(np.uint64).astype(np.uint32)
+    raise ValueError("not an integer value type: %r" % (val_type,))
+
+
+def words_to_float(val_type, words):
+    w = np.asarray(words, dtype=np.uint32)
+    return w.astype(np.float32) if val_type == GL_VAL_UNSIGNED else (w.astype(np.float64) / 16777216.0).astype(np.float32)
 
 
 def fill_f32(buf, value, count):

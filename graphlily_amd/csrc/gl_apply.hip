@@ -91,6 +91,37 @@ struct RelaxSource {
     __device__ void begin_chunk(uint32_t) const {}
 };
 
+// ---- the apply kernels for the integer value types (gl_common.h): SAT = ap_ufixed<32,8,AP_RND,AP_SAT>, else unsigned
+template <bool SAT>
+__global__ __launch_bounds__(256) void ewise_add_bits_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t len, uint32_t val) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < len; i += gridDim.x * 256u) out[i] = SAT ? sat_add_u32(in[i], val) : in[i] + val;
+}
+
+template <int MASK>
+__global__ __launch_bounds__(256) void assign_dense_bits_kernel(const uint32_t *__restrict__ mask, uint32_t *__restrict__ inout, uint32_t len,
+                                                                uint32_t val) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < len; i += gridDim.x * 256u) {
+        const bool z = mask[i] == 0u;
+        if (MASK == GL_MASK_WRITETOZERO ? z : !z) inout[i] = val;
+    }
+}
+
+struct RelaxSourceBits {   // RelaxSource with the unsigned ordering of the bits (both integer types order like that)
+    const gl_idx_val *mask;
+    uint32_t *inout;
+    __device__ uint32_t size() const { return mask[0].index; }
+    __device__ bool get(uint32_t i, gl_idx_val &out) const {
+        out = mask[1u + i];
+        return inout[out.index] > __float_as_uint(out.val);
+    }
+    __device__ void consumed(uint32_t i) const {
+        const gl_idx_val m = mask[1u + i];
+        if (inout[m.index] > __float_as_uint(m.val)) inout[m.index] = __float_as_uint(m.val);
+    }
+    __device__ void emitted(const gl_idx_val &) const {}
+    __device__ void begin_chunk(uint32_t) const {}
+};
+
 // graphlily/global.h:153-164
 __global__ __launch_bounds__(256) void sparse_scatter_kernel(const gl_idx_val *__restrict__ sv, float *__restrict__ dense,
                                                              uint32_t range) {
@@ -193,6 +224,69 @@ int gl_sparse_to_dense(const gl_idx_val *d_sparse, float *d_dense, uint32_t rang
     gl::sparse_scatter_kernel<<<gl::stream_grid(max_entries), 256, 0, gl::ctx().stream>>>(d_sparse, d_dense, range);
     GL_LAUNCH_CHECK();
     return GL_OK;
+}
+
+// ---- the same operators over the reference's other value types (bit patterns; see gl_common.h)
+static int check_val_type(int val_type, const char *who) {
+    if (val_type == GL_VAL_FLOAT || val_type == GL_VAL_UNSIGNED || val_type == GL_VAL_UFIXED_32_8) return GL_OK;
+    return gl::set_error(GL_ERR_INVALID_ARG, "%s: unknown value type %d", who, val_type);
+}
+
+int gl_ewise_add_typed(const void *d_in, void *d_out, uint32_t len, uint32_t val_bits, int val_type) {
+    GL_REQUIRE_INIT();
+    int rc = check_val_type(val_type, "gl_ewise_add_typed");
+    if (rc != GL_OK) return rc;
+    if (val_type == GL_VAL_FLOAT) return gl_ewise_add((const float *)d_in, (float *)d_out, len, __builtin_bit_cast(float, val_bits));
+    if (len == 0) return GL_OK;
+    GL_ARG(d_in != nullptr && d_out != nullptr);
+    if (val_type == GL_VAL_UFIXED_32_8)
+        gl::ewise_add_bits_kernel<true><<<gl::stream_grid(len), 256, 0, gl::ctx().stream>>>((const uint32_t *)d_in, (uint32_t *)d_out, len, val_bits);
+    else
+        gl::ewise_add_bits_kernel<false><<<gl::stream_grid(len), 256, 0, gl::ctx().stream>>>((const uint32_t *)d_in, (uint32_t *)d_out, len, val_bits);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int gl_assign_dense_typed(const void *d_mask, void *d_inout, uint32_t len, uint32_t val_bits, int mask_type, int val_type) {
+    GL_REQUIRE_INIT();
+    int rc = check_val_type(val_type, "gl_assign_dense_typed");
+    if (rc != GL_OK) return rc;
+    if (val_type == GL_VAL_FLOAT)
+        return gl_assign_dense((const float *)d_mask, (float *)d_inout, len, __builtin_bit_cast(float, val_bits), mask_type);
+    if (mask_type != GL_MASK_WRITETOZERO && mask_type != GL_MASK_WRITETOONE)
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_assign_dense: Invalid mask type %d", mask_type);
+    if (len == 0) return GL_OK;
+    GL_ARG(d_mask != nullptr && d_inout != nullptr);
+    hipStream_t s = gl::ctx().stream;
+    if (mask_type == GL_MASK_WRITETOZERO)
+        gl::assign_dense_bits_kernel<GL_MASK_WRITETOZERO><<<gl::stream_grid(len), 256, 0, s>>>((const uint32_t *)d_mask, (uint32_t *)d_inout, len, val_bits);
+    else
+        gl::assign_dense_bits_kernel<GL_MASK_WRITETOONE><<<gl::stream_grid(len), 256, 0, s>>>((const uint32_t *)d_mask, (uint32_t *)d_inout, len, val_bits);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+/* value moves only: the float entry point with the bits passed through */
+int gl_assign_sparse_typed(const void *d_mask, void *d_inout, uint32_t val_bits, uint32_t max_entries) {
+    return gl_assign_sparse((const gl_idx_val *)d_mask, (float *)d_inout, __builtin_bit_cast(float, val_bits), max_entries);
+}
+
+int gl_sparse_to_dense_typed(const void *d_sparse, void *d_dense, uint32_t range, uint32_t zero_bits, uint32_t max_entries) {
+    return gl_sparse_to_dense((const gl_idx_val *)d_sparse, (float *)d_dense, range, __builtin_bit_cast(float, zero_bits), max_entries);
+}
+
+int gl_assign_sparse_new_frontier_typed(const void *d_mask, void *d_inout, void *d_new_frontier, uint32_t max_entries, int val_type) {
+    GL_REQUIRE_INIT();
+    int rc = check_val_type(val_type, "gl_assign_sparse_new_frontier_typed");
+    if (rc != GL_OK) return rc;
+    if (val_type == GL_VAL_FLOAT)
+        return gl_assign_sparse_new_frontier((const gl_idx_val *)d_mask, (float *)d_inout, (gl_idx_val *)d_new_frontier, max_entries);
+    GL_ARG(d_mask != nullptr && d_inout != nullptr && d_new_frontier != nullptr && d_mask != d_new_frontier);
+    void *counts = nullptr;
+    rc = gl::scratch_reserve((size_t)(gl::cdiv(max_entries, gl::kCompactChunk) + 1) * sizeof(uint32_t), &counts);
+    if (rc != GL_OK) return rc;
+    gl::RelaxSourceBits src{(const gl_idx_val *)d_mask, (uint32_t *)d_inout};
+    return gl::run_compaction(src, max_entries, (uint32_t *)counts, (gl_idx_val *)d_new_frontier, 0.0f, gl::ctx().stream);
 }
 
 }  // extern "C"

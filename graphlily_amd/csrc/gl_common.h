@@ -105,6 +105,63 @@ struct Semiring<GL_OP_ADDMIN> {
     __device__ static float finish(float zero, float s) { return (s < zero) ? s : zero; }
 };
 
+// ------------------------------------------------------------------ the reference's other value types
+// graphlily/global.h:62-64 lets val_t be `unsigned` or ap_ufixed<32, 8, AP_RND, AP_SAT> (the shipped default) instead of
+// float.  Both are 32-bit words, so they travel through the same kernels, buffers and plan layouts as BIT PATTERNS
+// inside `float` variables (loads, stores and register moves never change bits); only the semiring policies below and
+// the mask tests look inside.  Internally the value type is folded into the op code: opx = op + 3 * val_type.
+//   unsigned        C arithmetic: + and * wrap mod 2^32 (associative, so even (+,x) is exact in any order),
+//                   a && b / a || b give 1, MIN is the unsigned minimum (hw/ufixed_pe_fwd.h:23-65 with ValT = unsigned);
+//   ufixed<32,8>    value = bits / 2^24; a + b saturates at 2^32 - 1 (AP_SAT), a && b / a || b give 1.0 = 1 << 24, MIN is
+//                   the unsigned minimum of the bits.  (+,x) is not offered: a saturating sum depends on its order.
+constexpr int kOpU32MulAdd = 3, kOpU32AndOr = 4, kOpU32AddMin = 5, kOpFixAndOr = 7, kOpFixAddMin = 8;
+constexpr uint32_t kFixOne = 1u << 24;
+
+__device__ __forceinline__ uint32_t fbits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ float bitsf(uint32_t v) { return __uint_as_float(v); }
+__device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
+    const uint32_t s = a + b;
+    return s < a ? 0xffffffffu : s;
+}
+
+template <>
+struct Semiring<kOpU32MulAdd> {
+    __device__ static float ident(float) { return bitsf(0u); }
+    __device__ static float mul(float a, float b) { return bitsf(fbits(a) * fbits(b)); }
+    __device__ static float add(float a, float b) { return bitsf(fbits(a) + fbits(b)); }
+    __device__ static float finish(float zero, float s) { return bitsf(fbits(zero) + fbits(s)); }
+};
+
+template <uint32_t ONE>
+struct SemiringBitsAndOr {
+    __device__ static float ident(float) { return bitsf(0u); }
+    __device__ static float mul(float a, float b) { return bitsf((fbits(a) != 0u && fbits(b) != 0u) ? ONE : 0u); }
+    __device__ static float add(float a, float b) { return bitsf((fbits(a) != 0u || fbits(b) != 0u) ? ONE : 0u); }
+    __device__ static float finish(float zero, float s) { return add(zero, s); }
+};
+template <>
+struct Semiring<kOpU32AndOr> : SemiringBitsAndOr<1u> {};
+template <>
+struct Semiring<kOpFixAndOr> : SemiringBitsAndOr<kFixOne> {};
+
+template <bool SAT>
+struct SemiringBitsAddMin {
+    __device__ static float ident(float) { return bitsf(0xffffffffu); }
+    __device__ static float mul(float a, float b) { return bitsf(SAT ? sat_add_u32(fbits(a), fbits(b)) : fbits(a) + fbits(b)); }
+    __device__ static float add(float a, float b) { return bitsf(min(fbits(a), fbits(b))); }
+    __device__ static float finish(float zero, float s) { return add(zero, s); }
+};
+template <>
+struct Semiring<kOpU32AddMin> : SemiringBitsAddMin<false> {};
+template <>
+struct Semiring<kOpFixAddMin> : SemiringBitsAddMin<true> {};
+
+// is this word "zero" for a mask test?  float: compares equal to 0.0 (so -0.0 is zero); the integer types: all bits clear
+template <int OPX>
+__device__ __forceinline__ bool value_is_zero(float v) {
+    return OPX < 3 ? (v == 0.0f) : (__float_as_uint(v) == 0u);
+}
+
 // streamed-once 8-byte load (matrix streams): non-temporal so the stream does not
 // evict the dense vector from L2
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -128,6 +185,14 @@ __device__ __forceinline__ uint32_t load_const(const uint32_t *p) {
 __device__ __forceinline__ uint4 load_const(const uint4 *p) {
     const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
     return make_uint4(load_const(q), load_const(q + 1), load_const(q + 2), load_const(q + 3));
+}
+
+// the same test for a mask compared with 0 in the value type of opx (SpMV epilogue, dense assign)
+template <int MASK, int OPX>
+__device__ __forceinline__ bool mask_allows_zero(float m) {
+    if (MASK == GL_MASK_WRITETOZERO) return value_is_zero<OPX>(m);
+    if (MASK == GL_MASK_WRITETOONE) return !value_is_zero<OPX>(m);
+    return true;
 }
 
 // mask test shared by SpMV epilogue and dense assign: "does the mask allow a write here?"

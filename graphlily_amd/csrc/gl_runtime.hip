@@ -212,6 +212,9 @@ int gl_prof_end(double *total_ms, uint32_t *launches) {
 // ---- hipGraph capture of a launch sequence on the library's stream
 int gl_graph_begin_capture(void) {
     GL_REQUIRE_INIT();
+    if (gl::ctx().stream == nullptr)   // an adopted NULL stream: HIP's legacy default stream cannot be captured
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_graph_begin_capture: the library is on the NULL stream (gl_set_stream(NULL)); "
+                             "capture needs a created stream (gl_reset_stream)");
     GL_HIP(hipStreamBeginCapture(gl::ctx().stream, hipStreamCaptureModeThreadLocal));
     return GL_OK;
 }

@@ -99,7 +99,13 @@ __device__ __forceinline__ void atomic_min_float(float *addr, float v) {
 
 template <int OP>
 __device__ __forceinline__ void scatter_one(float *acc, uint32_t row, float a, float xv) {
-    if (OP == GL_OP_MULADD) {
+    if (OP == kOpU32MulAdd) {            // the integer value types (gl_common.h): the accumulator holds bits
+        atomicAdd(reinterpret_cast<unsigned int *>(&acc[row]), fbits(a) * fbits(xv));
+    } else if (OP == kOpU32AndOr || OP == kOpFixAndOr) {
+        if (fbits(a) != 0u && fbits(xv) != 0u) reinterpret_cast<uint32_t *>(acc)[row] = (OP == kOpU32AndOr) ? 1u : kFixOne;
+    } else if (OP == kOpU32AddMin || OP == kOpFixAddMin) {
+        atomicMin(reinterpret_cast<unsigned int *>(&acc[row]), fbits(Semiring<OP>::mul(a, xv)));
+    } else if (OP == GL_OP_MULADD) {
         unsafeAtomicAdd(&acc[row], a * xv);
     } else if (OP == GL_OP_ANDOR) {
         if (a != 0.0f && xv != 0.0f) acc[row] = 1.0f;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256) void spmspv_frontier_dense_kernel(const gl_idx
 }
 
 // compaction source over the dense accumulator
-template <int MASK>
+template <int MASK, bool BITS = false>   // BITS: the integer value types compare bit patterns (zero may be 0xffffffff, a NaN as a float)
 struct AccSource {
     float *acc;
     const float *mask;
@@ -323,17 +329,19 @@ struct AccSource {
     __device__ uint32_t size() const { return nrows; }
     __device__ bool get(uint32_t i, gl_idx_val &out) const {
         float v = acc[i];
-        if (v == zero) return false;  // checkout_results: dense_data != zero (kernel_spmspv_impl.h:199-226)
+        if (BITS ? (__float_as_uint(v) == __float_as_uint(zero)) : (v == zero)) return false;  // checkout_results: dense_data != zero (kernel_spmspv_impl.h:199-226)
         if (MASK != GL_NOMASK) {
             // write_back_gmem compares the mask with `zero` (kernel_spmspv_impl.h:262-283)
-            if (!mask_allows<MASK>(mask[row_begin + i], zero)) return false;
+            const float m = mask[row_begin + i];
+            const bool eq = BITS ? (__float_as_uint(m) == __float_as_uint(zero)) : (m == zero);
+            if (MASK == GL_MASK_WRITETOZERO ? !eq : eq) return false;
         }
         out.index = row_begin + i;
         out.val = v;
         return true;
     }
     __device__ void consumed(uint32_t i) const {
-        if (acc[i] != zero) acc[i] = zero;
+        if (BITS ? (__float_as_uint(acc[i]) != __float_as_uint(zero)) : (acc[i] != zero)) acc[i] = zero;
     }
     // the entry's own row: no other thread reads or writes assign[item.index] in this pass
     __device__ void emitted(const gl_idx_val &item) const {
@@ -480,10 +488,35 @@ int gl_spmspv_run_assign(gl_spmspv_plan p, const gl_idx_val *d_vector, const flo
                                nullptr, 0u, 0.0f, 0);
 }
 
+static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
+                           int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
+                           const uint32_t *d_gate, uint32_t gate_value, int gate_op,
+                           uint32_t *d_ctl, uint32_t slot, float dir_threshold, int may_continue_push, int val_type);
+
 int gl_spmspv_run_gated(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
                         int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
                         const uint32_t *d_gate, uint32_t gate_value, int gate_op,
                         uint32_t *d_ctl, uint32_t slot, float dir_threshold, int may_continue_push) {
+    return spmspv_run_impl(p, d_vector, d_mask, d_result, op, zero, mask_type, d_inout, val, d_next_bits, d_gate, gate_value, gate_op,
+                           d_ctl, slot, dir_threshold, may_continue_push, GL_VAL_FLOAT);
+}
+
+/* the sparse elements of the integer value types are {uint32 index; uint32 value bits}: same size and layout */
+int gl_spmspv_run_typed(gl_spmspv_plan p, const void *d_vector, const void *d_mask, void *d_result, int op, uint32_t zero_bits,
+                        int mask_type, int val_type) {
+    if (val_type != GL_VAL_FLOAT && val_type != GL_VAL_UNSIGNED && val_type != GL_VAL_UFIXED_32_8)
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_run_typed: unknown value type %d", val_type);
+    if (val_type == GL_VAL_UFIXED_32_8 && op == GL_OP_MULADD)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmspv_run_typed: (+,x) over ap_ufixed<32,8,AP_RND,AP_SAT> is not offered (order-dependent saturation)");
+    return spmspv_run_impl(p, (const gl_idx_val *)d_vector, (const float *)d_mask, (gl_idx_val *)d_result, op,
+                           __builtin_bit_cast(float, zero_bits), mask_type, nullptr, 0.0f, nullptr, nullptr, 0u, GL_GATE_EQ, nullptr, 0u,
+                           0.0f, 0, val_type);
+}
+
+static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
+                           int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
+                           const uint32_t *d_gate, uint32_t gate_value, int gate_op,
+                           uint32_t *d_ctl, uint32_t slot, float dir_threshold, int may_continue_push, int val_type) {
     GL_REQUIRE_INIT();
     GL_ARG(gate_op == GL_GATE_EQ || gate_op == GL_GATE_GT || gate_op == GL_GATE_LE);
     GL_ARG(d_next_bits == nullptr || (p != nullptr && (p->row_begin & 31u) == 0u));
@@ -522,7 +555,7 @@ int gl_spmspv_run_gated(gl_spmspv_plan p, const gl_idx_val *d_vector, const floa
     if (op == GL_OP_ANDOR && zero == 0.0f) pull_plan = p->pull;
     else if (op == GL_OP_MULADD && zero == 0.0f && p->pull_arith && !(p->pull_arith->flags & GL_PLAN_NO_MULADD)) pull_plan = p->pull_arith;
     else if (op == GL_OP_ADDMIN && zero <= gl::kFloatInf) pull_plan = p->pull_arith;
-    bool may_pull = pull_plan != nullptr && nrows > 0 && gl::env_long("GRAPHLILY_SPMSPV_PULL", 1) != 0;
+    bool may_pull = pull_plan != nullptr && nrows > 0 && val_type == GL_VAL_FLOAT && gl::env_long("GRAPHLILY_SPMSPV_PULL", 1) != 0;
     // a caller that knows how many entries the vector holds (gl_spmspv_plan_hint) spares tiny frontiers the
     // decision kernels: they cannot reach the threshold whatever their columns are
     if (may_pull && p->frontier_hint != ~0ull && p->frontier_hint * (uint64_t)p->max_col_len <= threshold) may_pull = false;
@@ -553,10 +586,16 @@ int gl_spmspv_run_gated(gl_spmspv_plan p, const gl_idx_val *d_vector, const floa
     if (grid > cap) grid = cap;
     if (grid == 0) grid = 1;
     int rc;
-    switch (op) {
+    switch (op + 3 * val_type) {
         case GL_OP_MULADD: rc = gl::launch_scatter<GL_OP_MULADD>(a, grid, s); break;
         case GL_OP_ANDOR: rc = gl::launch_scatter<GL_OP_ANDOR>(a, grid, s); break;
-        default: rc = gl::launch_scatter<GL_OP_ADDMIN>(a, grid, s); break;
+        case GL_OP_ADDMIN: rc = gl::launch_scatter<GL_OP_ADDMIN>(a, grid, s); break;
+        case gl::kOpU32MulAdd: rc = gl::launch_scatter<gl::kOpU32MulAdd>(a, grid, s); break;
+        case gl::kOpU32AndOr: rc = gl::launch_scatter<gl::kOpU32AndOr>(a, grid, s); break;
+        case gl::kOpU32AddMin: rc = gl::launch_scatter<gl::kOpU32AddMin>(a, grid, s); break;
+        case gl::kOpFixAndOr: rc = gl::launch_scatter<gl::kOpFixAndOr>(a, grid, s); break;
+        case gl::kOpFixAddMin: rc = gl::launch_scatter<gl::kOpFixAddMin>(a, grid, s); break;
+        default: return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmspv_run: semiring op %d is not offered for value type %d", op, val_type);
     }
     if (rc != GL_OK) return rc;
     if (may_pull && op != GL_OP_ANDOR) {
@@ -583,6 +622,22 @@ int gl_spmspv_run_gated(gl_spmspv_plan p, const gl_idx_val *d_vector, const floa
         if (rc != GL_OK) return rc;
     }
 
+    if (val_type != GL_VAL_FLOAT) {
+        switch (mask_type) {
+            case GL_NOMASK: {
+                gl::AccSource<GL_NOMASK, true> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
+                return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
+            }
+            case GL_MASK_WRITETOZERO: {
+                gl::AccSource<GL_MASK_WRITETOZERO, true> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
+                return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
+            }
+            default: {
+                gl::AccSource<GL_MASK_WRITETOONE, true> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
+                return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
+            }
+        }
+    }
     switch (mask_type) {
         case GL_NOMASK: {
             gl::AccSource<GL_NOMASK> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};

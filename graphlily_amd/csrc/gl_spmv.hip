@@ -140,6 +140,66 @@ struct Tile<GL_OP_ADDMIN> {
     __device__ static float finish(float zero, float s) { return (s < zero) ? s : zero; }
 };
 
+// ---- the integer value types (gl_common.h): 32-bit LDS accumulators holding the bits
+template <>
+struct Tile<kOpU32MulAdd> {
+    using T = uint32_t;
+    __device__ static T ident() { return 0u; }
+    __device__ static void acc(T *t, uint32_t r, float a, float xv) {
+        __hip_atomic_fetch_add(&t[r], fbits(a) * fbits(xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ static T lift(float z) { return fbits(z); }
+    __device__ static void accz(T *t, uint32_t r, float z) {
+        __hip_atomic_fetch_add(&t[r], fbits(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ static T comb(T x, T y) { return x + y; }
+    __device__ static float get(const T *t, uint32_t r) { return bitsf(t[r]); }
+    __device__ static float init(float zero) { return zero; }
+    __device__ static float finish(float zero, float s) { return bitsf(fbits(zero) + fbits(s)); }
+};
+
+template <uint32_t ONE>
+struct TileBitsAndOr {
+    using T = uint32_t;
+    __device__ static T ident() { return 0u; }
+    __device__ static void acc(T *t, uint32_t r, float a, float xv) {
+        if (fbits(a) != 0u && fbits(xv) != 0u) t[r] = ONE;   // every writer stores the same value
+    }
+    __device__ static T lift(float z) { return fbits(z) != 0u ? ONE : 0u; }
+    __device__ static void accz(T *t, uint32_t r, float z) {
+        if (fbits(z) != 0u) t[r] = ONE;
+    }
+    __device__ static T comb(T x, T y) { return (x | y) ? ONE : 0u; }
+    __device__ static float get(const T *t, uint32_t r) { return bitsf(t[r]); }
+    __device__ static float init(float zero) { return bitsf(fbits(zero) != 0u ? ONE : 0u); }
+    __device__ static float finish(float zero, float s) { return bitsf((fbits(zero) | fbits(s)) ? ONE : 0u); }
+};
+template <>
+struct Tile<kOpU32AndOr> : TileBitsAndOr<1u> {};
+template <>
+struct Tile<kOpFixAndOr> : TileBitsAndOr<kFixOne> {};
+
+template <int OPX>
+struct TileBitsAddMin {
+    using T = uint32_t;
+    __device__ static T ident() { return 0xffffffffu; }
+    __device__ static void acc(T *t, uint32_t r, float a, float xv) {
+        __hip_atomic_fetch_min(&t[r], fbits(Semiring<OPX>::mul(a, xv)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ static T lift(float z) { return fbits(z); }
+    __device__ static void accz(T *t, uint32_t r, float z) {
+        __hip_atomic_fetch_min(&t[r], fbits(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ static T comb(T x, T y) { return min(x, y); }
+    __device__ static float get(const T *t, uint32_t r) { return bitsf(t[r]); }
+    __device__ static float init(float zero) { return zero; }
+    __device__ static float finish(float zero, float s) { return bitsf(min(fbits(zero), fbits(s))); }
+};
+template <>
+struct Tile<kOpU32AddMin> : TileBitsAddMin<kOpU32AddMin> {};
+template <>
+struct Tile<kOpFixAddMin> : TileBitsAddMin<kOpFixAddMin> {};
+
 // after the sweep: hub slots -> rows, then y (unsplit blocks) or this unit's plane (split blocks)
 template <int OP, int MASK>
 __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename Tile<OP>::T *tile, const uint4 d, const uint4 dh) {
@@ -172,7 +232,7 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
             float out = TL::finish(a.zero, TL::get(tile, i));
             if (MASK != GL_NOMASK) {
                 // masked-off rows are literal 0, and the mask is compared with 0 (spmv_module.h:518-530)
-                if (!mask_allows<MASK>(a.mask[row], 0.0f)) out = 0.0f;
+                if (!mask_allows_zero<MASK, OP>(a.mask[row])) out = 0.0f;
             }
             a.y[row] = out;
         }
@@ -428,7 +488,7 @@ __global__ __launch_bounds__(256) void spmv_init_kernel(uint32_t r0, uint32_t r1
     for (uint32_t r = r0 + blockIdx.x * 256u + threadIdx.x; r < r1; r += gridDim.x * 256u) {
         float out = Tile<OP>::init(zero);
         if (MASK != GL_NOMASK) {
-            if (!mask_allows<MASK>(mask[r], 0.0f)) out = 0.0f;
+            if (!mask_allows_zero<MASK, OP>(mask[r])) out = 0.0f;
         }
         y[r] = out;
     }
@@ -463,7 +523,7 @@ __global__ __launch_bounds__(256) void spmv_combine_kernel(const uint4 *__restri
         }
         float out = Tile<OP>::finish(zero, s);
         if (MASK != GL_NOMASK) {
-            if (!mask_allows<MASK>(mask[row], 0.0f)) out = 0.0f;
+            if (!mask_allows_zero<MASK, OP>(mask[row])) out = 0.0f;
         }
         y[row] = out;
     }
@@ -715,6 +775,11 @@ int spmv_init_rows(int op, int mask_type, uint32_t r0, uint32_t r1, const float 
         case GL_OP_MULADD: return init_rows_mask<GL_OP_MULADD>(mask_type, r0, r1, mask, y, zero, s);
         case GL_OP_ANDOR: return init_rows_mask<GL_OP_ANDOR>(mask_type, r0, r1, mask, y, zero, s);
         case GL_OP_ADDMIN: return init_rows_mask<GL_OP_ADDMIN>(mask_type, r0, r1, mask, y, zero, s);
+        case kOpU32MulAdd: return init_rows_mask<kOpU32MulAdd>(mask_type, r0, r1, mask, y, zero, s);
+        case kOpU32AndOr: return init_rows_mask<kOpU32AndOr>(mask_type, r0, r1, mask, y, zero, s);
+        case kOpU32AddMin: return init_rows_mask<kOpU32AddMin>(mask_type, r0, r1, mask, y, zero, s);
+        case kOpFixAndOr: return init_rows_mask<kOpFixAndOr>(mask_type, r0, r1, mask, y, zero, s);
+        case kOpFixAddMin: return init_rows_mask<kOpFixAddMin>(mask_type, r0, r1, mask, y, zero, s);
         default: return set_error(GL_ERR_INVALID_ARG, "invalid semiring op %d", op);
     }
 }
@@ -1390,6 +1455,25 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     return gl::spmv_run_general(p, d_x, d_mask, d_y, op, zero, mask_type, nullptr);
 }
 
+int gl_spmv_run_typed(gl_spmv_plan p, const void *d_x, const void *d_mask, void *d_y, int op, uint32_t zero_bits, int mask_type,
+                      int val_type) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && d_y != nullptr);
+    GL_ARG(d_x != nullptr || p->nnz == 0);
+    GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
+    GL_ARG(op == GL_OP_MULADD || op == GL_OP_ANDOR || op == GL_OP_ADDMIN);
+    const float zero = __builtin_bit_cast(float, zero_bits);
+    if (val_type == GL_VAL_FLOAT) return gl_spmv_run(p, (const float *)d_x, (const float *)d_mask, (float *)d_y, op, zero, mask_type);
+    if (val_type != GL_VAL_UNSIGNED && val_type != GL_VAL_UFIXED_32_8)
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_run_typed: unknown value type %d", val_type);
+    if (p->boolean)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run_typed: GL_PLAN_BOOLEAN plans serve float (||,&&) only; create the plan without it");
+    if (val_type == GL_VAL_UFIXED_32_8 && op == GL_OP_MULADD)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run_typed: (+,x) over ap_ufixed<32,8,AP_RND,AP_SAT> is not offered: a saturating, "
+                             "rounding sum depends on the order of its terms, so no parallel order reproduces the reference bit for bit");
+    return gl::spmv_run_general(p, (const float *)d_x, (const float *)d_mask, (float *)d_y, op + 3 * val_type, zero, mask_type, nullptr);
+}
+
 }  // extern "C"
 
 namespace gl {
@@ -1432,10 +1516,15 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
     a.tickets = tickets;
     hipStream_t s = gl::ctx().stream;
     int rc;
-    switch (op) {
+    switch (op) {   // op + 3 * value type (gl_common.h)
         case GL_OP_MULADD: rc = gl::dispatch_mask<GL_OP_MULADD>(mask_type, p, a, s); break;
         case GL_OP_ANDOR: rc = gl::dispatch_mask<GL_OP_ANDOR>(mask_type, p, a, s); break;
         case GL_OP_ADDMIN: rc = gl::dispatch_mask<GL_OP_ADDMIN>(mask_type, p, a, s); break;
+        case gl::kOpU32MulAdd: rc = gl::dispatch_mask<gl::kOpU32MulAdd>(mask_type, p, a, s); break;
+        case gl::kOpU32AndOr: rc = gl::dispatch_mask<gl::kOpU32AndOr>(mask_type, p, a, s); break;
+        case gl::kOpU32AddMin: rc = gl::dispatch_mask<gl::kOpU32AddMin>(mask_type, p, a, s); break;
+        case gl::kOpFixAndOr: rc = gl::dispatch_mask<gl::kOpFixAndOr>(mask_type, p, a, s); break;
+        case gl::kOpFixAddMin: rc = gl::dispatch_mask<gl::kOpFixAddMin>(mask_type, p, a, s); break;
         default: rc = gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid semiring op %d", op); break;
     }
     if (d_clocks) {   // debugging only: blocking dump (100 MHz ticks), last run wins

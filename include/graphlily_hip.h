@@ -309,6 +309,58 @@ int gl_assign_sparse(const gl_idx_val *d_mask, float *d_inout, float val, uint32
 int gl_assign_sparse_new_frontier(const gl_idx_val *d_mask, float *d_inout,
                                   gl_idx_val *d_new_frontier, uint32_t max_entries);
 
+/* ------------------------------------------------- the reference's other value types
+ * graphlily/global.h:62-64: val_t is `unsigned`, ap_ufixed<32, 8, AP_RND, AP_SAT> (the shipped default) or float.
+ * Both integer types are 32-bit words; they use the float entry points' buffers, plans (gl_*_plan_create take the
+ * value words through the `float *` parameter, bit for bit -- create SpMV plans without GL_PLAN_BOOLEAN) and
+ * sparse elements ({uint32 index; uint32 value}), and these entry points with the value type spelled out.
+ * Semantics (hw/ufixed_pe_fwd.h:23-65):
+ *   GL_VAL_UNSIGNED     + and * wrap mod 2^32, a && b / a || b give 1, MIN is unsigned; all three semirings
+ *                       (modular sums are exact in any order).
+ *   GL_VAL_UFIXED_32_8  value = word / 2^24; a + b saturates at 2^32 - 1 (AP_SAT), a && b / a || b give 1.0 = 1 << 24,
+ *                       MIN is the unsigned minimum of the words; (||,&&) and (min,+).  (+,x) returns
+ *                       GL_ERR_UNSUPPORTED: a saturating, rounding sum depends on the order of its terms.
+ * Mask tests compare words with 0 (SpMV, dense assign) or with `zero_bits` (SpMSpV), masked-off SpMV rows are 0.
+ * Results are bit-exact against oracle/graphlily_oracle.c's integer restatement (tests/test_gpu_typed.py). */
+#define GL_VAL_FLOAT 0
+#define GL_VAL_UNSIGNED 1
+#define GL_VAL_UFIXED_32_8 2
+int gl_spmv_run_typed(gl_spmv_plan plan, const void *d_x, const void *d_mask, void *d_y, int op, uint32_t zero_bits,
+                      int mask_type, int val_type);
+int gl_spmspv_run_typed(gl_spmspv_plan plan, const void *d_vector, const void *d_mask, void *d_result, int op,
+                        uint32_t zero_bits, int mask_type, int val_type);
+int gl_ewise_add_typed(const void *d_in, void *d_out, uint32_t len, uint32_t val_bits, int val_type);
+int gl_assign_dense_typed(const void *d_mask, void *d_inout, uint32_t len, uint32_t val_bits, int mask_type, int val_type);
+int gl_assign_sparse_typed(const void *d_mask, void *d_inout, uint32_t val_bits, uint32_t max_entries);
+int gl_assign_sparse_new_frontier_typed(const void *d_mask, void *d_inout, void *d_new_frontier, uint32_t max_entries,
+                                        int val_type);
+int gl_sparse_to_dense_typed(const void *d_sparse, void *d_dense, uint32_t range, uint32_t zero_bits, uint32_t max_entries);
+
+/* ------------------------------------------------------------------ multi-GPU exchange (RCCL over xGMI)
+ * The reference is single-device; SURVEY.md 8(e): the matrix is cut into contiguous row ranges, one per GPU /
+ * process (gl_*_plan_create's [row_begin,row_end), SpMVModule::set_row_shard), every iteration each rank produces its
+ * slice of the result vector and ONE all-gather rebuilds the whole vector -- the next iteration's input -- on every
+ * rank.  These calls are that exchange step for C / C++ callers (graphlily_amd/dist.py does the same through
+ * torch.distributed): asynchronous, on the library's stream, in place.  RCCL is loaded at run time.
+ *   gl_dist_unique_id   rank 0 obtains 128 bytes and hands them to the other ranks by any means (file, MPI, socket);
+ *   gl_dist_init        every rank, after gl_init(its device): ncclCommInitRank;
+ *   gl_dist_all_gather_f32     d_full[bounds[r] .. bounds[r+1]) is valid on rank r before, everywhere after;
+ *                              slices may differ in length (nnz-balanced ranges): point-to-point pushes in one group;
+ *   gl_dist_all_gather_bits    the same for a bit vector (gl_pack_bits / gl_bfs_pull_step), bounds in ROWS, multiples
+ *                              of 32 -- a sharded BFS pull exchanges n/8 bytes per iteration instead of 4n;
+ *   gl_dist_all_gather_sparse  the ranks' sparse result lists (disjoint ascending row ranges) concatenated in rank order
+ *                              into d_full with head {total, head_val}; reads the counts back (blocking), like
+ *                              SpMSpVModule::get_results_nnz in the reference's push loops. */
+typedef struct gl_dist_s *gl_dist;
+int gl_dist_unique_id(void *id128);
+int gl_dist_init(gl_dist *comm, int rank, int world_size, const void *id128);
+int gl_dist_destroy(gl_dist comm);
+int gl_dist_rank(gl_dist comm, int *rank, int *world_size);
+int gl_dist_all_gather_f32(gl_dist comm, float *d_full, const uint32_t *bounds);
+int gl_dist_all_gather_bits(gl_dist comm, uint32_t *d_bits, const uint32_t *row_bounds);
+int gl_dist_all_gather_sparse(gl_dist comm, const gl_idx_val *d_local, gl_idx_val *d_full, uint32_t capacity, float head_val,
+                              uint32_t *total);
+
 /* ---------------------------------------------------------------- utilities */
 /* convert_sparse_vec_to_dense_vec (graphlily/global.h:153-164) on device; replaces
  * the host round trip at the push->pull switch (app/bfs.h:196-201). */

@@ -372,3 +372,145 @@ void orc_spmv_omp(int op, float zero, uint32_t num_rows,
         y[r] = acc;
     }
 }
+
+/* ============================================================================================================
+ * The reference's other value types (graphlily/global.h:62-64): `unsigned` and ap_ufixed<32, 8, AP_RND, AP_SAT>.
+ *
+ * PARITY UNPINNED for this section: the reference has no CPU path in these types -- its compute_reference_results
+ * members always compute in float (spmv_module.h:478-532 works on the float copy of the matrix) and its tests compare
+ * float(kernel result) with that within 1e-4 (test_module_spmv_spmspv.cpp:33-40).  What is restated here is the
+ * arithmetic of the device ALUs, hw/ufixed_pe_fwd.h:23-65 (pe_ufixed_mul_alu: a * b / a && b / a + b;
+ * pe_ufixed_add_alu: a + b / a || b / MIN(a, b)), applied in the loop order of the float reference, with the
+ * assignment semantics of the value type written out:
+ *   unsigned                 C arithmetic, results wrap mod 2^32; a && b and a || b are 0 / 1.
+ *   ap_ufixed<32,8,RND,SAT>  word w stands for w / 2^24.  A product has 48 fraction bits and is assigned with
+ *                            AP_RND (add half an ulp, truncate: round half up) and AP_SAT (clamp to 2^32 - 1); a sum
+ *                            has the operands' fraction bits and is only clamped; a && b and a || b are 0 / 1.0 = 1 << 24.
+ * Words travel as uint32_t; a sparse element is {uint32 index; uint32 value}.
+ * ============================================================================================================ */
+enum { ORC_VAL_FLOAT = 0, ORC_VAL_UNSIGNED = 1, ORC_VAL_UFIXED_32_8 = 2 };
+typedef struct { uint32_t index; uint32_t val; } orc_idx_word_t;
+
+static uint32_t orc_w_one(int vt) { return vt == ORC_VAL_UFIXED_32_8 ? (1u << 24) : 1u; }
+
+/* pe_ufixed_mul_alu (hw/ufixed_pe_fwd.h:27-45) followed by the assignment to ValT */
+static uint32_t orc_w_mul(int op, int vt, uint32_t a, uint32_t b)
+{
+    switch (op) {
+    case ORC_MULADD:
+        if (vt == ORC_VAL_UNSIGNED) return a * b;
+        {
+            uint64_t p = (uint64_t)a * (uint64_t)b;        /* 16 integer bits, 48 fraction bits */
+            uint64_t r = (p + (1ull << 23)) >> 24;         /* AP_RND to 24 fraction bits */
+            return r > 0xffffffffull ? 0xffffffffu : (uint32_t)r;   /* AP_SAT */
+        }
+    case ORC_ANDOR:
+        return (a != 0 && b != 0) ? orc_w_one(vt) : 0u;
+    default: /* ORC_ADDMIN */
+        if (vt == ORC_VAL_UNSIGNED) return a + b;
+        {
+            uint64_t s = (uint64_t)a + (uint64_t)b;
+            return s > 0xffffffffull ? 0xffffffffu : (uint32_t)s;
+        }
+    }
+}
+
+/* pe_ufixed_add_alu (hw/ufixed_pe_fwd.h:47-65) followed by the assignment to ValT */
+static uint32_t orc_w_add(int op, int vt, uint32_t a, uint32_t b)
+{
+    switch (op) {
+    case ORC_MULADD:
+        if (vt == ORC_VAL_UNSIGNED) return a + b;
+        {
+            uint64_t s = (uint64_t)a + (uint64_t)b;
+            return s > 0xffffffffull ? 0xffffffffu : (uint32_t)s;
+        }
+    case ORC_ANDOR:
+        return (a != 0 || b != 0) ? orc_w_one(vt) : 0u;
+    default:
+        return a < b ? a : b;
+    }
+}
+
+/* float -> value word, the conversion csr_matrix_convert_from_float<val_t> performs (io/data_loader.h:75-84):
+ * unsigned: C conversion (truncation toward zero); ap_ufixed: AP_RND / AP_SAT (negative values clamp to 0) */
+uint32_t orc_word_from_float(int vt, float v)
+{
+    if (vt == ORC_VAL_UNSIGNED) return v <= 0.0f ? 0u : (v >= 4294967296.0f ? 0xffffffffu : (uint32_t)v);
+    if (!(v > 0.0f)) return 0u;
+    double q = (double)v * 16777216.0 + 0.5;
+    if (q >= 4294967296.0) return 0xffffffffu;
+    return (uint32_t)q;   /* floor: q > 0 */
+}
+
+float orc_word_to_float(int vt, uint32_t w)
+{
+    return vt == ORC_VAL_UNSIGNED ? (float)w : (float)((double)w / 16777216.0);
+}
+
+/* SpMVModule::compute_reference_results (module/spmv_module.h:478-532) in the value type: accumulator initialised to
+ * zero, sequential CSR order; masked-off rows are the literal 0 and the mask is compared with 0 */
+void orc_spmv_words(int op, int vt, uint32_t zero, int mask_type, uint32_t num_rows,
+                    const uint32_t *indptr, const uint32_t *indices, const uint32_t *data,
+                    const uint32_t *x, const uint32_t *mask, uint32_t *y)
+{
+    for (uint32_t r = 0; r < num_rows; r++) {
+        uint32_t acc = zero;
+        for (uint32_t i = indptr[r]; i < indptr[r + 1]; i++)
+            acc = orc_w_add(op, vt, acc, orc_w_mul(op, vt, data[i], x[indices[i]]));
+        if (mask_type == ORC_WRITETOZERO) { if (mask[r] != 0) acc = 0; }
+        else if (mask_type != ORC_NOMASK) { if (mask[r] == 0) acc = 0; }
+        y[r] = acc;
+    }
+}
+
+/* SpMSpVModule::compute_reference_results (module/spmspv_module.h:445-520) in the value type: dense result; the mask
+ * is compared with `zero` and masked-off rows are `zero` */
+void orc_spmspv_words(int op, int vt, uint32_t zero, int mask_type, uint32_t num_rows,
+                      const uint32_t *csc_indptr, const uint32_t *csc_indices, const uint32_t *csc_data,
+                      const orc_idx_word_t *v, const uint32_t *mask, uint32_t *y)
+{
+    for (uint32_t r = 0; r < num_rows; r++) y[r] = zero;
+    uint32_t active = v[0].index;
+    for (uint32_t k = 1; k <= active; k++) {
+        uint32_t col = v[k].index, xv = v[k].val;
+        for (uint32_t e = csc_indptr[col]; e < csc_indptr[col + 1]; e++) {
+            uint32_t row = csc_indices[e];
+            y[row] = orc_w_add(op, vt, y[row], orc_w_mul(op, vt, csc_data[e], xv));
+        }
+    }
+    for (uint32_t r = 0; r < num_rows; r++) {
+        int off = 0;
+        if (mask_type == ORC_WRITETOONE) off = (mask[r] == zero);
+        else if (mask_type == ORC_WRITETOZERO) off = (mask[r] != zero);
+        if (off) y[r] = zero;
+    }
+}
+
+/* kernel_add_scalar_vector_dense (hw/kernel_add_scalar_vector_dense_impl.h:6-27): out = in + val in the value type */
+void orc_ewise_add_words(int vt, const uint32_t *in, uint32_t len, uint32_t val, uint32_t *out)
+{
+    for (uint32_t i = 0; i < len; i++) out[i] = orc_w_add(ORC_MULADD, vt, in[i], val);
+}
+
+/* kernel_assign_vector_dense (hw/kernel_assign_vector_dense_impl.h:8-47) */
+void orc_assign_dense_words(int mask_type, const uint32_t *mask, uint32_t *inout, uint32_t len, uint32_t val)
+{
+    for (uint32_t i = 0; i < len; i++)
+        if ((mask_type == ORC_WRITETOZERO) ? (mask[i] == 0) : (mask[i] != 0)) inout[i] = val;
+}
+
+/* kernel_assign_vector_sparse_new_frontier (hw/kernel_assign_vector_sparse_new_frontier_impl.h:4-78): both value
+ * types order like their words */
+void orc_assign_sparse_new_frontier_words(const orc_idx_word_t *mask, uint32_t *inout, orc_idx_word_t *new_frontier)
+{
+    uint32_t n = mask[0].index, cnt = 0;
+    for (uint32_t k = 1; k <= n; k++) {
+        if (inout[mask[k].index] > mask[k].val) {
+            inout[mask[k].index] = mask[k].val;
+            new_frontier[++cnt] = mask[k];
+        }
+    }
+    new_frontier[0].index = cnt;
+    new_frontier[0].val = 0;
+}

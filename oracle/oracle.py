@@ -26,6 +26,10 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _ivp = np.ctypeslib.ndpointer(dtype=IDX_VAL, flags="C_CONTIGUOUS")
+# sparse element of the integer value types: {uint32 index; uint32 value word}
+IDX_WORD = np.dtype([("index", np.uint32), ("val", np.uint32)])
+_iwp = np.ctypeslib.ndpointer(dtype=IDX_WORD, flags="C_CONTIGUOUS")
+VAL_FLOAT, VAL_UNSIGNED, VAL_UFIXED_32_8 = 0, 1, 2   # graphlily/global.h:62-64
 _u32 = ctypes.c_uint32
 _f32 = ctypes.c_float
 _int = ctypes.c_int
@@ -54,6 +58,11 @@ def _load():
         "orc_assign_dense": [_int, _f32p, _f32p, _u32, _f32],
         "orc_assign_sparse": [_ivp, _f32p, _f32],
         "orc_assign_sparse_new_frontier": [_ivp, _f32p, _ivp],
+        "orc_spmv_words": [_int, _int, _u32, _int, _u32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p],
+        "orc_spmspv_words": [_int, _int, _u32, _int, _u32, _u32p, _u32p, _u32p, _iwp, _u32p, _u32p],
+        "orc_ewise_add_words": [_int, _u32p, _u32, _u32, _u32p],
+        "orc_assign_dense_words": [_int, _u32p, _u32p, _u32, _u32],
+        "orc_assign_sparse_new_frontier_words": [_iwp, _u32p, _iwp],
         "orc_bfs": [_u32, _u32p, _u32p, _f32p, _u32, _u32, _f32p],
         "orc_pagerank": [_u32, _u32p, _u32p, _f32p, _f32, _u32, _f32p],
         "orc_sssp": [_u32, _u32p, _u32p, _f32p, _f32, _u32, _u32, _f32p],
@@ -62,6 +71,10 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = None
+    lib.orc_word_from_float.argtypes = [_int, _f32]
+    lib.orc_word_from_float.restype = _u32
+    lib.orc_word_to_float.argtypes = [_int, _u32]
+    lib.orc_word_to_float.restype = _f32
     lib.orc_sssp_preprocess.restype = _u32
     lib.orc_assign_dense.restype = _int
     return lib
@@ -259,3 +272,51 @@ def sssp(csr, source, num_iterations, zero=UFIXED_INF):
     lib().orc_sssp(csr.num_rows, csr.adj_indptr, csr.adj_indices, csr.adj_data, float(zero),
                    source, num_iterations, d)
     return d
+
+
+# ------------------------------------------------------------------ the reference's integer value types (words)
+def _u32a(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def words_from_float(vt, values):
+    """float -> value words, the conversion of csr_matrix_convert_from_float<val_t> (io/data_loader.h:75-84)."""
+    f = lib().orc_word_from_float
+    return np.array([f(vt, float(v)) for v in np.asarray(values, dtype=np.float32).ravel()], dtype=np.uint32)
+
+
+def spmv_words(csr_indptr, csr_indices, data_words, x_words, op, vt, zero_word, mask=None, mask_type=NOMASK):
+    n = len(csr_indptr) - 1
+    y = np.zeros(n, dtype=np.uint32)
+    m = _u32a(mask) if mask is not None else np.zeros(n, dtype=np.uint32)
+    lib().orc_spmv_words(op, vt, int(zero_word), mask_type if mask is not None else NOMASK, n, _u32a(csr_indptr),
+                         _u32a(csr_indices), _u32a(data_words), _u32a(x_words), m, y)
+    return y
+
+
+def spmspv_words(csc_indptr, csc_indices, data_words, v, num_rows, op, vt, zero_word, mask=None, mask_type=NOMASK):
+    y = np.zeros(num_rows, dtype=np.uint32)
+    m = _u32a(mask) if mask is not None else np.zeros(num_rows, dtype=np.uint32)
+    lib().orc_spmspv_words(op, vt, int(zero_word), mask_type if mask is not None else NOMASK, num_rows, _u32a(csc_indptr),
+                           _u32a(csc_indices), _u32a(data_words), np.ascontiguousarray(v, dtype=IDX_WORD), m, y)
+    return y
+
+
+def ewise_add_words(vt, inp, val_word):
+    inp = _u32a(inp)
+    out = np.zeros_like(inp)
+    lib().orc_ewise_add_words(vt, inp, inp.shape[0], int(val_word), out)
+    return out
+
+
+def assign_dense_words(mask_type, mask, inout, val_word):
+    assert inout.dtype == np.uint32 and inout.flags["C_CONTIGUOUS"]
+    lib().orc_assign_dense_words(mask_type, _u32a(mask), inout, inout.shape[0], int(val_word))
+
+
+def assign_sparse_new_frontier_words(mask_sv, inout):
+    assert inout.dtype == np.uint32 and inout.flags["C_CONTIGUOUS"]
+    mask_sv = np.ascontiguousarray(mask_sv, dtype=IDX_WORD)
+    nf = np.zeros(int(mask_sv["index"][0]) + 1, dtype=IDX_WORD)
+    lib().orc_assign_sparse_new_frontier_words(mask_sv, inout, nf)
+    return nf[:int(nf["index"][0]) + 1]

@@ -150,3 +150,33 @@ def test_bench_self_launches_two_ranks(gpu):
     assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["selfcheck_ok"] is True
     assert rec["scaling"] == "strong" and "roofline" in rec
     assert "error" not in rec.get("bfs", {}), rec["bfs"]
+
+
+def test_gl_dist_c_abi_single_rank(gpu):
+    """gl_dist_* (the RCCL exchange step in the C ABI): the box has one GPU, so this is a world of one -- RCCL loads at
+    run time, ncclCommInitRank succeeds on the device, the dense / bit gathers leave the vector alone and the sparse gather
+    builds the concatenated list with its head.  (The N > 1 exchange is the same grouped send / recv with more peers.)"""
+    from graphlily_amd import capi
+    d = capi.Dist(0, 1, capi.Dist.unique_id())
+    n = 4096
+    x = np.arange(n, dtype=np.float32)
+    bx = capi.DeviceBuffer.from_host(x)
+    d.all_gather_f32(bx, [0, n])
+    bits = capi.DeviceBuffer.from_host(np.arange(n // 32, dtype=np.uint32))
+    d.all_gather_bits(bits, [0, n])
+    capi.sync()
+    assert np.array_equal(bx.read(np.float32, n), x)
+    assert np.array_equal(bits.read(np.uint32, n // 32), np.arange(n // 32, dtype=np.uint32))
+    local = np.zeros(n + 1, dtype=capi.IDX_VAL)
+    local["index"][0] = 5
+    local["index"][1:6] = [3, 9, 27, 81, 243]
+    local["val"][1:6] = [1, 2, 3, 4, 5]
+    bl, bf = capi.DeviceBuffer.from_host(local), capi.DeviceBuffer(8 * (n + 1))
+    total = d.all_gather_sparse(bl, bf, n, 255.0)
+    capi.sync()
+    got = bf.read(capi.IDX_VAL, 6)
+    assert total == 5 and got["index"][0] == 5 and got["val"][0] == 255.0
+    assert np.array_equal(got[1:], local[1:6])
+    with pytest.raises(capi.GraphLilyError):
+        d.all_gather_bits(bits, [0, 100, n]) if False else capi.Dist(0, 1, b"short")   # a unique id is 128 bytes
+    d.destroy()
