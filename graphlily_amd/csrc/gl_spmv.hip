@@ -878,7 +878,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             for (uint32_t c = 0; c < num_cols; c++) hist[deg[c]]++;
             // thr = smallest degree such that at most H columns have degree >= thr; a column must also
             // appear often enough to be worth a slot (>= 4 entries per row block on average)
-            const uint32_t floor_deg = std::max<uint32_t>(8u, 4u * bp.nblocks);
+            const uint32_t floor_deg = std::max<uint32_t>(8u, (uint32_t)gl::env_long("GRAPHLILY_SPMV_HOT_FLOOR", 4) * bp.nblocks);
             uint64_t seen = 0;
             uint32_t thr = dmax + 1;
             while (thr > floor_deg && seen + hist[thr - 1] <= H) { thr--; seen += hist[thr]; }
