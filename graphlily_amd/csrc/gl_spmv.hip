@@ -67,6 +67,7 @@ struct SpmvArgs {
     uint32_t prow;            // rows per segment plane
     uint32_t row_begin;
     uint32_t tickets;         // 1: wavefronts draw iterations from the LDS ticket; 0: static split (GRAPHLILY_SPMV_TICKETS=0)
+    const uint32_t *self_hot_cols;   // non-null: no helper launch ran -- every workgroup gathers its (small) hot table from x itself
 };
 
 // debugging: stamp k of this unit (entry, prologue done, wave 0's loop done, all waves done, end)
@@ -390,8 +391,13 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
 
     __shared__ uint32_t next_iter;   // ticket: the first kWaves iterations are taken by wave number
     if (threadIdx.x == 0) next_iter = kWaves;
-    if (UH > 0)
-        for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];   // coalesced, L2 hits
+    if (UH > 0) {
+        if (a.self_hot_cols) {   // short streams: a helper launch in front would cost more than these few scattered reads
+            for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.x[a.self_hot_cols[i]];
+        } else {
+            for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];   // coalesced, L2 hits
+        }
+    }
     for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
     __syncthreads();
 
@@ -481,6 +487,37 @@ __global__ __launch_bounds__(256) void spmv_hot_gather_kernel(const float *__res
         if (base + k * 256u < n4) reinterpret_cast<float4 *>(xc)[base + k * 256u] = v[k];
 }
 
+// The same two vectors filled in ONE STREAMING PASS over x: colmap[c] says where column c's value goes (bit 31: hot slot,
+// else index into the packed vector, 0xffffffff: nowhere).  The gathering kernels above read x once per degree class
+// (every class is an ascending column list that touches nearly every line of x: 4 x 12 MB on the orkut stand-in, plus
+// the 8 MB index list); this one reads x and the map once and lets the L2 assemble the packed lines from the scattered
+// 4-byte stores (each class region is written in ascending order).  Used when a quarter or more of the columns are
+// gathered.  Four columns per thread, 256 apart, so every load and store instruction of a wavefront is contiguous.
+template <int OP, bool PATTERN>
+__global__ __launch_bounds__(256) void spmv_spread_x_kernel(const float *__restrict__ x, const uint32_t *__restrict__ colmap,
+                                                            const float *__restrict__ colval_bycol, float *__restrict__ packed,
+                                                            float *__restrict__ hot_x, uint32_t num_cols,
+                                                            const uint32_t *__restrict__ run_flag) {
+    if (run_flag && *run_flag == 0u) return;
+    const uint32_t cb = blockIdx.x * 1024u + threadIdx.x, last = num_cols - 1u;
+    uint32_t m[4];
+    float v[4], kv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {   // every load of the thread issued before the first store
+        const uint32_t c = cb + 256u * k, cc = min(c, last);
+        m[k] = c < num_cols ? colmap[cc] : 0xffffffffu;
+        v[k] = x[cc];
+        kv[k] = PATTERN ? colval_bycol[cc] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (m[k] == 0xffffffffu) continue;
+        const float out = PATTERN ? Semiring<OP>::mul(kv[k], v[k]) : v[k];
+        if (m[k] >> 31) hot_x[m[k] & 0x7fffffffu] = out;
+        else packed[m[k]] = out;
+    }
+}
+
 // y initialisation for the rows of blocks that are split into several units
 template <int OP, int MASK>
 __global__ __launch_bounds__(256) void spmv_init_kernel(uint32_t r0, uint32_t r1, const float *__restrict__ mask,
@@ -556,7 +593,17 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
         GL_LAUNCH_CHECK();
         return GL_OK;
     }
-    if (p->pattern) {
+    if (p->self_hot) {
+        // no helper launch: the workgroups gather their hot table themselves, the cold entries index x directly
+    } else if (p->d_colmap) {
+        if (p->pattern)
+            spmv_spread_x_kernel<OP, true><<<cdiv(p->num_cols, 1024), 256, 0, s>>>(a.x, p->d_colmap, p->d_colval_bycol, p->d_z, p->d_hot_x,
+                                                                                       p->num_cols, a.run_flag);
+        else
+            spmv_spread_x_kernel<OP, false><<<cdiv(p->num_cols, 1024), 256, 0, s>>>(a.x, p->d_colmap, nullptr, p->d_xc, p->d_hot_x,
+                                                                                        p->num_cols, a.run_flag);
+        GL_LAUNCH_CHECK();
+    } else if (p->pattern) {
         const uint32_t nz = p->ncompact ? p->ncompact : p->num_cols;
         spmv_prescale_kernel<OP><<<cdiv(std::max(cdiv(nz, 4), p->nhot), 256), 256, 0, s>>>(a.x, p->ncompact ? p->d_ccols : nullptr, p->d_colval, p->d_z,
                                                                                          nz, p->num_cols, p->d_hot_cols, p->d_hot_colval, p->d_hot_x,
@@ -909,7 +956,12 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     //      Lines touched per block sweep on the ogbn-products stand-in: 68.7 K (x) -> 48.5 K (packed) -> 29.2 K
     //      (classes); a full sort by degree gives 28.5 K.
     std::vector<uint32_t> ccols, cmap;
-    if (nnz > 0 && gl::env_long("GRAPHLILY_SPMV_COMPACT", 1) != 0) {
+    // (short streams whose hot table is small enough for the workgroups to gather themselves skip the packed vector: the
+    //  helper launch that would fill it costs more than the denser gathers save -- googleplus stand-in: 23.7 -> 22.8 us)
+    const long helper_mode = gl::env_long("GRAPHLILY_SPMV_HELPER", -1);
+    const bool want_self_hot = (helper_mode == 2 || (helper_mode < 0 && nnz <= (16ull << 20))) && hot_cols.size() <= 4096u &&
+                               gl::env_long("GRAPHLILY_SPMV_COMPACT", 1) != 3;
+    if (nnz > 0 && gl::env_long("GRAPHLILY_SPMV_COMPACT", 1) != 0 && !want_self_hot) {
         const uint32_t nb = bp.nblocks;
         const bool by_class = bp.Smax == 1 && gl::env_long("GRAPHLILY_SPMV_COMPACT", 1) != 2;
         const uint32_t edge[3] = {std::max(nb / 4u, 1u), std::max(nb / 16u, 1u), std::max(nb / 64u, 1u)};
@@ -1287,6 +1339,40 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             p->device_bytes += (size_t)gather_cols * sizeof(float);
         }
     }
+    // ---- how the hot table / packed vector are refilled per run (launch_spmv):
+    //   self-hot   short streams (the whole sweep takes a few tens of microseconds) with a small hot table and no packed
+    //              vector: no helper launch at all, every workgroup gathers the table from x in its prologue;
+    //   spread     a quarter or more of the columns are gathered: one streaming pass over x (spmv_spread_x_kernel);
+    //   gather     otherwise (sparse shards): spmv_hot_gather_kernel / spmv_prescale_kernel read only what they need.
+    {
+        const long mode = gl::env_long("GRAPHLILY_SPMV_HELPER", -1);   // -1 automatic, 0 gather, 1 spread, 2 self-hot (if possible)
+        // (pattern plans always need their helper: it forms z = colval (x) x)
+        const bool can_self = !compact && !pattern && nhot_table <= 4096u;
+        p->self_hot = can_self && (mode == 2 || (mode < 0 && nnz <= (16ull << 20)));
+        // (split plans keep one ascending class, which the gathering kernels already read sequentially: pokec stand-in
+        //  0.0742 ms gathered, 0.0760 ms spread; unsplit plans: equal on the general layout, orkut pattern layout 0.2146 -> 0.2102)
+        const bool spread = !p->self_hot && compact &&
+                            (mode == 1 || (mode < 0 && Smax == 1 && 4ull * ((uint64_t)gather_cols + nhot_table) >= num_cols));
+        if (spread) {
+            std::vector<uint32_t> colmap(num_cols, 0xffffffffu);
+            for (uint32_t c = 0; c < num_cols; c++) {
+                if (have_hot && hot_slot[c] != 0xffffffffu) colmap[c] = 0x80000000u | hot_slot[c];
+                else colmap[c] = cmap[c];   // 0xffffffff: never gathered
+            }
+            if ((rc = up((void **)&p->d_colmap, colmap.data(), colmap.size() * 4u)) != GL_OK) {
+                gl_spmv_plan_destroy(p);
+                return rc;
+            }
+            if (pattern) {
+                std::vector<uint32_t> cv(colmap.size(), 0u);
+                for (uint32_t c = 0; c < num_cols; c++) cv[c] = colbits[c];
+                if ((rc = up((void **)&p->d_colval_bycol, cv.data(), cv.size() * 4u)) != GL_OK) {
+                    gl_spmv_plan_destroy(p);
+                    return rc;
+                }
+            }
+        }
+    }
     if (diag_mode) {
         if ((rc = up((void **)&p->d_diag, diag_val.data(), diag_val.size() * sizeof(float))) != GL_OK ||
             (rc = up((void **)&p->d_diag_has, diag_has.data(), diag_has.size() * sizeof(uint32_t))) != GL_OK) {
@@ -1307,6 +1393,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         (void)hipFree(p->d_hot_x);
         p->d_hot_x = nullptr;
         hipError_t he = hipMalloc((void **)&p->d_hot_x, (size_t)nhot_table * sizeof(float));
+        if (he == hipSuccess) he = hipMemsetAsync(p->d_hot_x, 0, (size_t)nhot_table * sizeof(float), gl::ctx().stream);   // padding slots stay 0
         if (he != hipSuccess) {
             gl_spmv_plan_destroy(p);
             return gl::set_error(GL_ERR_HIP, "gl_spmv_plan_create: hipMalloc(hot_x): %s", hipGetErrorString(he));
@@ -1330,6 +1417,8 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_colval);
     (void)hipFree(p->d_hot_colval);
     (void)hipFree(p->d_ccols);
+    (void)hipFree(p->d_colmap);
+    (void)hipFree(p->d_colval_bycol);
     (void)hipFree(p->d_xc);
     (void)hipFree(p->d_diag);
     (void)hipFree(p->d_diag_has);
@@ -1514,6 +1603,7 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
     a.row_begin = p->row_begin;
     static const uint32_t tickets = gl::env_long("GRAPHLILY_SPMV_TICKETS", 1) != 0;
     a.tickets = tickets;
+    a.self_hot_cols = p->self_hot ? p->d_hot_cols : nullptr;
     hipStream_t s = gl::ctx().stream;
     int rc;
     switch (op) {   // op + 3 * value type (gl_common.h)

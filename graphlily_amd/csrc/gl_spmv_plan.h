@@ -106,6 +106,10 @@ struct gl_spmv_plan_s {
     uint32_t ncompact = 0;           // 0: gather from x (z) directly
     uint32_t *d_ccols = nullptr;     // packed index -> column, ascending
     float *d_xc = nullptr;           // general plans: x[ccols[j]]
+    uint32_t *d_colmap = nullptr;    // non-null: the vectors are refilled by one streaming pass over x (spmv_spread_x_kernel):
+                                     // per column 0x80000000 | hot slot, packed index, or 0xffffffff
+    float *d_colval_bycol = nullptr; // pattern plans in that mode: the column values indexed by column
+    bool self_hot = false;           // no helper launch: the workgroups gather their (small) hot table from x themselves
     bool wide = false;               // general layout with lane-interleaved group pairs (16-byte stream loads)
     bool pattern = false;            // every column's values are equal: 4-byte entries, z = colval (x) x per run
     float *d_colval = nullptr, *d_z = nullptr;
