@@ -290,3 +290,13 @@ int gl_assign_sparse_new_frontier_typed(const void *d_mask, void *d_inout, void 
 }
 
 }  // extern "C"
+
+// gl_init loads this translation unit's code object up front (HIP defers that to the unit's first launch, which would put
+// tens of milliseconds into somebody's timed call)
+namespace gl {
+int preload_apply() {
+    hipFuncAttributes attr;
+    GL_HIP(hipFuncGetAttributes(&attr, (const void *)sparse_scatter_kernel));
+    return GL_OK;
+}
+}  // namespace gl

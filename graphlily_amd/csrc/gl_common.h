@@ -46,6 +46,13 @@ inline bool prof_take(Profiler &pf) {
 
 int set_error(int code, const char *fmt, ...);
 
+// one per translation unit with kernels: force the unit's code object onto the device (gl_init)
+int preload_spmv();
+int preload_spmv_bool();
+int preload_spmspv();
+int preload_apply();
+int preload_format();
+
 #define GL_REQUIRE_INIT()                                                           \
     do {                                                                            \
         if (!gl::ctx().initialized)                                                 \

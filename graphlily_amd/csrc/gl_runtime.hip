@@ -154,6 +154,12 @@ int gl_init(int device) {
     c.stream = c.own_stream;
     c.device = device;
     c.initialized = true;
+    int rc;
+    if ((rc = gl::preload_spmv()) != GL_OK || (rc = gl::preload_spmv_bool()) != GL_OK || (rc = gl::preload_spmspv()) != GL_OK ||
+        (rc = gl::preload_apply()) != GL_OK || (rc = gl::preload_format()) != GL_OK) {
+        c.initialized = false;
+        return rc;
+    }
     return GL_OK;
 }
 

@@ -53,6 +53,7 @@ struct gl_spmspv_plan_s {
     uint32_t max_col_len = 0;           // longest column of the shard
     uint64_t frontier_hint = ~0ull;     // caller's upper bound on the next run's vector nnz (~0 = unknown)
     uint32_t *d_mode = nullptr;         // [0] 1 = this run goes row-wise, [1] block ticket, [2..3] work counter
+    bool last_decided_on_device = false;   // the last run launched the decision kernel (d_mode[0] is its verdict)
     uint64_t device_bytes = 0;
 };
 
@@ -565,9 +566,8 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
         uint32_t wgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), 64u);
         gl::spmspv_work_kernel<<<wgrid ? wgrid : 1u, 256, 0, s>>>(d_vector, p->d_indptr, p->num_cols, p->d_mode, threshold, gate);
         GL_LAUNCH_CHECK();
-    } else if (p->pull != nullptr || p->pull_arith != nullptr) {
-        GL_HIP(hipMemsetAsync(p->d_mode, 0, sizeof(uint32_t), s));   // gl_spmspv_last_direction: scatter
     }
+    p->last_decided_on_device = may_pull;   // gl_spmspv_last_direction: else the run scattered, nothing to read back
 
     gl::ScatterArgs a;
     a.gate = gate;
@@ -685,9 +685,11 @@ int gl_spmspv_last_direction(gl_spmspv_plan p, int *row_wise) {
     GL_REQUIRE_INIT();
     GL_ARG(p != nullptr && row_wise != nullptr);
     uint32_t m = 0;
-    hipStream_t s = gl::ctx().stream;
-    GL_HIP(hipMemcpyAsync(&m, p->d_mode, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    GL_HIP(hipStreamSynchronize(s));
+    if (p->last_decided_on_device) {
+        hipStream_t s = gl::ctx().stream;
+        GL_HIP(hipMemcpyAsync(&m, p->d_mode, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        GL_HIP(hipStreamSynchronize(s));
+    }
     *row_wise = ((p->pull != nullptr || p->pull_arith != nullptr) && m != 0u) ? 1 : 0;
     return GL_OK;
 }
@@ -706,3 +708,13 @@ int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz) {
 }
 
 }  // extern "C"
+
+// gl_init loads this translation unit's code object up front (HIP defers that to the unit's first launch, which would put
+// tens of milliseconds into somebody's timed call)
+namespace gl {
+int preload_spmspv() {
+    hipFuncAttributes attr;
+    GL_HIP(hipFuncGetAttributes(&attr, (const void *)spmspv_work_kernel));
+    return GL_OK;
+}
+}  // namespace gl

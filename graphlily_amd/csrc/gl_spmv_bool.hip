@@ -584,3 +584,13 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
 }
 
 }  // namespace gl
+
+// gl_init loads this translation unit's code object up front (HIP defers that to the unit's first launch, which would put
+// tens of milliseconds into somebody's timed call)
+namespace gl {
+int preload_spmv_bool() {
+    hipFuncAttributes attr;
+    GL_HIP(hipFuncGetAttributes(&attr, (const void *)spmv_bool_pack_kernel));
+    return GL_OK;
+}
+}  // namespace gl
