@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--bfs-runs", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for debugging")
     ap.add_argument("--same-gpu", action="store_true", help="debugging: put every rank on cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still create the process group and run every collective (one-rank RCCL on one GPU)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` from a plain shell: start the N ranks ourselves (one process per GPU, the launch the
@@ -82,13 +84,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
-        comm = Comm(True)
+        comm = Comm(True, force=args.force_dist)
     else:
         comm = Comm(None)
 
@@ -122,11 +128,11 @@ def main():
 
     def step():
         plan.run(bx, None, by, capi.GL_OP_MULADD, 0.0, capi.GL_NOMASK)
-        if world > 1:
+        if use_dist:
             comm.all_gather_slices(y, bounds)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,7 +149,7 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     kern_ms_total, launches = capi.prof_end()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -242,7 +248,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -274,7 +280,7 @@ def _bench_pattern(capi, csr, r0, r1, bx, by, y, y_general, args, fence, world, 
 
     def step():
         plan.run(bx, None, by, capi.GL_OP_MULADD, 0.0, capi.GL_NOMASK)
-        if world > 1:
+        if comm.distributed:
             comm.all_gather_slices(y, bounds)
 
     for _ in range(args.warmup):
@@ -287,7 +293,7 @@ def _bench_pattern(capi, csr, r0, r1, bx, by, y, y_general, args, fence, world, 
     fence()
     wall = time.perf_counter() - t0
     kern_ms_total, launches = capi.prof_end()
-    if world > 1:
+    if comm.distributed:
         t = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())

@@ -42,7 +42,10 @@ def partition_rows_by_nnz(indptr, world_size, align=64, equal_rows_tolerance=0.0
 class Comm:
     """Thin wrapper around a torch.distributed process group (None = single process)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
+        # force: take the collective paths even in a one-rank group (lets ONE GPU exercise RCCL itself: communicator
+        # set-up, the in-place all_gather_into_tensor, the sparse-list gather -- tests/test_gpu_dist.py)
+        self.force = bool(force) and group is not None
         self.group = group
         if group is None:
             self.rank, self.world_size = 0, 1
@@ -56,7 +59,7 @@ class Comm:
 
     @property
     def distributed(self):
-        return self.world_size > 1
+        return self.world_size > 1 or self.force
 
     def all_gather_slices(self, full, bounds):
         """`full` is a 1-D tensor over the whole vertex range whose slice

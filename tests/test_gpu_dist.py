@@ -152,6 +152,27 @@ def test_bench_self_launches_two_ranks(gpu):
     assert "error" not in rec.get("bfs", {}), rec["bfs"]
 
 
+def test_bench_one_rank_rccl(gpu):
+    """The RCCL leg of bench.py as far as one GPU allows: `--force-dist` creates the nccl process group for a world of
+    one and runs every collective of the N > 1 path on it -- the in-place all_gather_into_tensor of the SpMV step, the
+    max-over-ranks all_reduce, and the bit / sparse-list gathers of the row-sharded BFS driver."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "20", "--warmup", "2",
+                        "--scale", "0.1", "--bfs-runs", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["selfcheck_ok"] is True
+    assert "error" not in rec.get("bfs", {}), rec["bfs"]
+    assert rec["bfs"]["pull"]["reached"] == rec["bfs"]["pull_push"]["reached"] > 0
+
+
 def test_gl_dist_c_abi_single_rank(gpu):
     """gl_dist_* (the RCCL exchange step in the C ABI): the box has one GPU, so this is a world of one -- RCCL loads at
     run time, ncclCommInitRank succeeds on the device, the dense / bit gathers leave the vector alone and the sparse gather
