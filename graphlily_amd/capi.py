@@ -38,7 +38,7 @@ EXPORTS = [
     "gl_assign_sparse_new_frontier_typed", "gl_sparse_to_dense_typed",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32", "gl_buf_fill_u32_gated",
     "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim",
-    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_layout", "gl_spmv_plan_export", "gl_spmv_run",
+    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_helper", "gl_spmv_plan_layout", "gl_spmv_plan_export", "gl_spmv_run",
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits", "gl_bfs_pull_step",
     "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run", "gl_spmspv_run_assign",
@@ -100,6 +100,7 @@ def lib():
         "gl_spmv_plan_destroy": [vp], "gl_spmv_plan_info": [vp, P(u64), P(u64), P(u32)],
         "gl_spmv_plan_shape": [vp, P(u32), P(u32), P(u32), P(u64)],
         "gl_spmv_plan_hot": [vp, P(u32), P(u64), P(i32)],
+        "gl_spmv_plan_helper": [vp, P(i32), P(u32)],
         "gl_spmv_plan_layout": [vp, P(i32)],
         "gl_spmv_plan_export": [vp, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)],
         "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
@@ -309,7 +310,10 @@ class SpMVPlan:
                                      ctypes.byref(mix)))
         lay = ctypes.c_int(0)
         check(lib().gl_spmv_plan_layout(ctypes.c_void_p(self.handle), ctypes.byref(lay)))
-        return {"nnz": nnz.value, "device_bytes": nbytes.value, "num_units": ntiles.value, "blocks": b.value,
+        hm, pc = ctypes.c_int(0), ctypes.c_uint32(0)
+        check(lib().gl_spmv_plan_helper(ctypes.c_void_p(self.handle), ctypes.byref(hm), ctypes.byref(pc)))
+        return {"helper": ("gather", "spread", "self-hot", "none")[hm.value], "packed_columns": pc.value,
+                "nnz": nnz.value, "device_bytes": nbytes.value, "num_units": ntiles.value, "blocks": b.value,
                 "segments": sg.value, "max_block_rows": mr.value, "groups": g.value,
                 "hot_columns": hc.value, "hot_nnz": hn.value, "mix": mix.value,
                 "layout": ("general", "pattern", "boolean")[lay.value]}

@@ -747,7 +747,49 @@ BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin,
     const uint64_t nz0 = h_indptr[row_begin], nz1 = h_indptr[row_end], nnz = nz1 - nz0;
     std::vector<uint32_t> &bstart = bp.bstart;
     bstart.push_back(row_begin);
-    if (nnz > 0) {
+    // Balance: the launch ends with its slowest unit, so the cuts minimise the LARGEST block (binary search on its size,
+    // greedy fill) instead of tracking cumulative targets -- with whole-row cuts a block next to a hub row used to end up
+    // several per cent over the mean (orkut stand-in: 765 K .. 888 K entries per block around a mean of 827 K, and the
+    // 888 K unit finished 28 us after the average one in a 313 us launch).  GRAPHLILY_SPMV_BALANCE=0: cumulative targets.
+    if (nnz > 0 && env_long("GRAPHLILY_SPMV_BALANCE", 1) != 0 && shape.blocks > 1) {
+        // blocks needed when no block may hold more than `cap` entries (a single longer row gets a block of its own)
+        auto cut = [&](uint64_t cap, std::vector<uint32_t> *out) -> uint32_t {
+            uint32_t r = row_begin, made = 0;
+            while (r < row_end) {
+                const uint32_t hi = (uint32_t)std::min<uint64_t>(row_end, (uint64_t)r + max_rows);
+                const uint64_t lim = (uint64_t)h_indptr[r] + cap;
+                const uint32_t *ub = std::upper_bound(h_indptr + r + 1, h_indptr + hi + 1, (uint32_t)std::min<uint64_t>(lim, 0xffffffffull));
+                uint32_t e = (uint32_t)(ub - h_indptr) - 1u;
+                if (e < r + 1) e = r + 1;
+                if (align > 1u && e < row_end) {
+                    uint32_t ea = e / align * align;
+                    if (ea <= r) ea = std::min<uint64_t>(row_end, (uint64_t)(r / align + 1u) * align);
+                    e = ea;
+                }
+                if (out) out->push_back(e);
+                r = e;
+                made++;
+            }
+            return made;
+        };
+        uint64_t lo = (nnz + shape.blocks - 1) / shape.blocks, hi = nnz;   // smallest cap that needs <= shape.blocks blocks
+        if (cut(hi, nullptr) > shape.blocks) {
+            lo = hi;   // the row cap alone forces more blocks than planned: fill them as evenly as the cap allows
+            const uint32_t forced = cut(hi, nullptr);
+            uint64_t l2 = (nnz + forced - 1) / forced, h2 = nnz;
+            while (l2 < h2) {
+                const uint64_t mid = (l2 + h2) / 2;
+                if (cut(mid, nullptr) <= forced) h2 = mid; else l2 = mid + 1;
+            }
+            lo = l2;
+        } else {
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) / 2;
+                if (cut(mid, nullptr) <= shape.blocks) hi = mid; else lo = mid + 1;
+            }
+        }
+        cut(lo, &bstart);
+    } else if (nnz > 0) {
         const double target = (double)nnz / (double)shape.blocks;
         uint32_t r = row_begin, made = 0;
         while (r < row_end) {
@@ -1445,6 +1487,15 @@ int gl_spmv_plan_hot(gl_spmv_plan p, uint32_t *hot_columns, uint64_t *hot_nnz, i
     if (hot_columns) *hot_columns = p->nhot;
     if (hot_nnz) *hot_nnz = p->hot_nnz;
     if (mix) *mix = p->mix;
+    return GL_OK;
+}
+
+int gl_spmv_plan_helper(gl_spmv_plan p, int *mode, uint32_t *packed_columns) {
+    GL_ARG(p != nullptr);
+    if (mode)
+        *mode = p->boolean ? GL_HELPER_NONE : p->self_hot ? GL_HELPER_SELF_HOT : p->d_colmap ? GL_HELPER_SPREAD
+                : (p->pattern || p->nhot || p->ncompact) ? GL_HELPER_GATHER : GL_HELPER_NONE;
+    if (packed_columns) *packed_columns = p->ncompact;
     return GL_OK;
 }
 

@@ -184,6 +184,14 @@ int gl_bfs_pull_step(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_t *d_b
 /* hot-column cache: columns whose x value is kept in LDS, the non-zeros they serve, and the cold/hot
  * interleave in use (0 = no hot table, 5 = 3 cold + 3 hot groups per wavefront iteration) */
 int gl_spmv_plan_hot(gl_spmv_plan plan, uint32_t *hot_columns, uint64_t *hot_nnz, int *mix);
+/* how the plan refills its hot table / packed gather vector per run (chosen at creation): a gathering
+ * helper kernel, one streaming pass over x, or no helper launch at all (short streams with a small hot table: the
+ * workgroups gather it themselves); packed_columns = length of the packed vector (0: cold entries index x itself) */
+#define GL_HELPER_GATHER 0
+#define GL_HELPER_SPREAD 1
+#define GL_HELPER_SELF_HOT 2
+#define GL_HELPER_NONE 3
+int gl_spmv_plan_helper(gl_spmv_plan plan, int *mode, uint32_t *packed_columns);
 
 /* gl_spmv_run replaces enqueueTask(overlay, mode = 1) (module/spmv_module.h:471-475,
  * hw/overlay.cpp:308-330 -> hw/kernel_spmv_impl.h:392-819):

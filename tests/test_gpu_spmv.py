@@ -420,3 +420,49 @@ def test_packed_gather_vector_changes_nothing(gpu, keep_values, monkeypatch):
                         np.testing.assert_allclose(outs[(mode, sem, mk)], outs[("1", sem, mk)], rtol=2e-6, atol=0)
                     else:
                         assert np.array_equal(outs[(mode, sem, mk)], outs[("1", sem, mk)]), (mode, sem, mk, shape)
+
+
+@pytest.mark.parametrize("keep_values", [True, False])
+def test_helper_modes_agree(gpu, keep_values, monkeypatch):
+    """How a plan refills its hot table / packed gather vector per run -- gathering helper kernel, one streaming pass
+    over x, or (general layout, small hot table) no helper launch at all -- is chosen per plan (GRAPHLILY_SPMV_HELPER
+    forces it).  The three produce the same vectors, so every semiring x mask must agree bit for bit between them and
+    match the oracle, on unsplit and split plans."""
+    from graphlily_amd import capi
+    m = spmv_prepare("rmat_sym_50K")
+    rng = np.random.default_rng(29)
+    m.adj_data = (rng.integers(1, 9, size=m.nnz) / np.float32(8)).astype(np.float32) if keep_values else \
+        np.full(m.nnz, np.float32(0.5), np.float32)
+    x = np.where(rand01(m.num_cols, 5) > 0, rng.random(m.num_cols, dtype=np.float32) + np.float32(0.25), 0).astype(np.float32)
+    mask = rand01(m.num_rows, 6)
+    dx, dm, dy = capi.DeviceBuffer(4 * m.num_cols), capi.DeviceBuffer(4 * m.num_rows), capi.DeviceBuffer(4 * m.num_rows)
+    dx.write(x)
+    dm.write(mask)
+    flags = capi.GL_PLAN_KEEP_VALUES if keep_values else 0
+    monkeypatch.setenv("GRAPHLILY_SPMV_HOT", "2048")     # a table small enough for the self-hot mode
+    seen = set()
+    for shape in ((0, 0), (5, 3)):
+        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
+        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        outs = {}
+        for mode in ("0", "1", "2"):
+            monkeypatch.setenv("GRAPHLILY_SPMV_HELPER", mode)
+            plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=flags)
+            info = plan.info()
+            seen.add((info["helper"], info["packed_columns"] > 0))
+            for sem, (op, zero) in SEMIRINGS.items():
+                for mk, mt in MASKS.items():
+                    plan.run(dx, dm if mt else None, dy, op, zero, mt)
+                    outs[(mode, sem, mk)] = dy.read(np.float32, m.num_rows).copy()
+        for sem, (op, zero) in SEMIRINGS.items():
+            for mk in MASKS:
+                _check(outs[("0", sem, mk)], m, sem, mk, x, mask, "helper 0 shape %s %s %s" % (shape, sem, mk))
+                for mode in ("1", "2"):
+                    a, b = outs[("0", sem, mk)], outs[(mode, sem, mk)]
+                    if op == 0:   # (+,x): f64 sums of the same products; the packed order may differ between modes
+                        assert np.allclose(a, b, rtol=1e-6, atol=0), (mode, shape, sem, mk)
+                    else:
+                        assert np.array_equal(a, b), (mode, shape, sem, mk)
+    assert ("gather", True) in seen and ("spread", True) in seen
+    if keep_values:
+        assert ("self-hot", False) in seen       # pattern plans always need their helper (it forms z)
