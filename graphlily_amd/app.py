@@ -346,9 +346,11 @@ class BFS(_GraphApp):
         st = getattr(self, "dev_loop_", None)
         if st is None:
             words = self.SpMV_.bits_words()
-            both = B.alloc(n + 4, np.float32)     # distances, then the control words: one read-back fetches both
+            both = B.alloc(n + 8, np.float32)     # distances, then the control words: one read-back fetches both
+            scratch = B.alloc(n // 1024 + 4, np.float32)   # block counts of the bits -> list pass (word 0: its ticket)
+            B.fill(scratch, 0.0, n // 1024 + 4)
             st = self.dev_loop_ = {
-                "both": both, "ctl": B.view(both, n, 4, 4), "distance": B.view(both, 0, n, 4),
+                "both": both, "ctl": B.view(both, n, 8, 4), "distance": B.view(both, 0, n, 4), "scratch": scratch,
                 "F": [B.alloc(n + 1, capi.IDX_VAL), B.alloc(n + 1, capi.IDX_VAL)],
                 "bits": [B.alloc(words, np.float32), B.alloc(words, np.float32)], "words": words, "graphs": {},
                 "src": np.zeros(1, np.uint32)}
@@ -357,21 +359,36 @@ class BFS(_GraphApp):
         ctl, distance, F, bits, words = st["ctl"], st["distance"], st["F"], st["bits"], st["words"]
         self.SpMSpV_.bind_mask_buf(distance)
 
+        # Back to pushing (an extension; the reference pulls to the end once it has switched, app/bfs.h:106-126): when a
+        # pull step finds fewer than `back` * n new vertices the next slot pushes again -- the last iterations of a BFS
+        # have tiny frontiers, and a pull step streams the whole matrix whatever the frontier holds (orkut stand-in:
+        # 22 458 and 34 vertices in iterations 5 and 6 of 6).  Distances do not depend on the direction.
+        # Only where a pull step costs well more than a push step's fixed launches (~50 us): a pull streams 4 B per
+        # non-zero at ~5.5 TB/s, i.e. 17 us on the googleplus stand-in (where going back doubled the run) and 155 us on orkut.
+        dflt = max(float(threshold), 1.0 / 64.0) if self.get_nnz() >= (128 << 20) else 0.0
+        back = float(os.environ.get("GRAPHLILY_BFS_BACK", str(dflt)))
+
         def schedule():
             # slot `it`: frontier list F[it & 1] / bits[it & 1] in, F[(it + 1) & 1] / bits[(it + 1) & 1] out
             capi.bfs_begin(ctl, distance, n, F[1], bits[1], words)
             for it in range(1, num_iterations + 1):
                 cur, nxt = it & 1, (it + 1) & 1
-                # ctl[0] = first pull slot: slot `it` pulls if ctl[0] <= it, pushes if ctl[0] > it
-                self.SpMV_.bfs_pull_step_gated(bits[cur], bits[nxt], distance, float(it + 1), ctl, it, capi.GL_GATE_LE)
-                # the push step's counting pass clears the words of bits[nxt] that its write pass ORs the new frontier
+                # ctl[0] = first pull slot: slot `it` pushes if ctl[0] > it, pulls if ctl[0] <= it.  The push step comes
+                # first: a decision taken by this slot's pull step must not open the push gate of its own slot.
+                # The push step's counting pass clears the words of bits[nxt] that its write pass ORs the new frontier
                 # into, and its scan pass takes the reference's loop decision (threshold, iterations left)
                 self.SpMSpV_.run_gated(F[cur], F[nxt], distance, float(it + 1), bits[nxt], ctl, it, capi.GL_GATE_GT,
-                                       ctl=ctl, slot=it, threshold=threshold, may_continue=it + 1 < num_iterations)
+                                       ctl=ctl, slot=it, threshold=threshold,
+                                       may_continue=(1 if it + 1 < num_iterations else 0) | (2 if it + 1 <= num_iterations else 0))
+                if back > 0.0:
+                    self.SpMV_.bfs_pull_step_back(bits[cur], bits[nxt], distance, float(it + 1), ctl, it, back,
+                                                  it + 1 <= num_iterations, F[nxt], st["scratch"])
+                else:
+                    self.SpMV_.bfs_pull_step_gated(bits[cur], bits[nxt], distance, float(it + 1), ctl, it, capi.GL_GATE_LE)
 
         st["src"][0] = source
         B.upload(B.view(ctl, 2, 1, 4), st["src"])        # ctl[2] = source: the one host->device word per run
-        key = (num_iterations, float(threshold))
+        key = (num_iterations, float(threshold), back)
         use_graph = os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0"
         g = st["graphs"].get(key)
         if g is None and use_graph and st.get("warm") == key:
@@ -387,8 +404,9 @@ class BFS(_GraphApp):
             schedule()
             st["warm"] = key                              # buffers, attributes and scratch exist now: the next call captures
         B.sync()
-        out = B.download_result(st["both"], n + 4)
-        self.push_iterations_ = int(out[n + 1:n + 2].view(np.uint32)[0])
+        out = B.download_result(st["both"], n + 8)
+        self.push_iterations_ = int(out[n + 1:n + 2].view(np.uint32)[0])          # the reference's count (first push phase)
+        self.push_iterations_again_ = int(out[n + 3:n + 4].view(np.uint32)[0])   # pushes after a pull step handed back
         return out[:n]
 
     def pull_push(self, source, num_iterations, threshold=0.05):

@@ -31,7 +31,7 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
-    "gl_bfs_begin", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated",
+    "gl_bfs_begin", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
     "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32", "gl_dist_all_gather_bits",
     "gl_dist_all_gather_sparse",
     "gl_spmv_run_typed", "gl_spmspv_run_typed", "gl_ewise_add_typed", "gl_assign_dense_typed", "gl_assign_sparse_typed",
@@ -81,6 +81,7 @@ def lib():
         "gl_bfs_begin": [vp, vp, u32, vp, vp, u32],
         "gl_spmspv_run_gated": [vp, vp, vp, vp, i32, f32, i32, vp, f32, vp, vp, u32, i32, vp, u32, f32, i32],
         "gl_bfs_pull_step_gated": [vp, vp, vp, vp, f32, vp, u32, i32],
+        "gl_bfs_pull_step_back": [vp, vp, vp, vp, f32, vp, u32, f32, i32, vp, vp],
         "gl_dist_unique_id": [vp], "gl_dist_init": [P(vp), i32, i32, vp], "gl_dist_destroy": [vp], "gl_dist_rank": [vp, P(i32), P(i32)],
         "gl_dist_all_gather_f32": [vp, vp, vp], "gl_dist_all_gather_bits": [vp, vp, vp],
         "gl_dist_all_gather_sparse": [vp, vp, vp, u32, f32, P(u32)],
@@ -344,6 +345,10 @@ class SpMVPlan:
         check(lib().gl_bfs_pull_step_gated(ctypes.c_void_p(self.handle), _p(bits_in), _p(bits_out), _p(distance), float(level),
                                            _p(gate), int(gate_value), int(gate_op)))
 
+    def bfs_pull_step_back(self, bits_in, bits_out, distance, level, ctl, slot, back_threshold, may_continue, frontier_out, scratch):
+        check(lib().gl_bfs_pull_step_back(ctypes.c_void_p(self.handle), _p(bits_in), _p(bits_out), _p(distance), float(level), _p(ctl),
+                                          int(slot), float(back_threshold), int(bool(may_continue)), _p(frontier_out), _p(scratch)))
+
     def bfs_pull_step(self, bits_in, bits_out, distance, level):
         check(lib().gl_bfs_pull_step(ctypes.c_void_p(self.handle), _p(bits_in), _p(bits_out), _p(distance), float(level)))
 
@@ -401,7 +406,7 @@ class SpMSpVPlan:
                   ctl=None, slot=0, threshold=0.0, may_continue=False):
         check(lib().gl_spmspv_run_gated(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op), float(zero),
                                         int(mask_type), _p(inout), float(val), _p(next_bits), _p(gate), int(gate_value),
-                                        int(gate_op), _p(ctl), int(slot), float(threshold), int(bool(may_continue))))
+                                        int(gate_op), _p(ctl), int(slot), float(threshold), int(may_continue)))
 
     def run_typed(self, vector, mask, result, op, zero_bits, mask_type, val_type):
         check(lib().gl_spmspv_run_typed(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op), int(zero_bits),

@@ -133,8 +133,10 @@ __global__ __launch_bounds__(256) void sparse_scatter_kernel(const gl_idx_val *_
     }
 }
 
-// ---- device-side bookkeeping of a whole BFS (gl_bfs_begin, gl_spmspv_run_gated): ctl[0] = first pull slot (0xffffffff
-//      while pushing), ctl[1] = push iterations done, ctl[2] = source vertex (written by the host before the schedule)
+// ---- device-side bookkeeping of a whole BFS (gl_bfs_begin, gl_spmspv_run_gated, gl_bfs_pull_step_back): eight words,
+//      ctl[0] = first pull slot (0xffffffff while pushing), ctl[1] = push iterations done, ctl[2] = source vertex (written
+//      by the host before the schedule), ctl[4] = slot whose pull result is wanted as a list, ctl[5..6] = count / ticket
+//      of the running pull step
 __global__ __launch_bounds__(256) void bfs_begin_kernel(uint32_t *__restrict__ ctl, float *__restrict__ distance, uint32_t n,
                                                         gl_idx_val *__restrict__ frontier, uint32_t *__restrict__ bits, uint32_t words) {
     const uint32_t src = ctl[2];
@@ -143,6 +145,11 @@ __global__ __launch_bounds__(256) void bfs_begin_kernel(uint32_t *__restrict__ c
     if (bits)
         for (uint32_t w = tid; w < words; w += stride) bits[w] = (w == (src >> 5)) ? (1u << (src & 31u)) : 0u;
     if (tid == 0) {
+        ctl[3] = 0u;
+        ctl[4] = 0xffffffffu;   // no slot has asked for its pull result as a list yet (gl_bfs_pull_step_back)
+        ctl[5] = 0u;            // new-frontier count of the running pull step
+        ctl[6] = 0u;            // its workgroup ticket
+        ctl[7] = 0u;
         if (frontier) {
             frontier[0].index = 1u;          // one source vertex (app/bfs.h:162-166)
             frontier[0].val = 0.0f;
@@ -152,6 +159,31 @@ __global__ __launch_bounds__(256) void bfs_begin_kernel(uint32_t *__restrict__ c
         ctl[0] = frontier ? 0xffffffffu : 0u;   // first pull slot: none yet / every slot
         ctl[1] = 0u;
     }
+}
+
+// the set bits of a frontier bit vector as list candidates (gl_bfs_pull_step_back): entry {row, 1}
+struct BitsSource {
+    const uint32_t *bits;
+    uint32_t n;
+    __device__ uint32_t size() const { return n; }
+    __device__ bool get(uint32_t i, gl_idx_val &out) const {
+        out.index = i;
+        out.val = 1.0f;
+        return (bits[i >> 5] >> (i & 31u)) & 1u;
+    }
+    __device__ void consumed(uint32_t) const {}
+    __device__ void emitted(const gl_idx_val &) const {}
+    __device__ void begin_chunk(uint32_t) const {}
+};
+
+int bits_to_sparse_gated(const uint32_t *d_bits, uint32_t n, gl_idx_val *d_out, uint32_t *d_counts, const uint32_t *gate_word,
+                         uint32_t gate_value, hipStream_t s) {
+    BitsSource src{d_bits, n};
+    Gate gate;
+    gate.word = gate_word;
+    gate.value = gate_value;
+    gate.op = GL_GATE_EQ;
+    return run_compaction(src, n, d_counts, d_out, 0.0f, s, nullptr, gate);
 }
 
 }  // namespace gl

@@ -43,17 +43,23 @@ struct Gate {
 
 // Optional epilogue of the scan: the push -> pull decision of a BFS, taken where the result count is produced
 // (do { push } while (iter < num_iterations && nnz / n < threshold), app/bfs.h:180-190).  ctl[0] = first pull slot
-// (0xffffffff while pushing), ctl[1] = push iterations done.  The push step of slot `slot` is gated on ctl[0] > slot,
+// (0xffffffff while pushing), ctl[1] = push iterations done (bit 0 of may_continue: the reference's loop condition).  The push step of slot `slot` is gated on ctl[0] > slot,
 // so writing slot + 1 here does not close the gate of the write pass that follows in the same step.
 struct Direction {
     uint32_t *ctl = nullptr;
     uint32_t n = 1, slot = 0;
     float threshold = 0.0f;
     uint32_t may_continue = 0;
+    // After a pull step has handed the loop back to pushing (gl_bfs_pull_step_back: ctl[4] = its slot, ctl[7] = the
+    // threshold it used) the pushes are counted apart (ctl[3]; ctl[1] stays the reference's count), may run through the
+    // last iteration (bit 1 of may_continue: a slot follows) and stay for as long as the frontier is below ctl[7].
     __device__ void decide(uint32_t nnz) const {
         if (!ctl || ctl[0] != 0xffffffffu) return;
-        ctl[1] += 1u;
-        if (!(may_continue != 0u && ((float)nnz / (float)n < threshold))) ctl[0] = slot + 1u;
+        const bool again = ctl[4] != 0xffffffffu;
+        ctl[again ? 3 : 1] += 1u;
+        const bool cont = again ? (may_continue & 2u) != 0u : (may_continue & 1u) != 0u;
+        const float thr = again ? __uint_as_float(ctl[7]) : threshold;
+        if (!(cont && ((float)nnz / (float)n < thr))) ctl[0] = slot + 1u;
     }
 };
 

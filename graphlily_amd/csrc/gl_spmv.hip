@@ -1544,6 +1544,25 @@ int gl_bfs_pull_step_gated(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *
     return gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, gl::ctx().stream, d_gate, gate_value, gate_op);
 }
 
+int gl_bfs_pull_step_back(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level,
+                          uint32_t *d_ctl, uint32_t slot, float back_threshold, int may_continue, gl_idx_val *d_frontier_out,
+                          uint32_t *d_scratch) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && d_bits_in != nullptr && d_bits_out != nullptr && d_distance != nullptr);
+    GL_ARG(d_ctl != nullptr && d_frontier_out != nullptr && d_scratch != nullptr);
+    GL_ARG(d_bits_in != d_bits_out);
+    GL_ARG((((uintptr_t)d_bits_in | (uintptr_t)d_bits_out) & 15u) == 0);
+    if (!p->boolean)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step_back: the plan does not hold the GL_PLAN_BOOLEAN layout");
+    if (p->row_begin != 0 || p->row_end != p->num_rows)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step_back: row shards decide on the host (their frontier counts are partial)");
+    hipStream_t s = gl::ctx().stream;
+    const int rc = gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, s, d_ctl, slot, GL_GATE_LE, d_ctl, slot,
+                                          back_threshold, may_continue);
+    if (rc != GL_OK) return rc;
+    return gl::bits_to_sparse_gated(d_bits_out, p->num_rows, d_frontier_out, d_scratch, d_ctl + 4, slot, s);
+}
+
 int gl_spmv_plan_export(gl_spmv_plan p, int array, void *h_dst, size_t capacity, size_t *bytes) {
     GL_REQUIRE_INIT();
     GL_ARG(p != nullptr && bytes != nullptr);

@@ -36,6 +36,13 @@ struct BoolArgs {
     const uint32_t *gate = nullptr;   // non-null: the launch is a no-op unless gate[0] (gate_op) gate_value (gl_bfs_pull_step_gated)
     uint32_t gate_value = 0;
     int gate_op = GL_GATE_EQ;
+    // pull -> push decision of a device-resident BFS schedule (gl_bfs_pull_step_back): the fused epilogue counts the rows
+    // it puts into the next frontier (ctl[5]); the workgroup that finishes last (ticket ctl[6]) compares the count with
+    // back_threshold * n and, if the frontier has become that small and iterations remain, re-opens the push gate
+    // (ctl[0] = 0xffffffff) and marks the slot (ctl[4]) so that the list-building pass behind this launch runs
+    uint32_t *back_ctl = nullptr;
+    uint32_t back_slot = 0, back_may_continue = 0, back_n = 1;
+    float back_threshold = 0.0f;
 };
 
 // x != 0 packed little-endian, 64 columns per wavefront step; words past num_cols are zero
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         // SpMV masked by `distance == 0`, eWiseAdd(+0), assign(level) where the result is set, and the packing of
         // the next frontier (app/bfs.h:118-123) in one epilogue: 64 rows per wavefront step, one 64-bit word out.
         // Blocks of boolean plans start on multiples of 64 rows, so every word has exactly one writer.
+        uint32_t nfresh = 0;   // lane 0 of every wavefront: rows this wavefront put into the next frontier
         for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < nrows; i0 += kThreads) {
             const uint32_t i = i0 + lane, row = row0 + i;
             bool fresh = false;
@@ -193,6 +201,29 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
             }
             const uint64_t m = __ballot(fresh);
             if (lane == 0) reinterpret_cast<uint64_t *>(a.bits_out)[(row0 + i0) >> 6] = m;
+            nfresh += (uint32_t)__popcll(m);
+        }
+        if (a.back_ctl) {
+            __shared__ uint32_t fresh_s;   // one global atomic per workgroup, not per wavefront
+            if (threadIdx.x == 0) fresh_s = 0u;
+            __syncthreads();
+            if (lane == 0 && nfresh) atomicAdd(&fresh_s, nfresh);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (fresh_s) atomicAdd(&a.back_ctl[5], fresh_s);
+                __threadfence();
+            }
+            if (threadIdx.x == 0 && atomicAdd(&a.back_ctl[6], 1u) == gridDim.x - 1u) {   // the last workgroup decides
+                __threadfence();
+                const uint32_t total = __hip_atomic_load(&a.back_ctl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.back_ctl[5] = 0u;
+                a.back_ctl[6] = 0u;
+                if (a.back_may_continue != 0u && (float)total / (float)a.back_n < a.back_threshold) {
+                    a.back_ctl[0] = 0xffffffffu;     // pushing again from the next slot on
+                    a.back_ctl[4] = a.back_slot;     // ... and this slot's new frontier is wanted as a list
+                    a.back_ctl[7] = __float_as_uint(a.back_threshold);   // Direction::decide: stay while below this
+                }
+            }
         }
     } else if (direct) {
         for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
@@ -257,7 +288,8 @@ static int launch_bool(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
 // One BFS pull iteration on the bit layout (see the FUSED epilogue).  Unsplit plans whose shard starts on a
 // multiple of 64 rows only; bits_out must not alias bits_in.
 int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s,
-                       const uint32_t *gate, uint32_t gate_value, int gate_op) {
+                       const uint32_t *gate, uint32_t gate_value, int gate_op, uint32_t *back_ctl, uint32_t back_slot,
+                       float back_threshold, int back_may_continue) {
     if (p->row_end == p->row_begin) return GL_OK;
     if (p->segments > 1 || (p->row_begin & 63u) || !p->nunits)
         return set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step: needs an unsplit boolean plan whose shard starts on a multiple of 64 rows");
@@ -278,6 +310,11 @@ int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_o
     a.gate = gate;
     a.gate_value = gate_value;
     a.gate_op = gate_op;
+    a.back_ctl = back_ctl;
+    a.back_slot = back_slot;
+    a.back_threshold = back_threshold;
+    a.back_may_continue = back_may_continue ? 1u : 0u;
+    a.back_n = p->num_rows ? p->num_rows : 1u;
     a.tickets = bool_tickets();
     return launch_bool_variant<GL_NOMASK, 1>(p, a, s);
 }

@@ -213,6 +213,9 @@ class SpMVModule(BaseModule):
     def bfs_pull_step_gated(self, bits_in, bits_out, distance_buf, level, gate, gate_value, gate_op):
         self.plan_.bfs_pull_step_gated(bits_in, bits_out, distance_buf, level, gate, gate_value, gate_op)
 
+    def bfs_pull_step_back(self, bits_in, bits_out, distance_buf, level, ctl, slot, back_threshold, may_continue, frontier_out, scratch):
+        self.plan_.bfs_pull_step_back(bits_in, bits_out, distance_buf, level, ctl, slot, back_threshold, may_continue, frontier_out, scratch)
+
     def fused_bfs_ok(self):
         if self.plan_ is None or not self._plan_serves(self.semiring_.op) or self.semiring_.zero != 0.0:
             return False

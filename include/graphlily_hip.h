@@ -248,8 +248,9 @@ int gl_spmspv_run_assign(gl_spmspv_plan plan, const gl_idx_val *d_vector, const 
  * push iteration to decide the direction, app/bfs.h:180-190, and converts the frontier on the host at the switch,
  * :195-205).  A driver enqueues the WHOLE schedule -- for every iteration slot both a pull step and a push step --
  * and a device-side word decides which of them runs:
- *   d_ctl            three words: [0] first pull slot (0xffffffff while pushing), [1] push iterations done,
- *                    [2] source vertex (written by the host before the schedule is enqueued).
+ *   d_ctl            eight words: [0] first pull slot (0xffffffff while pushing), [1] push iterations done,
+ *                    [2] source vertex (written by the host before the schedule is enqueued), [3..7] see
+ *                    gl_bfs_pull_step_back (gl_bfs_begin initialises all but [2]).
  *   gate             a launch predicate: the call does nothing unless *d_gate (gate_op) gate_value.  The pull step of
  *                    slot s is gated GL_GATE_LE on d_ctl with value s, its push step GL_GATE_GT.
  *   gl_bfs_begin     distance[i] = (i == source), the one-entry frontier list {1,(source,1)} (or, with d_frontier NULL,
@@ -258,13 +259,28 @@ int gl_spmspv_run_assign(gl_spmspv_plan plan, const gl_idx_val *d_vector, const 
  *                    d_next_bits (may be NULL; the words of the plan's rows are rewritten, the shard must start on a
  *                    multiple of 32 rows) -- so the push -> pull switch needs no conversion pass -- and (b) with d_ctl
  *                    set, takes the reference's loop decision where the result count is produced: ctl[1]++, and
- *                    ctl[0] = slot + 1 unless may_continue_push and float(count) / num_rows < threshold.
+ *                    ctl[0] = slot + 1 unless bit 0 of may_continue_push is set and float(count) / num_rows < threshold.
+ *                    (After a gl_bfs_pull_step_back has handed the loop back to pushing, the pushes are counted in ctl[3]
+ *                    instead and continue while bit 1 of may_continue_push -- "a slot follows" -- is set and the count stays
+ *                    below the threshold that step used.)
  *   gl_bfs_pull_step_gated   gl_bfs_pull_step under a gate.
  * No call of the schedule synchronises or copies to the host; it can be captured once (gl_graph_*) and replayed. */
+/*   gl_bfs_pull_step_back    the pull step of slot `slot` (gated GL_GATE_LE on d_ctl[0] like gl_bfs_pull_step_gated) that
+ *                    also takes the OPPOSITE decision -- an extension of this build, the reference never returns to
+ *                    pushing: the fused epilogue counts the rows it puts into the next frontier; if that count is below
+ *                    back_threshold * num_rows and may_continue is set, the push gate re-opens (d_ctl[0] = 0xffffffff) and the
+ *                    new frontier is also written to d_frontier_out as the sparse list the next slot's push step reads
+ *                    (ascending rows, value 1).  Distances do not depend on the direction, so results are unchanged; the
+ *                    last iterations of a BFS, whose frontiers are tiny again, stop streaming the whole matrix.  A slot
+ *                    must enqueue its push step BEFORE this call (the decision then cannot open a gate of its own slot).
+ *                    d_ctl has eight words ([4..6] are used here); d_scratch: num_rows / 1024 + 2 words, word 0 zero. */
 #define GL_GATE_EQ 0
 #define GL_GATE_GT 1
 #define GL_GATE_LE 2
 int gl_bfs_begin(uint32_t *d_ctl, float *d_distance, uint32_t n, gl_idx_val *d_frontier, uint32_t *d_bits, uint32_t bits_words);
+int gl_bfs_pull_step_back(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level,
+                          uint32_t *d_ctl, uint32_t slot, float back_threshold, int may_continue, gl_idx_val *d_frontier_out,
+                          uint32_t *d_scratch);
 int gl_spmspv_run_gated(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
                         int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
                         const uint32_t *d_gate, uint32_t gate_value, int gate_op,

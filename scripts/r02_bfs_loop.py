@@ -19,4 +19,4 @@ for mode, gr, ov in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "0
     for i in range(9):
         capi.sync(); t = time.perf_counter(); d = bfs.pull_push(0, iters, 0.001); ts.append((time.perf_counter() - t) * 1e3)
     print("device_loop=%s graph=%s overlap=%s: median %.3f ms (%s), pushes %d reached %d" % (
-        mode, gr, ov, float(np.median(ts[3:])), " ".join("%.3f" % x for x in ts), bfs.push_iterations_, int((d != 0).sum())))
+        mode, gr, ov, float(np.median(ts[3:])), " ".join("%.3f" % x for x in ts), bfs.push_iterations_, int((d != 0).sum())), "again", getattr(bfs, "push_iterations_again_", None))

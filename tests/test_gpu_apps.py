@@ -239,3 +239,36 @@ def test_bfs_pull_push_device_loop_equals_host_loop(gpu, name, monkeypatch):
                 assert bfs.push_iterations_ == pushes, "thr %g src %d: device %d vs host %d push iterations" % (
                     thr, src, pushes, bfs.push_iterations_)
     assert any(bfs.dev_loop_["graphs"].values()), "the schedule was captured as a graph"
+
+
+@pytest.mark.parametrize("name", ["rmat_sym_50K", "uniform_10K_10"])
+@pytest.mark.parametrize("back", ["0.9", "0.02", "0.0001"])
+def test_bfs_pull_push_returns_to_push(gpu, name, back, monkeypatch):
+    """An extension of the device-resident schedule: when a pull step finds fewer than `back` * n new vertices the next
+    slot pushes again (gl_bfs_pull_step_back; the default only does so on matrices whose pull step costs far more than a
+    push step's launches, GRAPHLILY_BFS_BACK forces it).  Distances do not depend on the direction: every threshold /
+    source combination must give the oracle's result, eagerly and replayed, and the reference's push count (the first
+    push phase) must not change."""
+    monkeypatch.setenv("GRAPHLILY_BFS_BACK", back)
+    m = named_matrix(name)
+    om = _oracle_prepared(m, "bfs")
+    bfs = app.BFS(M.num_hbm_channels, 0, 0, 0)
+    bfs.set_up_runtime()
+    bfs.load_and_format_matrix(m, True)
+    bfs.send_matrix_host_to_device()
+    assert bfs._device_loop_ok()
+    deg = np.diff(m.adj_indptr.astype(np.int64))
+    sources = [0, int(np.argmax(deg)), int(np.nonzero(deg > 0)[0][-1])]
+    again = 0
+    for thr in (0.001, 0.05):
+        for rep in range(3):                       # eager, capture, replay
+            for src in sources:
+                monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "1")
+                got = bfs.pull_push(src, 9, thr)
+                pushes, again = bfs.push_iterations_, again + bfs.push_iterations_again_
+                assert np.array_equal(got, O.bfs(om, src, 9)), "back %s thr %g rep %d src %d" % (back, thr, rep, src)
+                monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "0")
+                assert np.array_equal(bfs.pull_push(src, 9, thr), got)
+                assert bfs.push_iterations_ == pushes
+    if back == "0.9":
+        assert again > 0, "with back = 0.9 some pull step must have handed the loop back to pushing"
