@@ -377,6 +377,7 @@ class BFS(_GraphApp):
                 # first: a decision taken by this slot's pull step must not open the push gate of its own slot.
                 # The push step's counting pass clears the words of bits[nxt] that its write pass ORs the new frontier
                 # into, and its scan pass takes the reference's loop decision (threshold, iterations left)
+                self.SpMSpV_.plan_.frontier_bits(bits[cur])   # a heavy frontier goes row-wise straight from these bits
                 self.SpMSpV_.run_gated(F[cur], F[nxt], distance, float(it + 1), bits[nxt], ctl, it, capi.GL_GATE_GT,
                                        ctl=ctl, slot=it, threshold=threshold,
                                        may_continue=(1 if it + 1 < num_iterations else 0) | (2 if it + 1 <= num_iterations else 0))

@@ -31,7 +31,7 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
-    "gl_bfs_begin", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
+    "gl_bfs_begin", "gl_spmspv_plan_frontier_bits", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
     "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32", "gl_dist_all_gather_bits",
     "gl_dist_all_gather_sparse",
     "gl_spmv_run_typed", "gl_spmspv_run_typed", "gl_ewise_add_typed", "gl_assign_dense_typed", "gl_assign_sparse_typed",
@@ -81,6 +81,7 @@ def lib():
         "gl_bfs_begin": [vp, vp, u32, vp, vp, u32],
         "gl_spmspv_run_gated": [vp, vp, vp, vp, i32, f32, i32, vp, f32, vp, vp, u32, i32, vp, u32, f32, i32],
         "gl_bfs_pull_step_gated": [vp, vp, vp, vp, f32, vp, u32, i32],
+        "gl_spmspv_plan_frontier_bits": [vp, vp],
         "gl_bfs_pull_step_back": [vp, vp, vp, vp, f32, vp, u32, f32, i32, vp, vp],
         "gl_dist_unique_id": [vp], "gl_dist_init": [P(vp), i32, i32, vp], "gl_dist_destroy": [vp], "gl_dist_rank": [vp, P(i32), P(i32)],
         "gl_dist_all_gather_f32": [vp, vp, vp], "gl_dist_all_gather_bits": [vp, vp, vp],
@@ -389,6 +390,9 @@ class SpMSpVPlan:
         check(lib().gl_spmspv_plan_attach_pull(ctypes.c_void_p(self.handle),
                                                ctypes.c_void_p(spmv_plan.handle) if spmv_plan is not None else None))
         self._pull_keepalive = spmv_plan
+
+    def frontier_bits(self, bits):
+        check(lib().gl_spmspv_plan_frontier_bits(ctypes.c_void_p(self.handle), _p(bits)))
 
     def hint(self, vector_nnz_upper_bound):
         check(lib().gl_spmspv_plan_hint(ctypes.c_void_p(self.handle), int(vector_nnz_upper_bound)))

@@ -20,6 +20,8 @@
 
 #include "gl_common.h"
 
+#include <cstdlib>
+
 namespace gl {
 
 constexpr uint32_t kCompactThreads = 256;
@@ -188,15 +190,38 @@ static __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__r
     }
 }
 
+// `own_offsets`: long lists.  offsets[1 ..] still hold the blocks' raw counts: every block sums the counts in front of it
+// itself (a few loads per thread) instead of waiting for a one-block scan launch between the two passes, and the last
+// block writes the head element and takes the loop decision -- one dependent launch less per SpMSpV (~4 us).
 template <typename Src>
 __global__ __launch_bounds__(256) void compact_write_kernel(Src src, const uint32_t *__restrict__ offsets,
-                                                            gl_idx_val *__restrict__ out, Gate gate) {
+                                                            gl_idx_val *__restrict__ out, Gate gate, bool own_offsets, float head_val,
+                                                            uint32_t *__restrict__ reset_word, Direction dir) {
     __shared__ uint32_t lds4[4];
     if (gate.closed()) return;
     const uint32_t n = src.size();
     const uint32_t base = blockIdx.x * kCompactChunk;
-    if (base >= n) return;
-    uint32_t pos = offsets[1u + blockIdx.x];
+    uint32_t pos;
+    if (own_offsets) {
+        uint32_t part = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kCompactThreads) part += offsets[1u + i];
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) part += __shfl_down(part, dlt);
+        if ((threadIdx.x & 63u) == 0) lds4[threadIdx.x >> 6] = part;
+        __syncthreads();
+        pos = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+        __syncthreads();
+        if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0) {   // total = everything in front of the last block + its own count
+            const uint32_t total = pos + offsets[1u + blockIdx.x];
+            out[0].index = total;
+            out[0].val = head_val;
+            if (reset_word) *reset_word = 0u;
+            dir.decide(total);
+        }
+        if (base >= n) return;
+    } else {
+        if (base >= n) return;
+        pos = offsets[1u + blockIdx.x];
+    }
 #pragma unroll
     for (uint32_t j = 0; j < kCompactItems; j++) {
         uint32_t i = base + j * kCompactThreads + threadIdx.x;
@@ -216,6 +241,12 @@ __global__ __launch_bounds__(256) void compact_write_kernel(Src src, const uint3
     }
 }
 
+// GRAPHLILY_COMPACT_SCAN=1: keep the separate one-block scan launch for long lists (A/B)
+static inline bool env_flag_scan_launch() {
+    const char *e = getenv("GRAPHLILY_COMPACT_SCAN");
+    return e && atoi(e) != 0;
+}
+
 // Runs the passes for at most `max_items` candidates (host-side bound for the grid).
 template <typename Src>
 static int run_compaction(Src src, uint32_t max_items, uint32_t *d_counts, gl_idx_val *d_out, float head_val,
@@ -225,11 +256,12 @@ static int run_compaction(Src src, uint32_t max_items, uint32_t *d_counts, gl_id
     const bool fused = nblocks <= kCompactFuseBlocks;
     compact_count_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out, head_val, d_reset_word, fused, gate, dir);
     GL_LAUNCH_CHECK();
-    if (!fused) {
+    static const bool scan_launch = env_flag_scan_launch();
+    if (!fused && scan_launch) {
         compact_scan_kernel<<<1, 1024, 0, s>>>(d_counts, nblocks, d_out, head_val, d_reset_word, gate, dir);
         GL_LAUNCH_CHECK();
     }
-    compact_write_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out, gate);
+    compact_write_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out, gate, !fused && !scan_launch, head_val, d_reset_word, dir);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

@@ -53,6 +53,7 @@ struct gl_spmspv_plan_s {
     uint32_t max_col_len = 0;           // longest column of the shard
     uint64_t frontier_hint = ~0ull;     // caller's upper bound on the next run's vector nnz (~0 = unknown)
     uint32_t *d_mode = nullptr;         // [0] 1 = this run goes row-wise, [1] block ticket, [2..3] work counter
+    const uint32_t *frontier_bits = nullptr;   // one-shot (gl_spmspv_plan_frontier_bits): the next run's vector as a bit vector
     bool last_decided_on_device = false;   // the last run launched the decision kernel (d_mode[0] is its verdict)
     uint64_t device_bytes = 0;
 };
@@ -561,6 +562,10 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     // decision kernels: they cannot reach the threshold whatever their columns are
     if (may_pull && p->frontier_hint != ~0ull && p->frontier_hint * (uint64_t)p->max_col_len <= threshold) may_pull = false;
     p->frontier_hint = ~0ull;
+    struct ClearBits {   // one-shot, whatever path the run takes
+        gl_spmspv_plan p;
+        ~ClearBits() { p->frontier_bits = nullptr; }
+    } clear_bits{p};
     if (may_pull) {
         // few blocks: each ends with one atomic on the same ticket word
         uint32_t wgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), 64u);
@@ -613,12 +618,17 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     } else if (may_pull) {
         // row-wise: frontier -> bit vector -> boolean SpMV into the (all-zero) accumulator; both kernels return
         // at once when the run is a scatter run
-        uint32_t *bits = gl::bool_plan_xbits(p->pull);
-        GL_HIP(hipMemsetAsync(bits, 0, gl::bool_plan_xbits_bytes(p->pull), s));
-        uint32_t bgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 8u);
-        gl::spmspv_frontier_bits_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(d_vector, p->num_cols, bits, p->d_mode);
-        GL_LAUNCH_CHECK();
-        rc = gl::bool_plan_run_bits(p->pull, p->d_acc - p->row_begin, p->d_mode, s);
+        if (p->frontier_bits) {
+            // the caller keeps the frontier as bits anyway (a device-resident BFS schedule): no clear + list -> bits pass
+            rc = gl::bool_plan_run_bits(p->pull, p->d_acc - p->row_begin, p->d_mode, s, p->frontier_bits);
+        } else {
+            uint32_t *bits = gl::bool_plan_xbits(p->pull);
+            GL_HIP(hipMemsetAsync(bits, 0, gl::bool_plan_xbits_bytes(p->pull), s));
+            uint32_t bgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 8u);
+            gl::spmspv_frontier_bits_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(d_vector, p->num_cols, bits, p->d_mode);
+            GL_LAUNCH_CHECK();
+            rc = gl::bool_plan_run_bits(p->pull, p->d_acc - p->row_begin, p->d_mode, s);
+        }
         if (rc != GL_OK) return rc;
     }
 
@@ -672,6 +682,13 @@ int gl_spmspv_plan_attach_pull(gl_spmspv_plan p, gl_spmv_plan pull) {
         p->device_bytes += (size_t)p->num_cols * sizeof(float);
     }
     p->pull_arith = pull;
+    return GL_OK;
+}
+
+int gl_spmspv_plan_frontier_bits(gl_spmspv_plan p, const uint32_t *d_bits) {
+    GL_ARG(p != nullptr);
+    GL_ARG(((uintptr_t)d_bits & 15u) == 0);
+    p->frontier_bits = d_bits;
     return GL_OK;
 }
 

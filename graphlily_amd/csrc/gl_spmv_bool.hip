@@ -374,7 +374,7 @@ size_t bool_plan_xbits_bytes(gl_spmv_plan p) { return (size_t)p->nphases * kBool
 
 // gl_spmspv_run's row-wise path: x bits are already in place, no mask, zero = 0, output rows y[row_begin..row_end);
 // the kernels do nothing unless run_flag[0] != 0.  Split plans rely on y being all zero on entry.
-int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s) {
+int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s, const uint32_t *xbits) {
     if (p->row_end == p->row_begin || !p->nunits) return GL_OK;
     BoolArgs a;
     a.entries = p->d_entries;
@@ -382,7 +382,7 @@ int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hip
     a.units = p->d_units;
     a.hub_rows = p->d_hub_rows;
     a.spans = p->d_spans;
-    a.xbits = p->d_xbits;
+    a.xbits = xbits ? xbits : p->d_xbits;
     a.mask = nullptr;
     a.y = d_y;
     a.zero = 0.0f;

@@ -183,7 +183,7 @@ int pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits, hipStream_t s);
 int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s,
                        const uint32_t *gate = nullptr, uint32_t gate_value = 0, int gate_op = GL_GATE_EQ, uint32_t *back_ctl = nullptr,
                        uint32_t back_slot = 0, float back_threshold = 0.0f, int back_may_continue = 0);
-int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s);
+int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s, const uint32_t *xbits = nullptr);
 // gl_apply.hip: the set bits of d_bits[0..n) as a sparse list {row, 1} with head {count, 0}; no-op unless *gate_word == gate_value
 int bits_to_sparse_gated(const uint32_t *d_bits, uint32_t n, gl_idx_val *d_out, uint32_t *d_counts, const uint32_t *gate_word,
                          uint32_t gate_value, hipStream_t s);

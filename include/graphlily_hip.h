@@ -303,6 +303,11 @@ int gl_spmspv_plan_attach_pull(gl_spmspv_plan plan, gl_spmv_plan pull);
  * the previous iteration's gl_sparse_nnz).  Frontiers too small to reach the threshold whatever their columns
  * are then skip the decision kernels.  One-shot: consumed by the next gl_spmspv_run. */
 int gl_spmspv_plan_hint(gl_spmspv_plan plan, uint32_t vector_nnz_upper_bound);
+/* One-shot like the hint: the vector of the NEXT gl_spmspv_run* call is also available as a bit vector (bit c set iff
+ * column c is in the vector; gl_spmv_plan_bits_words words of the attached GL_PLAN_BOOLEAN plan, 16-byte aligned, bits past
+ * the columns zero).  A run that goes row-wise on that plan then reads it directly instead of clearing and filling the
+ * plan's own bit vector (two launches less); results are unchanged. */
+int gl_spmspv_plan_frontier_bits(gl_spmspv_plan plan, const uint32_t *d_bits);
 /* which way the last run went (1 = row-wise).  Blocking; for tests and reports. */
 int gl_spmspv_last_direction(gl_spmspv_plan plan, int *row_wise);
 
