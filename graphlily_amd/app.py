@@ -378,9 +378,13 @@ class BFS(_GraphApp):
                 # The push step's counting pass clears the words of bits[nxt] that its write pass ORs the new frontier
                 # into, and its scan pass takes the reference's loop decision (threshold, iterations left)
                 self.SpMSpV_.plan_.frontier_bits(bits[cur])   # a heavy frontier goes row-wise straight from these bits
+                if it == 1:
+                    self.SpMSpV_.plan_.hint(1)                # one source vertex: no direction decision to launch
                 self.SpMSpV_.run_gated(F[cur], F[nxt], distance, float(it + 1), bits[nxt], ctl, it, capi.GL_GATE_GT,
                                        ctl=ctl, slot=it, threshold=threshold,
                                        may_continue=(1 if it + 1 < num_iterations else 0) | (2 if it + 1 <= num_iterations else 0))
+                if it == 1:
+                    continue        # the first slot always pushes (the frontier is the source vertex): no pull step to gate off
                 if back > 0.0:
                     self.SpMV_.bfs_pull_step_back(bits[cur], bits[nxt], distance, float(it + 1), ctl, it, back,
                                                   it + 1 <= num_iterations, F[nxt], st["scratch"])
