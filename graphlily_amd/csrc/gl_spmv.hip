@@ -75,9 +75,13 @@ struct SpmvArgs {
 constexpr uint32_t kClockStamps = 6;
 __device__ __forceinline__ void clock_stamp(const SpmvArgs &a, uint32_t k) {
     if (a.clocks && threadIdx.x == 0) {
-        a.clocks[kClockStamps * blockIdx.x + k] = wall_clock64();
+        // (a copy of the workgroup id made inside this branch: used directly, the compiler reuses the id's SGPR for the
+        //  address arithmetic below, keeps the id itself in a VGPR from then on, and every descriptor / base-column load of
+        //  the kernel turns from a scalar into a vector load)
+        const uint32_t bid = __builtin_amdgcn_readfirstlane(blockIdx.x);
+        a.clocks[kClockStamps * bid + k] = wall_clock64();
         if (k == 0)   // s_getreg_b32 hwreg(HW_REG_HW_ID = 4, 0, 32) and hwreg(HW_REG_XCC_ID = 20, 0, 32)
-            a.clocks[kClockStamps * blockIdx.x + 5] =
+            a.clocks[kClockStamps * bid + 5] =
                 (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
     }
 }
@@ -384,7 +388,8 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
 
     if (a.run_flag && *a.run_flag == 0u) return;
     clock_stamp(a, 0);
-    const uint4 d = load_const(a.units + 2u * blockIdx.x), dh = load_const(a.units + 2u * blockIdx.x + 1u);   // scalar loads
+    const uint32_t unit = __builtin_amdgcn_readfirstlane(blockIdx.x);   // pinned to an SGPR: see clock_stamp
+    const uint4 d = load_const(a.units + 2u * unit), dh = load_const(a.units + 2u * unit + 1u);   // scalar loads
     const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
     const uint32_t nhub = dh.y, nhotg = dh.z;
     const uint32_t nslots = nrows + kHubSlots * nhub;
