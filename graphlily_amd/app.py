@@ -414,7 +414,73 @@ class BFS(_GraphApp):
         self.push_iterations_again_ = int(out[n + 3:n + 4].view(np.uint32)[0])   # pushes after a pull step handed back
         return out[:n]
 
+    def _pull_push_bits(self, source, num_iterations, threshold):
+        """The device-resident schedule with the frontier as BITS only (gl_bfs_bits_*): a slot is two launches -- a push
+        step that scatters straight into the next frontier's bit vector and writes the levels itself (no dense
+        accumulator, no compaction, no chunk queue), and the fused pull step, which also serves a push whose frontier is
+        heavy (row-wise) and otherwise takes the push step's decisions.  13 launches for the 6 iterations of the orkut
+        stand-in where the list-based schedule above needs 51.  Slot s reads bit vector s and writes vector s + 1.
+        The read-back of distances + control words is enqueued behind the schedule (page-locked destination taken from
+        the results the caller has dropped): one wait per run."""
+        B, n, N = self.backend, self.n_, num_iterations
+        st = getattr(self, "bits_loop_", None)
+        if st is None or st["N"] < N:
+            words = (int(self.SpMV_.bits_words()) + 3) & ~3
+            nvec, ctl_words = N + 2, (17 + N + 15) & ~15
+            both = B.alloc(n + ctl_words, np.float32)          # distances, then the control words: one read-back fetches both
+            vecs = B.alloc(nvec * words, np.float32)
+            st = self.bits_loop_ = {"N": N, "both": both, "vecs": vecs, "words": words, "nvec": nvec, "ctl_words": ctl_words,
+                                    "ctl": B.view(both, n, ctl_words, 4), "distance": B.view(both, 0, n, 4),
+                                    "bits": [B.view(vecs, k * words, words, 4) for k in range(nvec)], "graphs": {},
+                                    "src": np.zeros(1, np.uint32), "warm": set()}
+        ctl, distance, bits, words = st["ctl"], st["distance"], st["bits"], st["words"]
+        # hand the loop back to pushing when a pull step finds a small new frontier (an extension, see _pull_push_device;
+        # a push step of this schedule is one short launch, so it pays wherever a pull step is not tiny itself)
+        dflt = max(float(threshold), 1.0 / 64.0) if self.get_nnz() >= (16 << 20) else 0.0
+        back = float(os.environ.get("GRAPHLILY_BFS_BACK", str(dflt)))
+        csc_plan, pull_plan = self.SpMSpV_.plan_, self.SpMV_.plan_
+
+        def schedule():
+            capi.bfs_bits_begin(ctl, st["ctl_words"], distance, n, st["vecs"], words, st["nvec"])
+            for it in range(1, N + 1):
+                may = (1 if it + 1 < N else 0) | (2 if it + 1 <= N else 0)
+                capi.bfs_bits_push_step(csc_plan, bits[it], bits[it + 1], None, words, distance, float(it + 1), ctl, it, threshold, may)
+                # (also in the first slot, which always pushes: the gated-off pull step takes the push step's decisions)
+                capi.bfs_bits_pull_step(pull_plan, csc_plan, bits[it], bits[it + 1], distance, float(it + 1), ctl, it, threshold,
+                                        may, back)
+
+        st["src"][0] = source
+        B.upload(B.view(ctl, 2, 1, 4), st["src"])        # ctl[2] = source: the one host->device word per run
+        key = (N, float(threshold), back)
+        g = st["graphs"].get(key)
+        if g is None and os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0" and key in st["warm"]:
+            try:
+                with capi.Graph.capture() as g:
+                    schedule()
+                st["graphs"][key] = g
+            except capi.GraphLilyError:
+                g = st["graphs"][key] = False              # capture not possible here: keep enqueueing
+        if g:
+            g.launch()
+        else:
+            schedule()
+            st["warm"].add(key)
+        out = capi.pinned_recycled(n + st["ctl_words"], np.float32)
+        st["both"].read_async(out)
+        B.sync()
+        c = out[n:].view(np.uint32)
+        self.push_iterations_ = int(c[1])          # the reference's count (first push phase)
+        self.push_iterations_again_ = int(c[3])    # pushes after a pull step handed back
+        self.bfs_slot_counts_ = c[17:17 + N].copy()   # vertices reached per slot
+        return out[:n]
+
+    def _bits_loop_ok(self):
+        return (self._device_loop_ok() and os.environ.get("GRAPHLILY_BFS_BITS", "1") != "0"
+                and hasattr(capi, "bfs_bits_push_step") and self.SpMV_.plan_ is not None and self.SpMSpV_.plan_ is not None)
+
     def pull_push(self, source, num_iterations, threshold=0.05):
+        if self._bits_loop_ok():
+            return self._pull_push_bits(source, num_iterations, threshold)
         if self._device_loop_ok():
             return self._pull_push_device(source, num_iterations, threshold)
         n = self.n_

@@ -31,6 +31,8 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
+    "gl_bfs_bits_begin", "gl_bfs_bits_push_step", "gl_bfs_bits_pull_step",
+    "gl_buf_d2h_async",
     "gl_bfs_begin", "gl_spmspv_plan_frontier_bits", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
     "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32", "gl_dist_all_gather_bits",
     "gl_dist_all_gather_sparse",
@@ -79,6 +81,10 @@ def lib():
     sigs = {
         "gl_graph_begin_capture": [], "gl_graph_end_capture": [P(vp)], "gl_graph_launch": [vp], "gl_graph_destroy": [vp],
         "gl_bfs_begin": [vp, vp, u32, vp, vp, u32],
+        "gl_bfs_bits_begin": [vp, u32, vp, u32, vp, u32, u32],
+        "gl_buf_d2h_async": [vp, vp, ctypes.c_size_t],
+        "gl_bfs_bits_push_step": [vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
+        "gl_bfs_bits_pull_step": [vp, vp, vp, vp, vp, f32, vp, u32, f32, i32, f32],
         "gl_spmspv_run_gated": [vp, vp, vp, vp, i32, f32, i32, vp, f32, vp, vp, u32, i32, vp, u32, f32, i32],
         "gl_bfs_pull_step_gated": [vp, vp, vp, vp, f32, vp, u32, i32],
         "gl_spmspv_plan_frontier_bits": [vp, vp],
@@ -183,6 +189,39 @@ class _PinnedBlock:
             pass
 
 
+_pinned_free = {}      # nbytes -> [_PinnedBlock]: blocks whose arrays have been dropped (pinned_recycled)
+
+
+class _RecycledBlock:
+    """Owner of a page-locked block handed out by pinned_recycled(): returns it to the free list when the array dies."""
+
+    def __init__(self, blk):
+        self.blk = blk
+        self.ptr, self.nbytes = blk.ptr, blk.nbytes
+
+    def __del__(self):
+        try:
+            lst = _pinned_free.setdefault(self.nbytes, [])
+            if len(lst) < 4:
+                lst.append(self.blk)
+        except Exception:
+            pass
+
+
+def pinned_recycled(count, dtype):
+    """pinned_empty() from a free list: page-locking 12 MB costs ~2 ms, so result arrays that a driver returns by value
+    take their block from the arrays the caller has dropped (a caller that keeps every result just gets new blocks).
+    A copy into page-locked memory can be enqueued behind the kernels that produce its source (DeviceBuffer.read_async)."""
+    dtype = np.dtype(dtype)
+    nbytes = max(count * dtype.itemsize, 4)
+    lst = _pinned_free.get(nbytes)
+    blk = _RecycledBlock(lst.pop() if lst else _PinnedBlock(nbytes))
+    raw = (ctypes.c_char * blk.nbytes).from_address(blk.ptr)
+    arr = np.frombuffer(raw, dtype=dtype, count=count).view(_OwnedArray)
+    arr._owner = (raw, blk)
+    return arr
+
+
 def pinned_empty(count, dtype):
     """numpy array in page-locked host memory (freed with the array): read-backs into it run at the
     full PCIe rate instead of the pageable-memory rate."""
@@ -250,6 +289,13 @@ class DeviceBuffer:
             out = out[:count]
         assert offset_bytes + out.nbytes <= self.nbytes
         check(lib().gl_buf_d2h(_np_ptr(out), ctypes.c_void_p(self.ptr + offset_bytes), out.nbytes))
+        return out
+
+    def read_async(self, out, offset_bytes=0):
+        """Enqueue the device->host copy into `out` (page-locked: pinned_recycled / pinned_empty) behind the kernels already
+        on the library stream, without waiting; capi.sync() before `out` is read."""
+        assert out.flags["C_CONTIGUOUS"] and offset_bytes + out.nbytes <= self.nbytes
+        check(lib().gl_buf_d2h_async(_np_ptr(out), ctypes.c_void_p(self.ptr + offset_bytes), out.nbytes))
         return out
 
     def free(self):
@@ -509,6 +555,21 @@ class Dist:
 
 def fill_u32_gated(buf, value, count, gate, gate_value):
     check(lib().gl_buf_fill_u32_gated(_p(buf), int(value), int(count), _p(gate), int(gate_value)))
+
+
+def bfs_bits_begin(ctl, ctl_words, distance, n, bits, bits_words, nvec):
+    check(lib().gl_bfs_bits_begin(_p(ctl), int(ctl_words), _p(distance), int(n), _p(bits), int(bits_words), int(nvec)))
+
+
+def bfs_bits_push_step(csc_plan, bits_in, bits_out, bits_spare, bits_words, distance, level, ctl, slot, threshold, may_continue):
+    check(lib().gl_bfs_bits_push_step(ctypes.c_void_p(csc_plan.handle), _p(bits_in), _p(bits_out), _p(bits_spare), int(bits_words),
+                                      _p(distance), float(level), _p(ctl), int(slot), float(threshold), int(may_continue)))
+
+
+def bfs_bits_pull_step(pull_plan, csc_plan, bits_in, bits_out, distance, level, ctl, slot, threshold, may_continue, back_threshold):
+    check(lib().gl_bfs_bits_pull_step(ctypes.c_void_p(pull_plan.handle), ctypes.c_void_p(csc_plan.handle), _p(bits_in), _p(bits_out),
+                                      _p(distance), float(level), _p(ctl), int(slot), float(threshold), int(may_continue),
+                                      float(back_threshold)))
 
 
 def bfs_begin(ctl, distance, n, frontier, bits, bits_words):

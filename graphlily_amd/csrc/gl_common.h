@@ -169,6 +169,42 @@ __device__ __forceinline__ bool value_is_zero(float v) {
     return OPX < 3 ? (v == 0.0f) : (__float_as_uint(v) == 0u);
 }
 
+// ------------------------------------------------------------------ device-resident BFS schedule, frontier as bits only
+// (gl_bfs_bits_*): 16 control words + one per slot (the new-frontier count of slot s in word 16 + s).  [0] first pull slot (0xffffffff while pushing), [1] push iterations of the first
+// push phase (the reference's count), [2] source vertex, [3] pushes after a pull step handed the loop back, [4] the slot
+// that handed back (0xffffffff: none), [5] new-frontier count of the running step, [6] workgroup ticket of the running
+// step, [7] the threshold the hand-back used, [8] the slot whose PUSH goes row-wise (its frontier's columns hold more
+// than `heavy` non-zeros; 0: none), [10..11] sum of the column lengths of the new frontier (64 bits; ctl is 8-byte aligned).
+// Every step of slot s ends with decide(): the reference's loop condition (do { push } while (it < num_iterations &&
+// nnz / n < threshold), app/bfs.h:180-190) where the step pushed, the opposite decision where it pulled, and the
+// direction of the next slot's push.
+struct BfsBitsCtl {
+    uint32_t *ctl = nullptr;
+    uint32_t slot = 0, n = 1;
+    uint32_t may_continue = 0;     // bit 0: the reference's loop may go on after this slot, bit 1: a slot follows
+    float threshold = 0.0f;        // push while new frontier / n < threshold
+    float back_threshold = 0.0f;   // pull hands back to push when new frontier / n < back_threshold (0: never)
+    unsigned long long heavy = ~0ull;
+    __device__ bool pushes() const { return ctl[0] > slot; }
+    __device__ bool row_wise() const { return ctl[8] == slot; }
+    // called by the workgroup that finishes the step last, with the step's totals
+    __device__ void decide(uint32_t fresh, unsigned long long work) const {
+        ctl[16u + slot] = fresh;       // the slot's new-frontier size, for the host (which late slots changed distances?)
+        if (ctl[0] > slot) {
+            const bool again = ctl[4] != 0xffffffffu;
+            ctl[again ? 3 : 1] += 1u;
+            const bool cont = again ? (may_continue & 2u) != 0u : (may_continue & 1u) != 0u;
+            const float thr = again ? __uint_as_float(ctl[7]) : threshold;
+            if (!(cont && ((float)fresh / (float)n < thr))) ctl[0] = slot + 1u;
+        } else if (back_threshold > 0.0f && (may_continue & 2u) != 0u && (float)fresh / (float)n < back_threshold) {
+            ctl[0] = 0xffffffffu;
+            ctl[4] = slot;
+            ctl[7] = __float_as_uint(back_threshold);
+        }
+        if (ctl[0] > slot + 1u && work > heavy) ctl[8] = slot + 1u;
+    }
+};
+
 // streamed-once 8-byte load (matrix streams): non-temporal so the stream does not
 // evict the dense vector from L2
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));

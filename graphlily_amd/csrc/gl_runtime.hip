@@ -493,6 +493,14 @@ int gl_buf_d2h(void *h_dst, const void *d_src, size_t bytes) {
     return GL_OK;
 }
 
+int gl_buf_d2h_async(void *h_dst, const void *d_src, size_t bytes) {
+    GL_REQUIRE_INIT();
+    if (bytes == 0) return GL_OK;
+    GL_ARG(h_dst != nullptr && d_src != nullptr);
+    GL_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, gl::ctx().stream));
+    return GL_OK;
+}
+
 int gl_buf_d2d(void *d_dst, const void *d_src, size_t bytes) {
     GL_REQUIRE_INIT();
     if (bytes == 0) return GL_OK;

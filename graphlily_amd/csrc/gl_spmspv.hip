@@ -55,6 +55,11 @@ struct gl_spmspv_plan_s {
     uint32_t *d_mode = nullptr;         // [0] 1 = this run goes row-wise, [1] block ticket, [2..3] work counter
     const uint32_t *frontier_bits = nullptr;   // one-shot (gl_spmspv_plan_frontier_bits): the next run's vector as a bit vector
     bool last_decided_on_device = false;   // the last run launched the decision kernel (d_mode[0] is its verdict)
+    // gl_bfs_bits_push_step: the chunks of every long column as a static list {column, first entry, count, -}; a push
+    // step tests the frontier bit of each chunk's column instead of queueing chunks at run time (no second launch)
+    uint4 *d_long_chunks = nullptr;
+    uint32_t n_long_chunks = 0;
+    uint32_t *d_bfs_acc = nullptr;   // kBfsAccSlots x 32 words: the push step's totals, spread over 64 lines (see bfs_push_bits_kernel)
     uint64_t device_bytes = 0;
 };
 
@@ -76,6 +81,7 @@ void spmspv_detach_everywhere(gl_spmv_plan dying) {
 
 constexpr uint32_t kBigColumn = 4096;  // columns at least this long are cut into queue chunks
 constexpr uint32_t kChunk = 4096;      // entries per queue chunk (one workgroup pass in kernel 1b)
+constexpr uint32_t kBfsAccSlots = 64;  // accumulator lines of the bit-frontier BFS push step (a power of two)
 
 struct ScatterArgs {
     const uint32_t *indptr;
@@ -317,6 +323,171 @@ __global__ __launch_bounds__(256) void spmspv_frontier_dense_kernel(const gl_idx
     }
 }
 
+// ------------------------------------------------------------------ BFS push step on a bit frontier (gl_bfs_bits_push_step)
+// SpMSpV (||,&&) masked WriteToZero by the distances + AssignVectorSparse(level) (app/bfs.h:146-148) with the bit vector
+// of the next frontier as the accumulator: a product whose row is still unvisited sets the row's bit, and the thread that
+// sets it first writes the level -- no dense accumulator, no compaction, ONE launch.  Long columns are not queued at run
+// time: the plan lists their chunks, every workgroup tests the frontier bit of the chunks it is dealt.
+struct BfsPushArgs {
+    const uint32_t *indptr;
+    const uint2 *stream;
+    const uint4 *chunks;
+    uint32_t nchunks;
+    uint32_t num_cols;
+    const uint32_t *bits_in;
+    uint32_t *bits_out;      // all zero on entry (the push step of two slots earlier cleared it)
+    uint32_t *bits_spare;    // cleared here, gate or not: the next slot's bits_out
+    uint32_t words;          // words of each bit vector
+    uint32_t col_words;      // words that hold columns
+    float *dist;
+    float level;
+    uint32_t *acc;           // kBfsAccSlots x 32 words, zero between steps: [0] new vertices, [2..3] their column lengths
+    BfsBitsCtl c;
+};
+
+// the first thread to set an unvisited row's bit writes its level and counts it (and the row's column: the next push's work)
+__device__ __forceinline__ void bfs_claim(const BfsPushArgs &a, bool cand, uint32_t row, uint32_t &fresh, uint32_t &work) {
+    if (!cand) return;
+    const uint32_t m = 1u << (row & 31u);
+    const uint32_t old = atomicOr(&a.bits_out[row >> 5], m);
+    if (old & m) return;
+    a.dist[row] = a.level;
+    fresh += 1u;
+    if (row < a.num_cols) work += a.indptr[row + 1u] - a.indptr[row];
+}
+// candidate = the product a && x is true and the mask (distance == 0: not visited, app/bfs.h:146) lets it through
+__device__ __forceinline__ bool bfs_candidate(const BfsPushArgs &a, bool valid, uint2 rv) {
+    return valid && (rv.y << 1) != 0u && a.dist[rv.x] == 0.0f;
+}
+
+__global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
+    __shared__ uint32_t s_words[256];
+    __shared__ uint32_t s_start[256];
+    __shared__ uint32_t s_deg[256];
+    __shared__ uint32_t s_task[257];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_fresh, s_nhit;
+    __shared__ unsigned long long s_work;
+    if (a.bits_spare)
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.words; i += gridDim.x * 256u) a.bits_spare[i] = 0u;
+    if (!(a.c.pushes() && !a.c.row_wise())) return;
+    if (threadIdx.x == 0) {
+        s_fresh = 0u;
+        s_nhit = 0u;
+        s_work = 0ull;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t fresh = 0u, work = 0u;
+
+    // this workgroup's slice of the frontier words: read 256 words at a time (one load per thread), then 8 words = 256
+    // columns per batch out of LDS; empty pieces cost one barrier
+    const uint32_t per = ((a.col_words + gridDim.x - 1u) / gridDim.x + 7u) & ~7u;
+    const uint32_t w_begin = blockIdx.x * per, w_end = min(a.col_words, w_begin + per);
+    for (uint32_t wp = w_begin; wp < w_end; wp += 256u) {
+        const uint32_t mine = (wp + threadIdx.x < w_end) ? a.bits_in[wp + threadIdx.x] : 0u;
+        __syncthreads();                      // the previous piece's batches are done with s_words
+        s_words[threadIdx.x] = mine;
+        if (!__syncthreads_or(mine != 0u)) continue;
+        const uint32_t nw = min(256u, w_end - wp);
+        for (uint32_t b0 = 0; b0 < nw; b0 += 8u) {
+            const uint32_t word = s_words[b0 + (threadIdx.x >> 5)];
+            {   // block-uniform: any of the batch's 8 words set?
+                uint32_t any = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) any |= s_words[b0 + k];
+                if (!any) continue;
+            }
+            const uint32_t col = (wp + b0 + (threadIdx.x >> 5)) * 32u + (threadIdx.x & 31u);
+            uint32_t start = 0, deg = 0;
+            if (((word >> (threadIdx.x & 31u)) & 1u) && col < a.num_cols) {
+                start = a.indptr[col];
+                deg = a.indptr[col + 1u] - start;
+                if (deg >= kBigColumn) deg = 0u;      // served from the chunk list below
+            }
+            uint32_t ttotal;
+            const uint32_t toff = block_exclusive_256((deg + 63u) >> 6, s_wave, &ttotal);
+            s_start[threadIdx.x] = start;
+            s_deg[threadIdx.x] = deg;
+            s_task[threadIdx.x] = toff;
+            if (threadIdx.x == 255) s_task[256] = ttotal;
+            __syncthreads();
+            // two wave tasks of <= 64 entries per step: the stream loads, the distance loads and the atomics of the two are
+            // in flight together (a task is three dependent memory round trips)
+            for (uint32_t t = wave; t < ttotal; t += 8u) {
+                uint2 rv[2];
+                bool valid[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t tu = min(t + 4u * u, ttotal - 1u);
+                    uint32_t lo = 0, hi = 255;   // largest j with s_task[j] <= tu (wave-uniform)
+#pragma unroll
+                    for (int it = 0; it < 8; it++) {
+                        const uint32_t mid = (lo + hi + 1u) >> 1;
+                        if (s_task[mid] <= tu) lo = mid; else hi = mid - 1u;
+                    }
+                    const uint32_t j = __builtin_amdgcn_readfirstlane(lo);
+                    const uint32_t item = ((tu - s_task[j]) << 6) + lane;
+                    valid[u] = (t + 4u * u < ttotal) && item < s_deg[j];
+                    rv[u] = valid[u] ? load_stream_nt(a.stream + s_start[j] + item) : make_uint2(0u, 0u);
+                }
+                const bool c0 = bfs_candidate(a, valid[0], rv[0]), c1 = bfs_candidate(a, valid[1], rv[1]);
+                bfs_claim(a, c0, rv[0].x, fresh, work);
+                bfs_claim(a, c1, rv[1].x, fresh, work);
+            }
+            __syncthreads();
+        }
+    }
+    // chunks of long columns: every thread tests the frontier bit of one chunk, the hits are processed by the whole workgroup
+    __syncthreads();
+    // (thread t of workgroup b tests chunk t * #workgroups + b of the pass: the chunks of one hub column, neighbours in the
+    // list, go to different workgroups -- dealt 256 in a row to one workgroup, a hub's 25 chunks ran one after the other:
+    // 784 us for a 330-vertex frontier of the pokec stand-in)
+    for (uint32_t q0 = 0; q0 < a.nchunks; q0 += gridDim.x * 256u) {
+        const uint32_t q = q0 + threadIdx.x * gridDim.x + blockIdx.x;
+        if (q < a.nchunks) {
+            const uint32_t col = a.chunks[q].x;
+            if ((a.bits_in[col >> 5] >> (col & 31u)) & 1u) s_start[atomicAdd(&s_nhit, 1u)] = q;
+        }
+        __syncthreads();
+        const uint32_t nhit = s_nhit;
+        __syncthreads();
+        if (threadIdx.x == 0) s_nhit = 0u;
+        for (uint32_t h = 0; h < nhit; h++) {
+            const uint4 ch = a.chunks[s_start[h]];
+            for (uint32_t k = threadIdx.x; k < ch.z; k += 512u) {
+                const bool v1 = k + 256u < ch.z;
+                const uint2 r0 = load_stream_nt(a.stream + ch.y + k);
+                const uint2 r1 = v1 ? load_stream_nt(a.stream + ch.y + k + 256u) : make_uint2(0u, 0u);
+                const bool c0 = bfs_candidate(a, true, r0), c1 = bfs_candidate(a, v1, r1);
+                bfs_claim(a, c0, r0.x, fresh, work);
+                bfs_claim(a, c1, r1.x, fresh, work);
+            }
+        }
+        __syncthreads();
+    }
+    // totals of the step
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        fresh += __shfl_down(fresh, d);
+        work += __shfl_down(work, d);       // (a wavefront's share stays far below 2^32)
+    }
+    __syncthreads();
+    if (lane == 0 && fresh) {
+        atomicAdd(&s_fresh, fresh);
+        atomicAdd(&s_work, (unsigned long long)work);
+    }
+    __syncthreads();
+    // The step's totals go to one of 64 accumulator lines (thousands of workgroups ending on ONE word serialise: 45 us for
+    // an empty step on 2048 workgroups); the pull step of the same slot -- launched right behind, gated off -- adds them
+    // up and takes the step's decisions (bool_plan_bfs_step), so no workgroup here has to find out that it is the last.
+    if (threadIdx.x == 0 && s_fresh) {
+        uint32_t *line = a.acc + 32u * (blockIdx.x & (kBfsAccSlots - 1u));
+        atomicAdd(line, s_fresh);
+        atomicAdd(reinterpret_cast<unsigned long long *>(line + 2), s_work);
+    }
+}
+
 // compaction source over the dense accumulator
 template <int MASK, bool BITS = false>   // BITS: the integer value types compare bit patterns (zero may be 0xffffffff, a NaN as a float)
 struct AccSource {
@@ -428,6 +599,14 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
         if (d >= gl::kBigColumn) chunks += (d + gl::kChunk - 1u) / gl::kChunk;
     }
     p->queue_capacity = (uint32_t)std::min<uint64_t>(chunks + 1u, 0x7fffffffu);
+    std::vector<uint4> long_chunks;
+    long_chunks.reserve((size_t)chunks);
+    for (uint32_t c = 0; c < num_cols; c++) {
+        const uint32_t d = indptr[c + 1] - indptr[c];
+        if (d < gl::kBigColumn) continue;
+        for (uint32_t k = 0; k < d; k += gl::kChunk) long_chunks.push_back(make_uint4(c, indptr[c] + k, std::min(gl::kChunk, d - k), 0u));
+    }
+    p->n_long_chunks = (uint32_t)long_chunks.size();
     auto fail = [&](hipError_t e) {
         gl_spmspv_plan_destroy(p);
         return gl::set_error(GL_ERR_HIP, "gl_spmspv_plan_create: %s", hipGetErrorString(e));
@@ -445,12 +624,18 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     if ((e = hipMalloc((void **)&p->d_queue, b_queue)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_queue_count, 16)) != hipSuccess) return fail(e);
     if ((e = hipMemset(p->d_queue_count, 0, 16)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_long_chunks, (long_chunks.size() + 1u) * sizeof(uint4))) != hipSuccess) return fail(e);
+    if (!long_chunks.empty() &&
+        (e = hipMemcpy(p->d_long_chunks, long_chunks.data(), long_chunks.size() * sizeof(uint4), hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(e);
+    if ((e = hipMalloc((void **)&p->d_bfs_acc, gl::kBfsAccSlots * 128u)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(p->d_bfs_acc, 0, gl::kBfsAccSlots * 128u)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_mode, 16)) != hipSuccess) return fail(e);
     if ((e = hipMemset(p->d_mode, 0, 16)) != hipSuccess) return fail(e);
     if (!on_device && (e = hipMemcpy(p->d_indptr, indptr.data(), b_indptr, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if (!on_device && b_stream && (e = hipMemcpy(p->d_stream, stream.data(), b_stream, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e);   // the memsets above ran on the null stream
-    p->device_bytes = b_indptr + b_stream + b_acc + b_counts + b_queue;
+    p->device_bytes = b_indptr + b_stream + b_acc + b_counts + b_queue + long_chunks.size() * sizeof(uint4);
     gl::live_spmspv_plans().push_back(p);
     *plan = p;
     return GL_OK;
@@ -467,6 +652,8 @@ int gl_spmspv_plan_destroy(gl_spmspv_plan p) {
     (void)hipFree(p->d_queue);
     (void)hipFree(p->d_queue_count);
     (void)hipFree(p->d_mode);
+    (void)hipFree(p->d_long_chunks);
+    (void)hipFree(p->d_bfs_acc);
     (void)hipFree(p->d_xdense);
     delete p;
     return GL_OK;
@@ -711,6 +898,43 @@ int gl_spmspv_last_direction(gl_spmspv_plan p, int *row_wise) {
     return GL_OK;
 }
 
+int gl_bfs_bits_push_step(gl_spmspv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,
+                          uint32_t bits_words, float *d_distance, float level, uint32_t *d_ctl, uint32_t slot, float threshold,
+                          int may_continue) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && d_bits_in != nullptr && d_bits_out != nullptr);
+    GL_ARG(d_distance != nullptr && d_ctl != nullptr && slot >= 1u && ((uintptr_t)d_ctl & 7u) == 0);
+    GL_ARG(d_bits_in != d_bits_out && d_bits_in != d_bits_spare && d_bits_out != d_bits_spare);
+    GL_ARG((uint64_t)bits_words * 32u >= p->num_cols && (uint64_t)bits_words * 32u >= p->num_rows);
+    if (p->row_begin != 0 || p->row_end != p->num_rows)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_push_step: row shards decide on the host (their frontier counts are partial)");
+    gl::BfsPushArgs a;
+    a.indptr = p->d_indptr;
+    a.stream = p->d_stream;
+    a.chunks = p->d_long_chunks;
+    a.nchunks = p->n_long_chunks;
+    a.num_cols = p->num_cols;
+    a.bits_in = d_bits_in;
+    a.bits_out = d_bits_out;
+    a.bits_spare = d_bits_spare;
+    a.words = bits_words;
+    a.col_words = gl::cdiv(p->num_cols, 32);
+    a.dist = d_distance;
+    a.level = level;
+    a.acc = p->d_bfs_acc;
+    a.c.ctl = d_ctl;
+    a.c.slot = slot;
+    a.c.n = p->num_rows ? p->num_rows : 1u;
+    a.c.may_continue = (uint32_t)may_continue;
+    a.c.threshold = threshold;
+    a.c.back_threshold = 0.0f;
+    a.c.heavy = gl::spmspv_heavy_work(p);
+    uint32_t grid = std::min<uint32_t>((uint32_t)gl::ctx().num_cus * 8u, std::max<uint32_t>(gl::cdiv(a.col_words, 8), 1u));
+    gl::bfs_push_bits_kernel<<<grid, 256, 0, gl::ctx().stream>>>(a);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz) {
     GL_REQUIRE_INIT();
     GL_ARG(d_sparse != nullptr && nnz != nullptr);
@@ -729,6 +953,16 @@ int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz) {
 // gl_init loads this translation unit's code object up front (HIP defers that to the unit's first launch, which would put
 // tens of milliseconds into somebody's timed call)
 namespace gl {
+// a frontier whose columns hold more non-zeros than this is applied row-wise (the rule of gl_spmspv_run's direction switch)
+unsigned long long spmspv_heavy_work(gl_spmspv_plan p) {
+    const long div = env_long("GRAPHLILY_SPMSPV_PULL_DIV", 32);
+    return div > 0 ? p->nnz / (unsigned long long)div : ~0ull;
+}
+const uint32_t *spmspv_plan_indptr(gl_spmspv_plan p) { return p->d_indptr; }
+uint32_t spmspv_plan_num_cols(gl_spmspv_plan p) { return p->num_cols; }
+uint32_t *spmspv_plan_bfs_acc(gl_spmspv_plan p) { return p->d_bfs_acc; }
+bool spmspv_plan_whole(gl_spmspv_plan p, uint32_t num_rows) { return p->row_begin == 0 && p->row_end == p->num_rows && p->num_rows == num_rows; }
+
 int preload_spmspv() {
     hipFuncAttributes attr;
     GL_HIP(hipFuncGetAttributes(&attr, (const void *)spmspv_work_kernel));

@@ -1568,6 +1568,29 @@ int gl_bfs_pull_step_back(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *d
     return gl::bits_to_sparse_gated(d_bits_out, p->num_rows, d_frontier_out, d_scratch, d_ctl + 4, slot, s);
 }
 
+int gl_bfs_bits_pull_step(gl_spmv_plan p, gl_spmspv_plan csc, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance,
+                          float level, uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue, float back_threshold) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && csc != nullptr && d_bits_in != nullptr && d_bits_out != nullptr && d_distance != nullptr);
+    GL_ARG(d_ctl != nullptr && slot >= 1u && ((uintptr_t)d_ctl & 7u) == 0);
+    GL_ARG(d_bits_in != d_bits_out);
+    GL_ARG((((uintptr_t)d_bits_in | (uintptr_t)d_bits_out) & 15u) == 0);
+    if (!p->boolean)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_pull_step: the plan does not hold the GL_PLAN_BOOLEAN layout");
+    if (p->row_begin != 0 || p->row_end != p->num_rows || !gl::spmspv_plan_whole(csc, p->num_rows))
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_pull_step: row shards decide on the host (their frontier counts are partial)");
+    gl::BfsBitsCtl c;
+    c.ctl = d_ctl;
+    c.slot = slot;
+    c.n = p->num_rows ? p->num_rows : 1u;
+    c.may_continue = (uint32_t)may_continue;
+    c.threshold = threshold;
+    c.back_threshold = back_threshold;
+    c.heavy = gl::spmspv_heavy_work(csc);
+    return gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, gl::ctx().stream, nullptr, 0u, GL_GATE_EQ, nullptr, 0u, 0.0f, 0,
+                                  &c, gl::spmspv_plan_indptr(csc), gl::spmspv_plan_num_cols(csc), gl::spmspv_plan_bfs_acc(csc));
+}
+
 int gl_spmv_plan_export(gl_spmv_plan p, int array, void *h_dst, size_t capacity, size_t *bytes) {
     GL_REQUIRE_INIT();
     GL_ARG(p != nullptr && bytes != nullptr);

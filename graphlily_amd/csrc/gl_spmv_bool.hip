@@ -43,6 +43,13 @@ struct BoolArgs {
     uint32_t *back_ctl = nullptr;
     uint32_t back_slot = 0, back_may_continue = 0, back_n = 1;
     float back_threshold = 0.0f;
+    // bit-frontier BFS schedule (gl_bfs_bits_pull_step, BfsBitsCtl in gl_common.h): the launch runs when its slot pulls
+    // OR when the slot's push goes row-wise -- the same pass either way; the fused epilogue also sums the column lengths
+    // of the rows it adds (the next push's work) and the workgroup that finishes last takes the step's decisions
+    BfsBitsCtl v2;
+    const uint32_t *v2_indptr = nullptr;   // column pointers of the CSC plan of the same matrix
+    uint32_t v2_ncols = 0;
+    uint32_t *v2_push_acc = nullptr;       // totals of the slot's push step (64 lines of 32 words), when that one ran
 };
 
 // x != 0 packed little-endian, 64 columns per wavefront step; words past num_cols are zero
@@ -86,6 +93,26 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     uint32_t *xw = lds_words + kBoolTileWords;      // kBoolPhaseWords
 
     if (a.run_flag && load_const(a.run_flag) == 0u) return;
+    if (a.v2.ctl && a.v2.pushes() && !a.v2.row_wise()) {
+        // the slot's push step ran (it is enqueued in front of this launch): add up its totals and take its decisions.
+        // decide() does not change what pushes() / row_wise() say about THIS slot, so the other workgroups may look later.
+        if (blockIdx.x == 0 && threadIdx.x < 64u) {
+            uint32_t *line = a.v2_push_acc + 32u * threadIdx.x;
+            uint32_t fresh = line[0];
+            unsigned long long work = *reinterpret_cast<unsigned long long *>(line + 2);
+            if (fresh) {
+                line[0] = 0u;
+                *reinterpret_cast<unsigned long long *>(line + 2) = 0ull;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                fresh += __shfl_down(fresh, d);
+                work += __shfl_down(work, d);
+            }
+            if (threadIdx.x == 0) a.v2.decide(fresh, work);
+        }
+        return;
+    }
     if (a.gate) {   // (a plain load: the word is written by kernels earlier in the stream)
         const uint32_t w = *a.gate;
         if (!(a.gate_op == GL_GATE_EQ ? w == a.gate_value : a.gate_op == GL_GATE_GT ? w > a.gate_value : w <= a.gate_value)) return;
@@ -192,18 +219,52 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         // the next frontier (app/bfs.h:118-123) in one epilogue: 64 rows per wavefront step, one 64-bit word out.
         // Blocks of boolean plans start on multiples of 64 rows, so every word has exactly one writer.
         uint32_t nfresh = 0;   // lane 0 of every wavefront: rows this wavefront put into the next frontier
+        unsigned long long work = 0ull;   // v2: column lengths of this lane's fresh rows
         for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < nrows; i0 += kThreads) {
             const uint32_t i = i0 + lane, row = row0 + i;
             bool fresh = false;
             if (i < nrows && ((tile[i >> 5] >> (i & 31u)) & 1u) && a.dist[row] == 0.0f) {
                 a.dist[row] = a.level;
                 fresh = true;
+                if (a.v2_indptr && row < a.v2_ncols) work += a.v2_indptr[row + 1u] - a.v2_indptr[row];
             }
             const uint64_t m = __ballot(fresh);
             if (lane == 0) reinterpret_cast<uint64_t *>(a.bits_out)[(row0 + i0) >> 6] = m;
             nfresh += (uint32_t)__popcll(m);
         }
-        if (a.back_ctl) {
+        if (a.v2.ctl) {
+            __shared__ uint32_t v2_fresh_s;
+            __shared__ unsigned long long v2_work_s;
+            if (threadIdx.x == 0) {
+                v2_fresh_s = 0u;
+                v2_work_s = 0ull;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) work += __shfl_down(work, d);
+            if (lane == 0 && nfresh) {
+                atomicAdd(&v2_fresh_s, nfresh);
+                atomicAdd(&v2_work_s, work);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned long long *gwork = reinterpret_cast<unsigned long long *>(a.v2.ctl + 10);
+                if (v2_fresh_s) {
+                    atomicAdd(&a.v2.ctl[5], v2_fresh_s);
+                    atomicAdd(gwork, v2_work_s);
+                }
+                __threadfence();
+                if (atomicAdd(&a.v2.ctl[6], 1u) == gridDim.x - 1u) {   // the last workgroup decides
+                    __threadfence();
+                    const uint32_t total = __hip_atomic_load(&a.v2.ctl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long wk = __hip_atomic_load(gwork, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.v2.ctl[5] = 0u;
+                    a.v2.ctl[6] = 0u;
+                    *gwork = 0ull;
+                    a.v2.decide(total, wk);
+                }
+            }
+        } else if (a.back_ctl) {
             __shared__ uint32_t fresh_s;   // one global atomic per workgroup, not per wavefront
             if (threadIdx.x == 0) fresh_s = 0u;
             __syncthreads();
@@ -289,7 +350,8 @@ static int launch_bool(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
 // multiple of 64 rows only; bits_out must not alias bits_in.
 int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s,
                        const uint32_t *gate, uint32_t gate_value, int gate_op, uint32_t *back_ctl, uint32_t back_slot,
-                       float back_threshold, int back_may_continue) {
+                       float back_threshold, int back_may_continue, const BfsBitsCtl *v2, const uint32_t *v2_indptr, uint32_t v2_ncols,
+                       uint32_t *v2_push_acc) {
     if (p->row_end == p->row_begin) return GL_OK;
     if (p->segments > 1 || (p->row_begin & 63u) || !p->nunits)
         return set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step: needs an unsplit boolean plan whose shard starts on a multiple of 64 rows");
@@ -315,6 +377,12 @@ int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_o
     a.back_threshold = back_threshold;
     a.back_may_continue = back_may_continue ? 1u : 0u;
     a.back_n = p->num_rows ? p->num_rows : 1u;
+    if (v2) {
+        a.v2 = *v2;
+        a.v2_indptr = v2_indptr;
+        a.v2_ncols = v2_ncols;
+        a.v2_push_acc = v2_push_acc;
+    }
     a.tickets = bool_tickets();
     return launch_bool_variant<GL_NOMASK, 1>(p, a, s);
 }

@@ -182,7 +182,8 @@ int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const 
 int pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits, hipStream_t s);
 int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s,
                        const uint32_t *gate = nullptr, uint32_t gate_value = 0, int gate_op = GL_GATE_EQ, uint32_t *back_ctl = nullptr,
-                       uint32_t back_slot = 0, float back_threshold = 0.0f, int back_may_continue = 0);
+                       uint32_t back_slot = 0, float back_threshold = 0.0f, int back_may_continue = 0, const BfsBitsCtl *v2 = nullptr,
+                       const uint32_t *v2_indptr = nullptr, uint32_t v2_ncols = 0, uint32_t *v2_push_acc = nullptr);
 int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s, const uint32_t *xbits = nullptr);
 // gl_apply.hip: the set bits of d_bits[0..n) as a sparse list {row, 1} with head {count, 0}; no-op unless *gate_word == gate_value
 int bits_to_sparse_gated(const uint32_t *d_bits, uint32_t n, gl_idx_val *d_out, uint32_t *d_counts, const uint32_t *gate_word,
@@ -191,6 +192,12 @@ uint32_t *bool_plan_xbits(gl_spmv_plan p);
 size_t bool_plan_xbits_bytes(gl_spmv_plan p);
 int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
                      const uint32_t *run_flag);
+// gl_spmspv.hip: what the pull step of the bit-frontier BFS schedule (gl_bfs_bits_pull_step) needs from the CSC plan
+unsigned long long spmspv_heavy_work(gl_spmspv_plan p);
+const uint32_t *spmspv_plan_indptr(gl_spmspv_plan p);
+uint32_t spmspv_plan_num_cols(gl_spmspv_plan p);
+uint32_t *spmspv_plan_bfs_acc(gl_spmspv_plan p);   // 64 lines of 32 words: {new vertices, -, column lengths (64 bits)} of a push step
+bool spmspv_plan_whole(gl_spmspv_plan p, uint32_t num_rows);
 // gl_spmspv.hip: forget `dying` wherever gl_spmspv_plan_attach_pull attached it
 void spmspv_detach_everywhere(gl_spmv_plan dying);
 // gl_spmv.hip: y initialisation for plans whose units fold into y

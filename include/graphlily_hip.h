@@ -83,6 +83,9 @@ int gl_buf_alloc(void **d_ptr, size_t bytes);
 int gl_buf_free(void *d_ptr);
 int gl_buf_h2d(void *d_dst, const void *h_src, size_t bytes);   /* blocking */
 int gl_buf_d2h(void *h_dst, const void *d_src, size_t bytes);   /* blocking */
+/* the same copy enqueued on the library stream without waiting (h_dst page-locked, gl_host_alloc: it then runs behind the
+ * kernels already enqueued, with no host round trip in between; gl_sync before h_dst is read) */
+int gl_buf_d2h_async(void *h_dst, const void *d_src, size_t bytes);
 int gl_buf_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async    */
 int gl_buf_fill_f32(float *d_dst, float value, size_t count);   /* async    */
 /* 32-bit fill that does nothing unless *d_gate == gate_value (d_gate NULL: always) */
@@ -288,6 +291,36 @@ int gl_spmspv_run_gated(gl_spmspv_plan plan, const gl_idx_val *d_vector, const f
 int gl_bfs_pull_step_gated(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level,
                            const uint32_t *d_gate, uint32_t gate_value, int gate_op);
 
+/* Second form of the device-resident BFS schedule (replaces app/bfs.h:146-152 + :180-205 for a whole-matrix BFS on one
+ * GPU): the frontier lives as BITS only and an iteration slot is TWO launches.
+ *   d_ctl     ctl_words >= 17 + slots words, 8-byte aligned: [0] first pull slot (0xffffffff while pushing), [1] push
+ *             iterations of the first push phase (the reference's count), [2] source vertex (written by the host before
+ *             the schedule), [3] pushes after a pull step handed the loop back, [4] the slot that handed back, [5..15]
+ *             internal, [16 + s] the number of vertices slot s reached.
+ *   d_bits    nvec >= slots + 2 bit vectors of bits_words words each, contiguous, 16-byte aligned (bits_words a multiple of
+ *             4, at least gl_spmv_plan_bits_words of the pull plan): slot s (1, 2, ...) reads vector s and writes vector
+ *             s + 1, which therefore holds exactly the vertices at distance s + 1 when the schedule has run.
+ *   gl_bfs_bits_begin       distance[i] = (i == source), vector 1 = {source}, the others and the control words cleared.
+ *   gl_bfs_bits_push_step   SpMSpV (||,&&) masked WriteToZero by d_distance + AssignVectorSparse(level) with the next
+ *             frontier's bit vector as the accumulator (no dense accumulator, no compaction): runs when slot `slot`
+ *             pushes and its frontier is light; a frontier whose columns hold more than 1/32 of the non-zeros is left to
+ *             the pull step of the same slot (the same rule as gl_spmspv_plan_attach_pull).  d_bits_out must be all zero on entry; d_bits_spare, if not NULL, is cleared
+ *             (gate or not) -- for callers that rotate three vectors instead of keeping one per slot.
+ *   gl_bfs_bits_pull_step   gl_bfs_pull_step; runs when the slot pulls, or pushes a heavy frontier (row-wise: the same
+ *             pass).  `csc` = the SpMSpV plan of the same matrix (column lengths: the next push's work).  It follows the push
+ *             step of its slot also when that one ran: gated off, it adds up the push step's totals and decides for it.
+ * Whichever of the two ran ends with the reference's loop decision (ctl[1]++; keep pushing while bit 0 of may_continue
+ * is set and new frontier / num_rows < threshold) or, after a pull, the opposite one (back_threshold > 0, bit 1 of
+ * may_continue -- "a slot follows" -- set and new frontier / num_rows < back_threshold: push again; pushes after that are
+ * counted in ctl[3]).  A slot enqueues its push step BEFORE its pull step.  No call synchronises or copies; the schedule can
+ * be captured once (gl_graph_*) and replayed for any source. */
+int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
+                      uint32_t nvec);
+int gl_bfs_bits_push_step(gl_spmspv_plan csc, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,
+                          uint32_t bits_words, float *d_distance, float level, uint32_t *d_ctl, uint32_t slot, float threshold,
+                          int may_continue);
+int gl_bfs_bits_pull_step(gl_spmv_plan plan, gl_spmspv_plan csc, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance,
+                          float level, uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue, float back_threshold);
 /* Extension: direction switch inside the operator.  `pull` is an SpMV plan over the same matrix and row shard
  * (BFS holds both, app/bfs.h:83-99).  A run with zero == 0 whose frontier columns hold more than 1/32 of the
  * matrix's non-zeros is then computed row-wise into the dense accumulator instead of being scattered: a

@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_apps.py -m gpu -x -q 2>&1 | tail -15
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bfs_trace && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/bfs_trace -- python $GRAFT_REPO_ROOT/scripts/r02_bfs_trace.py > /tmp/bfs_trace.log 2>&1
+cd $GRAFT_REPO_ROOT; grep "^CALL" /tmp/bfs_trace.log || tail -20 /tmp/bfs_trace.log
+python scripts/r02_timeline.py /tmp/bfs_trace | tee gpurun_out/r02_bfs_bits_timeline.txt
+python scripts/r02_bfs_loop.py 2>&1 | tail -7
+python scripts/r02_bfs_loop.py googleplus 2>&1 | tail -6
+python scripts/r02_bfs_loop.py pokec 2>&1 | tail -6

@@ -13,7 +13,7 @@ for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
 kern.sort(); cop.sort()
 # rocprofv3 timestamps and time.time_ns() share CLOCK_REALTIME only approximately: locate the last call by its kernels --
 # the last bfs_begin_kernel starts it
-begins = [k for k in kern if "bfs_begin_kernel" in k[2]]
+begins = [k for k in kern if "bfs_begin_kernel" in k[2] or "bfs_bits_begin_kernel" in k[2]]
 t0 = begins[-1][0]
 ks = [k for k in kern if k[0] >= t0]
 cs = [c for c in cop if c[0] >= t0 - 200000]

@@ -211,8 +211,9 @@ def test_fused_bfs_pull_step_equals_the_three_calls(gpu, monkeypatch):
     assert not bits[(n + 31) // 32:].any() or np.all(bits[(n + 31) // 32:] == 0xFFFFFFFF)   # words past the rows untouched
 
 
+@pytest.mark.parametrize("bits", ["1", "0"])     # the bit-frontier schedule (gl_bfs_bits_*) / the list-based one
 @pytest.mark.parametrize("name", ["rmat_sym_50K", "uniform_10K_10"])
-def test_bfs_pull_push_device_loop_equals_host_loop(gpu, name, monkeypatch):
+def test_bfs_pull_push_device_loop_equals_host_loop(gpu, name, bits, monkeypatch):
     """pull_push with the direction decided on the device (no read-back per iteration; the schedule is
     captured as a hipGraph from the second call on) gives the oracle's distances and switches direction after the same
     number of push iterations as the host-driven loop of the reference (app/bfs.h:180-190), for several sources and
@@ -224,6 +225,8 @@ def test_bfs_pull_push_device_loop_equals_host_loop(gpu, name, monkeypatch):
     bfs.load_and_format_matrix(m, True)
     bfs.send_matrix_host_to_device()
     assert bfs._device_loop_ok()
+    monkeypatch.setenv("GRAPHLILY_BFS_BITS", bits)
+    assert bfs._bits_loop_ok() == (bits == "1")
     deg = np.diff(m.adj_indptr.astype(np.int64))
     sources = [0, int(np.argmax(deg)), int(np.nonzero(deg > 0)[0][-1])]
     for thr in (0.001, 0.05, 1.0):
@@ -238,18 +241,21 @@ def test_bfs_pull_push_device_loop_equals_host_loop(gpu, name, monkeypatch):
                 assert np.array_equal(ref, got)
                 assert bfs.push_iterations_ == pushes, "thr %g src %d: device %d vs host %d push iterations" % (
                     thr, src, pushes, bfs.push_iterations_)
-    assert any(bfs.dev_loop_["graphs"].values()), "the schedule was captured as a graph"
+    state = bfs.bits_loop_ if bits == "1" else bfs.dev_loop_
+    assert any(state["graphs"].values()), "the schedule was captured as a graph"
 
 
+@pytest.mark.parametrize("bits", ["1", "0"])
 @pytest.mark.parametrize("name", ["rmat_sym_50K", "uniform_10K_10"])
 @pytest.mark.parametrize("back", ["0.9", "0.02", "0.0001"])
-def test_bfs_pull_push_returns_to_push(gpu, name, back, monkeypatch):
+def test_bfs_pull_push_returns_to_push(gpu, name, back, bits, monkeypatch):
     """An extension of the device-resident schedule: when a pull step finds fewer than `back` * n new vertices the next
     slot pushes again (gl_bfs_pull_step_back; the default only does so on matrices whose pull step costs far more than a
     push step's launches, GRAPHLILY_BFS_BACK forces it).  Distances do not depend on the direction: every threshold /
     source combination must give the oracle's result, eagerly and replayed, and the reference's push count (the first
     push phase) must not change."""
     monkeypatch.setenv("GRAPHLILY_BFS_BACK", back)
+    monkeypatch.setenv("GRAPHLILY_BFS_BITS", bits)
     m = named_matrix(name)
     om = _oracle_prepared(m, "bfs")
     bfs = app.BFS(M.num_hbm_channels, 0, 0, 0)
@@ -272,3 +278,41 @@ def test_bfs_pull_push_returns_to_push(gpu, name, back, monkeypatch):
                 assert bfs.push_iterations_ == pushes
     if back == "0.9":
         assert again > 0, "with back = 0.9 some pull step must have handed the loop back to pushing"
+
+
+def test_bfs_bits_schedule_long_columns_and_heavy_frontiers(gpu, monkeypatch):
+    """gl_bfs_bits_*: columns of 4096 entries and more are served from the plan's static chunk list (two hub vertices with
+    ~6000 and ~9000 neighbours, one of them the source), and a push whose frontier holds more than 1/PULL_DIV of the
+    non-zeros is left to the pull step of its slot (forced on and off through GRAPHLILY_SPMSPV_PULL_DIV).  Distances and
+    the reference's push count must not depend on any of it."""
+    rng = np.random.default_rng(5)
+    n = 40000
+    rows = [rng.integers(0, n, size=12 * n), np.full(6000, 7), np.full(9000, 11)]
+    cols = [rng.integers(0, n, size=12 * n), rng.choice(n, 6000, replace=False), rng.choice(n, 9000, replace=False)]
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    r, c = np.concatenate([r, c]), np.concatenate([c, r])       # symmetric
+    key = np.unique(r.astype(np.int64) * n + c)
+    r, c = (key // n).astype(np.uint32), (key % n).astype(np.uint32)
+    indptr = np.zeros(n + 1, np.uint32)
+    np.add.at(indptr, r.astype(np.int64) + 1, 1)
+    indptr = np.cumsum(indptr).astype(np.uint32)
+    m = io.CSRMatrix(n, n, np.ones(len(c), np.float32), c, indptr)
+    om = _oracle_prepared(m, "bfs")
+    for div in ("32", "1000000", "1"):
+        monkeypatch.setenv("GRAPHLILY_SPMSPV_PULL_DIV", div)
+        bfs = app.BFS(M.num_hbm_channels, 0, 0, 0)
+        bfs.set_up_runtime()
+        bfs.load_and_format_matrix(m, True)
+        bfs.send_matrix_host_to_device()
+        monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "1")
+        assert bfs._bits_loop_ok()
+        for thr in (0.001, 0.3, 1.0):
+            for rep in range(3):
+                for src in (7, 11, 0, 12345):
+                    monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "1")
+                    got = bfs.pull_push(src, 7, thr)
+                    pushes = bfs.push_iterations_
+                    assert np.array_equal(got, O.bfs(om, src, 7)), "div %s thr %g rep %d src %d" % (div, thr, rep, src)
+                    monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "0")
+                    assert np.array_equal(bfs.pull_push(src, 7, thr), got)
+                    assert bfs.push_iterations_ == pushes, "div %s thr %g src %d" % (div, thr, src)
