@@ -273,6 +273,8 @@ class BFS(_GraphApp):
         return self.backend.download_result(distance, self.n_)
 
     def pull(self, source, num_iterations):
+        if self._bits_loop_ok():
+            return self._pull_push_bits(source, num_iterations, -1.0, pull_only=True)
         n = self.n_
         vector = self._new_dense(n, self.semiring_.zero, source, 1.0)
         distance = self._new_dense(n, 0.0, source, 1.0)
@@ -414,8 +416,9 @@ class BFS(_GraphApp):
         self.push_iterations_again_ = int(out[n + 3:n + 4].view(np.uint32)[0])   # pushes after a pull step handed back
         return out[:n]
 
-    def _pull_push_bits(self, source, num_iterations, threshold):
-        """The device-resident schedule with the frontier as BITS only (gl_bfs_bits_*): a slot is two launches -- a push
+    def _pull_push_bits(self, source, num_iterations, threshold, pull_only=False):
+        """(pull_only: the same machinery for BFS.pull -- every slot is the fused pull step, app/bfs.h:106-126.)
+        The device-resident schedule with the frontier as BITS only (gl_bfs_bits_*): a slot is two launches -- a push
         step that scatters straight into the next frontier's bit vector and writes the levels itself (no dense
         accumulator, no compaction, no chunk queue), and the fused pull step, which also serves a push whose frontier is
         heavy (row-wise) and otherwise takes the push step's decisions.  13 launches for the 6 iterations of the orkut
@@ -423,6 +426,7 @@ class BFS(_GraphApp):
         The read-back of distances + control words is enqueued behind the schedule (page-locked destination taken from
         the results the caller has dropped): one wait per run."""
         B, n, N = self.backend, self.n_, num_iterations
+        self.fused_ = True          # (every pull step of this schedule is the fused one, see _bind_pull)
         st = getattr(self, "bits_loop_", None)
         if st is None or st["N"] < N:
             words = (int(self.SpMV_.bits_words()) + 3) & ~3
@@ -434,24 +438,27 @@ class BFS(_GraphApp):
                                     "bits": [B.view(vecs, k * words, words, 4) for k in range(nvec)], "graphs": {},
                                     "src": np.zeros(1, np.uint32), "warm": set()}
         ctl, distance, bits, words = st["ctl"], st["distance"], st["bits"], st["words"]
-        # hand the loop back to pushing when a pull step finds a small new frontier (an extension, see _pull_push_device;
-        # a push step of this schedule is one short launch, so it pays wherever a pull step is not tiny itself)
-        dflt = max(float(threshold), 1.0 / 64.0) if self.get_nnz() >= (16 << 20) else 0.0
-        back = float(os.environ.get("GRAPHLILY_BFS_BACK", str(dflt)))
+        # Once the reference's rule has switched to pulling (frontier / n >= threshold, app/bfs.h:180-190), every later slot
+        # is handed back to the push step (an extension, see _pull_push_device), which leaves heavy frontiers to the pull
+        # step of its slot anyway: from then on the direction follows the work (GRAPHLILY_BFS_HEAVY_DIV).  A push step of
+        # this schedule is one short launch, so this pays on all six stand-ins (same-box sweep: hollywood 0.47 -> 0.41 ms).
+        back = 0.0 if pull_only else float(os.environ.get("GRAPHLILY_BFS_BACK", "1.0"))
         csc_plan, pull_plan = self.SpMSpV_.plan_, self.SpMV_.plan_
 
         def schedule():
-            capi.bfs_bits_begin(ctl, st["ctl_words"], distance, n, st["vecs"], words, st["nvec"])
+            capi.bfs_bits_begin(ctl, st["ctl_words"], distance, n, st["vecs"], words, st["nvec"], 0 if pull_only else 0xffffffff)
             for it in range(1, N + 1):
                 may = (1 if it + 1 < N else 0) | (2 if it + 1 <= N else 0)
-                capi.bfs_bits_push_step(csc_plan, bits[it], bits[it + 1], None, words, distance, float(it + 1), ctl, it, threshold, may)
+                if not pull_only:
+                    capi.bfs_bits_push_step(csc_plan, bits[it], bits[it + 1], None, words, distance, float(it + 1), ctl, it,
+                                            threshold, may)
                 # (also in the first slot, which always pushes: the gated-off pull step takes the push step's decisions)
                 capi.bfs_bits_pull_step(pull_plan, csc_plan, bits[it], bits[it + 1], distance, float(it + 1), ctl, it, threshold,
                                         may, back)
 
         st["src"][0] = source
         B.upload(B.view(ctl, 2, 1, 4), st["src"])        # ctl[2] = source: the one host->device word per run
-        key = (N, float(threshold), back)
+        key = (N, float(threshold), back, pull_only)
         g = st["graphs"].get(key)
         if g is None and os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0" and key in st["warm"]:
             try:
@@ -476,7 +483,7 @@ class BFS(_GraphApp):
 
     def _bits_loop_ok(self):
         return (self._device_loop_ok() and os.environ.get("GRAPHLILY_BFS_BITS", "1") != "0"
-                and hasattr(capi, "bfs_bits_push_step") and self.SpMV_.plan_ is not None and self.SpMSpV_.plan_ is not None)
+                and os.environ.get("GRAPHLILY_BFS_FUSED", "1") != "0" and hasattr(capi, "bfs_bits_push_step") and self.SpMV_.plan_ is not None and self.SpMSpV_.plan_ is not None)
 
     def pull_push(self, source, num_iterations, threshold=0.05):
         if self._bits_loop_ok():

@@ -81,7 +81,7 @@ def lib():
     sigs = {
         "gl_graph_begin_capture": [], "gl_graph_end_capture": [P(vp)], "gl_graph_launch": [vp], "gl_graph_destroy": [vp],
         "gl_bfs_begin": [vp, vp, u32, vp, vp, u32],
-        "gl_bfs_bits_begin": [vp, u32, vp, u32, vp, u32, u32],
+        "gl_bfs_bits_begin": [vp, u32, vp, u32, vp, u32, u32, u32],
         "gl_buf_d2h_async": [vp, vp, ctypes.c_size_t],
         "gl_bfs_bits_push_step": [vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
         "gl_bfs_bits_pull_step": [vp, vp, vp, vp, vp, f32, vp, u32, f32, i32, f32],
@@ -557,8 +557,9 @@ def fill_u32_gated(buf, value, count, gate, gate_value):
     check(lib().gl_buf_fill_u32_gated(_p(buf), int(value), int(count), _p(gate), int(gate_value)))
 
 
-def bfs_bits_begin(ctl, ctl_words, distance, n, bits, bits_words, nvec):
-    check(lib().gl_bfs_bits_begin(_p(ctl), int(ctl_words), _p(distance), int(n), _p(bits), int(bits_words), int(nvec)))
+def bfs_bits_begin(ctl, ctl_words, distance, n, bits, bits_words, nvec, first_pull_slot=0xffffffff):
+    check(lib().gl_bfs_bits_begin(_p(ctl), int(ctl_words), _p(distance), int(n), _p(bits), int(bits_words), int(nvec),
+                                  int(first_pull_slot)))
 
 
 def bfs_bits_push_step(csc_plan, bits_in, bits_out, bits_spare, bits_words, distance, level, ctl, slot, threshold, may_continue):

@@ -164,12 +164,13 @@ __global__ __launch_bounds__(256) void bfs_begin_kernel(uint32_t *__restrict__ c
 // gl_bfs_bits_begin: distances, the bit vectors (vector 1 = {source}: slot s reads vector s and writes vector s + 1, slot 1
 // is the first) and the control words (BfsBitsCtl, gl_common.h)
 __global__ __launch_bounds__(256) void bfs_bits_begin_kernel(uint32_t *__restrict__ ctl, uint32_t ctl_words, float *__restrict__ distance,
-                                                             uint32_t n, uint32_t *__restrict__ bits, uint32_t words, uint32_t nvec) {
+                                                             uint32_t n, uint32_t *__restrict__ bits, uint32_t words, uint32_t nvec,
+                                                             uint32_t first_pull_slot) {
     const uint32_t src = ctl[2];
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
     for (uint32_t i = tid; i < n; i += stride) distance[i] = (i == src) ? 1.0f : 0.0f;      // app/bfs.h:168-171
     for (uint32_t w = tid; w < nvec * words; w += stride) bits[w] = (w == words + (src >> 5)) ? (1u << (src & 31u)) : 0u;
-    if (tid < ctl_words && tid != 2u) ctl[tid] = (tid == 0u || tid == 4u) ? 0xffffffffu : 0u;
+    if (tid < ctl_words && tid != 2u) ctl[tid] = tid == 0u ? first_pull_slot : (tid == 4u ? 0xffffffffu : 0u);
 }
 
 // the set bits of a frontier bit vector as list candidates (gl_bfs_pull_step_back): entry {row, 1}
@@ -212,11 +213,12 @@ int gl_bfs_begin(uint32_t *d_ctl, float *d_distance, uint32_t n, gl_idx_val *d_f
 
 
 int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
-                      uint32_t nvec) {
+                      uint32_t nvec, uint32_t first_pull_slot) {
     GL_REQUIRE_INIT();
     GL_ARG(d_ctl != nullptr && d_distance != nullptr && d_bits != nullptr && n > 0 && (uint64_t)bits_words * 32u >= n);
     GL_ARG(((uintptr_t)d_ctl & 7u) == 0 && ctl_words >= 18u && ctl_words <= 65536u && nvec >= 3u);
-    gl::bfs_bits_begin_kernel<<<gl::stream_grid(n), 256, 0, gl::ctx().stream>>>(d_ctl, ctl_words, d_distance, n, d_bits, bits_words, nvec);
+    gl::bfs_bits_begin_kernel<<<gl::stream_grid(n), 256, 0, gl::ctx().stream>>>(d_ctl, ctl_words, d_distance, n, d_bits, bits_words, nvec,
+                                                                                  first_pull_slot);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

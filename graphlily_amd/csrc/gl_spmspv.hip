@@ -953,9 +953,12 @@ int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz) {
 // gl_init loads this translation unit's code object up front (HIP defers that to the unit's first launch, which would put
 // tens of milliseconds into somebody's timed call)
 namespace gl {
-// a frontier whose columns hold more non-zeros than this is applied row-wise (the rule of gl_spmspv_run's direction switch)
+// The bit-frontier BFS schedule applies a frontier whose columns hold more non-zeros than this row-wise (the pull step of
+// the slot).  A push step retires ~11 G products/s (three dependent round trips per 64 of them), the boolean SpMV streams
+// ~1.4 T entries/s: they cost the same near nnz / 128 (same-box sweep of 32 ... 256 on the six stand-ins; the list-based
+// gl_spmspv_run, whose scatter also pays for a compaction, keeps its 1 / 32).
 unsigned long long spmspv_heavy_work(gl_spmspv_plan p) {
-    const long div = env_long("GRAPHLILY_SPMSPV_PULL_DIV", 32);
+    const long div = env_long("GRAPHLILY_BFS_HEAVY_DIV", 128);
     return div > 0 ? p->nnz / (unsigned long long)div : ~0ull;
 }
 const uint32_t *spmspv_plan_indptr(gl_spmspv_plan p) { return p->d_indptr; }

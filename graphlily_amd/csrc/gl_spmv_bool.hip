@@ -219,48 +219,96 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         // the next frontier (app/bfs.h:118-123) in one epilogue: 64 rows per wavefront step, one 64-bit word out.
         // Blocks of boolean plans start on multiples of 64 rows, so every word has exactly one writer.
         uint32_t nfresh = 0;   // lane 0 of every wavefront: rows this wavefront put into the next frontier
-        unsigned long long work = 0ull;   // v2: column lengths of this lane's fresh rows
-        for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < nrows; i0 += kThreads) {
-            const uint32_t i = i0 + lane, row = row0 + i;
-            bool fresh = false;
-            if (i < nrows && ((tile[i >> 5] >> (i & 31u)) & 1u) && a.dist[row] == 0.0f) {
-                a.dist[row] = a.level;
-                fresh = true;
-                if (a.v2_indptr && row < a.v2_ncols) work += a.v2_indptr[row + 1u] - a.v2_indptr[row];
+        uint32_t work = 0u;    // v2: column lengths of this lane's fresh rows (a lane sees <= 15 rows: no overflow below 2^28 each)
+        // Four row groups per step, every load of a stage issued before the first use: a row is three dependent round trips
+        // (distance, then -- bit-frontier schedule only -- its two column pointers), and one at a time they made the epilogue
+        // a sixth of the launch.  No two threads touch the same row, so the stores of a step cannot feed its loads.
+        constexpr int E = 4;
+        for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < nrows; i0 += E * kThreads) {
+            bool hit[E];
+            float dv[E];
+#pragma unroll
+            for (int u = 0; u < E; u++) {
+                const uint32_t i = i0 + u * kThreads + lane;
+                hit[u] = i < nrows && ((tile[i >> 5] >> (i & 31u)) & 1u);
+                dv[u] = hit[u] ? a.dist[row0 + i] : 1.0f;
             }
-            const uint64_t m = __ballot(fresh);
-            if (lane == 0) reinterpret_cast<uint64_t *>(a.bits_out)[(row0 + i0) >> 6] = m;
-            nfresh += (uint32_t)__popcll(m);
+            uint32_t p0[E], p1[E];
+#pragma unroll
+            for (int u = 0; u < E; u++) {
+                const uint32_t row = row0 + i0 + u * kThreads + lane;
+                hit[u] = hit[u] && dv[u] == 0.0f;       // fresh: reached now, never before
+                const bool want = hit[u] && a.v2_indptr != nullptr && row < a.v2_ncols;
+                p0[u] = want ? a.v2_indptr[row] : 0u;
+                p1[u] = want ? a.v2_indptr[row + 1u] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < E; u++) {
+                const uint32_t g0 = i0 + u * kThreads;   // wave-uniform
+                if (g0 < nrows) {
+                    if (hit[u]) a.dist[row0 + g0 + lane] = a.level;
+                    const uint64_t m = __ballot(hit[u]);
+                    if (lane == 0) reinterpret_cast<uint64_t *>(a.bits_out)[(row0 + g0) >> 6] = m;
+                    nfresh += (uint32_t)__popcll(m);
+                    work += p1[u] - p0[u];
+                }
+            }
         }
-        if (a.v2.ctl) {
-            __shared__ uint32_t v2_fresh_s;
+        if (a.v2.ctl && a.v2_push_acc) {     // (no accumulator lines: a schedule that only pulls, nothing to decide)
+            __shared__ uint32_t v2_fresh_s, v2_last_s;
             __shared__ unsigned long long v2_work_s;
             if (threadIdx.x == 0) {
                 v2_fresh_s = 0u;
                 v2_work_s = 0ull;
             }
             __syncthreads();
+            unsigned long long work64 = work;
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) work += __shfl_down(work, d);
+            for (int d = 32; d > 0; d >>= 1) work64 += __shfl_down(work64, d);
             if (lane == 0 && nfresh) {
                 atomicAdd(&v2_fresh_s, nfresh);
-                atomicAdd(&v2_work_s, work);
+                atomicAdd(&v2_work_s, work64);
             }
             __syncthreads();
+            // Totals and "who is last" through the 64 accumulator lines of the push step (idle in a slot whose pull step
+            // runs), then one root ticket per line: all 256 workgroups end within microseconds of each other, and three
+            // atomics each on ONE word cost ~5 us per launch (measured: BFS.pull on 23 slots +110 us).
             if (threadIdx.x == 0) {
-                unsigned long long *gwork = reinterpret_cast<unsigned long long *>(a.v2.ctl + 10);
+                const uint32_t l = blockIdx.x & 63u, nlines = min(gridDim.x, 64u);
+                uint32_t *line = a.v2_push_acc + 32u * l;
                 if (v2_fresh_s) {
-                    atomicAdd(&a.v2.ctl[5], v2_fresh_s);
-                    atomicAdd(gwork, v2_work_s);
+                    atomicAdd(line, v2_fresh_s);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(line + 2), v2_work_s);
                 }
                 __threadfence();
-                if (atomicAdd(&a.v2.ctl[6], 1u) == gridDim.x - 1u) {   // the last workgroup decides
+                bool last = atomicAdd(line + 4, 1u) == (gridDim.x - l + 63u) / 64u - 1u;   // last workgroup of this line
+                if (last) {
                     __threadfence();
-                    const uint32_t total = __hip_atomic_load(&a.v2.ctl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long wk = __hip_atomic_load(gwork, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.v2.ctl[5] = 0u;
+                    last = atomicAdd(&a.v2.ctl[6], 1u) == nlines - 1u;                      // ... of the launch
+                }
+                v2_last_s = last ? 1u : 0u;
+            }
+            __syncthreads();
+            if (v2_last_s && threadIdx.x < 64u) {   // one wavefront adds up the lines (one thread doing it: +8 us per launch)
+                __threadfence();
+                const uint32_t nlines = min(gridDim.x, 64u);
+                uint32_t total = 0u;
+                unsigned long long wk = 0ull;
+                if (threadIdx.x < nlines) {
+                    uint32_t *ln = a.v2_push_acc + 32u * threadIdx.x;
+                    total = __hip_atomic_load(ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    wk = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ln + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ln[0] = 0u;
+                    *reinterpret_cast<unsigned long long *>(ln + 2) = 0ull;
+                    ln[4] = 0u;
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    total += __shfl_down(total, d);
+                    wk += __shfl_down(wk, d);
+                }
+                if (threadIdx.x == 0) {
                     a.v2.ctl[6] = 0u;
-                    *gwork = 0ull;
                     a.v2.decide(total, wk);
                 }
             }

@@ -300,7 +300,10 @@ int gl_bfs_pull_step_gated(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_
  *   d_bits    nvec >= slots + 2 bit vectors of bits_words words each, contiguous, 16-byte aligned (bits_words a multiple of
  *             4, at least gl_spmv_plan_bits_words of the pull plan): slot s (1, 2, ...) reads vector s and writes vector
  *             s + 1, which therefore holds exactly the vertices at distance s + 1 when the schedule has run.
- *   gl_bfs_bits_begin       distance[i] = (i == source), vector 1 = {source}, the others and the control words cleared.
+ *   gl_bfs_bits_begin       distance[i] = (i == source), vector 1 = {source}, the others and the control words cleared;
+ *             ctl[0] = first_pull_slot: 0xffffffff for pull_push (push until the rule says otherwise), 0 for a BFS that
+ *             pulls in every slot (app/bfs.h:106-126: then only the pull steps are enqueued, with threshold < 0 -- "this
+ *             schedule never pushes": the steps skip the bookkeeping the decisions need).
  *   gl_bfs_bits_push_step   SpMSpV (||,&&) masked WriteToZero by d_distance + AssignVectorSparse(level) with the next
  *             frontier's bit vector as the accumulator (no dense accumulator, no compaction): runs when slot `slot`
  *             pushes and its frontier is light; a frontier whose columns hold more than 1/32 of the non-zeros is left to
@@ -315,7 +318,7 @@ int gl_bfs_pull_step_gated(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_
  * counted in ctl[3]).  A slot enqueues its push step BEFORE its pull step.  No call synchronises or copies; the schedule can
  * be captured once (gl_graph_*) and replayed for any source. */
 int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
-                      uint32_t nvec);
+                      uint32_t nvec, uint32_t first_pull_slot);
 int gl_bfs_bits_push_step(gl_spmspv_plan csc, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,
                           uint32_t bits_words, float *d_distance, float level, uint32_t *d_ctl, uint32_t slot, float threshold,
                           int may_continue);

@@ -25,7 +25,10 @@ for mode, bits, gr in (("0", "0", "0"), ("1", "0", "1"), ("1", "1", "0"), ("1", 
     print("%s device_loop=%s bits=%s graph=%s: median %.3f ms (%s), pushes %d again %s reached %d same %s" % (
         g, mode, bits, gr, float(np.median(ts[3:])), " ".join("%.3f" % x for x in ts), bfs.push_iterations_,
         getattr(bfs, "push_iterations_again_", None), int((d != 0).sum()), bool(np.array_equal(d, ref))))
-ts = []
-for i in range(7):
-    capi.sync(); t = time.perf_counter(); d = bfs.pull(src, iters); ts.append((time.perf_counter() - t) * 1e3)
-print("%s pull: median %.3f ms same %s" % (g, float(np.median(ts[2:])), bool(np.array_equal(d, ref))))
+for bits, gr in (("0", "1"), ("1", "1"), ("1", "0"), ("0", "1"), ("1", "1"), ("1", "0")):
+    os.environ["GRAPHLILY_BFS_BITS"] = bits
+    os.environ["GRAPHLILY_BFS_GRAPH"] = gr
+    ts = []
+    for i in range(9):
+        capi.sync(); t = time.perf_counter(); d = bfs.pull(src, iters); ts.append((time.perf_counter() - t) * 1e3)
+    print("%s pull bits=%s graph=%s: median %.3f ms same %s" % (g, bits, gr, float(np.median(ts[3:])), bool(np.array_equal(d, ref))))

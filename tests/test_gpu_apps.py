@@ -283,7 +283,7 @@ def test_bfs_pull_push_returns_to_push(gpu, name, back, bits, monkeypatch):
 def test_bfs_bits_schedule_long_columns_and_heavy_frontiers(gpu, monkeypatch):
     """gl_bfs_bits_*: columns of 4096 entries and more are served from the plan's static chunk list (two hub vertices with
     ~6000 and ~9000 neighbours, one of them the source), and a push whose frontier holds more than 1/PULL_DIV of the
-    non-zeros is left to the pull step of its slot (forced on and off through GRAPHLILY_SPMSPV_PULL_DIV).  Distances and
+    non-zeros is left to the pull step of its slot (forced on and off through GRAPHLILY_BFS_HEAVY_DIV).  Distances and
     the reference's push count must not depend on any of it."""
     rng = np.random.default_rng(5)
     n = 40000
@@ -298,8 +298,8 @@ def test_bfs_bits_schedule_long_columns_and_heavy_frontiers(gpu, monkeypatch):
     indptr = np.cumsum(indptr).astype(np.uint32)
     m = io.CSRMatrix(n, n, np.ones(len(c), np.float32), c, indptr)
     om = _oracle_prepared(m, "bfs")
-    for div in ("32", "1000000", "1"):
-        monkeypatch.setenv("GRAPHLILY_SPMSPV_PULL_DIV", div)
+    for div in ("128", "1000000", "1"):
+        monkeypatch.setenv("GRAPHLILY_BFS_HEAVY_DIV", div)
         bfs = app.BFS(M.num_hbm_channels, 0, 0, 0)
         bfs.set_up_runtime()
         bfs.load_and_format_matrix(m, True)
