@@ -449,9 +449,9 @@ class BFS(_GraphApp):
             capi.bfs_bits_begin(ctl, st["ctl_words"], distance, n, st["vecs"], words, st["nvec"], 0 if pull_only else 0xffffffff)
             for it in range(1, N + 1):
                 may = (1 if it + 1 < N else 0) | (2 if it + 1 <= N else 0)
-                if not pull_only:
-                    capi.bfs_bits_push_step(csc_plan, bits[it], bits[it + 1], None, words, distance, float(it + 1), ctl, it,
-                                            threshold, may)
+                # (pull_only: never scatters, but the launch is also the bottom-up pull of the late slots)
+                capi.bfs_bits_push_step(csc_plan, pull_plan, bits[it], bits[it + 1], None, words, distance, float(it + 1), ctl, it,
+                                        threshold, may)
                 # (also in the first slot, which always pushes: the gated-off pull step takes the push step's decisions)
                 capi.bfs_bits_pull_step(pull_plan, csc_plan, bits[it], bits[it + 1], distance, float(it + 1), ctl, it, threshold,
                                         may, back)

@@ -83,7 +83,7 @@ def lib():
         "gl_bfs_begin": [vp, vp, u32, vp, vp, u32],
         "gl_bfs_bits_begin": [vp, u32, vp, u32, vp, u32, u32, u32],
         "gl_buf_d2h_async": [vp, vp, ctypes.c_size_t],
-        "gl_bfs_bits_push_step": [vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
+        "gl_bfs_bits_push_step": [vp, vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
         "gl_bfs_bits_pull_step": [vp, vp, vp, vp, vp, f32, vp, u32, f32, i32, f32],
         "gl_spmspv_run_gated": [vp, vp, vp, vp, i32, f32, i32, vp, f32, vp, vp, u32, i32, vp, u32, f32, i32],
         "gl_bfs_pull_step_gated": [vp, vp, vp, vp, f32, vp, u32, i32],
@@ -562,8 +562,9 @@ def bfs_bits_begin(ctl, ctl_words, distance, n, bits, bits_words, nvec, first_pu
                                   int(first_pull_slot)))
 
 
-def bfs_bits_push_step(csc_plan, bits_in, bits_out, bits_spare, bits_words, distance, level, ctl, slot, threshold, may_continue):
-    check(lib().gl_bfs_bits_push_step(ctypes.c_void_p(csc_plan.handle), _p(bits_in), _p(bits_out), _p(bits_spare), int(bits_words),
+def bfs_bits_push_step(csc_plan, rows_plan, bits_in, bits_out, bits_spare, bits_words, distance, level, ctl, slot, threshold, may_continue):
+    check(lib().gl_bfs_bits_push_step(ctypes.c_void_p(csc_plan.handle), ctypes.c_void_p(rows_plan.handle if rows_plan is not None else 0),
+                                      _p(bits_in), _p(bits_out), _p(bits_spare), int(bits_words),
                                       _p(distance), float(level), _p(ctl), int(slot), float(threshold), int(may_continue)))
 
 

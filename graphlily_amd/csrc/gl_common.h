@@ -174,7 +174,8 @@ __device__ __forceinline__ bool value_is_zero(float v) {
 // push phase (the reference's count), [2] source vertex, [3] pushes after a pull step handed the loop back, [4] the slot
 // that handed back (0xffffffff: none), [5] new-frontier count of the running step, [6] workgroup ticket of the running
 // step, [7] the threshold the hand-back used, [8] the slot whose PUSH goes row-wise (its frontier's columns hold more
-// than `heavy` non-zeros; 0: none), [10..11] sum of the column lengths of the new frontier (64 bits; ctl is 8-byte aligned).
+// than `heavy` non-zeros; 0: none), [9] the slot whose pull goes bottom-up, [12..13] non-zeros in the rows reached so far
+// (64 bits; ctl is 8-byte aligned).
 // Every step of slot s ends with decide(): the reference's loop condition (do { push } while (it < num_iterations &&
 // nnz / n < threshold), app/bfs.h:180-190) where the step pushed, the opposite decision where it pulled, and the
 // direction of the next slot's push.
@@ -185,11 +186,21 @@ struct BfsBitsCtl {
     float threshold = 0.0f;        // push while new frontier / n < threshold
     float back_threshold = 0.0f;   // pull hands back to push when new frontier / n < back_threshold (0: never)
     unsigned long long heavy = ~0ull;
+    // bottom-up pull (bfs_bottom_up in gl_spmspv.hip): a slot that does not scatter visits only the rows not reached
+    // yet, row-wise with an early exit, when those rows hold fewer than bu_limit non-zeros (ctl[9] = that slot;
+    // ctl[12..13] = non-zeros in the rows reached so far); nnz_rows = all non-zeros.  bu_limit 0: never.
+    unsigned long long nnz_rows = 0, bu_limit = 0;
     __device__ bool pushes() const { return ctl[0] > slot; }
     __device__ bool row_wise() const { return ctl[8] == slot; }
-    // called by the workgroup that finishes the step last, with the step's totals
-    __device__ void decide(uint32_t fresh, unsigned long long work) const {
-        ctl[16u + slot] = fresh;       // the slot's new-frontier size, for the host (which late slots changed distances?)
+    __device__ bool scatters() const { return ctl[0] > slot && ctl[8] != slot; }
+    __device__ bool bottom_up() const { return !scatters() && ctl[9] == slot; }
+    // called once per slot, when the step that ran is complete, with the step's totals: vertices reached, non-zeros in
+    // their columns (what a push from them scatters) and in their rows (what a pull no longer has to look at)
+    __device__ void decide(uint32_t fresh, unsigned long long work, unsigned long long work_rows) const {
+        ctl[16u + slot] = fresh;       // the slot's new-frontier size, for the host
+        unsigned long long *visited = reinterpret_cast<unsigned long long *>(ctl + 12);
+        const unsigned long long vis = *visited + work_rows;
+        *visited = vis;
         if (ctl[0] > slot) {
             const bool again = ctl[4] != 0xffffffffu;
             ctl[again ? 3 : 1] += 1u;
@@ -201,7 +212,9 @@ struct BfsBitsCtl {
             ctl[4] = slot;
             ctl[7] = __float_as_uint(back_threshold);
         }
+        const bool next_scatters = ctl[0] > slot + 1u && work <= heavy;
         if (ctl[0] > slot + 1u && work > heavy) ctl[8] = slot + 1u;
+        if (!next_scatters && nnz_rows - min(vis, nnz_rows) < bu_limit) ctl[9] = slot + 1u;
     }
 };
 

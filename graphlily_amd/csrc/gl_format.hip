@@ -779,6 +779,28 @@ int devcsr_stage(DevCsr **out, const uint32_t *h_indptr, const uint32_t *h_indic
     return GL_OK;
 }
 
+// A whole-matrix boolean plan keeps the staged rows for the bottom-up BFS step: entries whose value is zero (a && b is
+// false for them) get the column 0xffffffff, which no frontier holds.
+__global__ __launch_bounds__(256) void fmt_mark_zero_values_kernel(uint32_t *__restrict__ indices, const uint32_t *__restrict__ data,
+                                                                   uint64_t nnz) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * 256u)
+        if ((data[i] << 1) == 0u) indices[i] = 0xffffffffu;
+}
+
+int devcsr_adopt_rows(DevCsr *c, uint32_t **d_indptr, uint32_t **d_indices) {
+    if (c->nnz) {
+        fmt_mark_zero_values_kernel<<<(unsigned)std::min<uint64_t>((c->nnz + 255u) / 256u, (uint64_t)ctx().num_cus * 16u), 256, 0, ctx().stream>>>(
+            c->d_indices, c->d_data, c->nnz);
+        GL_LAUNCH_CHECK();
+        GL_HIP(hipStreamSynchronize(ctx().stream));
+    }
+    *d_indptr = c->d_indptr;
+    *d_indices = c->d_indices;
+    c->d_indptr = nullptr;
+    c->d_indices = nullptr;
+    return GL_OK;
+}
+
 void devcsr_release(DevCsr *c) {
     if (!c) return;
     (void)hipFree(c->d_indptr);

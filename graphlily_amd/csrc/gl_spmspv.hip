@@ -59,6 +59,7 @@ struct gl_spmspv_plan_s {
     // step tests the frontier bit of each chunk's column instead of queueing chunks at run time (no second launch)
     uint4 *d_long_chunks = nullptr;
     uint32_t n_long_chunks = 0;
+    const void *bfs_rows_plan = nullptr;   // the SpMV plan whose rows the last gl_bfs_bits_push_step could scan bottom-up (or null)
     uint32_t *d_bfs_acc = nullptr;   // kBfsAccSlots x 32 words: the push step's totals, spread over 64 lines (see bfs_push_bits_kernel)
     uint64_t device_bytes = 0;
 };
@@ -341,12 +342,16 @@ struct BfsPushArgs {
     uint32_t col_words;      // words that hold columns
     float *dist;
     float level;
-    uint32_t *acc;           // kBfsAccSlots x 32 words, zero between steps: [0] new vertices, [2..3] their column lengths
+    uint32_t *acc;           // kBfsAccSlots x 32 words, zero between steps: [0] new vertices, [2..3] their column lengths,
+                             // [6..7] their row lengths ([4]: the pull step's per-line ticket)
+    const uint32_t *row_ptr; // the rows as plain CSR (whole-matrix boolean SpMV plan of the same matrix), or null:
+    const uint32_t *row_idx; //   row lengths for the bookkeeping, and the bottom-up branch
+    uint32_t num_rows;
     BfsBitsCtl c;
 };
 
 // the first thread to set an unvisited row's bit writes its level and counts it (and the row's column: the next push's work)
-__device__ __forceinline__ void bfs_claim(const BfsPushArgs &a, bool cand, uint32_t row, uint32_t &fresh, uint32_t &work) {
+__device__ __forceinline__ void bfs_claim(const BfsPushArgs &a, bool cand, uint32_t row, uint32_t &fresh, uint32_t &work, uint32_t &work_rows) {
     if (!cand) return;
     const uint32_t m = 1u << (row & 31u);
     const uint32_t old = atomicOr(&a.bits_out[row >> 5], m);
@@ -354,6 +359,7 @@ __device__ __forceinline__ void bfs_claim(const BfsPushArgs &a, bool cand, uint3
     a.dist[row] = a.level;
     fresh += 1u;
     if (row < a.num_cols) work += a.indptr[row + 1u] - a.indptr[row];
+    if (a.row_ptr) work_rows += a.row_ptr[row + 1u] - a.row_ptr[row];
 }
 // candidate = the product a && x is true and the mask (distance == 0: not visited, app/bfs.h:146) lets it through
 __device__ __forceinline__ bool bfs_candidate(const BfsPushArgs &a, bool valid, uint2 rv) {
@@ -367,18 +373,76 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
     __shared__ uint32_t s_task[257];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_fresh, s_nhit;
-    __shared__ unsigned long long s_work;
+    __shared__ unsigned long long s_work, s_work_rows;
     if (a.bits_spare)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.words; i += gridDim.x * 256u) a.bits_spare[i] = 0u;
-    if (!(a.c.pushes() && !a.c.row_wise())) return;
+    const bool scatter = a.c.scatters();
+    if (!scatter && !(a.row_idx && a.c.bottom_up())) return;
     if (threadIdx.x == 0) {
         s_fresh = 0u;
         s_nhit = 0u;
         s_work = 0ull;
+        s_work_rows = 0ull;
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t fresh = 0u, work = 0u;
+    uint32_t fresh = 0u, work = 0u, work_rows = 0u;
+    if (!scatter) {
+        // ---- bottom-up pull (the slot pulls, or pushes a heavy frontier, and few non-zeros are left in unreached rows):
+        // a thread per row not reached yet looks through the row, four entries per step, until it finds a neighbour in the
+        // frontier; 64 rows per wavefront = one word of the next frontier.  Same result as the streaming pull step
+        // (masked (||,&&) SpMV + assign, app/bfs.h:118-123), at the cost of the unreached rows instead of the matrix.
+        const uint32_t nwords64 = (a.num_rows + 63u) >> 6;
+        for (uint32_t wd = blockIdx.x * 4u + wave; wd < nwords64; wd += gridDim.x * 4u) {
+            const uint32_t row = wd * 64u + lane;
+            const bool live = row < a.num_rows && a.dist[row] == 0.0f;
+            uint32_t beg = 0, end = 0;
+            if (live) {
+                beg = a.row_ptr[row];
+                end = a.row_ptr[row + 1u];
+            }
+            const uint32_t len = end - beg;
+            bool hit = false;
+            for (int step = 0; step < 8 && __any(!hit && beg < end); step++) {
+                if (!hit && beg < end) {
+                    uint32_t c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) c[u] = beg + u < end ? a.row_idx[beg + u] : 0xffffffffu;
+                    uint32_t any = 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) any |= c[u] < a.num_cols ? (a.bits_in[c[u] >> 5] >> (c[u] & 31u)) & 1u : 0u;
+                    hit = any != 0u;
+                    beg += 4u;
+                }
+            }
+            // rows still undecided after 32 entries are finished by the whole wavefront, 256 entries per step: a hub row
+            // the BFS never reaches (another component) must not keep one thread busy for its 100 K entries
+            for (uint64_t pending = __ballot(!hit && beg < end); pending; pending &= pending - 1ull) {
+                const int src = __ffsll((unsigned long long)pending) - 1;
+                const uint32_t b = __shfl(beg, src), e = __shfl(end, src);
+                bool found = false;
+                for (uint32_t base = b; base < e && !found; base += 256u) {
+                    uint32_t any = 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t k = base + 64u * u + lane;
+                        const uint32_t c = k < e ? a.row_idx[k] : 0xffffffffu;
+                        any |= c < a.num_cols ? (a.bits_in[c >> 5] >> (c & 31u)) & 1u : 0u;
+                    }
+                    found = __any(any != 0u);
+                }
+                if ((int)lane == src) hit = found;
+            }
+            if (hit) {
+                a.dist[row] = a.level;
+                fresh += 1u;
+                work_rows += len;
+                if (row < a.num_cols) work += a.indptr[row + 1u] - a.indptr[row];
+            }
+            const uint64_t m = __ballot(hit);
+            if (lane == 0) reinterpret_cast<uint64_t *>(a.bits_out)[wd] = m;
+        }
+    } else {
 
     // this workgroup's slice of the frontier words: read 256 words at a time (one load per thread), then 8 words = 256
     // columns per batch out of LDS; empty pieces cost one barrier
@@ -432,8 +496,8 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
                     rv[u] = valid[u] ? load_stream_nt(a.stream + s_start[j] + item) : make_uint2(0u, 0u);
                 }
                 const bool c0 = bfs_candidate(a, valid[0], rv[0]), c1 = bfs_candidate(a, valid[1], rv[1]);
-                bfs_claim(a, c0, rv[0].x, fresh, work);
-                bfs_claim(a, c1, rv[1].x, fresh, work);
+                bfs_claim(a, c0, rv[0].x, fresh, work, work_rows);
+                bfs_claim(a, c1, rv[1].x, fresh, work, work_rows);
             }
             __syncthreads();
         }
@@ -460,22 +524,26 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
                 const uint2 r0 = load_stream_nt(a.stream + ch.y + k);
                 const uint2 r1 = v1 ? load_stream_nt(a.stream + ch.y + k + 256u) : make_uint2(0u, 0u);
                 const bool c0 = bfs_candidate(a, true, r0), c1 = bfs_candidate(a, v1, r1);
-                bfs_claim(a, c0, r0.x, fresh, work);
-                bfs_claim(a, c1, r1.x, fresh, work);
+                bfs_claim(a, c0, r0.x, fresh, work, work_rows);
+                bfs_claim(a, c1, r1.x, fresh, work, work_rows);
             }
         }
         __syncthreads();
     }
+    }   // scatter
     // totals of the step
+    unsigned long long work64 = work, rows64 = work_rows;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         fresh += __shfl_down(fresh, d);
-        work += __shfl_down(work, d);       // (a wavefront's share stays far below 2^32)
+        work64 += __shfl_down(work64, d);
+        rows64 += __shfl_down(rows64, d);
     }
     __syncthreads();
     if (lane == 0 && fresh) {
         atomicAdd(&s_fresh, fresh);
-        atomicAdd(&s_work, (unsigned long long)work);
+        atomicAdd(&s_work, work64);
+        atomicAdd(&s_work_rows, rows64);
     }
     __syncthreads();
     // The step's totals go to one of 64 accumulator lines (thousands of workgroups ending on ONE word serialise: 45 us for
@@ -485,6 +553,7 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
         uint32_t *line = a.acc + 32u * (blockIdx.x & (kBfsAccSlots - 1u));
         atomicAdd(line, s_fresh);
         atomicAdd(reinterpret_cast<unsigned long long *>(line + 2), s_work);
+        if (s_work_rows) atomicAdd(reinterpret_cast<unsigned long long *>(line + 6), s_work_rows);
     }
 }
 
@@ -898,7 +967,7 @@ int gl_spmspv_last_direction(gl_spmspv_plan p, int *row_wise) {
     return GL_OK;
 }
 
-int gl_bfs_bits_push_step(gl_spmspv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,
+int gl_bfs_bits_push_step(gl_spmspv_plan p, gl_spmv_plan rows, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,
                           uint32_t bits_words, float *d_distance, float level, uint32_t *d_ctl, uint32_t slot, float threshold,
                           int may_continue) {
     GL_REQUIRE_INIT();
@@ -922,6 +991,12 @@ int gl_bfs_bits_push_step(gl_spmspv_plan p, const uint32_t *d_bits_in, uint32_t 
     a.dist = d_distance;
     a.level = level;
     a.acc = p->d_bfs_acc;
+    const bool have_rows = rows != nullptr && rows->d_csr_indptr != nullptr && rows->num_rows == p->num_rows &&
+                           rows->num_cols == p->num_cols && rows->row_begin == 0 && rows->row_end == rows->num_rows;
+    p->bfs_rows_plan = have_rows ? rows : nullptr;
+    a.row_ptr = have_rows ? rows->d_csr_indptr : nullptr;
+    a.row_idx = have_rows ? rows->d_csr_indices : nullptr;
+    a.num_rows = p->num_rows;
     a.c.ctl = d_ctl;
     a.c.slot = slot;
     a.c.n = p->num_rows ? p->num_rows : 1u;
@@ -961,6 +1036,14 @@ unsigned long long spmspv_heavy_work(gl_spmspv_plan p) {
     const long div = env_long("GRAPHLILY_BFS_HEAVY_DIV", 128);
     return div > 0 ? p->nnz / (unsigned long long)div : ~0ull;
 }
+// ... and visits only the rows not reached yet once those hold fewer non-zeros than this (bottom-up: a thread per row with
+// an early exit reads an entry ~4 x more expensively than the streaming kernel, but stops at the first hit)
+unsigned long long spmspv_bottom_up_limit(gl_spmspv_plan p) {
+    const long div = env_long("GRAPHLILY_BFS_BU_DIV", 3);
+    return div > 0 ? p->nnz / (unsigned long long)div : 0ull;
+}
+unsigned long long spmspv_plan_nnz(gl_spmspv_plan p) { return p->nnz; }
+const void *spmspv_plan_bfs_rows(gl_spmspv_plan p) { return p->bfs_rows_plan; }
 const uint32_t *spmspv_plan_indptr(gl_spmspv_plan p) { return p->d_indptr; }
 uint32_t spmspv_plan_num_cols(gl_spmspv_plan p) { return p->num_cols; }
 uint32_t *spmspv_plan_bfs_acc(gl_spmspv_plan p) { return p->d_bfs_acc; }

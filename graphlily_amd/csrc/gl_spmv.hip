@@ -1475,6 +1475,8 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_z);
     (void)hipFree(p->d_partials);
     (void)hipFree(p->d_xbits);
+    (void)hipFree(p->d_csr_indptr);
+    (void)hipFree(p->d_csr_indices);
     delete p;
     return GL_OK;
 }
@@ -1587,12 +1589,14 @@ int gl_bfs_bits_pull_step(gl_spmv_plan p, gl_spmspv_plan csc, const uint32_t *d_
     c.threshold = threshold;
     c.back_threshold = back_threshold;
     c.heavy = gl::spmspv_heavy_work(csc);
+    c.nnz_rows = gl::spmspv_plan_nnz(csc);
+    c.bu_limit = (p->d_csr_indptr && gl::spmspv_plan_bfs_rows(csc) == p) ? gl::spmspv_bottom_up_limit(csc) : 0ull;
     // the new frontier's column lengths decide the direction of the NEXT slot's push: of no use to a schedule that never pushes
-    const bool only_pulls = threshold < 0.0f;   // BFS.pull: gl_bfs_bits_begin(first_pull_slot = 0), no push steps enqueued
+    const bool only_pulls = threshold < 0.0f;   // BFS.pull: gl_bfs_bits_begin(first_pull_slot = 0)
     const bool may_push = (may_continue & 2) != 0 && !only_pulls;
     return gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, gl::ctx().stream, nullptr, 0u, GL_GATE_EQ, nullptr, 0u, 0.0f, 0,
                                   &c, may_push ? gl::spmspv_plan_indptr(csc) : nullptr, gl::spmspv_plan_num_cols(csc),
-                                  only_pulls ? nullptr : gl::spmspv_plan_bfs_acc(csc));
+                                  gl::spmspv_plan_bfs_acc(csc));
 }
 
 int gl_spmv_plan_export(gl_spmv_plan p, int array, void *h_dst, size_t capacity, size_t *bytes) {

@@ -50,6 +50,7 @@ struct BoolArgs {
     const uint32_t *v2_indptr = nullptr;   // column pointers of the CSC plan of the same matrix
     uint32_t v2_ncols = 0;
     uint32_t *v2_push_acc = nullptr;       // totals of the slot's push step (64 lines of 32 words), when that one ran
+    const uint32_t *v2_rowptr = nullptr;   // row pointers of this plan's own CSR copy (row lengths: the bottom-up bookkeeping)
 };
 
 // x != 0 packed little-endian, 64 columns per wavefront step; words past num_cols are zero
@@ -93,23 +94,27 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     uint32_t *xw = lds_words + kBoolTileWords;      // kBoolPhaseWords
 
     if (a.run_flag && load_const(a.run_flag) == 0u) return;
-    if (a.v2.ctl && a.v2.pushes() && !a.v2.row_wise()) {
-        // the slot's push step ran (it is enqueued in front of this launch): add up its totals and take its decisions.
-        // decide() does not change what pushes() / row_wise() say about THIS slot, so the other workgroups may look later.
+    if (a.v2.ctl && (a.v2.scatters() || a.v2.bottom_up())) {
+        // the slot's push step ran (it is enqueued in front of this launch) -- scattering, or as the bottom-up pull: add up
+        // its totals and take its decisions.  decide() does not change what scatters() / bottom_up() say about THIS slot,
+        // so the other workgroups may look later.
         if (blockIdx.x == 0 && threadIdx.x < 64u) {
             uint32_t *line = a.v2_push_acc + 32u * threadIdx.x;
             uint32_t fresh = line[0];
             unsigned long long work = *reinterpret_cast<unsigned long long *>(line + 2);
+            unsigned long long work_rows = *reinterpret_cast<unsigned long long *>(line + 6);
             if (fresh) {
                 line[0] = 0u;
                 *reinterpret_cast<unsigned long long *>(line + 2) = 0ull;
+                *reinterpret_cast<unsigned long long *>(line + 6) = 0ull;
             }
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) {
                 fresh += __shfl_down(fresh, d);
                 work += __shfl_down(work, d);
+                work_rows += __shfl_down(work_rows, d);
             }
-            if (threadIdx.x == 0) a.v2.decide(fresh, work);
+            if (threadIdx.x == 0) a.v2.decide(fresh, work, work_rows);
         }
         return;
     }
@@ -220,6 +225,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         // Blocks of boolean plans start on multiples of 64 rows, so every word has exactly one writer.
         uint32_t nfresh = 0;   // lane 0 of every wavefront: rows this wavefront put into the next frontier
         uint32_t work = 0u;    // v2: column lengths of this lane's fresh rows (a lane sees <= 15 rows: no overflow below 2^28 each)
+        uint32_t work_rows = 0u;   // ... and their row lengths
         // Four row groups per step, every load of a stage issued before the first use: a row is three dependent round trips
         // (distance, then -- bit-frontier schedule only -- its two column pointers), and one at a time they made the epilogue
         // a sixth of the launch.  No two threads touch the same row, so the stores of a step cannot feed its loads.
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                 hit[u] = i < nrows && ((tile[i >> 5] >> (i & 31u)) & 1u);
                 dv[u] = hit[u] ? a.dist[row0 + i] : 1.0f;
             }
-            uint32_t p0[E], p1[E];
+            uint32_t p0[E], p1[E], r0[E], r1[E];
 #pragma unroll
             for (int u = 0; u < E; u++) {
                 const uint32_t row = row0 + i0 + u * kThreads + lane;
@@ -241,6 +247,9 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                 const bool want = hit[u] && a.v2_indptr != nullptr && row < a.v2_ncols;
                 p0[u] = want ? a.v2_indptr[row] : 0u;
                 p1[u] = want ? a.v2_indptr[row + 1u] : 0u;
+                const bool wantr = hit[u] && a.v2_rowptr != nullptr;
+                r0[u] = wantr ? a.v2_rowptr[row] : 0u;
+                r1[u] = wantr ? a.v2_rowptr[row + 1u] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < E; u++) {
@@ -251,23 +260,29 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                     if (lane == 0) reinterpret_cast<uint64_t *>(a.bits_out)[(row0 + g0) >> 6] = m;
                     nfresh += (uint32_t)__popcll(m);
                     work += p1[u] - p0[u];
+                    work_rows += r1[u] - r0[u];
                 }
             }
         }
-        if (a.v2.ctl && a.v2_push_acc) {     // (no accumulator lines: a schedule that only pulls, nothing to decide)
+        if (a.v2.ctl) {
             __shared__ uint32_t v2_fresh_s, v2_last_s;
-            __shared__ unsigned long long v2_work_s;
+            __shared__ unsigned long long v2_work_s, v2_rows_s;
             if (threadIdx.x == 0) {
                 v2_fresh_s = 0u;
                 v2_work_s = 0ull;
+                v2_rows_s = 0ull;
             }
             __syncthreads();
-            unsigned long long work64 = work;
+            unsigned long long work64 = work, rows64 = work_rows;
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) work64 += __shfl_down(work64, d);
+            for (int d = 32; d > 0; d >>= 1) {
+                work64 += __shfl_down(work64, d);
+                rows64 += __shfl_down(rows64, d);
+            }
             if (lane == 0 && nfresh) {
                 atomicAdd(&v2_fresh_s, nfresh);
                 atomicAdd(&v2_work_s, work64);
+                atomicAdd(&v2_rows_s, rows64);
             }
             __syncthreads();
             // Totals and "who is last" through the 64 accumulator lines of the push step (idle in a slot whose pull step
@@ -279,6 +294,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                 if (v2_fresh_s) {
                     atomicAdd(line, v2_fresh_s);
                     atomicAdd(reinterpret_cast<unsigned long long *>(line + 2), v2_work_s);
+                    if (v2_rows_s) atomicAdd(reinterpret_cast<unsigned long long *>(line + 6), v2_rows_s);
                 }
                 __threadfence();
                 bool last = atomicAdd(line + 4, 1u) == (gridDim.x - l + 63u) / 64u - 1u;   // last workgroup of this line
@@ -293,23 +309,26 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                 __threadfence();
                 const uint32_t nlines = min(gridDim.x, 64u);
                 uint32_t total = 0u;
-                unsigned long long wk = 0ull;
+                unsigned long long wk = 0ull, wr = 0ull;
                 if (threadIdx.x < nlines) {
                     uint32_t *ln = a.v2_push_acc + 32u * threadIdx.x;
                     total = __hip_atomic_load(ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     wk = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ln + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    wr = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ln + 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ln[0] = 0u;
                     *reinterpret_cast<unsigned long long *>(ln + 2) = 0ull;
+                    *reinterpret_cast<unsigned long long *>(ln + 6) = 0ull;
                     ln[4] = 0u;
                 }
 #pragma unroll
                 for (int d = 32; d > 0; d >>= 1) {
                     total += __shfl_down(total, d);
                     wk += __shfl_down(wk, d);
+                    wr += __shfl_down(wr, d);
                 }
                 if (threadIdx.x == 0) {
                     a.v2.ctl[6] = 0u;
-                    a.v2.decide(total, wk);
+                    a.v2.decide(total, wk, wr);
                 }
             }
         } else if (a.back_ctl) {
@@ -430,6 +449,7 @@ int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_o
         a.v2_indptr = v2_indptr;
         a.v2_ncols = v2_ncols;
         a.v2_push_acc = v2_push_acc;
+        a.v2_rowptr = p->d_csr_indptr;
     }
     a.tickets = bool_tickets();
     return launch_bool_variant<GL_NOMASK, 1>(p, a, s);
@@ -569,6 +589,10 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
         eb.num_cols = num_cols;
         uint32_t tallest = 0;
         if ((rc = fmt_emit_bool(staged.c, eb, p, &tallest)) != GL_OK) return rc;
+        if (row_begin == 0 && row_end == p->num_rows && env_long("GRAPHLILY_BFS_KEEP_ROWS", 1) != 0) {
+            if ((rc = devcsr_adopt_rows(staged.c, &p->d_csr_indptr, &p->d_csr_indices)) != GL_OK) return rc;
+            p->device_bytes += ((size_t)rows + 1u) * 4u + (size_t)p->nnz * 4u;
+        }
         p->boolean = true;
         p->nblocks = nblocks;
         p->segments = bp.Smax;
@@ -733,6 +757,15 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
     p->b_spans = spans.size() * sizeof(uint4);
     GL_HIP(hipMalloc((void **)&p->d_xbits, (size_t)nphases * kBoolPhaseWords * 4u));
     p->device_bytes += (size_t)nphases * kBoolPhaseWords * 4u;
+    if (row_begin == 0 && row_end == p->num_rows && env_long("GRAPHLILY_BFS_KEEP_ROWS", 1) != 0) {
+        // the rows as plain CSR for the bottom-up BFS step (see gl_spmv_plan.h); zero values -> column 0xffffffff
+        std::vector<uint32_t> cols(h_indices, h_indices + p->nnz);
+        for (uint64_t i = 0; i < p->nnz; i++)
+            if (h_data[i] == 0.0f) cols[i] = 0xffffffffu;
+        if ((rc = up((void **)&p->d_csr_indptr, h_indptr, ((size_t)rows + 1u) * 4u)) != GL_OK ||
+            (rc = up((void **)&p->d_csr_indices, cols.data(), cols.size() * 4u)) != GL_OK)
+            return rc;
+    }
     return GL_OK;
 }
 

@@ -123,6 +123,9 @@ struct gl_spmv_plan_s {
     uint32_t nphases = 0;
     uint4 *d_spans = nullptr;      // {first word of the phase in xbits, first group, end group, lo4 | hi4 << 16}
     uint32_t *d_xbits = nullptr;   // nphases * kBoolPhaseWords words
+    // whole-matrix boolean plans also keep the rows as plain CSR (4 B per non-zero more): gl_bfs_bits_push_step's bottom-up
+    // branch scans the rows a BFS has not reached yet; zero-valued entries carry the column 0xffffffff
+    uint32_t *d_csr_indptr = nullptr, *d_csr_indices = nullptr;
     uint64_t device_bytes = 0;
     size_t b_entries = 0, b_bases = 0, b_units = 0, b_hub_rows = 0, b_spans = 0;   // sizes of the formatted arrays (gl_spmv_plan_export)
 };
@@ -138,6 +141,8 @@ struct DevCsr;   // the shard's indptr / indices / data on the device
 int devcsr_stage(DevCsr **out, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
                  uint32_t row_begin, uint32_t row_end);
 void devcsr_release(DevCsr *c);
+// hand the staged rows over to a plan (the bottom-up BFS step reads them); zero-valued entries get column 0xffffffff
+int devcsr_adopt_rows(DevCsr *c, uint32_t **d_indptr, uint32_t **d_indices);
 bool format_on_device(uint32_t flags, uint64_t nnz);   // policy: GL_PLAN_HOST_FORMAT / GRAPHLILY_PLAN_DEVICE / size
 int fmt_column_degrees(DevCsr *c, uint32_t num_cols, std::vector<uint32_t> &deg, int *bad_col);
 int fmt_detect_pattern(DevCsr *c, uint32_t num_cols, std::vector<uint32_t> &colbits, std::vector<uint32_t> &diag_has,
@@ -194,6 +199,9 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
                      const uint32_t *run_flag);
 // gl_spmspv.hip: what the pull step of the bit-frontier BFS schedule (gl_bfs_bits_pull_step) needs from the CSC plan
 unsigned long long spmspv_heavy_work(gl_spmspv_plan p);
+unsigned long long spmspv_bottom_up_limit(gl_spmspv_plan p);
+unsigned long long spmspv_plan_nnz(gl_spmspv_plan p);
+const void *spmspv_plan_bfs_rows(gl_spmspv_plan p);   // the plan the slot's push step (enqueued first) can scan bottom-up
 const uint32_t *spmspv_plan_indptr(gl_spmspv_plan p);
 uint32_t spmspv_plan_num_cols(gl_spmspv_plan p);
 uint32_t *spmspv_plan_bfs_acc(gl_spmspv_plan p);   // 64 lines of 32 words: {new vertices, -, column lengths (64 bits)} of a push step

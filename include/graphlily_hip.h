@@ -302,13 +302,18 @@ int gl_bfs_pull_step_gated(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_
  *             s + 1, which therefore holds exactly the vertices at distance s + 1 when the schedule has run.
  *   gl_bfs_bits_begin       distance[i] = (i == source), vector 1 = {source}, the others and the control words cleared;
  *             ctl[0] = first_pull_slot: 0xffffffff for pull_push (push until the rule says otherwise), 0 for a BFS that
- *             pulls in every slot (app/bfs.h:106-126: then only the pull steps are enqueued, with threshold < 0 -- "this
- *             schedule never pushes": the steps skip the bookkeeping the decisions need).
+ *             pulls in every slot (app/bfs.h:106-126; the steps get threshold < 0 -- "this schedule never scatters"; the
+ *             push steps are still enqueued for their bottom-up role).
  *   gl_bfs_bits_push_step   SpMSpV (||,&&) masked WriteToZero by d_distance + AssignVectorSparse(level) with the next
  *             frontier's bit vector as the accumulator (no dense accumulator, no compaction): runs when slot `slot`
  *             pushes and its frontier is light; a frontier whose columns hold more than 1/32 of the non-zeros is left to
  *             the pull step of the same slot (the same rule as gl_spmspv_plan_attach_pull).  d_bits_out must be all zero on entry; d_bits_spare, if not NULL, is cleared
  *             (gate or not) -- for callers that rotate three vectors instead of keeping one per slot.
+ *             `rows` (may be NULL) = the whole-matrix GL_PLAN_BOOLEAN plan of the pull steps, which keeps the rows as plain
+ *             CSR: the launch then has a second role, the BOTTOM-UP pull -- when the slot does not scatter and the rows the
+ *             BFS has not reached yet hold less than a third of the non-zeros, a thread per unreached row looks through
+ *             the row until it finds a neighbour in the frontier (same result as the pull step, whose launch then only
+ *             does the bookkeeping); the last iterations of a BFS stop streaming the whole matrix.
  *   gl_bfs_bits_pull_step   gl_bfs_pull_step; runs when the slot pulls, or pushes a heavy frontier (row-wise: the same
  *             pass).  `csc` = the SpMSpV plan of the same matrix (column lengths: the next push's work).  It follows the push
  *             step of its slot also when that one ran: gated off, it adds up the push step's totals and decides for it.
@@ -319,7 +324,7 @@ int gl_bfs_pull_step_gated(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_
  * be captured once (gl_graph_*) and replayed for any source. */
 int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
                       uint32_t nvec, uint32_t first_pull_slot);
-int gl_bfs_bits_push_step(gl_spmspv_plan csc, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,
+int gl_bfs_bits_push_step(gl_spmspv_plan csc, gl_spmv_plan rows, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,
                           uint32_t bits_words, float *d_distance, float level, uint32_t *d_ctl, uint32_t slot, float threshold,
                           int may_continue);
 int gl_bfs_bits_pull_step(gl_spmv_plan plan, gl_spmspv_plan csc, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance,

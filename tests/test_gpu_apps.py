@@ -316,3 +316,37 @@ def test_bfs_bits_schedule_long_columns_and_heavy_frontiers(gpu, monkeypatch):
                     monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "0")
                     assert np.array_equal(bfs.pull_push(src, 7, thr), got)
                     assert bfs.push_iterations_ == pushes, "div %s thr %g src %d" % (div, thr, src)
+
+
+def test_bfs_bottom_up_with_an_unreachable_hub(gpu, monkeypatch):
+    """The bottom-up pull of the bit-frontier schedule (gl_bfs_bits_push_step with the pull plan's rows) visits only the
+    rows not reached yet.  A hub the BFS never reaches (a star of 30 000 leaves in another component) stays in that set for
+    the whole run: its row is finished by a whole wavefront, not by one thread.  pull, pull_push with the bottom-up step
+    forced on for every non-scattering slot (BU_DIV 1) and switched off (0) must give the oracle's distances."""
+    rng = np.random.default_rng(9)
+    n = 60000
+    r = [rng.integers(0, 30000, size=400000), np.full(30000, 30000)]
+    c = [rng.integers(0, 30000, size=400000), np.arange(30001, 60001) % n]
+    r, c = np.concatenate(r), np.concatenate(c)
+    r, c = np.concatenate([r, c]), np.concatenate([c, r])
+    key = np.unique(r.astype(np.int64) * n + c)
+    r, c = (key // n).astype(np.uint32), (key % n).astype(np.uint32)
+    indptr = np.zeros(n + 1, np.uint32)
+    np.add.at(indptr, r.astype(np.int64) + 1, 1)
+    indptr = np.cumsum(indptr).astype(np.uint32)
+    m = io.CSRMatrix(n, n, np.ones(len(c), np.float32), c, indptr)
+    om = _oracle_prepared(m, "bfs")
+    for div in ("3", "1", "0"):
+        monkeypatch.setenv("GRAPHLILY_BFS_BU_DIV", div)
+        bfs = app.BFS(M.num_hbm_channels, 0, 0, 0)
+        bfs.set_up_runtime()
+        bfs.load_and_format_matrix(m, True)
+        bfs.send_matrix_host_to_device()
+        assert bfs._bits_loop_ok()
+        for src in (0, 5, 30000, 30001):
+            ref = O.bfs(om, src, 8)
+            for rep in range(3):
+                assert np.array_equal(bfs.pull(src, 8), ref), "pull div %s src %d rep %d" % (div, src, rep)
+                assert np.array_equal(bfs.pull_push(src, 8, 0.01), ref), "pull_push div %s src %d rep %d" % (div, src, rep)
+    counts = bfs.bfs_slot_counts_
+    assert counts.shape[0] == 8
