@@ -487,8 +487,20 @@ class Graph:
 
     @classmethod
     def capture(cls):
+        # No garbage collection while the stream records: a collected plan or buffer of some earlier object is freed with
+        # hipFree, which is not allowed on a capturing thread and invalidates the capture (seen as "operation failed due to a
+        # previous error during capture" when a BFS schedule was recorded right after tests that had dropped many plans).
+        import gc
         g = cls()
-        check(lib().gl_graph_begin_capture())
+        g._gc_was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            check(lib().gl_graph_begin_capture())
+        except Exception:
+            if g._gc_was_enabled:
+                gc.enable()
+            raise
         return g
 
     def __enter__(self):
@@ -497,6 +509,9 @@ class Graph:
     def __exit__(self, exc_type, exc, tb):
         h = ctypes.c_void_p(0)
         rc = lib().gl_graph_end_capture(ctypes.byref(h))
+        if getattr(self, "_gc_was_enabled", False):
+            import gc
+            gc.enable()
         if exc_type is None:
             check(rc)
             self.handle = h.value

@@ -222,15 +222,30 @@ struct BfsBitsCtl {
 // evict the dense vector from L2
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 load_stream_nt(const uint2 *p) {
+#ifdef GL_STREAM_PLAIN   // A/B builds only (scripts/build_variant.sh): ordinary loads, so that small matrices may stay in the caches
+    return *p;
+#else
     u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t *>(p));
     return make_uint2(v.x, v.y);
+#endif
 }
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 load_stream_nt16(const uint4 *p) {
+#ifdef GL_STREAM_PLAIN
+    return *p;
+#else
     u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
+#endif
 }
+
+// the same loads WITHOUT the non-temporal hint, for matrices small enough to stay in the 256 MB Infinity Cache from one run
+// to the next (iterative algorithms stream the same matrix every iteration): same-box, the pokec stand-in's pattern
+// layout (155 MB) 0.059 -> 0.046 ms, the googleplus general layout (88 MB) 51 -> 57 % of the HBM peak -- and orkut (1.7 GB)
+// 70 -> 62 %, which is what the hint is for
+__device__ __forceinline__ uint2 load_stream_keep(const uint2 *p) { return *p; }
+__device__ __forceinline__ uint4 load_stream_keep16(const uint4 *p) { return *p; }
 
 // Plan metadata is read-only for the whole launch: loading it through the constant address space lets the
 // compiler keep wave-uniform loads on the scalar unit even though the span loop contains barriers

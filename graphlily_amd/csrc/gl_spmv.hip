@@ -264,7 +264,8 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
 //   QUAD   16 B: { A.index .. D.index }                  4 groups  (default pattern layout)
 // index = (col - group_base) << 14 | slot.  Pattern plans (every column's stored values are equal) fold the
 // value into z[c] = colval[c] (x) x[c] once per run (spmv_prescale_kernel) and gather z instead of x.
-enum { kLayNarrow = 0, kLayWide = 1, kLayPair = 2, kLayQuad = 3 };
+//   WIDE_KEEP / QUAD_KEEP: the same streams read without the non-temporal hint (plans that fit the Infinity Cache)
+enum { kLayNarrow = 0, kLayWide = 1, kLayPair = 2, kLayQuad = 3, kLayWideKeep = 4, kLayQuadKeep = 5 };
 
 template <int L>
 struct Lay;
@@ -311,6 +312,15 @@ struct Lay<kLayQuad> {
     __device__ static E pad() { return make_uint4(kRowPad, kRowPad, kRowPad, kRowPad); }
     __device__ static uint32_t key(const E &e, int k) { return k == 0 ? e.x : k == 1 ? e.y : k == 2 ? e.z : e.w; }
     __device__ static float val(const E &, int) { return 0.0f; }
+};
+
+template <>
+struct Lay<kLayWideKeep> : Lay<kLayWide> {
+    __device__ static E load(const void *s, size_t i) { return load_stream_keep16(static_cast<const uint4 *>(s) + i); }
+};
+template <>
+struct Lay<kLayQuadKeep> : Lay<kLayQuad> {
+    __device__ static E load(const void *s, size_t i) { return load_stream_keep16(static_cast<const uint4 *>(s) + i); }
 };
 
 // One slot's work: UC cold and UH hot stream elements (either may be 0).  Every load is unconditional -- indices clamp
@@ -630,7 +640,33 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     const bool timed = prof_take(pf);
     if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
     int rc;
-    if (p->pattern && p->wide) {
+    // float plans whose device arrays fit the Infinity Cache (256 MB) but not the L2s keep their stream cached between runs
+    // (same-box: googleplus general 88 MB 50.5 -> 57.6 %, pokec pattern 155 MB 0.059 -> 0.047 ms, ogbl-ppa pattern 173 MB
+    // 0.048 -> 0.046 ms; the 45 MB googleplus pattern plan lost 3 %: below 64 MB the hint stays)
+    static const size_t keep_bytes = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MB", 224) << 20;
+    static const size_t keep_min = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MIN_MB", 64) << 20;
+    const bool keep = OP < 3 && p->wide && p->device_bytes <= keep_bytes && p->device_bytes >= keep_min;
+    if (OP < 3 && keep && p->pattern) {
+        switch (p->mix) {
+            case 0: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayQuadKeep, 2, 0>(p, a, lds, s); break;
+            case 1: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayQuadKeep, 2, 1>(p, a, lds, s); break;
+            case 9: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayQuadKeep, 1, 2>(p, a, lds, s); break;
+            case 6: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayQuadKeep, 2, 2>(p, a, lds, s); break;
+            default: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayQuadKeep, 1, 1>(p, a, lds, s); break;
+        }
+    } else if (OP < 3 && keep) {
+        switch (p->mix) {
+            case 0: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 2, 0>(p, a, lds, s); break;
+            case 1: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 2, 1>(p, a, lds, s); break;
+            case 2: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 1, 1>(p, a, lds, s); break;
+            case 3: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 3, 1>(p, a, lds, s); break;
+            case 6: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 3, 2>(p, a, lds, s); break;
+            case 7: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 3, 3>(p, a, lds, s); break;
+            case 8: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 1, 2>(p, a, lds, s); break;
+            case 9: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 2, 3>(p, a, lds, s); break;
+            default: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 2, 2>(p, a, lds, s); break;
+        }
+    } else if (p->pattern && p->wide) {
         switch (p->mix) {   // cold quads, hot quads per iteration
             case 0: rc = launch_variant<OP, MASK, kLayQuad, 2, 0>(p, a, lds, s); break;
             case 1: rc = launch_variant<OP, MASK, kLayQuad, 2, 1>(p, a, lds, s); break;

@@ -74,19 +74,22 @@ constexpr int kBoolLane = kBoolGroup / 64;   // entries per lane and load
 struct BoolElem {   // one lane's share of a group
     uint32_t v[kBoolLane];
 };
+template <int KEEP>   // KEEP: no non-temporal hint -- plans that fit the Infinity Cache stay there between runs (gl_common.h)
 __device__ __forceinline__ BoolElem bool_load(const void *entries, size_t group, uint32_t lane) {
     BoolElem e;
     if (kBoolLane == 4) {
-        const uint4 t = load_stream_nt16(static_cast<const uint4 *>(entries) + group * 64u + lane);
+        const uint4 *q = static_cast<const uint4 *>(entries) + group * 64u + lane;
+        const uint4 t = KEEP ? load_stream_keep16(q) : load_stream_nt16(q);
         e.v[0] = t.x, e.v[1] = t.y, e.v[kBoolLane - 2] = t.z, e.v[kBoolLane - 1] = t.w;
     } else {
-        const uint2 t = load_stream_nt(static_cast<const uint2 *>(entries) + group * 64u + lane);
+        const uint2 *q = static_cast<const uint2 *>(entries) + group * 64u + lane;
+        const uint2 t = KEEP ? load_stream_keep(q) : load_stream_nt(q);
         e.v[0] = t.x, e.v[1] = t.y;
     }
     return e;
 }
 
-template <int MASK, int U, int FUSED>
+template <int MASK, int U, int FUSED, int KEEP = 0>
 __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
     // tile first: its byte offsets fit the 16-bit immediate of the LDS instructions either way
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         for (int u = 0; u < U; u++) {
             li[u] = wave + u * kWaves;
             const uint32_t gi = min(s.y + li[u], glast);
-            e[u] = bool_load(a.entries, gi, lane);
+            e[u] = bool_load<KEEP>(a.entries, gi, lane);
             b[u] = load_const(a.bases + gi);
             // keep slot order = issue order: if the scheduler reverses these loads, slot 0 becomes the youngest
             // and the loop header needs vmcnt(0), which empties the ring once per iteration
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                 for (int k = 0; k < kBoolStep; k++) {
                     li[u + k] = a.tickets ? t + k : li[u + k] + kWaves * U;
                     const uint32_t gn = min(s.y + li[u + k], glast);
-                    e[u + k] = bool_load(a.entries, gn, lane);
+                    e[u + k] = bool_load<KEEP>(a.entries, gn, lane);
                     b[u + k] = load_const(a.bases + gn);
                 }
             }
@@ -388,24 +391,35 @@ static uint32_t bool_tickets() {
 constexpr int kBoolUnroll = GL_BOOL_U;
 constexpr size_t kBoolLds = ((size_t)kBoolPhaseWords + kBoolTileWords) * 4u;
 
-template <int MASK, int FUSED>
-static int launch_bool_variant(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
+template <int MASK, int FUSED, int KEEP>
+static int launch_bool_keep(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
     static int attr_device = -1;   // the opt-in is per device (gl_init may switch devices)
     if (attr_device != ctx().device) {
-        GL_HIP(hipFuncSetAttribute((const void *)spmv_bool_kernel<MASK, kBoolUnroll, FUSED>,
+        GL_HIP(hipFuncSetAttribute((const void *)spmv_bool_kernel<MASK, kBoolUnroll, FUSED, KEEP>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBoolLds));
         attr_device = ctx().device;
     }
     Profiler &pf = prof();
     const bool timed = prof_take(pf);
     if (timed) GL_HIP(hipEventRecord(pf.events[2 * pf.used], s));
-    spmv_bool_kernel<MASK, kBoolUnroll, FUSED><<<p->nunits, kThreads, kBoolLds, s>>>(a);
+    spmv_bool_kernel<MASK, kBoolUnroll, FUSED, KEEP><<<p->nunits, kThreads, kBoolLds, s>>>(a);
     GL_LAUNCH_CHECK();
     if (timed) {
         GL_HIP(hipEventRecord(pf.events[2 * pf.used + 1], s));
         pf.used++;
     }
     return GL_OK;
+}
+
+template <int MASK, int FUSED>
+static int launch_bool_variant(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
+    static const size_t keep_bytes = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MB", 224) << 20;
+    static const size_t keep_min = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MIN_MB", 64) << 20;
+    // (the CSR copy for the bottom-up BFS step is not streamed by this kernel)
+    const size_t rows_bytes = p->d_csr_indptr ? ((size_t)(p->row_end - p->row_begin) + 1u) * 4u + (size_t)p->nnz * 4u : 0u;
+    const size_t streamed = p->device_bytes - std::min<size_t>(rows_bytes, p->device_bytes);
+    if (streamed <= keep_bytes && streamed >= keep_min) return launch_bool_keep<MASK, FUSED, 1>(p, a, s);
+    return launch_bool_keep<MASK, FUSED, 0>(p, a, s);
 }
 
 template <int MASK>
