@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void bfs_bits_begin_kernel(uint32_t *__restric
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
     for (uint32_t i = tid; i < n; i += stride) distance[i] = (i == src) ? 1.0f : 0.0f;      // app/bfs.h:168-171
     for (uint32_t w = tid; w < nvec * words; w += stride) bits[w] = (w == words + (src >> 5)) ? (1u << (src & 31u)) : 0u;
-    if (tid < ctl_words && tid != 2u) ctl[tid] = tid == 0u ? first_pull_slot : (tid == 4u ? 0xffffffffu : 0u);
+    if (tid < ctl_words && tid != 2u) ctl[tid] = tid == 0u ? first_pull_slot : (tid == 4u ? 0xffffffffu : (tid == 15u ? ctl_words : 0u));
 }
 
 // the set bits of a frontier bit vector as list candidates (gl_bfs_pull_step_back): entry {row, 1}

@@ -197,7 +197,7 @@ struct BfsBitsCtl {
     // called once per slot, when the step that ran is complete, with the step's totals: vertices reached, non-zeros in
     // their columns (what a push from them scatters) and in their rows (what a pull no longer has to look at)
     __device__ void decide(uint32_t fresh, unsigned long long work, unsigned long long work_rows) const {
-        ctl[16u + slot] = fresh;       // the slot's new-frontier size, for the host
+        if (16u + slot < ctl[15]) ctl[16u + slot] = fresh;   // the slot's new-frontier size, for the host (ctl[15] = words of ctl)
         unsigned long long *visited = reinterpret_cast<unsigned long long *>(ctl + 12);
         const unsigned long long vis = *visited + work_rows;
         *visited = vis;

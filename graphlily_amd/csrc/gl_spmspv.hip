@@ -59,6 +59,8 @@ struct gl_spmspv_plan_s {
     // step tests the frontier bit of each chunk's column instead of queueing chunks at run time (no second launch)
     uint4 *d_long_chunks = nullptr;
     uint32_t n_long_chunks = 0;
+    // gl_spmspv_plan_hint_tiny (one-shot): the caller expects the next run's vector to be tiny -- then the run is ONE launch
+    bool tiny_hint = false;
     const void *bfs_rows_plan = nullptr;   // the SpMV plan whose rows the last gl_bfs_bits_push_step could scan bottom-up (or null)
     uint32_t *d_bfs_acc = nullptr;   // kBfsAccSlots x 32 words: the push step's totals, spread over 64 lines (see bfs_push_bits_kernel)
     uint64_t device_bytes = 0;
@@ -598,6 +600,289 @@ struct AccSource {
     }
 };
 
+// ------------------------------------------------------------------ tiny runs: one launch (gl_spmspv_plan_hint_tiny)
+// A run whose vector holds <= kTinyVec entries with <= kTinyWork non-zeros in their columns (1024 / 2048: what one compute
+// unit gets through in a few microseconds -- with 8192 a run took longer than the four launches) is done by ONE workgroup:
+// scatter with atomics that return the old value -- the first product to reach a row (old == fill) appends the row to an LDS
+// list --, sort the list, and emit it in ascending row order through the same AccSource as the compaction passes (mask, assign,
+// next-frontier bits, accumulator reset).  The four dependent launches of the general path (scatter, queue, count, write) cost
+// ~50 us per blocking call whatever the vector holds; this one ~20.  The kernel checks the two bounds itself on the vector it
+// actually finds: a vector that is not tiny after all is still computed correctly, by the same workgroup, slowly (a dense
+// pass over the shard's rows) -- the hint is about speed, never about results.
+constexpr uint32_t kTinyVec = 1024, kTinyWork = 2048, kTinyThreads = 1024;
+
+struct TinyArgs {
+    const uint32_t *indptr;
+    const uint2 *stream;
+    const gl_idx_val *vec;
+    float *acc;
+    uint32_t row_begin, nrows, num_cols;
+    gl_idx_val *out;
+    float head_val;
+    uint32_t zero_bits;
+    uint32_t *next_bits;     // (also in the source functor) cleared here over the shard's rows before the emission ORs into it
+};
+
+__device__ __forceinline__ uint32_t atomic_min_float_old(float *addr, float v) {
+    if (!(__float_as_uint(v) >> 31)) return (uint32_t)atomicMin((int *)addr, __float_as_int(v));
+    return atomicMax((unsigned int *)addr, __float_as_uint(v));
+}
+
+// scatter one product; true when this was the first product to reach the row (the atomic saw the fill value)
+template <int OP>
+__device__ __forceinline__ bool tiny_scatter(float *acc, uint32_t row, float a, float xv, uint32_t zero_bits) {
+    if (OP == GL_OP_MULADD) return __float_as_uint(unsafeAtomicAdd(&acc[row], a * xv)) == zero_bits;
+    if (OP == GL_OP_ANDOR) {
+        if (a == 0.0f || xv == 0.0f) return false;
+        return atomicExch(reinterpret_cast<unsigned int *>(&acc[row]), __float_as_uint(1.0f)) == zero_bits;
+    }
+    float incr;   // the saturating add of the (min,+) PE, as in scatter_one
+    if (a > kFloatInf || xv > kFloatInf) {
+        incr = kFloatInf;
+    } else {
+        incr = a + xv;
+        if (incr > kFloatInf) incr = kFloatInf;
+    }
+    return atomic_min_float_old(&acc[row], incr) == zero_bits;
+}
+
+// exclusive prefix of v over the 1024 threads of the block, total in *total (s_wave: 16 words)
+__device__ __forceinline__ uint32_t block_exclusive_1024(uint32_t v, uint32_t *s_wave, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
+        uint32_t up = __shfl_up(incl, dlt);
+        if (lane >= dlt) incl += up;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t c = s_wave[k];
+        if (k < w) before += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return before + incl - v;
+}
+
+template <int OP, typename Src>
+__global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, Src src, Gate gate, Direction dir) {
+    __shared__ uint32_t s_start[kTinyVec];
+    __shared__ uint32_t s_pref[kTinyVec + 1];
+    __shared__ float s_val[kTinyVec];
+    __shared__ __attribute__((aligned(16))) uint32_t s_key[kTinyWork + 4];
+    __shared__ uint32_t s_tmp[2048];
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_cnt;
+    if (gate.closed()) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t vnnz = a.vec[0].index;
+    if (a.next_bits) {
+        for (uint32_t w = tid; w < (a.nrows + 31u) / 32u; w += kTinyThreads) a.next_bits[(a.row_begin >> 5) + w] = 0u;
+        __threadfence();
+    }
+    if (tid == 0) s_cnt = 0u;
+
+    // ---- the vector's columns and the exclusive prefix of their lengths (first kTinyVec entries)
+    uint32_t start = 0, deg = 0;
+    float xv = 0.0f;
+    if (tid < vnnz) {
+        const gl_idx_val iv = a.vec[1u + tid];
+        if (iv.index < a.num_cols) {
+            start = a.indptr[iv.index];
+            deg = a.indptr[iv.index + 1u] - start;
+            xv = iv.val;
+        }
+    }
+    uint32_t work;
+    const uint32_t pre = block_exclusive_1024(deg, s_wave, &work);
+    s_start[tid] = start;
+    s_pref[tid] = pre;
+    s_val[tid] = xv;
+    if (tid == kTinyThreads - 1u) s_pref[kTinyVec] = work;
+    __syncthreads();
+
+    if (vnnz > kTinyVec || work > kTinyWork) {
+        // ---- not tiny after all (a stale hint): everything by this one workgroup, slowly but correctly.  Scatter batch
+        // by batch, then an ordered dense pass over the shard's rows.
+        for (uint32_t b0 = 0; b0 < vnnz; b0 += kTinyThreads) {
+            __syncthreads();
+            uint32_t st = 0, dg = 0;
+            float x = 0.0f;
+            if (b0 + tid < vnnz) {
+                const gl_idx_val iv = a.vec[1u + b0 + tid];
+                if (iv.index < a.num_cols) {
+                    st = a.indptr[iv.index];
+                    dg = a.indptr[iv.index + 1u] - st;
+                    x = iv.val;
+                }
+            }
+            uint32_t wk;
+            const uint32_t pr = block_exclusive_1024(dg, s_wave, &wk);
+            s_start[tid] = st;
+            s_pref[tid] = pr;
+            s_val[tid] = x;
+            if (tid == kTinyThreads - 1u) s_pref[kTinyVec] = wk;
+            __syncthreads();
+            for (uint32_t item = tid; item < wk; item += kTinyThreads) {
+                uint32_t lo = 0, hi = kTinyVec - 1u;   // largest j with s_pref[j] <= item
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1u) >> 1;
+                    if (s_pref[mid] <= item) lo = mid; else hi = mid - 1u;
+                }
+                const uint2 rv = load_stream_nt(a.stream + s_start[lo] + (item - s_pref[lo]));
+                (void)tiny_scatter<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), s_val[lo], a.zero_bits);
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        uint32_t pos = 0;
+        for (uint32_t base = 0; base < a.nrows; base += kTinyThreads) {
+            const uint32_t i = base + tid;
+            gl_idx_val item;
+            bool keep = false;
+            if (i < a.nrows) {
+                keep = src.get(i, item);
+                src.consumed(i);
+            }
+            uint32_t tot;
+            const uint32_t rank = block_exclusive_1024(keep ? 1u : 0u, s_wave, &tot);
+            if (keep) {
+                a.out[1u + pos + rank] = item;
+                src.emitted(item);
+            }
+            pos += tot;
+        }
+        if (tid == 0) {
+            a.out[0].index = pos;
+            a.out[0].val = a.head_val;
+            dir.decide(pos);
+        }
+        return;
+    }
+
+    // ---- scatter; rows reached for the first time go to the candidate list.  work <= 2 * kTinyThreads: a thread has at most
+    // two products, whose stream loads and atomics are issued together (each is two dependent round trips)
+    {
+        uint2 rv[2];
+        float xs[2];
+        bool has[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t item = tid + u * kTinyThreads;
+            has[u] = item < work;
+            uint32_t lo = 0, hi = kTinyVec - 1u;   // largest j with s_pref[j] <= item (zero-length columns share a prefix:
+            while (lo < hi) {                      // the largest such j is the one that owns the item)
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (s_pref[mid] <= item) lo = mid; else hi = mid - 1u;
+            }
+            xs[u] = s_val[lo];
+            rv[u] = has[u] ? load_stream_nt(a.stream + s_start[lo] + (item - s_pref[lo])) : make_uint2(0u, 0u);
+        }
+        bool first[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            first[u] = has[u] && tiny_scatter<OP>(a.acc, rv[u].x - a.row_begin, __uint_as_float(rv[u].y), xs[u], a.zero_bits);
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (first[u]) s_key[atomicAdd(&s_cnt, 1u)] = rv[u].x - a.row_begin;
+    }
+    __syncthreads();
+    const uint32_t C = s_cnt;
+
+    // ---- ascending rows.  Short lists by rank (a thread counts the keys in front of its own: C^2 compares, ~5 us at 512 on
+    // the one compute unit this kernel has), longer ones by a bitonic network in LDS (~10 us at 2048)
+    if (C <= 512u) {
+        for (uint32_t i = C + tid; i < ((C + 3u) & ~3u); i += kTinyThreads) s_key[i] = 0xffffffffu;
+        __syncthreads();
+        if (tid < C) {     // (wavefronts without a key skip the loop)
+            const uint32_t k = s_key[tid];
+            uint32_t r = 0;
+            const uint4 *keys4 = reinterpret_cast<const uint4 *>(s_key);
+#pragma unroll 4
+            for (uint32_t j4 = 0; j4 < (C + 3u) / 4u; j4++) {
+                const uint4 q = keys4[j4];
+                const uint32_t j = 4u * j4;
+                r += (q.x < k || (q.x == k && j < tid)) ? 1u : 0u;
+                r += (q.y < k || (q.y == k && j + 1u < tid)) ? 1u : 0u;
+                r += (q.z < k || (q.z == k && j + 2u < tid)) ? 1u : 0u;
+                r += (q.w < k || (q.w == k && j + 3u < tid)) ? 1u : 0u;
+            }
+            s_tmp[r] = k;
+        }
+        __syncthreads();
+        if (tid < C) s_key[tid] = s_tmp[tid];
+        __syncthreads();
+    } else {
+        const uint32_t P = C <= 1024u ? 1024u : 2048u;
+        for (uint32_t i = C + tid; i < P; i += kTinyThreads) s_key[i] = 0xffffffffu;
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                if (tid < (P >> 1)) {
+                    const uint32_t i = ((tid & ~(j - 1u)) << 1) | (tid & (j - 1u)), l = i | j;
+                    const uint32_t x = s_key[i], y = s_key[l];
+                    if ((x > y) == ((i & k) == 0u)) {
+                        s_key[i] = y;
+                        s_key[l] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- emission in row order: duplicates (a row that went back to the fill value and was reached again) are neighbours
+    uint32_t pos = 0;
+    for (uint32_t base = 0; base < C; base += kTinyThreads) {
+        const uint32_t idx = base + tid;
+        gl_idx_val item;
+        bool keep = false;
+        if (idx < C) {
+            const uint32_t i = s_key[idx];
+            if (idx == 0u || s_key[idx - 1u] != i) {
+                keep = src.get(i, item);
+                src.consumed(i);
+            }
+        }
+        uint32_t tot;
+        const uint32_t rank = block_exclusive_1024(keep ? 1u : 0u, s_wave, &tot);
+        if (keep) {
+            a.out[1u + pos + rank] = item;
+            src.emitted(item);
+        }
+        pos += tot;
+    }
+    if (tid == 0) {
+        a.out[0].index = pos;
+        a.out[0].val = a.head_val;
+        dir.decide(pos);
+    }
+}
+
+template <int OP, int MASK>
+static int launch_tiny(const TinyArgs &a, const float *mask, float zero, float *inout, float val, uint32_t *next_bits, Gate gate,
+                       Direction dir, hipStream_t s) {
+    AccSource<MASK> src{a.acc, mask, a.nrows, a.row_begin, zero, inout, val, next_bits};
+    spmspv_tiny_kernel<OP, AccSource<MASK>><<<1, kTinyThreads, 0, s>>>(a, src, gate, dir);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+template <int OP>
+static int launch_tiny_mask(int mask_type, const TinyArgs &a, const float *mask, float zero, float *inout, float val,
+                            uint32_t *next_bits, Gate gate, Direction dir, hipStream_t s) {
+    switch (mask_type) {
+        case GL_NOMASK: return launch_tiny<OP, GL_NOMASK>(a, mask, zero, inout, val, next_bits, gate, dir, s);
+        case GL_MASK_WRITETOZERO: return launch_tiny<OP, GL_MASK_WRITETOZERO>(a, mask, zero, inout, val, next_bits, gate, dir, s);
+        default: return launch_tiny<OP, GL_MASK_WRITETOONE>(a, mask, zero, inout, val, next_bits, gate, dir, s);
+    }
+}
+
 template <int OP>
 static int launch_scatter(const ScatterArgs &a, uint32_t grid, hipStream_t s) {
     spmspv_scatter_kernel<OP><<<grid, 256, 0, s>>>(a);
@@ -803,6 +1088,32 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
         p->acc_valid = true;
     }
 
+    // a caller that expects a tiny vector (gl_spmspv_plan_hint_tiny): the whole run is one launch of one workgroup
+    const bool tiny = p->tiny_hint && val_type == GL_VAL_FLOAT && nrows > 0 && gl::env_long("GRAPHLILY_SPMSPV_TINY", 1) != 0;
+    p->tiny_hint = false;
+    if (tiny) {
+        p->frontier_hint = ~0ull;
+        p->frontier_bits = nullptr;
+        p->last_decided_on_device = false;
+        gl::TinyArgs t;
+        t.indptr = p->d_indptr;
+        t.stream = p->d_stream;
+        t.vec = d_vector;
+        t.acc = p->d_acc;
+        t.row_begin = p->row_begin;
+        t.nrows = nrows;
+        t.num_cols = p->num_cols;
+        t.out = d_result;
+        t.head_val = zero;
+        t.zero_bits = __builtin_bit_cast(uint32_t, zero);
+        t.next_bits = d_next_bits;
+        switch (op) {
+            case GL_OP_MULADD: return gl::launch_tiny_mask<GL_OP_MULADD>(mask_type, t, d_mask, zero, d_inout, val, d_next_bits, gate, dir, s);
+            case GL_OP_ANDOR: return gl::launch_tiny_mask<GL_OP_ANDOR>(mask_type, t, d_mask, zero, d_inout, val, d_next_bits, gate, dir, s);
+            default: return gl::launch_tiny_mask<GL_OP_ADDMIN>(mask_type, t, d_mask, zero, d_inout, val, d_next_bits, gate, dir, s);
+        }
+    }
+
     // (||,&&) with an attached boolean SpMV plan: decide on the device which way this run goes
     const long div = gl::env_long("GRAPHLILY_SPMSPV_PULL_DIV", 32);
     const uint64_t threshold = div > 0 ? p->nnz / (uint64_t)div : 0ull;
@@ -948,6 +1259,12 @@ int gl_spmspv_plan_frontier_bits(gl_spmspv_plan p, const uint32_t *d_bits) {
     return GL_OK;
 }
 
+int gl_spmspv_plan_hint_tiny(gl_spmspv_plan p, uint32_t vector_nnz, uint64_t work) {
+    GL_ARG(p != nullptr);
+    p->tiny_hint = vector_nnz <= gl::kTinyVec && work <= gl::kTinyWork;
+    return GL_OK;
+}
+
 int gl_spmspv_plan_hint(gl_spmspv_plan p, uint32_t vector_nnz_upper_bound) {
     GL_ARG(p != nullptr);
     p->frontier_hint = vector_nnz_upper_bound;
@@ -975,6 +1292,8 @@ int gl_bfs_bits_push_step(gl_spmspv_plan p, gl_spmv_plan rows, const uint32_t *d
     GL_ARG(d_distance != nullptr && d_ctl != nullptr && slot >= 1u && ((uintptr_t)d_ctl & 7u) == 0);
     GL_ARG(d_bits_in != d_bits_out && d_bits_in != d_bits_spare && d_bits_out != d_bits_spare);
     GL_ARG((uint64_t)bits_words * 32u >= p->num_cols && (uint64_t)bits_words * 32u >= p->num_rows);
+    // the bottom-up branch writes the next frontier as whole 64-bit words
+    GL_ARG((bits_words & 1u) == 0 && (((uintptr_t)d_bits_in | (uintptr_t)d_bits_out) & 7u) == 0);
     if (p->row_begin != 0 || p->row_end != p->num_rows)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_push_step: row shards decide on the host (their frontier counts are partial)");
     gl::BfsPushArgs a;

@@ -67,6 +67,11 @@ def convert_sparse_vec_to_dense_vec(sparse_vector, rng, zero):
 
 
 class BaseModule:
+    # Counts the module calls that write device memory (any module's run / send_* / copy).  An SpMSpVModule remembers the
+    # value right after it uploaded a tiny vector; while nothing else has written since, its runs tell the library that
+    # the vector is still that tiny one (gl_spmspv_plan_hint_tiny: one launch instead of four).
+    device_writes_ = 0
+
     def __init__(self, kernel_name="overlay"):
         self.kernel_name_ = kernel_name
         self.target_ = "hw"
@@ -88,10 +93,12 @@ class BaseModule:
         capi.init(self.device_)
 
     def copy_buffer_device_to_device(self, src, dst, nbytes):
+        BaseModule.device_writes_ += 1
         capi.copy_d2d(dst, src, nbytes)
         capi.sync()
 
     def _finish(self):
+        BaseModule.device_writes_ += 1       # every run / send_* of every module ends here
         if self.blocking:
             capi.sync()
 
@@ -328,9 +335,19 @@ class SpMSpVModule(BaseModule):
         """The vector may be shorter than num_cols + 1; the device copy is always that long
         (spmspv_module.h:280, :379)."""
         vector = np.ascontiguousarray(vector, dtype=IDX_VAL)
-        self.hint_vector_nnz(int(vector["index"][0]) if vector.shape[0] else 0)
+        cnt = int(vector["index"][0]) if vector.shape[0] else 0
+        self.hint_vector_nnz(cnt)
         self.vector_buf = capi.DeviceBuffer(8 * (self.get_num_cols() + 1))
         self.vector_buf.write(vector[:self.get_num_cols() + 1])
+        # a tiny vector: remember its size and the non-zeros of its columns (the host holds the CSC), see run()
+        self.tiny_ = None
+        BaseModule.device_writes_ += 1
+        if 0 < cnt <= 1024 and cnt < vector.shape[0] and self.csc_matrix_ is not None:   # (a row shard holds no more than this)
+            cols = vector["index"][1:1 + cnt].astype(np.int64)
+            cols = cols[cols < self.get_num_cols()]
+            ip = self.csc_matrix_.adj_indptr
+            work = int(ip[cols + 1].astype(np.int64).sum() - ip[cols].astype(np.int64).sum())
+            self.tiny_ = (cnt, work, BaseModule.device_writes_)
 
     def send_mask_host_to_device(self, mask):
         mask = np.ascontiguousarray(mask, dtype=np.float32)
@@ -342,12 +359,25 @@ class SpMSpVModule(BaseModule):
 
     def bind_vector_buf(self, src_buf):
         self.vector_buf = src_buf
+        self.tiny_ = None
+
+    def _hint_tiny(self):
+        """Before a run: is the vector still the tiny one this module uploaded (no module call has written since)?"""
+        t = getattr(self, "tiny_", None)
+        if t is not None and t[2] == BaseModule.device_writes_:
+            self.plan_.hint_tiny(t[0], t[1])
+            return True
+        self.tiny_ = None
+        return False
 
     def run(self):
         mask = self.mask_buf if self.mask_type_ != kNoMask else None
+        tiny = self._hint_tiny()
         self.plan_.run(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
                        self.mask_type_)
         self._finish()
+        if tiny:      # this run wrote the results and the accumulator, not the vector
+            self.tiny_ = (self.tiny_[0], self.tiny_[1], BaseModule.device_writes_)
 
     def run_assign(self, inout_buf, val):
         """Extension (gl_spmspv_run_assign): run() followed by AssignVectorSparseModule.run(val) with the results as
@@ -362,6 +392,7 @@ class SpMSpVModule(BaseModule):
         """Extension (gl_spmspv_run_gated): run_assign on explicit vector / result buffers under a device-side launch
         predicate; leaves the emitted rows as bits in `next_bits` and, with `ctl`, takes the push -> pull decision."""
         mask = self.mask_buf if self.mask_type_ != kNoMask else None
+        BaseModule.device_writes_ += 1
         self.plan_.run_gated(vector_buf, mask, results_buf, self.semiring_.op, self.semiring_.zero, self.mask_type_,
                              inout_buf, val, next_bits, gate, gate_value, gate_op, ctl, slot, threshold, may_continue)
 

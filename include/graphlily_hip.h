@@ -295,10 +295,10 @@ int gl_bfs_pull_step_gated(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_
  * GPU): the frontier lives as BITS only and an iteration slot is TWO launches.
  *   d_ctl     ctl_words >= 17 + slots words, 8-byte aligned: [0] first pull slot (0xffffffff while pushing), [1] push
  *             iterations of the first push phase (the reference's count), [2] source vertex (written by the host before
- *             the schedule), [3] pushes after a pull step handed the loop back, [4] the slot that handed back, [5..15]
- *             internal, [16 + s] the number of vertices slot s reached.
+ *             the schedule), [3] pushes after a pull step handed the loop back, [4] the slot that handed back, [5..14]
+ *             internal, [15] ctl_words, [16 + s] the number of vertices slot s reached (slots beyond ctl_words are not recorded).
  *   d_bits    nvec >= slots + 2 bit vectors of bits_words words each, contiguous, 16-byte aligned (bits_words a multiple of
- *             4, at least gl_spmv_plan_bits_words of the pull plan): slot s (1, 2, ...) reads vector s and writes vector
+ *             4 -- the steps write whole 64-bit words --, at least gl_spmv_plan_bits_words of the pull plan): slot s (1, 2, ...) reads vector s and writes vector
  *             s + 1, which therefore holds exactly the vertices at distance s + 1 when the schedule has run.
  *   gl_bfs_bits_begin       distance[i] = (i == source), vector 1 = {source}, the others and the control words cleared;
  *             ctl[0] = first_pull_slot: 0xffffffff for pull_push (push until the rule says otherwise), 0 for a BFS that
@@ -344,6 +344,12 @@ int gl_spmspv_plan_attach_pull(gl_spmspv_plan plan, gl_spmv_plan pull);
  * the previous iteration's gl_sparse_nnz).  Frontiers too small to reach the threshold whatever their columns
  * are then skip the decision kernels.  One-shot: consumed by the next gl_spmspv_run. */
 int gl_spmspv_plan_hint(gl_spmspv_plan plan, uint32_t vector_nnz_upper_bound);
+/* One-shot: the caller expects the NEXT run's vector to hold vector_nnz entries whose columns hold `work` non-zeros in total
+ * (a module that has just uploaded the vector from the host knows both).  Up to 1024 entries and 2048 non-zeros the run is
+ * then ONE launch of one workgroup (scatter, sort of the rows reached, ordered emission) instead of four dependent ones:
+ * ~30 us per blocking call instead of ~55.  Results never depend on the hint: the kernel checks both bounds on the vector it
+ * finds and computes a bigger one correctly (slowly, alone). */
+int gl_spmspv_plan_hint_tiny(gl_spmspv_plan plan, uint32_t vector_nnz, uint64_t work);
 /* One-shot like the hint: the vector of the NEXT gl_spmspv_run* call is also available as a bit vector (bit c set iff
  * column c is in the vector; gl_spmv_plan_bits_words words of the attached GL_PLAN_BOOLEAN plan, 16-byte aligned, bits past
  * the columns zero).  A run that goes row-wise on that plan then reads it directly instead of clearing and filling the

@@ -367,3 +367,63 @@ def test_many_long_columns_fill_the_chunk_queue(gpu, sem):
     mod.run()
     got3 = M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), n, zero)
     assert_parity(got3, O.spmspv(to_oracle(csc), v, op, zero, mask, O.NOMASK), op, "run after overflow " + sem)
+
+
+@pytest.mark.parametrize("sem", list(SEMIRINGS))
+@pytest.mark.parametrize("mask_name", list(MASKS))
+def test_tiny_runs_are_one_launch_with_the_same_result(gpu, sem, mask_name, monkeypatch):
+    """gl_spmspv_plan_hint_tiny: a module that has just uploaded a vector of <= 1024 entries whose columns hold <= 2048
+    non-zeros runs it as ONE launch (scatter with first-touch detection, sort of the rows reached, ordered emission).  The
+    result list must be the general path's, entry for entry ((+,x): same rows, values within the float tolerance -- atomics
+    add in arrival order either way), and the oracle's; repeated runs keep the hint, another module's write drops it."""
+    from graphlily_amd import capi
+    csc = _csc("rmat_20K")
+    op, zero = SEMIRINGS[sem]
+    coldeg = np.diff(csc.adj_indptr.astype(np.int64))
+    rng = np.random.default_rng(3)
+    order = np.argsort(coldeg)
+    light = order[coldeg[order] > 0][:4000]                      # short columns: many entries stay tiny
+    picks = {"one": light[:1], "ten": light[5:15], "many": np.sort(rng.choice(light, 900, replace=False)),
+             "hub": np.array([order[-1]]),                         # one long column: > 2048 non-zeros -> general path
+             "dups": np.array([light[3], light[3], light[7]])}     # a column named twice
+    mask = rand01(csc.num_rows, 11)
+    for name, cols in picks.items():
+        vals = (rng.integers(1, 10, size=len(cols)) / 10.0).astype(np.float32)
+        v = M.make_sparse_vec(cols.astype(np.uint32), vals)
+        out = {}
+        for tiny in ("1", "0"):
+            monkeypatch.setenv("GRAPHLILY_SPMSPV_TINY", tiny)
+            got, mod = _run(gpu, csc, sem, mask_name, v, mask)
+            res1 = mod.send_results_device_to_host()
+            mod.run()                                             # the hint survives the module's own runs
+            res2 = mod.send_results_device_to_host()
+            n1 = int(res1["index"][0])
+            assert n1 == int(res2["index"][0]) and np.array_equal(res1["index"][1:n1 + 1], res2["index"][1:n1 + 1])
+            out[tiny] = (got, res1, n1)
+            work = int(coldeg[cols].sum())
+            assert (mod.tiny_ is not None) == (len(cols) <= 1024), name
+            if tiny == "1" and name == "ten":
+                assert work <= 2048
+        (g1, r1, n1), (g0, r0, n0) = out["1"], out["0"]
+        assert n1 == n0 and np.array_equal(r1["index"][1:n1 + 1], r0["index"][1:n0 + 1]), "%s: rows differ" % name
+        if op == 0:
+            assert np.allclose(r1["val"][1:n1 + 1], r0["val"][1:n0 + 1], rtol=1e-5, atol=0)
+        else:
+            assert np.array_equal(r1["val"][1:n1 + 1], r0["val"][1:n0 + 1]), "%s: values differ" % name
+        ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS[mask_name])
+        assert_parity(g1, ref, op, "tiny %s/%s/%s" % (sem, mask_name, name))
+    # a stale hint: the plan is told "tiny", the vector is not -- the one workgroup still computes it (slowly)
+    monkeypatch.setenv("GRAPHLILY_SPMSPV_TINY", "1")
+    cols = np.sort(rng.choice(order[coldeg[order] > 0], 3000, replace=False))
+    v = M.make_sparse_vec(cols.astype(np.uint32), np.full(len(cols), 0.5, np.float32))
+    got, mod = _run(gpu, csc, sem, mask_name, v, mask)            # general path (3000 entries: no hint from the module)
+    ref_res = mod.send_results_device_to_host()
+    mod.plan_.hint_tiny(10, 100)
+    mod.run()
+    res = mod.send_results_device_to_host()
+    n = int(res["index"][0])
+    assert n == int(ref_res["index"][0]) and np.array_equal(res["index"][1:n + 1], ref_res["index"][1:n + 1])
+    if op == 0:
+        assert np.allclose(res["val"][1:n + 1], ref_res["val"][1:n + 1], rtol=1e-5, atol=0)
+    else:
+        assert np.array_equal(res["val"][1:n + 1], ref_res["val"][1:n + 1])
