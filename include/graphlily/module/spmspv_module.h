@@ -93,6 +93,17 @@ public:
         const size_t used = std::min(std::min(vector.size(), slots), (size_t)vector[0].index + 1);
         vector_buf.upload(vector.data(), sizeof(idx_val_t) * used);
         hint_vector_nnz((uint32_t)vector[0].index);
+        // a tiny vector (the host holds the CSC: entry count and the non-zeros of its columns are known here): the next
+        // run is one launch instead of four (gl_spmspv_plan_hint_tiny; one-shot, and never result-relevant)
+        const uint32_t cnt = (uint32_t)(used - 1);
+        if (plan_ && cnt > 0 && cnt <= 1024) {
+            uint64_t work = 0;
+            for (uint32_t k = 1; k <= cnt; k++) {
+                const uint32_t c = vector[k].index;
+                if (c < csc_matrix_float_.num_cols) work += csc_matrix_float_.adj_indptr[c + 1] - csc_matrix_float_.adj_indptr[c];
+            }
+            GRAPHLILY_CHECK(gl_spmspv_plan_hint_tiny(plan_, cnt, work));
+        }
     }
 
     void send_mask_host_to_device(aligned_dense_vec_t &mask) {
