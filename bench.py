@@ -328,7 +328,12 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence):
     """bench_bfs.cpp:55-89: 1 warm-up + timed whole-algorithm runs, pull_push threshold 0.001, source 0;
     GTEPS = nnz * iters / t (nominal edges, independent of direction)."""
     t0 = time.time()
-    bfs = app.BFS(16, 0, 0, 0, comm=comm, backend=app.HipBackend(device, use_torch=True))
+    # One GPU: the library goes back to its own stream -- torch's current stream is the NULL stream, on which the BFS
+    # schedule cannot be recorded as a hipGraph (it would be enqueued launch by launch: ~5 % slower).  Row-sharded runs
+    # keep torch's stream: their collectives are torch.distributed calls on it.
+    if not comm.distributed:
+        capi.reset_stream()
+    bfs = app.BFS(16, 0, 0, 0, comm=comm, backend=app.HipBackend(device, use_torch=comm.distributed))
     bfs.set_up_runtime()
     bfs.load_and_format_matrix(raw, True)
     bfs.send_matrix_host_to_device()
