@@ -84,6 +84,11 @@ void spmspv_detach_everywhere(gl_spmv_plan dying) {
 
 constexpr uint32_t kBigColumn = 4096;  // columns at least this long are cut into queue chunks
 constexpr uint32_t kChunk = 4096;      // entries per queue chunk (one workgroup pass in kernel 1b)
+#ifndef GL_BFS_CHUNK
+#define GL_BFS_CHUNK 1024
+#endif
+constexpr uint32_t kBfsChunk = GL_BFS_CHUNK;   // bit-frontier BFS push step: columns at least this long are served from the plan's
+                                               // static list of chunks of this many entries (two round trips of a workgroup)
 constexpr uint32_t kBfsAccSlots = 64;  // accumulator lines of the bit-frontier BFS push step (a power of two)
 
 struct ScatterArgs {
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
             if (((word >> (threadIdx.x & 31u)) & 1u) && col < a.num_cols) {
                 start = a.indptr[col];
                 deg = a.indptr[col + 1u] - start;
-                if (deg >= kBigColumn) deg = 0u;      // served from the chunk list below
+                if (deg >= kBfsChunk) deg = 0u;       // served from the chunk list below
             }
             uint32_t ttotal;
             const uint32_t toff = block_exclusive_256((deg + 63u) >> 6, s_wave, &ttotal);
@@ -953,12 +958,11 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
         if (d >= gl::kBigColumn) chunks += (d + gl::kChunk - 1u) / gl::kChunk;
     }
     p->queue_capacity = (uint32_t)std::min<uint64_t>(chunks + 1u, 0x7fffffffu);
-    std::vector<uint4> long_chunks;
-    long_chunks.reserve((size_t)chunks);
+    std::vector<uint4> long_chunks;   // (gl_bfs_bits_push_step: its own, shorter chunks)
     for (uint32_t c = 0; c < num_cols; c++) {
         const uint32_t d = indptr[c + 1] - indptr[c];
-        if (d < gl::kBigColumn) continue;
-        for (uint32_t k = 0; k < d; k += gl::kChunk) long_chunks.push_back(make_uint4(c, indptr[c] + k, std::min(gl::kChunk, d - k), 0u));
+        if (d < gl::kBfsChunk) continue;
+        for (uint32_t k = 0; k < d; k += gl::kBfsChunk) long_chunks.push_back(make_uint4(c, indptr[c] + k, std::min(gl::kBfsChunk, d - k), 0u));
     }
     p->n_long_chunks = (uint32_t)long_chunks.size();
     auto fail = [&](hipError_t e) {
