@@ -194,9 +194,13 @@ struct BfsBitsCtl {
     __device__ bool row_wise() const { return ctl[8] == slot; }
     __device__ bool scatters() const { return ctl[0] > slot && ctl[8] != slot; }
     __device__ bool bottom_up() const { return !scatters() && ctl[9] == slot; }
+    // ctl[14]: a slot reached nothing -- the frontier is empty, no later slot can change a distance: the steps only keep
+    // the books from then on (the reference's loops run their remaining iterations on an empty vector)
+    __device__ bool finished() const { return ctl[14] != 0u; }
     // called once per slot, when the step that ran is complete, with the step's totals: vertices reached, non-zeros in
     // their columns (what a push from them scatters) and in their rows (what a pull no longer has to look at)
     __device__ void decide(uint32_t fresh, unsigned long long work, unsigned long long work_rows) const {
+        if (fresh == 0u) ctl[14] = 1u;
         if (16u + slot < ctl[15]) ctl[16u + slot] = fresh;   // the slot's new-frontier size, for the host (ctl[15] = words of ctl)
         unsigned long long *visited = reinterpret_cast<unsigned long long *>(ctl + 12);
         const unsigned long long vis = *visited + work_rows;

@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
     __shared__ unsigned long long s_work, s_work_rows;
     if (a.bits_spare)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.words; i += gridDim.x * 256u) a.bits_spare[i] = 0u;
+    if (a.c.finished()) return;
     const bool scatter = a.c.scatters();
     if (!scatter && !(a.row_idx && a.c.bottom_up())) return;
     if (threadIdx.x == 0) {

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
     uint32_t *xw = lds_words + kBoolTileWords;      // kBoolPhaseWords
 
     if (a.run_flag && load_const(a.run_flag) == 0u) return;
-    if (a.v2.ctl && (a.v2.scatters() || a.v2.bottom_up())) {
+    if (a.v2.ctl && (a.v2.finished() || a.v2.scatters() || a.v2.bottom_up())) {
         // the slot's push step ran (it is enqueued in front of this launch) -- scattering, or as the bottom-up pull: add up
         // its totals and take its decisions.  decide() does not change what scatters() / bottom_up() say about THIS slot,
         // so the other workgroups may look later.
