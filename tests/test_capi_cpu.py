@@ -117,3 +117,16 @@ def test_compute_fails_loudly_without_gpu():
     ip = np.zeros(2, np.uint32)
     rc = L.gl_spmv_plan_create(ctypes.byref(h), 1, 1, ip.ctypes.data, None, None, 0, 1)
     assert rc == capi.GL_ERR_NOT_INITIALIZED
+
+
+@pytest.mark.skipif(capi.device_count() > 0, reason="checks the no-GPU failure mode")
+def test_bfs_schedule_entry_points_fail_loudly_without_gpu():
+    """The bit-frontier BFS steps and the asynchronous read-back are compute entry points: without a device they must
+    refuse (GL_ERR_NOT_INITIALIZED), not pretend; the hints validate their handle; the host-side patch helper is gone."""
+    L = capi.lib()
+    assert L.gl_bfs_bits_begin(None, 32, None, 8, None, 4, 3, 0) == capi.GL_ERR_NOT_INITIALIZED
+    assert L.gl_bfs_bits_push_step(None, None, None, None, None, 4, None, 2.0, None, 1, 0.5, 3) == capi.GL_ERR_NOT_INITIALIZED
+    assert L.gl_bfs_bits_pull_step(None, None, None, None, None, 2.0, None, 1, 0.5, 3, 1.0) == capi.GL_ERR_NOT_INITIALIZED
+    assert L.gl_buf_d2h_async(None, None, 16) == capi.GL_ERR_NOT_INITIALIZED
+    assert L.gl_spmspv_plan_hint_tiny(None, 1, 1) == capi.GL_ERR_INVALID_ARG
+    assert not hasattr(L, "gl_host_patch_bits") and not hasattr(L, "gl_side_copy_d2h")
