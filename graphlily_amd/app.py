@@ -209,6 +209,9 @@ class BFS(_GraphApp):
         if hasattr(self.SpMSpV_, "attach_pull"):
             self.SpMSpV_.attach_pull(self.SpMV_)     # heavy frontiers of a push iteration go row-wise
         self.results_ = self.bits_a_ = self.bits_b_ = None   # per-matrix scratch of the pull loop
+        # the device-resident schedules hold buffers sized for the old n and hipGraphs with the old plans' device
+        # pointers baked in: a matrix sent again (or another one) must rebuild them
+        self.bits_loop_ = self.dev_loop_ = self.shard_loop_ = None
 
     # -- pull ------------------------------------------------------------------------------------
     def _bind_pull(self, vector, distance):

@@ -120,8 +120,12 @@ struct Semiring<GL_OP_ADDMIN> {
 //   unsigned        C arithmetic: + and * wrap mod 2^32 (associative, so even (+,x) is exact in any order),
 //                   a && b / a || b give 1, MIN is the unsigned minimum (hw/ufixed_pe_fwd.h:23-65 with ValT = unsigned);
 //   ufixed<32,8>    value = bits / 2^24; a + b saturates at 2^32 - 1 (AP_SAT), a && b / a || b give 1.0 = 1 << 24, MIN is
-//                   the unsigned minimum of the bits.  (+,x) is not offered: a saturating sum depends on its order.
-constexpr int kOpU32MulAdd = 3, kOpU32AndOr = 4, kOpU32AddMin = 5, kOpFixAndOr = 7, kOpFixAddMin = 8;
+//                   the unsigned minimum of the bits.  (+,x): the PRODUCT is rounded to 24 fraction bits (AP_RND, half up)
+//                   and saturated when it is assigned to ValT (hw/ufixed_pe_fwd.h:29-31: `out = a * b`), the add only
+//                   saturates (:53-55).  Every term is non-negative, so a clamped running sum equals
+//                   min(sum of the terms, 2^32 - 1) in ANY order: the kernels add the rounded products exactly (64-bit
+//                   accumulators in LDS, clamped compare-and-swap adds in global memory) and clamp once.
+constexpr int kOpU32MulAdd = 3, kOpU32AndOr = 4, kOpU32AddMin = 5, kOpFixMulAdd = 6, kOpFixAndOr = 7, kOpFixAddMin = 8;
 constexpr uint32_t kFixOne = 1u << 24;
 
 __device__ __forceinline__ uint32_t fbits(float v) { return __float_as_uint(v); }
@@ -137,6 +141,20 @@ struct Semiring<kOpU32MulAdd> {
     __device__ static float mul(float a, float b) { return bitsf(fbits(a) * fbits(b)); }
     __device__ static float add(float a, float b) { return bitsf(fbits(a) + fbits(b)); }
     __device__ static float finish(float zero, float s) { return bitsf(fbits(zero) + fbits(s)); }
+};
+
+// a * b of two ap_ufixed<32,8> assigned to one: 48 fraction bits rounded half up to 24 (AP_RND), saturated (AP_SAT)
+__device__ __forceinline__ uint32_t fix_mul_u32(uint32_t a, uint32_t b) {
+    const unsigned long long p = (unsigned long long)a * (unsigned long long)b;
+    const unsigned long long r = (p + (1ull << 23)) >> 24;   // p < 2^64 - 2^33: the rounding add cannot wrap
+    return r > 0xffffffffull ? 0xffffffffu : (uint32_t)r;
+}
+template <>
+struct Semiring<kOpFixMulAdd> {
+    __device__ static float ident(float) { return bitsf(0u); }
+    __device__ static float mul(float a, float b) { return bitsf(fix_mul_u32(fbits(a), fbits(b))); }
+    __device__ static float add(float a, float b) { return bitsf(sat_add_u32(fbits(a), fbits(b))); }
+    __device__ static float finish(float zero, float s) { return add(zero, s); }
 };
 
 template <uint32_t ONE>

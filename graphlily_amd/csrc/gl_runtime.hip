@@ -30,20 +30,48 @@ namespace gl {
 // Cached bytes are capped (GRAPHLILY_POOL_MAX_MB, default 8192 device / 2048 host); gl_pool_trim releases them.
 struct BlockPool {
     std::mutex mu;
-    std::unordered_map<void *, size_t> live;             // block -> rounded size | pinned flag (bit 0, host pool)
+    // Device blocks up to a quarter slab are carved from 256 MB slabs (a genuine hipMalloc costs 0.2 ms).  A slab counts
+    // the blocks it has handed out; when the last one comes back its cached pieces are dropped and carving restarts at
+    // offset 0 (that is the only coalescing there is, and the only point at which a slab can be released).  A slab is
+    // RETIRED when the library moves to another device: its blocks are then never cached again and it is released with
+    // its last live block.
+    struct Slab {
+        char *base;
+        size_t size, used, live;
+        int device;
+        bool retired;
+    };
+    struct Live {
+        size_t size;     // the block's own (rounded) size, which may exceed what the caller asked for (best fit)
+        Slab *slab;      // nullptr: its own allocation
+        int device;
+        bool pinned;     // host pool: page-locked
+    };
+    std::unordered_map<void *, Live> live;
     std::multimap<size_t, void *> cached;                // rounded size -> free block
     std::unordered_map<void *, size_t> pinned_cached;    // host pool: cached blocks that are page-locked
     std::unordered_map<size_t, bool> grown;              // host pool: sizes that got their one extra block (see gl_host_pool_alloc)
-    struct Slab {
-        char *base;
-        size_t size, used;
-    };
-    std::vector<Slab> slabs;                             // device pool: blocks are carved from these
-    size_t slab_live = 0;                                // carved blocks currently handed out
-    bool in_slab(const void *p) const {
-        for (const Slab &s : slabs)
-            if ((const char *)p >= s.base && (const char *)p < s.base + s.size) return true;
-        return false;
+    std::vector<Slab *> slabs;
+    Slab *slab_of(const void *p) const {
+        for (Slab *s : slabs)
+            if ((const char *)p >= s->base && (const char *)p < s->base + s->size) return s;
+        return nullptr;
+    }
+    // drop the cached pieces of a slab (caller holds mu)
+    void purge_slab(const Slab *sl) {
+        for (auto it = cached.begin(); it != cached.end();) {
+            if ((char *)it->second >= sl->base && (char *)it->second < sl->base + sl->size) {
+                cached_bytes -= it->first;
+                it = cached.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    size_t slab_bytes() const {
+        size_t b = 0;
+        for (const Slab *s : slabs) b += s->size;
+        return b;
     }
     size_t cached_bytes = 0, cap_bytes = 0;
 };
@@ -80,6 +108,8 @@ static bool spare_on_miss() {
     return on;
 }
 
+void device_pool_leave_device();
+
 Context &ctx() {
     static Context c;
     return c;
@@ -113,6 +143,19 @@ __global__ void fill_u32_gated_kernel(uint32_t *__restrict__ dst, uint32_t v, si
     for (; i < n; i += stride) dst[i] = v;
 }
 
+// gl_init is moving to another device: drain the stream, release what is cached, and retire the slabs that still have
+// live blocks (they are released with their last block, gl_buf_free)
+void device_pool_leave_device() {
+    if (ctx().stream || ctx().own_stream) (void)hipStreamSynchronize(ctx().stream);
+    gl_pool_trim();
+    BlockPool &P = device_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (BlockPool::Slab *sl : P.slabs) {
+        sl->retired = true;
+        P.purge_slab(sl);
+    }
+}
+
 }  // namespace gl
 
 extern "C" {
@@ -143,6 +186,7 @@ int gl_init(int device) {
     GL_ARG(device >= 0 && device < n);
     GL_HIP(hipSetDevice(device));
     if (c.initialized && c.device == device) return GL_OK;
+    if (c.initialized) gl::device_pool_leave_device();   // cached blocks of the old device must not be handed out on the new one
     if (c.own_stream) {
         (void)hipStreamDestroy(c.own_stream);
         c.own_stream = nullptr;
@@ -263,33 +307,45 @@ int gl_buf_alloc(void **d_ptr, size_t bytes) {
     *d_ptr = nullptr;
     gl::BlockPool &P = gl::device_pool();
     const size_t want = gl::round_block(bytes ? bytes : 4);
+    const int dev = gl::ctx().device;
     {
         std::lock_guard<std::mutex> lk(P.mu);
-        auto it = P.cached.find(want);
-        if (it != P.cached.end()) {
+        if (!P.cap_bytes) P.cap_bytes = gl::pool_cap("device", 8192);
+        // best fit with bounded waste: the smallest cached block of want .. want + 25 %
+        auto it = P.cached.lower_bound(want);
+        if (it != P.cached.end() && it->first <= want + want / 4) {
+            const size_t have = it->first;
             *d_ptr = it->second;
             P.cached.erase(it);
-            P.cached_bytes -= want;
-            P.live[*d_ptr] = want | (P.in_slab(*d_ptr) ? 1u : 0u);
+            P.cached_bytes -= have;
+            gl::BlockPool::Slab *sl = P.slab_of(*d_ptr);
+            if (sl) sl->live++;
+            P.live[*d_ptr] = gl::BlockPool::Live{have, sl, dev, false};
             return GL_OK;
         }
-        // Not cached: carve it from a slab.  A genuine hipMalloc costs 0.2 ms (rocprofv3 trace of the reference's
-        // bench_bfs on this backend) and a driver that re-sends its vectors on every call (app/bfs.h:107-113) holds
+        // Not cached: carve it from a slab.  A driver that re-sends its vectors on every call (app/bfs.h:107-113) holds
         // the previous call's buffers while it allocates the new ones, so its first calls all miss the cache;
-        // carving makes a miss as cheap as a hit.  Blocks above a quarter slab get their own allocation.
+        // carving makes a miss as cheap as a hit.  Blocks above a quarter slab get their own allocation, and so does
+        // everything once the slabs have reached the pool's cap.
         if (want <= gl::kSlabBytes / 4) {
-            if (P.slabs.empty() || P.slabs.back().size - P.slabs.back().used < want) {
+            gl::BlockPool::Slab *sl = nullptr;
+            for (gl::BlockPool::Slab *c : P.slabs)
+                if (!c->retired && c->device == dev && c->size - c->used >= want) sl = c;
+            if (!sl && P.slab_bytes() + gl::kSlabBytes <= P.cap_bytes) {
                 void *base = nullptr;
                 if (gl::pool_trace()) fprintf(stderr, "[pool] new device slab (%zu MB) for a %zu-byte block\n", gl::kSlabBytes >> 20, want);
-                if (hipMalloc(&base, gl::kSlabBytes) == hipSuccess) P.slabs.push_back(gl::BlockPool::Slab{(char *)base, gl::kSlabBytes, 0});
-                else (void)hipGetLastError();   // no room for a slab: plain allocation below
+                if (hipMalloc(&base, gl::kSlabBytes) == hipSuccess) {
+                    sl = new gl::BlockPool::Slab{(char *)base, gl::kSlabBytes, 0, 0, dev, false};
+                    P.slabs.push_back(sl);
+                } else {
+                    (void)hipGetLastError();   // no room for a slab: plain allocation below
+                }
             }
-            if (!P.slabs.empty() && P.slabs.back().size - P.slabs.back().used >= want) {
-                gl::BlockPool::Slab &sl = P.slabs.back();
-                *d_ptr = sl.base + sl.used;
-                sl.used += want;
-                P.live[*d_ptr] = want | 1u;
-                P.slab_live++;
+            if (sl) {
+                *d_ptr = sl->base + sl->used;
+                sl->used += want;
+                sl->live++;
+                P.live[*d_ptr] = gl::BlockPool::Live{want, sl, dev, false};
                 return GL_OK;
             }
         }
@@ -303,7 +359,7 @@ int gl_buf_alloc(void **d_ptr, size_t bytes) {
     }
     if (e != hipSuccess) return gl::set_error(GL_ERR_HIP, "gl_buf_alloc: hipMalloc(%zu): %s", want, hipGetErrorString(e));
     std::lock_guard<std::mutex> lk(P.mu);
-    P.live[*d_ptr] = want;
+    P.live[*d_ptr] = gl::BlockPool::Live{want, nullptr, dev, false};
     return GL_OK;
 }
 
@@ -311,23 +367,46 @@ int gl_buf_free(void *d_ptr) {
     GL_REQUIRE_INIT();
     if (!d_ptr) return GL_OK;
     gl::BlockPool &P = gl::device_pool();
+    char *release_slab = nullptr;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         if (!P.cap_bytes) P.cap_bytes = gl::pool_cap("device", 8192);
         auto it = P.live.find(d_ptr);
         if (it != P.live.end()) {
-            const size_t sz = it->second & ~(size_t)1;
-            const bool slab = (it->second & 1u) != 0;
+            const gl::BlockPool::Live b = it->second;
             P.live.erase(it);
-            if (slab) P.slab_live--;
-            if (slab || P.cached_bytes + sz <= P.cap_bytes) {   // slab blocks can only be recycled
-                P.cached.emplace(sz, d_ptr);
-                P.cached_bytes += sz;
+            if (gl::BlockPool::Slab *sl = b.slab) {
+                sl->live--;
+                if (sl->live == 0) {
+                    // every block of the slab is back: forget its pieces and start carving from the front again;
+                    // a retired slab (another device's) or a surplus one goes back to the driver
+                    P.purge_slab(sl);
+                    sl->used = 0;
+                    size_t same_device = 0;
+                    for (const gl::BlockPool::Slab *c : P.slabs) same_device += (!c->retired && c->device == sl->device) ? 1u : 0u;
+                    if (sl->retired || same_device > 1) {
+                        for (size_t i = 0; i < P.slabs.size(); i++)
+                            if (P.slabs[i] == sl) { P.slabs.erase(P.slabs.begin() + i); break; }
+                        release_slab = sl->base;
+                        delete sl;
+                    }
+                } else if (!sl->retired) {
+                    P.cached.emplace(b.size, d_ptr);   // a piece of a slab can only be recycled
+                    P.cached_bytes += b.size;
+                }
+                d_ptr = nullptr;
+            } else if (b.device == gl::ctx().device && P.cached_bytes + b.size <= P.cap_bytes) {
+                P.cached.emplace(b.size, d_ptr);
+                P.cached_bytes += b.size;
                 return GL_OK;
             }
         }
     }
-    GL_HIP(hipFree(d_ptr));   // not from gl_buf_alloc, or the pool is full
+    if (release_slab) {
+        (void)hipStreamSynchronize(gl::ctx().stream);   // work queued on the library's stream may still use its blocks
+        GL_HIP(hipFree(release_slab));
+    }
+    if (d_ptr) GL_HIP(hipFree(d_ptr));   // not from gl_buf_alloc, another device's, or the pool is full
     return GL_OK;
 }
 
@@ -336,35 +415,49 @@ int gl_pool_trim(void) {
         gl::BlockPool &P = host ? gl::host_pool() : gl::device_pool();
         std::multimap<size_t, void *> drop;
         std::unordered_map<void *, size_t> pinned;
-        std::vector<gl::BlockPool::Slab> slabs;
+        std::vector<char *> slabs;
         {
             std::lock_guard<std::mutex> lk(P.mu);
-            if (!host && P.slab_live) {   // carved blocks are still out: only the separately allocated ones can go
-                for (auto it = P.cached.begin(); it != P.cached.end();) {
-                    if (P.in_slab(it->second)) { ++it; continue; }
-                    drop.emplace(it->first, it->second);
-                    P.cached_bytes -= it->first;
-                    it = P.cached.erase(it);
+            // slabs without a live block go (with their cached pieces); the pieces of slabs that are still in use stay
+            // cached -- they cannot be returned one by one
+            for (size_t i = 0; i < P.slabs.size();) {
+                gl::BlockPool::Slab *sl = P.slabs[i];
+                if (sl->live == 0) {
+                    P.purge_slab(sl);
+                    slabs.push_back(sl->base);
+                    delete sl;
+                    P.slabs.erase(P.slabs.begin() + i);
+                } else {
+                    i++;
                 }
-            } else {
-                drop.swap(P.cached);
-                pinned.swap(P.pinned_cached);
-                slabs.swap(P.slabs);
-                P.cached_bytes = 0;
             }
+            for (auto it = P.cached.begin(); it != P.cached.end();) {
+                if (P.slab_of(it->second)) { ++it; continue; }
+                drop.emplace(it->first, it->second);
+                P.cached_bytes -= it->first;
+                it = P.cached.erase(it);
+            }
+            pinned.swap(P.pinned_cached);
         }
         if (drop.empty() && slabs.empty()) continue;
         if (!host && gl::ctx().initialized) (void)hipStreamSynchronize(gl::ctx().stream);   // queued work may still use them
         for (auto &kv : drop) {
-            bool carved = false;
-            for (const gl::BlockPool::Slab &sl : slabs) carved = carved || ((char *)kv.second >= sl.base && (char *)kv.second < sl.base + sl.size);
-            if (carved) continue;
             if (!host) (void)hipFree(kv.second);
             else if (pinned.count(kv.second)) (void)hipHostFree(kv.second);
             else free(kv.second);
         }
-        for (const gl::BlockPool::Slab &sl : slabs) (void)hipFree(sl.base);
+        for (char *base : slabs) (void)hipFree(base);
     }
+    return GL_OK;
+}
+
+/* how many device blocks are out, how many bytes are parked, how many slabs exist (tests, leak hunting) */
+int gl_pool_stats(uint64_t *live_blocks, uint64_t *cached_bytes, uint32_t *slabs) {
+    gl::BlockPool &P = gl::device_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (live_blocks) *live_blocks = P.live.size();
+    if (cached_bytes) *cached_bytes = P.cached_bytes;
+    if (slabs) *slabs = (uint32_t)P.slabs.size();
     return GL_OK;
 }
 
@@ -383,7 +476,7 @@ int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
                 *h_ptr = it->second;
                 P.cached.erase(it);
                 P.cached_bytes -= want;
-                P.live[*h_ptr] = want | P.pinned_cached[*h_ptr];
+                P.live[*h_ptr] = gl::BlockPool::Live{want, nullptr, -1, P.pinned_cached.count(*h_ptr) != 0};
                 P.pinned_cached.erase(*h_ptr);
                 // A driver call needs one block more from its second call on: the previous call's result is still
                 // alive while the new one is allocated (kernel_results = bfs.pull(...), benchmark/bench_bfs.cpp:60).
@@ -427,7 +520,7 @@ int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
             else spare = nullptr;
         }
         std::lock_guard<std::mutex> lk(P.mu);
-        P.live[*h_ptr] = want | pinned;
+        P.live[*h_ptr] = gl::BlockPool::Live{want, nullptr, -1, pinned != 0};
         if (spare) {
             if (!P.cap_bytes) P.cap_bytes = gl::pool_cap("host", 2048);
             if (P.cached_bytes + want <= P.cap_bytes) {
@@ -449,7 +542,7 @@ int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
 int gl_host_pool_free(void *h_ptr) {
     if (!h_ptr) return GL_OK;
     gl::BlockPool &P = gl::host_pool();
-    size_t tag;
+    bool pinned;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         if (!P.cap_bytes) P.cap_bytes = gl::pool_cap("host", 2048);
@@ -458,17 +551,17 @@ int gl_host_pool_free(void *h_ptr) {
             free(h_ptr);   // a small block
             return GL_OK;
         }
-        tag = it->second;
+        pinned = it->second.pinned;
+        const size_t sz = it->second.size;
         P.live.erase(it);
-        const size_t sz = tag & ~(size_t)1;
         if (P.cached_bytes + sz <= P.cap_bytes) {
             P.cached.emplace(sz, h_ptr);
-            if (tag & 1) P.pinned_cached[h_ptr] = 1;
+            if (pinned) P.pinned_cached[h_ptr] = 1;
             P.cached_bytes += sz;
             return GL_OK;
         }
     }
-    if (tag & 1) (void)hipHostFree(h_ptr);
+    if (pinned) (void)hipHostFree(h_ptr);
     else free(h_ptr);
     return GL_OK;
 }

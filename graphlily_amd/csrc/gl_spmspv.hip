@@ -117,6 +117,19 @@ template <int OP>
 __device__ __forceinline__ void scatter_one(float *acc, uint32_t row, float a, float xv) {
     if (OP == kOpU32MulAdd) {            // the integer value types (gl_common.h): the accumulator holds bits
         atomicAdd(reinterpret_cast<unsigned int *>(&acc[row]), fbits(a) * fbits(xv));
+    } else if (OP == kOpFixMulAdd) {
+        // acc = min(acc + round(a * x), 2^32 - 1): clamped adds of non-negative terms give min(sum, 2^32 - 1) in any order
+        // (gl_common.h), so a compare-and-swap loop reproduces the reference's sequential saturating sum bit for bit
+        const uint32_t t = fix_mul_u32(fbits(a), fbits(xv));
+        if (t != 0u) {
+            unsigned int *w = reinterpret_cast<unsigned int *>(&acc[row]);
+            unsigned int old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (old != 0xffffffffu) {
+                const unsigned int seen = atomicCAS(w, old, sat_add_u32(old, t));
+                if (seen == old) break;
+                old = seen;
+            }
+        }
     } else if (OP == kOpU32AndOr || OP == kOpFixAndOr) {
         if (fbits(a) != 0u && fbits(xv) != 0u) reinterpret_cast<uint32_t *>(acc)[row] = (OP == kOpU32AndOr) ? 1u : kFixOne;
     } else if (OP == kOpU32AddMin || OP == kOpFixAddMin) {
@@ -1054,8 +1067,6 @@ int gl_spmspv_run_typed(gl_spmspv_plan p, const void *d_vector, const void *d_ma
                         int mask_type, int val_type) {
     if (val_type != GL_VAL_FLOAT && val_type != GL_VAL_UNSIGNED && val_type != GL_VAL_UFIXED_32_8)
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_run_typed: unknown value type %d", val_type);
-    if (val_type == GL_VAL_UFIXED_32_8 && op == GL_OP_MULADD)
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmspv_run_typed: (+,x) over ap_ufixed<32,8,AP_RND,AP_SAT> is not offered (order-dependent saturation)");
     return spmspv_run_impl(p, (const gl_idx_val *)d_vector, (const float *)d_mask, (gl_idx_val *)d_result, op,
                            __builtin_bit_cast(float, zero_bits), mask_type, nullptr, 0.0f, nullptr, nullptr, 0u, GL_GATE_EQ, nullptr, 0u,
                            0.0f, 0, val_type);
@@ -1170,6 +1181,7 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
         case gl::kOpU32MulAdd: rc = gl::launch_scatter<gl::kOpU32MulAdd>(a, grid, s); break;
         case gl::kOpU32AndOr: rc = gl::launch_scatter<gl::kOpU32AndOr>(a, grid, s); break;
         case gl::kOpU32AddMin: rc = gl::launch_scatter<gl::kOpU32AddMin>(a, grid, s); break;
+        case gl::kOpFixMulAdd: rc = gl::launch_scatter<gl::kOpFixMulAdd>(a, grid, s); break;
         case gl::kOpFixAndOr: rc = gl::launch_scatter<gl::kOpFixAndOr>(a, grid, s); break;
         case gl::kOpFixAddMin: rc = gl::launch_scatter<gl::kOpFixAddMin>(a, grid, s); break;
         default: return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmspv_run: semiring op %d is not offered for value type %d", op, val_type);

@@ -166,6 +166,26 @@ struct Tile<kOpU32MulAdd> {
     __device__ static float finish(float zero, float s) { return bitsf(fbits(zero) + fbits(s)); }
 };
 
+// (+,x) over ap_ufixed<32,8,AP_RND,AP_SAT>: the rounded, saturated products (non-negative) are added EXACTLY in 64 bits
+// (ds_add_u64; a row of 2^32 products of < 2^32 each still fits) and clamped once when the row is read -- the same word as the
+// reference's clamped running sum in any order (gl_common.h)
+template <>
+struct Tile<kOpFixMulAdd> {
+    using T = unsigned long long;
+    __device__ static T ident() { return 0ull; }
+    __device__ static void acc(T *t, uint32_t r, float a, float xv) {
+        __hip_atomic_fetch_add(&t[r], (T)fix_mul_u32(fbits(a), fbits(xv)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ static T lift(float z) { return (T)fbits(z); }
+    __device__ static void accz(T *t, uint32_t r, float z) {   // z = colval (x) x, already rounded (pattern plans)
+        __hip_atomic_fetch_add(&t[r], (T)fbits(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ static T comb(T x, T y) { return x + y; }
+    __device__ static float get(const T *t, uint32_t r) { return bitsf(t[r] > 0xffffffffull ? 0xffffffffu : (uint32_t)t[r]); }
+    __device__ static float init(float zero) { return zero; }
+    __device__ static float finish(float zero, float s) { return bitsf(sat_add_u32(fbits(zero), fbits(s))); }
+};
+
 template <uint32_t ONE>
 struct TileBitsAndOr {
     using T = uint32_t;
@@ -911,6 +931,7 @@ int spmv_init_rows(int op, int mask_type, uint32_t r0, uint32_t r1, const float 
         case kOpU32MulAdd: return init_rows_mask<kOpU32MulAdd>(mask_type, r0, r1, mask, y, zero, s);
         case kOpU32AndOr: return init_rows_mask<kOpU32AndOr>(mask_type, r0, r1, mask, y, zero, s);
         case kOpU32AddMin: return init_rows_mask<kOpU32AddMin>(mask_type, r0, r1, mask, y, zero, s);
+        case kOpFixMulAdd: return init_rows_mask<kOpFixMulAdd>(mask_type, r0, r1, mask, y, zero, s);
         case kOpFixAndOr: return init_rows_mask<kOpFixAndOr>(mask_type, r0, r1, mask, y, zero, s);
         case kOpFixAddMin: return init_rows_mask<kOpFixAddMin>(mask_type, r0, r1, mask, y, zero, s);
         default: return set_error(GL_ERR_INVALID_ARG, "invalid semiring op %d", op);
@@ -1702,9 +1723,6 @@ int gl_spmv_run_typed(gl_spmv_plan p, const void *d_x, const void *d_mask, void 
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_run_typed: unknown value type %d", val_type);
     if (p->boolean)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run_typed: GL_PLAN_BOOLEAN plans serve float (||,&&) only; create the plan without it");
-    if (val_type == GL_VAL_UFIXED_32_8 && op == GL_OP_MULADD)
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run_typed: (+,x) over ap_ufixed<32,8,AP_RND,AP_SAT> is not offered: a saturating, "
-                             "rounding sum depends on the order of its terms, so no parallel order reproduces the reference bit for bit");
     return gl::spmv_run_general(p, (const float *)d_x, (const float *)d_mask, (float *)d_y, op + 3 * val_type, zero, mask_type, nullptr);
 }
 
@@ -1715,7 +1733,7 @@ namespace gl {
 int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
                      const uint32_t *run_flag) {
     if (p->boolean) return set_error(GL_ERR_UNSUPPORTED, "spmv_run_general: boolean layout");
-    if ((p->flags & (GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD)) && op == GL_OP_MULADD && p->nhot &&
+    if ((p->flags & (GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD)) && (op == GL_OP_MULADD || op == gl::kOpFixMulAdd) && p->nhot &&
         (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(gl::Tile<GL_OP_MULADD>::T) > gl::kLdsBudget)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_NO_MULADD "
                              "(hot-column table sized for 4-byte accumulators); (+,x) needs a plan without it");
@@ -1758,6 +1776,7 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
         case gl::kOpU32MulAdd: rc = gl::dispatch_mask<gl::kOpU32MulAdd>(mask_type, p, a, s); break;
         case gl::kOpU32AndOr: rc = gl::dispatch_mask<gl::kOpU32AndOr>(mask_type, p, a, s); break;
         case gl::kOpU32AddMin: rc = gl::dispatch_mask<gl::kOpU32AddMin>(mask_type, p, a, s); break;
+        case gl::kOpFixMulAdd: rc = gl::dispatch_mask<gl::kOpFixMulAdd>(mask_type, p, a, s); break;
         case gl::kOpFixAndOr: rc = gl::dispatch_mask<gl::kOpFixAndOr>(mask_type, p, a, s); break;
         case gl::kOpFixAddMin: rc = gl::dispatch_mask<gl::kOpFixAddMin>(mask_type, p, a, s); break;
         default: rc = gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid semiring op %d", op); break;

@@ -99,12 +99,18 @@ int gl_host_free(void *h_ptr);
  * hipHostMalloc of 12 MB cost more than the SpMV they serve.  gl_buf_alloc / gl_buf_free therefore recycle device
  * blocks by size (reuse is ordered by the library's stream), and gl_host_pool_alloc / gl_host_pool_free do the
  * same for 4 KiB-aligned host blocks of 64 KiB and more (no mmap + page faults per vector; they work before
- * gl_init: the C++ layer's aligned_allocator sits on them).  Host blocks are plain pages -- on the MI355X box
+ * gl_init: the C++ layer's aligned_allocator sits on them).  Device blocks up to 64 MB are carved from 256 MB slabs; a
+ * request is served by the smallest parked block of its size .. +25 %; a slab whose blocks have all come back is carved
+ * from its start again (and released if another one exists); moving to another device (gl_init) releases what is parked
+ * and retires the slabs still in use.  Host blocks are plain pages -- on the MI355X box
  * pageable and page-locked copies run at the same 56 GB/s while page-locking 12 MB costs 2.5 ms
  * (profiles/r02_ubench_host.txt); GRAPHLILY_HOST_PIN=1 page-locks them.  gl_pool_trim returns every cached block. */
 int gl_host_pool_alloc(void **h_ptr, size_t bytes);
 int gl_host_pool_free(void *h_ptr);
 int gl_pool_trim(void);
+/* device pool counters for tests and leak hunting: blocks currently handed out by gl_buf_alloc, bytes parked for reuse,
+ * number of 256 MB slabs the small blocks are carved from (any pointer may be NULL) */
+int gl_pool_stats(uint64_t *live_blocks, uint64_t *cached_bytes, uint32_t *slabs);
 
 /* --------------------------------------------------------------------- SpMV
  * gl_spmv_plan_create replaces SpMVModule::load_and_format_matrix +
