@@ -601,6 +601,19 @@ class PageRank(_GraphApp):
         # The device epilogue computes zero + sum in float, so passing the teleport term AS the semiring's zero gives
         # the same float (a + b == b + a), and the two buffers swap roles instead of being copied: one launch and
         # 8n bytes less per iteration.
+        if getattr(self.SpMV_, "plan_flags_", 0) & capi.GL_PLAN_REFERENCE_ORDER:
+            # diagnostic run in the reference's own evaluation order: the literal module sequence, SpMV with zero = 0
+            # and then eWiseAdd(teleport) (teleport + sum started from the teleport term rounds differently)
+            self.SpMV_.bind_vector_buf(vector)
+            self.SpMV_.bind_results_buf(results)
+            self.eWiseAdd_.bind_in_buf(self._own(results))
+            self.eWiseAdd_.bind_out_buf(self._own(vector))
+            for _ in range(num_iterations):
+                self.SpMV_.run()
+                self.eWiseAdd_.run(self.r1_ - self.r0_, float(teleport))
+                self._gather(vector)
+            B.sync()
+            return B.download_result(vector, n)
         saved = self.SpMV_.semiring_
         self.SpMV_.set_semiring(M.SemiringType(M.kMulAdd, 1.0, float(teleport)))
         try:

@@ -337,6 +337,7 @@ GL_GATE_EQ, GL_GATE_GT, GL_GATE_LE = 0, 1, 2
 GL_VAL_FLOAT, GL_VAL_UNSIGNED, GL_VAL_UFIXED_32_8 = 0, 1, 2
 GL_PLAN_HOST_FORMAT = 8
 GL_PLAN_DEVICE_FORMAT = 16
+GL_PLAN_REFERENCE_ORDER = 32
 PLAN_ARRAYS = {"entries": 0, "bases": 1, "units": 2, "hub_rows": 3, "spans": 4}
 GL_ERR_UNSUPPORTED = -5
 
@@ -375,7 +376,7 @@ class SpMVPlan:
                 "nnz": nnz.value, "device_bytes": nbytes.value, "num_units": ntiles.value, "blocks": b.value,
                 "segments": sg.value, "max_block_rows": mr.value, "groups": g.value,
                 "hot_columns": hc.value, "hot_nnz": hn.value, "mix": mix.value,
-                "layout": ("general", "pattern", "boolean")[lay.value]}
+                "layout": ("general", "pattern", "boolean", "reference-order")[lay.value]}
 
     def run(self, x, mask, y, op, zero, mask_type):
         check(lib().gl_spmv_run(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero),

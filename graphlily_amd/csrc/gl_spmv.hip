@@ -604,6 +604,69 @@ __global__ __launch_bounds__(256) void spmv_combine_kernel(const uint4 *__restri
     }
 }
 
+// ---------------------------------------------------------------- GL_PLAN_REFERENCE_ORDER
+// SpMVModule::compute_reference_results (module/spmv_module.h:478-532) evaluated the way the reference writes it: one
+// thread per row, the row's entries in CSR order, a float accumulator that starts at `zero`, a separately rounded float
+// multiply and add per entry (no FMA contraction: __fmul_rn / __fadd_rn), std::min's operand order for (min,+).  The
+// result is bit-equal to the reference loop BY CONSTRUCTION -- which is the point: the fast layouts differ from it only
+// in the order (and, for (+,x), the width) of the accumulation, and a run on this layout shows that nothing else does.
+template <int OP, int MASK>
+__global__ __launch_bounds__(256) void spmv_reference_order_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                                   const float *__restrict__ data, const float *__restrict__ x,
+                                                                   const float *__restrict__ mask, float *__restrict__ y, float zero,
+                                                                   uint32_t row_begin, uint32_t rows) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < rows; i += gridDim.x * 256u) {
+        float acc = zero;
+        const uint32_t e1 = indptr[i + 1u];
+        for (uint32_t e = indptr[i]; e < e1; e++) {
+            const float a = data[e], xv = x[indices[e]];
+            if (OP == GL_OP_MULADD) {
+                acc = __fadd_rn(acc, __fmul_rn(a, xv));                       // y[r] += data[i] * x[col]  (:495)
+            } else if (OP == GL_OP_ANDOR) {
+                acc = (acc != 0.0f || (a != 0.0f && xv != 0.0f)) ? 1.0f : 0.0f;   // y[r] = y[r] || (data && x)  (:498)
+            } else {
+                const float t = __fadd_rn(a, xv);                             // std::min(y[r], data + x) == (t < y) ? t : y  (:501)
+                acc = (t < acc) ? t : acc;
+            }
+        }
+        const uint32_t row = row_begin + i;
+        if (MASK != GL_NOMASK) {
+            if (!mask_allows_zero<MASK, OP>(mask[row])) acc = 0.0f;          // masked-off rows are literal 0 (:518-530)
+        }
+        y[row] = acc;
+    }
+}
+
+template <int OP>
+static int launch_reference_order(gl_spmv_plan p, const float *x, const float *mask, float *y, float zero, int mask_type, hipStream_t s) {
+    const uint32_t rows = p->row_end - p->row_begin;
+    if (!rows) return GL_OK;
+    const unsigned grid = std::min<unsigned>(cdiv(rows, 256), (unsigned)ctx().num_cus * 16u);
+    switch (mask_type) {
+        case GL_NOMASK:
+            spmv_reference_order_kernel<OP, GL_NOMASK><<<grid, 256, 0, s>>>(p->d_csr_indptr, p->d_csr_indices, p->d_csr_data, x, mask, y, zero, p->row_begin, rows);
+            break;
+        case GL_MASK_WRITETOZERO:
+            spmv_reference_order_kernel<OP, GL_MASK_WRITETOZERO><<<grid, 256, 0, s>>>(p->d_csr_indptr, p->d_csr_indices, p->d_csr_data, x, mask, y, zero, p->row_begin, rows);
+            break;
+        case GL_MASK_WRITETOONE:
+            spmv_reference_order_kernel<OP, GL_MASK_WRITETOONE><<<grid, 256, 0, s>>>(p->d_csr_indptr, p->d_csr_indices, p->d_csr_data, x, mask, y, zero, p->row_begin, rows);
+            break;
+        default: return set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid mask type %d", mask_type);
+    }
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int spmv_run_reference_order(gl_spmv_plan p, const float *x, const float *mask, float *y, int op, float zero, int mask_type, hipStream_t s) {
+    switch (op) {
+        case GL_OP_MULADD: return launch_reference_order<GL_OP_MULADD>(p, x, mask, y, zero, mask_type, s);
+        case GL_OP_ANDOR: return launch_reference_order<GL_OP_ANDOR>(p, x, mask, y, zero, mask_type, s);
+        case GL_OP_ADDMIN: return launch_reference_order<GL_OP_ADDMIN>(p, x, mask, y, zero, mask_type, s);
+        default: return set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid semiring op %d", op);
+    }
+}
+
 }  // namespace gl
 
 namespace gl {
@@ -961,6 +1024,36 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     GL_ARG(nnz == 0 || (h_indices != nullptr && h_data != nullptr));
     const uint32_t rows = row_end - row_begin;
     for (uint32_t r = row_begin; r < row_end; r++) GL_ARG(h_indptr[r + 1] >= h_indptr[r]);
+
+    // ---- GL_PLAN_REFERENCE_ORDER: the shard's CSR as it is (diagnostic layout, spmv_reference_order_kernel)
+    if (flags & GL_PLAN_REFERENCE_ORDER) {
+        for (uint64_t i = nz0; i < nz1; i++)
+            if (h_indices[i] >= num_cols)
+                return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", num_cols);
+        gl_spmv_plan p = new gl_spmv_plan_s();
+        p->num_rows = num_rows;
+        p->num_cols = num_cols;
+        p->row_begin = row_begin;
+        p->row_end = row_end;
+        p->nnz = nnz;
+        p->flags = flags;
+        p->reference_order = true;
+        std::vector<uint32_t> ip((size_t)rows + 1u);
+        for (uint32_t r = 0; r <= rows; r++) ip[r] = (uint32_t)(h_indptr[row_begin + r] - nz0);
+        hipError_t e = hipMalloc((void **)&p->d_csr_indptr, ip.size() * 4u);
+        if (e == hipSuccess) e = hipMalloc((void **)&p->d_csr_indices, std::max<uint64_t>(nnz, 1u) * 4u);
+        if (e == hipSuccess) e = hipMalloc((void **)&p->d_csr_data, std::max<uint64_t>(nnz, 1u) * 4u);
+        if (e == hipSuccess) e = hipMemcpy(p->d_csr_indptr, ip.data(), ip.size() * 4u, hipMemcpyHostToDevice);
+        if (e == hipSuccess && nnz) e = hipMemcpy(p->d_csr_indices, h_indices + nz0, nnz * 4u, hipMemcpyHostToDevice);
+        if (e == hipSuccess && nnz) e = hipMemcpy(p->d_csr_data, h_data + nz0, nnz * 4u, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            gl_spmv_plan_destroy(p);
+            return gl::set_error(GL_ERR_HIP, "gl_spmv_plan_create: reference-order plan: %s", hipGetErrorString(e));
+        }
+        p->device_bytes = ip.size() * 4u + nnz * 8u;
+        *plan = p;
+        return GL_OK;
+    }
 
     // ---- (||,&&)-only plans have their own layout (gl_spmv_bool.hip); very wide matrices keep the general one
     if ((flags & GL_PLAN_BOOLEAN) && nnz > 0 && gl::cdiv(num_cols, gl::kBoolPhaseCols) <= gl::kBoolMaxPhases &&
@@ -1534,6 +1627,7 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_xbits);
     (void)hipFree(p->d_csr_indptr);
     (void)hipFree(p->d_csr_indices);
+    (void)hipFree(p->d_csr_data);
     delete p;
     return GL_OK;
 }
@@ -1681,7 +1775,7 @@ int gl_spmv_plan_export(gl_spmv_plan p, int array, void *h_dst, size_t capacity,
 
 int gl_spmv_plan_layout(gl_spmv_plan p, int *layout) {
     GL_ARG(p != nullptr && layout != nullptr);
-    *layout = p->boolean ? GL_LAYOUT_BOOLEAN : (p->pattern ? GL_LAYOUT_PATTERN : GL_LAYOUT_GENERAL);
+    *layout = p->reference_order ? GL_LAYOUT_REFERENCE_ORDER : p->boolean ? GL_LAYOUT_BOOLEAN : (p->pattern ? GL_LAYOUT_PATTERN : GL_LAYOUT_GENERAL);
     return GL_OK;
 }
 
@@ -1701,6 +1795,7 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
     GL_ARG(p != nullptr && d_y != nullptr);
     GL_ARG(d_x != nullptr || p->nnz == 0);
     GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
+    if (p->reference_order) return gl::spmv_run_reference_order(p, d_x, d_mask, d_y, op, zero, mask_type, gl::ctx().stream);
     if (p->boolean) {
         if (op != GL_OP_ANDOR)
             return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_BOOLEAN and "
@@ -1721,8 +1816,8 @@ int gl_spmv_run_typed(gl_spmv_plan p, const void *d_x, const void *d_mask, void 
     if (val_type == GL_VAL_FLOAT) return gl_spmv_run(p, (const float *)d_x, (const float *)d_mask, (float *)d_y, op, zero, mask_type);
     if (val_type != GL_VAL_UNSIGNED && val_type != GL_VAL_UFIXED_32_8)
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_run_typed: unknown value type %d", val_type);
-    if (p->boolean)
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run_typed: GL_PLAN_BOOLEAN plans serve float (||,&&) only; create the plan without it");
+    if (p->boolean || p->reference_order)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run_typed: GL_PLAN_BOOLEAN / GL_PLAN_REFERENCE_ORDER plans serve float only; create the plan without the flag");
     return gl::spmv_run_general(p, (const float *)d_x, (const float *)d_mask, (float *)d_y, op + 3 * val_type, zero, mask_type, nullptr);
 }
 
@@ -1732,7 +1827,7 @@ namespace gl {
 // the general / pattern layouts; run_flag as in SpmvArgs
 int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
                      const uint32_t *run_flag) {
-    if (p->boolean) return set_error(GL_ERR_UNSUPPORTED, "spmv_run_general: boolean layout");
+    if (p->boolean || p->reference_order) return set_error(GL_ERR_UNSUPPORTED, "spmv_run_general: boolean / reference-order layout");
     if ((p->flags & (GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD)) && (op == GL_OP_MULADD || op == gl::kOpFixMulAdd) && p->nhot &&
         (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(gl::Tile<GL_OP_MULADD>::T) > gl::kLdsBudget)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_NO_MULADD "

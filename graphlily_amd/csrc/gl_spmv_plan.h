@@ -126,6 +126,10 @@ struct gl_spmv_plan_s {
     // whole-matrix boolean plans also keep the rows as plain CSR (4 B per non-zero more): gl_bfs_bits_push_step's bottom-up
     // branch scans the rows a BFS has not reached yet; zero-valued entries carry the column 0xffffffff
     uint32_t *d_csr_indptr = nullptr, *d_csr_indices = nullptr;
+    // GL_PLAN_REFERENCE_ORDER: the shard's plain CSR (indptr rebased to 0, values kept), evaluated a thread per row in
+    // the reference's own order -- a diagnostic layout, not a fast one
+    bool reference_order = false;
+    float *d_csr_data = nullptr;
     uint64_t device_bytes = 0;
     size_t b_entries = 0, b_bases = 0, b_units = 0, b_hub_rows = 0, b_spans = 0;   // sizes of the formatted arrays (gl_spmv_plan_export)
 };

@@ -114,6 +114,7 @@ class SpMVModule(BaseModule):
         self.plan_ = None
         self.row_begin_, self.row_end_ = 0, None
         self.vector_buf = self.mask_buf = self.results_buf = None
+        self.plan_flags_ = 0
 
     def set_semiring(self, semiring):
         self.semiring_ = semiring
@@ -124,6 +125,12 @@ class SpMVModule(BaseModule):
     def set_row_shard(self, row_begin, row_end):
         """Multi-GPU extension: this device owns rows [row_begin, row_end) of the matrix."""
         self.row_begin_, self.row_end_ = int(row_begin), int(row_end)
+
+    def set_plan_flags(self, flags):
+        """Extension: GL_PLAN_* flags for the plans this module creates (before send_matrix_host_to_device), e.g.
+        capi.GL_PLAN_REFERENCE_ORDER -- the diagnostic layout that evaluates compute_reference_results' own loop
+        (module/spmv_module.h:478-510) on the device -- or capi.GL_PLAN_KEEP_VALUES."""
+        self.plan_flags_ = int(flags)
 
     def get_num_rows(self):
         return self.csr_matrix_.num_rows
@@ -147,6 +154,8 @@ class SpMVModule(BaseModule):
 
     def _plan_serves(self, op):
         f = self.plan_.flags
+        if f & capi.GL_PLAN_REFERENCE_ORDER:
+            return True
         if (f & capi.GL_PLAN_BOOLEAN) and op != kLogicalAndOr:
             return False
         return not ((f & capi.GL_PLAN_NO_MULADD) and op == kMulAdd)
@@ -156,7 +165,9 @@ class SpMVModule(BaseModule):
         re = m.num_rows if self.row_end_ is None else self.row_end_
         # the semiring known at upload time sizes the LDS split (accumulators vs hot-column table); a later
         # switch to (+,x) on a plan built for the 4-byte semirings re-formats the matrix (see run())
-        flags = self._plan_flags(self.semiring_.op)
+        flags = self._plan_flags(self.semiring_.op) | self.plan_flags_
+        if flags & capi.GL_PLAN_REFERENCE_ORDER:
+            flags = capi.GL_PLAN_REFERENCE_ORDER
         for client in getattr(self, "pull_clients_", ()):   # the old plan is about to go away
             client._attach(None)
         self.plan_ = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data,
@@ -208,7 +219,9 @@ class SpMVModule(BaseModule):
 
     # extensions for row-sharded (||,&&) runs: x as a bit vector (gl_spmv_plan_bits_words / gl_spmv_run_bits)
     def bits_words(self):
-        return self.plan_.bits_words() if self.plan_ is not None and self._plan_serves(self.semiring_.op) else 0
+        if self.plan_ is None or (self.plan_.flags & capi.GL_PLAN_REFERENCE_ORDER):
+            return 0
+        return self.plan_.bits_words() if self._plan_serves(self.semiring_.op) else 0
 
     def bfs_pull_step(self, bits_in, bits_out, distance_buf, level):
         """Extension (gl_bfs_pull_step): this module's masked (||,&&) run + eWiseAdd(+0) + dense assign(level) of a

@@ -147,6 +147,13 @@ int gl_spmv_plan_create(gl_spmv_plan *plan,
  * variable GRAPHLILY_PLAN_DEVICE=0/1 does the same for plans created without them. */
 #define GL_PLAN_HOST_FORMAT 8u
 #define GL_PLAN_DEVICE_FORMAT 16u
+/* GL_PLAN_REFERENCE_ORDER: a DIAGNOSTIC layout.  The shard's CSR is kept as it is and gl_spmv_run evaluates
+ * SpMVModule::compute_reference_results (module/spmv_module.h:478-532) the way the reference writes it: a thread per
+ * row, the entries in CSR order, a float accumulator starting at `zero`, separately rounded float multiply and add (no
+ * FMA).  Results are bit-equal to the reference's CPU loop by construction, for all three semirings and masks -- the
+ * tests run it next to the fast layouts to show that summation order (and the f64 accumulator of (+,x)) is the only
+ * thing in which they differ from the reference.  Slow on hub rows (one thread walks the whole row); float only. */
+#define GL_PLAN_REFERENCE_ORDER 32u
 int gl_spmv_plan_create_ex(gl_spmv_plan *plan,
                            uint32_t num_rows, uint32_t num_cols,
                            const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
@@ -162,6 +169,7 @@ int gl_spmv_plan_shape(gl_spmv_plan plan, uint32_t *blocks, uint32_t *segments, 
 #define GL_LAYOUT_GENERAL 0
 #define GL_LAYOUT_PATTERN 1
 #define GL_LAYOUT_BOOLEAN 2
+#define GL_LAYOUT_REFERENCE_ORDER 3
 int gl_spmv_plan_layout(gl_spmv_plan plan, int *layout);
 /* Debugging / tests: copy one of the plan's device arrays to the host.  `array` is one of GL_PLAN_ARRAY_*; *bytes
  * receives its size (also when h_dst is NULL or capacity is too small, in which case nothing is copied and

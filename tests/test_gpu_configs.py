@@ -97,6 +97,20 @@ def test_spmv_arith_ogbn_products_full(gpu):
         calm = rel_ref_exact <= 5e-6
         assert np.all(rel_ref[calm] <= 1e-5)
         plan.destroy()
+    # The diagnostic layout evaluates the reference's own loop on the device -- thread per row, CSR order, fp32 multiply
+    # and add rounded separately -- and must agree with the oracle BIT FOR BIT on every one of the 2.45 M rows, the
+    # 171 K-entry hub row included: summation order (and the f64 accumulator) is the ONLY thing in which the fast
+    # layouts above differ from the reference's CPU path.
+    plan = M.capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=M.capi.GL_PLAN_REFERENCE_ORDER)
+    assert plan.info()["layout"] == "reference-order"
+    dx, dy = M.capi.DeviceBuffer.from_host(x), M.capi.DeviceBuffer(4 * m.num_rows)
+    t0 = time.time()
+    plan.run(dx, None, dy, 0, 0.0, 0)
+    got_ro = dy.read(np.float32, m.num_rows)
+    _margin(config="spmv (+,x) ogbn_products", layout="reference-order", rows=int(m.num_rows),
+            words_differing_from_oracle=int((got_ro.view(np.uint32) != ref.view(np.uint32)).sum()), seconds=round(time.time() - t0, 3))
+    assert np.array_equal(got_ro.view(np.uint32), ref.view(np.uint32))
+    plan.destroy()
 
 
 # ------------------------------------------------------------------------------------------- configs[2] + orkut BFS
@@ -166,6 +180,30 @@ def _pagerank_worker(rank, world, port, out_q):
         out_q.put((rank, got, (pr.r0_, pr.r1_)))
     finally:
         dist.destroy_process_group()
+
+
+def test_pagerank_hollywood_reference_order_is_bit_equal(gpu):
+    """PageRank::pull (app/pagerank.h:80-90) on hollywood, 10 iterations, with the SpMV module on the diagnostic
+    reference-order layout and the literal module sequence (SpMV zero = 0, then eWiseAdd(teleport)): every word equal to
+    O.pagerank.  Together with the 1e-5-of-the-exact-recurrence bound of the fast path below this pins what the two
+    differ in: the order and width of the row sums, nothing else."""
+    m = _graph("hollywood")
+    om = _oracle_prepared(m, "pagerank")
+    t0 = time.time()
+    ref = O.pagerank(om, 0.9, 10)
+    t_oracle = time.time() - t0
+    pr = app.PageRank(16, 0, 0)
+    pr.SpMV_.set_plan_flags(M.capi.GL_PLAN_REFERENCE_ORDER)
+    pr.set_up_runtime()
+    pr.load_and_format_matrix(m, 0.9, True)
+    pr.send_matrix_host_to_device()
+    assert pr.SpMV_.plan_.info()["layout"] == "reference-order"
+    t0 = time.time()
+    got = pr.pull(0.9, 10)
+    _margin(config="pagerank hollywood reference-order", n=int(om.num_rows), iterations=10,
+            words_differing_from_oracle=int((got.view(np.uint32) != ref.view(np.uint32)).sum()),
+            seconds=round(time.time() - t0, 3), oracle_seconds=round(t_oracle, 2))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
 def test_pagerank_hollywood_two_ranks(gpu):

@@ -1,0 +1,108 @@
+"""GPU tests of the runtime plumbing (csrc/gl_runtime.hip): the device block pool behind gl_buf_alloc / gl_buf_free, which
+replaces the per-call cl::Buffer construction of the reference's modules (module/spmv_module.h:424-439,
+app/bfs.h:107-113), and the drivers' behaviour when a matrix is sent again (BaseModule::set_up_runtime +
+send_matrix_host_to_device may be called more than once, app/bfs.h:100-103)."""
+import numpy as np
+import pytest
+
+from graphlily_amd import app, capi, datasets, io
+from oracle import oracle as O
+
+from helpers import to_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _pattern(n, seed):
+    return np.random.default_rng(seed).integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+
+
+def test_pool_recycled_block_survives_trim(gpu):
+    """alloc, free, alloc the same size (a cache hit on a slab-carved block), gl_pool_trim, then use the buffer: the
+    round-2 pool lost count of the re-issued block and released the slab under it."""
+    capi.pool_trim()
+    a = capi.DeviceBuffer(1 << 20)
+    pa = a.ptr
+    a.free()
+    b = capi.DeviceBuffer(1 << 20)
+    assert b.ptr == pa, "the freed block is the one handed out again"
+    keep = _pattern(1 << 18, 1)
+    b.write(keep)
+    capi.pool_trim()                       # b is live: its slab must stay
+    live, cached, slabs = capi.pool_stats()
+    assert slabs >= 1 and live >= 1
+    # allocations after the trim must not land on b
+    others = [capi.DeviceBuffer(1 << 20) for _ in range(8)]
+    for i, o in enumerate(others):
+        assert o.ptr != b.ptr
+        o.write(_pattern(1 << 18, 100 + i))
+    assert np.array_equal(b.read(np.uint32, 1 << 18), keep)
+    for o in others:
+        o.free()
+    b.free()
+    capi.pool_trim()
+
+
+def test_pool_best_fit_and_slab_reset(gpu):
+    import gc
+    gc.collect()                           # buffers of earlier tests that nobody holds any more
+    capi.pool_trim()
+    live0, _, _ = capi.pool_stats()
+    # a 1.00 MB request is served by a parked 1.125 MB block (<= 25 % larger), not by a 2 MB one
+    big, mid = capi.DeviceBuffer(2 << 20), capi.DeviceBuffer((1 << 20) + (1 << 17))
+    pmid, pbig = mid.ptr, big.ptr
+    anchor = capi.DeviceBuffer(4096)       # keeps the slab alive, so the two stay parked
+    big.free()
+    mid.free()
+    c = capi.DeviceBuffer(1 << 20)
+    assert c.ptr == pmid
+    d = capi.DeviceBuffer(1 << 20)
+    assert d.ptr not in (pmid, pbig), "a 2 MB block is more than 25 % too large: fresh space instead"
+    # many distinct sizes, freed: once the slab is idle its space is carved from the start again (no monotonic growth)
+    sizes = [(3 + 5 * k) << 12 for k in range(200)]
+    bufs = [capi.DeviceBuffer(sz) for sz in sizes]
+    first = min(b.ptr for b in bufs)
+    for b in bufs + [c, d, anchor]:
+        b.free()
+    live, cached, slabs = capi.pool_stats()
+    assert live == live0
+    if live0 == 0:                         # (a block of some earlier test still out would keep its slab from going idle)
+        e = capi.DeviceBuffer(7 << 12)
+        assert e.ptr <= first, "the idle slab is reused from its start"
+        e.free()
+    capi.pool_trim()
+    assert capi.pool_stats()[1] == 0
+
+
+def test_pool_large_blocks_bypass_slabs_and_recycle(gpu):
+    capi.pool_trim()
+    a = capi.DeviceBuffer(80 << 20)        # above a quarter slab: its own allocation
+    p = a.ptr
+    a.write(_pattern(1024, 3))
+    a.free()
+    b = capi.DeviceBuffer(80 << 20)
+    assert b.ptr == p
+    b.free()
+    capi.pool_trim()
+    assert capi.pool_stats()[1] == 0
+
+
+def test_bfs_matrix_sent_again_rebuilds_the_device_schedules(gpu):
+    """BFS.send_matrix_host_to_device on an object that has already run: the captured hipGraphs and bit-vector buffers of
+    the first matrix hold its plans' device pointers and its n -- they must be dropped, not replayed."""
+    g1 = datasets.rmat(20000, 300000, seed=21, symmetric=True)
+    g2 = datasets.rmat(33000, 500000, seed=22, symmetric=True)
+    bfs = app.BFS(16, 0, 0, 0)
+    bfs.set_up_runtime()
+    for g in (g1, g2, g1):
+        bfs.load_and_format_matrix(g, True)
+        bfs.send_matrix_host_to_device()
+        ref_m = g.copy()
+        io.util_round_csr_matrix_dim(ref_m, 128, 128)
+        ref_m.adj_data = np.ones(ref_m.nnz, np.float32)
+        deg = np.diff(g.adj_indptr.astype(np.int64))
+        src = int(np.argmax(deg > 0))
+        ref = O.bfs(to_oracle(ref_m), src, 6)
+        for _ in range(3):                 # eager, capture, replay
+            assert np.array_equal(bfs.pull_push(src, 6, 0.01), ref)
+            assert np.array_equal(bfs.pull(src, 6), ref)

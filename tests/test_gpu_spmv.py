@@ -466,3 +466,70 @@ def test_helper_modes_agree(gpu, keep_values, monkeypatch):
     assert ("gather", True) in seen and ("spread", True) in seen
     if keep_values:
         assert ("self-hot", False) in seen       # pattern plans always need their helper (it forms z)
+
+
+@pytest.mark.parametrize("mask_name", list(MASKS))
+@pytest.mark.parametrize("sem", ["Arithmetic", "Logical", "Tropical", "TropicalFloatInf"])
+def test_reference_order_layout_is_bit_equal_to_the_oracle(gpu, sem, mask_name):
+    """GL_PLAN_REFERENCE_ORDER evaluates compute_reference_results' own loop (module/spmv_module.h:478-532) on the
+    device: thread per row, CSR order, separately rounded fp32 multiply and add.  Random float weights and a dense
+    random x -- the case in which the fast (+,x) layouts differ from the oracle in the last bits -- whole matrix and row
+    shards: every word equal."""
+    m = spmv_prepare("rmat_sym_50K")
+    rng = np.random.default_rng(19)
+    op, zero = SEMIRINGS[sem]
+    if op == 0:
+        m.adj_data = rng.random(m.nnz, dtype=np.float32)
+        x = rng.random(m.num_cols, dtype=np.float32)
+    elif op == 1:
+        m.adj_data = rng.integers(0, 2, size=m.nnz).astype(np.float32)
+        x = rand01(m.num_cols, 3)
+    else:
+        m.adj_data = rng.integers(1, 9, size=m.nnz).astype(np.float32) + rng.random(m.nnz, dtype=np.float32)
+        x = np.where(rand01(m.num_cols, 3) > 0, np.float32(zero), rng.random(m.num_cols, dtype=np.float32) * 50).astype(np.float32)
+    mask = rand01(m.num_rows, 4)
+    ref = _ref_spmv(m, sem, mask_name, x, mask)
+    dx, dm = M.capi.DeviceBuffer.from_host(x), M.capi.DeviceBuffer.from_host(mask)
+    for r0, r1 in ((0, m.num_rows), (0, 20032), (20032, m.num_rows)):
+        plan = M.capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, r0, r1,
+                               flags=M.capi.GL_PLAN_REFERENCE_ORDER)
+        assert plan.info()["layout"] == "reference-order" and plan.info()["nnz"] == int(m.adj_indptr[r1]) - int(m.adj_indptr[r0])
+        dy = M.capi.DeviceBuffer(4 * m.num_rows)
+        plan.run(dx, dm if MASKS[mask_name] else None, dy, op, zero, MASKS[mask_name])
+        got = dy.read(np.float32, m.num_rows)[r0:r1]
+        assert np.array_equal(got.view(np.uint32), ref[r0:r1].view(np.uint32)), (sem, mask_name, r0, r1)
+    if op == 0 and mask_name == "NoMask":
+        # ... while the fast layout, on the same inputs, is NOT bit-equal (f64 accumulation in another order) -- and is the
+        # one that is closer to the exactly evaluated product
+        fast = _run_spmv(gpu, m, sem, mask_name, x, mask)
+        exact, _, _ = arith_exact(m, x)
+        nz = exact != 0
+        assert (fast.view(np.uint32) != ref.view(np.uint32)).sum() > 0
+        err_fast = np.abs(fast[nz] - exact[nz]) / np.abs(exact[nz])
+        err_ref = np.abs(ref[nz] - exact[nz]) / np.abs(exact[nz])
+        assert err_fast.max() <= err_ref.max() and err_fast.max() <= 1e-6
+
+
+def test_reference_order_through_the_module(gpu):
+    m = spmv_prepare("uniform_10K_10")
+    rng = np.random.default_rng(23)
+    m.adj_data = rng.random(m.nnz, dtype=np.float32)
+    x = rng.random(m.num_cols, dtype=np.float32)
+    mod = M.SpMVModule(M.num_hbm_channels, 1024, 256)
+    mod.set_semiring(M.ArithmeticSemiring)
+    mod.set_mask_type(M.kNoMask)
+    mod.set_plan_flags(M.capi.GL_PLAN_REFERENCE_ORDER)
+    mod.set_up_runtime()
+    mod.load_and_format_matrix(m, True)
+    mod.send_matrix_host_to_device()
+    mod.send_vector_host_to_device(x)
+    mod.run()
+    got = mod.send_results_device_to_host()
+    ref = O.spmv(to_oracle(m), x, O.MULADD, 0.0)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    mod.set_semiring(M.TropicalSemiring)      # any semiring runs on this layout: no re-format
+    plan = mod.plan_
+    mod.run()
+    assert mod.plan_ is plan
+    ref = O.spmv(to_oracle(m), x, O.ADDMIN, M.FLOAT_INF)
+    assert np.array_equal(mod.send_results_device_to_host().view(np.uint32), ref.view(np.uint32))
