@@ -607,7 +607,8 @@ __global__ __launch_bounds__(256) void spmv_combine_kernel(const uint4 *__restri
 // ---------------------------------------------------------------- GL_PLAN_REFERENCE_ORDER
 // SpMVModule::compute_reference_results (module/spmv_module.h:478-532) evaluated the way the reference writes it: one
 // thread per row, the row's entries in CSR order, a float accumulator that starts at `zero`, a separately rounded float
-// multiply and add per entry (no FMA contraction: __fmul_rn / __fadd_rn), std::min's operand order for (min,+).  The
+// multiply and add per entry (no FMA: `#pragma clang fp contract(off)` -- HIP's __fmul_rn / __fadd_rn are plain `*` / `+`
+// and contract under hipcc's default -ffp-contract=fast, found by the first run of the test), std::min's operand order.  The
 // result is bit-equal to the reference loop BY CONSTRUCTION -- which is the point: the fast layouts differ from it only
 // in the order (and, for (+,x), the width) of the accumulation, and a run on this layout shows that nothing else does.
 template <int OP, int MASK>
@@ -615,17 +616,21 @@ __global__ __launch_bounds__(256) void spmv_reference_order_kernel(const uint32_
                                                                    const float *__restrict__ data, const float *__restrict__ x,
                                                                    const float *__restrict__ mask, float *__restrict__ y, float zero,
                                                                    uint32_t row_begin, uint32_t rows) {
+#pragma clang fp contract(off)
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < rows; i += gridDim.x * 256u) {
         float acc = zero;
         const uint32_t e1 = indptr[i + 1u];
         for (uint32_t e = indptr[i]; e < e1; e++) {
             const float a = data[e], xv = x[indices[e]];
             if (OP == GL_OP_MULADD) {
-                acc = __fadd_rn(acc, __fmul_rn(a, xv));                       // y[r] += data[i] * x[col]  (:495)
+                {
+                    const float prod = a * xv;                                   // y[r] += data[i] * x[col]  (:495)
+                    acc = acc + prod;
+                }
             } else if (OP == GL_OP_ANDOR) {
                 acc = (acc != 0.0f || (a != 0.0f && xv != 0.0f)) ? 1.0f : 0.0f;   // y[r] = y[r] || (data && x)  (:498)
             } else {
-                const float t = __fadd_rn(a, xv);                             // std::min(y[r], data + x) == (t < y) ? t : y  (:501)
+                const float t = a + xv;                                       // std::min(y[r], data + x) == (t < y) ? t : y  (:501)
                 acc = (t < acc) ? t : acc;
             }
         }

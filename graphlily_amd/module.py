@@ -322,6 +322,9 @@ class SpMSpVModule(BaseModule):
         self.plan_.attach_pull(None)
         if plan is None:
             return
+        mine = self.plan_
+        if (plan.num_rows, plan.num_cols, plan.row_begin, plan.row_end) != (mine.num_rows, mine.num_cols, mine.row_begin, mine.row_end):
+            return      # the SpMV module already holds the next matrix; this module attaches when its own is sent
         # boolean layout -> serves (||,&&); general / pattern layout -> (min,+) and, unless GL_PLAN_NO_MULADD, (+,x)
         self.plan_.attach_pull(plan)
 

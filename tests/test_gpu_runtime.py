@@ -59,7 +59,7 @@ def test_pool_best_fit_and_slab_reset(gpu):
     d = capi.DeviceBuffer(1 << 20)
     assert d.ptr not in (pmid, pbig), "a 2 MB block is more than 25 % too large: fresh space instead"
     # many distinct sizes, freed: once the slab is idle its space is carved from the start again (no monotonic growth)
-    sizes = [(3 + 5 * k) << 12 for k in range(200)]
+    sizes = [(3 + k) << 12 for k in range(200)]       # 84 MB: one slab
     bufs = [capi.DeviceBuffer(sz) for sz in sizes]
     first = min(b.ptr for b in bufs)
     for b in bufs + [c, d, anchor]:
