@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--bfs-runs", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for debugging")
     ap.add_argument("--same-gpu", action="store_true", help="debugging: put every rank on cuda:0")
+    ap.add_argument("--emulate-rank", default="",
+                    help="k/N[,k/N...]: after the one-GPU BFS leg, build rank k's row shard of an N-rank run on this GPU and "
+                         "time its bit-frontier BFS schedule with the exchange stubbed (graphlily_amd.dist.EmulatedComm)")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still create the process group and run every collective (one-rank RCCL on one GPU)")
     args = ap.parse_args()
@@ -238,9 +241,13 @@ def main():
     # ------------------------------------------------------------------ BFS GTEPS (same graph)
     if not args.no_bfs:
         try:
-            out["bfs"] = _bench_bfs(app, capi, comm, raw, g["iters"], local_rank, args.bfs_runs, fence)
+            keep = {}
+            out["bfs"] = _bench_bfs(app, capi, comm, raw, g["iters"], local_rank, args.bfs_runs, fence, keep)
+            if args.emulate_rank and world == 1:
+                out["bfs_emulated_ranks"] = _bench_emulated(app, capi, raw, g["iters"], local_rank, args.bfs_runs, args.emulate_rank,
+                                                            keep["bfs"], out["bfs"]["source"])
         except Exception as e:  # never lose the SpMV line because the extra leg failed
-            out["bfs"] = {"error": repr(e)}
+            out.setdefault("bfs", {})["error"] = repr(e)
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -324,7 +331,55 @@ def _pmc_traffic(graph, world, scale):
         return None
 
 
-def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence):
+def _bench_emulated(app, capi, raw, iters, device, runs, specs, whole, source):
+    """One rank at a time of an N-rank row-sharded BFS on THIS GPU (no multi-GPU node is available to the build): rank k's
+    shard plans, the deferred-decision schedule, slice-only read-back; the all-gather of every slot is replaced by copying
+    the other ranks' rows of the frontier from the one-GPU run.  `schedule_ms` = GPU time of the replayed schedule
+    (kernels + the stub copies + launch gaps, HIP events on the library's stream), `wall_ms` = the whole call including
+    the read-back of the rank's slice.  NOT a scaling measurement: the collective is not in it."""
+    from graphlily_amd.dist import EmulatedComm
+    res = []
+    for spec in specs.split(","):
+        k, n_ranks = (int(v) for v in spec.split("/"))
+        comm = EmulatedComm(k, n_ranks)
+        b = app.BFS(16, 0, 0, 0, comm=comm, backend=app.HipBackend(device))
+        b.set_up_runtime()
+        t0 = time.time()
+        b.load_and_format_matrix(raw, True)
+        b.send_matrix_host_to_device()
+        setup = time.time() - t0
+        b.gather_result_ = False
+        entry = {"rank": k, "world": n_ranks, "rows": int(b.r1_ - b.r0_), "shard_nnz": int(b.SpMV_.plan_.info()["nnz"]),
+                 "plan": {kk: b.SpMV_.plan_.info()[kk] for kk in ("blocks", "segments", "num_units")}, "setup_s": round(setup, 2)}
+        for mode in ("pull_push", "pull"):
+            run_whole = (lambda: whole.pull_push(source, iters, 0.001)) if mode == "pull_push" else (lambda: whole.pull(source, iters))
+            fn = (lambda: b.pull_push(source, iters, 0.001)) if mode == "pull_push" else (lambda: b.pull(source, iters))
+            ref = run_whole().copy()
+            st = whole.bits_loop_
+            comm.set_truth(st["vecs"], st["words"])
+            b.time_schedule_ = False
+            for _ in range(3):
+                d = fn()
+            r0, r1 = b.result_range_
+            ok = bool(np.array_equal(d, ref[r0:r1]))
+            walls, sched = [], []
+            for _ in range(runs):
+                capi.sync()
+                b.time_schedule_ = False
+                t0 = time.perf_counter()
+                fn()
+                walls.append(time.perf_counter() - t0)
+                b.time_schedule_ = True
+                fn()
+                sched.append(b.schedule_ms_)
+            entry[mode] = {"schedule_ms": round(float(np.median(sched)), 4), "wall_ms": round(float(np.median(walls)) * 1e3, 4),
+                           "slice_equals_one_gpu_run": ok, "push_iterations": b.push_iterations_}
+        res.append(entry)
+        del b
+    return res
+
+
+def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence, keep=None):
     """bench_bfs.cpp:55-89: 1 warm-up + timed whole-algorithm runs, pull_push threshold 0.001, source 0;
     GTEPS = nnz * iters / t (nominal edges, independent of direction)."""
     t0 = time.time()
@@ -360,6 +415,8 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence):
         if mode == "pull_push":
             res[mode]["push_iterations"] = bfs.push_iterations_
     res.update({"iters": iters, "nnz": nnz, "setup_s": round(setup, 2), "threshold": 0.001, "source": source})
+    if keep is not None:
+        keep["bfs"] = bfs
     return res
 
 

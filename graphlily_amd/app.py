@@ -202,6 +202,12 @@ class BFS(_GraphApp):
         self.SpMSpV_.load_and_format_matrix(csc)
         self.n_ = self.SpMV_.get_num_rows()
         assert self.n_ == self.SpMV_.get_num_cols()
+        if self.comm.distributed:
+            # row shards take the schedule's decisions from GLOBAL lengths (gl_bfs_bits_decide): every rank keeps the two
+            # n-word arrays of the whole matrix
+            self.row_len_ = np.diff(csr.adj_indptr.astype(np.int64)).astype(np.uint32)
+            self.col_len_ = np.diff(csc.adj_indptr.astype(np.int64)).astype(np.uint32)
+            self.nnz_global_ = int(csr.adj_indptr[csr.num_rows])
 
     def send_matrix_host_to_device(self):
         self.SpMV_.send_matrix_host_to_device()
@@ -427,9 +433,17 @@ class BFS(_GraphApp):
         heavy (row-wise) and otherwise takes the push step's decisions.  13 launches for the 6 iterations of the orkut
         stand-in where the list-based schedule above needs 51.  Slot s reads bit vector s and writes vector s + 1.
         The read-back of distances + control words is enqueued behind the schedule (page-locked destination taken from
-        the results the caller has dropped): one wait per run."""
+        the results the caller has dropped): one wait per run.
+
+        ROW SHARDS (comm.distributed) run the same schedule with the decisions deferred (GL_BFS_DEFERRED): the two steps
+        of a slot work on the rank's rows only, ONE all-gather of n/8 bytes rebuilds the slot's output vector on every
+        rank, and gl_bfs_bits_decide takes the slot's decisions from the gathered vector (popcount + global column / row
+        lengths) -- identical on every rank, so the whole run is still enqueued up front: no synchronisation, no
+        device->host copy and no reduction between the first launch and the read-back, and every rank reads back ITS
+        SLICE of the distances (`gather_result_` = True all-gathers them first and returns the whole vector)."""
         B, n, N = self.backend, self.n_, num_iterations
         self.fused_ = True          # (every pull step of this schedule is the fused one, see _bind_pull)
+        sharded = self.comm.distributed
         st = getattr(self, "bits_loop_", None)
         if st is None or st["N"] < N:
             words = (int(self.SpMV_.bits_words()) + 3) & ~3
@@ -440,6 +454,9 @@ class BFS(_GraphApp):
                                     "ctl": B.view(both, n, ctl_words, 4), "distance": B.view(both, 0, n, 4),
                                     "bits": [B.view(vecs, k * words, words, 4) for k in range(nvec)], "graphs": {},
                                     "src": np.zeros(1, np.uint32), "warm": set()}
+            if sharded:
+                st["col_len"] = capi.DeviceBuffer.from_host(self.col_len_)
+                st["row_len"] = capi.DeviceBuffer.from_host(self.row_len_)
         ctl, distance, bits, words = st["ctl"], st["distance"], st["bits"], st["words"]
         # Once the reference's rule has switched to pulling (frontier / n >= threshold, app/bfs.h:180-190), every later slot
         # is handed back to the push step (an extension, see _pull_push_device), which leaves heavy frontiers to the pull
@@ -447,46 +464,89 @@ class BFS(_GraphApp):
         # this schedule is one short launch, so this pays on all six stand-ins (same-box sweep: hollywood 0.47 -> 0.41 ms).
         back = 0.0 if pull_only else float(os.environ.get("GRAPHLILY_BFS_BACK", "1.0"))
         csc_plan, pull_plan = self.SpMSpV_.plan_, self.SpMV_.plan_
+        deferred = capi.GL_BFS_DEFERRED if sharded else 0
 
         def schedule():
             capi.bfs_bits_begin(ctl, st["ctl_words"], distance, n, st["vecs"], words, st["nvec"], 0 if pull_only else 0xffffffff)
             for it in range(1, N + 1):
-                may = (1 if it + 1 < N else 0) | (2 if it + 1 <= N else 0)
+                may = (1 if it + 1 < N else 0) | (2 if it + 1 <= N else 0) | deferred
                 # (pull_only: never scatters, but the launch is also the bottom-up pull of the late slots)
                 capi.bfs_bits_push_step(csc_plan, pull_plan, bits[it], bits[it + 1], None, words, distance, float(it + 1), ctl, it,
                                         threshold, may)
                 # (also in the first slot, which always pushes: the gated-off pull step takes the push step's decisions)
                 capi.bfs_bits_pull_step(pull_plan, csc_plan, bits[it], bits[it + 1], distance, float(it + 1), ctl, it, threshold,
                                         may, back)
+                if sharded:
+                    self._exchange_bits(st, it + 1)
+                    capi.bfs_bits_decide(csc_plan, bits[it + 1], st["col_len"], st["row_len"], self.nnz_global_, ctl, it, threshold,
+                                         may, back)
 
         st["src"][0] = source
         B.upload(B.view(ctl, 2, 1, 4), st["src"])        # ctl[2] = source: the one host->device word per run
         key = (N, float(threshold), back, pull_only)
         g = st["graphs"].get(key)
-        if g is None and os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0" and key in st["warm"]:
+        # (a torch.distributed collective is not recorded by the library's capture: those runs are enqueued call by call)
+        capturable = not sharded or getattr(self.comm, "capturable", False)
+        if g is None and capturable and os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0" and key in st["warm"]:
             try:
                 with capi.Graph.capture() as g:
                     schedule()
                 st["graphs"][key] = g
             except capi.GraphLilyError:
                 g = st["graphs"][key] = False              # capture not possible here: keep enqueueing
+        timed = getattr(self, "time_schedule_", False)      # bench: GPU time of the schedule without the read-back
+        if timed:
+            capi.span_begin()
         if g:
             g.launch()
         else:
             schedule()
             st["warm"].add(key)
-        out = capi.pinned_recycled(n + st["ctl_words"], np.float32)
-        st["both"].read_async(out)
-        B.sync()
-        c = out[n:].view(np.uint32)
+        if timed:
+            self.schedule_ms_ = capi.span_end()
+        cw = st["ctl_words"]
+        if sharded and not getattr(self, "gather_result_", True):
+            # this rank's slice of the distances + the control words: two copies behind the schedule, one wait
+            own = self.r1_ - self.r0_
+            out = capi.pinned_recycled(own + cw, np.float32)
+            st["both"].read_async(out[:own], 4 * self.r0_)
+            st["both"].read_async(out[own:], 4 * n)
+            B.sync()
+            res, c = out[:own], out[own:].view(np.uint32)
+            self.result_range_ = (self.r0_, self.r1_)
+        else:
+            if sharded:
+                self.comm.all_gather_slices(st["both"].tensor[:n] if st["both"].tensor is not None else st["both"], self.bounds_)
+            out = capi.pinned_recycled(n + cw, np.float32)
+            st["both"].read_async(out)
+            B.sync()
+            res, c = out[:n], out[n:].view(np.uint32)
+            self.result_range_ = (0, n)
         self.push_iterations_ = int(c[1])          # the reference's count (first push phase)
         self.push_iterations_again_ = int(c[3])    # pushes after a pull step handed back
         self.bfs_slot_counts_ = c[17:17 + N].copy()   # vertices reached per slot
-        return out[:n]
+        return res
+
+    def _exchange_bits(self, st, k):
+        """The one exchange step of a sharded slot: every rank's rows of bit vector k to every rank."""
+        comm = self.comm
+        if hasattr(comm, "exchange_bits"):                 # the C-ABI communicator (gl_dist_*) or the one-GPU emulation
+            comm.exchange_bits(st["bits"][k], k, self.bounds_)
+            return
+        t = st["vecs"].tensor[k * st["words"]:(k + 1) * st["words"]]
+        comm.all_gather_slices(t, [b // 32 for b in self.bounds_])
 
     def _bits_loop_ok(self):
-        return (self._device_loop_ok() and os.environ.get("GRAPHLILY_BFS_BITS", "1") != "0"
-                and os.environ.get("GRAPHLILY_BFS_FUSED", "1") != "0" and hasattr(capi, "bfs_bits_push_step") and self.SpMV_.plan_ is not None and self.SpMSpV_.plan_ is not None)
+        if os.environ.get("GRAPHLILY_BFS_BITS", "1") == "0" or os.environ.get("GRAPHLILY_BFS_FUSED", "1") == "0":
+            return False
+        if not hasattr(capi, "bfs_bits_push_step") or getattr(self.SpMV_, "plan_", None) is None or getattr(self.SpMSpV_, "plan_", None) is None:
+            return False
+        if self.comm.distributed:
+            # any boolean plan whose row range is cut on multiples of 64 rows (split plans claim rows with atomics)
+            return (os.environ.get("GRAPHLILY_BFS_DEVICE_LOOP", "1") != "0" and hasattr(self.SpMV_, "bits_words")
+                    and self.SpMV_.bits_words() > 0 and self.SpMV_.semiring_.zero == 0.0
+                    and all(b % 64 == 0 for b in self.bounds_[:-1]))
+        return self._device_loop_ok()
 
     def pull_push(self, source, num_iterations, threshold=0.05):
         if self._bits_loop_ok():

@@ -31,7 +31,7 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
-    "gl_bfs_bits_begin", "gl_bfs_bits_push_step", "gl_bfs_bits_pull_step",
+    "gl_bfs_bits_begin", "gl_bfs_bits_push_step", "gl_bfs_bits_pull_step", "gl_bfs_bits_decide",
     "gl_buf_d2h_async",
     "gl_bfs_begin", "gl_spmspv_plan_frontier_bits", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
     "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32", "gl_dist_all_gather_bits",
@@ -42,7 +42,7 @@ EXPORTS = [
     "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim", "gl_pool_stats",
     "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_helper", "gl_spmv_plan_layout", "gl_spmv_plan_export", "gl_spmv_run",
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits", "gl_bfs_pull_step",
-    "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every",
+    "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every", "gl_span_begin", "gl_span_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run", "gl_spmspv_run_assign",
     "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_plan_hint_tiny", "gl_spmspv_last_direction",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
@@ -85,6 +85,7 @@ def lib():
         "gl_buf_d2h_async": [vp, vp, ctypes.c_size_t],
         "gl_bfs_bits_push_step": [vp, vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
         "gl_bfs_bits_pull_step": [vp, vp, vp, vp, vp, f32, vp, u32, f32, i32, f32],
+        "gl_bfs_bits_decide": [vp, vp, vp, vp, u64, vp, u32, f32, i32, f32],
         "gl_spmspv_run_gated": [vp, vp, vp, vp, i32, f32, i32, vp, f32, vp, vp, u32, i32, vp, u32, f32, i32],
         "gl_bfs_pull_step_gated": [vp, vp, vp, vp, f32, vp, u32, i32],
         "gl_spmspv_plan_frontier_bits": [vp, vp],
@@ -114,7 +115,7 @@ def lib():
         "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
         "gl_bfs_pull_step": [vp, vp, vp, vp, f32],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
-        "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)], "gl_prof_sample_every": [u32],
+        "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)], "gl_prof_sample_every": [u32], "gl_span_begin": [], "gl_span_end": [P(ctypes.c_double)],
         "gl_spmspv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmspv_plan_destroy": [vp], "gl_spmspv_plan_info": [vp, P(u64), P(u64)],
         "gl_spmspv_run": [vp, vp, vp, vp, i32, f32, i32],
@@ -605,6 +606,15 @@ def bfs_bits_pull_step(pull_plan, csc_plan, bits_in, bits_out, distance, level, 
                                       float(back_threshold)))
 
 
+GL_BFS_DEFERRED = 4
+
+
+def bfs_bits_decide(csc_plan, bits_next, col_len, row_len, nnz_global, ctl, slot, threshold, may_continue, back_threshold):
+    """gl_bfs_bits_decide: the slot's decisions of a row-sharded schedule, from the all-gathered next frontier."""
+    check(lib().gl_bfs_bits_decide(ctypes.c_void_p(csc_plan.handle), _p(bits_next), _p(col_len), _p(row_len), int(nnz_global), _p(ctl),
+                                   int(slot), float(threshold), int(may_continue), float(back_threshold)))
+
+
 def bfs_begin(ctl, distance, n, frontier, bits, bits_words):
     check(lib().gl_bfs_begin(_p(ctl), _p(distance), int(n), _p(frontier), _p(bits), int(bits_words)))
 
@@ -624,6 +634,17 @@ def prof_end():
     ms, n = ctypes.c_double(0.0), ctypes.c_uint32(0)
     check(lib().gl_prof_end(ctypes.byref(ms), ctypes.byref(n)))
     return ms.value, n.value
+
+
+def span_begin():
+    check(lib().gl_span_begin())
+
+
+def span_end():
+    """-> GPU milliseconds between span_begin() and here on the library's stream (waits for the work in between)."""
+    ms = ctypes.c_double(0.0)
+    check(lib().gl_span_end(ctypes.byref(ms)))
+    return ms.value
 
 
 def sparse_nnz(buf):

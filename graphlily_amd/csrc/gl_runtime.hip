@@ -259,6 +259,27 @@ int gl_prof_end(double *total_ms, uint32_t *launches) {
     return GL_OK;
 }
 
+// ---- GPU time of whatever is enqueued between the two calls (one event pair on the library's stream)
+static hipEvent_t g_span[2] = {nullptr, nullptr};
+int gl_span_begin(void) {
+    GL_REQUIRE_INIT();
+    for (hipEvent_t &e : g_span)
+        if (!e) GL_HIP(hipEventCreate(&e));
+    GL_HIP(hipEventRecord(g_span[0], gl::ctx().stream));
+    return GL_OK;
+}
+
+int gl_span_end(double *ms) {
+    GL_REQUIRE_INIT();
+    GL_ARG(ms != nullptr && g_span[1] != nullptr);
+    GL_HIP(hipEventRecord(g_span[1], gl::ctx().stream));
+    GL_HIP(hipEventSynchronize(g_span[1]));
+    float t = 0.0f;
+    GL_HIP(hipEventElapsedTime(&t, g_span[0], g_span[1]));
+    *ms = t;
+    return GL_OK;
+}
+
 // ---- hipGraph capture of a launch sequence on the library's stream
 int gl_graph_begin_capture(void) {
     GL_REQUIRE_INIT();

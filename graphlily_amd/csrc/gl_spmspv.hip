@@ -364,9 +364,14 @@ struct BfsPushArgs {
     float level;
     uint32_t *acc;           // kBfsAccSlots x 32 words, zero between steps: [0] new vertices, [2..3] their column lengths,
                              // [6..7] their row lengths ([4]: the pull step's per-line ticket)
-    const uint32_t *row_ptr; // the rows as plain CSR (whole-matrix boolean SpMV plan of the same matrix), or null:
+    const uint32_t *row_ptr; // the rows as plain CSR (boolean SpMV plan of the same matrix and shard), or null:
     const uint32_t *row_idx; //   row lengths for the bookkeeping, and the bottom-up branch
     uint32_t num_rows;
+    // row shard [row_begin, row_end): row_ptr is indexed by row - row_begin and holds GLOBAL offsets, row_idx is indexed by
+    // offset - nz_base.  deferred: the step keeps no totals and takes no decision -- a shard's counts are partial; the driver
+    // all-gathers the next frontier and runs gl_bfs_bits_decide on it
+    uint32_t row_begin, row_end, nz_base;
+    bool deferred;
     BfsBitsCtl c;
 };
 
@@ -377,9 +382,10 @@ __device__ __forceinline__ void bfs_claim(const BfsPushArgs &a, bool cand, uint3
     const uint32_t old = atomicOr(&a.bits_out[row >> 5], m);
     if (old & m) return;
     a.dist[row] = a.level;
+    if (a.deferred) return;
     fresh += 1u;
     if (row < a.num_cols) work += a.indptr[row + 1u] - a.indptr[row];
-    if (a.row_ptr) work_rows += a.row_ptr[row + 1u] - a.row_ptr[row];
+    if (a.row_ptr) work_rows += a.row_ptr[row - a.row_begin + 1u] - a.row_ptr[row - a.row_begin];
 }
 // candidate = the product a && x is true and the mask (distance == 0: not visited, app/bfs.h:146) lets it through
 __device__ __forceinline__ bool bfs_candidate(const BfsPushArgs &a, bool valid, uint2 rv) {
@@ -413,14 +419,15 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
         // a thread per row not reached yet looks through the row, four entries per step, until it finds a neighbour in the
         // frontier; 64 rows per wavefront = one word of the next frontier.  Same result as the streaming pull step
         // (masked (||,&&) SpMV + assign, app/bfs.h:118-123), at the cost of the unreached rows instead of the matrix.
-        const uint32_t nwords64 = (a.num_rows + 63u) >> 6;
-        for (uint32_t wd = blockIdx.x * 4u + wave; wd < nwords64; wd += gridDim.x * 4u) {
+        // (shard bounds are multiples of 64 rows: every 64-bit word of the next frontier has one writer)
+        const uint32_t nwords64 = (a.row_end + 63u) >> 6;
+        for (uint32_t wd = (a.row_begin >> 6) + blockIdx.x * 4u + wave; wd < nwords64; wd += gridDim.x * 4u) {
             const uint32_t row = wd * 64u + lane;
-            const bool live = row < a.num_rows && a.dist[row] == 0.0f;
+            const bool live = row < a.row_end && a.dist[row] == 0.0f;
             uint32_t beg = 0, end = 0;
             if (live) {
-                beg = a.row_ptr[row];
-                end = a.row_ptr[row + 1u];
+                beg = a.row_ptr[row - a.row_begin] - a.nz_base;
+                end = a.row_ptr[row - a.row_begin + 1u] - a.nz_base;
             }
             const uint32_t len = end - beg;
             bool hit = false;
@@ -456,9 +463,11 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
             }
             if (hit) {
                 a.dist[row] = a.level;
-                fresh += 1u;
-                work_rows += len;
-                if (row < a.num_cols) work += a.indptr[row + 1u] - a.indptr[row];
+                if (!a.deferred) {
+                    fresh += 1u;
+                    work_rows += len;
+                    if (row < a.num_cols) work += a.indptr[row + 1u] - a.indptr[row];
+                }
             }
             const uint64_t m = __ballot(hit);
             if (lane == 0) reinterpret_cast<uint64_t *>(a.bits_out)[wd] = m;
@@ -552,6 +561,7 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
         __syncthreads();
     }
     }   // scatter
+    if (a.deferred) return;
     // totals of the step
     unsigned long long work64 = work, rows64 = work_rows;
 #pragma unroll
@@ -575,6 +585,90 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
         atomicAdd(line, s_fresh);
         atomicAdd(reinterpret_cast<unsigned long long *>(line + 2), s_work);
         if (s_work_rows) atomicAdd(reinterpret_cast<unsigned long long *>(line + 6), s_work_rows);
+    }
+}
+
+// ------------------------------------------------------------------ the slot's decisions of a ROW-SHARDED schedule
+// (gl_bfs_bits_decide).  A shard sees only its own rows of the new frontier, so its steps keep no totals (deferred);
+// after the all-gather every rank holds the whole bit vector and takes the decisions from IT: vertices reached =
+// popcount, the next push's work = sum of their GLOBAL column lengths, non-zeros in their rows = sum of their global row
+// lengths -- the same three numbers the one-GPU steps accumulate, hence the same decisions (the reference's loop
+// condition, app/bfs.h:180-190) on every rank.  The last workgroup (ticket) adds up the 64 accumulator lines.
+struct BfsDecideArgs {
+    const uint32_t *bits;       // the gathered next frontier
+    uint32_t n;
+    const uint32_t *col_len;    // n global column lengths (the CSC of the WHOLE matrix)
+    const uint32_t *row_len;    // n global row lengths, or null
+    uint32_t *acc;              // kBfsAccSlots x 32 words, zero between launches; [4] of line 0 is the ticket
+    BfsBitsCtl c;
+};
+
+__global__ __launch_bounds__(256) void bfs_bits_decide_kernel(BfsDecideArgs a) {
+    __shared__ uint32_t s_fresh, s_last;
+    __shared__ unsigned long long s_work, s_rows;
+    if (threadIdx.x == 0) {
+        s_fresh = 0u;
+        s_work = 0ull;
+        s_rows = 0ull;
+    }
+    __syncthreads();
+    const uint32_t nw = (a.n + 31u) >> 5;
+    uint32_t fresh = 0u;
+    unsigned long long work = 0ull, rows = 0ull;
+    if (!a.c.finished()) {
+        for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < nw; w += gridDim.x * 256u) {
+            uint32_t m = a.bits[w];
+            fresh += (uint32_t)__popc(m);
+            while (m) {
+                const uint32_t v = w * 32u + (uint32_t)__ffs(m) - 1u;
+                m &= m - 1u;
+                if (v < a.n) {
+                    work += a.col_len[v];
+                    if (a.row_len) rows += a.row_len[v];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        fresh += __shfl_down(fresh, d);
+        work += __shfl_down(work, d);
+        rows += __shfl_down(rows, d);
+    }
+    if ((threadIdx.x & 63u) == 0u && fresh) {
+        atomicAdd(&s_fresh, fresh);
+        atomicAdd(&s_work, work);
+        atomicAdd(&s_rows, rows);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t *line = a.acc + 32u * (blockIdx.x & (kBfsAccSlots - 1u));
+        if (s_fresh) {
+            atomicAdd(line, s_fresh);
+            atomicAdd(reinterpret_cast<unsigned long long *>(line + 2), s_work);
+            if (s_rows) atomicAdd(reinterpret_cast<unsigned long long *>(line + 6), s_rows);
+        }
+        __threadfence();
+        s_last = atomicAdd(a.acc + 4, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64u) {
+        __threadfence();
+        uint32_t *ln = a.acc + 32u * threadIdx.x;
+        uint32_t total = __hip_atomic_load(ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long wk = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ln + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long wr = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ln + 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ln[0] = 0u;
+        *reinterpret_cast<unsigned long long *>(ln + 2) = 0ull;
+        *reinterpret_cast<unsigned long long *>(ln + 6) = 0ull;
+        if (threadIdx.x == 0) ln[4] = 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            total += __shfl_down(total, d);
+            wk += __shfl_down(wk, d);
+            wr += __shfl_down(wr, d);
+        }
+        if (threadIdx.x == 0) a.c.decide(total, wk, wr);
     }
 }
 
@@ -1311,8 +1405,11 @@ int gl_bfs_bits_push_step(gl_spmspv_plan p, gl_spmv_plan rows, const uint32_t *d
     GL_ARG((uint64_t)bits_words * 32u >= p->num_cols && (uint64_t)bits_words * 32u >= p->num_rows);
     // the bottom-up branch writes the next frontier as whole 64-bit words
     GL_ARG((bits_words & 1u) == 0 && (((uintptr_t)d_bits_in | (uintptr_t)d_bits_out) & 7u) == 0);
-    if (p->row_begin != 0 || p->row_end != p->num_rows)
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_push_step: row shards decide on the host (their frontier counts are partial)");
+    const bool deferred = (may_continue & GL_BFS_DEFERRED) != 0;
+    if ((p->row_begin != 0 || p->row_end != p->num_rows) && !deferred)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_push_step: a row shard's frontier counts are partial -- pass GL_BFS_DEFERRED "
+                             "in may_continue and take the slot's decisions with gl_bfs_bits_decide after the all-gather");
+    GL_ARG((p->row_begin & 63u) == 0u && (p->row_end == p->num_rows || (p->row_end & 63u) == 0u));
     gl::BfsPushArgs a;
     a.indptr = p->d_indptr;
     a.stream = p->d_stream;
@@ -1328,20 +1425,54 @@ int gl_bfs_bits_push_step(gl_spmspv_plan p, gl_spmv_plan rows, const uint32_t *d
     a.level = level;
     a.acc = p->d_bfs_acc;
     const bool have_rows = rows != nullptr && rows->d_csr_indptr != nullptr && rows->num_rows == p->num_rows &&
-                           rows->num_cols == p->num_cols && rows->row_begin == 0 && rows->row_end == rows->num_rows;
+                           rows->num_cols == p->num_cols && rows->row_begin == p->row_begin && rows->row_end == p->row_end;
     p->bfs_rows_plan = have_rows ? rows : nullptr;
     a.row_ptr = have_rows ? rows->d_csr_indptr : nullptr;
     a.row_idx = have_rows ? rows->d_csr_indices : nullptr;
     a.num_rows = p->num_rows;
+    a.row_begin = p->row_begin;
+    a.row_end = p->row_end;
+    a.nz_base = have_rows ? rows->csr_nz_base : 0u;
+    a.deferred = deferred;
     a.c.ctl = d_ctl;
     a.c.slot = slot;
     a.c.n = p->num_rows ? p->num_rows : 1u;
-    a.c.may_continue = (uint32_t)may_continue;
+    a.c.may_continue = (uint32_t)may_continue & 3u;
     a.c.threshold = threshold;
     a.c.back_threshold = 0.0f;
     a.c.heavy = gl::spmspv_heavy_work(p);
     uint32_t grid = std::min<uint32_t>((uint32_t)gl::ctx().num_cus * 8u, std::max<uint32_t>(gl::cdiv(a.col_words, 8), 1u));
     gl::bfs_push_bits_kernel<<<grid, 256, 0, gl::ctx().stream>>>(a);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int gl_bfs_bits_decide(gl_spmspv_plan p, const uint32_t *d_bits_next, const uint32_t *d_col_len, const uint32_t *d_row_len,
+                       uint64_t nnz_global, uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue, float back_threshold) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && d_bits_next != nullptr && d_col_len != nullptr);
+    GL_ARG(d_ctl != nullptr && slot >= 1u && ((uintptr_t)d_ctl & 7u) == 0);
+    gl::BfsDecideArgs a;
+    a.bits = d_bits_next;
+    a.n = p->num_rows;
+    a.col_len = d_col_len;
+    a.row_len = d_row_len;
+    a.acc = p->d_bfs_acc;
+    a.c.ctl = d_ctl;
+    a.c.slot = slot;
+    a.c.n = p->num_rows ? p->num_rows : 1u;
+    a.c.may_continue = (uint32_t)may_continue & 3u;
+    a.c.threshold = threshold;
+    a.c.back_threshold = back_threshold;
+    // the GLOBAL matrix decides: a shard's push costs its share of the frontier's columns, its pull its share of the stream
+    const long hdiv = gl::env_long("GRAPHLILY_BFS_HEAVY_DIV", 128), bdiv = gl::env_long("GRAPHLILY_BFS_BU_DIV", 3);
+    a.c.heavy = hdiv > 0 ? nnz_global / (unsigned long long)hdiv : ~0ull;
+    a.c.nnz_rows = nnz_global;
+    // bottom-up slots need the rows on every rank: the push step of this slot (enqueued before) recorded whether it has them
+    a.c.bu_limit = (d_row_len != nullptr && p->bfs_rows_plan != nullptr && bdiv > 0) ? nnz_global / (unsigned long long)bdiv : 0ull;
+    const uint32_t nw = gl::cdiv(p->num_rows, 32);
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(gl::cdiv(nw, 256 * 4), 256u));
+    gl::bfs_bits_decide_kernel<<<grid, 256, 0, gl::ctx().stream>>>(a);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

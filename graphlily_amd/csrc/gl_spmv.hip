@@ -1735,13 +1735,16 @@ int gl_bfs_bits_pull_step(gl_spmv_plan p, gl_spmspv_plan csc, const uint32_t *d_
     GL_ARG((((uintptr_t)d_bits_in | (uintptr_t)d_bits_out) & 15u) == 0);
     if (!p->boolean)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_pull_step: the plan does not hold the GL_PLAN_BOOLEAN layout");
-    if (p->row_begin != 0 || p->row_end != p->num_rows || !gl::spmspv_plan_whole(csc, p->num_rows))
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_pull_step: row shards decide on the host (their frontier counts are partial)");
+    const bool deferred = (may_continue & GL_BFS_DEFERRED) != 0;
+    const bool whole = p->row_begin == 0 && p->row_end == p->num_rows && gl::spmspv_plan_whole(csc, p->num_rows);
+    if (!whole && !deferred)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_pull_step: a row shard's frontier counts are partial -- pass GL_BFS_DEFERRED "
+                             "in may_continue and take the slot's decisions with gl_bfs_bits_decide after the all-gather");
     gl::BfsBitsCtl c;
     c.ctl = d_ctl;
     c.slot = slot;
     c.n = p->num_rows ? p->num_rows : 1u;
-    c.may_continue = (uint32_t)may_continue;
+    c.may_continue = (uint32_t)may_continue & 3u;
     c.threshold = threshold;
     c.back_threshold = back_threshold;
     c.heavy = gl::spmspv_heavy_work(csc);
@@ -1749,10 +1752,10 @@ int gl_bfs_bits_pull_step(gl_spmv_plan p, gl_spmspv_plan csc, const uint32_t *d_
     c.bu_limit = (p->d_csr_indptr && gl::spmspv_plan_bfs_rows(csc) == p) ? gl::spmspv_bottom_up_limit(csc) : 0ull;
     // the new frontier's column lengths decide the direction of the NEXT slot's push: of no use to a schedule that never pushes
     const bool only_pulls = threshold < 0.0f;   // BFS.pull: gl_bfs_bits_begin(first_pull_slot = 0)
-    const bool may_push = (may_continue & 2) != 0 && !only_pulls;
+    const bool may_push = (may_continue & 2) != 0 && !only_pulls && !deferred;
     return gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, gl::ctx().stream, nullptr, 0u, GL_GATE_EQ, nullptr, 0u, 0.0f, 0,
                                   &c, may_push ? gl::spmspv_plan_indptr(csc) : nullptr, gl::spmspv_plan_num_cols(csc),
-                                  gl::spmspv_plan_bfs_acc(csc));
+                                  gl::spmspv_plan_bfs_acc(csc), deferred);
 }
 
 int gl_spmv_plan_export(gl_spmv_plan p, int array, void *h_dst, size_t capacity, size_t *bytes) {

@@ -51,6 +51,9 @@ struct BoolArgs {
     uint32_t v2_ncols = 0;
     uint32_t *v2_push_acc = nullptr;       // totals of the slot's push step (64 lines of 32 words), when that one ran
     const uint32_t *v2_rowptr = nullptr;   // row pointers of this plan's own CSR copy (row lengths: the bottom-up bookkeeping)
+    // row-sharded schedule: the launch runs or not by the same control words, but keeps no totals and decides nothing
+    // (gl_bfs_bits_decide does, on the all-gathered frontier)
+    bool v2_deferred = false;
 };
 
 // x != 0 packed little-endian, 64 columns per wavefront step; words past num_cols are zero
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         // the slot's push step ran (it is enqueued in front of this launch) -- scattering, or as the bottom-up pull: add up
         // its totals and take its decisions.  decide() does not change what scatters() / bottom_up() say about THIS slot,
         // so the other workgroups may look later.
-        if (blockIdx.x == 0 && threadIdx.x < 64u) {
+        if (!a.v2_deferred && blockIdx.x == 0 && threadIdx.x < 64u) {
             uint32_t *line = a.v2_push_acc + 32u * threadIdx.x;
             uint32_t fresh = line[0];
             unsigned long long work = *reinterpret_cast<unsigned long long *>(line + 2);
@@ -222,7 +225,19 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         __syncthreads();
     }
 
-    if (FUSED) {
+    if (FUSED == 2) {
+        // The same step for SPLIT plans (several units share a block's rows, each with a part of the columns) and only inside
+        // the bit-frontier schedule, whose next-frontier vector starts all zero: a row this unit reached whose distance is
+        // still 0 sets its bit, and the unit whose atomicOr set it first writes the level -- as the push step does.  (A unit
+        // that reads a distance another unit has just written sees `level`, not 0, and leaves the row alone: same result.)
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
+            if (!((tile[i >> 5] >> (i & 31u)) & 1u)) continue;
+            const uint32_t row = row0 + i;
+            if (a.dist[row] != 0.0f) continue;
+            const uint32_t m = 1u << (row & 31u);
+            if (!(atomicOr(&a.bits_out[row >> 5], m) & m)) a.dist[row] = a.level;
+        }
+    } else if (FUSED) {
         // SpMV masked by `distance == 0`, eWiseAdd(+0), assign(level) where the result is set, and the packing of
         // the next frontier (app/bfs.h:118-123) in one epilogue: 64 rows per wavefront step, one 64-bit word out.
         // Blocks of boolean plans start on multiples of 64 rows, so every word has exactly one writer.
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                 }
             }
         }
-        if (a.v2.ctl) {
+        if (a.v2.ctl && !a.v2_deferred) {
             __shared__ uint32_t v2_fresh_s, v2_last_s;
             __shared__ unsigned long long v2_work_s, v2_rows_s;
             if (threadIdx.x == 0) {
@@ -432,10 +447,13 @@ static int launch_bool(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
 int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s,
                        const uint32_t *gate, uint32_t gate_value, int gate_op, uint32_t *back_ctl, uint32_t back_slot,
                        float back_threshold, int back_may_continue, const BfsBitsCtl *v2, const uint32_t *v2_indptr, uint32_t v2_ncols,
-                       uint32_t *v2_push_acc) {
+                       uint32_t *v2_push_acc, bool v2_deferred) {
     if (p->row_end == p->row_begin) return GL_OK;
-    if (p->segments > 1 || (p->row_begin & 63u) || !p->nunits)
+    // split plans: only inside the bit-frontier schedule (the claiming epilogue needs an all-zero output vector)
+    const bool claim = p->segments > 1 && v2 != nullptr;
+    if ((p->segments > 1 && !claim) || (p->row_begin & 63u))
         return set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step: needs an unsplit boolean plan whose shard starts on a multiple of 64 rows");
+    if (!p->nunits) return GL_OK;   // no stored entry in this shard: nothing is reached here
     BoolArgs a;
     a.entries = p->d_entries;
     a.bases = p->d_bases;
@@ -463,9 +481,15 @@ int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_o
         a.v2_indptr = v2_indptr;
         a.v2_ncols = v2_ncols;
         a.v2_push_acc = v2_push_acc;
-        a.v2_rowptr = p->d_csr_indptr;
+        a.v2_rowptr = v2_deferred ? nullptr : p->d_csr_indptr;
+        a.v2_deferred = v2_deferred;
     }
     a.tickets = bool_tickets();
+    if (claim) {
+        if (!v2_deferred)
+            return set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_pull_step: a split plan keeps no totals -- run it with GL_BFS_DEFERRED");
+        return launch_bool_variant<GL_NOMASK, 2>(p, a, s);
+    }
     return launch_bool_variant<GL_NOMASK, 1>(p, a, s);
 }
 
@@ -603,8 +627,9 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
         eb.num_cols = num_cols;
         uint32_t tallest = 0;
         if ((rc = fmt_emit_bool(staged.c, eb, p, &tallest)) != GL_OK) return rc;
-        if (row_begin == 0 && row_end == p->num_rows && env_long("GRAPHLILY_BFS_KEEP_ROWS", 1) != 0) {
+        if (env_long("GRAPHLILY_BFS_KEEP_ROWS", 1) != 0) {
             if ((rc = devcsr_adopt_rows(staged.c, &p->d_csr_indptr, &p->d_csr_indices)) != GL_OK) return rc;
+            p->csr_nz_base = h_indptr[row_begin];
             p->device_bytes += ((size_t)rows + 1u) * 4u + (size_t)p->nnz * 4u;
         }
         p->boolean = true;
@@ -771,14 +796,16 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
     p->b_spans = spans.size() * sizeof(uint4);
     GL_HIP(hipMalloc((void **)&p->d_xbits, (size_t)nphases * kBoolPhaseWords * 4u));
     p->device_bytes += (size_t)nphases * kBoolPhaseWords * 4u;
-    if (row_begin == 0 && row_end == p->num_rows && env_long("GRAPHLILY_BFS_KEEP_ROWS", 1) != 0) {
+    if (env_long("GRAPHLILY_BFS_KEEP_ROWS", 1) != 0) {
         // the rows as plain CSR for the bottom-up BFS step (see gl_spmv_plan.h); zero values -> column 0xffffffff
-        std::vector<uint32_t> cols(h_indices, h_indices + p->nnz);
+        const uint64_t nz0 = h_indptr[row_begin];
+        std::vector<uint32_t> cols(h_indices + nz0, h_indices + nz0 + p->nnz);
         for (uint64_t i = 0; i < p->nnz; i++)
-            if (h_data[i] == 0.0f) cols[i] = 0xffffffffu;
-        if ((rc = up((void **)&p->d_csr_indptr, h_indptr, ((size_t)rows + 1u) * 4u)) != GL_OK ||
+            if (h_data[nz0 + i] == 0.0f) cols[i] = 0xffffffffu;
+        if ((rc = up((void **)&p->d_csr_indptr, h_indptr + row_begin, ((size_t)rows + 1u) * 4u)) != GL_OK ||
             (rc = up((void **)&p->d_csr_indices, cols.data(), cols.size() * 4u)) != GL_OK)
             return rc;
+        p->csr_nz_base = (uint32_t)nz0;
     }
     return GL_OK;
 }

@@ -125,7 +125,10 @@ struct gl_spmv_plan_s {
     uint32_t *d_xbits = nullptr;   // nphases * kBoolPhaseWords words
     // whole-matrix boolean plans also keep the rows as plain CSR (4 B per non-zero more): gl_bfs_bits_push_step's bottom-up
     // branch scans the rows a BFS has not reached yet; zero-valued entries carry the column 0xffffffff
+    // (row shards keep theirs too: d_csr_indptr[r - row_begin] are offsets into the WHOLE matrix' entry list, of which
+    // d_csr_indices holds the shard's part starting at csr_nz_base)
     uint32_t *d_csr_indptr = nullptr, *d_csr_indices = nullptr;
+    uint32_t csr_nz_base = 0;
     // GL_PLAN_REFERENCE_ORDER: the shard's plain CSR (indptr rebased to 0, values kept), evaluated a thread per row in
     // the reference's own order -- a diagnostic layout, not a fast one
     bool reference_order = false;
@@ -192,7 +195,7 @@ int pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits, hipStream_t s);
 int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s,
                        const uint32_t *gate = nullptr, uint32_t gate_value = 0, int gate_op = GL_GATE_EQ, uint32_t *back_ctl = nullptr,
                        uint32_t back_slot = 0, float back_threshold = 0.0f, int back_may_continue = 0, const BfsBitsCtl *v2 = nullptr,
-                       const uint32_t *v2_indptr = nullptr, uint32_t v2_ncols = 0, uint32_t *v2_push_acc = nullptr);
+                       const uint32_t *v2_indptr = nullptr, uint32_t v2_ncols = 0, uint32_t *v2_push_acc = nullptr, bool v2_deferred = false);
 int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s, const uint32_t *xbits = nullptr);
 // gl_apply.hip: the set bits of d_bits[0..n) as a sparse list {row, 1} with head {count, 0}; no-op unless *gate_word == gate_value
 int bits_to_sparse_gated(const uint32_t *d_bits, uint32_t n, gl_idx_val *d_out, uint32_t *d_counts, const uint32_t *gate_word,

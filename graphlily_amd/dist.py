@@ -130,3 +130,66 @@ class Comm:
     def barrier(self):
         if self.distributed:
             self.dist.barrier(group=self.group)
+
+
+class EmulatedComm:
+    """ONE rank of a `world_size`-rank row-sharded run on ONE GPU, with the exchange step stubbed: no 8-GPU node is
+    available to this build, so the per-rank work of the sharded schedules is measured this way (bench.py
+    --emulate-rank k/N).  The other ranks' rows of every exchanged bit vector are copied from the vectors of a
+    whole-matrix run of the same BFS on the same GPU (`set_truth`: slot s of the bit-frontier schedule writes vector
+    s + 1 = the vertices at distance s + 1, whatever the sharding) -- two device-to-device copies of at most n/8 bytes
+    where a real run has RCCL's all-gather -- so the rank's kernels see exactly the frontiers, and take exactly the
+    decisions, of a real N-rank run.  What is NOT measured: the collective itself (tabulated separately)."""
+    emulated = True
+    capturable = True          # plain device-to-device copies: the schedule can be recorded as a hipGraph
+    group = None
+
+    def __init__(self, rank, world_size):
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.truth = None
+
+    @property
+    def distributed(self):
+        return True
+
+    def set_truth(self, vecs_buf, words):
+        """vecs_buf: the (N + 2) x words bit vectors a whole-matrix BFS._pull_push_bits left behind (device)."""
+        self.truth, self.truth_words = vecs_buf, int(words)
+
+    def exchange_bits(self, bits_buf, k, bounds):
+        from . import capi
+        assert self.truth is not None, "EmulatedComm.set_truth first"
+        lo, hi = bounds[self.rank] // 8, bounds[self.rank + 1] // 8          # bytes (bounds are multiples of 64 rows)
+        total = bits_buf.nbytes
+        base = 4 * k * self.truth_words
+        for a, b in ((0, lo), (hi, total)):
+            if b > a:
+                dst = capi.DeviceBuffer(b - a, ptr=bits_buf.ptr + a, keepalive=bits_buf)
+                src = capi.DeviceBuffer(b - a, ptr=self.truth.ptr + base + a, keepalive=self.truth)
+                capi.copy_d2d(dst, src, b - a)
+
+    def all_gather_slices(self, full, bounds):
+        return                 # nothing to gather from: only this rank's slice of `full` is valid
+
+    def all_gather_sparse(self, *a, **k):
+        raise NotImplementedError("the emulation covers the bit-frontier schedules only")
+
+    def barrier(self):
+        return
+
+
+class CabiComm(Comm):
+    """Comm whose bit-vector exchange goes through the C ABI (gl_dist_all_gather_bits: grouped ncclSend / ncclRecv on the
+    library's stream) instead of torch.distributed -- what a C++ caller of the drop-in headers uses.  The communicator's
+    unique id travels through the torch process group."""
+
+    def __init__(self, group=True):
+        super().__init__(group)
+        from . import capi
+        import torch.distributed as dist
+        uid = [capi.Dist.unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0, group=self.group)
+        self.gl = capi.Dist(self.rank, self.world_size, uid[0])
+
+    def exchange_bits(self, bits_buf, k, bounds):
+        self.gl.all_gather_bits(bits_buf, bounds)

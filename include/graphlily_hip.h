@@ -230,6 +230,11 @@ int gl_prof_end(double *total_ms, uint32_t *launches);
  * overlapping the kernel's first and last workgroups, so bracketing every launch slows a back-to-back sequence
  * by ~5 %; sampling keeps the timed region close to what it is without the profiler. */
 int gl_prof_sample_every(uint32_t n);
+/* GPU time of everything enqueued on the library's stream between the two calls (one HIP event pair; gl_span_end waits
+ * for the second event): how long a whole launch sequence -- e.g. a replayed BFS schedule -- occupies the device,
+ * without the read-back that follows it. */
+int gl_span_begin(void);
+int gl_span_end(double *ms);
 
 /* ------------------------------------------------------------------- SpMSpV
  * gl_spmspv_plan_create replaces SpMSpVModule::load_and_format_matrix +
@@ -336,6 +341,19 @@ int gl_bfs_pull_step_gated(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_
  * may_continue -- "a slot follows" -- set and new frontier / num_rows < back_threshold: push again; pushes after that are
  * counted in ctl[3]).  A slot enqueues its push step BEFORE its pull step.  No call synchronises or copies; the schedule can
  * be captured once (gl_graph_*) and replayed for any source. */
+/* ROW SHARDS (one process per GPU) run the same schedule with the decisions DEFERRED: a shard reaches only its
+ * own rows of the new frontier, so its counts are partial.  With GL_BFS_DEFERRED set in may_continue the two steps of a slot
+ * run or not by the same control words but keep no totals and decide nothing (plans of any row range starting on a multiple
+ * of 64 rows; split plans included -- their units claim rows with atomicOr); the driver then all-gathers the slot's output
+ * vector (gl_dist_all_gather_bits, n/8 bytes, on the library's stream) and calls
+ *   gl_bfs_bits_decide   popcount of the GATHERED vector + the sums of the GLOBAL column / row lengths of its vertices
+ *             (d_col_len / d_row_len: n words each, the whole matrix'; d_row_len may be NULL = never bottom-up), then the
+ *             slot's decisions exactly as above -- identical on every rank, no host in the loop, no reduction collective.
+ *             `csc` is the rank's own SpMSpV plan (scratch lines); nnz_global the non-zeros of the whole matrix.
+ * Each rank's d_distance is full-length but only its own rows are written: read back the slice. */
+#define GL_BFS_DEFERRED 4
+int gl_bfs_bits_decide(gl_spmspv_plan csc, const uint32_t *d_bits_next, const uint32_t *d_col_len, const uint32_t *d_row_len,
+                       uint64_t nnz_global, uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue, float back_threshold);
 int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
                       uint32_t nvec, uint32_t first_pull_slot);
 int gl_bfs_bits_push_step(gl_spmspv_plan csc, gl_spmv_plan rows, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,

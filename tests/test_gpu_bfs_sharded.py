@@ -1,0 +1,110 @@
+"""GPU parity of the ROW-SHARDED bit-frontier BFS schedule (reference loop app/bfs.h:160-219), one rank
+at a time on the one GPU of the test box: `EmulatedComm` stands in for the all-gather by copying the other ranks' rows of
+every exchanged bit vector from a whole-matrix run, so rank k of N executes exactly the kernels, sees exactly the frontiers
+and must take exactly the decisions of a real N-rank run -- shard plans (split ones included), deferred decisions
+(gl_bfs_bits_decide on the gathered vector), bottom-up slots on a shard's rows, slice-only read-back.  Every rank's slice
+must equal the oracle's distances bit for bit and the control words (push iterations, vertices per slot) the one-GPU run's."""
+import numpy as np
+import pytest
+
+from graphlily_amd import app, capi, datasets, io
+from graphlily_amd.dist import EmulatedComm
+from oracle import oracle as O
+
+from helpers import to_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _prepared(g):
+    m = g.copy()
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    m.adj_data = np.ones(m.nnz, np.float32)
+    return m
+
+
+def _whole(g):
+    bfs = app.BFS(16, 0, 0, 0)
+    bfs.set_up_runtime()
+    bfs.load_and_format_matrix(g, True)
+    bfs.send_matrix_host_to_device()
+    return bfs
+
+
+def _rank(g, k, world, whole):
+    comm = EmulatedComm(k, world)
+    b = app.BFS(16, 0, 0, 0, comm=comm)
+    b.set_up_runtime()
+    b.load_and_format_matrix(g, True)
+    b.send_matrix_host_to_device()
+    b.gather_result_ = False
+    st = whole.bits_loop_
+    comm.set_truth(st["vecs"], st["words"])
+    return b
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("name", ["rmat_sym", "rmat_directed"])
+def test_every_rank_of_a_sharded_bfs_matches_the_oracle(gpu, name, world):
+    g = datasets.rmat(60000, 1500000, seed=31, symmetric=True) if name == "rmat_sym" else datasets.rmat(50000, 900000, seed=32, symmetric=False)
+    deg = np.diff(g.adj_indptr.astype(np.int64))
+    src = int(np.argmax(deg > 0))
+    iters = 8
+    ref = O.bfs(to_oracle(_prepared(g)), src, iters)
+    whole = _whole(g)
+    for threshold, mode in ((0.001, "pull_push"), (0.05, "pull_push"), (0.9, "pull_push"), (None, "pull")):
+        run_whole = (lambda: whole.pull_push(src, iters, threshold)) if mode == "pull_push" else (lambda: whole.pull(src, iters))
+        assert np.array_equal(run_whole(), ref)
+        pushes, counts = whole.push_iterations_, whole.bfs_slot_counts_.copy()
+        assert counts.sum() + 1 == (ref != 0).sum()
+        covered = 0
+        for k in range(world):
+            b = _rank(g, k, world, whole)
+            for rep in range(3):                 # enqueued, captured, replayed
+                run_whole()                      # (the truth vectors are the whole run's, rewritten by every run)
+                got = b.pull_push(src, iters, threshold) if mode == "pull_push" else b.pull(src, iters)
+                r0, r1 = b.result_range_
+                assert (r0, r1) == (b.bounds_[k], b.bounds_[k + 1]) and got.shape[0] == r1 - r0
+                assert np.array_equal(got, ref[r0:r1]), "rank %d/%d %s thr %s rep %d: %d rows differ" % (
+                    k, world, mode, threshold, rep, int((got != ref[r0:r1]).sum()))
+                assert b.push_iterations_ == pushes, "the same decisions as the one-GPU run"
+                assert np.array_equal(b.bfs_slot_counts_, counts)
+            covered += r1 - r0
+            del b
+        assert covered == ref.shape[0]
+
+
+def test_sharded_bfs_on_split_shard_plans(gpu, monkeypatch):
+    """Shard plans cut into column segments (several units share a block's rows): the pull step claims rows with atomicOr."""
+    monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", "3")
+    g = datasets.rmat(60000, 1500000, seed=33, symmetric=True)
+    src = int(np.argmax(np.diff(g.adj_indptr.astype(np.int64)) > 0))
+    ref = O.bfs(to_oracle(_prepared(g)), src, 7)
+    monkeypatch.delenv("GRAPHLILY_SPMV_SEGMENTS")
+    whole = _whole(g)
+    assert np.array_equal(whole.pull(src, 7), ref)
+    monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", "3")
+    for k in range(4):
+        b = _rank(g, k, 4, whole)
+        assert b.SpMV_.plan_.info()["segments"] == 3
+        for fn in (lambda: b.pull(src, 7), lambda: b.pull_push(src, 7, 0.001)):
+            whole.pull(src, 7)
+            got = fn()
+            r0, r1 = b.result_range_
+            assert np.array_equal(got, ref[r0:r1])
+
+
+def test_deferred_decisions_on_a_whole_matrix_plan_equal_the_fused_ones(gpu):
+    """One rank of a world of one: the steps run deferred and gl_bfs_bits_decide decides from the bit vector -- the same
+    distances, push iterations and per-slot counts as the decisions fused into the steps."""
+    g = datasets.rmat(80000, 2400000, seed=34, symmetric=True)
+    src = int(np.argmax(np.diff(g.adj_indptr.astype(np.int64)) > 0))
+    whole = _whole(g)
+    for thr in (0.0005, 0.01, 0.2):
+        ref = whole.pull_push(src, 9, thr).copy()
+        pushes, again, counts = whole.push_iterations_, whole.push_iterations_again_, whole.bfs_slot_counts_.copy()
+        b = _rank(g, 0, 1, whole)
+        got = b.pull_push(src, 9, thr)
+        assert np.array_equal(got, ref)
+        assert (b.push_iterations_, b.push_iterations_again_) == (pushes, again)
+        assert np.array_equal(b.bfs_slot_counts_, counts)

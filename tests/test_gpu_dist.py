@@ -42,7 +42,7 @@ def _run_apps(comm, which):
         a.load_and_format_matrix(m, True)
         a.send_matrix_host_to_device()
         out = [a.pull(0, 7), a.pull_push(0, 7, 0.001), a.pull_push(0, 7, 0.5)]
-        assert a.bits_ is not None, "the pull iterations of a sharded BFS exchange bit vectors"
+        assert a.bits_loop_ is not None, "a sharded BFS runs the device-resident bit-frontier schedule (bit vectors exchanged)"
         return out
     if which == "pagerank":
         a = app.PageRank(16, 0, 0, comm=comm, backend=B)
