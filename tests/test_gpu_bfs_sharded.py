@@ -86,7 +86,7 @@ def test_sharded_bfs_on_split_shard_plans(gpu, monkeypatch):
     monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", "3")
     for k in range(4):
         b = _rank(g, k, 4, whole)
-        assert b.SpMV_.plan_.info()["segments"] == 3
+        assert b.SpMV_.plan_.info()["segments"] > 1
         for fn in (lambda: b.pull(src, 7), lambda: b.pull_push(src, 7, 0.001)):
             whole.pull(src, 7)
             got = fn()
