@@ -465,20 +465,24 @@ class BFS(_GraphApp):
         back = 0.0 if pull_only else float(os.environ.get("GRAPHLILY_BFS_BACK", "1.0"))
         csc_plan, pull_plan = self.SpMSpV_.plan_, self.SpMV_.plan_
         deferred = capi.GL_BFS_DEFERRED if sharded else 0
+        # (one-GPU emulation of a rank without an exchange step, dist.EmulatedComm: the slots read the whole run's vectors)
+        gathered = bits
+        if sharded and getattr(self.comm, "emulated", False) and not self.comm.copy:
+            gathered = [self.comm.truth_vector(k) for k in range(st["nvec"])]
 
         def schedule():
             capi.bfs_bits_begin(ctl, st["ctl_words"], distance, n, st["vecs"], words, st["nvec"], 0 if pull_only else 0xffffffff)
             for it in range(1, N + 1):
                 may = (1 if it + 1 < N else 0) | (2 if it + 1 <= N else 0) | deferred
                 # (pull_only: never scatters, but the launch is also the bottom-up pull of the late slots)
-                capi.bfs_bits_push_step(csc_plan, pull_plan, bits[it], bits[it + 1], None, words, distance, float(it + 1), ctl, it,
+                capi.bfs_bits_push_step(csc_plan, pull_plan, gathered[it], bits[it + 1], None, words, distance, float(it + 1), ctl, it,
                                         threshold, may)
                 # (also in the first slot, which always pushes: the gated-off pull step takes the push step's decisions)
-                capi.bfs_bits_pull_step(pull_plan, csc_plan, bits[it], bits[it + 1], distance, float(it + 1), ctl, it, threshold,
+                capi.bfs_bits_pull_step(pull_plan, csc_plan, gathered[it], bits[it + 1], distance, float(it + 1), ctl, it, threshold,
                                         may, back)
                 if sharded:
                     self._exchange_bits(st, it + 1)
-                    capi.bfs_bits_decide(csc_plan, bits[it + 1], st["col_len"], st["row_len"], self.nnz_global_, ctl, it, threshold,
+                    capi.bfs_bits_decide(csc_plan, gathered[it + 1], st["col_len"], st["row_len"], self.nnz_global_, ctl, it, threshold,
                                          may, back)
 
         st["src"][0] = source

@@ -603,7 +603,7 @@ struct BfsDecideArgs {
     BfsBitsCtl c;
 };
 
-__global__ __launch_bounds__(256) void bfs_bits_decide_kernel(BfsDecideArgs a) {
+__global__ __launch_bounds__(1024) void bfs_bits_decide_kernel(BfsDecideArgs a) {
     __shared__ uint32_t s_fresh, s_last;
     __shared__ unsigned long long s_work, s_rows;
     if (threadIdx.x == 0) {
@@ -612,20 +612,32 @@ __global__ __launch_bounds__(256) void bfs_bits_decide_kernel(BfsDecideArgs a) {
         s_rows = 0ull;
     }
     __syncthreads();
-    const uint32_t nw = (a.n + 31u) >> 5;
+    // a wavefront per 64 vertices: skip empty 64-bit words (sparse frontiers), otherwise a lane per vertex -- the two length
+    // arrays are then read in whole lines (a dense frontier of a million vertices: 24 MB streamed instead of 2 M gathers)
+    const uint32_t nw64 = (a.n + 63u) >> 6, lane = threadIdx.x & 63u;
     uint32_t fresh = 0u;
     unsigned long long work = 0ull, rows = 0ull;
     if (!a.c.finished()) {
-        for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < nw; w += gridDim.x * 256u) {
-            uint32_t m = a.bits[w];
-            fresh += (uint32_t)__popc(m);
-            while (m) {
-                const uint32_t v = w * 32u + (uint32_t)__ffs(m) - 1u;
-                m &= m - 1u;
-                if (v < a.n) {
-                    work += a.col_len[v];
-                    if (a.row_len) rows += a.row_len[v];
-                }
+        // 16 words = 1024 vertices per wavefront step: lanes 0..15 fetch the words in one coalesced load, then every load of
+        // the step is issued before the first use (no branch on the words: predicated-off lanes cost no traffic) -- with a
+        // dependent load per word the kernel was latency-bound at 13 us whatever the frontier held
+        constexpr uint32_t K = 16;
+        for (uint32_t w0 = (blockIdx.x * 16u + (threadIdx.x >> 6)) * K; w0 < nw64; w0 += gridDim.x * 16u * K) {
+            const uint64_t mine = (lane < K && w0 + lane < nw64) ? reinterpret_cast<const uint64_t *>(a.bits)[w0 + lane] : 0ull;
+            uint32_t cl[K], rl[K], bit[K];
+#pragma unroll
+            for (uint32_t u = 0; u < K; u++) {
+                const uint64_t m = __shfl(mine, (int)u);
+                const uint32_t v = (w0 + u) * 64u + lane;
+                bit[u] = (uint32_t)((m >> lane) & 1ull) & (v < a.n ? 1u : 0u);
+                cl[u] = bit[u] ? a.col_len[v] : 0u;
+                rl[u] = (bit[u] && a.row_len) ? a.row_len[v] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < K; u++) {
+                fresh += bit[u];
+                work += cl[u];
+                rows += rl[u];
             }
         }
     }
@@ -641,15 +653,23 @@ __global__ __launch_bounds__(256) void bfs_bits_decide_kernel(BfsDecideArgs a) {
         atomicAdd(&s_rows, rows);
     }
     __syncthreads();
+    // totals and "who is last" through the 64 accumulator lines, then one root ticket per line (ctl[6]): hundreds of
+    // workgroups ending on ONE word serialise (measured on the push step: 45 us for 2048 of them)
     if (threadIdx.x == 0) {
-        uint32_t *line = a.acc + 32u * (blockIdx.x & (kBfsAccSlots - 1u));
+        const uint32_t l = blockIdx.x & (kBfsAccSlots - 1u), nlines = min(gridDim.x, kBfsAccSlots);
+        uint32_t *line = a.acc + 32u * l;
         if (s_fresh) {
             atomicAdd(line, s_fresh);
             atomicAdd(reinterpret_cast<unsigned long long *>(line + 2), s_work);
             if (s_rows) atomicAdd(reinterpret_cast<unsigned long long *>(line + 6), s_rows);
         }
         __threadfence();
-        s_last = atomicAdd(a.acc + 4, 1u) == gridDim.x - 1u ? 1u : 0u;
+        bool last = atomicAdd(line + 4, 1u) == (gridDim.x - l + kBfsAccSlots - 1u) / kBfsAccSlots - 1u;   // last workgroup of this line
+        if (last) {
+            __threadfence();
+            last = atomicAdd(&a.c.ctl[6], 1u) == nlines - 1u;                                            // ... of the launch
+        }
+        s_last = last ? 1u : 0u;
     }
     __syncthreads();
     if (s_last && threadIdx.x < 64u) {
@@ -661,14 +681,17 @@ __global__ __launch_bounds__(256) void bfs_bits_decide_kernel(BfsDecideArgs a) {
         ln[0] = 0u;
         *reinterpret_cast<unsigned long long *>(ln + 2) = 0ull;
         *reinterpret_cast<unsigned long long *>(ln + 6) = 0ull;
-        if (threadIdx.x == 0) ln[4] = 0u;
+        ln[4] = 0u;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             total += __shfl_down(total, d);
             wk += __shfl_down(wk, d);
             wr += __shfl_down(wr, d);
         }
-        if (threadIdx.x == 0) a.c.decide(total, wk, wr);
+        if (threadIdx.x == 0) {
+            a.c.ctl[6] = 0u;
+            a.c.decide(total, wk, wr);
+        }
     }
 }
 
@@ -1470,9 +1493,13 @@ int gl_bfs_bits_decide(gl_spmspv_plan p, const uint32_t *d_bits_next, const uint
     a.c.nnz_rows = nnz_global;
     // bottom-up slots need the rows on every rank: the push step of this slot (enqueued before) recorded whether it has them
     a.c.bu_limit = (d_row_len != nullptr && p->bfs_rows_plan != nullptr && bdiv > 0) ? nnz_global / (unsigned long long)bdiv : 0ull;
-    const uint32_t nw = gl::cdiv(p->num_rows, 32);
-    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(gl::cdiv(nw, 256 * 4), 256u));
-    gl::bfs_bits_decide_kernel<<<grid, 256, 0, gl::ctx().stream>>>(a);
+    // every workgroup ends with a fence and a ticket: a thousand of those cost 20 us whatever the frontier holds, and 64
+    // workgroups of 16 wavefronts 12 us (measured: few compute units stream the length arrays slowly)
+    const uint32_t nw64 = gl::cdiv(p->num_rows, 64);
+    // (a wavefront step is a chain of dependent loads: the grid is sized so that every wavefront has ONE step up to 256 x 16 x 1024
+    // vertices; more steps per wavefront run one after the other, 3 us each)
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(gl::cdiv(nw64, 16 * 16), (uint32_t)gl::env_long("GRAPHLILY_BFS_DECIDE_GRID", 256)));
+    gl::bfs_bits_decide_kernel<<<grid, 1024, 0, gl::ctx().stream>>>(a);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

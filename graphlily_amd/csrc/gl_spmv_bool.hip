@@ -230,12 +230,22 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         // the bit-frontier schedule, whose next-frontier vector starts all zero: a row this unit reached whose distance is
         // still 0 sets its bit, and the unit whose atomicOr set it first writes the level -- as the push step does.  (A unit
         // that reads a distance another unit has just written sees `level`, not 0, and leaves the row alone: same result.)
-        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) {
-            if (!((tile[i >> 5] >> (i & 31u)) & 1u)) continue;
+        // 64 rows per wavefront step (blocks start on multiples of 64 rows): one coalesced distance load, ONE atomicOr per
+        // 32-bit word of the output vector with the wavefront's combined mask -- a dense frontier would otherwise cost an
+        // atomic per row and unit (orkut's heavy slot on a 1/8 shard: 3 M of them)
+        for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < nrows; i0 += kThreads) {
+            const uint32_t i = i0 + lane;
+            bool cand = i < nrows && ((tile[i >> 5] >> (i & 31u)) & 1u);
+            if (!__any(cand)) continue;
             const uint32_t row = row0 + i;
-            if (a.dist[row] != 0.0f) continue;
-            const uint32_t m = 1u << (row & 31u);
-            if (!(atomicOr(&a.bits_out[row >> 5], m) & m)) a.dist[row] = a.level;
+            cand = cand && a.dist[row] == 0.0f;
+            const uint64_t m = __ballot(cand);
+            if (!m) continue;
+            const uint32_t half = lane >> 5, mine = (uint32_t)(m >> (32u * half));
+            uint32_t old = 0u;
+            if ((lane & 31u) == 0u && mine) old = atomicOr(&a.bits_out[(row0 + i0) / 32u + half], mine);
+            old = __shfl(old, (int)(half * 32u));
+            if (cand && !((old >> (lane & 31u)) & 1u)) a.dist[row] = a.level;
         }
     } else if (FUSED) {
         // SpMV masked by `distance == 0`, eWiseAdd(+0), assign(level) where the result is set, and the packing of

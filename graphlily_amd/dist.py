@@ -137,16 +137,26 @@ class EmulatedComm:
     available to this build, so the per-rank work of the sharded schedules is measured this way (bench.py
     --emulate-rank k/N).  The other ranks' rows of every exchanged bit vector are copied from the vectors of a
     whole-matrix run of the same BFS on the same GPU (`set_truth`: slot s of the bit-frontier schedule writes vector
-    s + 1 = the vertices at distance s + 1, whatever the sharding) -- two device-to-device copies of at most n/8 bytes
-    where a real run has RCCL's all-gather -- so the rank's kernels see exactly the frontiers, and take exactly the
-    decisions, of a real N-rank run.  What is NOT measured: the collective itself (tabulated separately)."""
+    s + 1 = the vertices at distance s + 1, whatever the sharding), so the rank's kernels see exactly the frontiers, and
+    take exactly the decisions, of a real N-rank run.  Two forms:
+      copy=False (default)  no exchange step at all: slot s READS the whole run's vector s and writes the rank's own rows
+                            of vector s + 1 into the rank's own buffer (compared with the truth by the tests);
+      copy=True             the exchange step is there, as (at most two) device-to-device copies of the other ranks' rows
+                            into the rank's vector -- the place RCCL's all-gather takes in a real run.
+    What is NOT measured either way: the collective itself (tabulated separately)."""
     emulated = True
     capturable = True          # plain device-to-device copies: the schedule can be recorded as a hipGraph
     group = None
 
-    def __init__(self, rank, world_size):
-        self.rank, self.world_size = int(rank), int(world_size)
+    def __init__(self, rank, world_size, copy=False):
+        self.rank, self.world_size, self.copy = int(rank), int(world_size), bool(copy)
         self.truth = None
+
+    def truth_vector(self, k):
+        """vector k of the whole-matrix run (copy=False: the frontier the rank's slot k reads)"""
+        from . import capi
+        nb = 4 * self.truth_words
+        return capi.DeviceBuffer(nb, ptr=self.truth.ptr + k * nb, keepalive=self.truth)
 
     @property
     def distributed(self):
@@ -159,6 +169,8 @@ class EmulatedComm:
     def exchange_bits(self, bits_buf, k, bounds):
         from . import capi
         assert self.truth is not None, "EmulatedComm.set_truth first"
+        if not self.copy:
+            return
         lo, hi = bounds[self.rank] // 8, bounds[self.rank + 1] // 8          # bytes (bounds are multiples of 64 rows)
         total = bits_buf.nbytes
         base = 4 * k * self.truth_words

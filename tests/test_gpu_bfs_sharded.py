@@ -31,8 +31,8 @@ def _whole(g):
     return bfs
 
 
-def _rank(g, k, world, whole):
-    comm = EmulatedComm(k, world)
+def _rank(g, k, world, whole, copy=False):
+    comm = EmulatedComm(k, world, copy=copy)
     b = app.BFS(16, 0, 0, 0, comm=comm)
     b.set_up_runtime()
     b.load_and_format_matrix(g, True)
@@ -59,7 +59,8 @@ def test_every_rank_of_a_sharded_bfs_matches_the_oracle(gpu, name, world):
         assert counts.sum() + 1 == (ref != 0).sum()
         covered = 0
         for k in range(world):
-            b = _rank(g, k, world, whole)
+            # (with and without the stand-in for the exchange step: copies of the other ranks' rows / the whole run's vectors read in place)
+            b = _rank(g, k, world, whole, copy=(k % 2 == 1))
             for rep in range(3):                 # enqueued, captured, replayed
                 run_whole()                      # (the truth vectors are the whole run's, rewritten by every run)
                 got = b.pull_push(src, iters, threshold) if mode == "pull_push" else b.pull(src, iters)
@@ -69,6 +70,11 @@ def test_every_rank_of_a_sharded_bfs_matches_the_oracle(gpu, name, world):
                     k, world, mode, threshold, rep, int((got != ref[r0:r1]).sum()))
                 assert b.push_iterations_ == pushes, "the same decisions as the one-GPU run"
                 assert np.array_equal(b.bfs_slot_counts_, counts)
+            # the rank's own rows of every vector it wrote are the whole run's (what an all-gather would have published)
+            words = whole.bits_loop_["words"]
+            mine = b.bits_loop_["vecs"].read(np.uint32).reshape(-1, words)[1:iters + 2, r0 // 32:r1 // 32]
+            truth = whole.bits_loop_["vecs"].read(np.uint32).reshape(-1, words)[1:iters + 2, r0 // 32:r1 // 32]
+            assert np.array_equal(mine, truth)
             covered += r1 - r0
             del b
         assert covered == ref.shape[0]
