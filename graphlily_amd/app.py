@@ -760,12 +760,6 @@ class SSSP(_GraphApp):
         self.n_ = self.SpMV_.get_num_rows()
         assert self.n_ == self.SpMV_.get_num_cols()
 
-    def send_matrix_host_to_device(self):
-        self.SpMV_.send_matrix_host_to_device()
-        self.SpMSpV_.send_matrix_host_to_device()
-        if hasattr(self.SpMSpV_, "attach_pull"):
-            self.SpMSpV_.attach_pull(self.SpMV_)     # heavy frontiers of a push iteration go row-wise
-
     def _initial_distance(self, source):
         return self._new_dense(self.n_, self.semiring_.zero, source, 0.0)
 
@@ -819,7 +813,79 @@ class SSSP(_GraphApp):
         self.backend.sync()
         return self.backend.download_result(distance, self.n_)
 
+    # -- pull_push without the host in the loop (the reference reads the result count back every push
+    #    iteration, app/sssp.h:221) ------------------------------------------------------------------------------------
+    def _device_loop_ok(self):
+        plan = getattr(self.SpMV_, "plan_", None)
+        return (not self.comm.distributed and os.environ.get("GRAPHLILY_SSSP_DEVICE_LOOP", "1") != "0"
+                and hasattr(self.SpMSpV_, "run_gated") and plan is not None and hasattr(plan, "run_flagged")
+                and getattr(self.SpMSpV_, "plan_", None) is not None
+                and plan.info()["layout"] in ("general", "pattern") and plan.info()["num_units"] > 0)
+
+    def _pull_push_device(self, source, num_iterations, threshold):
+        """The whole schedule enqueued up front (and replayed as a hipGraph from the third call on): slot `it` holds a push
+        step -- SpMSpV (min,+) + the relax / new-frontier pass, gated on `ctl[0] > it` -- and, from the second slot on, a pull
+        step -- SpMV (min,+) + the results -> vector copy (eWiseAdd +0, app/sssp.h:236-241), predicated on the slot's pull
+        flag.  The SpMSpV's compaction takes the reference's decision where the result count is produced (the same float
+        comparison, gl_compact.h Direction) and raises the pull flags of every later slot.  No synchronisation and no
+        device->host copy between the first launch and the read-back of distances + control words."""
+        B, n, N = self.backend, self.n_, num_iterations
+        st = getattr(self, "dev_loop_", None)
+        if st is None or st["N"] < N:
+            cw = (33 + N + 15) & ~15
+            both = B.alloc(n + cw, np.float32)                 # distances, then the control words: one read-back
+            st = self.dev_loop_ = {"N": N, "both": both, "cw": cw, "ctl": B.view(both, n, cw, 4), "distance": B.view(both, 0, n, 4),
+                                   "results": B.alloc(n, np.float32), "frontier": B.alloc(n + 1, capi.IDX_VAL),
+                                   "candidates": B.alloc(n + 1, capi.IDX_VAL), "graphs": {}, "warm": set(), "src": np.zeros(1, np.uint32)}
+            st["flags"] = [B.view(st["ctl"], 32 + it, 1, 4) for it in range(N + 1)]
+        ctl, distance, results, frontier, cand = st["ctl"], st["distance"], st["results"], st["frontier"], st["candidates"]
+        sem, plan = self.semiring_, self.SpMV_.plan_
+
+        def schedule():
+            capi.sssp_begin(ctl, st["cw"], distance, n, sem.zero, frontier)
+            for it in range(1, N + 1):
+                may = (1 if it + 1 < N else 0) | capi.GL_STEP_PULL_FLAGS
+                self.SpMSpV_.run_gated(frontier, cand, None, 0.0, None, ctl, it, capi.GL_GATE_GT, ctl=ctl, slot=it,
+                                       threshold=threshold, may_continue=may)
+                capi.assign_sparse_new_frontier_gated(cand, distance, frontier, n, ctl, it, capi.GL_GATE_GT)
+                if it >= 2:      # (the first slot always pushes: do { } while, app/sssp.h:217-223)
+                    plan.run_flagged(distance, None, results, sem.op, sem.zero, M.kNoMask, st["flags"][it])
+                    capi.ewise_add_flagged(results, distance, n, 0.0, st["flags"][it])
+
+        st["src"][0] = source
+        B.upload(B.view(ctl, 2, 1, 4), st["src"])        # ctl[2] = source: the one host->device word per run
+        self.SpMSpV_.bind_mask_buf(distance)
+        key = (N, float(threshold))
+        g = st["graphs"].get(key)
+        if g is None and os.environ.get("GRAPHLILY_SSSP_GRAPH", "1") != "0" and key in st["warm"]:
+            try:
+                with capi.Graph.capture() as g:
+                    schedule()
+                st["graphs"][key] = g
+            except capi.GraphLilyError:
+                g = st["graphs"][key] = False
+        if g:
+            g.launch()
+        else:
+            schedule()
+            st["warm"].add(key)
+        out = capi.pinned_recycled(n + st["cw"], np.float32)
+        st["both"].read_async(out)
+        B.sync()
+        c = out[n:].view(np.uint32)
+        self.push_iterations_ = int(c[1])
+        return out[:n]
+
+    def send_matrix_host_to_device(self):
+        self.SpMV_.send_matrix_host_to_device()
+        self.SpMSpV_.send_matrix_host_to_device()
+        if hasattr(self.SpMSpV_, "attach_pull"):
+            self.SpMSpV_.attach_pull(self.SpMV_)     # heavy frontiers of a push iteration go row-wise
+        self.dev_loop_ = None                        # the schedule holds the old plans' device pointers
+
     def pull_push(self, source, num_iterations, threshold=0.05):
+        if self._device_loop_ok():
+            return self._pull_push_device(source, num_iterations, threshold)
         n = self.n_
         frontier, distance, candidates, local = self._start_push(source)
         it = 1

@@ -33,6 +33,7 @@ EXPORTS = [
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
     "gl_bfs_bits_begin", "gl_bfs_bits_push_step", "gl_bfs_bits_pull_step", "gl_bfs_bits_decide",
     "gl_buf_d2h_async",
+    "gl_sssp_begin", "gl_assign_sparse_new_frontier_gated", "gl_spmv_run_flagged", "gl_ewise_add_flagged",
     "gl_bfs_begin", "gl_spmspv_plan_frontier_bits", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
     "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32", "gl_dist_all_gather_bits",
     "gl_dist_all_gather_sparse",
@@ -86,6 +87,8 @@ def lib():
         "gl_bfs_bits_push_step": [vp, vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
         "gl_bfs_bits_pull_step": [vp, vp, vp, vp, vp, f32, vp, u32, f32, i32, f32],
         "gl_bfs_bits_decide": [vp, vp, vp, vp, u64, vp, u32, f32, i32, f32],
+        "gl_sssp_begin": [vp, u32, vp, u32, f32, vp], "gl_assign_sparse_new_frontier_gated": [vp, vp, vp, u32, vp, u32, i32],
+        "gl_spmv_run_flagged": [vp, vp, vp, vp, i32, f32, i32, vp], "gl_ewise_add_flagged": [vp, vp, u32, f32, vp],
         "gl_spmspv_run_gated": [vp, vp, vp, vp, i32, f32, i32, vp, f32, vp, vp, u32, i32, vp, u32, f32, i32],
         "gl_bfs_pull_step_gated": [vp, vp, vp, vp, f32, vp, u32, i32],
         "gl_spmspv_plan_frontier_bits": [vp, vp],
@@ -383,6 +386,10 @@ class SpMVPlan:
         check(lib().gl_spmv_run(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero),
                                 int(mask_type)))
 
+    def run_flagged(self, x, mask, y, op, zero, mask_type, flag):
+        """gl_spmv_run_flagged: gl_spmv_run that does nothing unless the device word `flag` is non-zero."""
+        check(lib().gl_spmv_run_flagged(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero), int(mask_type), _p(flag)))
+
     def run_typed(self, x, mask, y, op, zero_bits, mask_type, val_type):
         """gl_spmv_run_typed: the buffers hold 32-bit value words of `val_type` (GL_VAL_*)."""
         check(lib().gl_spmv_run_typed(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), int(zero_bits), int(mask_type),
@@ -607,6 +614,20 @@ def bfs_bits_pull_step(pull_plan, csc_plan, bits_in, bits_out, distance, level, 
 
 
 GL_BFS_DEFERRED = 4
+GL_STEP_PULL_FLAGS = 8
+
+
+def sssp_begin(ctl, ctl_words, distance, n, zero, frontier):
+    check(lib().gl_sssp_begin(_p(ctl), int(ctl_words), _p(distance), int(n), float(zero), _p(frontier)))
+
+
+def assign_sparse_new_frontier_gated(mask, inout, new_frontier, max_entries, gate, gate_value, gate_op):
+    check(lib().gl_assign_sparse_new_frontier_gated(_p(mask), _p(inout), _p(new_frontier), int(max_entries), _p(gate), int(gate_value),
+                                                    int(gate_op)))
+
+
+def ewise_add_flagged(inp, out, length, val, flag):
+    check(lib().gl_ewise_add_flagged(_p(inp), _p(out), int(length), float(val), _p(flag)))
 
 
 def bfs_bits_decide(csc_plan, bits_next, col_len, row_len, nnz_global, ctl, slot, threshold, may_continue, back_threshold):

@@ -54,6 +54,39 @@ __global__ __launch_bounds__(256) void ewise_add_kernel(const float *__restrict_
     }
 }
 
+// the same under a launch predicate: nothing happens unless *flag != 0 (a pull iteration of a device-resident SSSP schedule)
+__global__ __launch_bounds__(256) void ewise_add_flagged_kernel(const float *__restrict__ in, float *__restrict__ out, uint32_t len, float val,
+                                                                const uint32_t *__restrict__ flag) {
+    if (*flag == 0u) return;
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    const uint32_t n4 = len >> 2;   // (both vectors 16-byte aligned: checked by the caller)
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    float4 *out4 = reinterpret_cast<float4 *>(out);
+    for (uint32_t i = tid; i < n4; i += stride) {
+        float4 v = in4[i];
+        v.x += val; v.y += val; v.z += val; v.w += val;
+        out4[i] = v;
+    }
+    for (uint32_t i = (n4 << 2) + tid; i < len; i += stride) out[i] = in[i] + val;
+}
+
+// gl_sssp_begin: SSSP::pull_push's set-up (app/sssp.h:197-212) on the device -- distance = zero except 0 at the source
+// (ctl[2], written by the host), the one-entry frontier {1, (source, 0)}, the control words of the push -> pull decision
+// (Direction, gl_compact.h) and the per-slot pull flags ctl[32 + s]
+__global__ __launch_bounds__(256) void sssp_begin_kernel(uint32_t *__restrict__ ctl, uint32_t ctl_words, float *__restrict__ distance, uint32_t n,
+                                                         float zero, gl_idx_val *__restrict__ frontier) {
+    const uint32_t src = ctl[2];
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    for (uint32_t i = tid; i < n; i += stride) distance[i] = (i == src) ? 0.0f : zero;
+    if (tid < ctl_words && tid != 2u) ctl[tid] = tid == 0u ? 0xffffffffu : (tid == 4u ? 0xffffffffu : (tid == 15u ? ctl_words : 0u));
+    if (tid == 0) {
+        frontier[0].index = 1u;
+        frontier[0].val = 0.0f;
+        frontier[1].index = src;
+        frontier[1].val = 0.0f;
+    }
+}
+
 // hw/kernel_assign_vector_dense_impl.h:8-47
 template <int MASK>
 __global__ __launch_bounds__(256) void assign_dense_kernel(const float *__restrict__ mask, float *__restrict__ inout,
@@ -259,15 +292,44 @@ int gl_assign_sparse(const gl_idx_val *d_mask, float *d_inout, float val, uint32
 
 int gl_assign_sparse_new_frontier(const gl_idx_val *d_mask, float *d_inout, gl_idx_val *d_new_frontier,
                                   uint32_t max_entries) {
+    return gl_assign_sparse_new_frontier_gated(d_mask, d_inout, d_new_frontier, max_entries, nullptr, 0u, GL_GATE_EQ);
+}
+
+int gl_assign_sparse_new_frontier_gated(const gl_idx_val *d_mask, float *d_inout, gl_idx_val *d_new_frontier, uint32_t max_entries,
+                                        const uint32_t *d_gate, uint32_t gate_value, int gate_op) {
     GL_REQUIRE_INIT();
     GL_ARG(d_mask != nullptr && d_inout != nullptr && d_new_frontier != nullptr);
     GL_ARG((const void *)d_mask != (const void *)d_new_frontier);
+    GL_ARG(gate_op == GL_GATE_EQ || gate_op == GL_GATE_GT || gate_op == GL_GATE_LE);
     void *counts = nullptr;
     int rc = gl::scratch_reserve((size_t)(gl::cdiv(max_entries, gl::kCompactChunk) + 1) * sizeof(uint32_t), &counts);
     if (rc != GL_OK) return rc;
     gl::RelaxSource src{d_mask, d_inout};
+    gl::Gate gate;
+    gate.word = d_gate;
+    gate.value = gate_value;
+    gate.op = gate_op;
     // head of the new frontier is {count, 0} (kernel_assign_vector_sparse_new_frontier_impl.h:73-77)
-    return gl::run_compaction(src, max_entries, (uint32_t *)counts, d_new_frontier, 0.0f, gl::ctx().stream);
+    return gl::run_compaction(src, max_entries, (uint32_t *)counts, d_new_frontier, 0.0f, gl::ctx().stream, nullptr, gate);
+}
+
+int gl_sssp_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, float zero, gl_idx_val *d_frontier) {
+    GL_REQUIRE_INIT();
+    GL_ARG(d_ctl != nullptr && d_distance != nullptr && d_frontier != nullptr && n > 0);
+    GL_ARG(ctl_words >= 34u && ctl_words <= 65536u);
+    gl::sssp_begin_kernel<<<gl::stream_grid(n), 256, 0, gl::ctx().stream>>>(d_ctl, ctl_words, d_distance, n, zero, d_frontier);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int gl_ewise_add_flagged(const float *d_in, float *d_out, uint32_t len, float val, const uint32_t *d_flag) {
+    GL_REQUIRE_INIT();
+    if (len == 0) return GL_OK;
+    GL_ARG(d_in != nullptr && d_out != nullptr && d_flag != nullptr);
+    GL_ARG(((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0);
+    gl::ewise_add_flagged_kernel<<<gl::stream_grid((len + 3) / 4), 256, 0, gl::ctx().stream>>>(d_in, d_out, len, val, d_flag);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
 }
 
 int gl_sparse_to_dense(const gl_idx_val *d_sparse, float *d_dense, uint32_t range, float zero, uint32_t max_entries) {

@@ -52,6 +52,9 @@ struct Direction {
     uint32_t n = 1, slot = 0;
     float threshold = 0.0f;
     uint32_t may_continue = 0;
+    // bit 3 of may_continue (GL_STEP_PULL_FLAGS): the schedule keeps one word per slot at ctl[32 + s] that says "slot s pulls"
+    // (gl_spmv_run_flagged / gl_ewise_add_flagged read it as their launch predicate: SSSP's pull iterations are plain SpMV
+    // runs, app/sssp.h:227-242); the decision that ends the push phase sets the words of every later slot (ctl[15] = words of ctl)
     // After a pull step has handed the loop back to pushing (gl_bfs_pull_step_back: ctl[4] = its slot, ctl[7] = the
     // threshold it used) the pushes are counted apart (ctl[3]; ctl[1] stays the reference's count), may run through the
     // last iteration (bit 1 of may_continue: a slot follows) and stay for as long as the frontier is below ctl[7].
@@ -61,7 +64,13 @@ struct Direction {
         ctl[again ? 3 : 1] += 1u;
         const bool cont = again ? (may_continue & 2u) != 0u : (may_continue & 1u) != 0u;
         const float thr = again ? __uint_as_float(ctl[7]) : threshold;
-        if (!(cont && ((float)nnz / (float)n < thr))) ctl[0] = slot + 1u;
+        if (!(cont && ((float)nnz / (float)n < thr))) {
+            ctl[0] = slot + 1u;
+            if (may_continue & 8u) {
+                const uint32_t cw = ctl[15];
+                for (uint32_t s = slot + 1u; 32u + s < cw; s++) ctl[32u + s] = 1u;
+            }
+        }
     }
 };
 

@@ -1205,7 +1205,7 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     dir.n = p ? p->num_rows : 1u;
     dir.slot = slot;
     dir.threshold = dir_threshold;
-    dir.may_continue = (uint32_t)may_continue_push;   // bit 0: the reference's loop condition, bit 1: a slot follows
+    dir.may_continue = (uint32_t)may_continue_push;   // bit 0: the reference's loop condition, bit 1: a slot follows, bit 3: pull flags
     GL_ARG(p != nullptr && d_vector != nullptr && d_result != nullptr);
     GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
     GL_ARG(op == GL_OP_MULADD || op == GL_OP_ANDOR || op == GL_OP_ADDMIN);

@@ -695,6 +695,7 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     if (rows == 0) return GL_OK;
     if (p->nunits == 0) {   // no stored entries in this shard: y = mask(zero)
         unsigned grid = std::min<unsigned>(cdiv(rows, 256), (unsigned)ctx().num_cus * 8u);
+        if (a.run_flag) return set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: a shard without stored entries cannot run under a launch predicate");
         spmv_init_kernel<OP, MASK><<<grid, 256, 0, s>>>(p->row_begin, p->row_end, a.mask, a.y, a.zero);
         GL_LAUNCH_CHECK();
         return GL_OK;
@@ -1811,6 +1812,17 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
         return gl::bool_plan_run(p, d_x, nullptr, d_mask, d_y, zero, mask_type, gl::ctx().stream);
     }
     return gl::spmv_run_general(p, d_x, d_mask, d_y, op, zero, mask_type, nullptr);
+}
+
+int gl_spmv_run_flagged(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
+                        const uint32_t *d_flag) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && d_y != nullptr && d_flag != nullptr);
+    GL_ARG(d_x != nullptr || p->nnz == 0);
+    GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
+    if (p->boolean || p->reference_order)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run_flagged: general / pattern layouts only");
+    return gl::spmv_run_general(p, d_x, d_mask, d_y, op, zero, mask_type, d_flag);
 }
 
 int gl_spmv_run_typed(gl_spmv_plan p, const void *d_x, const void *d_mask, void *d_y, int op, uint32_t zero_bits, int mask_type,

@@ -310,6 +310,24 @@ int gl_spmspv_run_gated(gl_spmspv_plan plan, const gl_idx_val *d_vector, const f
 int gl_bfs_pull_step_gated(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level,
                            const uint32_t *d_gate, uint32_t gate_value, int gate_op);
 
+/* The same for SSSP::pull_push (app/sssp.h:197-243: do { SpMSpV; AssignVectorSparse (new frontier); nnz = get_results_nnz()
+ * } while (iter < num_iterations && nnz / n < threshold), then SpMV + eWiseAdd(+0) to the end): the whole schedule is
+ * enqueued up front, the push steps gated GL_GATE_GT on d_ctl[0], the pull steps on a per-slot word.
+ *   d_ctl   ctl_words >= 33 + slots words: [0] first pull slot, [1] push iterations done, [2] source (host), [15] ctl_words,
+ *           [32 + s] != 0 iff slot s pulls -- set for every later slot by the decision that ends the push phase when
+ *           GL_STEP_PULL_FLAGS is part of gl_spmspv_run_gated's may_continue_push.
+ *   gl_sssp_begin                       distance = zero except 0 at the source, frontier = {1, (source, 0)}, control words
+ *   gl_assign_sparse_new_frontier_gated gl_assign_sparse_new_frontier under a gate (the relax step of a push slot)
+ *   gl_spmv_run_flagged                 gl_spmv_run that does nothing unless *d_flag != 0 (general / pattern layouts)
+ *   gl_ewise_add_flagged                gl_ewise_add likewise (the results -> vector copy of a pull iteration; 16-byte aligned) */
+#define GL_STEP_PULL_FLAGS 8
+int gl_sssp_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, float zero, gl_idx_val *d_frontier);
+int gl_assign_sparse_new_frontier_gated(const gl_idx_val *d_mask, float *d_inout, gl_idx_val *d_new_frontier, uint32_t max_entries,
+                                        const uint32_t *d_gate, uint32_t gate_value, int gate_op);
+int gl_spmv_run_flagged(gl_spmv_plan plan, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
+                        const uint32_t *d_flag);
+int gl_ewise_add_flagged(const float *d_in, float *d_out, uint32_t len, float val, const uint32_t *d_flag);
+
 /* Second form of the device-resident BFS schedule (replaces app/bfs.h:146-152 + :180-205 for a whole-matrix BFS on one
  * GPU): the frontier lives as BITS only and an iteration slot is TWO launches.
  *   d_ctl     ctl_words >= 17 + slots words, 8-byte aligned: [0] first pull slot (0xffffffff while pushing), [1] push

@@ -350,3 +350,39 @@ def test_bfs_bottom_up_with_an_unreachable_hub(gpu, monkeypatch):
                 assert np.array_equal(bfs.pull_push(src, 8, 0.01), ref), "pull_push div %s src %d rep %d" % (div, src, rep)
     counts = bfs.bfs_slot_counts_
     assert counts.shape[0] == 8
+
+
+@pytest.mark.parametrize("zero", [255.0, 999999999.0])
+@pytest.mark.parametrize("name", ["rmat_sym_50K", "gplus_small"])
+def test_sssp_pull_push_device_loop_equals_host_loop(gpu, name, zero, monkeypatch):
+    """SSSP::pull_push (app/sssp.h:197-243) as a device-resident schedule (SURVEY 8f-1): same distances and the same number
+    of push iterations as the host-driven loop (which reads the count back like the reference) and as the oracle, for
+    thresholds that end the push phase after every possible iteration; enqueued, captured and replayed."""
+    m = named_matrix(name)
+    iters = 7
+    ref = O.sssp(_oracle_prepared(m, "sssp"), 0, iters, zero)
+    sem = M.SemiringType(M.kAddMin, 0.0, zero)
+    dev = app.SSSP(M.num_hbm_channels, 1024, 512, 256, semiring=sem)
+    dev.set_up_runtime()
+    dev.load_and_format_matrix(m, True)
+    dev.send_matrix_host_to_device()
+    assert dev._device_loop_ok()
+    monkeypatch.setenv("GRAPHLILY_SSSP_DEVICE_LOOP", "0")
+    host = app.SSSP(M.num_hbm_channels, 1024, 512, 256, semiring=sem)
+    host.set_up_runtime()
+    host.load_and_format_matrix(m, True)
+    host.send_matrix_host_to_device()
+    seen = set()
+    for thr in (0.0, 1e-4, 1e-3, 1e-2, 0.05, 0.3, 2.0):
+        monkeypatch.setenv("GRAPHLILY_SSSP_DEVICE_LOOP", "0")
+        want = host.pull_push(0, iters, thr)
+        assert np.array_equal(want, ref)
+        monkeypatch.setenv("GRAPHLILY_SSSP_DEVICE_LOOP", "1")
+        for rep in range(3):
+            got = dev.pull_push(0, iters, thr)
+            assert np.array_equal(got, ref), (name, zero, thr, rep)
+            assert dev.push_iterations_ == host.push_iterations_, (thr, rep)
+        seen.add(host.push_iterations_)
+    assert len(seen) >= 3 and 1 in seen and (iters - 1) in seen, seen
+    # another iteration count on the same object (buffers regrow, graphs are rebuilt)
+    assert np.array_equal(dev.pull_push(0, 10, 0.01), O.sssp(_oracle_prepared(m, "sssp"), 0, 10, zero))
