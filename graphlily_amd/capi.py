@@ -40,7 +40,7 @@ EXPORTS = [
     "gl_spmv_run_typed", "gl_spmspv_run_typed", "gl_ewise_add_typed", "gl_assign_dense_typed", "gl_assign_sparse_typed",
     "gl_assign_sparse_new_frontier_typed", "gl_sparse_to_dense_typed",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32", "gl_buf_fill_u32_gated",
-    "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim", "gl_pool_stats",
+    "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim", "gl_pool_stats", "gl_host_pool_reserve", "gl_host_fill_u32", "gl_host_sparse_to_dense",
     "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_helper", "gl_spmv_plan_layout", "gl_spmv_plan_export", "gl_spmv_run",
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits", "gl_bfs_pull_step",
     "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every", "gl_span_begin", "gl_span_end",
@@ -104,6 +104,7 @@ def lib():
         "gl_buf_alloc": [P(vp), ctypes.c_size_t], "gl_buf_free": [vp],
         "gl_host_alloc": [P(vp), ctypes.c_size_t], "gl_host_free": [vp],
         "gl_host_pool_alloc": [P(vp), ctypes.c_size_t], "gl_host_pool_free": [vp], "gl_pool_trim": [], "gl_pool_stats": [P(u64), P(u64), P(u32)],
+        "gl_host_pool_reserve": [ctypes.c_size_t, u32], "gl_host_fill_u32": [vp, u32, ctypes.c_size_t], "gl_host_sparse_to_dense": [vp, u32, u32, vp],
         "gl_buf_h2d": [vp, vp, ctypes.c_size_t], "gl_buf_d2h": [vp, vp, ctypes.c_size_t],
         "gl_buf_d2d": [vp, vp, ctypes.c_size_t], "gl_buf_fill_f32": [vp, f32, ctypes.c_size_t],
         "gl_buf_fill_u32_gated": [vp, u32, ctypes.c_size_t, vp, u32],

@@ -257,6 +257,7 @@ int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, ui
 }
 
 int gl_ewise_add(const float *d_in, float *d_out, uint32_t len, float val) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     if (len == 0) return GL_OK;
     GL_ARG(d_in != nullptr && d_out != nullptr);
@@ -267,6 +268,7 @@ int gl_ewise_add(const float *d_in, float *d_out, uint32_t len, float val) {
 }
 
 int gl_assign_dense(const float *d_mask, float *d_inout, uint32_t len, float val, int mask_type) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     if (mask_type != GL_MASK_WRITETOZERO && mask_type != GL_MASK_WRITETOONE)
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_assign_dense: Invalid mask type %d", mask_type);
@@ -282,6 +284,7 @@ int gl_assign_dense(const float *d_mask, float *d_inout, uint32_t len, float val
 }
 
 int gl_assign_sparse(const gl_idx_val *d_mask, float *d_inout, float val, uint32_t max_entries) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(d_mask != nullptr && d_inout != nullptr);
     if (max_entries == 0) return GL_OK;
@@ -297,6 +300,7 @@ int gl_assign_sparse_new_frontier(const gl_idx_val *d_mask, float *d_inout, gl_i
 
 int gl_assign_sparse_new_frontier_gated(const gl_idx_val *d_mask, float *d_inout, gl_idx_val *d_new_frontier, uint32_t max_entries,
                                         const uint32_t *d_gate, uint32_t gate_value, int gate_op) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(d_mask != nullptr && d_inout != nullptr && d_new_frontier != nullptr);
     GL_ARG((const void *)d_mask != (const void *)d_new_frontier);
@@ -333,6 +337,7 @@ int gl_ewise_add_flagged(const float *d_in, float *d_out, uint32_t len, float va
 }
 
 int gl_sparse_to_dense(const gl_idx_val *d_sparse, float *d_dense, uint32_t range, float zero, uint32_t max_entries) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(d_sparse != nullptr && d_dense != nullptr);
     int rc = gl_buf_fill_f32(d_dense, zero, range);

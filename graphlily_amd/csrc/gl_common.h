@@ -46,6 +46,23 @@ inline bool prof_take(Profiler &pf) {
 
 int set_error(int code, const char *fmt, ...);
 
+// GRAPHLILY_TRACE_API=<file>: host-side timeline of the C ABI calls a process makes (name, start, duration in
+// microseconds since the first call, an optional size), written at exit -- where an UNMODIFIED reference driver spends its
+// time between its module calls (profiles/r03_api_timeline_*.txt).  Off: one predictable branch per call.
+struct ApiTrace {
+    const char *name;
+    double t0;
+    unsigned long long arg;
+    static bool on();
+    static double now_us();
+    static void record(const char *name, double t0, double t1, unsigned long long arg);
+    explicit ApiTrace(const char *n, unsigned long long a = 0) : name(n), t0(on() ? now_us() : 0.0), arg(a) {}
+    ~ApiTrace() {
+        if (on()) record(name, t0, now_us(), arg);
+    }
+};
+#define GL_TRACE(...) gl::ApiTrace gl_trace_(__func__, ##__VA_ARGS__)
+
 // one per translation unit with kernels: force the unit's code object onto the device (gl_init)
 int preload_spmv();
 int preload_spmv_bool();

@@ -3,6 +3,9 @@
 // cl::Buffer migrate/copy calls of the reference modules.
 #include "gl_common.h"
 
+#include <chrono>
+#include <omp.h>
+#include <sys/mman.h>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -118,6 +121,50 @@ Context &ctx() {
 Profiler &prof() {
     static Profiler p;
     return p;
+}
+
+// ---- GRAPHLILY_TRACE_API
+namespace {
+struct TraceRec {
+    const char *name;
+    double t0, t1;
+    unsigned long long arg;
+};
+std::vector<TraceRec> &trace_recs() {
+    static std::vector<TraceRec> *v = new std::vector<TraceRec>();
+    return *v;
+}
+std::mutex g_trace_mu;
+void trace_dump() {
+    const char *path = getenv("GRAPHLILY_TRACE_API");
+    FILE *f = (path && strcmp(path, "1") != 0 && strcmp(path, "stderr") != 0) ? fopen(path, "w") : stderr;
+    if (!f) return;
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    double prev = 0.0;
+    for (const TraceRec &r : trace_recs()) {
+        fprintf(f, "%12.1f  dur %9.1f  gap %9.1f  %-36s %llu\n", r.t0, r.t1 - r.t0, r.t0 - prev, r.name, r.arg);
+        prev = r.t1;
+    }
+    if (f != stderr) fclose(f);
+}
+}  // namespace
+
+bool ApiTrace::on() {
+    static const bool v = [] {
+        const char *e = getenv("GRAPHLILY_TRACE_API");
+        const bool yes = e && *e && strcmp(e, "0") != 0;
+        if (yes) atexit(trace_dump);
+        return yes;
+    }();
+    return v;
+}
+double ApiTrace::now_us() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+void ApiTrace::record(const char *name, double t0, double t1, unsigned long long arg) {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    trace_recs().push_back(TraceRec{name, t0, t1, arg});
 }
 
 static thread_local char g_err[512] = "";
@@ -317,12 +364,14 @@ int gl_graph_destroy(gl_graph graph) {
 }
 
 int gl_sync(void) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_HIP(hipStreamSynchronize(gl::ctx().stream));
     return GL_OK;
 }
 
 int gl_buf_alloc(void **d_ptr, size_t bytes) {
+    GL_TRACE(bytes);
     GL_REQUIRE_INIT();
     GL_ARG(d_ptr != nullptr);
     *d_ptr = nullptr;
@@ -385,6 +434,7 @@ int gl_buf_alloc(void **d_ptr, size_t bytes) {
 }
 
 int gl_buf_free(void *d_ptr) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     if (!d_ptr) return GL_OK;
     gl::BlockPool &P = gl::device_pool();
@@ -482,7 +532,92 @@ int gl_pool_stats(uint64_t *live_blocks, uint64_t *cached_bytes, uint32_t *slabs
     return GL_OK;
 }
 
+namespace gl {
+// A fresh host block of `want` bytes, paged in.  Blocks of 2 MB and more are 2 MB-aligned and advised as huge pages: a 12 MB
+// vector is then 6 faults instead of 3000 (first touch 0.3 ms instead of 2 ms where transparent huge pages are available).
+static void *fresh_host_block(size_t want, bool touch) {
+    void *p = nullptr;
+    const size_t huge = 2u << 20;
+    if (want >= huge) {
+        const size_t sz = (want + huge - 1) / huge * huge;
+        if (posix_memalign(&p, huge, sz) != 0) return nullptr;
+        (void)madvise(p, sz, MADV_HUGEPAGE);
+    } else if (posix_memalign(&p, 4096, want) != 0) {
+        return nullptr;
+    }
+    if (touch) {
+        const size_t nthreads = want >= (4u << 20) ? 4 : 1;
+        (void)nthreads;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+        for (long long off = 0; off < (long long)want; off += (1 << 20)) memset((char *)p + off, 0, std::min<size_t>(1u << 20, want - (size_t)off));
+    }
+    return p;
+}
+}  // namespace gl
+
+int gl_host_pool_reserve(size_t bytes, uint32_t count) {
+    if (bytes < gl::kHostPoolThreshold) return GL_OK;
+    gl::BlockPool &P = gl::host_pool();
+    const size_t want = gl::round_block(bytes);
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            if (!P.cap_bytes) P.cap_bytes = gl::pool_cap("host", 2048);
+            if (P.cached.count(want) >= count || P.cached_bytes + want > P.cap_bytes) return GL_OK;
+        }
+        void *p = gl::fresh_host_block(want, true);
+        if (!p) return gl::set_error(GL_ERR_INVALID_ARG, "gl_host_pool_reserve: out of host memory (%zu bytes)", want);
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.cached.emplace(want, p);
+        P.cached_bytes += want;
+        P.grown[want] = true;
+    }
+}
+
+int gl_host_fill_u32(void *h_dst, uint32_t word, size_t count) {
+    GL_ARG(h_dst != nullptr || count == 0);
+    uint32_t *d = static_cast<uint32_t *>(h_dst);
+    const int nt = count >= (1u << 20) ? 8 : 1;
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (long long i = 0; i < (long long)count; i++) d[i] = word;
+    return GL_OK;
+}
+
+int gl_host_sparse_to_dense(const gl_idx_val *h_sparse, uint32_t range, uint32_t zero_bits, void *h_dense) {
+    GL_ARG(h_sparse != nullptr && (h_dense != nullptr || range == 0));
+    uint32_t *d = static_cast<uint32_t *>(h_dense);
+    const uint32_t nnz = h_sparse[0].index;
+    const int nt = range >= (1u << 20) ? 8 : 1;
+    (void)nt;
+    // every thread fills its slice of the vector and then stores the entries that fall into it.  That needs the list in
+    // strictly ascending order (a SpMSpV result is: binary search for the slice's first entry); any other list -- where a
+    // repeated index means "the last one wins" -- is stored sequentially after the parallel fill.
+    int ascending = 1;
+#pragma omp parallel for num_threads(nt) schedule(static) reduction(&& : ascending)
+    for (long long k = 2; k <= (long long)nnz; k++) ascending = ascending && (h_sparse[k].index > h_sparse[k - 1].index);
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+        const uint32_t lo = (uint32_t)((uint64_t)range * t / T), hi = (uint32_t)((uint64_t)range * (t + 1) / T);
+        for (uint32_t i = lo; i < hi; i++) d[i] = zero_bits;
+        if (ascending) {
+            uint32_t a = 1, b = nnz + 1;
+            while (a < b) {
+                const uint32_t m = a + (b - a) / 2;
+                if (h_sparse[m].index < lo) a = m + 1; else b = m;
+            }
+            for (uint32_t k = a; k <= nnz && h_sparse[k].index < hi; k++) d[h_sparse[k].index] = __builtin_bit_cast(uint32_t, h_sparse[k].val);
+        }
+    }
+    if (!ascending)
+        for (uint32_t k = 1; k <= nnz; k++)
+            if (h_sparse[k].index < range) d[h_sparse[k].index] = __builtin_bit_cast(uint32_t, h_sparse[k].val);
+    return GL_OK;
+}
+
 int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
+    GL_TRACE(bytes);
     GL_ARG(h_ptr != nullptr);
     *h_ptr = nullptr;
     if (bytes == 0) bytes = 1;
@@ -509,9 +644,8 @@ int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
             }
         }
         if (hit) {
-            void *extra = nullptr;
-            if (grow && posix_memalign(&extra, 4096, want) == 0) {
-                memset(extra, 0, want);
+            void *extra = grow ? gl::fresh_host_block(want, true) : nullptr;
+            if (extra) {
                 std::lock_guard<std::mutex> lk(P.mu);
                 P.cached.emplace(want, extra);
                 P.cached_bytes += want;
@@ -528,18 +662,13 @@ int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
                 *h_ptr = nullptr;
             }
         }
-        if (!pinned && posix_memalign(h_ptr, 4096, want) != 0) {
-            *h_ptr = nullptr;
+        const bool page_in = !pinned && want >= gl::kSpareThreshold && gl::spare_on_miss();
+        if (!pinned && (*h_ptr = gl::fresh_host_block(want, page_in)) == nullptr)
             return gl::set_error(GL_ERR_INVALID_ARG, "gl_host_pool_alloc: out of host memory (%zu bytes)", want);
-        }
         // a miss on a large block parks one spare, and both are paged in now (a fresh 12 MB block costs ~3000 page
         // faults on first touch: 2 ms inside a 2 ms BFS, tests/cpp/api_breakdown.cpp)
         void *spare = nullptr;
-        if (!pinned && want >= gl::kSpareThreshold && gl::spare_on_miss()) {
-            memset(*h_ptr, 0, want);
-            if (posix_memalign(&spare, 4096, want) == 0) memset(spare, 0, want);
-            else spare = nullptr;
-        }
+        if (page_in) spare = gl::fresh_host_block(want, true);
         std::lock_guard<std::mutex> lk(P.mu);
         P.live[*h_ptr] = gl::BlockPool::Live{want, nullptr, -1, pinned != 0};
         if (spare) {
@@ -561,6 +690,7 @@ int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
 }
 
 int gl_host_pool_free(void *h_ptr) {
+    GL_TRACE();
     if (!h_ptr) return GL_OK;
     gl::BlockPool &P = gl::host_pool();
     bool pinned;
@@ -588,6 +718,7 @@ int gl_host_pool_free(void *h_ptr) {
 }
 
 int gl_buf_h2d(void *d_dst, const void *h_src, size_t bytes) {
+    GL_TRACE(bytes);
     GL_REQUIRE_INIT();
     if (bytes == 0) return GL_OK;
     GL_ARG(d_dst != nullptr && h_src != nullptr);
@@ -598,6 +729,7 @@ int gl_buf_h2d(void *d_dst, const void *h_src, size_t bytes) {
 }
 
 int gl_buf_d2h(void *h_dst, const void *d_src, size_t bytes) {
+    GL_TRACE(bytes);
     GL_REQUIRE_INIT();
     if (bytes == 0) return GL_OK;
     GL_ARG(h_dst != nullptr && d_src != nullptr);
@@ -616,6 +748,7 @@ int gl_buf_d2h_async(void *h_dst, const void *d_src, size_t bytes) {
 }
 
 int gl_buf_d2d(void *d_dst, const void *d_src, size_t bytes) {
+    GL_TRACE(bytes);
     GL_REQUIRE_INIT();
     if (bytes == 0) return GL_OK;
     GL_ARG(d_dst != nullptr && d_src != nullptr);
@@ -649,6 +782,7 @@ int gl_buf_fill_u32_gated(uint32_t *d_dst, uint32_t value, size_t count, const u
 }
 
 int gl_buf_fill_f32(float *d_dst, float value, size_t count) {
+    GL_TRACE(count);
     GL_REQUIRE_INIT();
     if (count == 0) return GL_OK;
     GL_ARG(d_dst != nullptr);

@@ -1035,6 +1035,7 @@ extern "C" {
 int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_cols,
                           const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
                           uint32_t row_begin, uint32_t row_end) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(plan != nullptr && h_indptr != nullptr);
     GL_ARG(row_begin <= row_end && row_end <= num_rows);
@@ -1175,6 +1176,7 @@ int gl_spmspv_run_gated(gl_spmspv_plan p, const gl_idx_val *d_vector, const floa
                         int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
                         const uint32_t *d_gate, uint32_t gate_value, int gate_op,
                         uint32_t *d_ctl, uint32_t slot, float dir_threshold, int may_continue_push) {
+    GL_TRACE();
     return spmspv_run_impl(p, d_vector, d_mask, d_result, op, zero, mask_type, d_inout, val, d_next_bits, d_gate, gate_value, gate_op,
                            d_ctl, slot, dir_threshold, may_continue_push, GL_VAL_FLOAT);
 }
@@ -1505,6 +1507,7 @@ int gl_bfs_bits_decide(gl_spmspv_plan p, const uint32_t *d_bits_next, const uint
 }
 
 int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(d_sparse != nullptr && nnz != nullptr);
     hipStream_t s = gl::ctx().stream;

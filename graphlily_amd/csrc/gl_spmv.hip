@@ -1020,6 +1020,7 @@ int gl_spmv_plan_create(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols
 int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_cols,
                            const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
                            uint32_t row_begin, uint32_t row_end, uint32_t flags) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(plan != nullptr && h_indptr != nullptr);
     GL_ARG(row_begin <= row_end && row_end <= num_rows);
@@ -1670,6 +1671,7 @@ int gl_spmv_plan_bits_words(gl_spmv_plan p, uint64_t *words) {
 }
 
 int gl_pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(n == 0 || (d_x != nullptr && d_bits != nullptr));
     GL_ARG(((uintptr_t)d_bits & 7u) == 0);
@@ -1677,6 +1679,7 @@ int gl_pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits) {
 }
 
 int gl_spmv_run_bits(gl_spmv_plan p, const uint32_t *d_bits, const float *d_mask, float *d_y, float zero, int mask_type) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(p != nullptr && d_y != nullptr && d_bits != nullptr);
     GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
@@ -1687,6 +1690,7 @@ int gl_spmv_run_bits(gl_spmv_plan p, const uint32_t *d_bits, const float *d_mask
 }
 
 int gl_bfs_pull_step(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(p != nullptr && d_bits_in != nullptr && d_bits_out != nullptr && d_distance != nullptr);
     GL_ARG(d_bits_in != d_bits_out);
@@ -1800,6 +1804,7 @@ int gl_spmv_plan_shape(gl_spmv_plan p, uint32_t *blocks, uint32_t *segments, uin
 
 int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero,
                 int mask_type) {
+    GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(p != nullptr && d_y != nullptr);
     GL_ARG(d_x != nullptr || p->nnz == 0);

@@ -15,9 +15,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <memory>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "graphlily_hip.h"
@@ -39,6 +42,13 @@ struct aligned_allocator {
         return reinterpret_cast<T *>(ptr);
     }
     void deallocate(T *p, std::size_t) { gl_host_pool_free(p); }
+    // vector<T, aligned_allocator<T>>(n) default-initialises its elements (no zero fill for the plain element types of this
+    // API: the n-element vectors the module layer creates for downloads are overwritten at once); vector(n, value) and
+    // every other construction go through the general overload as usual
+    template <typename U>
+    void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename A0, typename... Args>
+    void construct(U *p, A0 &&a0, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<A0>(a0), std::forward<Args>(args)...); }
     template <typename U>
     bool operator==(const aligned_allocator<U> &) const { return true; }
     template <typename U>
@@ -105,6 +115,18 @@ const std::string proj_folder_name = "proj";
 template <typename sparse_vec_t, typename dense_vec_t, typename value_t>
 dense_vec_t convert_sparse_vec_to_dense_vec(const sparse_vec_t &sparse_vector, uint32_t range, value_t zero) {
     dense_vec_t dense_vector(range);
+    typedef typename sparse_vec_t::value_type elem_t;
+    typedef typename dense_vec_t::value_type out_t;
+    // large float vectors (the push -> pull switch of app/bfs.h:196-201: a 3 M-element fill and a million scattered
+    // stores on the orkut stand-in) go to the library's few-thread host loop; same result, entry for entry
+    if (range >= (1u << 18) && sizeof(elem_t) == sizeof(gl_idx_val) && sizeof(out_t) == 4 && std::is_same<out_t, float>::value &&
+        !sparse_vector.empty() && (size_t)sparse_vector[0].index + 1 <= sparse_vector.size()) {
+        float z = (float)zero;
+        uint32_t zb;
+        memcpy(&zb, &z, 4);
+        if (gl_host_sparse_to_dense(reinterpret_cast<const gl_idx_val *>(sparse_vector.data()), range, zb, dense_vector.data()) == GL_OK)
+            return dense_vector;
+    }
     std::fill(dense_vector.begin(), dense_vector.end(), zero);
     const int nnz = sparse_vector[0].index;
     for (int i = 1; i < nnz + 1; i++) dense_vector[sparse_vector[i].index] = sparse_vector[i].val;

@@ -36,11 +36,15 @@ class SpMSpVModule : public BaseModule {
     // the head counts; only the head and those entries are transferred
     static aligned_sparse_vec_t download_sparse_(const DeviceBuffer &buf) {
         const size_t slots = buf.size() / sizeof(idx_val_t);
-        aligned_sparse_vec_t out(slots, idx_val_t{0, 0});
+        aligned_sparse_vec_t out(slots);   // (elements are not zero-filled: aligned_allocator::construct)
         if (!slots) return out;
         uint32_t nnz = 0;
         GRAPHLILY_CHECK(gl_sparse_nnz((const gl_idx_val *)buf.ptr(), &nnz));
-        buf.download(out.data(), sizeof(idx_val_t) * std::min(slots, (size_t)nnz + 1));
+        const size_t used = std::min(slots, (size_t)nnz + 1);
+        buf.download(out.data(), sizeof(idx_val_t) * used);
+        // beyond the entries the head counts the reference's mirror holds whatever earlier runs left there; here: zeros for
+        // vectors of moderate size, nothing defined for the multi-megabyte ones (filling 24 MB costs more than the download)
+        if (slots - used <= (1u << 16)) std::fill(out.begin() + used, out.end(), idx_val_t{0, 0});
         return out;
     }
 
@@ -74,6 +78,8 @@ public:
         plan_ = nullptr;
         GRAPHLILY_CHECK(gl_spmspv_plan_create(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
                                               m.adj_data.data(), sharded_ ? row_begin_ : 0, sharded_ ? row_end_ : m.num_rows));
+        GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(idx_val_t) * ((size_t)std::max(m.num_rows, m.num_cols) + 1), 2));
+        GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(float) * (size_t)std::max(m.num_rows, m.num_cols), 4));
         results_buf = DeviceBuffer(sizeof(idx_val_t) * ((size_t)m.num_rows + 1));
         const idx_val_t head{0, 0};   // an empty result list until the first run
         results_buf.upload(&head, sizeof(head));

@@ -105,6 +105,17 @@ int gl_host_free(void *h_ptr);
  * and retires the slabs still in use.  Host blocks are plain pages -- on the MI355X box
  * pageable and page-locked copies run at the same 56 GB/s while page-locking 12 MB costs 2.5 ms
  * (profiles/r02_ubench_host.txt); GRAPHLILY_HOST_PIN=1 page-locks them.  gl_pool_trim returns every cached block. */
+/* gl_host_pool_reserve: make sure `count` paged-in blocks for requests of `bytes` are parked (the C++ modules do this when a
+ * matrix is sent: a driver call then finds its n-element vectors -- two inputs, the result, the previous call's result still
+ * alive -- without a miss, which costs 2-4 ms of page faults for 12 MB inside a 2 ms BFS).  Blocks of 2 MB and more are
+ * 2 MB-aligned and advised as huge pages.
+ * gl_host_fill_u32 / gl_host_sparse_to_dense: the two host loops the reference's drivers run on n-element vectors between
+ * module calls -- vector fill and convert_sparse_vec_to_dense_vec (graphlily/global.h:153-164; the push -> pull switch of
+ * app/bfs.h:196-201) -- on a few host threads (the header-only C++ layer calls them for large vectors; the library is
+ * built with OpenMP, the caller need not be).  Need no GPU. */
+int gl_host_pool_reserve(size_t bytes, uint32_t count);
+int gl_host_fill_u32(void *h_dst, uint32_t word, size_t count);
+int gl_host_sparse_to_dense(const gl_idx_val *h_sparse, uint32_t range, uint32_t zero_bits, void *h_dense);
 int gl_host_pool_alloc(void **h_ptr, size_t bytes);
 int gl_host_pool_free(void *h_ptr);
 int gl_pool_trim(void);

@@ -130,3 +130,40 @@ def test_bfs_schedule_entry_points_fail_loudly_without_gpu():
     assert L.gl_buf_d2h_async(None, None, 16) == capi.GL_ERR_NOT_INITIALIZED
     assert L.gl_spmspv_plan_hint_tiny(None, 1, 1) == capi.GL_ERR_INVALID_ARG
     assert not hasattr(L, "gl_host_patch_bits") and not hasattr(L, "gl_side_copy_d2h")
+
+
+def test_host_helpers_need_no_gpu():
+    """gl_host_sparse_to_dense (convert_sparse_vec_to_dense_vec, graphlily/global.h:153-164, on a few host threads), gl_host_fill_u32
+    and gl_host_pool_reserve work without a device."""
+    import ctypes
+    L = capi.lib()
+    rng = np.random.default_rng(3)
+    n = 3_000_017
+    for kind in ("ascending", "unordered_with_repeats", "empty"):
+        if kind == "ascending":
+            idx = np.sort(rng.choice(n, size=400_000, replace=False)).astype(np.uint32)
+        elif kind == "unordered_with_repeats":
+            idx = rng.integers(0, n, size=300_000).astype(np.uint32)
+        else:
+            idx = np.zeros(0, np.uint32)
+        sv = np.zeros(idx.shape[0] + 1, dtype=capi.IDX_VAL)
+        sv["index"][0] = idx.shape[0]
+        sv["index"][1:] = idx
+        sv["val"][1:] = rng.random(idx.shape[0], dtype=np.float32) + 1.0
+        out = np.empty(n, np.float32)
+        zero = np.float32(255.0)
+        capi.check(L.gl_host_sparse_to_dense(sv.ctypes.data, n, int(zero.view(np.uint32)), out.ctypes.data))
+        ref = np.full(n, zero, np.float32)
+        for k in range(1, idx.shape[0] + 1) if kind != "ascending" else ():
+            ref[sv["index"][k]] = sv["val"][k]          # sequential: the last store to an index wins
+        if kind == "ascending":
+            ref[idx] = sv["val"][1:]
+        assert np.array_equal(out, ref), kind
+    buf = np.empty(2_500_001, np.uint32)
+    capi.check(L.gl_host_fill_u32(buf.ctypes.data, 0xdeadbeef, buf.shape[0]))
+    assert np.all(buf == 0xdeadbeef)
+    capi.check(L.gl_host_pool_reserve(5 << 20, 2))
+    p = ctypes.c_void_p(0)
+    capi.check(L.gl_host_pool_alloc(ctypes.byref(p), 5 << 20))
+    assert p.value and p.value % (2 << 20) == 0, "large host blocks are 2 MB-aligned (huge-page advice)"
+    capi.check(L.gl_host_pool_free(p))
