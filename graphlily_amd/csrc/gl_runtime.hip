@@ -549,7 +549,10 @@ static void *fresh_host_block(size_t want, bool touch) {
         const size_t nthreads = want >= (4u << 20) ? 4 : 1;
         (void)nthreads;
 #pragma omp parallel for num_threads(nthreads) schedule(static)
-        for (long long off = 0; off < (long long)want; off += (1 << 20)) memset((char *)p + off, 0, std::min<size_t>(1u << 20, want - (size_t)off));
+        for (long long off = 0; off < (long long)want; off += (1 << 20)) {   // one store per page: the kernel zero-fills on the fault
+            const size_t end = std::min<size_t>((size_t)off + (1u << 20), want);
+            for (size_t q = (size_t)off; q < end; q += 4096) ((volatile char *)p)[q] = 0;
+        }
     }
     return p;
 }
@@ -570,7 +573,6 @@ int gl_host_pool_reserve(size_t bytes, uint32_t count) {
         std::lock_guard<std::mutex> lk(P.mu);
         P.cached.emplace(want, p);
         P.cached_bytes += want;
-        P.grown[want] = true;
     }
 }
 

