@@ -392,6 +392,9 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence, keep=None):
     bfs.set_up_runtime()
     bfs.load_and_format_matrix(raw, True)
     bfs.send_matrix_host_to_device()
+    # row shards: every rank reads back ITS slice of the distances (the vector stays sharded); the count of
+    # reached vertices below is summed over the ranks
+    bfs.gather_result_ = not comm.distributed
     setup = time.time() - t0
     nnz = bfs.get_nnz()
     # the reference starts from vertex 0 (bench_bfs.cpp:46); the stand-ins are randomly relabelled, so
@@ -410,8 +413,14 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence, keep=None):
             fence()
             ts.append(time.perf_counter() - t0)
         t = float(np.median(ts))
-        res[mode] = {"ms": round(t * 1e3, 4), "gteps": round(nnz * iters / t / 1e9, 3),
-                     "reached": int((d != 0).sum())}
+        reached = int((d != 0).sum())
+        if comm.distributed and d.shape[0] < bfs.n_:      # a slice came back: sum the ranks' counts
+            import torch
+            gloo = comm.dist.get_backend(comm.group) == "gloo"
+            tt = torch.tensor([reached], dtype=torch.int64, device="cpu" if gloo else "cuda:%d" % device)
+            comm.dist.all_reduce(tt, group=comm.group)
+            reached = int(tt.item())
+        res[mode] = {"ms": round(t * 1e3, 4), "gteps": round(nnz * iters / t / 1e9, 3), "reached": reached}
         if mode == "pull_push":
             res[mode]["push_iterations"] = bfs.push_iterations_
     res.update({"iters": iters, "nnz": nnz, "setup_s": round(setup, 2), "threshold": 0.001, "source": source})

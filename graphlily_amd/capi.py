@@ -36,7 +36,7 @@ EXPORTS = [
     "gl_sssp_begin", "gl_assign_sparse_new_frontier_gated", "gl_spmv_run_flagged", "gl_ewise_add_flagged",
     "gl_bfs_begin", "gl_spmspv_plan_frontier_bits", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
     "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32", "gl_dist_all_gather_bits",
-    "gl_dist_all_gather_sparse",
+    "gl_dist_all_gather_sparse", "gl_dist_slice_plan",
     "gl_spmv_run_typed", "gl_spmspv_run_typed", "gl_ewise_add_typed", "gl_assign_dense_typed", "gl_assign_sparse_typed",
     "gl_assign_sparse_new_frontier_typed", "gl_sparse_to_dense_typed",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32", "gl_buf_fill_u32_gated",
@@ -95,7 +95,7 @@ def lib():
         "gl_bfs_pull_step_back": [vp, vp, vp, vp, f32, vp, u32, f32, i32, vp, vp],
         "gl_dist_unique_id": [vp], "gl_dist_init": [P(vp), i32, i32, vp], "gl_dist_destroy": [vp], "gl_dist_rank": [vp, P(i32), P(i32)],
         "gl_dist_all_gather_f32": [vp, vp, vp], "gl_dist_all_gather_bits": [vp, vp, vp],
-        "gl_dist_all_gather_sparse": [vp, vp, vp, u32, f32, P(u32)],
+        "gl_dist_all_gather_sparse": [vp, vp, vp, u32, f32, P(u32)], "gl_dist_slice_plan": [i32, i32, vp, vp, vp],
         "gl_spmv_run_typed": [vp, vp, vp, vp, i32, u32, i32, i32], "gl_spmspv_run_typed": [vp, vp, vp, vp, i32, u32, i32, i32],
         "gl_ewise_add_typed": [vp, vp, u32, u32, i32], "gl_assign_dense_typed": [vp, vp, u32, u32, i32, i32],
         "gl_assign_sparse_typed": [vp, vp, u32, u32], "gl_assign_sparse_new_frontier_typed": [vp, vp, vp, u32, i32],
@@ -551,6 +551,15 @@ class Graph:
                 lib().gl_graph_destroy(ctypes.c_void_p(self.handle))
         except Exception:
             pass
+
+
+def dist_slice_plan(kind, bounds_or_counts):
+    """gl_dist_slice_plan -> (lo_bytes, hi_bytes) per rank; kind 0 f32 bounds, 1 bit-vector row bounds, 2 sparse counts."""
+    a = np.ascontiguousarray(bounds_or_counts, dtype=np.uint32)
+    world = a.shape[0] - (0 if kind == 2 else 1)
+    lo, hi = np.zeros(world, np.uint64), np.zeros(world, np.uint64)
+    check(lib().gl_dist_slice_plan(int(kind), int(world), _np_ptr(a), ctypes.c_void_p(lo.ctypes.data), ctypes.c_void_p(hi.ctypes.data)))
+    return lo, hi
 
 
 class Dist:

@@ -85,18 +85,18 @@ int need_rccl(const char *who) {
     return set_error(GL_ERR_UNSUPPORTED, "%s: librccl.so could not be loaded (%s)", who, dlerror() ? dlerror() : "missing symbol");
 }
 
-// every rank's slice [lo[r], hi[r]) of `buf` (elements of `esize` bytes) to every other rank, in place
-int exchange_slices(gl_dist d, char *buf, const uint64_t *lo, const uint64_t *hi, size_t esize) {
+// every rank's slice [lo[r], hi[r]) (BYTE offsets into `buf`, gl_dist_slice_plan) to every other rank, in place
+int exchange_slices(gl_dist d, char *buf, const uint64_t *lo, const uint64_t *hi) {
     if (d->world == 1) return GL_OK;
     Rccl &R = rccl();
     hipStream_t s = ctx().stream;
-    const uint64_t mine = (hi[d->rank] - lo[d->rank]) * esize;
+    const uint64_t mine = hi[d->rank] - lo[d->rank];
     GL_NCCL(R.GroupStart());
     for (int p = 0; p < d->world; p++) {
         if (p == d->rank) continue;
-        const uint64_t theirs = (hi[p] - lo[p]) * esize;
-        if (mine) GL_NCCL(R.Send(buf + lo[d->rank] * esize, mine, ncclUint8, p, d->comm, s));
-        if (theirs) GL_NCCL(R.Recv(buf + lo[p] * esize, theirs, ncclUint8, p, d->comm, s));
+        const uint64_t theirs = hi[p] - lo[p];
+        if (mine) GL_NCCL(R.Send(buf + lo[d->rank], mine, ncclUint8, p, d->comm, s));
+        if (theirs) GL_NCCL(R.Recv(buf + lo[p], theirs, ncclUint8, p, d->comm, s));
     }
     GL_NCCL(R.GroupEnd());
     return GL_OK;
@@ -164,30 +164,57 @@ int gl_dist_rank(gl_dist d, int *rank, int *world_size) {
     return GL_OK;
 }
 
+// Which bytes of the exchanged buffer rank r owns (sends to everybody, is received from by everybody):
+//   GL_DIST_F32     in = world + 1 element bounds of a float vector           -> [4 lo, 4 hi)
+//   GL_DIST_BITS    in = world + 1 ROW bounds of a bit vector, multiples of 32 (the last one may be anything: it is the
+//                   end of the vector) -> whole 32-bit words [lo / 32, ceil(hi / 32)) x 4; a bound inside a word would
+//                   make two ranks write that word
+//   GL_DIST_SPARSE  in = world entry counts of the ranks' sparse lists -> rank r's entries follow the head element and
+//                   the entries of the ranks before it: [8 (1 + sum_{q<r} count_q), 8 (1 + sum_{q<=r} count_q))
+// Host arithmetic only (no device, no RCCL): what the three all-gathers below hand to the grouped send / receive.
+int gl_dist_slice_plan(int kind, int world_size, const uint32_t *in, uint64_t *lo_bytes, uint64_t *hi_bytes) {
+    GL_ARG(world_size >= 1 && in != nullptr && lo_bytes != nullptr && hi_bytes != nullptr);
+    uint64_t total = 0;
+    for (int r = 0; r < world_size; r++) {
+        switch (kind) {
+            case GL_DIST_F32:
+                GL_ARG(in[r] <= in[r + 1]);
+                lo_bytes[r] = 4ull * in[r];
+                hi_bytes[r] = 4ull * in[r + 1];
+                break;
+            case GL_DIST_BITS:
+                GL_ARG(in[r] <= in[r + 1]);
+                GL_ARG(in[r] % 32u == 0 && (in[r + 1] % 32u == 0 || r + 1 == world_size));
+                lo_bytes[r] = 4ull * (in[r] / 32u);
+                hi_bytes[r] = 4ull * (((uint64_t)in[r + 1] + 31u) / 32u);
+                break;
+            case GL_DIST_SPARSE:
+                lo_bytes[r] = 8ull * (1u + total);
+                total += in[r];
+                hi_bytes[r] = 8ull * (1u + total);
+                break;
+            default: return gl::set_error(GL_ERR_INVALID_ARG, "gl_dist_slice_plan: unknown kind %d", kind);
+        }
+    }
+    return GL_OK;
+}
+
 int gl_dist_all_gather_f32(gl_dist d, float *d_full, const uint32_t *bounds) {
     GL_REQUIRE_INIT();
     GL_ARG(d != nullptr && d_full != nullptr && bounds != nullptr);
     std::vector<uint64_t> lo(d->world), hi(d->world);
-    for (int r = 0; r < d->world; r++) {
-        GL_ARG(bounds[r] <= bounds[r + 1]);
-        lo[r] = bounds[r];
-        hi[r] = bounds[r + 1];
-    }
-    return gl::exchange_slices(d, reinterpret_cast<char *>(d_full), lo.data(), hi.data(), sizeof(float));
+    const int rc = gl_dist_slice_plan(GL_DIST_F32, d->world, bounds, lo.data(), hi.data());
+    if (rc != GL_OK) return rc;
+    return gl::exchange_slices(d, reinterpret_cast<char *>(d_full), lo.data(), hi.data());
 }
 
 int gl_dist_all_gather_bits(gl_dist d, uint32_t *d_bits, const uint32_t *row_bounds) {
     GL_REQUIRE_INIT();
     GL_ARG(d != nullptr && d_bits != nullptr && row_bounds != nullptr);
     std::vector<uint64_t> lo(d->world), hi(d->world);
-    for (int r = 0; r < d->world; r++) {
-        GL_ARG(row_bounds[r] <= row_bounds[r + 1]);
-        // whole words: a boundary inside a word would make two ranks write it
-        GL_ARG(row_bounds[r] % 32u == 0 && (row_bounds[r + 1] % 32u == 0 || r + 1 == d->world));
-        lo[r] = row_bounds[r] / 32u;
-        hi[r] = (row_bounds[r + 1] + 31u) / 32u;
-    }
-    return gl::exchange_slices(d, reinterpret_cast<char *>(d_bits), lo.data(), hi.data(), sizeof(uint32_t));
+    const int rc = gl_dist_slice_plan(GL_DIST_BITS, d->world, row_bounds, lo.data(), hi.data());
+    if (rc != GL_OK) return rc;
+    return gl::exchange_slices(d, reinterpret_cast<char *>(d_bits), lo.data(), hi.data());
 }
 
 int gl_dist_all_gather_sparse(gl_dist d, const gl_idx_val *d_local, gl_idx_val *d_full, uint32_t capacity, float head_val,
@@ -204,17 +231,19 @@ int gl_dist_all_gather_sparse(gl_dist d, const gl_idx_val *d_local, gl_idx_val *
     GL_HIP(hipMemcpyAsync(d->h_counts, d->d_counts, (size_t)d->world * 8u, hipMemcpyDeviceToHost, s));
     GL_HIP(hipStreamSynchronize(s));
     std::vector<uint64_t> lo(d->world), hi(d->world);
+    std::vector<uint32_t> counts(d->world);
     uint64_t total = 0;
     for (int r = 0; r < d->world; r++) {
-        lo[r] = 1u + total;            // entries follow the head element of the concatenated list
-        total += d->h_counts[2 * r];
-        hi[r] = 1u + total;
+        counts[r] = d->h_counts[2 * r];
+        total += counts[r];
     }
+    rc = gl_dist_slice_plan(GL_DIST_SPARSE, d->world, counts.data(), lo.data(), hi.data());   // entries follow the head element
+    if (rc != GL_OK) return rc;
     if (total > capacity) return gl::set_error(GL_ERR_INVALID_ARG, "gl_dist_all_gather_sparse: %llu entries exceed the capacity %u", (unsigned long long)total, capacity);
     // 2. my entries into my place of the full list, then the slices travel (rank order = ascending rows: the ranges are disjoint)
     const uint64_t mine = hi[d->rank] - lo[d->rank];
-    if (mine) GL_HIP(hipMemcpyAsync(d_full + lo[d->rank], d_local + 1, mine * sizeof(gl_idx_val), hipMemcpyDeviceToDevice, s));
-    rc = gl::exchange_slices(d, reinterpret_cast<char *>(d_full), lo.data(), hi.data(), sizeof(gl_idx_val));
+    if (mine) GL_HIP(hipMemcpyAsync(reinterpret_cast<char *>(d_full) + lo[d->rank], d_local + 1, mine, hipMemcpyDeviceToDevice, s));
+    rc = gl::exchange_slices(d, reinterpret_cast<char *>(d_full), lo.data(), hi.data());
     if (rc != GL_OK) return rc;
     gl::dist_write_head_kernel<<<1, 1, 0, s>>>(d_full, (uint32_t)total, head_val);
     GL_LAUNCH_CHECK();

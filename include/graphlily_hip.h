@@ -489,6 +489,14 @@ int gl_sparse_to_dense_typed(const void *d_sparse, void *d_dense, uint32_t range
  *                              into d_full with head {total, head_val}; reads the counts back (blocking), like
  *                              SpMSpVModule::get_results_nnz in the reference's push loops. */
 typedef struct gl_dist_s *gl_dist;
+/* gl_dist_slice_plan: the host arithmetic of the three all-gathers -- which BYTES of the exchanged buffer each rank owns:
+ * GL_DIST_F32 (in: world + 1 element bounds), GL_DIST_BITS (in: world + 1 row bounds, multiples of 32 except the last;
+ * whole words), GL_DIST_SPARSE (in: world entry counts; entries follow the head element in rank order).  Needs neither a
+ * device nor RCCL, so the uneven-bounds cases are unit-tested on the CPU. */
+#define GL_DIST_F32 0
+#define GL_DIST_BITS 1
+#define GL_DIST_SPARSE 2
+int gl_dist_slice_plan(int kind, int world_size, const uint32_t *in, uint64_t *lo_bytes, uint64_t *hi_bytes);
 int gl_dist_unique_id(void *id128);
 int gl_dist_init(gl_dist *comm, int rank, int world_size, const void *id128);
 int gl_dist_destroy(gl_dist comm);

@@ -106,10 +106,26 @@ def _graph():
     return m
 
 
-def _apps(comm, which):
+def _skewed_graph():
+    """Power-law rows in their generator order (no relabelling): the nnz-balanced row ranges of 4 and 8 ranks are far from
+    equal length, so every all-gather takes the pad / unpack branch (dist.Comm.all_gather_slices)."""
+    n, m = 4096, 60000
+    rng = np.random.default_rng(5)
+    w = 1.0 / np.arange(1, n + 1) ** 0.9
+    rows = rng.choice(n, size=m, p=w / w.sum())
+    cols = rng.integers(0, n, size=m)
+    rows, cols = np.concatenate([rows, cols]), np.concatenate([cols, rows])
+    key = np.unique(rows.astype(np.int64) * n + cols)
+    r, c = (key // n).astype(np.int64), (key % n).astype(np.uint32)
+    indptr = np.zeros(n + 1, np.int64)
+    np.add.at(indptr, r + 1, 1)
+    return io.CSRMatrix(n, n, np.ones(key.shape[0], np.float32), c, np.cumsum(indptr).astype(np.uint32))
+
+
+def _apps(comm, which, graph=None):
     from cpu_backend import CpuBackend
     from graphlily_amd import app, module as M
-    m = _graph()
+    m = _graph() if graph is None else graph
     if which == "bfs":
         a = app.BFS(16, 1024, 512, 256, comm=comm, backend=CpuBackend())
         a.set_up_runtime()
@@ -139,6 +155,42 @@ def _body_pagerank(comm):
 
 def _body_sssp(comm):
     return _apps(comm, "sssp")
+
+
+def _body_bfs_skewed(comm):
+    return _apps(comm, "bfs", _skewed_graph())
+
+
+def _body_pagerank_skewed(comm):
+    return _apps(comm, "pagerank", _skewed_graph())
+
+
+def _body_sssp_skewed(comm):
+    return _apps(comm, "sssp", _skewed_graph())
+
+
+def _body_gather_uneven_many(comm):
+    """float slices, bit-vector words and sparse lists over uneven ranges, one of them EMPTY"""
+    W, n = comm.world_size, 64 * 41
+    cuts = sorted(set([0, n] + [64 * k for k in (1, 2, 9, 9, 20, 33, 40)]))[: W + 1]
+    bounds = (cuts + [n] * (W + 1))[: W + 1]
+    bounds[-1] = n
+    bounds[2] = bounds[1]                      # rank 1 owns nothing
+    lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+    full = torch.full((n,), -1.0)
+    full[lo:hi] = torch.arange(lo, hi, dtype=torch.float32)
+    comm.all_gather_slices(full, bounds)
+    ok = bool(torch.equal(full, torch.arange(n, dtype=torch.float32)))
+    words = torch.zeros(n // 32, dtype=torch.int32)
+    words[lo // 32:hi // 32] = torch.arange(lo // 32, hi // 32, dtype=torch.int32) + 1
+    comm.all_gather_slices(words, [b // 32 for b in bounds])
+    ok = ok and bool(torch.equal(words, torch.arange(n // 32, dtype=torch.int32) + 1))
+    cnt = (comm.rank * 7) % 5                  # some ranks contribute nothing
+    local = torch.arange(100 * comm.rank, 100 * comm.rank + cnt, dtype=torch.int64)
+    out = torch.zeros(64, dtype=torch.int64)
+    total = comm.all_gather_sparse(local, cnt, 64, out)
+    want = [100 * r + k for r in range(W) for k in range((r * 7) % 5)]
+    return ok and total == len(want) and out[:total].tolist() == want
 
 
 # ------------------------------------------------------------------ tests
@@ -209,3 +261,85 @@ def test_distributed_sssp_matches_oracle():
     for r in (0, 1):
         for got in out[r]:
             assert np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------ worlds of 4 and 8, uneven ranges
+def _oracle_skewed(sssp=False, pagerank=False):
+    m = _skewed_graph()
+    om = O.CSR(m.num_rows, m.num_cols, m.adj_data, m.adj_indices, m.adj_indptr)
+    if sssp:
+        O.sssp_preprocess(om)
+    O.util_round_csr_matrix_dim(om, 128, 128)
+    if pagerank:
+        O.util_normalize_csr_matrix_by_outdegree(om)
+        om.adj_data = (om.adj_data * np.float32(0.9)).astype(np.float32)
+    elif not sssp:
+        om.adj_data[:] = 1
+    return om
+
+
+def test_skewed_partition_is_uneven():
+    m = _skewed_graph()
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    for w in (4, 8):
+        b = partition_rows_by_nnz(m.adj_indptr, w)
+        lens = np.diff(b)
+        assert lens.max() >= 3 * max(lens.min(), 1), "hub rows first: the balanced ranges differ several-fold in length"
+        per = np.diff(m.adj_indptr.astype(np.int64)[b])
+        assert per.max() <= 2.5 * m.nnz / w
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_gathers_over_many_uneven_ranges(world):
+    assert all(_spawn("_body_gather_uneven_many", world).values())
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_distributed_bfs_many_ranks(world):
+    ref = O.bfs(_oracle_skewed(), 0, 6)
+    out = _spawn("_body_bfs_skewed", world)
+    for r in range(world):
+        for got in out[r]:
+            assert np.array_equal(got, ref)
+    assert (ref != 0).sum() > ref.shape[0] // 2
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_distributed_pagerank_many_ranks(world):
+    ref = O.pagerank(_oracle_skewed(pagerank=True), 0.9, 5)
+    out = _spawn("_body_pagerank_skewed", world)
+    for r in range(world):
+        assert np.array_equal(out[r][0], ref)
+
+
+def test_distributed_sssp_four_ranks():
+    ref = O.sssp(_oracle_skewed(sssp=True), 0, 6, 255.0)
+    out = _spawn("_body_sssp_skewed", 4)
+    for r in range(4):
+        for got in out[r]:
+            assert np.array_equal(got, ref)
+
+
+def test_gl_dist_slice_plan_arithmetic():
+    """gl_dist_slice_plan: the bounds -> byte ranges arithmetic of the C ABI's three all-gathers (csrc/gl_dist.hip), which
+    no one-GPU box can exercise with peers: float slices, whole words of a bit vector, sparse lists behind the head."""
+    from graphlily_amd import capi
+    lo, hi = capi.dist_slice_plan(0, [0, 100, 100, 4096])
+    assert lo.tolist() == [0, 400, 400] and hi.tolist() == [400, 400, 16384]
+    # bit vectors: multiples of 32 rows inside, the end of the vector anywhere (rounded up to a whole word)
+    lo, hi = capi.dist_slice_plan(1, [0, 64, 64, 320, 1000])
+    assert lo.tolist() == [0, 8, 8, 40] and hi.tolist() == [8, 8, 40, 128]
+    assert all(h0 == l1 for h0, l1 in zip(hi[:-1], lo[1:])), "the ranges tile the vector: no word has two writers"
+    with pytest.raises(capi.GraphLilyError):
+        capi.dist_slice_plan(1, [0, 48, 128])              # a boundary inside a word
+    with pytest.raises(capi.GraphLilyError):
+        capi.dist_slice_plan(0, [0, 200, 100])             # decreasing
+    # sparse lists: entries follow the 8-byte head, rank order
+    lo, hi = capi.dist_slice_plan(2, [3, 0, 5, 1])
+    assert lo.tolist() == [8, 32, 32, 72] and hi.tolist() == [32, 32, 72, 80]
+    # the nnz-balanced bounds of a power-law matrix at 8 ranks
+    m = _skewed_graph()
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    b = partition_rows_by_nnz(m.adj_indptr, 8)
+    lo, hi = capi.dist_slice_plan(1, b)
+    assert lo[0] == 0 and hi[-1] == 4 * ((m.num_rows + 31) // 32) and np.all(hi[:-1] == lo[1:]) and np.all(hi >= lo)

@@ -152,6 +152,27 @@ def test_bench_self_launches_two_ranks(gpu):
     assert "error" not in rec.get("bfs", {}), rec["bfs"]
 
 
+def test_bench_self_launches_eight_ranks(gpu):
+    """The 8-rank launch the driver performs at round end, as far as one GPU goes: eight processes, eight row shards of the
+    stand-in (scale 0.05), gloo with host-staged collectives, every rank on cuda:0.  The row-sharded SpMV step (uneven
+    nnz-balanced ranges), the device-resident sharded BFS schedule with its per-slot all-gather and gl_bfs_bits_decide, and
+    the max-over-ranks timing all run with world = 8."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--same-gpu",
+                        "--steps", "5", "--warmup", "1", "--scale", "0.05", "--bfs-runs", "1", "--no-pattern"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["selfcheck_ok"] is True and rec["scaling"] == "strong"
+    assert "error" not in rec.get("bfs", {}), rec["bfs"]
+    assert rec["bfs"]["pull"]["reached"] == rec["bfs"]["pull_push"]["reached"] > 0
+
+
 def test_bench_one_rank_rccl(gpu):
     """The RCCL leg of bench.py as far as one GPU allows: `--force-dist` creates the nccl process group for a world of
     one and runs every collective of the N > 1 path on it -- the in-place all_gather_into_tensor of the SpMV step, the
