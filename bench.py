@@ -45,7 +45,9 @@ def spmv_bytes(nnz, n_rows, n_cols, masked=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)      # bench_spmv.cpp:96 runs 100
+    ap.add_argument("--steps", type=int, default=0,
+                    help="timed steps; 0 (default) = as many as make the timed region last ~1 s (bench_spmv.cpp:96 runs 100: "
+                         "at 0.3 ms per step that is a 30 ms region, too short for SMI sampling to see)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graph", default="orkut")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the stand-in (debug only)")
@@ -142,6 +144,18 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if args.steps <= 0:      # calibrate: ~1 s of timed steps, the same count on every rank
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step()
+        fence()
+        per = (time.perf_counter() - t0) / 20
+        k = int(min(max(1.0 / max(per, 1e-6), 100), 20000))
+        if use_dist:
+            tk = torch.tensor([k], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+            k = int(tk.item())
+        args.steps = k
     # HIP events bracket every 4th launch of the dominant kernel inside the timed region: an event pair keeps the
     # neighbouring launches from overlapping the kernel's first and last workgroups (every launch bracketed: +5 %
     # per step), so the roofline's per-launch time is the isolated one while `value` stays near the unprofiled rate
@@ -197,6 +211,8 @@ def main():
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": _pmc_traffic(args.graph, world, args.scale),
+            "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a RECORDED run of this "
+                              "workload (counters cannot be read from inside the benchmark process); null = no recorded run matches",
             "bytes_per_launch": shard_bytes, "kernel_ms": round(kern_ms, 5), "launches": launches,
             "launches_timed": "every %d-th of %d" % (args.prof_every, args.steps),
         },
@@ -424,9 +440,47 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence, keep=None):
         if mode == "pull_push":
             res[mode]["push_iterations"] = bfs.push_iterations_
     res.update({"iters": iters, "nnz": nnz, "setup_s": round(setup, 2), "threshold": 0.001, "source": source})
+    res["gteps_definition"] = "nnz x iterations / time (bench_bfs.cpp:68-71): NOMINAL edges, whatever the direction touched"
+    if not comm.distributed and getattr(bfs, "bfs_slot_modes_", None) is not None:
+        try:
+            res["pull_push"].update(_edges_traversed(bfs, raw, lambda: bfs.pull_push(source, iters, 0.001), iters, res["pull_push"]["ms"]))
+            res["pull"].update(_edges_traversed(bfs, raw, lambda: bfs.pull(source, iters), iters, res["pull"]["ms"]))
+        except Exception as e:
+            res["edges_traversed_error"] = repr(e)
     if keep is not None:
         keep["bfs"] = bfs
     return res
+
+
+def _edges_traversed(bfs, raw, fn, iters, ms):
+    """beside the nominal GTEPS, the edges a run actually looked at.  Per slot, from how the device evaluated
+    it (BFS.bfs_slot_modes_): scattered = the non-zeros of the frontier's columns; streamed row-wise = every non-zero of
+    the matrix; bottom-up = AT MOST the non-zeros of the rows not reached before the slot (a row stops at its first hit)."""
+    d = fn().astype(np.int64)
+    modes = [int(v) for v in bfs.bfs_slot_modes_]
+    n = d.shape[0]
+    ip = raw.adj_indptr.astype(np.int64)
+    row_len = np.zeros(n, np.int64)
+    row_len[:raw.num_rows] = np.diff(ip)
+    col_len = np.bincount(raw.adj_indices[:ip[-1]], minlength=n).astype(np.int64)
+    per_slot, total, bound = [], 0, False
+    for s in range(1, iters + 1):
+        m = modes[s - 1] if s - 1 < len(modes) else 0
+        if m == 1:
+            e = int(col_len[d == s].sum())
+        elif m == 2:
+            e = int(ip[-1])
+        elif m == 3:
+            e = int(row_len[(d == 0) | (d > s)].sum())
+            bound = True
+        else:
+            e = 0
+        per_slot.append(e)
+        total += e
+    return {"slot_modes": modes[:iters], "edges_traversed_per_slot": per_slot, "edges_traversed": total,
+            "edges_traversed_is_upper_bound": bound,
+            "gteps_traversed": round(total / (ms * 1e-3) / 1e9, 3),
+            "slot_modes_legend": "1 scattered (frontier columns), 2 streamed row-wise (whole matrix), 3 bottom-up (unreached rows, early exit), 0 nothing ran"}
 
 
 def _cpu_baseline(csr, x, alg_bytes):

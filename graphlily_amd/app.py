@@ -447,7 +447,7 @@ class BFS(_GraphApp):
         st = getattr(self, "bits_loop_", None)
         if st is None or st["N"] < N:
             words = (int(self.SpMV_.bits_words()) + 3) & ~3
-            nvec, ctl_words = N + 2, (17 + N + 15) & ~15
+            nvec, ctl_words = N + 2, (18 + 2 * N + 15) & ~15
             both = B.alloc(n + ctl_words, np.float32)          # distances, then the control words: one read-back fetches both
             vecs = B.alloc(nvec * words, np.float32)
             st = self.bits_loop_ = {"N": N, "both": both, "vecs": vecs, "words": words, "nvec": nvec, "ctl_words": ctl_words,
@@ -528,7 +528,9 @@ class BFS(_GraphApp):
             self.result_range_ = (0, n)
         self.push_iterations_ = int(c[1])          # the reference's count (first push phase)
         self.push_iterations_again_ = int(c[3])    # pushes after a pull step handed back
-        self.bfs_slot_counts_ = c[17:17 + N].copy()   # vertices reached per slot
+        S = (cw - 16) // 2
+        self.bfs_slot_counts_ = c[17:17 + N].copy()             # vertices reached per slot
+        self.bfs_slot_modes_ = c[17 + S:17 + S + N].copy()      # 1 scattered, 2 streamed row-wise, 3 bottom-up, 0 nothing ran
         return res
 
     def _exchange_bits(self, st, k):

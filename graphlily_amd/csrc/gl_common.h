@@ -205,7 +205,7 @@ __device__ __forceinline__ bool value_is_zero(float v) {
 }
 
 // ------------------------------------------------------------------ device-resident BFS schedule, frontier as bits only
-// (gl_bfs_bits_*): 16 control words + one per slot (the new-frontier count of slot s in word 16 + s).  [0] first pull slot (0xffffffff while pushing), [1] push iterations of the first
+// (gl_bfs_bits_*): 16 control words + two per slot (the new-frontier count of slot s in word 16 + s, how it was evaluated behind them).  [0] first pull slot (0xffffffff while pushing), [1] push iterations of the first
 // push phase (the reference's count), [2] source vertex, [3] pushes after a pull step handed the loop back, [4] the slot
 // that handed back (0xffffffff: none), [5] new-frontier count of the running step, [6] workgroup ticket of the running
 // step, [7] the threshold the hand-back used, [8] the slot whose PUSH goes row-wise (its frontier's columns hold more
@@ -232,11 +232,19 @@ struct BfsBitsCtl {
     // ctl[14]: a slot reached nothing -- the frontier is empty, no later slot can change a distance: the steps only keep
     // the books from then on (the reference's loops run their remaining iterations on an empty vector)
     __device__ bool finished() const { return ctl[14] != 0u; }
+    // ctl[15] = words of ctl: the words behind the 16 control words are two arrays of S = (ctl[15] - 16) / 2 entries, the
+    // vertices slot s reached (ctl[16 + s]) and HOW the slot was evaluated (ctl[16 + S + s]: 1 scattered, 2 streamed
+    // row-wise, 3 bottom-up; 0: nothing ran) -- the host's "edges actually traversed" 
+    __device__ uint32_t slot_capacity() const { return (ctl[15] - 16u) >> 1; }
+    __device__ void record_mode(uint32_t mode) const {
+        const uint32_t S = slot_capacity();
+        if (slot < S) ctl[16u + S + slot] = mode;
+    }
     // called once per slot, when the step that ran is complete, with the step's totals: vertices reached, non-zeros in
     // their columns (what a push from them scatters) and in their rows (what a pull no longer has to look at)
     __device__ void decide(uint32_t fresh, unsigned long long work, unsigned long long work_rows) const {
         if (fresh == 0u) ctl[14] = 1u;
-        if (16u + slot < ctl[15]) ctl[16u + slot] = fresh;   // the slot's new-frontier size, for the host (ctl[15] = words of ctl)
+        if (slot < slot_capacity()) ctl[16u + slot] = fresh;   // the slot's new-frontier size, for the host
         unsigned long long *visited = reinterpret_cast<unsigned long long *>(ctl + 12);
         const unsigned long long vis = *visited + work_rows;
         *visited = vis;

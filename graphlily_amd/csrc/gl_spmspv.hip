@@ -405,6 +405,7 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
     if (a.c.finished()) return;
     const bool scatter = a.c.scatters();
     if (!scatter && !(a.row_idx && a.c.bottom_up())) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.c.record_mode(scatter ? 1u : 3u);
     if (threadIdx.x == 0) {
         s_fresh = 0u;
         s_nhit = 0u;

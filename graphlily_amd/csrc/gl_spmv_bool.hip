@@ -128,6 +128,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         const uint32_t w = *a.gate;
         if (!(a.gate_op == GL_GATE_EQ ? w == a.gate_value : a.gate_op == GL_GATE_GT ? w > a.gate_value : w <= a.gate_value)) return;
     }
+    if (a.v2.ctl && blockIdx.x == 0 && threadIdx.x == 0) a.v2.record_mode(2u);   // this slot streams the matrix row-wise
     const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
     const uint32_t span0 = d.x, nspans = d.y, row0 = d.z;
     const uint32_t nrows = d.w & 0xffffu;

@@ -341,10 +341,12 @@ int gl_ewise_add_flagged(const float *d_in, float *d_out, uint32_t len, float va
 
 /* Second form of the device-resident BFS schedule (replaces app/bfs.h:146-152 + :180-205 for a whole-matrix BFS on one
  * GPU): the frontier lives as BITS only and an iteration slot is TWO launches.
- *   d_ctl     ctl_words >= 17 + slots words, 8-byte aligned: [0] first pull slot (0xffffffff while pushing), [1] push
+ *   d_ctl     ctl_words >= 18 + 2 * slots words, 8-byte aligned: [0] first pull slot (0xffffffff while pushing), [1] push
  *             iterations of the first push phase (the reference's count), [2] source vertex (written by the host before
  *             the schedule), [3] pushes after a pull step handed the loop back, [4] the slot that handed back, [5..14]
- *             internal, [15] ctl_words, [16 + s] the number of vertices slot s reached (slots beyond ctl_words are not recorded).
+ *             internal, [15] ctl_words; behind them two arrays of S = (ctl_words - 16) / 2 words: [16 + s] the number of
+ *             vertices slot s reached, [16 + S + s] how slot s was evaluated (1 scattered, 2 streamed row-wise, 3 bottom-up;
+ *             slots >= S are not recorded).
  *   d_bits    nvec >= slots + 2 bit vectors of bits_words words each, contiguous, 16-byte aligned (bits_words a multiple of
  *             4 -- the steps write whole 64-bit words --, at least gl_spmv_plan_bits_words of the pull plan): slot s (1, 2, ...) reads vector s and writes vector
  *             s + 1, which therefore holds exactly the vertices at distance s + 1 when the schedule has run.
