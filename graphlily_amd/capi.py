@@ -42,7 +42,7 @@ EXPORTS = [
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32", "gl_buf_fill_u32_gated",
     "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim", "gl_pool_stats", "gl_host_pool_reserve", "gl_host_fill_u32", "gl_host_sparse_to_dense",
     "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_helper", "gl_spmv_plan_layout", "gl_spmv_plan_export", "gl_spmv_run",
-    "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_spmv_run_bits", "gl_bfs_pull_step",
+    "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_unpack_bits", "gl_bfs_bits_begin_from", "gl_spmv_run_bits", "gl_bfs_pull_step",
     "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every", "gl_span_begin", "gl_span_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run", "gl_spmspv_run_assign",
     "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_plan_hint_tiny", "gl_spmspv_last_direction",
@@ -116,7 +116,7 @@ def lib():
         "gl_spmv_plan_helper": [vp, P(i32), P(u32)],
         "gl_spmv_plan_layout": [vp, P(i32)],
         "gl_spmv_plan_export": [vp, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)],
-        "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
+        "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_unpack_bits": [vp, u32, vp], "gl_bfs_bits_begin_from": [vp, u32, vp, u32, vp, u32], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
         "gl_bfs_pull_step": [vp, vp, vp, vp, f32],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
         "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)], "gl_prof_sample_every": [u32], "gl_span_begin": [], "gl_span_end": [P(ctypes.c_double)],

@@ -69,6 +69,28 @@ __global__ __launch_bounds__(256) void spmv_bool_pack_kernel(const float *__rest
     }
 }
 
+// the inverse: x[c] = bit c ? 1.0f : 0.0f (a frontier kept as bits handed back to a caller that reads the float vector)
+__global__ __launch_bounds__(256) void spmv_bool_unpack_kernel(const uint32_t *__restrict__ bits, uint32_t n, float *__restrict__ x) {
+    for (uint32_t c = blockIdx.x * 256u + threadIdx.x; c < n; c += gridDim.x * 256u) x[c] = ((bits[c >> 5] >> (c & 31u)) & 1u) ? 1.0f : 0.0f;
+}
+
+// gl_bfs_bits_begin_from: control words of a schedule that pulls in every slot + three rotating bit vectors, the first packed
+// from the caller's float frontier (the caller's distances are left alone)
+__global__ __launch_bounds__(256) void bfs_bits_begin_from_kernel(uint32_t *__restrict__ ctl, uint32_t ctl_words, const float *__restrict__ x,
+                                                                  uint32_t n, uint64_t *__restrict__ bits, uint32_t words64) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    if (tid < ctl_words) ctl[tid] = tid == 4u ? 0xffffffffu : (tid == 15u ? ctl_words : 0u);   // [0] = 0: every slot pulls
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < 3u * words64; w += gridDim.x * 4u) {
+        uint64_t m = 0ull;
+        if (w < words64) {
+            const uint32_t c = w * 64u + lane;
+            m = __ballot(c < n && x[c] != 0.0f);
+        }
+        if (lane == 0) bits[w] = m;
+    }
+}
+
 #ifndef GL_BOOL_STEP
 #define GL_BOOL_STEP 2
 #endif
@@ -550,6 +572,21 @@ int pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits, hipStream_t s) {
     if (!nwords64) return GL_OK;
     spmv_bool_pack_kernel<<<std::min<unsigned>(cdiv(nwords64, 4), (unsigned)ctx().num_cus * 16u), 256, 0, s>>>(
         d_x, n, reinterpret_cast<uint64_t *>(d_bits), nwords64);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int unpack_bits(const uint32_t *d_bits, uint32_t n, float *d_x, hipStream_t s) {
+    if (!n) return GL_OK;
+    spmv_bool_unpack_kernel<<<std::min<unsigned>(cdiv(n, 256), (unsigned)ctx().num_cus * 16u), 256, 0, s>>>(d_bits, n, d_x);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t words, hipStream_t s) {
+    const uint32_t words64 = words / 2u;
+    const unsigned grid = std::max<unsigned>(cdiv(ctl_words, 256), std::min<unsigned>(cdiv(3u * words64, 4), (unsigned)ctx().num_cus * 16u));
+    bfs_bits_begin_from_kernel<<<grid, 256, 0, s>>>(d_ctl, ctl_words, d_x, n, reinterpret_cast<uint64_t *>(d_bits), words64);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

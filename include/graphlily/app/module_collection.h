@@ -31,6 +31,7 @@ public:
 
     void add_module(BaseModule *module) {
         modules_.push_back(module);
+        module->set_owner(this);   // modules of one collection that hold the same matrix are paired (module/fusion.h)
         kernel_names_.push_back(module->get_kernel_name());
         num_modules_++;
     }

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -151,6 +152,10 @@ class DeviceBuffer {
     struct Impl {
         void *ptr = nullptr;
         size_t bytes = 0;
+        // Set while the buffer's contents are owed by a deferred / fused module call (module/fusion.h): the first access
+        // through ptr() settles the debt -- runs the deferred calls, or writes the float vector a fused BFS pull iteration
+        // kept as bits -- so every reader sees what the unfused call sequence would have left.
+        std::function<void()> on_access;
         ~Impl() { if (ptr) gl_buf_free(ptr); }
     };
     std::shared_ptr<Impl> impl_;
@@ -161,9 +166,17 @@ public:
         GRAPHLILY_CHECK(gl_buf_alloc(&impl_->ptr, bytes));
         impl_->bytes = bytes;
     }
-    void *ptr() const { return impl_ ? impl_->ptr : nullptr; }
+    void *ptr() const {
+        if (!impl_) return nullptr;
+        if (impl_->on_access) {
+            std::function<void()> f;
+            f.swap(impl_->on_access);     // cleared first: the settling code uses the buffer itself
+            f();
+        }
+        return impl_->ptr;
+    }
     size_t size() const { return impl_ ? impl_->bytes : 0; }
-    bool valid() const { return ptr() != nullptr; }
+    bool valid() const { return impl_ && impl_->ptr != nullptr; }
     void upload(const void *host, size_t bytes) const {
         assert(bytes <= size());
         GRAPHLILY_CHECK(gl_buf_h2d(ptr(), host, bytes));
@@ -171,6 +184,17 @@ public:
     void download(void *host, size_t bytes) const {
         assert(bytes <= size());
         GRAPHLILY_CHECK(gl_buf_d2h(host, ptr(), bytes));
+    }
+    // ---- for module/fusion.h
+    const void *id() const { return impl_.get(); }                       // identity of the allocation behind the handle
+    void *raw() const { return impl_ ? impl_->ptr : nullptr; }           // the pointer WITHOUT settling a debt
+    bool owed() const { return impl_ && (bool)impl_->on_access; }
+    void owe(std::function<void()> f) const { if (impl_) impl_->on_access = std::move(f); }
+    void settle_quietly() const { if (impl_) impl_->on_access = nullptr; }
+    std::function<void()> take_debt() const {
+        std::function<void()> f;
+        if (impl_) f.swap(impl_->on_access);
+        return f;
     }
 };
 

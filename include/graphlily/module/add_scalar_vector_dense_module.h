@@ -18,6 +18,10 @@ class eWiseAddModule : public BaseModule {
     using aligned_dense_vec_t = std::vector<vector_data_t, aligned_allocator<vector_data_t>>;
     aligned_dense_vec_t out_;   // host staging for send_out_device_to_host
 
+    void run_now_(uint32_t len, float val) {
+        GRAPHLILY_CHECK(gl_ewise_add((const float *)in_buf.ptr(), (float *)out_buf.ptr(), len, val));
+    }
+
 public:
     DeviceBuffer in_buf;
     DeviceBuffer out_buf;
@@ -25,6 +29,7 @@ public:
     eWiseAddModule() : BaseModule("overlay") {}
 
     void send_in_host_to_device(aligned_dense_vec_t &in) {
+        barrier_();
         in_buf = DeviceBuffer(sizeof(float) * in.size());
         in_buf.upload(in.data(), sizeof(float) * in.size());
     }
@@ -33,7 +38,10 @@ public:
     void bind_out_buf(DeviceBuffer src_buf) { out_buf = src_buf; }
 
     void run(uint32_t len, vector_data_t val) {
-        GRAPHLILY_CHECK(gl_ewise_add((const float *)in_buf.ptr(), (float *)out_buf.ptr(), len, val));
+        // the results -> vector copy of a BFS pull iteration whose SpMV is deferred?  Then it waits too (module/fusion.h)
+        if (!blocking_ && detail::fusion().defer_ewise(in_buf, out_buf, len, val, [this, len, val] { run_now_(len, val); })) return;
+        barrier_();
+        run_now_(len, val);
         finish_();
     }
 

@@ -34,10 +34,12 @@ public:
     }
 
     void send_mask_host_to_device(aligned_dense_vec_t &mask) {
+        barrier_();
         mask_buf = DeviceBuffer(sizeof(float) * mask.size());
         mask_buf.upload(mask.data(), sizeof(float) * mask.size());
     }
     void send_inout_host_to_device(aligned_dense_vec_t &inout) {
+        barrier_();
         inout_buf = DeviceBuffer(sizeof(float) * inout.size());
         inout_buf.upload(inout.data(), sizeof(float) * inout.size());
     }
@@ -49,6 +51,9 @@ public:
             std::cout << "Invalid mask type" << std::endl;
             exit(EXIT_FAILURE);
         }
+        // the third call of a BFS pull iteration whose first two are deferred: the three run as one fused step (module/fusion.h)
+        if (!blocking_ && detail::fusion().fire(mask_buf, inout_buf, len, val, (int)mask_type_)) return;
+        barrier_();
         GRAPHLILY_CHECK(gl_assign_dense((const float *)mask_buf.ptr(), (float *)inout_buf.ptr(), len, val, (int)mask_type_));
         finish_();
     }

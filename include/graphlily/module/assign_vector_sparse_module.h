@@ -44,6 +44,7 @@ public:
         : BaseModule("overlay"), generate_new_frontier_(generate_new_frontier) {}
 
     void send_mask_host_to_device(aligned_mask_t &mask) {
+        barrier_();
         mask_buf = DeviceBuffer(sizeof(gl_idx_val) * mask.size());
         mask_buf.upload(mask.data(), sizeof(gl_idx_val) * mask.size());
         if (generate_new_frontier_) {  // the new frontier can never be longer than the mask
@@ -53,6 +54,7 @@ public:
         }
     }
     void send_inout_host_to_device(aligned_dense_vec_t &inout) {
+        barrier_();
         inout_buf = DeviceBuffer(sizeof(float) * inout.size());
         inout_buf.upload(inout.data(), sizeof(float) * inout.size());
     }
@@ -65,12 +67,14 @@ public:
 
     // BFS mode
     void run(vector_data_t val) {
+        barrier_();
         if (generate_new_frontier_) die_("[ERROR]: this->generate_new_frontier_ should be false");
         GRAPHLILY_CHECK(gl_assign_sparse((const gl_idx_val *)mask_buf.ptr(), (float *)inout_buf.ptr(), val, capacity_()));
         finish_();
     }
     // SSSP mode
     void run() {
+        barrier_();
         if (!generate_new_frontier_) die_("[ERROR]: this->generate_new_frontier_ should be true");
         GRAPHLILY_CHECK(gl_assign_sparse_new_frontier((const gl_idx_val *)mask_buf.ptr(), (float *)inout_buf.ptr(),
                                                       (gl_idx_val *)new_frontier_buf.ptr(), capacity_()));

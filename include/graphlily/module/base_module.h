@@ -8,6 +8,7 @@
 #include <string>
 
 #include "graphlily/global.h"
+#include "graphlily/module/fusion.h"
 
 namespace graphlily {
 namespace module {
@@ -22,14 +23,18 @@ protected:
     // that hands data to the host (send_*_device_to_host, get_results_nnz, uploads) waits for it anyway, so the
     // callers see the same values without a host round trip per launch.
     bool blocking_ = true;
+    const void *owner_ = nullptr;   // the ModuleCollection this module belongs to (module/fusion.h pairs modules of one owner)
 
     void finish_() {
         if (blocking_) GRAPHLILY_CHECK(gl_sync());
     }
+    // every module call that is not the expected continuation of a deferred BFS pull iteration first lets the deferred
+    // calls run (module/fusion.h)
+    static void barrier_() { detail::fusion().flush(); }
 
 public:
     explicit BaseModule(std::string kernel_name) : kernel_name_(kernel_name) {}
-    virtual ~BaseModule() {}
+    virtual ~BaseModule() { detail::fusion().forget(this); }
 
     std::string get_kernel_name() { return kernel_name_; }
 
@@ -43,8 +48,10 @@ public:
 
     // extension: let a driver enqueue several module calls and synchronise once (gl_sync)
     void set_blocking(bool blocking) { blocking_ = blocking; }
+    void set_owner(const void *owner) { owner_ = owner; }
 
     void copy_buffer_device_to_device(DeviceBuffer src, DeviceBuffer dst, size_t bytes) {
+        barrier_();
         GRAPHLILY_CHECK(gl_buf_d2d(dst.ptr(), src.ptr(), bytes));
         finish_();
     }

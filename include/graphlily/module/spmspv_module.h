@@ -56,7 +56,10 @@ public:
     DeviceBuffer results_nnz_buf;  // unused: gl_sparse_nnz reads the head of results_buf directly
 
     explicit SpMSpVModule(uint32_t out_buf_len) : BaseModule("overlay"), out_buf_len_(out_buf_len) {}
-    ~SpMSpVModule() override { gl_spmspv_plan_destroy(plan_); }
+    ~SpMSpVModule() override {
+        detail::fusion().forget(this);
+        gl_spmspv_plan_destroy(plan_);
+    }
 
     uint32_t get_num_rows() { return csc_matrix_float_.num_rows; }
     uint32_t get_num_cols() { return csc_matrix_float_.num_cols; }
@@ -74,10 +77,13 @@ public:
 
     void send_matrix_host_to_device() {
         const CSCMatrix<float> &m = csc_matrix_float_;
+        detail::fusion().forget(this);
         gl_spmspv_plan_destroy(plan_);
         plan_ = nullptr;
         GRAPHLILY_CHECK(gl_spmspv_plan_create(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
                                               m.adj_data.data(), sharded_ ? row_begin_ : 0, sharded_ ? row_end_ : m.num_rows));
+        if (!sharded_ || (row_begin_ == 0 && row_end_ == m.num_rows))
+            detail::fusion().announce(this, owner_, nullptr, plan_, m.num_rows, m.num_cols, m.adj_indptr[m.num_cols]);
         GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(idx_val_t) * ((size_t)std::max(m.num_rows, m.num_cols) + 1), 2));
         GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(float) * (size_t)std::max(m.num_rows, m.num_cols), 6));
         results_buf = DeviceBuffer(sizeof(idx_val_t) * ((size_t)m.num_rows + 1));
@@ -87,6 +93,7 @@ public:
 
     // the vector may be shorter than num_cols + 1; the device copy always has that many slots
     void send_vector_host_to_device(aligned_sparse_vec_t &vector) {
+        barrier_();
         const size_t slots = (size_t)get_num_cols() + 1;   // reference :280,379
         vector_buf = DeviceBuffer(sizeof(idx_val_t) * slots);
         if (vector.empty()) {
@@ -113,6 +120,7 @@ public:
     }
 
     void send_mask_host_to_device(aligned_dense_vec_t &mask) {
+        barrier_();
         mask_buf = DeviceBuffer(sizeof(float) * mask.size());
         mask_buf.upload(mask.data(), sizeof(float) * mask.size());
     }
@@ -129,6 +137,7 @@ public:
     }
 
     void run() {
+        barrier_();
         GRAPHLILY_CHECK(gl_spmspv_run(plan_, (const gl_idx_val *)vector_buf.ptr(),
                                       mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
                                       (gl_idx_val *)results_buf.ptr(), (int)semiring_.op, semiring_.zero, (int)mask_type_));
@@ -137,6 +146,7 @@ public:
     // extension (gl_spmspv_run_assign): run() + AssignVectorSparseModule::run(val) with the results as its mask and
     // `inout` as its inout (the push iteration of app/bfs.h:146-148) in one call
     void run_assign(DeviceBuffer inout, float val) {
+        barrier_();
         GRAPHLILY_CHECK(gl_spmspv_run_assign(plan_, (const gl_idx_val *)vector_buf.ptr(),
                                              mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
                                              (gl_idx_val *)results_buf.ptr(), (int)semiring_.op, semiring_.zero,
@@ -146,6 +156,7 @@ public:
 
     aligned_sparse_vec_t send_vector_device_to_host() { return download_sparse_(vector_buf); }
     aligned_dense_vec_t send_mask_device_to_host() {
+        barrier_();
         aligned_dense_vec_t out(mask_buf.size() / sizeof(float));
         mask_buf.download(out.data(), sizeof(float) * out.size());
         return out;
@@ -154,6 +165,7 @@ public:
 
     // the per-iteration device->host control read of the push loops (reference :239-242)
     uint32_t get_results_nnz() {
+        barrier_();
         uint32_t nnz = 0;
         GRAPHLILY_CHECK(gl_sparse_nnz((const gl_idx_val *)results_buf.ptr(), &nnz));
         return nnz;

@@ -66,9 +66,23 @@ class SpMVModule : public BaseModule {
         gl_spmv_plan_destroy(plan_);
         plan_ = nullptr;
         plan_flags_ = flags_for_(semiring_.op);
+        detail::fusion().forget(this);
         GRAPHLILY_CHECK(gl_spmv_plan_create_ex(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
                                                m.adj_data.data(), sharded_ ? row_begin_ : 0,
                                                sharded_ ? row_end_ : m.num_rows, plan_flags_));
+        int layout = GL_LAYOUT_GENERAL;
+        uint32_t segments = 1;
+        GRAPHLILY_CHECK(gl_spmv_plan_layout(plan_, &layout));
+        GRAPHLILY_CHECK(gl_spmv_plan_shape(plan_, nullptr, &segments, nullptr, nullptr));
+        const bool whole = !sharded_ || (row_begin_ == 0 && row_end_ == m.num_rows);
+        fusable_plan_ = whole && layout == GL_LAYOUT_BOOLEAN && segments == 1 && m.num_rows == m.num_cols;
+        if (whole) detail::fusion().announce(this, owner_, plan_, nullptr, m.num_rows, m.num_cols, m.adj_indptr[m.num_rows]);
+    }
+    bool fusable_plan_ = false;
+    void run_now_() {
+        GRAPHLILY_CHECK(gl_spmv_run(plan_, (const float *)vector_buf.ptr(),
+                                    mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
+                                    (float *)results_buf.ptr(), (int)semiring_.op, semiring_.zero, (int)mask_type_));
     }
 
 public:
@@ -80,7 +94,10 @@ public:
 
     SpMVModule(uint32_t num_channels, uint32_t out_buf_len, uint32_t vec_buf_len)
         : BaseModule("overlay"), num_channels_(num_channels), out_buf_len_(out_buf_len), vec_buf_len_(vec_buf_len) {}
-    ~SpMVModule() override { gl_spmv_plan_destroy(plan_); }
+    ~SpMVModule() override {
+        detail::fusion().forget(this);
+        gl_spmv_plan_destroy(plan_);
+    }
 
     void set_semiring(SemiringType semiring) { semiring_ = semiring; }
     void set_mask_type(MaskType mask_type) { mask_type_ = mask_type; }
@@ -104,6 +121,7 @@ public:
         GRAPHLILY_CHECK(gl_pack_bits((const float *)x.ptr(), n, (uint32_t *)bits.ptr()));
     }
     void run_bits(DeviceBuffer bits) {
+        barrier_();
         GRAPHLILY_CHECK(gl_spmv_run_bits(plan_, (const uint32_t *)bits.ptr(),
                                          mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
                                          (float *)results_buf.ptr(), semiring_.zero, (int)mask_type_));
@@ -111,6 +129,7 @@ public:
     }
     // one BFS pull iteration (app/bfs.h:118-123) in one launch; false if the plan is split: use the three calls
     bool bfs_pull_step(DeviceBuffer bits_in, DeviceBuffer bits_out, DeviceBuffer distance, float level) {
+        barrier_();
         const int rc = gl_bfs_pull_step(plan_, (const uint32_t *)bits_in.ptr(), (uint32_t *)bits_out.ptr(),
                                         (float *)distance.ptr(), level);
         if (rc == GL_ERR_UNSUPPORTED) return false;
@@ -128,6 +147,7 @@ public:
 
     void send_matrix_host_to_device() {
         const CSRMatrix<float> &m = csr_matrix_float_;
+        barrier_();
         make_plan_();
         // host blocks for the n-element vectors a driver call builds and returns (two inputs, the result, the previous
         // call's result and the caller's reference result still alive): parked and paged in now, not inside the first timed call
@@ -137,27 +157,54 @@ public:
         finish_();
     }
 
-    void send_vector_host_to_device(aligned_dense_vec_t &vector) { vector_buf = upload_dense_(vector, get_num_cols()); }
+    void send_vector_host_to_device(aligned_dense_vec_t &vector) {
+        barrier_();
+        vector_buf = upload_dense_(vector, get_num_cols());
+    }
 
-    void send_mask_host_to_device(aligned_dense_vec_t &mask) { mask_buf = upload_dense_(mask, get_num_rows()); }
+    void send_mask_host_to_device(aligned_dense_vec_t &mask) {
+        barrier_();
+        mask_buf = upload_dense_(mask, get_num_rows());
+    }
 
-    void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }
-    void bind_vector_buf(DeviceBuffer src_buf) { vector_buf = src_buf; }    // extension
-    void bind_results_buf(DeviceBuffer src_buf) { results_buf = src_buf; }  // extension
+    void bind_mask_buf(DeviceBuffer src_buf) {
+        barrier_();
+        mask_buf = src_buf;
+    }
+    void bind_vector_buf(DeviceBuffer src_buf) {    // extension
+        barrier_();
+        vector_buf = src_buf;
+    }
+    void bind_results_buf(DeviceBuffer src_buf) {   // extension
+        barrier_();
+        results_buf = src_buf;
+    }
 
     void run() {
+        barrier_();
         if (!plan_serves_(semiring_.op)) {   // semiring switched after upload: re-format
             GRAPHLILY_CHECK(gl_sync());
             make_plan_();
         }
-        GRAPHLILY_CHECK(gl_spmv_run(plan_, (const float *)vector_buf.ptr(),
-                                    mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
-                                    (float *)results_buf.ptr(), (int)semiring_.op, semiring_.zero, (int)mask_type_));
+        // the first call of a BFS pull iteration (app/bfs.h:118-123)?  Then it waits for the two that follow (module/fusion.h)
+        detail::PullFusion &F = detail::fusion();
+        if (!blocking_ && fusable_plan_ && F.enabled() && semiring_.op == kLogicalAndOr && semiring_.zero == 0 &&
+            mask_type_ == kMaskWriteToZero && vector_buf.valid() && mask_buf.valid() && results_buf.valid()) {
+            if (gl_spmspv_plan csc = F.partner_of(this)) {
+                F.defer_spmv(this, plan_, csc, get_num_rows(), vector_buf, mask_buf, results_buf, [this] { run_now_(); });
+                return;
+            }
+        }
+        run_now_();
         finish_();
     }
 
+    // (a download of a buffer that a deferred / fused call still owes settles the debt first: DeviceBuffer::ptr)
     aligned_dense_vec_t send_vector_device_to_host() { return download_dense_(vector_buf, get_num_cols()); }
-    aligned_dense_vec_t send_mask_device_to_host() { return download_dense_(mask_buf, get_num_rows()); }
+    aligned_dense_vec_t send_mask_device_to_host() {
+        barrier_();
+        return download_dense_(mask_buf, get_num_rows());
+    }
     aligned_dense_vec_t send_results_device_to_host() { return download_dense_(results_buf, get_num_rows()); }
 
     // CPU reference the callers verify against (part of the reference's public API, :478-532).

@@ -199,6 +199,8 @@ int gl_spmv_plan_export(gl_spmv_plan plan, int array, void *h_dst, size_t capaci
  * bit vector (16-byte aligned) instead of a float x. */
 int gl_spmv_plan_bits_words(gl_spmv_plan plan, uint64_t *words);
 int gl_pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits);
+/* the inverse: x[i] = bit i ? 1.0f : 0.0f for i < n (a frontier kept as bits handed back as the float vector of the module API) */
+int gl_unpack_bits(const uint32_t *d_bits, uint32_t n, float *d_x);
 int gl_spmv_run_bits(gl_spmv_plan plan, const uint32_t *d_bits, const float *d_mask, float *d_y, float zero,
                      int mask_type);
 /* Extension: one BFS pull iteration fused into one launch.  Equivalent to SpMVModule::run with the (||,&&) semiring
@@ -387,6 +389,12 @@ int gl_bfs_bits_decide(gl_spmspv_plan csc, const uint32_t *d_bits_next, const ui
                        uint64_t nnz_global, uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue, float back_threshold);
 int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
                       uint32_t nvec, uint32_t first_pull_slot);
+/* gl_bfs_bits_begin_from: the set-up of a schedule that PULLS in every slot when the caller already holds the distances and
+ * the current frontier as a float vector (the C++ module layer recognises the reference's pull iteration -- SpMV, eWiseAdd(+0),
+ * AssignVectorDense, app/bfs.h:118-123 -- and runs it as gl_bfs_bits_push_step + gl_bfs_bits_pull_step on three rotating bit
+ * vectors, include/graphlily/module/fusion.h): control words as gl_bfs_bits_begin(first_pull_slot = 0) leaves them, d_bits =
+ * THREE vectors of bits_words words, the first = (x != 0), the other two cleared.  d_distance is not touched. */
+int gl_bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t bits_words);
 int gl_bfs_bits_push_step(gl_spmspv_plan csc, gl_spmv_plan rows, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,
                           uint32_t bits_words, float *d_distance, float level, uint32_t *d_ctl, uint32_t slot, float threshold,
                           int may_continue);

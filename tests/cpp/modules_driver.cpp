@@ -215,6 +215,85 @@ int main() {
         dense.copy_buffer_device_to_device(dense.mask_buf, dense.inout_buf, sizeof(val_t) * len);
         verify(mask, dense.send_inout_device_to_host(), "copy_buffer_device_to_device", true);
     }
+    // ---- the BFS pull iteration of the reference's driver (app/bfs.h:106-126) through a ModuleCollection: the three module
+    //      calls run fused (module/fusion.h).  After EVERY iteration the three buffers -- read through the module API -- must
+    //      hold what the unfused sequence leaves (GRAPHLILY_FUSE_PULL=0), and reading them must not disturb the next one.
+    {
+        struct Bfs : public app::ModuleCollection {
+            module::SpMVModule<val_t, val_t> *SpMV;
+            module::SpMSpVModule<val_t, val_t, idx_val_t> *SpMSpV;
+            module::eWiseAddModule<val_t> *eWise;
+            module::AssignVectorDenseModule<val_t> *Assign;
+            Bfs() {
+                SpMV = new module::SpMVModule<val_t, val_t>(16, 1024, 256);
+                SpMV->set_semiring(LogicalSemiring);
+                SpMV->set_mask_type(kMaskWriteToZero);
+                SpMSpV = new module::SpMSpVModule<val_t, val_t, idx_val_t>(1024);
+                SpMSpV->set_semiring(LogicalSemiring);
+                SpMSpV->set_mask_type(kMaskWriteToZero);
+                eWise = new module::eWiseAddModule<val_t>();
+                Assign = new module::AssignVectorDenseModule<val_t>();
+                Assign->set_mask_type(kMaskWriteToOne);
+                add_module(SpMV);
+                add_module(SpMSpV);
+                add_module(eWise);
+                add_module(Assign);
+            }
+        };
+        CSRMatrix<float> g = uniform_csr(20000, 6, 11);
+        io::util_round_csr_matrix_dim(g, 128, 128);
+        for (auto &x : g.adj_data) x = 1;
+        CSCMatrix<float> gc = io::csr2csc(g);
+        const uint32_t n = g.num_rows, iters = 7;
+        std::vector<fvec> seen[2];
+        for (int fused = 0; fused < 2; fused++) {
+            setenv("GRAPHLILY_FUSE_PULL", fused ? "1" : "0", 1);
+            Bfs bfs;
+            bfs.set_up_runtime("unused.xclbin");
+            bfs.SpMV->load_and_format_matrix(g, true);
+            bfs.SpMSpV->load_and_format_matrix(gc);
+            bfs.SpMV->send_matrix_host_to_device();
+            bfs.SpMSpV->send_matrix_host_to_device();
+            aligned_dense_vec_t input(n, 0), distance(n, 0);
+            input[3] = 1;
+            distance[3] = 1;
+            bfs.SpMV->send_vector_host_to_device(input);
+            bfs.SpMV->send_mask_host_to_device(distance);
+            bfs.Assign->bind_mask_buf(bfs.SpMV->vector_buf);
+            bfs.Assign->bind_inout_buf(bfs.SpMV->mask_buf);
+            bfs.eWise->bind_in_buf(bfs.SpMV->results_buf);
+            bfs.eWise->bind_out_buf(bfs.SpMV->vector_buf);
+            for (uint32_t it = 1; it <= iters; it++) {
+                bfs.SpMV->run();
+                bfs.eWise->run(n, 0);
+                bfs.Assign->run(n, float(it + 1));
+                // iterations 1, 2 and 5 are inspected (a reader in the middle of a run), 3, 4, 6, 7 chain fused step to fused step
+                if (it <= 2 || it == 5) {
+                    seen[fused].push_back(bfs.SpMV->send_vector_device_to_host());
+                    seen[fused].push_back(bfs.SpMV->send_results_device_to_host());
+                    seen[fused].push_back(bfs.SpMV->send_mask_device_to_host());
+                }
+            }
+            seen[fused].push_back(bfs.SpMV->send_mask_device_to_host());
+            seen[fused].push_back(bfs.SpMV->send_vector_device_to_host());
+            // a lone SpMV run() (no eWiseAdd / assign behind it) still delivers its results
+            bfs.SpMV->run();
+            seen[fused].push_back(bfs.SpMV->send_results_device_to_host());
+            // ... and so does SpMV + eWiseAdd followed by something else
+            bfs.SpMV->run();
+            bfs.eWise->run(n, 0);
+            seen[fused].push_back(bfs.SpMV->send_vector_device_to_host());
+        }
+        unsetenv("GRAPHLILY_FUSE_PULL");
+        uint32_t reached = 0;
+        for (float v : seen[0][seen[0].size() - 4]) reached += v != 0;
+        printf("fused BFS pull: %u of %u vertices reached in %u iterations\n", reached, n, iters);
+        failures += reached < n / 2;
+        for (size_t k = 0; k < seen[0].size(); k++) {
+            snprintf(name, sizeof(name), "fused BFS pull iteration == the three calls (read %zu)", k);
+            verify(seen[0][k], seen[1][k], name, true);
+        }
+    }
     printf("%s\n", failures ? "SOME CHECKS FAILED" : "ALL CHECKS PASSED");
     return failures ? 1 : 0;
 }
