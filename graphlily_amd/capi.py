@@ -116,7 +116,7 @@ def lib():
         "gl_spmv_plan_helper": [vp, P(i32), P(u32)],
         "gl_spmv_plan_layout": [vp, P(i32)],
         "gl_spmv_plan_export": [vp, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)],
-        "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_unpack_bits": [vp, u32, vp], "gl_bfs_bits_begin_from": [vp, u32, vp, u32, vp, u32], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
+        "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_unpack_bits": [vp, u32, vp], "gl_bfs_bits_begin_from": [vp, u32, vp, u32, vp, u32, vp, vp], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
         "gl_bfs_pull_step": [vp, vp, vp, vp, f32],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
         "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)], "gl_prof_sample_every": [u32], "gl_span_begin": [], "gl_span_end": [P(ctypes.c_double)],

@@ -1684,12 +1684,13 @@ int gl_unpack_bits(const uint32_t *d_bits, uint32_t n, float *d_x) {
     return gl::unpack_bits(d_bits, n, d_x, gl::ctx().stream);
 }
 
-int gl_bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t bits_words) {
+int gl_bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
+                           const float *d_distance, gl_spmv_plan rows) {
     GL_REQUIRE_INIT();
     GL_ARG(d_ctl != nullptr && d_x != nullptr && d_bits != nullptr && n > 0 && (uint64_t)bits_words * 32u >= n);
     GL_ARG(((uintptr_t)d_ctl & 7u) == 0 && ctl_words >= 18u && ctl_words <= 65536u);
     GL_ARG((bits_words & 3u) == 0 && ((uintptr_t)d_bits & 15u) == 0);
-    return gl::bfs_bits_begin_from(d_ctl, ctl_words, d_x, n, d_bits, bits_words, gl::ctx().stream);
+    return gl::bfs_bits_begin_from(d_ctl, ctl_words, d_x, n, d_bits, bits_words, gl::ctx().stream, d_distance, rows);
 }
 
 int gl_spmv_run_bits(gl_spmv_plan p, const uint32_t *d_bits, const float *d_mask, float *d_y, float zero, int mask_type) {

@@ -91,6 +91,19 @@ __global__ __launch_bounds__(256) void bfs_bits_begin_from_kernel(uint32_t *__re
     }
 }
 
+// ... and, for a schedule that starts in the middle of a BFS (the reference's pull_push hands over to pulling after a few push
+// iterations, app/bfs.h:195-216): the non-zeros in the rows reached so far, which the steps' bottom-up decision goes by
+// (BfsBitsCtl: ctl[12..13]).  Runs behind bfs_bits_begin_from_kernel.
+__global__ __launch_bounds__(256) void bfs_bits_visited_kernel(uint32_t *__restrict__ ctl, const float *__restrict__ distance, uint32_t n,
+                                                               const uint32_t *__restrict__ row_ptr) {
+    unsigned long long sum = 0ull;
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u)
+        if (distance[r] != 0.0f) sum += row_ptr[r + 1u] - row_ptr[r];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d);
+    if ((threadIdx.x & 63u) == 0u && sum) atomicAdd(reinterpret_cast<unsigned long long *>(ctl + 12), sum);
+}
+
 #ifndef GL_BOOL_STEP
 #define GL_BOOL_STEP 2
 #endif
@@ -583,11 +596,16 @@ int unpack_bits(const uint32_t *d_bits, uint32_t n, float *d_x, hipStream_t s) {
     return GL_OK;
 }
 
-int bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t words, hipStream_t s) {
+int bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t words, hipStream_t s,
+                        const float *d_distance, gl_spmv_plan rows) {
     const uint32_t words64 = words / 2u;
     const unsigned grid = std::max<unsigned>(cdiv(ctl_words, 256), std::min<unsigned>(cdiv(3u * words64, 4), (unsigned)ctx().num_cus * 16u));
     bfs_bits_begin_from_kernel<<<grid, 256, 0, s>>>(d_ctl, ctl_words, d_x, n, reinterpret_cast<uint64_t *>(d_bits), words64);
     GL_LAUNCH_CHECK();
+    if (d_distance && rows && rows->d_csr_indptr && rows->row_begin == 0 && rows->row_end == rows->num_rows && rows->num_rows == n) {
+        bfs_bits_visited_kernel<<<std::min<unsigned>(cdiv(n, 256), (unsigned)ctx().num_cus * 8u), 256, 0, s>>>(d_ctl, d_distance, n, rows->d_csr_indptr);
+        GL_LAUNCH_CHECK();
+    }
     return GL_OK;
 }
 

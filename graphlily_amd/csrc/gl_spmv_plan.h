@@ -193,7 +193,8 @@ int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const 
                   int mask_type, hipStream_t s);
 int pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits, hipStream_t s);
 int unpack_bits(const uint32_t *d_bits, uint32_t n, float *d_x, hipStream_t s);
-int bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t words, hipStream_t s);
+int bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t words, hipStream_t s,
+                        const float *d_distance, gl_spmv_plan rows);
 int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_out, float *d_distance, float level, hipStream_t s,
                        const uint32_t *gate = nullptr, uint32_t gate_value = 0, int gate_op = GL_GATE_EQ, uint32_t *back_ctl = nullptr,
                        uint32_t back_slot = 0, float back_threshold = 0.0f, int back_may_continue = 0, const BfsBitsCtl *v2 = nullptr,

@@ -181,7 +181,8 @@ struct PullFusion {
             // the frontier comes as the float vector (first iteration, somebody has touched it since, or the slots ran out)
             if (old) old();                          // (the float values an earlier fused iteration still owed)
             settle_last();                           // (... and those of another vector, before its bits are overwritten)
-            GRAPHLILY_CHECK(gl_bfs_bits_begin_from(ctl(), kCtlWords, (const float *)vec.raw(), n, vecbits(0), (uint32_t)words));
+            GRAPHLILY_CHECK(gl_bfs_bits_begin_from(ctl(), kCtlWords, (const float *)vec.raw(), n, vecbits(0), (uint32_t)words,
+                                                   (const float *)dist.ptr(), plan));
             slot = 1;
             cur = 0;
         }

@@ -393,8 +393,12 @@ int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, ui
  * the current frontier as a float vector (the C++ module layer recognises the reference's pull iteration -- SpMV, eWiseAdd(+0),
  * AssignVectorDense, app/bfs.h:118-123 -- and runs it as gl_bfs_bits_push_step + gl_bfs_bits_pull_step on three rotating bit
  * vectors, include/graphlily/module/fusion.h): control words as gl_bfs_bits_begin(first_pull_slot = 0) leaves them, d_bits =
- * THREE vectors of bits_words words, the first = (x != 0), the other two cleared.  d_distance is not touched. */
-int gl_bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t bits_words);
+ * THREE vectors of bits_words words, the first = (x != 0), the other two cleared.  d_distance (may be NULL) is only read: with
+ * `rows` -- the whole-matrix GL_PLAN_BOOLEAN plan, which keeps the rows as CSR -- the non-zeros of the rows already reached are
+ * counted, so that a schedule starting in the middle of a BFS (app/bfs.h:195-216) goes bottom-up as early as one that ran from
+ * the source. */
+int gl_bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
+                           const float *d_distance, gl_spmv_plan rows);
 int gl_bfs_bits_push_step(gl_spmspv_plan csc, gl_spmv_plan rows, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,
                           uint32_t bits_words, float *d_distance, float level, uint32_t *d_ctl, uint32_t slot, float threshold,
                           int may_continue);
