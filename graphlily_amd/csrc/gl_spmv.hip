@@ -825,10 +825,14 @@ static int dispatch_mask(int mask_type, gl_spmv_plan p, const SpmvArgs &a, hipSt
 
 // ------------------------------------------------------------------------------------- planner
 // matrix-stream rate (TB/s) sustained by the inner loop as a function of the mean column distance
-// between consecutive entries of a unit (scripts/ubench_gap.hip, shared x window)
+// between consecutive entries of a unit.  Round 1 took it from a microbenchmark (scripts/ubench_gap.hip: 4.4 TB/s at a gap
+// of 1.5 falling to 2.4 at 12); with the hot-column table and the packed gather vector the real kernels lose far less to a
+// wide gap, and the table made the planner split short-row graphs that run faster unsplit.  Round 3 re-fitted it to the
+// kernels themselves (8 nnz / (launch - 10 us) on the stand-ins at 256 and 512 unsplit blocks, one box:
+// hollywood 2.4 -> 5.8, orkut / ogbl-ppa 3.7 -> 5.75, products 5 -> 5.45 and 10 -> 4.9, pokec 13 -> 4.5 and 26 -> 3.8).
 static double stream_rate(double gap) {
-    static const double gx[] = {1.5, 3.0, 6.0, 12.0, 24.0, 48.0, 96.0};
-    static const double gy[] = {4.4, 4.35, 3.4, 2.4, 1.5, 1.0, 0.7};
+    static const double gx[] = {2.5, 5.0, 10.0, 13.0, 26.0, 52.0, 104.0};
+    static const double gy[] = {5.85, 5.45, 4.9, 4.5, 3.8, 3.0, 2.3};
     if (gap <= gx[0]) return gy[0];
     for (int i = 1; i < 7; i++)
         if (gap <= gx[i]) {
@@ -856,7 +860,8 @@ static Shape choose_shape(uint64_t rows, uint64_t cols, uint64_t nnz, int num_cu
             const double gap = (double)cols / ((double)R * deg);
             const double flush = (S == 1) ? 0.0 : (double)rows * 4.0 * (2.0 * S + 1.0) / (8.0 * nnz);   // planes out + in, y
             const double util = (double)B * S / ((double)num_cus * k);
-            const double t = (8.0 * nnz * (1.0 + flush)) / (stream_rate(gap) * 1e12) / util + 3.0e-6 * k + (S == 1 ? 0.0 : 3.0e-6);
+            // (a split plan pays its planes, the combine launch and a worse balance between units: measured ~8 us)
+            const double t = (8.0 * nnz * (1.0 + flush)) / (stream_rate(gap) * 1e12) / util + 3.0e-6 * k + (S == 1 ? 0.0 : 8.0e-6);
             if (t < best_cost) {
                 best_cost = t;
                 best = Shape{(uint32_t)B, S};
