@@ -975,6 +975,16 @@ int fmt_spmspv_stream(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_in
     }
     uint2 *stream = nullptr;
     uint32_t *out_ip = nullptr;
+    struct Guard {   // the two output arrays go back to the driver on every early return
+        uint2 *&stream;
+        uint32_t *&out_ip;
+        bool released = false;
+        ~Guard() {
+            if (released) return;
+            (void)hipFree(stream);
+            (void)hipFree(out_ip);
+        }
+    } guard{stream, out_ip};
     indptr_out.resize((size_t)num_cols + 1u);
     if (whole) {
         GL_HIP(hipMalloc((void **)&stream, nnz_all ? nnz_all * 8u : 16u));
@@ -998,7 +1008,6 @@ int fmt_spmspv_stream(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_in
         if (he == hipSuccess && (rc = tmp.alloc(tmp_bytes)) == GL_OK)
             he = rocprim::exclusive_scan(tmp.p, tmp_bytes, d_cnt.as<uint32_t>(), out_ip, 0u, (size_t)num_cols + 1u, rocprim::plus<uint32_t>(), s);
         if (he != hipSuccess || rc != GL_OK) {
-            (void)hipFree(out_ip);
             return rc != GL_OK ? rc : set_error(GL_ERR_HIP, "gl_spmspv_plan_create: scan: %s", hipGetErrorString(he));
         }
         GL_HIP(hipMemcpyAsync(indptr_out.data(), out_ip, indptr_out.size() * 4u, hipMemcpyDeviceToHost, s));
@@ -1012,11 +1021,8 @@ int fmt_spmspv_stream(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_in
     uint32_t bad = 0;
     GL_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
     GL_HIP(hipStreamSynchronize(s));
-    if (bad) {
-        (void)hipFree(stream);
-        (void)hipFree(out_ip);
-        return set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_create: row index out of range (num_rows %u)", num_rows);
-    }
+    if (bad) return set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_create: row index out of range (num_rows %u)", num_rows);
+    guard.released = true;
     *d_indptr_out = out_ip;
     *d_stream_out = stream;
     return GL_OK;
@@ -1029,6 +1035,11 @@ int fmt_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_indptr, 
     hipStream_t s = ctx().stream;
     const uint64_t nnz = h_indptr[num_rows];
     if (nnz >= 0xffffffffull) return set_error(GL_ERR_UNSUPPORTED, "gl_csr2csc: more than 2^32 - 1 entries");
+    // the kernels index the entry arrays with these offsets: a row pointer array that is not monotone (or starts off zero)
+    // would send them out of bounds
+    if (h_indptr[0] != 0u) return set_error(GL_ERR_INVALID_ARG, "gl_csr2csc: indptr[0] must be 0");
+    for (uint32_t r = 0; r < num_rows; r++)
+        if (h_indptr[r + 1] < h_indptr[r]) return set_error(GL_ERR_INVALID_ARG, "gl_csr2csc: indptr decreases at row %u", r);
     DevMem d_ip, d_cols, d_cols2, d_rowof, d_vals, d_pairs, d_pairs2, d_deg, d_bad;
     int rc;
     if ((rc = d_ip.alloc((size_t)(num_rows + 1ull) * 4u)) != GL_OK || (rc = d_cols.alloc(nnz * 4u)) != GL_OK || (rc = d_cols2.alloc(nnz * 4u)) != GL_OK ||
@@ -1053,8 +1064,10 @@ int fmt_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_indptr, 
         fmt_split_pairs_kernel<<<flat_grid(nnz), kFmtThreads, 0, s>>>(d_pairs2.as<uint2>(), nnz, d_rowof.as<uint32_t>(), d_vals.as<uint32_t>());
         GL_LAUNCH_CHECK();
     }
-    uint32_t bad = 0;
+    uint32_t bad = 0;   // (read back at once: no early return below may leave a copy into this stack word pending)
     GL_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
+    GL_HIP(hipStreamSynchronize(s));
+    if (bad) return set_error(GL_ERR_INVALID_ARG, "gl_csr2csc: column index out of range (num_cols %u)", num_cols);
     // column pointers: exclusive scan of the degrees (num_cols + 1 entries, the last one being the total)
     {
         size_t tmp_bytes = 0;
@@ -1068,7 +1081,6 @@ int fmt_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_indptr, 
         GL_HIP(hipMemcpyAsync(csc_indptr, out, (size_t)(num_cols + 1ull) * 4u, hipMemcpyDeviceToHost, s));
         GL_HIP(hipStreamSynchronize(s));
     }
-    if (bad) return set_error(GL_ERR_INVALID_ARG, "gl_csr2csc: column index out of range (num_cols %u)", num_cols);
     if (nnz) {
         GL_HIP(hipMemcpyAsync(csc_indices, d_rowof.p, nnz * 4u, hipMemcpyDeviceToHost, s));
         GL_HIP(hipMemcpyAsync(csc_data, d_vals.p, nnz * 4u, hipMemcpyDeviceToHost, s));

@@ -354,7 +354,13 @@ class SpMSpVModule(BaseModule):
         cnt = int(vector["index"][0]) if vector.shape[0] else 0
         self.hint_vector_nnz(cnt)
         self.vector_buf = capi.DeviceBuffer(8 * (self.get_num_cols() + 1))
-        self.vector_buf.write(vector[:self.get_num_cols() + 1])
+        up = vector[:self.get_num_cols() + 1]
+        if up.shape[0] and cnt + 1 > up.shape[0]:
+            # the head claims more entries than the vector holds (the reference would read its zero-initialised mirror):
+            # device blocks are recycled memory, so the head is clamped to what is uploaded
+            up = up.copy()
+            up["index"][0] = cnt = up.shape[0] - 1
+        self.vector_buf.write(up)
         # a tiny vector: remember its size and the non-zeros of its columns (the host holds the CSC), see run()
         self.tiny_ = None
         BaseModule.device_writes_ += 1

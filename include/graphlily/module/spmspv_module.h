@@ -105,7 +105,13 @@ public:
         // only the head and the entries it counts are meaningful
         const size_t used = std::min(std::min(vector.size(), slots), (size_t)vector[0].index + 1);
         vector_buf.upload(vector.data(), sizeof(idx_val_t) * used);
-        hint_vector_nnz((uint32_t)vector[0].index);
+        if ((size_t)vector[0].index + 1 > used) {
+            // the head claims more entries than the vector holds (the reference would read its zero-initialised mirror):
+            // the device block is recycled memory, so the head is clamped to what was uploaded
+            const idx_val_t head{(idx_t)(used - 1), vector[0].val};
+            vector_buf.upload(&head, sizeof(head));
+        }
+        hint_vector_nnz((uint32_t)(used - 1));
         // a tiny vector (the host holds the CSC: entry count and the non-zeros of its columns are known here): the next
         // run is one launch instead of four (gl_spmspv_plan_hint_tiny; one-shot, and never result-relevant)
         const uint32_t cnt = (uint32_t)(used - 1);

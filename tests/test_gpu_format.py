@@ -188,3 +188,20 @@ def test_spmspv_plan_built_on_device(gpu, monkeypatch, shard):
         lo, hi = shard if shard else (0, m.num_rows)
         assert np.array_equal(got[lo:hi], ref[lo:hi])
         assert np.all(got[:lo] == zero) and np.all(got[hi:] == zero)
+
+
+def test_device_csr2csc_rejects_a_malformed_row_pointer_array(gpu, monkeypatch):
+    """A row pointer array that decreases (or does not start at 0) would send the device kernels out of bounds: refused."""
+    from graphlily_amd import capi
+    monkeypatch.setenv("GRAPHLILY_PLAN_DEVICE", "1")
+    m = named_matrix("uniform_10K_10")
+    bad = m.adj_indptr.copy()
+    bad[5000], bad[5001] = bad[5001], bad[5000]
+    with pytest.raises(capi.GraphLilyError):
+        capi.host_csr2csc(m.num_rows, m.num_cols, bad, m.adj_indices, m.adj_data)
+    off = m.adj_indptr.copy()
+    off[0] = 3
+    with pytest.raises(capi.GraphLilyError):
+        capi.host_csr2csc(m.num_rows, m.num_cols, off, m.adj_indices, m.adj_data)
+    c = io.csr2csc(m)                                  # the library is fine afterwards
+    assert int(c.adj_indptr[-1]) == m.nnz

@@ -427,3 +427,33 @@ def test_tiny_runs_are_one_launch_with_the_same_result(gpu, sem, mask_name, monk
         assert np.allclose(res["val"][1:n + 1], ref_res["val"][1:n + 1], rtol=1e-5, atol=0)
     else:
         assert np.array_equal(res["val"][1:n + 1], ref_res["val"][1:n + 1])
+
+
+def test_vector_head_larger_than_the_vector_is_clamped(gpu):
+    """send_vector_host_to_device of a vector whose head count exceeds the entries it holds: the reference would read its
+    zero-initialised mirror (spmspv_module.h:280); here the device block is recycled memory, so the head is clamped to what
+    was uploaded and the run uses exactly those entries."""
+    from graphlily_amd import capi, io, module as M
+    from helpers import named_matrix, to_oracle
+    m = named_matrix("uniform_10K_10")
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    csc = io.csr2csc(m)
+    # dirty the pool's blocks of this size first
+    junk = capi.DeviceBuffer(8 * (csc.num_cols + 1))
+    junk.write(np.full(2 * (csc.num_cols + 1), 0x7fffffff, np.uint32))
+    junk.free()
+    mod = M.SpMSpVModule(1024)
+    mod.set_semiring(M.ArithmeticSemiring)
+    mod.set_mask_type(M.kNoMask)
+    mod.set_up_runtime()
+    mod.load_and_format_matrix(csc)
+    mod.send_matrix_host_to_device()
+    v = M.make_sparse_vec([3, 77, 4000], [1.0, 2.0, 3.0])
+    v["index"][0] = 500                                # claims 500 entries, holds 3
+    mod.send_vector_host_to_device(v)
+    mod.run()
+    res = mod.send_results_device_to_host()
+    got = M.convert_sparse_vec_to_dense_vec(res, csc.num_rows, 0.0)
+    good = M.make_sparse_vec([3, 77, 4000], [1.0, 2.0, 3.0])
+    ref = O.spmspv(to_oracle(csc), good, O.MULADD, 0.0)
+    assert np.allclose(got, ref, rtol=1e-6, atol=0)
