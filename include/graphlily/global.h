@@ -70,21 +70,80 @@ const uint32_t pack_size = 8;
 const uint32_t spmv_row_interleave_factor = 1;
 const uint32_t num_hbm_channels = 16;
 
+// ---- the value type.  The reference picks val_t in global.h:62-64: `unsigned`, ap_ufixed<32, 8, AP_RND, AP_SAT> (the shipped
+// default) or float.  Here float is the default; compiling with -DGRAPHLILY_VAL_UFIXED / -DGRAPHLILY_VAL_UNSIGNED selects the
+// other two, so that a driver written for the reference's default configuration instantiates the same module templates
+// (the kernels serve all three bit for bit, graphlily_hip.h GL_VAL_*).  Xilinx' ap_fixed.h is not needed: ufixed_32_8 below is
+// a plain 32-bit word with the conversions and the arithmetic the host side of the reference's drivers uses.
+struct ufixed_32_8 {
+    uint32_t bits;   // value = bits / 2^24
+    ufixed_32_8() = default;
+    // AP_RND (round half up to 24 fraction bits), AP_SAT (clamp to [0, 2^32 - 1]); every arithmetic type converts through double
+    ufixed_32_8(double v) {
+        if (!(v > 0.0)) bits = 0u;
+        else {
+            const double q = v * 16777216.0 + 0.5;
+            bits = q >= 4294967296.0 ? 0xffffffffu : (uint32_t)q;
+        }
+    }
+    operator float() const { return (float)((double)bits / 16777216.0); }
+    static ufixed_32_8 from_bits(uint32_t b) {
+        ufixed_32_8 r;
+        r.bits = b;
+        return r;
+    }
+};
+static_assert(sizeof(ufixed_32_8) == 4, "ufixed_32_8 is one 32-bit word");
+
+#if defined(GRAPHLILY_VAL_UFIXED)
+using val_t = ufixed_32_8;
+#elif defined(GRAPHLILY_VAL_UNSIGNED)
+using val_t = unsigned;
+#else
 using val_t = float;
+#endif
+
+// what the C ABI needs to know about a value type: GL_VAL_* and the 32-bit word of a value
+template <typename T>
+struct value_kind;
+template <>
+struct value_kind<float> {
+    static const int kind = GL_VAL_FLOAT;
+    static uint32_t bits(float v) {
+        uint32_t b;
+        memcpy(&b, &v, 4);
+        return b;
+    }
+    static float from_float(float v) { return v; }
+};
+template <>
+struct value_kind<unsigned> {
+    static const int kind = GL_VAL_UNSIGNED;
+    static uint32_t bits(unsigned v) { return v; }
+    // csr_matrix_convert_from_float<unsigned> (io/data_loader.h:75-84): the C conversion, clamped instead of undefined
+    static unsigned from_float(float v) { return v <= 0.0f ? 0u : (v >= 4294967296.0f ? 0xffffffffu : (unsigned)v); }
+};
+template <>
+struct value_kind<ufixed_32_8> {
+    static const int kind = GL_VAL_UFIXED_32_8;
+    static uint32_t bits(ufixed_32_8 v) { return v.bits; }
+    static ufixed_32_8 from_float(float v) { return ufixed_32_8((double)v); }
+};
+
 typedef uint32_t idx_t;
 const uint32_t idx_marker = 0xffffffff;
 typedef struct {idx_t data[pack_size];} packed_idx_t;
 
 typedef struct {idx_t index; val_t val;} idx_val_t;
 typedef struct {idx_t index; float val;} idx_float_t;
-static_assert(sizeof(idx_val_t) == sizeof(gl_idx_val), "idx_val_t must match the C ABI element");
+static_assert(sizeof(idx_val_t) == sizeof(gl_idx_val), "idx_val_t must match the C ABI element (32-bit index, 32-bit value word)");
 
 using aligned_dense_vec_t = std::vector<val_t, aligned_allocator<val_t>>;
 using aligned_sparse_vec_t = std::vector<idx_val_t, aligned_allocator<idx_val_t>>;
 using aligned_dense_float_vec_t = std::vector<float, aligned_allocator<float>>;
 using aligned_sparse_float_vec_t = std::vector<idx_float_t, aligned_allocator<idx_float_t>>;
 
-const val_t UINT_INF = 4294967295.0f;
+const val_t UINT_INF = val_t(4294967295.0);
 const val_t UFIXED_INF = 255;
 const val_t FLOAT_INF = 999999999;
 
@@ -102,8 +161,12 @@ struct SemiringType {
 
 const SemiringType ArithmeticSemiring = {kMulAdd, 1, 0};
 const SemiringType LogicalSemiring = {kLogicalAndOr, 1, 0};
-// the float line of the reference (global.h:100); the ap_ufixed build uses UFIXED_INF (:99)
+// float: the float line of the reference (global.h:100); the integer value types: its shipped line (:99, zero = UFIXED_INF)
+#if defined(GRAPHLILY_VAL_UFIXED) || defined(GRAPHLILY_VAL_UNSIGNED)
+const SemiringType TropicalSemiring = {kAddMin, 0, UFIXED_INF};
+#else
 const SemiringType TropicalSemiring = {kAddMin, 0, FLOAT_INF};
+#endif
 
 enum MaskType {
     kNoMask = 0,

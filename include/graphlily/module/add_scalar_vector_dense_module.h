@@ -14,12 +14,13 @@ namespace module {
 
 template <typename vector_data_t>
 class eWiseAddModule : public BaseModule {
-    static_assert(std::is_same<vector_data_t, float>::value, "the MI355X backend computes in float");
+    static_assert(sizeof(vector_data_t) == 4, "one of the reference's 32-bit value types (float, unsigned, graphlily::ufixed_32_8)");
+    typedef graphlily::value_kind<vector_data_t> VK;
     using aligned_dense_vec_t = std::vector<vector_data_t, aligned_allocator<vector_data_t>>;
     aligned_dense_vec_t out_;   // host staging for send_out_device_to_host
 
-    void run_now_(uint32_t len, float val) {
-        GRAPHLILY_CHECK(gl_ewise_add((const float *)in_buf.ptr(), (float *)out_buf.ptr(), len, val));
+    void run_now_(uint32_t len, vector_data_t val) {
+        GRAPHLILY_CHECK(gl_ewise_add_typed(in_buf.ptr(), out_buf.ptr(), len, VK::bits(val), VK::kind));
     }
 
 public:
@@ -39,7 +40,9 @@ public:
 
     void run(uint32_t len, vector_data_t val) {
         // the results -> vector copy of a BFS pull iteration whose SpMV is deferred?  Then it waits too (module/fusion.h)
-        if (!blocking_ && detail::fusion().defer_ewise(in_buf, out_buf, len, val, [this, len, val] { run_now_(len, val); })) return;
+        if (!blocking_ && VK::kind == GL_VAL_FLOAT &&
+            detail::fusion().defer_ewise(in_buf, out_buf, len, (float)val, [this, len, val] { run_now_(len, val); }))
+            return;
         barrier_();
         run_now_(len, val);
         finish_();

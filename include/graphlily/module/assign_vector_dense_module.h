@@ -14,7 +14,8 @@ namespace module {
 
 template <typename vector_data_t>
 class AssignVectorDenseModule : public BaseModule {
-    static_assert(std::is_same<vector_data_t, float>::value, "the MI355X backend computes in float");
+    static_assert(sizeof(vector_data_t) == 4, "one of the reference's 32-bit value types (float, unsigned, graphlily::ufixed_32_8)");
+    typedef graphlily::value_kind<vector_data_t> VK;
     using aligned_dense_vec_t = std::vector<vector_data_t, aligned_allocator<vector_data_t>>;
     graphlily::MaskType mask_type_ = graphlily::kNoMask;
     aligned_dense_vec_t mask_, inout_;
@@ -52,9 +53,9 @@ public:
             exit(EXIT_FAILURE);
         }
         // the third call of a BFS pull iteration whose first two are deferred: the three run as one fused step (module/fusion.h)
-        if (!blocking_ && detail::fusion().fire(mask_buf, inout_buf, len, val, (int)mask_type_)) return;
+        if (!blocking_ && VK::kind == GL_VAL_FLOAT && detail::fusion().fire(mask_buf, inout_buf, len, (float)val, (int)mask_type_)) return;
         barrier_();
-        GRAPHLILY_CHECK(gl_assign_dense((const float *)mask_buf.ptr(), (float *)inout_buf.ptr(), len, val, (int)mask_type_));
+        GRAPHLILY_CHECK(gl_assign_dense_typed(mask_buf.ptr(), inout_buf.ptr(), len, VK::bits(val), (int)mask_type_, VK::kind));
         finish_();
     }
 

@@ -16,8 +16,9 @@ namespace module {
 
 template <typename vector_data_t, typename sparse_vector_data_t>
 class AssignVectorSparseModule : public BaseModule {
-    static_assert(std::is_same<vector_data_t, float>::value, "the MI355X backend computes in float");
-    static_assert(sizeof(sparse_vector_data_t) == sizeof(gl_idx_val), "sparse element must be {uint32 index; float val}");
+    static_assert(sizeof(vector_data_t) == 4, "one of the reference's 32-bit value types (float, unsigned, graphlily::ufixed_32_8)");
+    static_assert(sizeof(sparse_vector_data_t) == sizeof(gl_idx_val), "sparse element must be {uint32 index; 32-bit value}");
+    typedef graphlily::value_kind<vector_data_t> VK;
     using aligned_mask_t = std::vector<sparse_vector_data_t, aligned_allocator<sparse_vector_data_t>>;
     using aligned_dense_vec_t = std::vector<vector_data_t, aligned_allocator<vector_data_t>>;
 
@@ -49,7 +50,7 @@ public:
         mask_buf.upload(mask.data(), sizeof(gl_idx_val) * mask.size());
         if (generate_new_frontier_) {  // the new frontier can never be longer than the mask
             new_frontier_buf = DeviceBuffer(sizeof(gl_idx_val) * mask.size());
-            const sparse_vector_data_t head{0, 0};
+            const gl_idx_val head{0u, 0.0f};
             if (!mask.empty()) new_frontier_buf.upload(&head, sizeof(head));
         }
     }
@@ -69,15 +70,14 @@ public:
     void run(vector_data_t val) {
         barrier_();
         if (generate_new_frontier_) die_("[ERROR]: this->generate_new_frontier_ should be false");
-        GRAPHLILY_CHECK(gl_assign_sparse((const gl_idx_val *)mask_buf.ptr(), (float *)inout_buf.ptr(), val, capacity_()));
+        GRAPHLILY_CHECK(gl_assign_sparse_typed(mask_buf.ptr(), inout_buf.ptr(), VK::bits(val), capacity_()));
         finish_();
     }
     // SSSP mode
     void run() {
         barrier_();
         if (!generate_new_frontier_) die_("[ERROR]: this->generate_new_frontier_ should be true");
-        GRAPHLILY_CHECK(gl_assign_sparse_new_frontier((const gl_idx_val *)mask_buf.ptr(), (float *)inout_buf.ptr(),
-                                                      (gl_idx_val *)new_frontier_buf.ptr(), capacity_()));
+        GRAPHLILY_CHECK(gl_assign_sparse_new_frontier_typed(mask_buf.ptr(), inout_buf.ptr(), new_frontier_buf.ptr(), capacity_(), VK::kind));
         finish_();
     }
 

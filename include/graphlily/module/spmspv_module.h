@@ -19,9 +19,11 @@ namespace module {
 
 template <typename matrix_data_t, typename vector_data_t, typename idx_val_t>
 class SpMSpVModule : public BaseModule {
-    static_assert(std::is_same<matrix_data_t, float>::value && std::is_same<vector_data_t, float>::value,
-                  "the MI355X backend computes in float (val_t = float)");
-    static_assert(sizeof(idx_val_t) == sizeof(gl_idx_val), "sparse element must be {uint32 index; float val}");
+    static_assert(std::is_same<matrix_data_t, vector_data_t>::value && sizeof(vector_data_t) == 4,
+                  "matrix and vector share one 32-bit value type (float, unsigned or graphlily::ufixed_32_8)");
+    static_assert(sizeof(idx_val_t) == sizeof(gl_idx_val), "sparse element must be {uint32 index; 32-bit value}");
+    typedef graphlily::value_kind<vector_data_t> VK;
+    static const bool kFloat = VK::kind == GL_VAL_FLOAT;
     using aligned_dense_vec_t = std::vector<vector_data_t, aligned_allocator<vector_data_t>>;
     using aligned_sparse_vec_t = std::vector<idx_val_t, aligned_allocator<idx_val_t>>;
 
@@ -80,14 +82,21 @@ public:
         detail::fusion().forget(this);
         gl_spmspv_plan_destroy(plan_);
         plan_ = nullptr;
+        const float *values = m.adj_data.data();
+        std::vector<vector_data_t> words;   // the integer value types: csc_matrix_convert_from_float (io/data_loader.h:86-90)
+        if (!kFloat) {
+            words.resize(m.adj_data.size());
+            for (size_t i = 0; i < words.size(); i++) words[i] = VK::from_float(m.adj_data[i]);
+            values = reinterpret_cast<const float *>(words.data());
+        }
         GRAPHLILY_CHECK(gl_spmspv_plan_create(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
-                                              m.adj_data.data(), sharded_ ? row_begin_ : 0, sharded_ ? row_end_ : m.num_rows));
-        if (!sharded_ || (row_begin_ == 0 && row_end_ == m.num_rows))
+                                              values, sharded_ ? row_begin_ : 0, sharded_ ? row_end_ : m.num_rows));
+        if (kFloat && (!sharded_ || (row_begin_ == 0 && row_end_ == m.num_rows)))
             detail::fusion().announce(this, owner_, nullptr, plan_, m.num_rows, m.num_cols, m.adj_indptr[m.num_cols]);
         GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(idx_val_t) * ((size_t)std::max(m.num_rows, m.num_cols) + 1), 2));
         GRAPHLILY_CHECK(gl_host_pool_reserve(sizeof(float) * (size_t)std::max(m.num_rows, m.num_cols), 6));
         results_buf = DeviceBuffer(sizeof(idx_val_t) * ((size_t)m.num_rows + 1));
-        const idx_val_t head{0, 0};   // an empty result list until the first run
+        const gl_idx_val head{0u, 0.0f};   // an empty result list until the first run
         results_buf.upload(&head, sizeof(head));
     }
 
@@ -97,7 +106,7 @@ public:
         const size_t slots = (size_t)get_num_cols() + 1;   // reference :280,379
         vector_buf = DeviceBuffer(sizeof(idx_val_t) * slots);
         if (vector.empty()) {
-            const idx_val_t head{0, 0};
+            const gl_idx_val head{0u, 0.0f};
             vector_buf.upload(&head, sizeof(head));
             hint_vector_nnz(0);
             return;
@@ -108,14 +117,15 @@ public:
         if ((size_t)vector[0].index + 1 > used) {
             // the head claims more entries than the vector holds (the reference would read its zero-initialised mirror):
             // the device block is recycled memory, so the head is clamped to what was uploaded
-            const idx_val_t head{(idx_t)(used - 1), vector[0].val};
+            idx_val_t head = vector[0];
+            head.index = (idx_t)(used - 1);
             vector_buf.upload(&head, sizeof(head));
         }
         hint_vector_nnz((uint32_t)(used - 1));
         // a tiny vector (the host holds the CSC: entry count and the non-zeros of its columns are known here): the next
         // run is one launch instead of four (gl_spmspv_plan_hint_tiny; one-shot, and never result-relevant)
         const uint32_t cnt = (uint32_t)(used - 1);
-        if (plan_ && cnt > 0 && cnt <= 1024) {
+        if (plan_ && kFloat && cnt > 0 && cnt <= 1024) {
             uint64_t work = 0;
             for (uint32_t k = 1; k <= cnt; k++) {
                 const uint32_t c = vector[k].index;
@@ -144,19 +154,24 @@ public:
 
     void run() {
         barrier_();
-        GRAPHLILY_CHECK(gl_spmspv_run(plan_, (const gl_idx_val *)vector_buf.ptr(),
-                                      mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
-                                      (gl_idx_val *)results_buf.ptr(), (int)semiring_.op, semiring_.zero, (int)mask_type_));
+        GRAPHLILY_CHECK(gl_spmspv_run_typed(plan_, vector_buf.ptr(), mask_type_ == kNoMask ? nullptr : mask_buf.ptr(), results_buf.ptr(),
+                                            (int)semiring_.op, VK::bits(semiring_.zero), (int)mask_type_, VK::kind));
         finish_();
     }
     // extension (gl_spmspv_run_assign): run() + AssignVectorSparseModule::run(val) with the results as its mask and
     // `inout` as its inout (the push iteration of app/bfs.h:146-148) in one call
-    void run_assign(DeviceBuffer inout, float val) {
+    void run_assign(DeviceBuffer inout, vector_data_t val) {
         barrier_();
+        if (!kFloat) {   // the fused call exists for float; the integer value types run the two steps
+            run();
+            GRAPHLILY_CHECK(gl_assign_sparse_typed(results_buf.ptr(), inout.ptr(), VK::bits(val), (uint32_t)(results_buf.size() / sizeof(gl_idx_val) - 1)));
+            finish_();
+            return;
+        }
         GRAPHLILY_CHECK(gl_spmspv_run_assign(plan_, (const gl_idx_val *)vector_buf.ptr(),
                                              mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
-                                             (gl_idx_val *)results_buf.ptr(), (int)semiring_.op, semiring_.zero,
-                                             (int)mask_type_, (float *)inout.ptr(), val));
+                                             (gl_idx_val *)results_buf.ptr(), (int)semiring_.op, (float)semiring_.zero,
+                                             (int)mask_type_, (float *)inout.ptr(), (float)val));
         finish_();
     }
 
@@ -182,7 +197,7 @@ public:
     graphlily::aligned_dense_float_vec_t compute_reference_results(graphlily::aligned_sparse_float_vec_t &vector,
                                                                     graphlily::aligned_dense_float_vec_t &mask) {
         const CSCMatrix<float> &m = csc_matrix_float_;
-        const float zero = semiring_.zero;
+        const float zero = (float)semiring_.zero;
         graphlily::aligned_dense_float_vec_t y(m.num_rows, zero);
         const uint32_t active = vector[0].index;
         for (uint32_t k = 1; k <= active; k++) {
@@ -196,8 +211,9 @@ public:
                 } else if (semiring_.op == kLogicalAndOr) {
                     acc = acc || (a && xv);
                 } else if (semiring_.op == kAddMin) {
-                    float t = (a > FLOAT_INF || xv > FLOAT_INF) ? FLOAT_INF : a + xv;
-                    if (t > FLOAT_INF) t = FLOAT_INF;
+                    const float finf = (float)FLOAT_INF;
+                    float t = (a > finf || xv > finf) ? finf : a + xv;
+                    if (t > finf) t = finf;
                     acc = (acc < t) ? acc : t;
                 } else {
                     std::cerr << "ERROR: [Module SpMSpV] Invalid semiring" << std::endl;

@@ -21,8 +21,13 @@ namespace module {
 
 template <typename matrix_data_t, typename vector_data_t>
 class SpMVModule : public BaseModule {
-    static_assert(std::is_same<matrix_data_t, float>::value && std::is_same<vector_data_t, float>::value,
-                  "the MI355X backend computes in float (val_t = float)");
+    // one of the reference's three value types (global.h:62-64) for matrix and vector alike: float, unsigned, or the 32-bit
+    // fixed point (graphlily::ufixed_32_8); the host matrix always arrives as float and is converted like
+    // csr_matrix_convert_from_float<matrix_data_t> does (io/data_loader.h:75-84)
+    static_assert(std::is_same<matrix_data_t, vector_data_t>::value && sizeof(vector_data_t) == 4,
+                  "matrix and vector share one 32-bit value type");
+    typedef graphlily::value_kind<vector_data_t> VK;
+    static const bool kFloat = VK::kind == GL_VAL_FLOAT;
     using aligned_dense_vec_t = std::vector<vector_data_t, aligned_allocator<vector_data_t>>;
 
     MaskType mask_type_ = kNoMask;
@@ -41,7 +46,7 @@ class SpMVModule : public BaseModule {
     static DeviceBuffer upload_dense_(aligned_dense_vec_t &src, size_t n) {
         DeviceBuffer buf(sizeof(float) * n);
         const size_t have = std::min(src.size(), n);
-        if (have) buf.upload(src.data(), sizeof(float) * have);
+        if (have) buf.upload(src.data(), sizeof(float) * have);   // (every value type is one 32-bit word; 0 is all bits clear)
         if (have < n) GRAPHLILY_CHECK(gl_buf_fill_f32((float *)buf.ptr() + have, 0.0f, n - have));
         return buf;
     }
@@ -54,7 +59,7 @@ class SpMVModule : public BaseModule {
     // The semiring known at upload time picks the layout: pattern-only entries and a bit vector for (||,&&),
     // a larger hot-column table for (min,+), 8-byte accumulators for (+,x).
     static uint32_t flags_for_(OperationType op) {
-        if (op == kLogicalAndOr) return GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD;
+        if (op == kLogicalAndOr && kFloat) return GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD;   // (the bit layout serves float only)
         return (op != kMulAdd) ? GL_PLAN_NO_MULADD : 0u;
     }
     bool plan_serves_(OperationType op) const {
@@ -67,22 +72,28 @@ class SpMVModule : public BaseModule {
         plan_ = nullptr;
         plan_flags_ = flags_for_(semiring_.op);
         detail::fusion().forget(this);
+        const float *values = m.adj_data.data();
+        std::vector<vector_data_t> words;   // the integer value types: the matrix as value words (same size, passed as bits)
+        if (!kFloat) {
+            words.resize(m.adj_data.size());
+            for (size_t i = 0; i < words.size(); i++) words[i] = VK::from_float(m.adj_data[i]);
+            values = reinterpret_cast<const float *>(words.data());
+        }
         GRAPHLILY_CHECK(gl_spmv_plan_create_ex(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
-                                               m.adj_data.data(), sharded_ ? row_begin_ : 0,
+                                               values, sharded_ ? row_begin_ : 0,
                                                sharded_ ? row_end_ : m.num_rows, plan_flags_));
         int layout = GL_LAYOUT_GENERAL;
         uint32_t segments = 1;
         GRAPHLILY_CHECK(gl_spmv_plan_layout(plan_, &layout));
         GRAPHLILY_CHECK(gl_spmv_plan_shape(plan_, nullptr, &segments, nullptr, nullptr));
         const bool whole = !sharded_ || (row_begin_ == 0 && row_end_ == m.num_rows);
-        fusable_plan_ = whole && layout == GL_LAYOUT_BOOLEAN && segments == 1 && m.num_rows == m.num_cols;
-        if (whole) detail::fusion().announce(this, owner_, plan_, nullptr, m.num_rows, m.num_cols, m.adj_indptr[m.num_rows]);
+        fusable_plan_ = kFloat && whole && layout == GL_LAYOUT_BOOLEAN && segments == 1 && m.num_rows == m.num_cols;
+        if (whole && kFloat) detail::fusion().announce(this, owner_, plan_, nullptr, m.num_rows, m.num_cols, m.adj_indptr[m.num_rows]);
     }
     bool fusable_plan_ = false;
     void run_now_() {
-        GRAPHLILY_CHECK(gl_spmv_run(plan_, (const float *)vector_buf.ptr(),
-                                    mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
-                                    (float *)results_buf.ptr(), (int)semiring_.op, semiring_.zero, (int)mask_type_));
+        GRAPHLILY_CHECK(gl_spmv_run_typed(plan_, vector_buf.ptr(), mask_type_ == kNoMask ? nullptr : mask_buf.ptr(), results_buf.ptr(),
+                                          (int)semiring_.op, VK::bits(semiring_.zero), (int)mask_type_, VK::kind));
     }
 
 public:
@@ -124,7 +135,7 @@ public:
         barrier_();
         GRAPHLILY_CHECK(gl_spmv_run_bits(plan_, (const uint32_t *)bits.ptr(),
                                          mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
-                                         (float *)results_buf.ptr(), semiring_.zero, (int)mask_type_));
+                                         (float *)results_buf.ptr(), (float)semiring_.zero, (int)mask_type_));
         finish_();
     }
     // one BFS pull iteration (app/bfs.h:118-123) in one launch; false if the plan is split: use the three calls
@@ -188,7 +199,7 @@ public:
         }
         // the first call of a BFS pull iteration (app/bfs.h:118-123)?  Then it waits for the two that follow (module/fusion.h)
         detail::PullFusion &F = detail::fusion();
-        if (!blocking_ && fusable_plan_ && F.enabled() && semiring_.op == kLogicalAndOr && semiring_.zero == 0 &&
+        if (!blocking_ && fusable_plan_ && F.enabled() && semiring_.op == kLogicalAndOr && VK::bits(semiring_.zero) == 0u &&
             mask_type_ == kMaskWriteToZero && vector_buf.valid() && mask_buf.valid() && results_buf.valid()) {
             if (gl_spmspv_plan csc = F.partner_of(this)) {
                 F.defer_spmv(this, plan_, csc, get_num_rows(), vector_buf, mask_buf, results_buf, [this] { run_now_(); });
@@ -211,9 +222,9 @@ public:
     // Sequential row loop with a float accumulator, like the reference.
     graphlily::aligned_dense_float_vec_t compute_reference_results(graphlily::aligned_dense_float_vec_t &vector) {
         const CSRMatrix<float> &m = csr_matrix_float_;
-        graphlily::aligned_dense_float_vec_t y(m.num_rows, semiring_.zero);
+        graphlily::aligned_dense_float_vec_t y(m.num_rows, (float)semiring_.zero);
         for (uint32_t r = 0; r < m.num_rows; r++) {
-            float acc = semiring_.zero;
+            float acc = (float)semiring_.zero;
             for (uint32_t i = m.adj_indptr[r]; i < m.adj_indptr[r + 1]; i++) {
                 const float a = m.adj_data[i], b = vector[m.adj_indices[i]];
                 switch (semiring_.op) {

@@ -23,6 +23,14 @@ static int compare(const A &ref, const B &got, const char *what, float eps) {
     return 0;
 }
 
+// -DGRAPHLILY_VAL_UFIXED (the reference's shipped val_t): distances are sums of weights rounded to 2^-24 each, against the
+// float sums of compute_reference_results -- a few 1e-7 apart, not equal; BFS levels and the PageRank bound stay as they are.
+#if defined(GRAPHLILY_VAL_UFIXED)
+static const float kSsspEps = 2e-6f;
+#else
+static const float kSsspEps = 0.f;
+#endif
+
 // With a GPU this runs the reference drivers end to end on the HIP backend (argv[1] = npz path).
 int main(int argc, char **argv) {
     if (argc < 2) { printf("usage: %s graph.npz\n", argv[0]); return 2; }
@@ -53,9 +61,9 @@ int main(int argc, char **argv) {
         sssp.load_and_format_matrix(argv[1], true);
         sssp.send_matrix_host_to_device();
         auto ref = sssp.compute_reference_results(0, 8);
-        bad += compare(ref, sssp.pull_push(0, 8, 0.1f), "reference SSSP::pull_push", 0.f);
-        bad += compare(ref, sssp.pull(0, 8), "reference SSSP::pull", 0.f);
-        bad += compare(ref, sssp.push(0, 8), "reference SSSP::push", 0.f);
+        bad += compare(ref, sssp.pull_push(0, 8, 0.1f), "reference SSSP::pull_push", kSsspEps);
+        bad += compare(ref, sssp.pull(0, 8), "reference SSSP::pull", kSsspEps);
+        bad += compare(ref, sssp.push(0, 8), "reference SSSP::push", kSsspEps);
     }
     return bad ? 1 : 0;
 }

@@ -24,6 +24,35 @@ def _build_driver():
                            "-L", LIBDIR, "-lgraphlily_hip", "-Wl,-rpath," + LIBDIR])
 
 
+def _build_typed_driver(define):
+    """tests/cpp/typed_modules_driver.cpp with val_t = the reference's default fixed point (-DGRAPHLILY_VAL_UFIXED) or
+    unsigned (-DGRAPHLILY_VAL_UNSIGNED): global.h:62-64 of the reference."""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    out = os.path.join(ROOT, "build", "typed_modules_driver_" + define)
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-DGRAPHLILY_VAL_" + define,
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "typed_modules_driver.cpp"),
+                           "-o", out, "-L", LIBDIR, "-lgraphlily_hip", "-Wl,-rpath," + LIBDIR])
+    return out
+
+
+@pytest.mark.parametrize("define", ["UFIXED", "UNSIGNED"])
+def test_module_headers_instantiate_with_the_integer_value_types(define, tmp_path):
+    from graphlily_amd import capi
+    exe = _build_typed_driver(define)
+    if capi.device_count() == 0:
+        r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+        assert r.returncode != 0 and "gl_init" in r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/graphlily/app"), reason="reference tree not present")
+@pytest.mark.parametrize("define", ["UFIXED", "UNSIGNED"])
+def test_reference_app_drivers_compile_with_the_integer_value_types(define, tmp_path):
+    """app/{bfs,pagerank,sssp}.h of the reference, unmodified, with val_t = its shipped default: compile + link only."""
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-w", "-DGRAPHLILY_VAL_" + define, "-I", os.path.join(ROOT, "include"),
+                           "-I", "/root/reference", os.path.join(ROOT, "tests", "cpp", "ref_apps_compile.cpp"),
+                           "-o", str(tmp_path / "ref_apps"), "-L", LIBDIR, "-lgraphlily_hip", "-Wl,-rpath," + LIBDIR])
+
+
 def test_module_headers_compile_and_fail_loudly_without_gpu():
     from graphlily_amd import capi
     _build_driver()
@@ -49,6 +78,77 @@ def test_cpp_module_layer_parity(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("define", ["UFIXED", "UNSIGNED"])
+def test_cpp_module_layer_integer_value_types(gpu, define, tmp_path):
+    """Every module instantiated with val_t = ap_ufixed<32,8> / unsigned, run on the GPU by the C++ driver; each output must
+    equal the oracle's integer restatement on the inputs the driver wrote, word for word.  Also pins the HOST conversions of
+    graphlily::ufixed_32_8 / value_kind<>::from_float against the oracle's (io/data_loader.h:75-90)."""
+    from graphlily_amd import capi
+    from oracle import oracle as O
+    exe = _build_typed_driver(define)
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "TYPED DRIVER DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    vt = capi.GL_VAL_UFIXED_32_8 if define == "UFIXED" else capi.GL_VAL_UNSIGNED
+
+    def rd(name, dtype=np.uint32):
+        return np.fromfile(str(tmp_path / (name + ".u32")), dtype=dtype)
+
+    indptr, indices = rd("csr_indptr"), rd("csr_indices")
+    data = O.words_from_float(vt, rd("csr_data_float", np.float32))
+    x, mask, zero = rd("x"), rd("mask"), rd("zero_words")
+    assert np.array_equal(x, O.words_from_float(vt, rd("x_float", np.float32))), "host float -> val_t conversion"
+    assert list(zero) == [0, 0, 255 << 24 if define == "UFIXED" else 255]
+    n = len(indptr) - 1
+    saturated = 0
+    for s in range(3):
+        for k in range(3):
+            ref = O.spmv_words(indptr, indices, data, x, s, vt, int(zero[s]), mask if k else None, k)
+            got = rd("spmv_%d_%d" % (s, k))
+            assert np.array_equal(got, ref), "SpMV op %d mask %d: %d rows differ" % (s, k, int((got != ref).sum()))
+            assert len(np.unique(ref)) > 2 or s == 1
+            saturated += int((ref == 0xffffffff).sum()) if s == 0 else 0
+    if define == "UFIXED":
+        assert saturated > 0, "the hub row's (+,x) sum saturates"
+    cptr, cidx = rd("csc_indptr"), rd("csc_indices")
+    cdata = O.words_from_float(vt, rd("csc_data_float", np.float32))
+    sv = rd("sv").view(O.IDX_WORD)
+    for s in range(3):
+        for k in range(3):
+            ref = O.spmspv_words(cptr, cidx, cdata, sv, n, s, vt, int(zero[s]), mask if k else None, k)
+            res = rd("spmspv_%d_%d" % (s, k)).view(O.IDX_WORD)
+            cnt = int(res["index"][0])
+            got = np.full(n, zero[s], np.uint32)
+            got[res["index"][1:cnt + 1]] = res["val"][1:cnt + 1]
+            assert len(np.unique(res["index"][1:cnt + 1])) == cnt
+            assert np.array_equal(got, ref), "SpMSpV op %d mask %d: %d rows differ" % (s, k, int((got != ref).sum()))
+            assert cnt == int((ref != zero[s]).sum())
+    # run_assign: (||,&&) WriteToZero, then the result rows of the mask vector set to 9
+    ref = O.spmspv_words(cptr, cidx, cdata, sv, n, 1, vt, 0, mask, 1)
+    want = mask.copy()
+    want[ref != 0] = O.words_from_float(vt, [9.0])[0]
+    assert np.array_equal(rd("run_assign_inout"), want)
+    # apply modules
+    assert np.array_equal(rd("ewise_out"), O.ewise_add_words(vt, rd("ewise_in"), int(rd("ewise_val")[0])))
+    for k in (1, 2):
+        want = rd("dense_inout_before").copy()
+        O.assign_dense_words(k, rd("dense_mask"), want, int(rd("dense_val")[0]))
+        assert np.array_equal(rd("dense_inout_after_%d" % k), want)
+    ms = rd("sparse_mask").view(O.IDX_WORD)
+    want = rd("sparse_io1_before").copy()
+    want[ms["index"][1:int(ms["index"][0]) + 1]] = rd("sparse_val")[0]
+    assert np.array_equal(rd("sparse_io1_after"), want)
+    want = rd("sparse_io2_before").copy()
+    nf = O.assign_sparse_new_frontier_words(ms, want)
+    assert np.array_equal(rd("sparse_io2_after"), want)
+    got_nf = rd("sparse_new_frontier").view(O.IDX_WORD)
+    c = int(got_nf["index"][0])
+    assert c == int(nf["index"][0]) and c > 0
+    order = np.argsort(got_nf["index"][1:c + 1], kind="stable")
+    assert np.array_equal(got_nf["index"][1:c + 1][order], nf["index"][1:c + 1])
+    assert np.array_equal(got_nf["val"][1:c + 1][order], nf["val"][1:c + 1])
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_APPS), reason="prebuilt reference drivers did not travel")
 def test_reference_app_drivers_run_on_hip_backend(gpu, tmp_path, golden_dir):
     import scipy.sparse as sp
@@ -58,11 +158,12 @@ def test_reference_app_drivers_run_on_hip_backend(gpu, tmp_path, golden_dir):
                       shape=(m.num_rows, m.num_cols), dtype=np.float32)
     p = str(tmp_path / "uniform_10K_10_csr_float32.npz")
     sp.save_npz(p, A)
-    for path in (p, os.path.join(golden_dir, "line_8_csr_float32.npz")):
-        r = subprocess.run([REF_APPS, path], capture_output=True, text=True, timeout=600)
-        print(r.stdout[-2000:])
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        assert r.stdout.count(" OK") == 7
+    for exe in (REF_APPS, REF_APPS + "_ufixed"):       # val_t = float, and the reference's shipped ap_ufixed<32, 8>
+        for path in (p, os.path.join(golden_dir, "line_8_csr_float32.npz")):
+            r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
+            print(r.stdout[-2000:])
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            assert r.stdout.count(" OK") == 7
 
 
 @pytest.mark.gpu
