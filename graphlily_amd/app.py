@@ -449,14 +449,18 @@ class BFS(_GraphApp):
             words = (int(self.SpMV_.bits_words()) + 3) & ~3
             nvec, ctl_words = N + 2, (18 + 2 * N + 15) & ~15
             both = B.alloc(n + ctl_words, np.float32)          # distances, then the control words: one read-back fetches both
-            vecs = B.alloc(nvec * words, np.float32)
+            # row shards: the ranks' tallies (gl_bfs_bits_shard_step) live behind the bit vectors and are cleared with them
+            tally_words = capi.bfs_tally_words(N, self.comm.world_size) if sharded else 0
+            nvec_all = nvec + (tally_words + words - 1) // words
+            vecs = B.alloc(nvec_all * words, np.float32)
             st = self.bits_loop_ = {"N": N, "both": both, "vecs": vecs, "words": words, "nvec": nvec, "ctl_words": ctl_words,
                                     "ctl": B.view(both, n, ctl_words, 4), "distance": B.view(both, 0, n, 4),
                                     "bits": [B.view(vecs, k * words, words, 4) for k in range(nvec)], "graphs": {},
-                                    "src": np.zeros(1, np.uint32), "warm": set()}
+                                    "src": np.zeros(1, np.uint32), "warm": set(), "nvec_all": nvec_all}
             if sharded:
                 st["col_len"] = capi.DeviceBuffer.from_host(self.col_len_)
                 st["row_len"] = capi.DeviceBuffer.from_host(self.row_len_)
+                st["tally"] = B.view(vecs, nvec * words, tally_words, 4)
         ctl, distance, bits, words = st["ctl"], st["distance"], st["bits"], st["words"]
         # Once the reference's rule has switched to pulling (frontier / n >= threshold, app/bfs.h:180-190), every later slot
         # is handed back to the push step (an extension, see _pull_push_device), which leaves heavy frontiers to the pull
@@ -470,7 +474,31 @@ class BFS(_GraphApp):
         if sharded and getattr(self.comm, "emulated", False) and not self.comm.copy:
             gathered = [self.comm.truth_vector(k) for k in range(st["nvec"])]
 
+        # ONE launch per slot (gl_bfs_bits_shard_step): the ranks' tallies of a slot travel with its bit vector, and the next
+        # slot's launch starts with the decision.  GRAPHLILY_BFS_SHARD_STEP=0: the three-launch slot (push step, pull step,
+        # gl_bfs_bits_decide on the gathered vector)
+        one_launch = sharded and os.environ.get("GRAPHLILY_BFS_SHARD_STEP", "1") != "0"
+        rank, world = self.comm.rank, self.comm.world_size
+        tally, tally_in = st.get("tally"), None
+        if one_launch and getattr(self.comm, "emulated", False):
+            table = self.comm.truth_tally((source, N), N, self.bounds_, self.col_len_, self.row_len_, n)
+            tally_in = None if self.comm.copy else table
+
+        def may_of(it):
+            return (1 if it + 1 < N else 0) | (2 if it + 1 <= N else 0)
+
+        def schedule_one_launch():
+            capi.bfs_bits_begin(ctl, st["ctl_words"], distance, n, st["vecs"], words, st["nvec_all"], 0 if pull_only else 0xffffffff)
+            for it in range(1, N + 1):
+                capi.bfs_bits_shard_step(csc_plan, pull_plan, gathered[it], bits[it + 1], words, distance, float(it + 1), ctl, tally,
+                                         tally_in, it, rank, world, st["col_len"], self.nnz_global_, threshold,
+                                         may_of(it - 1) if it > 1 else 0, back)
+                self._exchange_bits(st, it + 1, it)
+            capi.bfs_bits_shard_finish(csc_plan, pull_plan, ctl, tally, tally_in, N, rank, world, self.nnz_global_, threshold, may_of(N), back)
+
         def schedule():
+            if one_launch:
+                return schedule_one_launch()
             capi.bfs_bits_begin(ctl, st["ctl_words"], distance, n, st["vecs"], words, st["nvec"], 0 if pull_only else 0xffffffff)
             for it in range(1, N + 1):
                 may = (1 if it + 1 < N else 0) | (2 if it + 1 <= N else 0) | deferred
@@ -487,7 +515,7 @@ class BFS(_GraphApp):
 
         st["src"][0] = source
         B.upload(B.view(ctl, 2, 1, 4), st["src"])        # ctl[2] = source: the one host->device word per run
-        key = (N, float(threshold), back, pull_only)
+        key = (N, float(threshold), back, pull_only, one_launch)
         g = st["graphs"].get(key)
         # (a torch.distributed collective is not recorded by the library's capture: those runs are enqueued call by call)
         capturable = not sharded or getattr(self.comm, "capturable", False)
@@ -533,14 +561,23 @@ class BFS(_GraphApp):
         self.bfs_slot_modes_ = c[17 + S:17 + S + N].copy()      # 1 scattered, 2 streamed row-wise, 3 bottom-up, 0 nothing ran
         return res
 
-    def _exchange_bits(self, st, k):
-        """The one exchange step of a sharded slot: every rank's rows of bit vector k to every rank."""
-        comm = self.comm
+    def _exchange_bits(self, st, k, tally_slot=None):
+        """The one exchange step of a sharded slot: every rank's rows of bit vector k to every rank -- and, with the
+        one-launch slot, every rank's tallies of slot `tally_slot` (256 bytes each) along with them."""
+        comm, W = self.comm, self.comm.world_size
+        per = capi.GL_BFS_TALLY_RANK_WORDS
+        first = capi.GL_BFS_TALLY_HEAD_WORDS + (tally_slot - 1) * W * per if tally_slot is not None else 0
         if hasattr(comm, "exchange_bits"):                 # the C-ABI communicator (gl_dist_*) or the one-GPU emulation
-            comm.exchange_bits(st["bits"][k], k, self.bounds_)
+            if tally_slot is None:
+                comm.exchange_bits(st["bits"][k], k, self.bounds_)
+            else:
+                comm.exchange_bits(st["bits"][k], k, self.bounds_, self.backend.view(st["tally"], first, W * per, 4), tally_slot)
             return
         t = st["vecs"].tensor[k * st["words"]:(k + 1) * st["words"]]
         comm.all_gather_slices(t, [b // 32 for b in self.bounds_])
+        if tally_slot is not None:
+            base = st["nvec"] * st["words"] + first
+            comm.all_gather_slices(st["vecs"].tensor[base:base + W * per], [r * per for r in range(W + 1)])
 
     def _bits_loop_ok(self):
         if os.environ.get("GRAPHLILY_BFS_BITS", "1") == "0" or os.environ.get("GRAPHLILY_BFS_FUSED", "1") == "0":

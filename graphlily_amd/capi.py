@@ -32,6 +32,7 @@ EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
     "gl_bfs_bits_begin", "gl_bfs_bits_push_step", "gl_bfs_bits_pull_step", "gl_bfs_bits_decide",
+    "gl_bfs_bits_shard_step", "gl_bfs_bits_shard_finish", "gl_dist_all_gather_bits_tally",
     "gl_buf_d2h_async",
     "gl_sssp_begin", "gl_assign_sparse_new_frontier_gated", "gl_spmv_run_flagged", "gl_ewise_add_flagged",
     "gl_bfs_begin", "gl_spmspv_plan_frontier_bits", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
@@ -87,6 +88,9 @@ def lib():
         "gl_bfs_bits_push_step": [vp, vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
         "gl_bfs_bits_pull_step": [vp, vp, vp, vp, vp, f32, vp, u32, f32, i32, f32],
         "gl_bfs_bits_decide": [vp, vp, vp, vp, u64, vp, u32, f32, i32, f32],
+        "gl_bfs_bits_shard_step": [vp, vp, vp, vp, u32, vp, f32, vp, vp, vp, u32, i32, i32, vp, u64, f32, i32, f32],
+        "gl_bfs_bits_shard_finish": [vp, vp, vp, vp, vp, u32, i32, i32, u64, f32, i32, f32],
+        "gl_dist_all_gather_bits_tally": [vp, vp, vp, vp, u32],
         "gl_sssp_begin": [vp, u32, vp, u32, f32, vp], "gl_assign_sparse_new_frontier_gated": [vp, vp, vp, u32, vp, u32, i32],
         "gl_spmv_run_flagged": [vp, vp, vp, vp, i32, f32, i32, vp], "gl_ewise_add_flagged": [vp, vp, u32, f32, vp],
         "gl_spmspv_run_gated": [vp, vp, vp, vp, i32, f32, i32, vp, f32, vp, vp, u32, i32, vp, u32, f32, i32],
@@ -584,6 +588,12 @@ class Dist:
         b = np.ascontiguousarray(row_bounds, dtype=np.uint32)
         check(lib().gl_dist_all_gather_bits(ctypes.c_void_p(self.handle), _p(bits), _np_ptr(b)))
 
+    def all_gather_bits_tally(self, bits, row_bounds, tally_slot):
+        """the slot's bit vector and every rank's tallies of the slot in one grouped operation"""
+        b = np.ascontiguousarray(row_bounds, dtype=np.uint32)
+        check(lib().gl_dist_all_gather_bits_tally(ctypes.c_void_p(self.handle), _p(bits), _np_ptr(b), _p(tally_slot),
+                                                  4 * GL_BFS_TALLY_RANK_WORDS))
+
     def all_gather_sparse(self, local, full, capacity, head_val):
         n = ctypes.c_uint32(0)
         check(lib().gl_dist_all_gather_sparse(ctypes.c_void_p(self.handle), _p(local), _p(full), int(capacity), float(head_val),
@@ -644,6 +654,30 @@ def bfs_bits_decide(csc_plan, bits_next, col_len, row_len, nnz_global, ctl, slot
     """gl_bfs_bits_decide: the slot's decisions of a row-sharded schedule, from the all-gathered next frontier."""
     check(lib().gl_bfs_bits_decide(ctypes.c_void_p(csc_plan.handle), _p(bits_next), _p(col_len), _p(row_len), int(nnz_global), _p(ctl),
                                    int(slot), float(threshold), int(may_continue), float(back_threshold)))
+
+
+GL_BFS_TALLY_HEAD_WORDS = 64
+GL_BFS_TALLY_RANK_WORDS = 64
+
+
+def bfs_tally_words(slots, world):
+    return GL_BFS_TALLY_HEAD_WORDS + int(slots) * int(world) * GL_BFS_TALLY_RANK_WORDS
+
+
+def bfs_bits_shard_step(csc_plan, rows_plan, bits_in, bits_out, words, distance, level, ctl, tally, tally_in, slot, rank, world, col_len,
+                        nnz_global, threshold, may_continue_prev, back_threshold):
+    """gl_bfs_bits_shard_step: one slot of the row-sharded bit-frontier schedule in ONE launch."""
+    check(lib().gl_bfs_bits_shard_step(ctypes.c_void_p(csc_plan.handle), ctypes.c_void_p(rows_plan.handle), _p(bits_in), _p(bits_out),
+                                       int(words), _p(distance), float(level), _p(ctl), _p(tally), _p(tally_in), int(slot), int(rank),
+                                       int(world), _p(col_len), int(nnz_global), float(threshold), int(may_continue_prev),
+                                       float(back_threshold)))
+
+
+def bfs_bits_shard_finish(csc_plan, rows_plan, ctl, tally, tally_in, last_slot, rank, world, nnz_global, threshold, may_continue_last,
+                          back_threshold):
+    check(lib().gl_bfs_bits_shard_finish(ctypes.c_void_p(csc_plan.handle), ctypes.c_void_p(rows_plan.handle), _p(ctl), _p(tally),
+                                         _p(tally_in), int(last_slot), int(rank), int(world), int(nnz_global), float(threshold),
+                                         int(may_continue_last), float(back_threshold)))
 
 
 def bfs_begin(ctl, distance, n, frontier, bits, bits_words):

@@ -235,16 +235,25 @@ struct BfsBitsCtl {
     // ctl[15] = words of ctl: the words behind the 16 control words are two arrays of S = (ctl[15] - 16) / 2 entries, the
     // vertices slot s reached (ctl[16 + s]) and HOW the slot was evaluated (ctl[16 + S + s]: 1 scattered, 2 streamed
     // row-wise, 3 bottom-up; 0: nothing ran) -- the host's "edges actually traversed" 
-    __device__ uint32_t slot_capacity() const { return (ctl[15] - 16u) >> 1; }
+    // `local`: ctl points at a workgroup's PRIVATE copy of the 16 control words (the one-launch shard step, gl_bfs_shard.h:
+    // every workgroup replays the previous slot's decision for itself); the per-slot records then go to `records` -- the
+    // caller's control words -- from the one workgroup that is given the pointer, and nowhere from the others
+    uint32_t *records = nullptr;
+    bool local = false;
+    __device__ uint32_t *rec_() const { return local ? records : ctl; }
+    __device__ uint32_t slot_capacity() const {
+        const uint32_t *r = rec_();
+        return r ? (r[15] - 16u) >> 1 : 0u;
+    }
     __device__ void record_mode(uint32_t mode) const {
         const uint32_t S = slot_capacity();
-        if (slot < S) ctl[16u + S + slot] = mode;
+        if (slot < S) rec_()[16u + S + slot] = mode;
     }
     // called once per slot, when the step that ran is complete, with the step's totals: vertices reached, non-zeros in
     // their columns (what a push from them scatters) and in their rows (what a pull no longer has to look at)
     __device__ void decide(uint32_t fresh, unsigned long long work, unsigned long long work_rows) const {
         if (fresh == 0u) ctl[14] = 1u;
-        if (slot < slot_capacity()) ctl[16u + slot] = fresh;   // the slot's new-frontier size, for the host
+        if (slot < slot_capacity()) rec_()[16u + slot] = fresh;   // the slot's new-frontier size, for the host
         unsigned long long *visited = reinterpret_cast<unsigned long long *>(ctl + 12);
         const unsigned long long vis = *visited + work_rows;
         *visited = vis;

@@ -86,7 +86,8 @@ int need_rccl(const char *who) {
 }
 
 // every rank's slice [lo[r], hi[r]) (BYTE offsets into `buf`, gl_dist_slice_plan) to every other rank, in place
-int exchange_slices(gl_dist d, char *buf, const uint64_t *lo, const uint64_t *hi) {
+// (buf2: a second vector of equal slices -- `each2` bytes per rank, rank r's at r * each2 -- in the SAME group: one operation)
+int exchange_slices(gl_dist d, char *buf, const uint64_t *lo, const uint64_t *hi, char *buf2 = nullptr, uint64_t each2 = 0) {
     if (d->world == 1) return GL_OK;
     Rccl &R = rccl();
     hipStream_t s = ctx().stream;
@@ -97,6 +98,10 @@ int exchange_slices(gl_dist d, char *buf, const uint64_t *lo, const uint64_t *hi
         const uint64_t theirs = hi[p] - lo[p];
         if (mine) GL_NCCL(R.Send(buf + lo[d->rank], mine, ncclUint8, p, d->comm, s));
         if (theirs) GL_NCCL(R.Recv(buf + lo[p], theirs, ncclUint8, p, d->comm, s));
+        if (buf2 && each2) {
+            GL_NCCL(R.Send(buf2 + (uint64_t)d->rank * each2, each2, ncclUint8, p, d->comm, s));
+            GL_NCCL(R.Recv(buf2 + (uint64_t)p * each2, each2, ncclUint8, p, d->comm, s));
+        }
     }
     GL_NCCL(R.GroupEnd());
     return GL_OK;
@@ -215,6 +220,15 @@ int gl_dist_all_gather_bits(gl_dist d, uint32_t *d_bits, const uint32_t *row_bou
     const int rc = gl_dist_slice_plan(GL_DIST_BITS, d->world, row_bounds, lo.data(), hi.data());
     if (rc != GL_OK) return rc;
     return gl::exchange_slices(d, reinterpret_cast<char *>(d_bits), lo.data(), hi.data());
+}
+
+int gl_dist_all_gather_bits_tally(gl_dist d, uint32_t *d_bits, const uint32_t *row_bounds, uint32_t *d_tally_slot, uint32_t bytes_per_rank) {
+    GL_REQUIRE_INIT();
+    GL_ARG(d != nullptr && d_bits != nullptr && row_bounds != nullptr && d_tally_slot != nullptr && bytes_per_rank > 0);
+    std::vector<uint64_t> lo(d->world), hi(d->world);
+    const int rc = gl_dist_slice_plan(GL_DIST_BITS, d->world, row_bounds, lo.data(), hi.data());
+    if (rc != GL_OK) return rc;
+    return gl::exchange_slices(d, reinterpret_cast<char *>(d_bits), lo.data(), hi.data(), reinterpret_cast<char *>(d_tally_slot), bytes_per_rank);
 }
 
 int gl_dist_all_gather_sparse(gl_dist d, const gl_idx_val *d_local, gl_idx_val *d_full, uint32_t capacity, float head_val,

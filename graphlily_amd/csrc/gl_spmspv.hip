@@ -28,6 +28,7 @@
 #include "gl_common.h"
 #include "gl_compact.h"
 #include "gl_spmv_plan.h"
+#include "gl_bfs_shard.h"
 
 #include <algorithm>
 #include <cstring>
@@ -84,11 +85,6 @@ void spmspv_detach_everywhere(gl_spmv_plan dying) {
 
 constexpr uint32_t kBigColumn = 4096;  // columns at least this long are cut into queue chunks
 constexpr uint32_t kChunk = 4096;      // entries per queue chunk (one workgroup pass in kernel 1b)
-#ifndef GL_BFS_CHUNK
-#define GL_BFS_CHUNK 1024
-#endif
-constexpr uint32_t kBfsChunk = GL_BFS_CHUNK;   // bit-frontier BFS push step: columns at least this long are served from the plan's
-                                               // static list of chunks of this many entries (two round trips of a workgroup)
 constexpr uint32_t kBfsAccSlots = 64;  // accumulator lines of the bit-frontier BFS push step (a power of two)
 
 struct ScatterArgs {
@@ -344,54 +340,8 @@ __global__ __launch_bounds__(256) void spmspv_frontier_dense_kernel(const gl_idx
     }
 }
 
-// ------------------------------------------------------------------ BFS push step on a bit frontier (gl_bfs_bits_push_step)
-// SpMSpV (||,&&) masked WriteToZero by the distances + AssignVectorSparse(level) (app/bfs.h:146-148) with the bit vector
-// of the next frontier as the accumulator: a product whose row is still unvisited sets the row's bit, and the thread that
-// sets it first writes the level -- no dense accumulator, no compaction, ONE launch.  Long columns are not queued at run
-// time: the plan lists their chunks, every workgroup tests the frontier bit of the chunks it is dealt.
-struct BfsPushArgs {
-    const uint32_t *indptr;
-    const uint2 *stream;
-    const uint4 *chunks;
-    uint32_t nchunks;
-    uint32_t num_cols;
-    const uint32_t *bits_in;
-    uint32_t *bits_out;      // all zero on entry (the push step of two slots earlier cleared it)
-    uint32_t *bits_spare;    // cleared here, gate or not: the next slot's bits_out
-    uint32_t words;          // words of each bit vector
-    uint32_t col_words;      // words that hold columns
-    float *dist;
-    float level;
-    uint32_t *acc;           // kBfsAccSlots x 32 words, zero between steps: [0] new vertices, [2..3] their column lengths,
-                             // [6..7] their row lengths ([4]: the pull step's per-line ticket)
-    const uint32_t *row_ptr; // the rows as plain CSR (boolean SpMV plan of the same matrix and shard), or null:
-    const uint32_t *row_idx; //   row lengths for the bookkeeping, and the bottom-up branch
-    uint32_t num_rows;
-    // row shard [row_begin, row_end): row_ptr is indexed by row - row_begin and holds GLOBAL offsets, row_idx is indexed by
-    // offset - nz_base.  deferred: the step keeps no totals and takes no decision -- a shard's counts are partial; the driver
-    // all-gathers the next frontier and runs gl_bfs_bits_decide on it
-    uint32_t row_begin, row_end, nz_base;
-    bool deferred;
-    BfsBitsCtl c;
-};
-
-// the first thread to set an unvisited row's bit writes its level and counts it (and the row's column: the next push's work)
-__device__ __forceinline__ void bfs_claim(const BfsPushArgs &a, bool cand, uint32_t row, uint32_t &fresh, uint32_t &work, uint32_t &work_rows) {
-    if (!cand) return;
-    const uint32_t m = 1u << (row & 31u);
-    const uint32_t old = atomicOr(&a.bits_out[row >> 5], m);
-    if (old & m) return;
-    a.dist[row] = a.level;
-    if (a.deferred) return;
-    fresh += 1u;
-    if (row < a.num_cols) work += a.indptr[row + 1u] - a.indptr[row];
-    if (a.row_ptr) work_rows += a.row_ptr[row - a.row_begin + 1u] - a.row_ptr[row - a.row_begin];
-}
-// candidate = the product a && x is true and the mask (distance == 0: not visited, app/bfs.h:146) lets it through
-__device__ __forceinline__ bool bfs_candidate(const BfsPushArgs &a, bool valid, uint2 rv) {
-    return valid && (rv.y << 1) != 0u && a.dist[rv.x] == 0.0f;
-}
-
+// ------------------------------------------------------------------ BFS push step on a bit frontier (gl_bfs_bits_push_step):
+// BfsPushArgs, bfs_claim and bfs_candidate are in gl_bfs_shard.h (the one-launch shard step runs the same bodies)
 __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
     __shared__ uint32_t s_words[256];
     __shared__ uint32_t s_start[256];
@@ -1505,6 +1455,94 @@ int gl_bfs_bits_decide(gl_spmspv_plan p, const uint32_t *d_bits_next, const uint
     gl::bfs_bits_decide_kernel<<<grid, 1024, 0, gl::ctx().stream>>>(a);
     GL_LAUNCH_CHECK();
     return GL_OK;
+}
+
+// One slot of the row-sharded schedule in one launch (gl_bfs_shard.h).  finish: only the decision of slot `slot - 1` = the
+// last one, with the final state stored into d_ctl itself.
+static int bfs_bits_shard_launch(gl_spmspv_plan p, gl_spmv_plan rows, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t bits_words,
+                                 float *d_distance, float level, uint32_t *d_ctl, uint32_t *d_tally, const uint32_t *d_tally_in,
+                                 uint32_t slot, int rank, int world, const uint32_t *d_col_len, uint64_t nnz_global, float threshold,
+                                 int may_continue_prev, float back_threshold, bool finish) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && rows != nullptr && d_ctl != nullptr && d_tally != nullptr && slot >= 1u);
+    GL_ARG(world >= 1 && rank >= 0 && rank < world && (((uintptr_t)d_ctl | (uintptr_t)d_tally) & 15u) == 0);
+    if (!rows->boolean)
+        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_shard_step: the row plan does not hold the GL_PLAN_BOOLEAN layout");
+    GL_ARG(rows->num_rows == p->num_rows && rows->num_cols == p->num_cols && rows->row_begin == p->row_begin && rows->row_end == p->row_end);
+    if (!d_tally_in) d_tally_in = d_tally;
+    gl::BfsPushArgs a;
+    a.indptr = p->d_indptr;
+    a.stream = p->d_stream;
+    a.chunks = p->d_long_chunks;
+    a.nchunks = p->n_long_chunks;
+    a.num_cols = p->num_cols;
+    a.bits_in = d_bits_in;
+    a.bits_out = d_bits_out;
+    a.bits_spare = nullptr;
+    a.words = bits_words;
+    a.col_words = gl::cdiv(p->num_cols, 32);
+    a.dist = d_distance;
+    a.level = level;
+    a.acc = nullptr;
+    const bool have_rows = rows->d_csr_indptr != nullptr;
+    p->bfs_rows_plan = have_rows ? rows : nullptr;
+    a.row_ptr = have_rows ? rows->d_csr_indptr : nullptr;
+    a.row_idx = have_rows ? rows->d_csr_indices : nullptr;
+    a.num_rows = p->num_rows;
+    a.row_begin = p->row_begin;
+    a.row_end = p->row_end;
+    a.nz_base = have_rows ? rows->csr_nz_base : 0u;
+    a.deferred = false;
+    a.col_len = d_col_len;
+    gl::BfsShardArgs sa;
+    // the state after slot k lives in d_ctl for even k and in the head of d_tally for odd k: the launch of slot s reads the
+    // state after s - 2 (after s - 1 = 0 in slot 1) and stores the one after s - 1 into the buffer nobody reads meanwhile
+    uint32_t *buf[2] = {d_ctl, d_tally};
+    sa.state_in = slot == 1u ? d_ctl : buf[slot & 1u];
+    sa.state_out = slot == 1u ? nullptr : (finish ? d_ctl : buf[(slot - 1u) & 1u]);
+    sa.records = d_ctl;
+    const size_t per_slot = (size_t)world * gl::kTallyRankWords;
+    sa.tally_prev = slot == 1u ? nullptr : d_tally_in + gl::kTallyHeadWords + (size_t)(slot - 2u) * per_slot;
+    sa.lines_prev = (uint32_t)world * gl::kTallyLines;
+    sa.tally_mine = d_tally + gl::kTallyHeadWords + (size_t)(slot - 1u) * per_slot + (size_t)rank * gl::kTallyRankWords;
+    sa.slot = slot;
+    sa.finish = finish ? 1u : 0u;
+    sa.pull_units = 0;
+    // (one workgroup per compute unit fits next to the pull's LDS tile: a larger grid would run in rounds)
+    sa.push_blocks = std::min<uint32_t>((uint32_t)gl::ctx().num_cus, std::max<uint32_t>(gl::cdiv(a.col_words, 64), 1u));
+    gl::BfsBitsCtl &c = sa.prev;
+    c.ctl = nullptr;
+    c.slot = slot - 1u;
+    c.n = p->num_rows ? p->num_rows : 1u;
+    c.may_continue = (uint32_t)may_continue_prev & 3u;
+    c.threshold = threshold;
+    c.back_threshold = back_threshold;
+    // the GLOBAL matrix decides, as in gl_bfs_bits_decide
+    const long hdiv = gl::env_long("GRAPHLILY_BFS_HEAVY_DIV", 128), bdiv = gl::env_long("GRAPHLILY_BFS_BU_DIV", 3);
+    c.heavy = hdiv > 0 ? nnz_global / (unsigned long long)hdiv : ~0ull;
+    c.nnz_rows = nnz_global;
+    c.bu_limit = (have_rows && bdiv > 0) ? nnz_global / (unsigned long long)bdiv : 0ull;
+    if (!finish) {
+        GL_ARG(d_bits_in != nullptr && d_bits_out != nullptr && d_distance != nullptr && d_col_len != nullptr && d_bits_in != d_bits_out);
+        GL_ARG((uint64_t)bits_words * 32u >= p->num_cols && (uint64_t)bits_words * 32u >= p->num_rows);
+        GL_ARG((bits_words & 1u) == 0 && (((uintptr_t)d_bits_in | (uintptr_t)d_bits_out) & 15u) == 0);
+    }
+    return gl::bool_plan_bfs_shard_step(rows, a, sa, gl::ctx().stream);
+}
+
+int gl_bfs_bits_shard_step(gl_spmspv_plan p, gl_spmv_plan rows, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t bits_words,
+                           float *d_distance, float level, uint32_t *d_ctl, uint32_t *d_tally, const uint32_t *d_tally_in, uint32_t slot,
+                           int rank, int world_size, const uint32_t *d_col_len, uint64_t nnz_global, float threshold,
+                           int may_continue_prev, float back_threshold) {
+    return bfs_bits_shard_launch(p, rows, d_bits_in, d_bits_out, bits_words, d_distance, level, d_ctl, d_tally, d_tally_in, slot, rank,
+                                 world_size, d_col_len, nnz_global, threshold, may_continue_prev, back_threshold, false);
+}
+
+int gl_bfs_bits_shard_finish(gl_spmspv_plan p, gl_spmv_plan rows, uint32_t *d_ctl, uint32_t *d_tally, const uint32_t *d_tally_in,
+                             uint32_t last_slot, int rank, int world_size, uint64_t nnz_global, float threshold, int may_continue_last,
+                             float back_threshold) {
+    return bfs_bits_shard_launch(p, rows, nullptr, nullptr, 0u, nullptr, 0.0f, d_ctl, d_tally, d_tally_in, last_slot + 1u, rank, world_size,
+                                 nullptr, nnz_global, threshold, may_continue_last, back_threshold, true);
 }
 
 int gl_sparse_nnz(const gl_idx_val *d_sparse, uint32_t *nnz) {

@@ -13,6 +13,7 @@
 // What is left is the 4-byte stream at HBM speed.  Units, segment-major numbering, direct epilogue for
 // unsplit blocks and the init kernel + plain stores (1.0f, idempotent) for split ones are as in gl_spmv.hip.
 #include "gl_spmv_plan.h"
+#include "gl_bfs_shard.h"
 
 namespace gl {
 
@@ -54,6 +55,11 @@ struct BoolArgs {
     // row-sharded schedule: the launch runs or not by the same control words, but keeps no totals and decides nothing
     // (gl_bfs_bits_decide does, on the all-gathered frontier)
     bool v2_deferred = false;
+    // one-launch shard step (gl_bfs_shard.h): the epilogue tallies what it adds to the next frontier -- vertices, their
+    // GLOBAL column lengths (t_col_len) and their row lengths (v2_rowptr, indexed by row - v2_row_base) -- into the rank's lines
+    uint32_t *tally_mine = nullptr;
+    const uint32_t *t_col_len = nullptr;
+    uint32_t v2_row_base = 0;
 };
 
 // x != 0 packed little-endian, 64 columns per wavefront step; words past num_cols are zero
@@ -127,9 +133,9 @@ __device__ __forceinline__ BoolElem bool_load(const void *entries, size_t group,
     return e;
 }
 
-template <int MASK, int U, int FUSED, int KEEP = 0>
-__global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
+// the kernel's body for workgroup `unit` (also run by the one-launch shard step of the BFS schedule, below)
+template <int MASK, int U, int FUSED, int KEEP>
+__device__ __forceinline__ void spmv_bool_body(const BoolArgs &a, uint32_t *lds_words, const uint32_t unit) {
     // tile first: its byte offsets fit the 16-bit immediate of the LDS instructions either way
     uint32_t *tile = lds_words;                     // kBoolTileWords: one bit per row slot, slot 16383 = padding
     uint32_t *xw = lds_words + kBoolTileWords;      // kBoolPhaseWords
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         // the slot's push step ran (it is enqueued in front of this launch) -- scattering, or as the bottom-up pull: add up
         // its totals and take its decisions.  decide() does not change what scatters() / bottom_up() say about THIS slot,
         // so the other workgroups may look later.
-        if (!a.v2_deferred && blockIdx.x == 0 && threadIdx.x < 64u) {
+        if (!a.v2_deferred && unit == 0 && threadIdx.x < 64u) {
             uint32_t *line = a.v2_push_acc + 32u * threadIdx.x;
             uint32_t fresh = line[0];
             unsigned long long work = *reinterpret_cast<unsigned long long *>(line + 2);
@@ -163,8 +169,8 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         const uint32_t w = *a.gate;
         if (!(a.gate_op == GL_GATE_EQ ? w == a.gate_value : a.gate_op == GL_GATE_GT ? w > a.gate_value : w <= a.gate_value)) return;
     }
-    if (a.v2.ctl && blockIdx.x == 0 && threadIdx.x == 0) a.v2.record_mode(2u);   // this slot streams the matrix row-wise
-    const uint4 d = a.units[2u * blockIdx.x], dh = a.units[2u * blockIdx.x + 1u];
+    if (a.v2.ctl && unit == 0 && threadIdx.x == 0) a.v2.record_mode(2u);   // this slot streams the matrix row-wise
+    const uint4 d = a.units[2u * unit], dh = a.units[2u * unit + 1u];
     const uint32_t span0 = d.x, nspans = d.y, row0 = d.z;
     const uint32_t nrows = d.w & 0xffffu;
     const bool direct = (d.w >> 31) != 0u;
@@ -269,20 +275,51 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
         // 64 rows per wavefront step (blocks start on multiples of 64 rows): one coalesced distance load, ONE atomicOr per
         // 32-bit word of the output vector with the wavefront's combined mask -- a dense frontier would otherwise cost an
         // atomic per row and unit (orkut's heavy slot on a 1/8 shard: 3 M of them)
-        for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < nrows; i0 += kThreads) {
-            const uint32_t i = i0 + lane;
-            bool cand = i < nrows && ((tile[i >> 5] >> (i & 31u)) & 1u);
-            if (!__any(cand)) continue;
-            const uint32_t row = row0 + i;
-            cand = cand && a.dist[row] == 0.0f;
-            const uint64_t m = __ballot(cand);
-            if (!m) continue;
-            const uint32_t half = lane >> 5, mine = (uint32_t)(m >> (32u * half));
-            uint32_t old = 0u;
-            if ((lane & 31u) == 0u && mine) old = atomicOr(&a.bits_out[(row0 + i0) / 32u + half], mine);
-            old = __shfl(old, (int)(half * 32u));
-            if (cand && !((old >> (lane & 31u)) & 1u)) a.dist[row] = a.level;
+        uint32_t t_fresh = 0u, t_work = 0u, t_rows = 0u;   // one-launch shard step: this lane's claims (<= 16 rows)
+        // Four row groups per step, every load / atomic of a stage issued before the first use of its result: a group is a
+        // chain of dependent round trips (distance, atomicOr, then -- tallies -- the row's lengths), and a 1/8 shard's units
+        // share 12 K rows each: one group at a time the epilogue took as long as the stream
+        constexpr int E2 = 4;
+        for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < nrows; i0 += E2 * kThreads) {
+            bool cand[E2];
+            float dv[E2];
+#pragma unroll
+            for (int u = 0; u < E2; u++) {
+                const uint32_t i = i0 + u * kThreads + lane;
+                cand[u] = i < nrows && ((tile[i >> 5] >> (i & 31u)) & 1u);
+                dv[u] = cand[u] ? a.dist[row0 + i] : 1.0f;
+            }
+            uint32_t old[E2];
+#pragma unroll
+            for (int u = 0; u < E2; u++) {
+                cand[u] = cand[u] && dv[u] == 0.0f;
+                const uint64_t m = __ballot(cand[u]);
+                const uint32_t half = lane >> 5, mine = (uint32_t)(m >> (32u * half));
+                old[u] = 0u;
+                if ((lane & 31u) == 0u && mine) old[u] = atomicOr(&a.bits_out[(row0 + i0 + u * kThreads) / 32u + half], mine);
+            }
+            uint32_t cl[E2], r0[E2], r1[E2];
+#pragma unroll
+            for (int u = 0; u < E2; u++) {
+                const uint32_t row = row0 + i0 + u * kThreads + lane;
+                const uint32_t o = __shfl(old[u], (int)((lane >> 5) * 32u));
+                cand[u] = cand[u] && !((o >> (lane & 31u)) & 1u);     // this unit set the row's bit first
+                const bool t = cand[u] && a.tally_mine != nullptr;
+                cl[u] = t ? a.t_col_len[row] : 0u;
+                r0[u] = (t && a.v2_rowptr) ? a.v2_rowptr[row - a.v2_row_base] : 0u;
+                r1[u] = (t && a.v2_rowptr) ? a.v2_rowptr[row - a.v2_row_base + 1u] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < E2; u++) {
+                if (cand[u]) {
+                    a.dist[row0 + i0 + u * kThreads + lane] = a.level;
+                    t_fresh += 1u;
+                    t_work += cl[u];
+                    t_rows += r1[u] - r0[u];
+                }
+            }
         }
+        if (a.tally_mine) tally_block_add(a.tally_mine, unit, t_fresh, t_work, t_rows);
     } else if (FUSED) {
         // SpMV masked by `distance == 0`, eWiseAdd(+0), assign(level) where the result is set, and the packing of
         // the next frontier (app/bfs.h:118-123) in one epilogue: 64 rows per wavefront step, one 64-bit word out.
@@ -310,10 +347,10 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                 hit[u] = hit[u] && dv[u] == 0.0f;       // fresh: reached now, never before
                 const bool want = hit[u] && a.v2_indptr != nullptr && row < a.v2_ncols;
                 p0[u] = want ? a.v2_indptr[row] : 0u;
-                p1[u] = want ? a.v2_indptr[row + 1u] : 0u;
+                p1[u] = want ? a.v2_indptr[row + 1u] : ((hit[u] && a.t_col_len) ? a.t_col_len[row] : 0u);
                 const bool wantr = hit[u] && a.v2_rowptr != nullptr;
-                r0[u] = wantr ? a.v2_rowptr[row] : 0u;
-                r1[u] = wantr ? a.v2_rowptr[row + 1u] : 0u;
+                r0[u] = wantr ? a.v2_rowptr[row - a.v2_row_base] : 0u;
+                r1[u] = wantr ? a.v2_rowptr[row - a.v2_row_base + 1u] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < E; u++) {
@@ -328,7 +365,10 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
                 }
             }
         }
-        if (a.v2.ctl && !a.v2_deferred) {
+        if (a.tally_mine) {
+            // (nfresh is lane 0's count of the wavefront's rows; work / work_rows are per lane)
+            tally_block_add(a.tally_mine, unit, lane == 0 ? nfresh : 0u, work, work_rows);
+        } else if (a.v2.ctl && !a.v2_deferred) {
             __shared__ uint32_t v2_fresh_s, v2_last_s;
             __shared__ unsigned long long v2_work_s, v2_rows_s;
             if (threadIdx.x == 0) {
@@ -353,7 +393,7 @@ __global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
             // runs), then one root ticket per line: all 256 workgroups end within microseconds of each other, and three
             // atomics each on ONE word cost ~5 us per launch (measured: BFS.pull on 23 slots +110 us).
             if (threadIdx.x == 0) {
-                const uint32_t l = blockIdx.x & 63u, nlines = min(gridDim.x, 64u);
+                const uint32_t l = unit & 63u, nlines = min(gridDim.x, 64u);
                 uint32_t *line = a.v2_push_acc + 32u * l;
                 if (v2_fresh_s) {
                     atomicAdd(line, v2_fresh_s);
@@ -450,6 +490,40 @@ static uint32_t bool_tickets() {
 // ring depth.  Same-box sweep (orkut / products, masked, x density 0.5 and 0.02): groups of 256 entries (16-byte loads),
 // two slots per step, four slots deep 0.160 / 0.097 ms; 128-entry groups (8-byte loads), 2, 6: 0.170 / 0.102 ms.
 constexpr int kBoolUnroll = GL_BOOL_U;
+template <int MASK, int U, int FUSED, int KEEP = 0>
+__global__ __launch_bounds__(kThreads) void spmv_bool_kernel(BoolArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
+    spmv_bool_body<MASK, U, FUSED, KEEP>(a, lds_words, blockIdx.x);
+}
+
+// One slot of the bit-frontier BFS schedule on a row shard in ONE launch (gl_bfs_shard.h): the previous slot's decision
+// from all ranks' tallies, then the slot's step -- scattering push, bottom-up scan or streaming pull.
+template <int U, int FUSED, int KEEP>
+__global__ __launch_bounds__(kThreads) void bfs_shard_step_kernel(BoolArgs ba, BfsPushArgs pa, BfsShardArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
+    __shared__ uint32_t s_state[16];
+    const BfsBitsCtl c = shard_prologue(sa, s_state);
+    if (sa.finish || c.finished()) return;
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+    if (c.scatters()) {
+        if (first) c.record_mode(1u);
+        if (blockIdx.x >= sa.push_blocks) return;
+        uint32_t fresh = 0u, work = 0u, work_rows = 0u;
+        bfs_shard_scatter<kThreads>(pa, lds_words, blockIdx.x, sa.push_blocks, fresh, work, work_rows);
+        tally_block_add(sa.tally_mine, blockIdx.x, fresh, work, work_rows);
+        return;
+    }
+    if (pa.row_idx && c.bottom_up()) {
+        if (first) c.record_mode(3u);
+        uint32_t fresh = 0u, work = 0u, work_rows = 0u;
+        bfs_shard_bottom_up(pa, blockIdx.x * kWaves + (threadIdx.x >> 6), gridDim.x * kWaves, fresh, work, work_rows);
+        tally_block_add(sa.tally_mine, blockIdx.x, fresh, work, work_rows);
+        return;
+    }
+    if (first) c.record_mode(2u);
+    if (blockIdx.x < sa.pull_units) spmv_bool_body<GL_NOMASK, U, FUSED, KEEP>(ba, lds_words, blockIdx.x);
+}
+
 constexpr size_t kBoolLds = ((size_t)kBoolPhaseWords + kBoolTileWords) * 4u;
 
 template <int MASK, int FUSED, int KEEP>
@@ -537,6 +611,54 @@ int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_o
         return launch_bool_variant<GL_NOMASK, 2>(p, a, s);
     }
     return launch_bool_variant<GL_NOMASK, 1>(p, a, s);
+}
+
+template <int FUSED, int KEEP>
+static int launch_shard_step(uint32_t grid, const BoolArgs &a, const BfsPushArgs &pa, const BfsShardArgs &sa, hipStream_t s) {
+    static int attr_device = -1;
+    if (attr_device != ctx().device) {
+        GL_HIP(hipFuncSetAttribute((const void *)bfs_shard_step_kernel<kBoolUnroll, FUSED, KEEP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kBoolLds));
+        attr_device = ctx().device;
+    }
+    bfs_shard_step_kernel<kBoolUnroll, FUSED, KEEP><<<grid, kThreads, kBoolLds, s>>>(a, pa, sa);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// One slot of the bit-frontier BFS schedule on the rows of `p` in one launch (gl_bfs_bits_shard_step, gl_spmspv.hip fills
+// the push arguments from the CSC plan of the same shard).  col_len: global column lengths.
+int bool_plan_bfs_shard_step(gl_spmv_plan p, BfsPushArgs pa, BfsShardArgs sa, hipStream_t s) {
+    if ((p->row_begin & 63u) || (p->row_end != p->num_rows && (p->row_end & 63u)))
+        return set_error(GL_ERR_UNSUPPORTED, "gl_bfs_bits_shard_step: the shard must be cut on multiples of 64 rows");
+    BoolArgs a;
+    a.entries = p->d_entries;
+    a.bases = p->d_bases;
+    a.units = p->d_units;
+    a.hub_rows = p->d_hub_rows;
+    a.spans = p->d_spans;
+    a.xbits = pa.bits_in;
+    a.mask = nullptr;
+    a.y = nullptr;
+    a.zero = 0.0f;
+    a.run_flag = nullptr;
+    a.bits_out = pa.bits_out;
+    a.dist = pa.dist;
+    a.level = pa.level;
+    a.tickets = bool_tickets();
+    a.tally_mine = sa.tally_mine;
+    a.t_col_len = pa.col_len;
+    a.v2_rowptr = p->d_csr_indptr;
+    a.v2_row_base = p->row_begin;
+    sa.pull_units = p->nunits;
+    const uint32_t grid = sa.finish ? 1u : std::max<uint32_t>(std::max<uint32_t>(sa.pull_units, sa.push_blocks), 1u);
+    static const size_t keep_bytes = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MB", 224) << 20;
+    static const size_t keep_min = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MIN_MB", 64) << 20;
+    const size_t rows_bytes = p->d_csr_indptr ? ((size_t)(p->row_end - p->row_begin) + 1u) * 4u + (size_t)p->nnz * 4u : 0u;
+    const size_t streamed = p->device_bytes - std::min<size_t>(rows_bytes, p->device_bytes);
+    const bool keep = streamed <= keep_bytes && streamed >= keep_min;
+    if (p->segments > 1) return keep ? launch_shard_step<2, 1>(grid, a, pa, sa, s) : launch_shard_step<2, 0>(grid, a, pa, sa, s);
+    return keep ? launch_shard_step<1, 1>(grid, a, pa, sa, s) : launch_shard_step<1, 0>(grid, a, pa, sa, s);
 }
 
 // d_x != nullptr: pack it into the plan's bit vector first; else run on `bits` as the caller prepared them

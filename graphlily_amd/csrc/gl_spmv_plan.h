@@ -200,6 +200,10 @@ int bool_plan_bfs_step(gl_spmv_plan p, const uint32_t *bits_in, uint32_t *bits_o
                        uint32_t back_slot = 0, float back_threshold = 0.0f, int back_may_continue = 0, const BfsBitsCtl *v2 = nullptr,
                        const uint32_t *v2_indptr = nullptr, uint32_t v2_ncols = 0, uint32_t *v2_push_acc = nullptr, bool v2_deferred = false);
 int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hipStream_t s, const uint32_t *xbits = nullptr);
+// gl_bfs_shard.h: one slot of the bit-frontier BFS schedule on a row shard in one launch
+struct BfsPushArgs;
+struct BfsShardArgs;
+int bool_plan_bfs_shard_step(gl_spmv_plan p, BfsPushArgs pa, BfsShardArgs sa, hipStream_t s);
 // gl_apply.hip: the set bits of d_bits[0..n) as a sparse list {row, 1} with head {count, 0}; no-op unless *gate_word == gate_value
 int bits_to_sparse_gated(const uint32_t *d_bits, uint32_t n, gl_idx_val *d_out, uint32_t *d_counts, const uint32_t *gate_word,
                          uint32_t gate_value, hipStream_t s);

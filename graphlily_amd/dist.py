@@ -166,7 +166,7 @@ class EmulatedComm:
         """vecs_buf: the (N + 2) x words bit vectors a whole-matrix BFS._pull_push_bits left behind (device)."""
         self.truth, self.truth_words = vecs_buf, int(words)
 
-    def exchange_bits(self, bits_buf, k, bounds):
+    def exchange_bits(self, bits_buf, k, bounds, tally_slot_buf=None, tally_slot=None):
         from . import capi
         assert self.truth is not None, "EmulatedComm.set_truth first"
         if not self.copy:
@@ -179,6 +179,41 @@ class EmulatedComm:
                 dst = capi.DeviceBuffer(b - a, ptr=bits_buf.ptr + a, keepalive=bits_buf)
                 src = capi.DeviceBuffer(b - a, ptr=self.truth.ptr + base + a, keepalive=self.truth)
                 capi.copy_d2d(dst, src, b - a)
+        if tally_slot_buf is not None:      # the other ranks' tallies of the slot (their 256-byte blocks of the recorded table)
+            per = 4 * capi.GL_BFS_TALLY_RANK_WORDS
+            tbase = 4 * capi.GL_BFS_TALLY_HEAD_WORDS + (tally_slot - 1) * self.world_size * per
+            for a, b in ((0, self.rank * per), ((self.rank + 1) * per, self.world_size * per)):
+                if b > a:
+                    dst = capi.DeviceBuffer(b - a, ptr=tally_slot_buf.ptr + a, keepalive=tally_slot_buf)
+                    src = capi.DeviceBuffer(b - a, ptr=self._tally.ptr + tbase + a, keepalive=self._tally)
+                    capi.copy_d2d(dst, src, b - a)
+
+    def truth_tally(self, key, slots, bounds, col_len, row_len, n):
+        """Every rank's tallies of every slot of the whole-matrix run (gl_bfs_bits_shard_step's table: per slot and rank
+        {vertices reached in the rank's rows, their global column lengths, their row lengths}), computed on the host from
+        the recorded bit vectors: what the other ranks of a real run would have sent.  Cached per (source, slots)."""
+        from . import capi
+        if getattr(self, "_tally_key", None) == (key, self.truth.ptr):
+            return self._tally
+        W = self.world_size
+        table = np.zeros(capi.bfs_tally_words(slots, W), np.uint32)
+        vec = self.truth.read(np.uint32, (slots + 2) * self.truth_words).reshape(-1, self.truth_words)
+        cl, rl = np.asarray(col_len, np.uint64), np.asarray(row_len, np.uint64)
+        for s in range(1, slots + 1):
+            bits = np.unpackbits(vec[s + 1].view(np.uint8), bitorder="little")[:n].astype(bool)
+            for r in range(W):
+                lo, hi = bounds[r], bounds[r + 1]
+                sl = bits[lo:hi]
+                base = capi.GL_BFS_TALLY_HEAD_WORDS + ((s - 1) * W + r) * capi.GL_BFS_TALLY_RANK_WORDS
+                table[base] = int(sl.sum())
+                table[base + 2:base + 4] = np.array([int(cl[lo:hi][sl].sum())], np.uint64).view(np.uint32)
+                table[base + 4:base + 6] = np.array([int(rl[lo:hi][sl].sum())], np.uint64).view(np.uint32)
+        if getattr(self, "_tally", None) is None or self._tally.nbytes != table.nbytes:
+            self._tally = capi.DeviceBuffer(table.nbytes)
+        self._tally.write(table)
+        self._tally_key = (key, self.truth.ptr)
+        self.truth_tally_host = table
+        return self._tally
 
     def all_gather_slices(self, full, bounds):
         return                 # nothing to gather from: only this rank's slice of `full` is valid
@@ -203,5 +238,8 @@ class CabiComm(Comm):
         dist.broadcast_object_list(uid, src=0, group=self.group)
         self.gl = capi.Dist(self.rank, self.world_size, uid[0])
 
-    def exchange_bits(self, bits_buf, k, bounds):
-        self.gl.all_gather_bits(bits_buf, bounds)
+    def exchange_bits(self, bits_buf, k, bounds, tally_slot_buf=None, tally_slot=None):
+        if tally_slot_buf is None:
+            self.gl.all_gather_bits(bits_buf, bounds)
+        else:
+            self.gl.all_gather_bits_tally(bits_buf, bounds, tally_slot_buf)

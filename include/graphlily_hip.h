@@ -389,6 +389,32 @@ int gl_bfs_bits_decide(gl_spmspv_plan csc, const uint32_t *d_bits_next, const ui
                        uint64_t nnz_global, uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue, float back_threshold);
 int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
                       uint32_t nvec, uint32_t first_pull_slot);
+/* ONE LAUNCH PER SLOT on a row shard (csrc/gl_bfs_shard.h) -- the schedule above without gl_bfs_bits_decide and with the two
+ * steps of a slot in one kernel; what a 1/8 shard of the orkut stand-in needs, whose slots hold less work than a launch costs.
+ *   gl_bfs_bits_shard_step    slot `slot` (1-based) on the rows of `csc` / `rows` (the rank's SpMSpV plan and GL_PLAN_BOOLEAN
+ *             SpMV plan, same row range, cut on multiples of 64 rows).  Every rank TALLIES what its step adds to the next
+ *             frontier -- vertices, their global column lengths (d_col_len: n words, the whole matrix'), their row lengths --
+ *             into its 256 bytes of d_tally; the driver exchanges them together with the slot's bit vector
+ *             (gl_dist_all_gather_bits_tally: one grouped operation).  The launch of slot s starts with the decision of slot
+ *             s - 1: every workgroup adds up all ranks' tallies (integers: identical everywhere) and replays the reference's
+ *             loop condition on a private copy of the control words; then the step runs as that state says (scattering push,
+ *             bottom-up scan, streaming pull).  may_continue_prev / threshold / back_threshold: the values of slot - 1
+ *             (GL_BFS_DEFERRED is not used here).
+ *             d_tally: GL_BFS_TALLY_WORDS(slots, world) words, ALL ZERO at the start of a run (allocate it behind the bit
+ *             vectors and let gl_bfs_bits_begin clear it with them); d_tally_in: where the previous slot's tallies of ALL
+ *             ranks are read (NULL = d_tally, after the exchange; a one-GPU emulation passes a recorded table).
+ *   gl_bfs_bits_shard_finish  after the last slot: its decision, and the final control words into d_ctl (where the host
+ *             reads the reference's push count and the per-slot records, as above). */
+#define GL_BFS_TALLY_HEAD_WORDS 64
+#define GL_BFS_TALLY_RANK_WORDS 64
+#define GL_BFS_TALLY_WORDS(slots, world) (GL_BFS_TALLY_HEAD_WORDS + (size_t)(slots) * (size_t)(world) * GL_BFS_TALLY_RANK_WORDS)
+int gl_bfs_bits_shard_step(gl_spmspv_plan csc, gl_spmv_plan rows, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t bits_words,
+                           float *d_distance, float level, uint32_t *d_ctl, uint32_t *d_tally, const uint32_t *d_tally_in, uint32_t slot,
+                           int rank, int world_size, const uint32_t *d_col_len, uint64_t nnz_global, float threshold,
+                           int may_continue_prev, float back_threshold);
+int gl_bfs_bits_shard_finish(gl_spmspv_plan csc, gl_spmv_plan rows, uint32_t *d_ctl, uint32_t *d_tally, const uint32_t *d_tally_in,
+                             uint32_t last_slot, int rank, int world_size, uint64_t nnz_global, float threshold, int may_continue_last,
+                             float back_threshold);
 /* gl_bfs_bits_begin_from: the set-up of a schedule that PULLS in every slot when the caller already holds the distances and
  * the current frontier as a float vector (the C++ module layer recognises the reference's pull iteration -- SpMV, eWiseAdd(+0),
  * AssignVectorDense, app/bfs.h:118-123 -- and runs it as gl_bfs_bits_push_step + gl_bfs_bits_pull_step on three rotating bit
@@ -517,6 +543,9 @@ int gl_dist_destroy(gl_dist comm);
 int gl_dist_rank(gl_dist comm, int *rank, int *world_size);
 int gl_dist_all_gather_f32(gl_dist comm, float *d_full, const uint32_t *bounds);
 int gl_dist_all_gather_bits(gl_dist comm, uint32_t *d_bits, const uint32_t *row_bounds);
+/* ... and, in the same grouped operation, every rank's tallies of the slot (gl_bfs_bits_shard_step: d_tally_slot = the slot's
+ * table, world_size blocks of bytes_per_rank = 4 * GL_BFS_TALLY_RANK_WORDS bytes, rank r's block at r * bytes_per_rank) */
+int gl_dist_all_gather_bits_tally(gl_dist comm, uint32_t *d_bits, const uint32_t *row_bounds, uint32_t *d_tally_slot, uint32_t bytes_per_rank);
 int gl_dist_all_gather_sparse(gl_dist comm, const gl_idx_val *d_local, gl_idx_val *d_full, uint32_t capacity, float head_val,
                               uint32_t *total);
 

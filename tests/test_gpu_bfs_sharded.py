@@ -70,6 +70,17 @@ def test_every_rank_of_a_sharded_bfs_matches_the_oracle(gpu, name, world):
                     k, world, mode, threshold, rep, int((got != ref[r0:r1]).sum()))
                 assert b.push_iterations_ == pushes, "the same decisions as the one-GPU run"
                 assert np.array_equal(b.bfs_slot_counts_, counts)
+            # the rank's own tallies of every slot (gl_bfs_bits_shard_step: what it would have sent along with its rows of the
+            # bit vector) are the host's sums over the whole run's vectors
+            tab = b.bits_loop_["tally"].read(np.uint32)
+            truth_tab = b.comm.truth_tally_host
+            H, R = capi.GL_BFS_TALLY_HEAD_WORDS, capi.GL_BFS_TALLY_RANK_WORDS
+            for s in range(1, iters + 1):
+                blk = tab[H + ((s - 1) * world + k) * R:H + ((s - 1) * world + k + 1) * R].reshape(8, 8)
+                want = truth_tab[H + ((s - 1) * world + k) * R:][:6]
+                assert int(blk[:, 0].sum()) == int(want[0]), (s, k)
+                assert int(blk[:, 2:4].copy().view(np.uint64).sum()) == int(want[2:4].copy().view(np.uint64)[0]), (s, k)
+                assert int(blk[:, 4:6].copy().view(np.uint64).sum()) == int(want[4:6].copy().view(np.uint64)[0]), (s, k)
             # the rank's own rows of every vector it wrote are the whole run's (what an all-gather would have published)
             words = whole.bits_loop_["words"]
             mine = b.bits_loop_["vecs"].read(np.uint32).reshape(-1, words)[1:iters + 2, r0 // 32:r1 // 32]
@@ -114,3 +125,23 @@ def test_deferred_decisions_on_a_whole_matrix_plan_equal_the_fused_ones(gpu):
         assert np.array_equal(got, ref)
         assert (b.push_iterations_, b.push_iterations_again_) == (pushes, again)
         assert np.array_equal(b.bfs_slot_counts_, counts)
+
+
+def test_three_launch_slots_still_serve_shards(gpu, monkeypatch):
+    """GRAPHLILY_BFS_SHARD_STEP=0: push step, pull step and gl_bfs_bits_decide on the gathered vector (the slot before the
+    one-launch step existed; what a caller without the tally exchange uses)."""
+    monkeypatch.setenv("GRAPHLILY_BFS_SHARD_STEP", "0")
+    g = datasets.rmat(60000, 1500000, seed=31, symmetric=True)
+    src = int(np.argmax(np.diff(g.adj_indptr.astype(np.int64)) > 0))
+    ref = O.bfs(to_oracle(_prepared(g)), src, 8)
+    whole = _whole(g)
+    for thr in (0.001, 0.05):
+        assert np.array_equal(whole.pull_push(src, 8, thr), ref)
+        for k in range(4):
+            b = _rank(g, k, 4, whole, copy=(k % 2 == 0))
+            for rep in range(3):
+                whole.pull_push(src, 8, thr)
+                got = b.pull_push(src, 8, thr)
+                r0, r1 = b.result_range_
+                assert np.array_equal(got, ref[r0:r1])
+                assert b.push_iterations_ == whole.push_iterations_
