@@ -778,7 +778,10 @@ static Shape choose_shape_bool(uint64_t rows, uint64_t cols, uint64_t nnz, int n
             const double copies = (S == 1) ? nph : (nph + S - 1) / S;          // per unit
             const double t_bits = k * copies * phase_bytes / 45e9;              // one CU copies ~45 GB/s from L2
             const double t_fold = (S == 1) ? 0.0 : (double)rows * 8.0 / 4e12 + 3e-6;
-            const double t = t_stream + t_bits + t_fold + 3.0e-6 * k;
+            // the BFS epilogues walk a unit's rows 4096 at a time, each step a chain of dependent round trips (measured on
+            // one emulated rank of 8 of the orkut stand-in: 32 x 8 units 100 us per BFS, 64 x 4 93 us, 128 x 2 94 us, 256 x 1 98 us)
+            const double t_epi = (double)cdiv(R, 4096) * (S == 1 ? 4.0e-6 : 2.5e-6);
+            const double t = t_stream + t_bits + t_fold + t_epi + 3.0e-6 * k;
             if (t < best_cost) {
                 best_cost = t;
                 best = Shape{(uint32_t)B, S};
