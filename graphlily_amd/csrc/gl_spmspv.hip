@@ -62,6 +62,10 @@ struct gl_spmspv_plan_s {
     uint32_t n_long_chunks = 0;
     // gl_spmspv_plan_hint_tiny (one-shot): the caller expects the next run's vector to be tiny -- then the run is ONE launch
     bool tiny_hint = false;
+    // gl_spmspv_plan_hint_work (one-shot): the caller knows the next run's vector -- the non-zeros of its columns and the longest
+    // of them; ~0 = unknown
+    uint64_t work_hint = ~0ull;
+    uint32_t longest_hint = 0;
     const void *bfs_rows_plan = nullptr;   // the SpMV plan whose rows the last gl_bfs_bits_push_step could scan bottom-up (or null)
     uint32_t *d_bfs_acc = nullptr;   // kBfsAccSlots x 32 words: the push step's totals, spread over 64 lines (see bfs_push_bits_kernel)
     uint64_t device_bytes = 0;
@@ -970,10 +974,13 @@ static int launch_tiny_mask(int mask_type, const TinyArgs &a, const float *mask,
     }
 }
 
+// (queue_capacity == 0: the caller knows the vector names no long column -- no queue pass; a long column that turns up
+// anyway is scattered by its workgroup on the spot, see the kernel)
 template <int OP>
 static int launch_scatter(const ScatterArgs &a, uint32_t grid, hipStream_t s) {
     spmspv_scatter_kernel<OP><<<grid, 256, 0, s>>>(a);
     GL_LAUNCH_CHECK();
+    if (!a.queue_capacity) return GL_OK;
     spmspv_queue_kernel<OP><<<(unsigned)ctx().num_cus * 8u, 256, 0, s>>>(a);
     GL_LAUNCH_CHECK();
     return GL_OK;
@@ -1177,6 +1184,9 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     // a caller that expects a tiny vector (gl_spmspv_plan_hint_tiny): the whole run is one launch of one workgroup
     const bool tiny = p->tiny_hint && val_type == GL_VAL_FLOAT && nrows > 0 && gl::env_long("GRAPHLILY_SPMSPV_TINY", 1) != 0;
     p->tiny_hint = false;
+    const uint64_t work_hint = gl::env_long("GRAPHLILY_SPMSPV_WORK_HINT", 1) != 0 ? p->work_hint : ~0ull;
+    const uint32_t longest_hint = p->longest_hint;
+    p->work_hint = ~0ull;
     if (tiny) {
         p->frontier_hint = ~0ull;
         p->frontier_bits = nullptr;
@@ -1215,6 +1225,11 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     // decision kernels: they cannot reach the threshold whatever their columns are
     if (may_pull && p->frontier_hint != ~0ull && p->frontier_hint * (uint64_t)p->max_col_len <= threshold) may_pull = false;
     p->frontier_hint = ~0ull;
+    // ... and one that knows the work itself (gl_spmspv_plan_hint_work: a module that uploaded the vector from the host) takes
+    // the decision of spmspv_work_kernel here when it is "scatter": no decision kernel and none of the row-wise kernels that
+    // would only find out that they have nothing to do (five dependent launches, ~22 us of a 60 us call).  A stale hint costs
+    // time, never results: scattering is correct for any vector.
+    if (may_pull && work_hint != ~0ull && work_hint <= threshold) may_pull = false;
     struct ClearBits {   // one-shot, whatever path the run takes
         gl_spmspv_plan p;
         ~ClearBits() { p->frontier_bits = nullptr; }
@@ -1236,7 +1251,7 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     a.acc = p->d_acc;
     a.queue_count = p->d_queue_count;
     a.queue = p->d_queue;
-    a.queue_capacity = p->queue_capacity;
+    a.queue_capacity = (work_hint != ~0ull && longest_hint < gl::kBigColumn) ? 0u : p->queue_capacity;
     a.row_begin = p->row_begin;
     a.num_cols = p->num_cols;
     uint32_t grid = gl::cdiv(p->num_cols, 256);
@@ -1349,6 +1364,14 @@ int gl_spmspv_plan_frontier_bits(gl_spmspv_plan p, const uint32_t *d_bits) {
 int gl_spmspv_plan_hint_tiny(gl_spmspv_plan p, uint32_t vector_nnz, uint64_t work) {
     GL_ARG(p != nullptr);
     p->tiny_hint = vector_nnz <= gl::kTinyVec && work <= gl::kTinyWork;
+    return GL_OK;
+}
+
+int gl_spmspv_plan_hint_work(gl_spmspv_plan p, uint32_t vector_nnz, uint64_t work, uint32_t longest_column) {
+    GL_ARG(p != nullptr);
+    p->tiny_hint = vector_nnz <= gl::kTinyVec && work <= gl::kTinyWork;
+    p->work_hint = work;
+    p->longest_hint = longest_column;
     return GL_OK;
 }
 

@@ -361,15 +361,17 @@ class SpMSpVModule(BaseModule):
             up = up.copy()
             up["index"][0] = cnt = up.shape[0] - 1
         self.vector_buf.write(up)
-        # a tiny vector: remember its size and the non-zeros of its columns (the host holds the CSC), see run()
+        # the host holds the CSC: remember the vector's size, the non-zeros of its columns and the longest of them, see run()
+        # (gl_spmspv_plan_hint_work: a tiny vector runs as one launch, and one below the direction switch's threshold without
+        # the decision kernels)
         self.tiny_ = None
         BaseModule.device_writes_ += 1
-        if 0 < cnt <= 1024 and cnt < vector.shape[0] and self.csc_matrix_ is not None:   # (a row shard holds no more than this)
+        if 0 < cnt < vector.shape[0] and self.csc_matrix_ is not None:   # (a row shard holds no more than the whole matrix)
             cols = vector["index"][1:1 + cnt].astype(np.int64)
             cols = cols[cols < self.get_num_cols()]
             ip = self.csc_matrix_.adj_indptr
-            work = int(ip[cols + 1].astype(np.int64).sum() - ip[cols].astype(np.int64).sum())
-            self.tiny_ = (cnt, work, BaseModule.device_writes_)
+            lens = ip[cols + 1].astype(np.int64) - ip[cols].astype(np.int64)
+            self.tiny_ = (cnt, int(lens.sum()), BaseModule.device_writes_, int(lens.max()) if lens.shape[0] else 0)
 
     def send_mask_host_to_device(self, mask):
         mask = np.ascontiguousarray(mask, dtype=np.float32)
@@ -387,7 +389,7 @@ class SpMSpVModule(BaseModule):
         """Before a run: is the vector still the tiny one this module uploaded (no module call has written since)?"""
         t = getattr(self, "tiny_", None)
         if t is not None and t[2] == BaseModule.device_writes_:
-            self.plan_.hint_tiny(t[0], t[1])
+            self.plan_.hint_work(t[0], t[1], t[3])
             return True
         self.tiny_ = None
         return False
@@ -399,7 +401,7 @@ class SpMSpVModule(BaseModule):
                        self.mask_type_)
         self._finish()
         if tiny:      # this run wrote the results and the accumulator, not the vector
-            self.tiny_ = (self.tiny_[0], self.tiny_[1], BaseModule.device_writes_)
+            self.tiny_ = (self.tiny_[0], self.tiny_[1], BaseModule.device_writes_, self.tiny_[3])
 
     def run_assign(self, inout_buf, val):
         """Extension (gl_spmspv_run_assign): run() followed by AssignVectorSparseModule.run(val) with the results as

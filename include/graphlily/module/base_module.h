@@ -30,7 +30,16 @@ protected:
     }
     // every module call that is not the expected continuation of a deferred BFS pull iteration first lets the deferred
     // calls run (module/fusion.h)
-    static void barrier_() { detail::fusion().flush(); }
+    static void barrier_() {
+        ++calls_();
+        detail::fusion().flush();
+    }
+    // module calls so far, whichever module: a module that has learnt something about a device buffer from the host (the
+    // SpMSpV module: the work of the vector it uploaded) trusts it only while no other call has run in between
+    static uint64_t &calls_() {
+        static uint64_t n = 0;
+        return n;
+    }
 
 public:
     explicit BaseModule(std::string kernel_name) : kernel_name_(kernel_name) {}

@@ -122,18 +122,31 @@ public:
             vector_buf.upload(&head, sizeof(head));
         }
         hint_vector_nnz((uint32_t)(used - 1));
-        // a tiny vector (the host holds the CSC: entry count and the non-zeros of its columns are known here): the next
-        // run is one launch instead of four (gl_spmspv_plan_hint_tiny; one-shot, and never result-relevant)
-        const uint32_t cnt = (uint32_t)(used - 1);
-        if (plan_ && kFloat && cnt > 0 && cnt <= 1024) {
-            uint64_t work = 0;
-            for (uint32_t k = 1; k <= cnt; k++) {
-                const uint32_t c = vector[k].index;
-                if (c < csc_matrix_float_.num_cols) work += csc_matrix_float_.adj_indptr[c + 1] - csc_matrix_float_.adj_indptr[c];
-            }
-            GRAPHLILY_CHECK(gl_spmspv_plan_hint_tiny(plan_, cnt, work));
+        // the host holds the CSC: the vector's entry count, the non-zeros of its columns and the longest of them are known
+        // here (gl_spmspv_plan_hint_work: a tiny vector runs as one launch instead of four, one below the direction
+        // switch's threshold without the decision kernels; never result-relevant).  Valid for the runs that follow while
+        // no other module call comes in between (the reference's drivers overwrite vector_buf through
+        // copy_buffer_device_to_device, app/bfs.h:149).
+        hint_cnt_ = (uint32_t)(used - 1);
+        hint_work_ = 0;
+        hint_longest_ = 0;
+        for (uint32_t k = 1; k <= hint_cnt_; k++) {
+            const uint32_t c = vector[k].index;
+            if (c >= csc_matrix_float_.num_cols) continue;
+            const uint32_t len = csc_matrix_float_.adj_indptr[c + 1] - csc_matrix_float_.adj_indptr[c];
+            hint_work_ += len;
+            hint_longest_ = std::max(hint_longest_, len);
         }
+        hint_stamp_ = hint_cnt_ ? calls_() : 0;
     }
+
+private:
+    uint32_t hint_cnt_ = 0, hint_longest_ = 0;
+    uint64_t hint_work_ = 0, hint_stamp_ = 0;
+    // called right after barrier_(): is this the first module call since the stamp?
+    bool hint_fresh_() const { return plan_ && kFloat && hint_stamp_ != 0 && hint_stamp_ + 1 == calls_(); }
+
+public:
 
     void send_mask_host_to_device(aligned_dense_vec_t &mask) {
         barrier_();
@@ -142,7 +155,10 @@ public:
     }
 
     void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }      // extension
-    void bind_vector_buf(DeviceBuffer src_buf) { vector_buf = src_buf; }  // extension
+    void bind_vector_buf(DeviceBuffer src_buf) {                          // extension
+        vector_buf = src_buf;
+        hint_stamp_ = 0;
+    }
 
     // extensions (gl_spmspv_plan_attach_pull / gl_spmspv_plan_hint): a driver that also holds the matrix as a
     // (||,&&) SpMVModule lets heavy frontiers run row-wise; pass SpMVModule::plan_handle() after BOTH modules
@@ -154,6 +170,9 @@ public:
 
     void run() {
         barrier_();
+        const bool fresh = hint_fresh_();
+        if (fresh) GRAPHLILY_CHECK(gl_spmspv_plan_hint_work(plan_, hint_cnt_, hint_work_, hint_longest_));
+        hint_stamp_ = fresh ? calls_() : 0;      // (a run reads the vector: the knowledge stays good)
         GRAPHLILY_CHECK(gl_spmspv_run_typed(plan_, vector_buf.ptr(), mask_type_ == kNoMask ? nullptr : mask_buf.ptr(), results_buf.ptr(),
                                             (int)semiring_.op, VK::bits(semiring_.zero), (int)mask_type_, VK::kind));
         finish_();
@@ -187,6 +206,7 @@ public:
     // the per-iteration device->host control read of the push loops (reference :239-242)
     uint32_t get_results_nnz() {
         barrier_();
+        if (hint_fresh_()) hint_stamp_ = calls_();   // (reads only)
         uint32_t nnz = 0;
         GRAPHLILY_CHECK(gl_sparse_nnz((const gl_idx_val *)results_buf.ptr(), &nnz));
         return nnz;

@@ -451,6 +451,12 @@ int gl_spmspv_plan_hint(gl_spmspv_plan plan, uint32_t vector_nnz_upper_bound);
  * ~30 us per blocking call instead of ~55.  Results never depend on the hint: the kernel checks both bounds on the vector it
  * finds and computes a bigger one correctly (slowly, alone). */
 int gl_spmspv_plan_hint_tiny(gl_spmspv_plan plan, uint32_t vector_nnz, uint64_t work);
+/* The same with everything such a module knows about the vector: also the LONGEST of its columns.  Besides the tiny case, a
+ * run whose work stays below the direction switch's threshold (non-zeros / 32) then skips the decision kernel and the
+ * row-wise kernels that would only find the switch closed, and one without a long column (>= 4096 entries) the chunk-queue
+ * pass: 3 dependent launches instead of up to 9.  One-shot; results never depend on it (a wrong hint makes the run scatter
+ * a vector it would have applied row-wise, and a long column that turns up is scattered by one workgroup). */
+int gl_spmspv_plan_hint_work(gl_spmspv_plan plan, uint32_t vector_nnz, uint64_t work, uint32_t longest_column);
 /* One-shot like the hint: the vector of the NEXT gl_spmspv_run* call is also available as a bit vector (bit c set iff
  * column c is in the vector; gl_spmv_plan_bits_words words of the attached GL_PLAN_BOOLEAN plan, 16-byte aligned, bits past
  * the columns zero).  A run that goes row-wise on that plan then reads it directly instead of clearing and filling the

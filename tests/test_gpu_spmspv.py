@@ -429,6 +429,67 @@ def test_tiny_runs_are_one_launch_with_the_same_result(gpu, sem, mask_name, monk
         assert np.array_equal(res["val"][1:n + 1], ref_res["val"][1:n + 1])
 
 
+@pytest.mark.parametrize("sem", list(SEMIRINGS))
+def test_work_hint_never_changes_the_result(gpu, sem, monkeypatch):
+    """gl_spmspv_plan_hint_work: a module that uploaded the vector from the host tells the plan the non-zeros of its columns
+    and the longest of them; light vectors then skip the direction switch's decision kernels and, without a long column, the
+    chunk-queue pass.  With the switch attached (enable_own_pull), for light, long-column and heavy (row-wise) vectors: the
+    hinted run, the unhinted run (GRAPHLILY_SPMSPV_WORK_HINT=0) and the oracle agree; and a STALE hint -- "light, no long
+    column" for a vector that is heavy and names the hubs -- only costs time."""
+    csc = _csc("rmat_20K")
+    op, zero = SEMIRINGS[sem]
+    coldeg = np.diff(csc.adj_indptr.astype(np.int64))
+    order = np.argsort(coldeg)
+    rng = np.random.default_rng(5)
+    nz = order[coldeg[order] > 0]
+    picks = {"light": np.sort(rng.choice(nz[:len(nz) // 2], 300, replace=False)),
+             "hubs": np.sort(order[-6:]),                                     # long columns (>= 4096 entries on this graph?)
+             "heavy": np.sort(rng.choice(nz, len(nz) // 3, replace=False))}   # far beyond non-zeros / 32: row-wise
+    mask = rand01(csc.num_rows, 12)
+    mods = {}
+    for hint in ("1", "0"):
+        monkeypatch.setenv("GRAPHLILY_SPMSPV_WORK_HINT", hint)
+        mod = M.SpMSpVModule(512)
+        mod.set_semiring(M.SemiringType(op, 1.0, zero))
+        mod.set_mask_type(MASKS["WriteToZero"])
+        mod.set_up_runtime()
+        mod.load_and_format_matrix(csc)
+        mod.send_matrix_host_to_device()
+        mod.enable_own_pull()
+        mod.send_mask_host_to_device(mask)
+        mods[hint] = mod
+    for name, cols in picks.items():
+        vals = (rng.integers(1, 10, size=len(cols)) / 10.0).astype(np.float32)
+        v = M.make_sparse_vec(cols.astype(np.uint32), vals)
+        ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS["WriteToZero"])
+        dirs = {}
+        for hint in ("1", "0"):
+            monkeypatch.setenv("GRAPHLILY_SPMSPV_WORK_HINT", hint)
+            mod = mods[hint]
+            mod.send_vector_host_to_device(v)
+            for rep in range(2):                       # (the module repeats the hint while the vector is its own upload)
+                mod.run()
+                got = M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), csc.num_rows, zero)
+                assert_parity(got, ref, op, "work hint %s %s/%s rep %d" % (hint, sem, name, rep))
+            dirs[hint] = mod.plan_.last_direction()
+        assert dirs["1"] == dirs["0"], (name, dirs)
+        if name == "heavy":
+            assert dirs["1"] == "row-wise"
+    # stale: the plan is told "300 entries, 900 non-zeros, longest column 5" and finds the heavy vector with the hubs in it
+    monkeypatch.setenv("GRAPHLILY_SPMSPV_WORK_HINT", "1")
+    cols = np.union1d(picks["heavy"], picks["hubs"])
+    v = M.make_sparse_vec(cols.astype(np.uint32), np.full(len(cols), 0.5, np.float32))
+    ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS["WriteToZero"])
+    mod = mods["1"]
+    mod.send_vector_host_to_device(v)
+    mod.tiny_ = None                                   # (the module's own, correct hint is dropped ...)
+    mod.plan_.hint_work(300, 900, 5)                    # (... for a wrong one)
+    mod.run()
+    got = M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), csc.num_rows, zero)
+    assert_parity(got, ref, op, "stale work hint " + sem)
+    assert mod.plan_.last_direction() == "scatter"
+
+
 def test_vector_head_larger_than_the_vector_is_clamped(gpu):
     """send_vector_host_to_device of a vector whose head count exceeds the entries it holds: the reference would read its
     zero-initialised mirror (spmspv_module.h:280); here the device block is recycled memory, so the head is clamped to what
