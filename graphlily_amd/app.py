@@ -574,10 +574,11 @@ class BFS(_GraphApp):
                 comm.exchange_bits(st["bits"][k], k, self.bounds_, self.backend.view(st["tally"], first, W * per, 4), tally_slot)
             return
         t = st["vecs"].tensor[k * st["words"]:(k + 1) * st["words"]]
-        comm.all_gather_slices(t, [b // 32 for b in self.bounds_])
-        if tally_slot is not None:
+        if tally_slot is None:
+            comm.all_gather_slices(t, [b // 32 for b in self.bounds_])
+        else:                                              # ONE collective per slot: the tallies ride behind the rank's bits
             base = st["nvec"] * st["words"] + first
-            comm.all_gather_slices(st["vecs"].tensor[base:base + W * per], [r * per for r in range(W + 1)])
+            comm.all_gather_slices_with_tail(t, [b // 32 for b in self.bounds_], st["vecs"].tensor[base:base + W * per], per)
 
     def _bits_loop_ok(self):
         if os.environ.get("GRAPHLILY_BFS_BITS", "1") == "0" or os.environ.get("GRAPHLILY_BFS_FUSED", "1") == "0":

@@ -96,6 +96,32 @@ class Comm:
             self.dist.all_gather_into_tensor(self._stage, self._send, group=self.group)
         torch.cat([self._stage[r * mx:r * mx + lens[r]] for r in range(W)], out=full[bounds[0]:bounds[W]])
 
+    def all_gather_slices_with_tail(self, full, bounds, tail, per):
+        """all_gather_slices of `full` and, in the SAME collective, an all-gather of equal blocks: `tail` holds world_size
+        blocks of `per` elements, rank r's at r * per (the ranks' tallies of a BFS slot travel with the slot's bit vector:
+        one collective per slot, not two).  Always staged: every rank sends [its slice, padded to the longest | its block]."""
+        if not self.distributed:
+            return
+        import torch
+        W = self.world_size
+        lens = [bounds[r + 1] - bounds[r] for r in range(W)]
+        mx = max(lens) + per
+        key = ("tail", full.device, full.dtype, W * mx)
+        if getattr(self, "_tstage_key", None) != key:
+            self._tstage = torch.empty(W * mx, dtype=full.dtype, device=full.device)
+            self._tsend = torch.zeros(mx, dtype=full.dtype, device=full.device)
+            self._tstage_key = key
+        self._tsend[:lens[self.rank]].copy_(full[bounds[self.rank]:bounds[self.rank + 1]])
+        self._tsend[mx - per:].copy_(tail[self.rank * per:(self.rank + 1) * per])
+        if full.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            stage_h, send_h = self._tstage.cpu(), self._tsend.cpu()      # debugging aid, see all_gather_slices
+            self.dist.all_gather_into_tensor(stage_h, send_h, group=self.group)
+            self._tstage.copy_(stage_h)
+        else:
+            self.dist.all_gather_into_tensor(self._tstage, self._tsend, group=self.group)
+        torch.cat([self._tstage[r * mx:r * mx + lens[r]] for r in range(W)], out=full[bounds[0]:bounds[W]])
+        torch.cat([self._tstage[r * mx + mx - per:(r + 1) * mx] for r in range(W)], out=tail[:W * per])
+
     def all_gather_sparse(self, local, count, capacity_full, out):
         """Concatenate per-rank sparse lists ((index,val) pairs as an int64-viewable [k,2] float/int
         tensor) in rank order.  `local` holds this rank's entries (without a head), `count` their

@@ -289,6 +289,29 @@ def test_skewed_partition_is_uneven():
         assert per.max() <= 2.5 * m.nnz / w
 
 
+def _body_gather_with_tail(comm):
+    """The BFS slot exchange of the one-launch shard step: every rank's rows of the bit vector (uneven word ranges, one
+    of them empty) AND its 64-word tally block in ONE collective; bit patterns travel in a float tensor (NaNs included)."""
+    W, per = comm.world_size, 64
+    cuts = [0, 40, 40, 1000, 1017, 1500, 1501, 2900, 3072][:W] + [3072]
+    cuts = sorted(cuts)
+    words = torch.zeros(3072, dtype=torch.int32)
+    lo, hi = cuts[comm.rank], cuts[comm.rank + 1]
+    words[lo:hi] = (torch.arange(lo, hi, dtype=torch.int32) * 2654435 + 0x7fc00001)       # (NaN patterns as floats)
+    tail = torch.zeros(W * per + 8, dtype=torch.int32)
+    tail[comm.rank * per:(comm.rank + 1) * per] = torch.arange(per, dtype=torch.int32) + 1000 * (comm.rank + 1)
+    tail[W * per:] = -7                                                                    # (not part of the exchange)
+    comm.all_gather_slices_with_tail(words.view(torch.float32), cuts, tail.view(torch.float32), per)
+    ok = bool(torch.equal(words, torch.arange(3072, dtype=torch.int32) * 2654435 + 0x7fc00001))
+    want = torch.cat([torch.arange(per, dtype=torch.int32) + 1000 * (r + 1) for r in range(W)] + [torch.full((8,), -7, dtype=torch.int32)])
+    return ok and bool(torch.equal(tail, want))
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bits_and_tallies_travel_in_one_collective(world):
+    assert all(_spawn("_body_gather_with_tail", world).values())
+
+
 @pytest.mark.parametrize("world", [4, 8])
 def test_gathers_over_many_uneven_ranges(world):
     assert all(_spawn("_body_gather_uneven_many", world).values())
