@@ -202,12 +202,11 @@ class BFS(_GraphApp):
         self.SpMSpV_.load_and_format_matrix(csc)
         self.n_ = self.SpMV_.get_num_rows()
         assert self.n_ == self.SpMV_.get_num_cols()
-        if self.comm.distributed:
-            # row shards take the schedule's decisions from GLOBAL lengths (gl_bfs_bits_decide): every rank keeps the two
-            # n-word arrays of the whole matrix
-            self.row_len_ = np.diff(csr.adj_indptr.astype(np.int64)).astype(np.uint32)
-            self.col_len_ = np.diff(csc.adj_indptr.astype(np.int64)).astype(np.uint32)
-            self.nnz_global_ = int(csr.adj_indptr[csr.num_rows])
+        # the bit-frontier schedule takes its decisions from GLOBAL lengths (gl_bfs_bits_shard_step / gl_bfs_bits_decide):
+        # every rank keeps the two n-word arrays of the whole matrix
+        self.row_len_ = np.diff(csr.adj_indptr.astype(np.int64)).astype(np.uint32)
+        self.col_len_ = np.diff(csc.adj_indptr.astype(np.int64)).astype(np.uint32)
+        self.nnz_global_ = int(csr.adj_indptr[csr.num_rows])
 
     def send_matrix_host_to_device(self):
         self.SpMV_.send_matrix_host_to_device()
@@ -450,17 +449,17 @@ class BFS(_GraphApp):
             nvec, ctl_words = N + 2, (18 + 2 * N + 15) & ~15
             both = B.alloc(n + ctl_words, np.float32)          # distances, then the control words: one read-back fetches both
             # row shards: the ranks' tallies (gl_bfs_bits_shard_step) live behind the bit vectors and are cleared with them
-            tally_words = capi.bfs_tally_words(N, self.comm.world_size) if sharded else 0
+            tally_words = capi.bfs_tally_words(N, self.comm.world_size)
             nvec_all = nvec + (tally_words + words - 1) // words
             vecs = B.alloc(nvec_all * words, np.float32)
             st = self.bits_loop_ = {"N": N, "both": both, "vecs": vecs, "words": words, "nvec": nvec, "ctl_words": ctl_words,
                                     "ctl": B.view(both, n, ctl_words, 4), "distance": B.view(both, 0, n, 4),
                                     "bits": [B.view(vecs, k * words, words, 4) for k in range(nvec)], "graphs": {},
                                     "src": np.zeros(1, np.uint32), "warm": set(), "nvec_all": nvec_all}
+            st["col_len"] = capi.DeviceBuffer.from_host(self.col_len_)
+            st["tally"] = B.view(vecs, nvec * words, tally_words, 4)
             if sharded:
-                st["col_len"] = capi.DeviceBuffer.from_host(self.col_len_)
                 st["row_len"] = capi.DeviceBuffer.from_host(self.row_len_)
-                st["tally"] = B.view(vecs, nvec * words, tally_words, 4)
         ctl, distance, bits, words = st["ctl"], st["distance"], st["bits"], st["words"]
         # Once the reference's rule has switched to pulling (frontier / n >= threshold, app/bfs.h:180-190), every later slot
         # is handed back to the push step (an extension, see _pull_push_device), which leaves heavy frontiers to the pull
@@ -477,7 +476,10 @@ class BFS(_GraphApp):
         # ONE launch per slot (gl_bfs_bits_shard_step): the ranks' tallies of a slot travel with its bit vector, and the next
         # slot's launch starts with the decision.  GRAPHLILY_BFS_SHARD_STEP=0: the three-launch slot (push step, pull step,
         # gl_bfs_bits_decide on the gathered vector)
-        one_launch = sharded and os.environ.get("GRAPHLILY_BFS_SHARD_STEP", "1") != "0"
+        # (one GPU: the same kernel with a world of one -- 8 launches instead of 13 for the 6 iterations of the orkut stand-in,
+        # schedule 0.29 -> 0.27 ms; GRAPHLILY_BFS_ONE_LAUNCH=0 keeps the two-launch slot with its fused decisions)
+        one_launch = (os.environ.get("GRAPHLILY_BFS_SHARD_STEP", "1") != "0" if sharded
+                      else os.environ.get("GRAPHLILY_BFS_ONE_LAUNCH", "1") != "0")
         rank, world = self.comm.rank, self.comm.world_size
         tally, tally_in = st.get("tally"), None
         if one_launch and getattr(self.comm, "emulated", False):
@@ -493,7 +495,8 @@ class BFS(_GraphApp):
                 capi.bfs_bits_shard_step(csc_plan, pull_plan, gathered[it], bits[it + 1], words, distance, float(it + 1), ctl, tally,
                                          tally_in, it, rank, world, st["col_len"], self.nnz_global_, threshold,
                                          may_of(it - 1) if it > 1 else 0, back)
-                self._exchange_bits(st, it + 1, it)
+                if sharded:
+                    self._exchange_bits(st, it + 1, it)
             capi.bfs_bits_shard_finish(csc_plan, pull_plan, ctl, tally, tally_in, N, rank, world, self.nnz_global_, threshold, may_of(N), back)
 
         def schedule():

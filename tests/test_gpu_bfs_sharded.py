@@ -111,20 +111,32 @@ def test_sharded_bfs_on_split_shard_plans(gpu, monkeypatch):
             assert np.array_equal(got, ref[r0:r1])
 
 
-def test_deferred_decisions_on_a_whole_matrix_plan_equal_the_fused_ones(gpu):
-    """One rank of a world of one: the steps run deferred and gl_bfs_bits_decide decides from the bit vector -- the same
-    distances, push iterations and per-slot counts as the decisions fused into the steps."""
+def test_one_launch_and_deferred_decisions_equal_the_fused_ones(gpu, monkeypatch):
+    """The three ways a slot's decisions are taken give the same distances, push iterations (first phase and after a pull
+    handed back) and per-slot counts: fused into the two steps of a slot (one GPU, GRAPHLILY_BFS_ONE_LAUNCH=0), replayed
+    from the tallies at the start of the next slot's single launch (the default, one GPU and a world of one), and by
+    gl_bfs_bits_decide from the gathered bit vector (GRAPHLILY_BFS_SHARD_STEP=0)."""
     g = datasets.rmat(80000, 2400000, seed=34, symmetric=True)
     src = int(np.argmax(np.diff(g.adj_indptr.astype(np.int64)) > 0))
     whole = _whole(g)
     for thr in (0.0005, 0.01, 0.2):
+        monkeypatch.setenv("GRAPHLILY_BFS_ONE_LAUNCH", "0")
         ref = whole.pull_push(src, 9, thr).copy()
-        pushes, again, counts = whole.push_iterations_, whole.push_iterations_again_, whole.bfs_slot_counts_.copy()
-        b = _rank(g, 0, 1, whole)
-        got = b.pull_push(src, 9, thr)
-        assert np.array_equal(got, ref)
-        assert (b.push_iterations_, b.push_iterations_again_) == (pushes, again)
-        assert np.array_equal(b.bfs_slot_counts_, counts)
+        pushes, again, counts, modes = whole.push_iterations_, whole.push_iterations_again_, whole.bfs_slot_counts_.copy(), whole.bfs_slot_modes_.copy()
+        monkeypatch.delenv("GRAPHLILY_BFS_ONE_LAUNCH")
+        for rep in range(3):                 # enqueued, captured, replayed
+            got = whole.pull_push(src, 9, thr)
+            assert np.array_equal(got, ref)
+            assert (whole.push_iterations_, whole.push_iterations_again_) == (pushes, again)
+            assert np.array_equal(whole.bfs_slot_counts_, counts) and np.array_equal(whole.bfs_slot_modes_, modes)
+        for shard_step in ("1", "0"):
+            monkeypatch.setenv("GRAPHLILY_BFS_SHARD_STEP", shard_step)
+            b = _rank(g, 0, 1, whole)
+            got = b.pull_push(src, 9, thr)
+            assert np.array_equal(got, ref)
+            assert (b.push_iterations_, b.push_iterations_again_) == (pushes, again)
+            assert np.array_equal(b.bfs_slot_counts_, counts)
+        monkeypatch.delenv("GRAPHLILY_BFS_SHARD_STEP")
 
 
 def test_three_launch_slots_still_serve_shards(gpu, monkeypatch):
