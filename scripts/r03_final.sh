@@ -10,6 +10,20 @@ grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" gpurun_out/r03_gput
 cp gpurun_out/fullsize_margins.jsonl gpurun_out/r03_fullsize_margins.jsonl
 timeout 900 python bench.py --emulate-rank 0/8,3/8,7/8,1/4,0/2 > gpurun_out/r03_bench_orkut_n1.json 2> gpurun_out/r03_bench_final.err
 echo "bench rc=$?"; cut -c1-1200 gpurun_out/r03_bench_orkut_n1.json
+# the same emulated ranks with three launches per slot (push step, pull step, gl_bfs_bits_decide), and the one-GPU BFS with
+# two launches per slot: same-box A/B of the one-launch slot
+GRAPHLILY_BFS_SHARD_STEP=0 GRAPHLILY_BFS_ONE_LAUNCH=0 timeout 900 python bench.py --emulate-rank 0/8,1/4,0/2 --no-cpu-baseline --no-pattern > gpurun_out/r03_bench_orkut_n1_three_launch_slots.json 2>> gpurun_out/r03_bench_final.err
+python - <<'PY'
+import json
+for f in ("gpurun_out/r03_bench_orkut_n1.json", "gpurun_out/r03_bench_orkut_n1_three_launch_slots.json"):
+    for l in open(f):
+        if l.startswith('{"metric'):
+            d = json.loads(l)
+            print(f, {k: d["bfs"][k]["ms"] for k in ("pull_push", "pull")}, [(e["rank"], e["world"], e["pull_push"]["schedule_ms"], e["pull"]["schedule_ms"]) for e in d.get("bfs_emulated_ranks", [])])
+PY
+timeout 300 python scripts/r03_shard_shape_sweep.py orkut 0/8 0x0,32x8,64x4,128x2,256x1 2>&1 | grep shape | tee gpurun_out/r03_shard_shape_sweep.txt
+mkdir -p build && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/ubench_sync.hip -o build/ubench_sync && build/ubench_sync | tee gpurun_out/r03_ubench_sync.txt
+for c in "hollywood 0.999" "ogbn_products 0.9995" "googleplus 0.999" "pokec 0.9995"; do set -- $c; for h in 1 0; do echo "== $1 $2 work hint $h"; GRAPHLILY_SPMSPV_WORK_HINT=$h python scripts/r03_spmspv_call_trace.py $1 $2 2>&1 | grep "blocking\|enqueued"; done; done | tee gpurun_out/r03_spmspv_call_hint_ab.txt
 timeout 1500 bash scripts/profile_bench.sh > gpurun_out/r03_profile.log 2>&1; tail -3 gpurun_out/r03_profile.log
 timeout 900 python benchmarks/bench_graphs.py --out gpurun_out/r03_six_graphs.jsonl 2>&1 | grep -v amdgpu.ids | cut -c1-260
 timeout 600 python benchmarks/run_reference_benches.py --graph orkut --apps bfs,pagerank,sssp 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_reference_benches_on_hip.txt

@@ -157,3 +157,29 @@ def test_three_launch_slots_still_serve_shards(gpu, monkeypatch):
                 r0, r1 = b.result_range_
                 assert np.array_equal(got, ref[r0:r1])
                 assert b.push_iterations_ == whole.push_iterations_
+
+
+def test_shard_step_refuses_what_it_cannot_run(gpu):
+    """gl_bfs_bits_shard_step fails loudly: a row plan without the bit layout, plans of different row ranges, a slot of 0."""
+    from graphlily_amd import module as M
+    g = datasets.rmat(20000, 300000, seed=35, symmetric=True)
+    whole = _whole(g)
+    src = int(np.argmax(np.diff(g.adj_indptr.astype(np.int64)) > 0))
+    whole.pull_push(src, 4, 0.01)
+    st = whole.bits_loop_
+    csc_plan, rows_plan = whole.SpMSpV_.plan_, whole.SpMV_.plan_
+    args = lambda rows, slot: (csc_plan, rows, st["bits"][1], st["bits"][2], st["words"], st["distance"], 2.0, st["ctl"], st["tally"], None,
+                               slot, 0, 1, st["col_len"], whole.nnz_global_, 0.01, 0, 1.0)
+    m = _prepared(g)
+    general = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, np.full(m.nnz, 0.5, np.float32), flags=capi.GL_PLAN_KEEP_VALUES)
+    with pytest.raises(capi.GraphLilyError, match="GL_PLAN_BOOLEAN"):
+        capi.bfs_bits_shard_step(*args(general, 1))
+    half = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, 0, m.num_rows // 128 * 64,
+                         flags=capi.GL_PLAN_BOOLEAN | capi.GL_PLAN_NO_MULADD)
+    with pytest.raises(capi.GraphLilyError):
+        capi.bfs_bits_shard_step(*args(half, 1))
+    with pytest.raises(capi.GraphLilyError):
+        capi.bfs_bits_shard_step(*args(rows_plan, 0))
+    # and the schedule still runs afterwards
+    ref = O.bfs(to_oracle(m), src, 4)
+    assert np.array_equal(whole.pull_push(src, 4, 0.01), ref)
