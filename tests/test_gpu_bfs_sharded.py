@@ -183,3 +183,29 @@ def test_shard_step_refuses_what_it_cannot_run(gpu):
     # and the schedule still runs afterwards
     ref = O.bfs(to_oracle(m), src, 4)
     assert np.array_equal(whole.pull_push(src, 4, 0.01), ref)
+
+
+def test_dense_frontiers_pushed_through_the_scatter_body(gpu, monkeypatch):
+    """The scattering push of the one-launch slot where it normally never goes: frontiers of thousands of vertices whose
+    columns all hold 129 ... 1023 entries (set aside for the whole workgroup; the list of 256 per workgroup overflows and the
+    wavefronts apply the rest themselves), never handed to the streaming pull (GRAPHLILY_BFS_HEAVY_DIV=0) nor to the
+    bottom-up scan (GRAPHLILY_BFS_BU_DIV=0), threshold above 1: every slot pushes.  One GPU and every rank of 2 and of 16
+    (16 ranks x 8 tally lines: the prologue's loop over more than 64 lines)."""
+    monkeypatch.setenv("GRAPHLILY_BFS_HEAVY_DIV", "0")
+    monkeypatch.setenv("GRAPHLILY_BFS_BU_DIV", "0")
+    g = datasets.uniform(20480, 200, seed=36)
+    src = 5
+    ref = O.bfs(to_oracle(_prepared(g)), src, 5)
+    whole = _whole(g)
+    for rep in range(3):
+        assert np.array_equal(whole.pull_push(src, 5, 2.0), ref)
+    assert whole.push_iterations_ == 4 and list(whole.bfs_slot_modes_[:3]) == [1, 1, 1]
+    for world in (2, 16):
+        for k in range(world):
+            b = _rank(g, k, world, whole, copy=(k % 2 == 0))
+            whole.pull_push(src, 5, 2.0)
+            got = b.pull_push(src, 5, 2.0)
+            r0, r1 = b.result_range_
+            assert np.array_equal(got, ref[r0:r1]), (world, k)
+            assert b.push_iterations_ == whole.push_iterations_
+            assert np.array_equal(b.bfs_slot_counts_, whole.bfs_slot_counts_)
