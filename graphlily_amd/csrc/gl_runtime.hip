@@ -183,6 +183,14 @@ __global__ void fill_f32_kernel(float *__restrict__ dst, float v, size_t n) {
     for (; i < n; i += stride) dst[i] = v;
 }
 
+// gl_levels_to_u8: BFS levels (floats holding integers 0 ... 255) as bytes, four per thread and store
+__global__ __launch_bounds__(256) void levels_to_u8_kernel(const float4 *__restrict__ src, uint32_t *__restrict__ dst, uint32_t n4) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        const float4 v = src[i];
+        dst[i] = ((uint32_t)v.x & 255u) | (((uint32_t)v.y & 255u) << 8) | (((uint32_t)v.z & 255u) << 16) | ((uint32_t)v.w << 24);
+    }
+}
+
 // gl_buf_d2h_async: device -> page-locked host memory by stores over PCIe (16 bytes per lane, grid-stride)
 __global__ __launch_bounds__(256) void copy_out_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
@@ -772,6 +780,43 @@ int gl_buf_d2h_async(void *h_dst, const void *d_src, size_t bytes) {
         (void)hipGetLastError();   // (a pageable destination: not an error, the plain copy below serves it)
     }
     GL_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, gl::ctx().stream));
+    return GL_OK;
+}
+
+int gl_levels_to_u8(const float *d_levels, uint8_t *d_bytes, uint32_t n) {
+    GL_REQUIRE_INIT();
+    if (n == 0) return GL_OK;
+    GL_ARG(d_levels != nullptr && d_bytes != nullptr && (n & 3u) == 0 && (((uintptr_t)d_levels | (uintptr_t)d_bytes) & 15u) == 0);
+    const uint32_t n4 = n / 4u;
+    const unsigned grid = std::min<unsigned>(gl::cdiv(n4, 256), (unsigned)gl::ctx().num_cus * 8u);
+    gl::levels_to_u8_kernel<<<grid, 256, 0, gl::ctx().stream>>>(reinterpret_cast<const float4 *>(d_levels), reinterpret_cast<uint32_t *>(d_bytes), n4);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// the host half: bytes -> floats on a few cores (a 12 MB result is 3 MB over PCIe and ~30 us of this).  gl_host_threads_warm
+// wakes the same threads up front -- call it between enqueueing the GPU work and waiting for it, so that the wake-up of a
+// sleeping OpenMP team (tens of microseconds) overlaps the kernels.
+static int host_expand_threads(size_t n) {
+    static const int hw = std::max(1, std::min(32, omp_get_num_procs() / 2));
+    return n >= (1u << 18) ? hw : (n >= (1u << 16) ? std::min(hw, 8) : 1);
+}
+
+int gl_host_threads_warm(void) {
+    const int nt = host_expand_threads(1u << 20);
+    (void)nt;
+    volatile int sink = 0;
+#pragma omp parallel num_threads(nt)
+    { sink = sink + 0; }
+    return GL_OK;
+}
+
+int gl_host_expand_u8_f32(float *h_dst, const uint8_t *h_src, size_t n) {
+    GL_ARG((h_dst != nullptr && h_src != nullptr) || n == 0);
+    const int nt = host_expand_threads(n);
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (long long i = 0; i < (long long)n; i++) h_dst[i] = (float)h_src[i];
     return GL_OK;
 }
 

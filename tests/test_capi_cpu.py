@@ -167,3 +167,18 @@ def test_host_helpers_need_no_gpu():
     capi.check(L.gl_host_pool_alloc(ctypes.byref(p), 5 << 20))
     assert p.value and p.value % (2 << 20) == 0, "large host blocks are 2 MB-aligned (huge-page advice)"
     capi.check(L.gl_host_pool_free(p))
+
+
+def test_host_expand_u8_f32():
+    """gl_host_expand_u8_f32 (the host half of the BFS byte read-back): every byte value, sizes on both sides of the
+    thread-count steps, an unaligned tail."""
+    rng = np.random.default_rng(9)
+    for n in (0, 1, 255, 70001, (1 << 18) + 13, 3 << 20):
+        src = rng.integers(0, 256, size=n, dtype=np.uint8)
+        if n >= 256:
+            src[:256] = np.arange(256, dtype=np.uint8)
+        dst = np.full(n + 3, -1.0, np.float32)
+        capi.host_expand_u8_f32(dst, src, n)
+        assert np.array_equal(dst[:n], src.astype(np.float32))
+        assert np.all(dst[n:] == -1.0)
+    capi.host_threads_warm()

@@ -386,3 +386,42 @@ def test_sssp_pull_push_device_loop_equals_host_loop(gpu, name, zero, monkeypatc
     assert len(seen) >= 3 and 1 in seen and (iters - 1) in seen, seen
     # another iteration count on the same object (buffers regrow, graphs are rebuilt)
     assert np.array_equal(dev.pull_push(0, 10, 0.01), O.sssp(_oracle_prepared(m, "sssp"), 0, 10, zero))
+
+
+def test_bfs_byte_read_back_equals_the_float_one(gpu, monkeypatch):
+    """BFS levels cross PCIe as bytes when they fit (gl_levels_to_u8 + gl_host_expand_u8_f32) and as floats otherwise
+    (GRAPHLILY_BFS_U8=0, or more than 254 iterations): the same vector either way, equal to the oracle."""
+    from graphlily_amd import app, datasets, io
+    from oracle import oracle as O
+    from helpers import to_oracle
+    g = datasets.rmat(70000, 1200000, seed=41, symmetric=True)
+    m = g.copy()
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    m.adj_data = np.ones(m.nnz, np.float32)
+    src = int(np.argmax(np.diff(g.adj_indptr.astype(np.int64)) > 0))
+    bfs = app.BFS(16, 0, 0, 0)
+    bfs.set_up_runtime()
+    bfs.load_and_format_matrix(g, True)
+    bfs.send_matrix_host_to_device()
+    ref = O.bfs(to_oracle(m), src, 7)
+    for u8 in ("1", "0", "1"):
+        monkeypatch.setenv("GRAPHLILY_BFS_U8", u8)
+        for _ in range(3):
+            got = bfs.pull_push(src, 7, 0.01)
+            assert got.dtype == np.float32 and np.array_equal(got, ref)
+            assert np.array_equal(bfs.pull(src, 7), ref)
+    # a line graph walked for 300 iterations: levels beyond a byte -- the float read-back serves them
+    n = 70016
+    line = io.CSRMatrix(n, n, np.ones(n - 1, np.float32), np.arange(n - 1, dtype=np.uint32),
+                        np.concatenate([[0], np.arange(n, dtype=np.uint32)]).astype(np.uint32))
+    monkeypatch.setenv("GRAPHLILY_BFS_U8", "1")
+    b2 = app.BFS(16, 0, 0, 0)
+    b2.set_up_runtime()
+    b2.load_and_format_matrix(line, True)
+    b2.send_matrix_host_to_device()
+    lm = line.copy()
+    io.util_round_csr_matrix_dim(lm, 128, 128)
+    ref2 = O.bfs(to_oracle(lm), 0, 300)
+    assert ref2.max() > 255
+    assert np.array_equal(b2.pull(0, 300), ref2)
+    assert np.array_equal(b2.pull(0, 200), O.bfs(to_oracle(lm), 0, 200))      # (and with bytes again)
