@@ -544,24 +544,26 @@ class BFS(_GraphApp):
         lo, hi = (self.r0_, self.r1_) if sliced else (0, n)
         if sharded and not sliced:
             self.comm.all_gather_slices(st["both"].tensor[:n] if st["both"].tensor is not None else st["both"], self.bounds_)
-        # Levels are small integers: when they fit a byte (N + 1 <= 255) the result crosses PCIe as BYTES -- 3 MB instead of
-        # 12 MB on orkut, 55 us instead of 225 -- and a few host threads turn them into the floats the caller gets (woken while
-        # the GPU is still busy).  GRAPHLILY_BFS_U8=0: the floats themselves.
+        # Levels are small integers: when they fit a byte (N + 1 <= 255; a nibble up to 14 iterations) the result crosses PCIe
+        # PACKED -- 1.5 or 3 MB instead of 12 MB on orkut, 28 or 55 us instead of 225, the control words behind them in the
+        # same copy -- and a few host threads turn them into the floats the caller gets (woken while the GPU is still busy).
+        # GRAPHLILY_BFS_U8=0: the floats themselves.
         own = hi - lo
-        as_bytes = (N + 1 <= 255 and own % 4 == 0 and lo % 4 == 0 and own >= (1 << 16)
+        bits = 4 if N + 1 <= 15 else 8
+        as_bytes = (N + 1 <= 255 and own % 8 == 0 and lo % 4 == 0 and own >= (1 << 16)
                     and os.environ.get("GRAPHLILY_BFS_U8", "1") != "0")
         if as_bytes:
-            if st.get("lev8_n") != own:
-                st["lev8"], st["lev8_n"] = capi.DeviceBuffer(own), own
-                st["h8"], st["hc"] = capi.pinned_empty(own, np.uint8), capi.pinned_empty(cw, np.uint32)
-            capi.levels_to_u8(B.view(distance, lo, own, 4), st["lev8"], own)
+            pw = capi.levels_packed_words(own, bits)
+            if st.get("lev8_key") != (own, bits):
+                st["lev8"], st["lev8_key"] = capi.DeviceBuffer(4 * (pw + cw)), (own, bits)
+                st["h8"] = capi.pinned_empty(4 * (pw + cw), np.uint8)
+            capi.levels_pack(B.view(distance, lo, own, 4), own, bits, ctl, cw, st["lev8"])   # (levels, then the control words)
             st["lev8"].read_async(st["h8"])
-            ctl.read_async(st["hc"])
             res = capi.pinned_recycled(own, np.float32)       # (recycled: already paged in)
             capi.host_threads_warm()
             B.sync()
-            capi.host_expand_u8_f32(res, st["h8"], own)
-            c = st["hc"].copy()
+            capi.host_levels_unpack(res, st["h8"], own, bits)
+            c = st["h8"][4 * pw:].view(np.uint32).copy()
         else:
             # the distances (this rank's slice of them) + the control words: two copies behind the schedule, one wait
             out = capi.pinned_recycled(own + cw, np.float32)

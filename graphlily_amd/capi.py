@@ -33,7 +33,7 @@ EXPORTS = [
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
     "gl_bfs_bits_begin", "gl_bfs_bits_push_step", "gl_bfs_bits_pull_step", "gl_bfs_bits_decide",
     "gl_bfs_bits_shard_step", "gl_bfs_bits_shard_finish", "gl_dist_all_gather_bits_tally",
-    "gl_buf_d2h_async", "gl_levels_to_u8", "gl_host_expand_u8_f32", "gl_host_threads_warm",
+    "gl_buf_d2h_async", "gl_levels_pack", "gl_host_levels_unpack", "gl_host_threads_warm",
     "gl_sssp_begin", "gl_assign_sparse_new_frontier_gated", "gl_spmv_run_flagged", "gl_ewise_add_flagged",
     "gl_bfs_begin", "gl_spmspv_plan_frontier_bits", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
     "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32", "gl_dist_all_gather_bits",
@@ -85,7 +85,7 @@ def lib():
         "gl_bfs_begin": [vp, vp, u32, vp, vp, u32],
         "gl_bfs_bits_begin": [vp, u32, vp, u32, vp, u32, u32, u32],
         "gl_buf_d2h_async": [vp, vp, ctypes.c_size_t],
-        "gl_levels_to_u8": [vp, vp, u32], "gl_host_expand_u8_f32": [vp, vp, ctypes.c_size_t], "gl_host_threads_warm": [],
+        "gl_levels_pack": [vp, u32, i32, vp, u32, vp], "gl_host_levels_unpack": [vp, vp, ctypes.c_size_t, i32], "gl_host_threads_warm": [],
         "gl_bfs_bits_push_step": [vp, vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
         "gl_bfs_bits_pull_step": [vp, vp, vp, vp, vp, f32, vp, u32, f32, i32, f32],
         "gl_bfs_bits_decide": [vp, vp, vp, vp, u64, vp, u32, f32, i32, f32],
@@ -686,15 +686,20 @@ def bfs_bits_shard_finish(csc_plan, rows_plan, ctl, tally, tally_in, last_slot, 
                                          int(may_continue_last), float(back_threshold)))
 
 
-def levels_to_u8(levels, out_bytes, n):
-    """gl_levels_to_u8: n float levels (integers 0 ... 255) -> n bytes, on the device."""
-    check(lib().gl_levels_to_u8(_p(levels), _p(out_bytes), int(n)))
+def levels_pack(levels, n, bits, tail, tail_words, out):
+    """gl_levels_pack: n float levels (small integers) -> bytes (bits 8) or nibbles (bits 4) + `tail_words` raw words of `tail`."""
+    check(lib().gl_levels_pack(_p(levels), int(n), int(bits), _p(tail), int(tail_words), _p(out)))
 
 
-def host_expand_u8_f32(dst, src, n):
-    """gl_host_expand_u8_f32: dst[:n] (float32 array) = src[:n] (uint8 array), on a few host threads."""
-    assert dst.dtype == np.float32 and src.dtype == np.uint8 and dst.shape[0] >= n and src.shape[0] >= n
-    check(lib().gl_host_expand_u8_f32(_np_ptr(dst), _np_ptr(src), int(n)))
+def levels_packed_words(n, bits):
+    """32-bit words of n packed levels, rounded up to the 16-byte boundary the tail starts on"""
+    return (n // (32 // bits) + 3) & ~3
+
+
+def host_levels_unpack(dst, src, n, bits):
+    """gl_host_levels_unpack: dst[:n] (float32 array) = the levels packed in src (uint8 array), on a few host threads."""
+    assert dst.dtype == np.float32 and src.dtype == np.uint8 and dst.shape[0] >= n and src.shape[0] * (8 // bits) >= n
+    check(lib().gl_host_levels_unpack(_np_ptr(dst), _np_ptr(src), int(n), int(bits)))
 
 
 def host_threads_warm():

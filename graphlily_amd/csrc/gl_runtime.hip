@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <omp.h>
+#include <emmintrin.h>
 #include <sys/mman.h>
 #include <cstdlib>
 #include <cstring>
@@ -183,12 +184,24 @@ __global__ void fill_f32_kernel(float *__restrict__ dst, float v, size_t n) {
     for (; i < n; i += stride) dst[i] = v;
 }
 
-// gl_levels_to_u8: BFS levels (floats holding integers 0 ... 255) as bytes, four per thread and store
-__global__ __launch_bounds__(256) void levels_to_u8_kernel(const float4 *__restrict__ src, uint32_t *__restrict__ dst, uint32_t n4) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
-        const float4 v = src[i];
-        dst[i] = ((uint32_t)v.x & 255u) | (((uint32_t)v.y & 255u) << 8) | (((uint32_t)v.z & 255u) << 16) | ((uint32_t)v.w << 24);
+// gl_levels_pack: BFS levels (floats holding small integers) as bytes or nibbles, one 32-bit word per thread and store
+// (BITS = 8: 4 levels per word, BITS = 4: 8 levels); workgroup 0 also copies `tail_words` raw words behind the packed levels
+template <int BITS>
+__global__ __launch_bounds__(256) void levels_pack_kernel(const float4 *__restrict__ src, uint32_t *__restrict__ dst, uint32_t nwords,
+                                                          const uint32_t *__restrict__ tail, uint32_t tail_words, uint32_t tail_at) {
+    constexpr uint32_t M = (1u << BITS) - 1u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nwords; i += gridDim.x * 256u) {
+        if (BITS == 8) {
+            const float4 v = src[i];
+            dst[i] = ((uint32_t)v.x & M) | (((uint32_t)v.y & M) << 8) | (((uint32_t)v.z & M) << 16) | (((uint32_t)v.w & M) << 24);
+        } else {
+            const float4 v = src[2u * i], w = src[2u * i + 1u];
+            dst[i] = ((uint32_t)v.x & M) | (((uint32_t)v.y & M) << 4) | (((uint32_t)v.z & M) << 8) | (((uint32_t)v.w & M) << 12) |
+                     (((uint32_t)w.x & M) << 16) | (((uint32_t)w.y & M) << 20) | (((uint32_t)w.z & M) << 24) | (((uint32_t)w.w & M) << 28);
+        }
     }
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < tail_words; i += 256u) dst[tail_at + i] = tail[i];
 }
 
 // gl_buf_d2h_async: device -> page-locked host memory by stores over PCIe (16 bytes per lane, grid-stride)
@@ -783,20 +796,26 @@ int gl_buf_d2h_async(void *h_dst, const void *d_src, size_t bytes) {
     return GL_OK;
 }
 
-int gl_levels_to_u8(const float *d_levels, uint8_t *d_bytes, uint32_t n) {
+int gl_levels_pack(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *d_out) {
     GL_REQUIRE_INIT();
-    if (n == 0) return GL_OK;
-    GL_ARG(d_levels != nullptr && d_bytes != nullptr && (n & 3u) == 0 && (((uintptr_t)d_levels | (uintptr_t)d_bytes) & 15u) == 0);
-    const uint32_t n4 = n / 4u;
-    const unsigned grid = std::min<unsigned>(gl::cdiv(n4, 256), (unsigned)gl::ctx().num_cus * 8u);
-    gl::levels_to_u8_kernel<<<grid, 256, 0, gl::ctx().stream>>>(reinterpret_cast<const float4 *>(d_levels), reinterpret_cast<uint32_t *>(d_bytes), n4);
+    GL_ARG(d_levels != nullptr && d_out != nullptr && (bits == 4 || bits == 8) && (n & 7u) == 0);
+    GL_ARG((((uintptr_t)d_levels | (uintptr_t)d_out) & 15u) == 0 && (tail_words == 0 || d_tail != nullptr));
+    const uint32_t nwords = n / (32u / (uint32_t)bits);
+    const uint32_t tail_at = (nwords + 3u) & ~3u;      // (the tail starts on a 16-byte boundary)
+    const unsigned grid = std::max(1u, std::min<unsigned>(gl::cdiv(nwords, 256), (unsigned)gl::ctx().num_cus * 8u));
+    if (bits == 8)
+        gl::levels_pack_kernel<8><<<grid, 256, 0, gl::ctx().stream>>>(reinterpret_cast<const float4 *>(d_levels), static_cast<uint32_t *>(d_out),
+                                                                      nwords, d_tail, tail_words, tail_at);
+    else
+        gl::levels_pack_kernel<4><<<grid, 256, 0, gl::ctx().stream>>>(reinterpret_cast<const float4 *>(d_levels), static_cast<uint32_t *>(d_out),
+                                                                      nwords, d_tail, tail_words, tail_at);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
 
-// the host half: bytes -> floats on a few cores (a 12 MB result is 3 MB over PCIe and ~30 us of this).  gl_host_threads_warm
-// wakes the same threads up front -- call it between enqueueing the GPU work and waiting for it, so that the wake-up of a
-// sleeping OpenMP team (tens of microseconds) overlaps the kernels.
+// the host half: packed levels -> floats on a few cores (a 12 MB result is 1.5 or 3 MB over PCIe and ~30 us of this).
+// gl_host_threads_warm wakes the same threads up front -- call it between enqueueing the GPU work and waiting for it, so
+// that the wake-up of a sleeping OpenMP team (tens of microseconds) overlaps the kernels.
 static int host_expand_threads(size_t n) {
     static const int hw = std::max(1, std::min(32, omp_get_num_procs() / 2));
     return n >= (1u << 18) ? hw : (n >= (1u << 16) ? std::min(hw, 8) : 1);
@@ -811,12 +830,46 @@ int gl_host_threads_warm(void) {
     return GL_OK;
 }
 
-int gl_host_expand_u8_f32(float *h_dst, const uint8_t *h_src, size_t n) {
-    GL_ARG((h_dst != nullptr && h_src != nullptr) || n == 0);
+// 16 level bytes -> 16 floats, written past the caches (the caller reads them later, if at all: no read-for-ownership)
+static inline void expand16_stream(const __m128i v, float *dst) {
+    const __m128i z = _mm_setzero_si128();
+    const __m128i lo = _mm_unpacklo_epi8(v, z), hi = _mm_unpackhi_epi8(v, z);
+    _mm_stream_ps(dst, _mm_cvtepi32_ps(_mm_unpacklo_epi16(lo, z)));
+    _mm_stream_ps(dst + 4, _mm_cvtepi32_ps(_mm_unpackhi_epi16(lo, z)));
+    _mm_stream_ps(dst + 8, _mm_cvtepi32_ps(_mm_unpacklo_epi16(hi, z)));
+    _mm_stream_ps(dst + 12, _mm_cvtepi32_ps(_mm_unpackhi_epi16(hi, z)));
+}
+
+int gl_host_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits) {
+    GL_ARG(((h_dst != nullptr && h_src != nullptr) || n == 0) && (bits == 4 || bits == 8) && (bits == 8 || (n & 1u) == 0));
     const int nt = host_expand_threads(n);
     (void)nt;
-#pragma omp parallel for num_threads(nt) schedule(static)
-    for (long long i = 0; i < (long long)n; i++) h_dst[i] = (float)h_src[i];
+    const uint8_t *src = static_cast<const uint8_t *>(h_src);
+    // blocks of 32 levels (16 or 32 source bytes) through SSE2 -- the x86-64 baseline -- when the destination allows aligned
+    // streaming stores; the rest (and any other destination) by the plain loop
+    const size_t nblk = (((uintptr_t)h_dst & 15u) == 0) ? n / 32u : 0u;
+#pragma omp parallel num_threads(nt)
+    {
+        const size_t T = (size_t)omp_get_num_threads(), t = (size_t)omp_get_thread_num();
+        const size_t b0 = nblk * t / T, b1 = nblk * (t + 1) / T;
+        if (bits == 8) {
+            for (size_t b = b0; b < b1; b++) {
+                expand16_stream(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b)), h_dst + 32u * b);
+                expand16_stream(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b + 16u)), h_dst + 32u * b + 16u);
+            }
+        } else {
+            const __m128i m = _mm_set1_epi8(0x0f);
+            for (size_t b = b0; b < b1; b++) {
+                const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 16u * b));
+                const __m128i lo = _mm_and_si128(v, m), hi = _mm_and_si128(_mm_srli_epi16(v, 4), m);
+                expand16_stream(_mm_unpacklo_epi8(lo, hi), h_dst + 32u * b);          // levels 0 ... 15 of the block, in order
+                expand16_stream(_mm_unpackhi_epi8(lo, hi), h_dst + 32u * b + 16u);
+            }
+        }
+        _mm_sfence();
+    }
+    for (size_t i = nblk * 32u; i < n; i++)
+        h_dst[i] = bits == 8 ? (float)src[i] : (float)((src[i / 2u] >> (4u * (i & 1u))) & 15u);
     return GL_OK;
 }
 

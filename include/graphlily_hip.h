@@ -86,13 +86,15 @@ int gl_buf_d2h(void *h_dst, const void *d_src, size_t bytes);   /* blocking */
 /* the same copy enqueued on the library stream without waiting (h_dst page-locked, gl_host_alloc: it then runs behind the
  * kernels already enqueued, with no host round trip in between; gl_sync before h_dst is read) */
 int gl_buf_d2h_async(void *h_dst, const void *d_src, size_t bytes);
-/* A BFS result (levels: floats holding integers 0 ... 255) read back as BYTES: gl_levels_to_u8 packs n levels (n a multiple of
- * 4, 16-byte aligned buffers) on the device, the caller copies n bytes instead of 4 n over PCIe and gl_host_expand_u8_f32
- * turns them into the floats the reference's send_*_device_to_host returns, on a few host threads.  gl_host_threads_warm wakes
- * those threads: call it between enqueueing the GPU work and waiting for it.  (12 MB of levels: 225 us of PCIe become ~55 us
- * + ~30 us; values outside 0 ... 255 do not survive -- the drivers use this only when the level count allows.) */
-int gl_levels_to_u8(const float *d_levels, uint8_t *d_bytes, uint32_t n);
-int gl_host_expand_u8_f32(float *h_dst, const uint8_t *h_src, size_t n);
+/* A BFS result (levels: floats holding small integers) read back PACKED: gl_levels_pack writes n levels (n a multiple of 8,
+ * 16-byte aligned buffers) as bytes (bits = 8: levels 0 ... 255) or nibbles (bits = 4: 0 ... 15) into d_out, followed -- on the
+ * next 16-byte boundary -- by tail_words raw words of d_tail (the schedule's control words: one read-back fetches both);
+ * the caller copies n * bits / 8 bytes instead of 4 n over PCIe and gl_host_levels_unpack turns them into the floats the
+ * reference's send_*_device_to_host returns, on a few host threads.  gl_host_threads_warm wakes those threads: call it
+ * between enqueueing the GPU work and waiting for it.  (12 MB of levels: 225 us of PCIe become 28 - 55 us + ~30 us of host
+ * work; larger values do not survive -- the drivers use this only when the iteration count allows.) */
+int gl_levels_pack(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *d_out);
+int gl_host_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits);
 int gl_host_threads_warm(void);
 int gl_buf_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async    */
 int gl_buf_fill_f32(float *d_dst, float value, size_t count);   /* async    */

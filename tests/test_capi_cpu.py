@@ -169,16 +169,18 @@ def test_host_helpers_need_no_gpu():
     capi.check(L.gl_host_pool_free(p))
 
 
-def test_host_expand_u8_f32():
-    """gl_host_expand_u8_f32 (the host half of the BFS byte read-back): every byte value, sizes on both sides of the
-    thread-count steps, an unaligned tail."""
+def test_host_levels_unpack():
+    """gl_host_levels_unpack (the host half of the BFS packed read-back): every byte / nibble value, sizes on both sides of
+    the thread-count steps, nothing written past n."""
     rng = np.random.default_rng(9)
-    for n in (0, 1, 255, 70001, (1 << 18) + 13, 3 << 20):
-        src = rng.integers(0, 256, size=n, dtype=np.uint8)
-        if n >= 256:
-            src[:256] = np.arange(256, dtype=np.uint8)
-        dst = np.full(n + 3, -1.0, np.float32)
-        capi.host_expand_u8_f32(dst, src, n)
-        assert np.array_equal(dst[:n], src.astype(np.float32))
-        assert np.all(dst[n:] == -1.0)
+    for n in (0, 8, 256, 70000, (1 << 18) + 16, 3 << 20):
+        for bits in (8, 4):
+            lev = rng.integers(0, 1 << bits, size=n, dtype=np.uint8)
+            if n >= 256:
+                lev[:256] = np.arange(256, dtype=np.uint16) % (1 << bits)
+            src = lev if bits == 8 else (lev[0::2] | (lev[1::2] << 4)).astype(np.uint8)
+            dst = np.full(n + 3, -1.0, np.float32)
+            capi.host_levels_unpack(dst, np.ascontiguousarray(src), n, bits)
+            assert np.array_equal(dst[:n], lev.astype(np.float32)), (n, bits)
+            assert np.all(dst[n:] == -1.0)
     capi.host_threads_warm()
