@@ -401,8 +401,9 @@ class BFS(_GraphApp):
                 else:
                     self.SpMV_.bfs_pull_step_gated(bits[cur], bits[nxt], distance, float(it + 1), ctl, it, capi.GL_GATE_LE)
 
-        st["src"][0] = source
-        B.upload(B.view(ctl, 2, 1, 4), st["src"])        # ctl[2] = source: the one host->device word per run
+        # ctl[2] = source: the one host->device word per run -- as a one-word fill launch in front of the schedule (a blocking
+        # 4-byte copy costs the host ~15 us)
+        capi.fill_u32_gated(B.view(ctl, 2, 1, 4), int(source), 1, None, 0)
         key = (num_iterations, float(threshold), back)
         use_graph = os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0"
         g = st["graphs"].get(key)
@@ -516,8 +517,7 @@ class BFS(_GraphApp):
                     capi.bfs_bits_decide(csc_plan, gathered[it + 1], st["col_len"], st["row_len"], self.nnz_global_, ctl, it, threshold,
                                          may, back)
 
-        st["src"][0] = source
-        B.upload(B.view(ctl, 2, 1, 4), st["src"])        # ctl[2] = source: the one host->device word per run
+        capi.fill_u32_gated(B.view(ctl, 2, 1, 4), int(source), 1, None, 0)   # ctl[2] = source (see _pull_push_device)
         key = (N, float(threshold), back, pull_only, one_launch)
         g = st["graphs"].get(key)
         # (a torch.distributed collective is not recorded by the library's capture: those runs are enqueued call by call)
@@ -913,8 +913,7 @@ class SSSP(_GraphApp):
                     plan.run_flagged(distance, None, results, sem.op, sem.zero, M.kNoMask, st["flags"][it])
                     capi.ewise_add_flagged(results, distance, n, 0.0, st["flags"][it])
 
-        st["src"][0] = source
-        B.upload(B.view(ctl, 2, 1, 4), st["src"])        # ctl[2] = source: the one host->device word per run
+        capi.fill_u32_gated(B.view(ctl, 2, 1, 4), int(source), 1, None, 0)   # ctl[2] = source (see _pull_push_device)
         self.SpMSpV_.bind_mask_buf(distance)
         key = (N, float(threshold))
         g = st["graphs"].get(key)
