@@ -517,8 +517,33 @@ class BFS(_GraphApp):
                     capi.bfs_bits_decide(csc_plan, gathered[it + 1], st["col_len"], st["row_len"], self.nnz_global_, ctl, it, threshold,
                                          may, back)
 
+        # Levels are small integers: when they fit a byte (N + 1 <= 255; a nibble up to 14 iterations) the result crosses PCIe
+        # PACKED -- 1.5 or 3 MB instead of 12 MB on orkut, 28 or 55 us instead of 225, the control words behind them in the
+        # same copy -- and a few host threads turn them into the floats the caller gets (woken while the GPU is still busy).
+        # GRAPHLILY_BFS_U8=0: the floats themselves.  The pack and the copy kernel are part of the recorded schedule (fixed
+        # buffers) unless the bench wants the schedule's GPU time alone, or the distances are all-gathered first.
+        cw = st["ctl_words"]
+        timed = getattr(self, "time_schedule_", False)      # bench: GPU time of the schedule without the read-back
+        sliced = sharded and not getattr(self, "gather_result_", True)
+        lo, hi = (self.r0_, self.r1_) if sliced else (0, n)
+        own = hi - lo
+        pbits = 4 if N + 1 <= 15 else 8
+        as_bytes = (N + 1 <= 255 and own % 8 == 0 and lo % 4 == 0 and own >= (1 << 16)
+                    and os.environ.get("GRAPHLILY_BFS_U8", "1") != "0")
+        in_graph = as_bytes and not timed and (sliced or not sharded)
+        if as_bytes:
+            pw = capi.levels_packed_words(own, pbits)
+            if st.get("lev8_key") != (own, pbits):
+                st["lev8"], st["lev8_key"] = capi.DeviceBuffer(4 * (pw + cw)), (own, pbits)
+                st["h8"] = capi.pinned_empty(4 * (pw + cw), np.uint8)
+                st["graphs"] = {k: v for k, v in st["graphs"].items() if not k[5]}   # (graphs that recorded the old buffers)
+
+        def packed_read_back():
+            capi.levels_pack(B.view(distance, lo, own, 4), own, pbits, ctl, cw, st["lev8"])   # (levels, then the control words)
+            st["lev8"].read_async(st["h8"])
+
         capi.fill_u32_gated(B.view(ctl, 2, 1, 4), int(source), 1, None, 0)   # ctl[2] = source (see _pull_push_device)
-        key = (N, float(threshold), back, pull_only, one_launch)
+        key = (N, float(threshold), back, pull_only, one_launch, in_graph, lo, own)
         g = st["graphs"].get(key)
         # (a torch.distributed collective is not recorded by the library's capture: those runs are enqueued call by call)
         capturable = not sharded or getattr(self.comm, "capturable", False)
@@ -526,10 +551,11 @@ class BFS(_GraphApp):
             try:
                 with capi.Graph.capture() as g:
                     schedule()
+                    if in_graph:
+                        packed_read_back()
                 st["graphs"][key] = g
             except capi.GraphLilyError:
                 g = st["graphs"][key] = False              # capture not possible here: keep enqueueing
-        timed = getattr(self, "time_schedule_", False)      # bench: GPU time of the schedule without the read-back
         if timed:
             capi.span_begin()
         if g:
@@ -539,30 +565,15 @@ class BFS(_GraphApp):
             st["warm"].add(key)
         if timed:
             self.schedule_ms_ = capi.span_end()
-        cw = st["ctl_words"]
-        sliced = sharded and not getattr(self, "gather_result_", True)
-        lo, hi = (self.r0_, self.r1_) if sliced else (0, n)
         if sharded and not sliced:
             self.comm.all_gather_slices(st["both"].tensor[:n] if st["both"].tensor is not None else st["both"], self.bounds_)
-        # Levels are small integers: when they fit a byte (N + 1 <= 255; a nibble up to 14 iterations) the result crosses PCIe
-        # PACKED -- 1.5 or 3 MB instead of 12 MB on orkut, 28 or 55 us instead of 225, the control words behind them in the
-        # same copy -- and a few host threads turn them into the floats the caller gets (woken while the GPU is still busy).
-        # GRAPHLILY_BFS_U8=0: the floats themselves.
-        own = hi - lo
-        bits = 4 if N + 1 <= 15 else 8
-        as_bytes = (N + 1 <= 255 and own % 8 == 0 and lo % 4 == 0 and own >= (1 << 16)
-                    and os.environ.get("GRAPHLILY_BFS_U8", "1") != "0")
         if as_bytes:
-            pw = capi.levels_packed_words(own, bits)
-            if st.get("lev8_key") != (own, bits):
-                st["lev8"], st["lev8_key"] = capi.DeviceBuffer(4 * (pw + cw)), (own, bits)
-                st["h8"] = capi.pinned_empty(4 * (pw + cw), np.uint8)
-            capi.levels_pack(B.view(distance, lo, own, 4), own, bits, ctl, cw, st["lev8"])   # (levels, then the control words)
-            st["lev8"].read_async(st["h8"])
+            if not (g and in_graph):
+                packed_read_back()
             res = capi.pinned_recycled(own, np.float32)       # (recycled: already paged in)
             capi.host_threads_warm()
             B.sync()
-            capi.host_levels_unpack(res, st["h8"], own, bits)
+            capi.host_levels_unpack(res, st["h8"], own, pbits)
             c = st["h8"][4 * pw:].view(np.uint32).copy()
         else:
             # the distances (this rank's slice of them) + the control words: two copies behind the schedule, one wait

@@ -369,6 +369,9 @@ class SpMVPlan:
         self.indptr = self.indices = self.data = None
 
     def info(self):
+        cached = getattr(self, "_info", None)      # (a plan never changes: the drivers ask on every call)
+        if cached is not None:
+            return dict(cached)
         nnz, nbytes, ntiles = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint32(0)
         check(lib().gl_spmv_plan_info(ctypes.c_void_p(self.handle), ctypes.byref(nnz), ctypes.byref(nbytes),
                                       ctypes.byref(ntiles)))
@@ -382,11 +385,12 @@ class SpMVPlan:
         check(lib().gl_spmv_plan_layout(ctypes.c_void_p(self.handle), ctypes.byref(lay)))
         hm, pc = ctypes.c_int(0), ctypes.c_uint32(0)
         check(lib().gl_spmv_plan_helper(ctypes.c_void_p(self.handle), ctypes.byref(hm), ctypes.byref(pc)))
-        return {"helper": ("gather", "spread", "self-hot", "none")[hm.value], "packed_columns": pc.value,
-                "nnz": nnz.value, "device_bytes": nbytes.value, "num_units": ntiles.value, "blocks": b.value,
-                "segments": sg.value, "max_block_rows": mr.value, "groups": g.value,
-                "hot_columns": hc.value, "hot_nnz": hn.value, "mix": mix.value,
-                "layout": ("general", "pattern", "boolean", "reference-order")[lay.value]}
+        self._info = {"helper": ("gather", "spread", "self-hot", "none")[hm.value], "packed_columns": pc.value,
+                      "nnz": nnz.value, "device_bytes": nbytes.value, "num_units": ntiles.value, "blocks": b.value,
+                      "segments": sg.value, "max_block_rows": mr.value, "groups": g.value,
+                      "hot_columns": hc.value, "hot_nnz": hn.value, "mix": mix.value,
+                      "layout": ("general", "pattern", "boolean", "reference-order")[lay.value]}
+        return dict(self._info)
 
     def run(self, x, mask, y, op, zero, mask_type):
         check(lib().gl_spmv_run(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero),
