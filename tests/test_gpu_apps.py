@@ -242,7 +242,8 @@ def test_bfs_pull_push_device_loop_equals_host_loop(gpu, name, bits, monkeypatch
                 assert bfs.push_iterations_ == pushes, "thr %g src %d: device %d vs host %d push iterations" % (
                     thr, src, pushes, bfs.push_iterations_)
     state = bfs.bits_loop_ if bits == "1" else bfs.dev_loop_
-    assert any(state["graphs"].values()), "the schedule was captured as a graph"
+    if os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0":
+        assert any(state["graphs"].values()), "the schedule was captured as a graph"
 
 
 @pytest.mark.parametrize("bits", ["1", "0"])
