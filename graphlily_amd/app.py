@@ -571,9 +571,7 @@ class BFS(_GraphApp):
             if not (g and in_graph):
                 packed_read_back()
             res = capi.pinned_recycled(own, np.float32)       # (recycled: already paged in)
-            capi.host_threads_warm()
-            B.sync()
-            capi.host_levels_unpack(res, st["h8"], own, pbits)
+            capi.sync_levels_unpack(res, st["h8"], own, pbits)   # (the host threads start now and spin until the stream is done)
             c = st["h8"][4 * pw:].view(np.uint32).copy()
         else:
             # the distances (this rank's slice of them) + the control words: two copies behind the schedule, one wait

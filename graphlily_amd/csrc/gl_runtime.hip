@@ -204,6 +204,31 @@ __global__ __launch_bounds__(256) void levels_pack_kernel(const float4 *__restri
         for (uint32_t i = threadIdx.x; i < tail_words; i += 256u) dst[tail_at + i] = tail[i];
 }
 
+// gl_buf_d2h_levels: the same packing for a buffer that is only EXPECTED to hold small integers -- every value is checked
+// (a non-negative integer no larger than the field allows), a violation raises flag[0] and the caller falls back to the floats
+template <int BITS>
+__global__ __launch_bounds__(256) void levels_pack_checked_kernel(const float4 *__restrict__ src, uint32_t *__restrict__ dst, uint32_t nwords,
+                                                                  uint32_t *__restrict__ flag) {
+    constexpr uint32_t M = (1u << BITS) - 1u;
+    bool bad = false;
+    auto field = [&](float v) -> uint32_t {
+        const uint32_t u = v >= 0.0f && v <= (float)M ? (uint32_t)v : 0u;
+        bad = bad || __float_as_uint((float)u) != __float_as_uint(v);   // (bit for bit: -0.0 is not a level either)
+        return u;
+    };
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nwords; i += gridDim.x * 256u) {
+        if (BITS == 8) {
+            const float4 v = src[i];
+            dst[i] = field(v.x) | (field(v.y) << 8) | (field(v.z) << 16) | (field(v.w) << 24);
+        } else {
+            const float4 v = src[2u * i], w = src[2u * i + 1u];
+            dst[i] = field(v.x) | (field(v.y) << 4) | (field(v.z) << 8) | (field(v.w) << 12) | (field(w.x) << 16) | (field(w.y) << 20) |
+                     (field(w.z) << 24) | (field(w.w) << 28);
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63u) == 0u) flag[0] = 1u;
+}
+
 // gl_buf_d2h_async: device -> page-locked host memory by stores over PCIe (16 bytes per lane, grid-stride)
 __global__ __launch_bounds__(256) void copy_out_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
@@ -842,19 +867,33 @@ static inline void expand16_stream(const __m128i v, float *dst) {
     _mm_stream_ps(dst + 12, _mm_cvtepi32_ps(_mm_unpackhi_epi16(hi, z)));
 }
 
-int gl_host_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits) {
-    GL_ARG(((h_dst != nullptr && h_src != nullptr) || n == 0) && (bits == 4 || bits == 8) && (bits == 8 || (n & 1u) == 0));
+// wait_stream: the team is started FIRST and its master waits for the library's stream while the other threads spin on a
+// flag -- a team woken before the wait has gone back to sleep by the time a 0.3 ms schedule ends (measured in the reference's
+// bench_bfs: 187 us for the unpack of 12 MB instead of ~55), one woken after it costs its wake-up in full
+static int levels_unpack_impl(float *h_dst, const void *h_src, size_t n, int bits, bool wait_stream) {
     const int nt = host_expand_threads(n);
     (void)nt;
     const uint8_t *src = static_cast<const uint8_t *>(h_src);
+    int ready = wait_stream ? 0 : 1;
+    hipError_t waited = hipSuccess;
     // blocks of 32 levels (16 or 32 source bytes) through SSE2 -- the x86-64 baseline -- when the destination allows aligned
     // streaming stores; the rest (and any other destination) by the plain loop
     const size_t nblk = (((uintptr_t)h_dst & 15u) == 0) ? n / 32u : 0u;
 #pragma omp parallel num_threads(nt)
     {
         const size_t T = (size_t)omp_get_num_threads(), t = (size_t)omp_get_thread_num();
+        if (wait_stream) {
+            if (t == 0) {
+                waited = hipStreamSynchronize(gl::ctx().stream);
+                __atomic_store_n(&ready, 1, __ATOMIC_RELEASE);
+            } else {
+                while (!__atomic_load_n(&ready, __ATOMIC_ACQUIRE)) _mm_pause();
+            }
+        }
         const size_t b0 = nblk * t / T, b1 = nblk * (t + 1) / T;
-        if (bits == 8) {
+        if (waited != hipSuccess) {
+            // (nothing to unpack: the error is reported below)
+        } else if (bits == 8) {
             for (size_t b = b0; b < b1; b++) {
                 expand16_stream(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b)), h_dst + 32u * b);
                 expand16_stream(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b + 16u)), h_dst + 32u * b + 16u);
@@ -870,8 +909,75 @@ int gl_host_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits) {
         }
         _mm_sfence();
     }
+    if (waited != hipSuccess) return gl::set_error(GL_ERR_HIP, "gl_sync_levels_unpack: %s", hipGetErrorString(waited));
     for (size_t i = nblk * 32u; i < n; i++)
         h_dst[i] = bits == 8 ? (float)src[i] : (float)((src[i / 2u] >> (4u * (i & 1u))) & 15u);
+    return GL_OK;
+}
+
+int gl_host_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits) {
+    GL_ARG(((h_dst != nullptr && h_src != nullptr) || n == 0) && (bits == 4 || bits == 8) && (bits == 8 || (n & 1u) == 0));
+    return levels_unpack_impl(h_dst, h_src, n, bits, false);
+}
+
+int gl_sync_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits) {
+    GL_REQUIRE_INIT();
+    GL_ARG(((h_dst != nullptr && h_src != nullptr) || n == 0) && (bits == 4 || bits == 8) && (bits == 8 || (n & 1u) == 0));
+    return levels_unpack_impl(h_dst, h_src, n, bits, true);
+}
+
+int gl_buf_d2h_levels(float *h_dst, const float *d_src, size_t n, float max_level, int *packed) {
+    GL_TRACE(n * sizeof(float));
+    GL_REQUIRE_INIT();
+    if (packed) *packed = 0;
+    if (n == 0) return GL_OK;
+    GL_ARG(h_dst != nullptr && d_src != nullptr);
+    static const bool on = !(getenv("GRAPHLILY_D2H_LEVELS") && atoi(getenv("GRAPHLILY_D2H_LEVELS")) == 0);
+    const int bits = max_level <= 15.0f ? 4 : 8;
+    if (!on || !(max_level >= 0.0f && max_level <= 255.0f) || n < (1u << 16) || (n & 7u) != 0 || ((uintptr_t)d_src & 15u) != 0)
+        return gl_buf_d2h(h_dst, d_src, n * sizeof(float));
+    hipStream_t s = gl::ctx().stream;
+    const uint32_t nwords = (uint32_t)(n / (32u / (uint32_t)bits));
+    const size_t pbytes = ((size_t)nwords * 4u + 15u) & ~(size_t)15u, total = pbytes + 16u;   // packed levels, then the flag word
+    // one page-locked staging block of the library, grown on demand (this call is blocking: nobody else uses it meanwhile)
+    static void *stage = nullptr;
+    static size_t stage_bytes = 0;
+    if (stage_bytes < total) {
+        if (stage) (void)hipHostFree(stage);
+        stage = nullptr, stage_bytes = 0;
+        if (hipHostMalloc(&stage, total, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return gl_buf_d2h(h_dst, d_src, n * sizeof(float));
+        }
+        stage_bytes = total;
+    }
+    void *d_pack = nullptr;
+    int rc = gl_buf_alloc(&d_pack, total);
+    if (rc != GL_OK) return rc;
+    uint32_t *d_flag = reinterpret_cast<uint32_t *>(static_cast<char *>(d_pack) + pbytes);
+    hipError_t e = hipMemsetAsync(d_flag, 0, 16, s);
+    if (e == hipSuccess) {
+        const unsigned grid = std::max(1u, std::min<unsigned>(gl::cdiv(nwords, 256), (unsigned)gl::ctx().num_cus * 8u));
+        if (bits == 8)
+            gl::levels_pack_checked_kernel<8><<<grid, 256, 0, s>>>(reinterpret_cast<const float4 *>(d_src), static_cast<uint32_t *>(d_pack), nwords, d_flag);
+        else
+            gl::levels_pack_checked_kernel<4><<<grid, 256, 0, s>>>(reinterpret_cast<const float4 *>(d_src), static_cast<uint32_t *>(d_pack), nwords, d_flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        rc = gl_buf_d2h_async(stage, d_pack, total);
+        // (the team starts now and unpacks as soon as the stream has drained; a raised flag makes that wasted work)
+        if (rc == GL_OK) rc = levels_unpack_impl(h_dst, stage, n, bits, true);
+        else (void)hipStreamSynchronize(s);
+    } else {
+        (void)hipStreamSynchronize(s);
+    }
+    (void)gl_buf_free(d_pack);
+    if (e != hipSuccess) return gl::set_error(GL_ERR_HIP, "gl_buf_d2h_levels: %s", hipGetErrorString(e));
+    if (rc != GL_OK) return rc;
+    if (*reinterpret_cast<const uint32_t *>(static_cast<const char *>(stage) + pbytes) != 0u)
+        return gl_buf_d2h(h_dst, d_src, n * sizeof(float));      // not levels after all: the floats themselves
+    if (packed) *packed = 1;
     return GL_OK;
 }
 

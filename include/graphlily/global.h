@@ -219,6 +219,10 @@ class DeviceBuffer {
         // through ptr() settles the debt -- runs the deferred calls, or writes the float vector a fused BFS pull iteration
         // kept as bits -- so every reader sees what the unfused call sequence would have left.
         std::function<void()> on_access;
+        // >= 0: the last writer was a fused BFS iteration that wrote this level (module/fusion.h) -- the buffer probably holds
+        // levels only, and a download tries the packed read-back (gl_buf_d2h_levels checks every value).  Any other access
+        // through ptr() forgets it.
+        float levels_max = -1.0f;
         ~Impl() { if (ptr) gl_buf_free(ptr); }
     };
     std::shared_ptr<Impl> impl_;
@@ -236,6 +240,7 @@ public:
             f.swap(impl_->on_access);     // cleared first: the settling code uses the buffer itself
             f();
         }
+        impl_->levels_max = -1.0f;
         return impl_->ptr;
     }
     size_t size() const { return impl_ ? impl_->bytes : 0; }
@@ -246,8 +251,16 @@ public:
     }
     void download(void *host, size_t bytes) const {
         assert(bytes <= size());
-        GRAPHLILY_CHECK(gl_buf_d2h(host, ptr(), bytes));
+        const float levels = impl_ ? impl_->levels_max : -1.0f;     // (ptr() below forgets the hint: a download does not write)
+        void *p = ptr();
+        if (levels >= 0.0f && bytes == size() && (bytes & 3u) == 0) {
+            GRAPHLILY_CHECK(gl_buf_d2h_levels(static_cast<float *>(host), static_cast<const float *>(p), bytes / 4u, levels, nullptr));
+            impl_->levels_max = levels;
+        } else {
+            GRAPHLILY_CHECK(gl_buf_d2h(host, p, bytes));
+        }
     }
+    void mark_levels(float max_level) const { if (impl_) impl_->levels_max = max_level; }   // module/fusion.h
     // ---- for module/fusion.h
     const void *id() const { return impl_.get(); }                       // identity of the allocation behind the handle
     void *raw() const { return impl_ ? impl_->ptr : nullptr; }           // the pointer WITHOUT settling a debt

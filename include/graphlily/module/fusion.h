@@ -221,6 +221,7 @@ struct PullFusion {
         res.owe(settle);
         last_vec = vec;
         last_res = res;
+        dist.mark_levels(val);                      // (the distances now hold levels up to `val`, as far as this layer knows)
         stage = 0;
         run_spmv = nullptr;
         run_ewise = nullptr;

@@ -96,6 +96,14 @@ int gl_buf_d2h_async(void *h_dst, const void *d_src, size_t bytes);
 int gl_levels_pack(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *d_out);
 int gl_host_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits);
 int gl_host_threads_warm(void);
+/* gl_sync + gl_host_levels_unpack with the thread team started BEFORE the wait: its master waits for the library's stream, the
+ * others spin until it returns -- a team woken ahead of a 0.3 ms wait is asleep again when the wait ends. */
+int gl_sync_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits);
+/* Blocking read-back of n floats that are EXPECTED to be BFS levels no larger than max_level (a caller that has seen only
+ * level-writing kernels touch the buffer): packed on the device with every value checked, copied as nibbles / bytes, expanded
+ * on host threads; if any value is not a small non-negative integer the floats themselves are copied -- the result is always
+ * exactly the buffer's contents.  *packed (may be NULL) tells which way it went.  GRAPHLILY_D2H_LEVELS=0: always the floats. */
+int gl_buf_d2h_levels(float *h_dst, const float *d_src, size_t n, float max_level, int *packed);
 int gl_buf_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async    */
 int gl_buf_fill_f32(float *d_dst, float value, size_t count);   /* async    */
 /* 32-bit fill that does nothing unless *d_gate == gate_value (d_gate NULL: always) */

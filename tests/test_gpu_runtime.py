@@ -110,3 +110,30 @@ def test_bfs_matrix_sent_again_rebuilds_the_device_schedules(gpu):
         for _ in range(3):                 # eager, capture, replay
             assert np.array_equal(bfs.pull_push(src, 6, 0.01), ref)
             assert np.array_equal(bfs.pull(src, 6), ref)
+
+
+def test_d2h_levels_is_exact_whatever_the_buffer_holds(gpu):
+    """gl_buf_d2h_levels: packed when every value is a level that fits (nibbles up to 15, bytes up to 255), the floats
+    themselves otherwise -- a fraction, a negative, a NaN, a value above the promised maximum, -0.0 (a different word than 0.0): the words that come back are the buffer's."""
+    n = 1 << 18
+    rng = np.random.default_rng(11)
+    cases = {
+        "nibbles": (rng.integers(0, 16, size=n).astype(np.float32), 15.0, True),
+        "bytes": (rng.integers(0, 256, size=n).astype(np.float32), 255.0, True),
+        "bytes promised, nibbles held": (rng.integers(0, 8, size=n).astype(np.float32), 200.0, True),
+        "above the promise": (np.where(np.arange(n) == 777, 16.0, 3.0).astype(np.float32), 15.0, False),
+        "a fraction": (np.where(np.arange(n) == n - 1, 2.5, 2.0).astype(np.float32), 15.0, False),
+        "a negative": (np.where(np.arange(n) == 5, -1.0, 1.0).astype(np.float32), 255.0, False),
+        "a NaN": (np.where(np.arange(n) == 12345, np.nan, 1.0).astype(np.float32), 255.0, False),
+        "minus zero": (np.where(np.arange(n) == 9, -0.0, 0.0).astype(np.float32), 15.0, False),
+        "too many levels": (rng.integers(0, 300, size=n).astype(np.float32), 299.0, False),
+    }
+    for name, (vals, mx, want_packed) in cases.items():
+        buf = capi.DeviceBuffer.from_host(vals)
+        out = np.full(n, -7.0, np.float32)
+        packed = capi.d2h_levels(out, buf, n, mx)
+        assert packed == want_packed, name
+        assert np.array_equal(out.view(np.uint32), vals.view(np.uint32)), name      # (bit for bit either way)
+    small = capi.DeviceBuffer.from_host(np.arange(1000, dtype=np.float32) % 7)
+    out = np.zeros(1000, np.float32)
+    assert capi.d2h_levels(out, small, 1000, 15.0) is False and np.array_equal(out, np.arange(1000, dtype=np.float32) % 7)
