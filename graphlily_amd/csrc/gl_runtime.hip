@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <omp.h>
+#include <unistd.h>
 #include <emmintrin.h>
 #include <sys/mman.h>
 #include <cstdlib>
@@ -887,7 +888,11 @@ static int levels_unpack_impl(float *h_dst, const void *h_src, size_t n, int bit
                 waited = hipStreamSynchronize(gl::ctx().stream);
                 __atomic_store_n(&ready, 1, __ATOMIC_RELEASE);
             } else {
-                while (!__atomic_load_n(&ready, __ATOMIC_ACQUIRE)) _mm_pause();
+                // (spinning is for waits of a fraction of a millisecond; past ~2 ms the thread naps between looks)
+                for (uint32_t spins = 0; !__atomic_load_n(&ready, __ATOMIC_ACQUIRE); spins++) {
+                    if (spins < (1u << 16)) _mm_pause();
+                    else usleep(50);
+                }
             }
         }
         const size_t b0 = nblk * t / T, b1 = nblk * (t + 1) / T;
