@@ -529,7 +529,7 @@ class BFS(_GraphApp):
         own = hi - lo
         pbits = 4 if N + 1 <= 15 else 8
         as_bytes = (N + 1 <= 255 and own % 8 == 0 and lo % 4 == 0 and own >= (1 << 16)
-                    and os.environ.get("GRAPHLILY_BFS_U8", "1") != "0")
+                    and os.environ.get("GRAPHLILY_BFS_U8", "1") != "0" and capi.host_unpack_threads() >= 4)
         in_graph = as_bytes and not timed and (sliced or not sharded)
         if as_bytes:
             pw = capi.levels_packed_words(own, pbits)

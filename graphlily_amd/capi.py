@@ -33,7 +33,7 @@ EXPORTS = [
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
     "gl_bfs_bits_begin", "gl_bfs_bits_push_step", "gl_bfs_bits_pull_step", "gl_bfs_bits_decide",
     "gl_bfs_bits_shard_step", "gl_bfs_bits_shard_finish", "gl_dist_all_gather_bits_tally",
-    "gl_buf_d2h_async", "gl_levels_pack", "gl_host_levels_unpack", "gl_host_threads_warm", "gl_buf_d2h_levels", "gl_sync_levels_unpack",
+    "gl_buf_d2h_async", "gl_levels_pack", "gl_host_levels_unpack", "gl_host_threads_warm", "gl_host_unpack_threads", "gl_buf_d2h_levels", "gl_sync_levels_unpack",
     "gl_sssp_begin", "gl_assign_sparse_new_frontier_gated", "gl_spmv_run_flagged", "gl_ewise_add_flagged",
     "gl_bfs_begin", "gl_spmspv_plan_frontier_bits", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
     "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32", "gl_dist_all_gather_bits",
@@ -85,7 +85,7 @@ def lib():
         "gl_bfs_begin": [vp, vp, u32, vp, vp, u32],
         "gl_bfs_bits_begin": [vp, u32, vp, u32, vp, u32, u32, u32],
         "gl_buf_d2h_async": [vp, vp, ctypes.c_size_t],
-        "gl_levels_pack": [vp, u32, i32, vp, u32, vp], "gl_host_levels_unpack": [vp, vp, ctypes.c_size_t, i32], "gl_host_threads_warm": [], "gl_buf_d2h_levels": [vp, vp, ctypes.c_size_t, f32, P(i32)], "gl_sync_levels_unpack": [vp, vp, ctypes.c_size_t, i32],
+        "gl_levels_pack": [vp, u32, i32, vp, u32, vp], "gl_host_levels_unpack": [vp, vp, ctypes.c_size_t, i32], "gl_host_threads_warm": [], "gl_host_unpack_threads": [], "gl_buf_d2h_levels": [vp, vp, ctypes.c_size_t, f32, P(i32)], "gl_sync_levels_unpack": [vp, vp, ctypes.c_size_t, i32],
         "gl_bfs_bits_push_step": [vp, vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
         "gl_bfs_bits_pull_step": [vp, vp, vp, vp, vp, f32, vp, u32, f32, i32, f32],
         "gl_bfs_bits_decide": [vp, vp, vp, vp, u64, vp, u32, f32, i32, f32],
@@ -718,6 +718,10 @@ def d2h_levels(dst, buf, n, max_level):
     used = ctypes.c_int(0)
     check(lib().gl_buf_d2h_levels(_np_ptr(dst), _p(buf), int(n), float(max_level), ctypes.byref(used)))
     return bool(used.value)
+
+
+def host_unpack_threads():
+    return int(lib().gl_host_unpack_threads())
 
 
 def host_threads_warm():

@@ -849,6 +849,8 @@ static int host_expand_threads(size_t n) {
     return n >= (1u << 18) ? hw : (n >= (1u << 16) ? std::min(hw, 8) : 1);
 }
 
+int gl_host_unpack_threads(void) { return host_expand_threads(1u << 20); }
+
 int gl_host_threads_warm(void) {
     const int nt = host_expand_threads(1u << 20);
     (void)nt;
@@ -939,7 +941,9 @@ int gl_buf_d2h_levels(float *h_dst, const float *d_src, size_t n, float max_leve
     GL_ARG(h_dst != nullptr && d_src != nullptr);
     static const bool on = !(getenv("GRAPHLILY_D2H_LEVELS") && atoi(getenv("GRAPHLILY_D2H_LEVELS")) == 0);
     const int bits = max_level <= 15.0f ? 4 : 8;
-    if (!on || !(max_level >= 0.0f && max_level <= 255.0f) || n < (1u << 16) || (n & 7u) != 0 || ((uintptr_t)d_src & 15u) != 0)
+    // (with fewer than four host threads the expansion costs more than the PCIe time it saves)
+    if (!on || host_expand_threads(1u << 20) < 4 || !(max_level >= 0.0f && max_level <= 255.0f) || n < (1u << 16) || (n & 7u) != 0 ||
+        ((uintptr_t)d_src & 15u) != 0)
         return gl_buf_d2h(h_dst, d_src, n * sizeof(float));
     hipStream_t s = gl::ctx().stream;
     const uint32_t nwords = (uint32_t)(n / (32u / (uint32_t)bits));

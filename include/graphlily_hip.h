@@ -96,6 +96,7 @@ int gl_buf_d2h_async(void *h_dst, const void *d_src, size_t bytes);
 int gl_levels_pack(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *d_out);
 int gl_host_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits);
 int gl_host_threads_warm(void);
+int gl_host_unpack_threads(void);   /* how many threads gl_host_levels_unpack uses for a large vector (packing pays from 4 on) */
 /* gl_sync + gl_host_levels_unpack with the thread team started BEFORE the wait: its master waits for the library's stream, the
  * others spin until it returns -- a team woken ahead of a 0.3 ms wait is asleep again when the wait ends. */
 int gl_sync_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits);
