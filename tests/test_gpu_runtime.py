@@ -132,7 +132,7 @@ def test_d2h_levels_is_exact_whatever_the_buffer_holds(gpu):
         buf = capi.DeviceBuffer.from_host(vals)
         out = np.full(n, -7.0, np.float32)
         packed = capi.d2h_levels(out, buf, n, mx)
-        assert packed == want_packed, name
+        assert packed == (want_packed and capi.host_unpack_threads() >= 4), name
         assert np.array_equal(out.view(np.uint32), vals.view(np.uint32)), name      # (bit for bit either way)
     small = capi.DeviceBuffer.from_host(np.arange(1000, dtype=np.float32) % 7)
     out = np.zeros(1000, np.float32)
