@@ -49,6 +49,9 @@ def main():
                     help="timed steps; 0 (default) = as many as make the timed region last ~1 s (bench_spmv.cpp:96 runs 100: "
                          "at 0.3 ms per step that is a 30 ms region, too short for SMI sampling to see)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle", type=float, default=0.5,
+                    help="seconds the device idles between set-up (graph generation, plan creation: seconds of sorting kernels) and "
+                         "the warm-up steps")
     ap.add_argument("--graph", default="orkut")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the stand-in (debug only)")
     ap.add_argument("--no-bfs", action="store_true")
@@ -141,6 +144,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up has just run seconds of heavy formatting kernels: the steps directly behind them start 4-5 % slower than the steady
+    # state (scripts/r03_step_ramp.py).  A short idle in between separates the two; it matters to short timed regions only.
+    fence()
+    time.sleep(max(0.0, args.settle))
     for _ in range(args.warmup):
         step()
     fence()
