@@ -528,7 +528,9 @@ class BFS(_GraphApp):
         lo, hi = (self.r0_, self.r1_) if sliced else (0, n)
         own = hi - lo
         pbits = 4 if N + 1 <= 15 else 8
-        as_bytes = (N + 1 <= 255 and own % 8 == 0 and lo % 4 == 0 and own >= (1 << 16)
+        # (from half a million rows on: same-box A/B, profiles/r04_ab_schedules.txt -- the googleplus stand-in's 108 K levels are
+        # 0.43 MB as floats and came back 24 us SOONER unpacked, ogbl-ppa's 576 K tie, hollywood's 1 M gain 22 us packed)
+        as_bytes = (N + 1 <= 255 and own % 8 == 0 and lo % 4 == 0 and own >= (1 << 19)
                     and os.environ.get("GRAPHLILY_BFS_U8", "1") != "0" and capi.host_unpack_threads() >= 4)
         in_graph = as_bytes and not timed and (sliced or not sharded)
         if as_bytes:

@@ -57,6 +57,9 @@ struct BfsPushArgs {
     bool deferred;
     // one-launch shard step: the column lengths of the WHOLE matrix (a shard's own column pointers count its rows only)
     const uint32_t *col_len = nullptr;
+    // one-launch shard step, scattering push: frontier bits a lane takes (a power of two, 1 ... 32): a wavefront's strip is
+    // 64 x bpl bits.  Small graphs get narrow strips so that every wavefront of the grid has one (see bfs_shard_scatter)
+    uint32_t bpl = 32;
     BfsBitsCtl c;
 };
 
@@ -168,9 +171,13 @@ __device__ __forceinline__ BfsBitsCtl shard_prologue(const BfsShardArgs &sa, uin
 
 // The scattering push for workgroups that cannot be many (the streaming pull's LDS tile leaves room for ONE workgroup of T
 // threads per compute unit): every WAVEFRONT works on its own -- no workgroup barrier in the main loop, 16 independent
-// latency chains per compute unit.  A wavefront takes a strip of 64 frontier words (one per lane); per round every lane with
-// bits left takes its lowest one = up to 64 columns, whose entries are dealt to the lanes in order (prefix of the column
+// latency chains per compute unit.  A wavefront takes a strip of 64 x bpl frontier bits (bpl per lane); per round every lane
+// with bits left takes its lowest one = up to 64 columns, whose entries are dealt to the lanes in order (prefix of the column
 // lengths in the wavefront's 128 words of LDS, binary search per entry): two entries per lane and step in flight.
+// A round is a chain of four dependent round trips (column pointers, entries, distances, claims) and a lane has up to bpl
+// rounds: with whole words per lane (bpl = 32) the googleplus stand-in's 3375 frontier words were 53 strips -- 53 busy
+// wavefronts on the whole chip -- and a 20 762-vertex frontier of short columns took 12 rounds = 41 us (round 4,
+// profiles/r04_bfs_timeline_googleplus.txt); the host now picks bpl so that the strips cover the grid's wavefronts.
 // Columns of kBfsChunk entries and more come from the plan's chunk list, by the whole workgroup (as in gl_spmspv.hip).
 // `lds`: >= 128 * (T / 64) + T + 8 + 512 words.  Workgroup `blk` of `G`.
 template <uint32_t T>
@@ -191,14 +198,17 @@ __device__ __forceinline__ void bfs_shard_scatter(const BfsPushArgs &a, uint32_t
         *s_nlong = 0u;
     }
     __syncthreads();
-    const uint32_t nstrips = (a.col_words + 63u) >> 6;
+    const uint32_t bpl = a.bpl, strip_bits = 64u * bpl;
+    const uint32_t nstrips = (a.col_words * 32u + strip_bits - 1u) / strip_bits;
     for (uint32_t strip = blk + G * wave; strip < nstrips; strip += G * W) {   // (neighbouring strips go to different compute units)
-        const uint32_t wi = strip * 64u + lane;
+        const uint32_t bit0 = strip * strip_bits + lane * bpl;      // this lane's first frontier bit
+        const uint32_t wi = bit0 >> 5;
         uint32_t w = wi < a.col_words ? a.bits_in[wi] : 0u;
+        if (bpl < 32u) w = (w >> (bit0 & 31u)) & ((1u << bpl) - 1u);
         while (__any(w != 0u)) {
             uint32_t start = 0u, deg = 0u;
             if (w) {
-                const uint32_t col = wi * 32u + (uint32_t)__ffs((int)w) - 1u;
+                const uint32_t col = bit0 + (uint32_t)__ffs((int)w) - 1u;
                 w &= w - 1u;
                 if (col < a.num_cols) {
                     start = a.indptr[col];

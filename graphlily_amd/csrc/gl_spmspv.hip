@@ -9,24 +9,14 @@
 // (0, zero) entries, data_formatter.h:674-680, are not needed: a wavefront reads
 // any contiguous run of a column coalesced).
 //
-// Kernels per run:
-//  1. scatter: a workgroup takes 256 entries of the sparse input vector and
-//     buckets them in LDS by column length:
-//       long columns (>= 4096 non-zeros) are cut into 4096-entry chunks that go
-//         to a device-wide work queue (kernel 1b spreads them over the grid, so
-//         one hub vertex in the frontier does not serialise a workgroup);
-//       the others become wave tasks of <= 64 consecutive entries; an exclusive
-//         prefix of the task counts lives in LDS and each wavefront maps a task
-//         to its column with a wave-uniform binary search -- one search per 64
-//         non-zeros, coalesced 512-byte reads of the column's {row,val} stream.
-//     Products go into a dense accumulator with atomics: float add for (+,*),
-//     plain store of 1 for (||,&&), ordered-integer min for (min,+).
-//  2. ordered compaction of the accumulator into the (index, value) list with
-//     the mask applied (gl_compact.h); the pass also resets the accumulator to
-//     `zero`, restoring the invariant for the next run (the FPGA re-zeroes its
-//     output buffer per call instead, kernel_spmspv_impl.h:505-516).
+// Kernels per run (gl_spmspv_bin.h): BIN -- the products of the active columns, sorted by row tile in LDS, leave in runs into
+// per-tile bins -- and FOLD -- one workgroup per row tile accumulates its bin in LDS and writes its piece of the ordered
+// result list, with the mask, the fused sparse assign, the next-frontier bits and the driver's loop decision.  A vector of
+// at most 1024 entries / 2048 products is ONE launch of one workgroup (spmspv_tiny_kernel); one whose columns hold a large
+// part of the matrix is applied row-wise with an attached SpMV plan and folded from the dense accumulator.
 #include "gl_common.h"
 #include "gl_compact.h"
+#include "gl_spmspv_bin.h"
 #include "gl_spmv_plan.h"
 #include "gl_bfs_shard.h"
 
@@ -42,10 +32,22 @@ struct gl_spmspv_plan_s {
     float *d_acc = nullptr;        // dense accumulator over the shard's rows
     float acc_fill = 0.0f;
     bool acc_valid = false;        // d_acc is known to be all == acc_fill
-    uint32_t *d_counts = nullptr;  // compaction workspace
-    uint32_t *d_queue_count = nullptr;  // [0] = chunks queued by the current run
-    uint4 *d_queue = nullptr;           // chunk descriptors of long columns
+    // propagation blocking (gl_spmspv_bin.h): row tiles, one bin per tile with room for every non-zero of the tile
+    gl::TileMap tiles;
+    bool binned = false;               // false: more tiles than the bin kernel has counters for -- products go to d_acc
+    bool fold_tickets = false;         // more tiles than compute units: the fold hands its tiles out in arrival order
+    uint2 *d_bins = nullptr;
+    uint32_t *d_bin_base = nullptr;    // tiles + 1
+    uint32_t *d_cursor = nullptr;      // tiles, zero between runs
+    uint32_t *d_state = nullptr;       // tiles, zero between runs
+    uint32_t *d_sync = nullptr;        // gl::kSyncWords, zero between runs
+    unsigned long long *d_queue = nullptr;   // chunk descriptors of long columns (two words each)
     uint32_t queue_capacity = 0;
+    // a blocking caller's completion record: the fold's last workgroup stores seq << 32 | count (gl_spmspv_wait)
+    unsigned long long *h_rec = nullptr;     // page-locked, device-visible
+    uint32_t seq = 0;                        // of the last run that was given the record
+    bool rec_pending = false;                // that run is the last one enqueued on this plan
+    uint32_t nnz_hint = ~0u;                 // entries of the next run's vector, if a hint said so (sizes the bin grid)
     // direction switch inside the operator ((||,&&) only): a frontier whose columns hold more than 1/32 of the
     // matrix is cheaper to apply row-wise with the attached boolean SpMV plan than to scatter
     gl_spmv_plan pull = nullptr;        // not owned; boolean layout, serves (||,&&)
@@ -87,71 +89,9 @@ void spmspv_detach_everywhere(gl_spmv_plan dying) {
     }
 }
 
-constexpr uint32_t kBigColumn = 4096;  // columns at least this long are cut into queue chunks
-constexpr uint32_t kChunk = 4096;      // entries per queue chunk (one workgroup pass in kernel 1b)
 constexpr uint32_t kBfsAccSlots = 64;  // accumulator lines of the bit-frontier BFS push step (a power of two)
 
-struct ScatterArgs {
-    const uint32_t *indptr;
-    const uint2 *stream;
-    const gl_idx_val *vec;
-    float *acc;
-    uint32_t *queue_count;   // [0] = number of queued chunks (reset by the compaction scan)
-    uint4 *queue;            // {first entry, count, value bits, -}
-    uint32_t queue_capacity;
-    uint32_t row_begin;
-    uint32_t num_cols;
-    const uint32_t *mode;    // non-null: skip the scatter when mode[0] != 0 (the run goes row-wise instead)
-    Gate gate;               // driver-level predicate of the whole run (gl_spmspv_run_gated)
-};
-
-// ordered-integer trick: for IEEE floats, a >= 0 compares like int, a < 0 like reversed uint
-__device__ __forceinline__ void atomic_min_float(float *addr, float v) {
-    if (!(__float_as_uint(v) >> 31))   // by sign bit, so that -0.0 takes the negative path (v >= 0 is true for it)
-        atomicMin((int *)addr, __float_as_int(v));
-    else
-        atomicMax((unsigned int *)addr, __float_as_uint(v));
-}
-
-template <int OP>
-__device__ __forceinline__ void scatter_one(float *acc, uint32_t row, float a, float xv) {
-    if (OP == kOpU32MulAdd) {            // the integer value types (gl_common.h): the accumulator holds bits
-        atomicAdd(reinterpret_cast<unsigned int *>(&acc[row]), fbits(a) * fbits(xv));
-    } else if (OP == kOpFixMulAdd) {
-        // acc = min(acc + round(a * x), 2^32 - 1): clamped adds of non-negative terms give min(sum, 2^32 - 1) in any order
-        // (gl_common.h), so a compare-and-swap loop reproduces the reference's sequential saturating sum bit for bit
-        const uint32_t t = fix_mul_u32(fbits(a), fbits(xv));
-        if (t != 0u) {
-            unsigned int *w = reinterpret_cast<unsigned int *>(&acc[row]);
-            unsigned int old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (old != 0xffffffffu) {
-                const unsigned int seen = atomicCAS(w, old, sat_add_u32(old, t));
-                if (seen == old) break;
-                old = seen;
-            }
-        }
-    } else if (OP == kOpU32AndOr || OP == kOpFixAndOr) {
-        if (fbits(a) != 0u && fbits(xv) != 0u) reinterpret_cast<uint32_t *>(acc)[row] = (OP == kOpU32AndOr) ? 1u : kFixOne;
-    } else if (OP == kOpU32AddMin || OP == kOpFixAddMin) {
-        atomicMin(reinterpret_cast<unsigned int *>(&acc[row]), fbits(Semiring<OP>::mul(a, xv)));
-    } else if (OP == GL_OP_MULADD) {
-        unsafeAtomicAdd(&acc[row], a * xv);
-    } else if (OP == GL_OP_ANDOR) {
-        if (a != 0.0f && xv != 0.0f) acc[row] = 1.0f;
-    } else {
-        // saturating add of the (min,+) PE: hw/float_pe.h:24-33, spmspv_module.h:482-491
-        float incr;
-        if (a > kFloatInf || xv > kFloatInf) {
-            incr = kFloatInf;
-        } else {
-            incr = a + xv;
-            if (incr > kFloatInf) incr = kFloatInf;
-        }
-        atomic_min_float(&acc[row], incr);
-    }
-}
-
-// exclusive prefix of v over the 256 threads of the block; total broadcast through s_tot
+// exclusive prefix of v over the 256 threads of the block; total broadcast through *total
 __device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t *s_wave, uint32_t *total) {
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     uint32_t incl = v;
@@ -172,115 +112,6 @@ __device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t *s_
     __syncthreads();
     *total = tot;
     return before + incl - v;
-}
-
-template <int OP>
-__global__ __launch_bounds__(256) void spmspv_scatter_kernel(ScatterArgs a) {
-    __shared__ uint32_t s_start[256];
-    __shared__ uint32_t s_deg[256];
-    __shared__ uint32_t s_task[257];  // exclusive prefix of wave-task counts, s_task[256] = total
-    __shared__ float s_val[256];
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_qbase;
-    if (a.gate.closed()) return;
-    if (a.mode && a.mode[0]) return;
-    const uint32_t vnnz = a.vec[0].index;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-    // a small frontier is spread over the whole grid (E entries per workgroup, down to one) -- a few hundred
-    // hub vertices would otherwise be served by one or two workgroups
-    const uint32_t E = min(256u, max(1u, (vnnz + gridDim.x - 1u) / gridDim.x));
-    for (uint32_t batch = blockIdx.x * E; batch < vnnz; batch += gridDim.x * E) {
-        const uint32_t e = batch + threadIdx.x;
-        uint32_t start = 0, deg = 0;
-        float xv = 0.0f;
-        if (threadIdx.x < E && e < vnnz) {
-            const gl_idx_val iv = a.vec[1u + e];
-            if (iv.index < a.num_cols) {
-                start = a.indptr[iv.index];
-                deg = a.indptr[iv.index + 1u] - start;
-                xv = iv.val;
-            }
-        }
-        const bool big = deg >= kBigColumn;
-        // long columns -> queue chunks (one atomic per workgroup reserves the slots)
-        uint32_t nchunks = big ? (deg + kChunk - 1u) / kChunk : 0u, qtotal;
-        const uint32_t qoff = block_exclusive_256(nchunks, s_wave, &qtotal);
-        if (qtotal) {
-            if (threadIdx.x == 0) s_qbase = atomicAdd(a.queue_count, qtotal);
-            __syncthreads();
-            const uint32_t qb = s_qbase + qoff;
-            for (uint32_t c = 0; c < nchunks; c++) {
-                if (qb + c < a.queue_capacity)
-                    a.queue[qb + c] = make_uint4(start + c * kChunk, min(kChunk, deg - c * kChunk), __float_as_uint(xv), 0u);
-            }
-            // The queue holds one slot per chunk of every long column (exact, computed at plan creation), so it can
-            // only run out when the input vector names a column more than once.  Chunks without a slot are
-            // scattered right here by the whole workgroup: slow, never wrong.
-            if (s_qbase + qtotal > a.queue_capacity) {   // block-uniform
-                s_start[threadIdx.x] = start;
-                s_deg[threadIdx.x] = nchunks ? deg : 0u;
-                s_val[threadIdx.x] = xv;
-                s_task[threadIdx.x] = qb;
-                __syncthreads();
-                for (uint32_t j = 0; j < 256u; j++) {
-                    const uint32_t dj = s_deg[j];
-                    if (!dj) continue;
-                    const uint32_t nj = (dj + kChunk - 1u) / kChunk, qj = s_task[j];
-                    const uint32_t c0 = qj >= a.queue_capacity ? 0u : min(nj, a.queue_capacity - qj);   // first chunk without a slot
-                    for (uint32_t k = c0 * kChunk + threadIdx.x; k < dj; k += 256u) {
-                        const uint2 rv = load_stream_nt(a.stream + s_start[j] + k);
-                        scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), s_val[j]);
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        // the rest -> wave tasks of <= 64 entries
-        const uint32_t ntasks = big ? 0u : (deg + 63u) >> 6;
-        uint32_t ttotal;
-        const uint32_t toff = block_exclusive_256(ntasks, s_wave, &ttotal);
-        s_start[threadIdx.x] = start;
-        s_deg[threadIdx.x] = big ? 0u : deg;
-        s_val[threadIdx.x] = xv;
-        s_task[threadIdx.x] = toff;
-        if (threadIdx.x == 255) s_task[256] = ttotal;
-        __syncthreads();
-        for (uint32_t t = wave; t < ttotal; t += 4u) {
-            // largest j with s_task[j] <= t (wave-uniform: every lane reads the same words)
-            uint32_t lo = 0, hi = 255;
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const uint32_t mid = (lo + hi + 1u) >> 1;
-                if (s_task[mid] <= t) lo = mid; else hi = mid - 1u;
-            }
-            const uint32_t j = __builtin_amdgcn_readfirstlane(lo);
-            const uint32_t item = ((t - s_task[j]) << 6) + lane;
-            if (item < s_deg[j]) {
-                const uint2 rv = load_stream_nt(a.stream + s_start[j] + item);
-                scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), s_val[j]);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// queued chunks of long columns: one workgroup pass (256 threads x 16 coalesced entries) per chunk
-template <int OP>
-__global__ __launch_bounds__(256) void spmspv_queue_kernel(ScatterArgs a) {
-    if (a.gate.closed()) return;
-    if (a.mode && a.mode[0]) return;
-    uint32_t nq = a.queue_count[0];
-    if (nq > a.queue_capacity) nq = a.queue_capacity;
-    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
-        const uint4 c = a.queue[q];
-        const float xv = __uint_as_float(c.z);
-        for (uint32_t k = threadIdx.x; k < c.y; k += 256u) {
-            const uint2 rv = load_stream_nt(a.stream + c.x + k);
-            scatter_one<OP>(a.acc, rv.x - a.row_begin, __uint_as_float(rv.y), xv);
-        }
-    }
 }
 
 // work of this run = sum of the lengths of the frontier's columns; the last block to finish sets the mode
@@ -737,29 +568,6 @@ __device__ __forceinline__ bool tiny_scatter(float *acc, uint32_t row, float a, 
     return atomic_min_float_old(&acc[row], incr) == zero_bits;
 }
 
-// exclusive prefix of v over the 1024 threads of the block, total in *total (s_wave: 16 words)
-__device__ __forceinline__ uint32_t block_exclusive_1024(uint32_t v, uint32_t *s_wave, uint32_t *total) {
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
-        uint32_t up = __shfl_up(incl, dlt);
-        if (lane >= dlt) incl += up;
-    }
-    if (lane == 63) s_wave[w] = incl;
-    __syncthreads();
-    uint32_t before = 0, tot = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) {
-        const uint32_t c = s_wave[k];
-        if (k < w) before += c;
-        tot += c;
-    }
-    __syncthreads();
-    *total = tot;
-    return before + incl - v;
-}
-
 template <int OP, typename Src>
 __global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, Src src, Gate gate, Direction dir) {
     __shared__ uint32_t s_start[kTinyVec];
@@ -974,16 +782,78 @@ static int launch_tiny_mask(int mask_type, const TinyArgs &a, const float *mask,
     }
 }
 
-// (queue_capacity == 0: the caller knows the vector names no long column -- no queue pass; a long column that turns up
-// anyway is scattered by its workgroup on the spot, see the kernel)
-template <int OP>
-static int launch_scatter(const ScatterArgs &a, uint32_t grid, hipStream_t s) {
-    spmspv_scatter_kernel<OP><<<grid, 256, 0, s>>>(a);
-    GL_LAUNCH_CHECK();
-    if (!a.queue_capacity) return GL_OK;
-    spmspv_queue_kernel<OP><<<(unsigned)ctx().num_cus * 8u, 256, 0, s>>>(a);
+template <int OPX>
+static int launch_fold_op(const FoldArgs &f, hipStream_t s) {
+    using T = typename Tile<OPX>::T;
+    const size_t lds = (size_t)f.tiles.rows * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute((const void *)spmspv_fold_kernel<OPX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFoldMaxRows * 8u)));
+        attr_set = true;
+    }
+    spmspv_fold_kernel<OPX><<<f.tiles.count, kFoldThreads, lds, s>>>(f);
     GL_LAUNCH_CHECK();
     return GL_OK;
+}
+
+static int launch_fold(int opx, const FoldArgs &f, hipStream_t s) {
+    switch (opx) {
+        case GL_OP_MULADD: return launch_fold_op<GL_OP_MULADD>(f, s);
+        case GL_OP_ANDOR: return launch_fold_op<GL_OP_ANDOR>(f, s);
+        case GL_OP_ADDMIN: return launch_fold_op<GL_OP_ADDMIN>(f, s);
+        case kOpU32MulAdd: return launch_fold_op<kOpU32MulAdd>(f, s);
+        case kOpU32AndOr: return launch_fold_op<kOpU32AndOr>(f, s);
+        case kOpU32AddMin: return launch_fold_op<kOpU32AddMin>(f, s);
+        case kOpFixMulAdd: return launch_fold_op<kOpFixMulAdd>(f, s);
+        case kOpFixAndOr: return launch_fold_op<kOpFixAndOr>(f, s);
+        case kOpFixAddMin: return launch_fold_op<kOpFixAddMin>(f, s);
+        default: return set_error(GL_ERR_UNSUPPORTED, "gl_spmspv_run: unknown semiring / value type code %d", opx);
+    }
+}
+
+// plan creation: non-zeros per row tile = the capacity of the tile's bin
+__global__ __launch_bounds__(1024) void spmspv_tile_count_kernel(const uint2 *__restrict__ stream, uint64_t n, uint32_t row_begin, TileMap tiles,
+                                                                 uint32_t *__restrict__ counts) {
+    __shared__ uint32_t s_cnt[kBinMaxTiles];
+    for (uint32_t i = threadIdx.x; i < kBinMaxTiles; i += 1024u) s_cnt[i] = 0u;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 1024u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 1024u)
+        atomicAdd(&s_cnt[tiles.of(stream[i].x - row_begin)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < tiles.count; i += 1024u)
+        if (s_cnt[i]) atomicAdd(&counts[i], s_cnt[i]);
+}
+
+// rows per tile: one tile per compute unit where the shard has rows enough (every tile is folded by one workgroup, all at
+// the same time), a multiple of 64, at most kFoldMaxRows (the tile's 8-byte accumulators fill 128 KB of LDS)
+static TileMap choose_tiles(uint32_t nrows, uint32_t num_cus) {
+    TileMap tm;
+    uint32_t R = cdiv(std::max<uint32_t>(nrows, 1u), std::max<uint32_t>(num_cus, 1u));
+    R = std::min<uint32_t>(std::max<uint32_t>((R + 63u) & ~63u, 64u), kFoldMaxRows);
+    const long forced = env_long("GRAPHLILY_SPMSPV_TILE_ROWS", 0);   // tests: many small tiles on a small matrix
+    if (forced >= 64) R = std::min<uint32_t>(((uint32_t)forced + 63u) & ~63u, kFoldMaxRows);
+    for (;;) {
+        tm.rows = R;
+        tm.count = std::max<uint32_t>(cdiv(nrows, R), 1u);
+        uint32_t sh = 0;
+        while ((2u << sh) <= R) sh++;                 // floor(log2 R)
+        tm.shift = sh;
+        if ((R & (R - 1u)) == 0u) {
+            tm.magic = 0u;
+            return tm;
+        }
+        tm.magic = (uint32_t)((1ull << (32u + sh)) / R) + 1u;   // < 2^32: R > 2^sh
+        bool exact = true;
+        for (uint32_t t = 1; t <= tm.count && exact; t++) {
+            const uint64_t b = (uint64_t)t * R;
+            if (b - 1u <= 0xffffffffull) exact = tm.of((uint32_t)(b - 1u)) == t - 1u;
+            if (exact && b <= 0xffffffffull && b < (uint64_t)nrows + R) exact = tm.of((uint32_t)b) == t;
+        }
+        if (exact) return tm;
+        uint32_t p2 = 64u;                            // (never seen: fall back to a power of two)
+        while (p2 < R) p2 <<= 1;
+        R = std::min<uint32_t>(p2, kFoldMaxRows);
+    }
 }
 
 }  // namespace gl
@@ -1039,15 +909,17 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     p->d_indptr = dev_indptr;   // (null unless the device built them)
     p->d_stream = dev_stream;
     const uint32_t nrows = row_end - row_begin;
-    // one slot per chunk of every long column: a column of deg >= kBigColumn entries yields ceil(deg / kChunk) chunks
-    // (nnz / kChunk undercounts: two columns of 4097 entries need four slots).  A vector that lists a column twice
-    // can still exceed it; the scatter kernel then processes the surplus chunks itself.
+    // one slot per chunk of every long column: a column of deg >= kBigColumn entries yields ceil(deg / kChunk) chunks.  A vector
+    // that lists a column twice can still exceed it; the bin kernel then processes the surplus chunks itself.
     uint64_t chunks = 0;
     for (uint32_t c = 0; c < num_cols; c++) {
         const uint32_t d = indptr[c + 1] - indptr[c];
         if (d >= gl::kBigColumn) chunks += (d + gl::kChunk - 1u) / gl::kChunk;
     }
-    p->queue_capacity = (uint32_t)std::min<uint64_t>(chunks + 1u, 0x7fffffffu);
+    p->queue_capacity = chunks ? (uint32_t)std::min<uint64_t>(chunks + 1u, 0x7fffffffu) : 0u;
+    p->tiles = gl::choose_tiles(nrows, (uint32_t)gl::ctx().num_cus);
+    p->binned = p->tiles.count <= gl::kBinMaxTiles;
+    p->fold_tickets = p->tiles.count > (uint32_t)gl::ctx().num_cus;
     std::vector<uint4> long_chunks;   // (gl_bfs_bits_push_step: its own, shorter chunks)
     for (uint32_t c = 0; c < num_cols; c++) {
         const uint32_t d = indptr[c + 1] - indptr[c];
@@ -1062,16 +934,25 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     hipError_t e;
     size_t b_indptr = indptr.size() * sizeof(uint32_t), b_stream = kept * sizeof(uint2);
     size_t b_acc = (size_t)(nrows ? nrows : 1) * sizeof(float);
-    size_t b_counts = (size_t)(gl::cdiv(nrows, gl::kCompactChunk) + 1) * sizeof(uint32_t);
-    size_t b_queue = (size_t)p->queue_capacity * sizeof(uint4);
+    const uint32_t ntiles = p->tiles.count;
+    size_t b_tiles = (size_t)(ntiles + 1u) * sizeof(uint32_t);
+    size_t b_queue = ((size_t)p->queue_capacity + 1u) * 2u * sizeof(unsigned long long);
+    size_t b_bins = (p->binned && kept) ? kept * sizeof(uint2) : 16;
     if (!on_device && (e = hipMalloc((void **)&p->d_indptr, b_indptr)) != hipSuccess) return fail(e);
     if (!on_device && (e = hipMalloc((void **)&p->d_stream, b_stream ? b_stream : 16)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_acc, b_acc)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void **)&p->d_counts, b_counts)) != hipSuccess) return fail(e);
-    if ((e = hipMemset(p->d_counts, 0, sizeof(uint32_t))) != hipSuccess) return fail(e);   // the compaction's ticket word
     if ((e = hipMalloc((void **)&p->d_queue, b_queue)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void **)&p->d_queue_count, 16)) != hipSuccess) return fail(e);
-    if ((e = hipMemset(p->d_queue_count, 0, 16)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_sync, gl::kSyncWords * sizeof(uint32_t))) != hipSuccess) return fail(e);
+    if ((e = hipMemset(p->d_sync, 0, gl::kSyncWords * sizeof(uint32_t))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_bins, b_bins)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_bin_base, b_tiles)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_cursor, b_tiles)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_state, b_tiles)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(p->d_bin_base, 0, b_tiles)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(p->d_cursor, 0, b_tiles)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(p->d_state, 0, b_tiles)) != hipSuccess) return fail(e);
+    if ((e = hipHostMalloc((void **)&p->h_rec, 64, hipHostMallocDefault)) != hipSuccess) return fail(e);
+    *p->h_rec = 0ull;
     if ((e = hipMalloc((void **)&p->d_long_chunks, (long_chunks.size() + 1u) * sizeof(uint4))) != hipSuccess) return fail(e);
     if (!long_chunks.empty() &&
         (e = hipMemcpy(p->d_long_chunks, long_chunks.data(), long_chunks.size() * sizeof(uint4), hipMemcpyHostToDevice)) != hipSuccess)
@@ -1083,7 +964,29 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     if (!on_device && (e = hipMemcpy(p->d_indptr, indptr.data(), b_indptr, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if (!on_device && b_stream && (e = hipMemcpy(p->d_stream, stream.data(), b_stream, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e);   // the memsets above ran on the null stream
-    p->device_bytes = b_indptr + b_stream + b_acc + b_counts + b_queue + long_chunks.size() * sizeof(uint4);
+    if (p->binned && kept) {
+        // the bins' capacities: non-zeros per row tile, counted on the device from the stream just built (d_cursor serves as the
+        // counter and is cleared again)
+        gl::spmspv_tile_count_kernel<<<std::min<uint32_t>(gl::cdiv(kept, 8192), (uint32_t)gl::ctx().num_cus * 2u), 1024>>>(
+            p->d_stream, kept, row_begin, p->tiles, p->d_cursor);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e);
+        std::vector<uint32_t> cap(ntiles + 1u, 0u);
+        if ((e = hipMemcpy(cap.data(), p->d_cursor, (size_t)ntiles * sizeof(uint32_t), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e);
+        uint64_t run = 0;
+        for (uint32_t t = 0; t <= ntiles; t++) {
+            const uint32_t c = t < ntiles ? cap[t] : 0u;
+            cap[t] = (uint32_t)run;
+            run += c;
+        }
+        if (run != kept) {
+            gl_spmspv_plan_destroy(p);
+            return gl::set_error(GL_ERR_HIP, "gl_spmspv_plan_create: tile histogram counted %llu of %llu non-zeros", (unsigned long long)run, (unsigned long long)kept);
+        }
+        if ((e = hipMemcpy(p->d_bin_base, cap.data(), b_tiles, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+        if ((e = hipMemset(p->d_cursor, 0, b_tiles)) != hipSuccess) return fail(e);
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e);
+    }
+    p->device_bytes = b_indptr + b_stream + b_acc + 3u * b_tiles + b_queue + b_bins + long_chunks.size() * sizeof(uint4);
     gl::live_spmspv_plans().push_back(p);
     *plan = p;
     return GL_OK;
@@ -1096,9 +999,13 @@ int gl_spmspv_plan_destroy(gl_spmspv_plan p) {
     (void)hipFree(p->d_indptr);
     (void)hipFree(p->d_stream);
     (void)hipFree(p->d_acc);
-    (void)hipFree(p->d_counts);
     (void)hipFree(p->d_queue);
-    (void)hipFree(p->d_queue_count);
+    (void)hipFree(p->d_sync);
+    (void)hipFree(p->d_bins);
+    (void)hipFree(p->d_bin_base);
+    (void)hipFree(p->d_cursor);
+    (void)hipFree(p->d_state);
+    if (p->h_rec) (void)hipHostFree(p->h_rec);
     (void)hipFree(p->d_mode);
     (void)hipFree(p->d_long_chunks);
     (void)hipFree(p->d_bfs_acc);
@@ -1187,6 +1094,9 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     const uint64_t work_hint = gl::env_long("GRAPHLILY_SPMSPV_WORK_HINT", 1) != 0 ? p->work_hint : ~0ull;
     const uint32_t longest_hint = p->longest_hint;
     p->work_hint = ~0ull;
+    const uint32_t nnz_hint = p->nnz_hint;
+    p->nnz_hint = ~0u;
+    p->rec_pending = false;
     if (tiny) {
         p->frontier_hint = ~0ull;
         p->frontier_bits = nullptr;
@@ -1242,40 +1152,49 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     }
     p->last_decided_on_device = may_pull;   // gl_spmspv_last_direction: else the run scattered, nothing to read back
 
-    gl::ScatterArgs a;
+    gl::BinArgs a;
     a.gate = gate;
     a.mode = may_pull ? p->d_mode : nullptr;
     a.indptr = p->d_indptr;
     a.stream = p->d_stream;
     a.vec = d_vector;
+    a.bins = p->d_bins;
+    a.bin_base = p->d_bin_base;
+    a.cursor = p->d_cursor;
     a.acc = p->d_acc;
-    a.queue_count = p->d_queue_count;
+    a.sync = p->d_sync;
     a.queue = p->d_queue;
+    // (a caller that knows the vector's longest column spares the run the queue phase: one rendezvous of the grid)
     a.queue_capacity = (work_hint != ~0ull && longest_hint < gl::kBigColumn) ? 0u : p->queue_capacity;
+    a.tiles = p->tiles;
+    a.binned = p->binned ? 1u : 0u;
     a.row_begin = p->row_begin;
     a.num_cols = p->num_cols;
-    uint32_t grid = gl::cdiv(p->num_cols, 256);
-    uint32_t cap = (uint32_t)gl::ctx().num_cus * 8u;
-    if (grid > cap) grid = cap;
+    // at most one workgroup per compute unit (the queue phase waits for every workgroup of the grid: all must be resident),
+    // fewer when the caller has said how short the vector is
+    uint32_t grid = (uint32_t)gl::ctx().num_cus;
+    if (nnz_hint != ~0u) grid = std::min<uint32_t>(grid, std::max<uint32_t>(nnz_hint, 1u));
     if (grid == 0) grid = 1;
-    int rc;
-    switch (op + 3 * val_type) {
-        case GL_OP_MULADD: rc = gl::launch_scatter<GL_OP_MULADD>(a, grid, s); break;
-        case GL_OP_ANDOR: rc = gl::launch_scatter<GL_OP_ANDOR>(a, grid, s); break;
-        case GL_OP_ADDMIN: rc = gl::launch_scatter<GL_OP_ADDMIN>(a, grid, s); break;
-        case gl::kOpU32MulAdd: rc = gl::launch_scatter<gl::kOpU32MulAdd>(a, grid, s); break;
-        case gl::kOpU32AndOr: rc = gl::launch_scatter<gl::kOpU32AndOr>(a, grid, s); break;
-        case gl::kOpU32AddMin: rc = gl::launch_scatter<gl::kOpU32AddMin>(a, grid, s); break;
-        case gl::kOpFixMulAdd: rc = gl::launch_scatter<gl::kOpFixMulAdd>(a, grid, s); break;
-        case gl::kOpFixAndOr: rc = gl::launch_scatter<gl::kOpFixAndOr>(a, grid, s); break;
-        case gl::kOpFixAddMin: rc = gl::launch_scatter<gl::kOpFixAddMin>(a, grid, s); break;
-        default: return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmspv_run: semiring op %d is not offered for value type %d", op, val_type);
+    int rc = GL_OK;
+    if (nrows > 0) {
+        switch (op + 3 * val_type) {
+            case GL_OP_MULADD: gl::spmspv_bin_kernel<GL_OP_MULADD><<<grid, gl::kBinThreads, 0, s>>>(a); break;
+            case GL_OP_ANDOR: gl::spmspv_bin_kernel<GL_OP_ANDOR><<<grid, gl::kBinThreads, 0, s>>>(a); break;
+            case GL_OP_ADDMIN: gl::spmspv_bin_kernel<GL_OP_ADDMIN><<<grid, gl::kBinThreads, 0, s>>>(a); break;
+            case gl::kOpU32MulAdd: gl::spmspv_bin_kernel<gl::kOpU32MulAdd><<<grid, gl::kBinThreads, 0, s>>>(a); break;
+            case gl::kOpU32AndOr: gl::spmspv_bin_kernel<gl::kOpU32AndOr><<<grid, gl::kBinThreads, 0, s>>>(a); break;
+            case gl::kOpU32AddMin: gl::spmspv_bin_kernel<gl::kOpU32AddMin><<<grid, gl::kBinThreads, 0, s>>>(a); break;
+            case gl::kOpFixMulAdd: gl::spmspv_bin_kernel<gl::kOpFixMulAdd><<<grid, gl::kBinThreads, 0, s>>>(a); break;
+            case gl::kOpFixAndOr: gl::spmspv_bin_kernel<gl::kOpFixAndOr><<<grid, gl::kBinThreads, 0, s>>>(a); break;
+            case gl::kOpFixAddMin: gl::spmspv_bin_kernel<gl::kOpFixAddMin><<<grid, gl::kBinThreads, 0, s>>>(a); break;
+            default: return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmspv_run: semiring op %d is not offered for value type %d", op, val_type);
+        }
+        GL_LAUNCH_CHECK();
     }
-    if (rc != GL_OK) return rc;
     if (may_pull && op != GL_OP_ANDOR) {
         // row-wise (+,x) / (min,+): frontier -> dense x (0 / +inf elsewhere) -> SpMV on the attached general /
-        // pattern plan into the accumulator (same zero, no mask: the compaction applies the mask); its kernels
-        // return at once on a scatter run
+        // pattern plan into the accumulator (same zero, no mask: the fold applies the mask); its kernels
+        // return at once on a run that bins
         uint32_t bgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 8u);
         gl::spmspv_clear_dense_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(reinterpret_cast<float4 *>(p->d_xdense), gl::cdiv(p->num_cols, 4),
                                                                         op == GL_OP_MULADD ? 0.0f : __builtin_inff(), p->d_mode);
@@ -1286,7 +1205,7 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
         if (rc != GL_OK) return rc;
     } else if (may_pull) {
         // row-wise: frontier -> bit vector -> boolean SpMV into the (all-zero) accumulator; both kernels return
-        // at once when the run is a scatter run
+        // at once when the run bins
         if (p->frontier_bits) {
             // the caller keeps the frontier as bits anyway (a device-resident BFS schedule): no clear + list -> bits pass
             rc = gl::bool_plan_run_bits(p->pull, p->d_acc - p->row_begin, p->d_mode, s, p->frontier_bits);
@@ -1301,36 +1220,70 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
         if (rc != GL_OK) return rc;
     }
 
-    if (val_type != GL_VAL_FLOAT) {
-        switch (mask_type) {
-            case GL_NOMASK: {
-                gl::AccSource<GL_NOMASK, true> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
-                return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
+    // ---- fold: one workgroup per row tile
+    gl::FoldArgs f;
+    f.bins = p->d_bins;
+    f.bin_base = p->d_bin_base;
+    f.cursor = p->d_cursor;
+    f.acc = p->d_acc;
+    f.mask = d_mask;
+    f.mask_type = mask_type;
+    f.nrows = nrows;
+    f.row_begin = p->row_begin;
+    f.zero = zero;
+    f.tiles = p->tiles;
+    f.out = d_result;
+    f.head_val = zero;
+    f.assign = d_inout;
+    f.assign_val = val;
+    f.next_bits = d_next_bits;
+    f.state = p->d_state;
+    f.sync = p->d_sync;
+    f.tickets = p->fold_tickets ? 1u : 0u;
+    f.merge_all = p->binned ? 0u : 1u;
+    f.mode = may_pull ? p->d_mode : nullptr;
+    f.gate = gate;
+    f.dir = dir;
+    // a run that is neither gated nor being recorded into a graph reports its completion to the host (gl_spmspv_wait)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool report = d_gate == nullptr && cap == hipStreamCaptureStatusNone && p->h_rec != nullptr;
+    f.host_rec = report ? p->h_rec : nullptr;
+    f.seq = report ? ++p->seq : 0u;
+    p->rec_pending = report;
+    return gl::launch_fold(op + 3 * val_type, f, s);
+}
+
+int gl_spmspv_wait(gl_spmspv_plan p, uint32_t *nnz) {
+    GL_TRACE();
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr);
+    if (p->rec_pending) {
+        // the fold's last workgroup stores seq << 32 | count to page-locked memory once every result has been written: the host
+        // sees it ~5 us before hipStreamSynchronize returns (profiles/r03_ubench_sync.txt)
+        volatile unsigned long long *rec = p->h_rec;
+        const unsigned long long want = (unsigned long long)p->seq;
+        for (uint64_t spins = 0;; spins++) {
+            const unsigned long long v = *rec;
+            if ((v >> 32) == want) {
+                if (nnz) *nnz = (uint32_t)v;
+                return GL_OK;
             }
-            case GL_MASK_WRITETOZERO: {
-                gl::AccSource<GL_MASK_WRITETOZERO, true> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
-                return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
-            }
-            default: {
-                gl::AccSource<GL_MASK_WRITETOONE, true> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
-                return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
-            }
+            if (spins > (1ull << 16) && hipStreamQuery(gl::ctx().stream) != hipErrorNotReady) break;   // the stream is idle (or failed)
+            __builtin_ia32_pause();
         }
+        GL_HIP(hipStreamSynchronize(gl::ctx().stream));
+        const unsigned long long v = *rec;
+        if ((v >> 32) == want) {
+            if (nnz) *nnz = (uint32_t)v;
+            return GL_OK;
+        }
+        return gl::set_error(GL_ERR_HIP, "gl_spmspv_wait: the run finished without its completion record (sequence %u, found %u)", p->seq,
+                             (uint32_t)(v >> 32));
     }
-    switch (mask_type) {
-        case GL_NOMASK: {
-            gl::AccSource<GL_NOMASK> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
-            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
-        }
-        case GL_MASK_WRITETOZERO: {
-            gl::AccSource<GL_MASK_WRITETOZERO> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
-            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
-        }
-        default: {
-            gl::AccSource<GL_MASK_WRITETOONE> src{p->d_acc, d_mask, nrows, p->row_begin, zero, d_inout, val, d_next_bits};
-            return gl::run_compaction(src, nrows, p->d_counts, d_result, zero, s, p->d_queue_count, gate, dir);
-        }
-    }
+    GL_HIP(hipStreamSynchronize(gl::ctx().stream));
+    if (nnz) *nnz = 0xffffffffu;   // no record: read the head element (gl_sparse_nnz)
+    return GL_OK;
 }
 
 int gl_spmspv_plan_attach_pull(gl_spmspv_plan p, gl_spmv_plan pull) {
@@ -1364,6 +1317,7 @@ int gl_spmspv_plan_frontier_bits(gl_spmspv_plan p, const uint32_t *d_bits) {
 int gl_spmspv_plan_hint_tiny(gl_spmspv_plan p, uint32_t vector_nnz, uint64_t work) {
     GL_ARG(p != nullptr);
     p->tiny_hint = vector_nnz <= gl::kTinyVec && work <= gl::kTinyWork;
+    p->nnz_hint = vector_nnz;
     return GL_OK;
 }
 
@@ -1372,12 +1326,14 @@ int gl_spmspv_plan_hint_work(gl_spmspv_plan p, uint32_t vector_nnz, uint64_t wor
     p->tiny_hint = vector_nnz <= gl::kTinyVec && work <= gl::kTinyWork;
     p->work_hint = work;
     p->longest_hint = longest_column;
+    p->nnz_hint = vector_nnz;
     return GL_OK;
 }
 
 int gl_spmspv_plan_hint(gl_spmspv_plan p, uint32_t vector_nnz_upper_bound) {
     GL_ARG(p != nullptr);
     p->frontier_hint = vector_nnz_upper_bound;
+    p->nnz_hint = vector_nnz_upper_bound;
     return GL_OK;
 }
 
@@ -1532,7 +1488,15 @@ static int bfs_bits_shard_launch(gl_spmspv_plan p, gl_spmv_plan rows, const uint
     sa.finish = finish ? 1u : 0u;
     sa.pull_units = 0;
     // (one workgroup per compute unit fits next to the pull's LDS tile: a larger grid would run in rounds)
-    sa.push_blocks = std::min<uint32_t>((uint32_t)gl::ctx().num_cus, std::max<uint32_t>(gl::cdiv(a.col_words, 64), 1u));
+    // bits per lane of the scattering push: halve the strips until they cover the wavefronts of a one-workgroup-per-CU grid
+    {
+        const uint64_t waves = (uint64_t)gl::ctx().num_cus * (gl::kThreads / 64u), bits = (uint64_t)a.col_words * 32u;
+        uint32_t bpl = 32u;
+        while (bpl > 1u && 2u * gl::cdiv(bits, 64u * bpl) <= waves) bpl >>= 1;
+        a.bpl = bpl;
+        const uint32_t nstrips = std::max<uint32_t>(gl::cdiv(bits, 64u * bpl), 1u);
+        sa.push_blocks = std::min<uint32_t>((uint32_t)gl::ctx().num_cus, gl::cdiv(nstrips, gl::kThreads / 64u));
+    }
     gl::BfsBitsCtl &c = sa.prev;
     c.ctl = nullptr;
     c.slot = slot - 1u;

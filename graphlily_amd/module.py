@@ -399,7 +399,7 @@ class SpMSpVModule(BaseModule):
         tiny = self._hint_tiny()
         self.plan_.run(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
                        self.mask_type_)
-        self._finish()
+        self._finish_run()
         if tiny:      # this run wrote the results and the accumulator, not the vector
             self.tiny_ = (self.tiny_[0], self.tiny_[1], BaseModule.device_writes_, self.tiny_[3])
 
@@ -409,7 +409,7 @@ class SpMSpVModule(BaseModule):
         mask = self.mask_buf if self.mask_type_ != kNoMask else None
         self.plan_.run_assign(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
                               self.mask_type_, inout_buf, val)
-        self._finish()
+        self._finish_run()
 
     def run_gated(self, vector_buf, results_buf, inout_buf, val, next_bits, gate, gate_value, gate_op, ctl=None, slot=0,
                   threshold=0.0, may_continue=False):
@@ -420,7 +420,24 @@ class SpMSpVModule(BaseModule):
         self.plan_.run_gated(vector_buf, mask, results_buf, self.semiring_.op, self.semiring_.zero, self.mask_type_,
                              inout_buf, val, next_bits, gate, gate_value, gate_op, ctl, slot, threshold, may_continue)
 
+    def _finish_run(self):
+        """A blocking run waits for the operator's own completion record (gl_spmspv_wait: the fold's last workgroup stores the
+        result count to page-locked memory) instead of the whole stream, and remembers the count for get_results_nnz."""
+        BaseModule.device_writes_ += 1
+        self.nnz_known_ = None
+        if self.blocking:
+            n = self.plan_.wait()
+            if n is not None:
+                self.nnz_known_ = (n, self.results_buf, BaseModule.device_writes_)
+
     def get_results_nnz(self):
+        k = getattr(self, "nnz_known_", None)
+        if k is not None and k[1] is self.results_buf and k[2] == BaseModule.device_writes_:
+            return k[0]       # (no module call has written device memory since the run reported it)
+        if not self.blocking and getattr(self.plan_, "wait", None) is not None:
+            n = self.plan_.wait()       # the run's own completion record, if it kept one: no device -> host copy
+            if n is not None:
+                return n
         return capi.sparse_nnz(self.results_buf)
 
     def send_vector_device_to_host(self):

@@ -175,8 +175,27 @@ public:
         hint_stamp_ = fresh ? calls_() : 0;      // (a run reads the vector: the knowledge stays good)
         GRAPHLILY_CHECK(gl_spmspv_run_typed(plan_, vector_buf.ptr(), mask_type_ == kNoMask ? nullptr : mask_buf.ptr(), results_buf.ptr(),
                                             (int)semiring_.op, VK::bits(semiring_.zero), (int)mask_type_, VK::kind));
-        finish_();
+        finish_run_();
     }
+
+private:
+    // The result count of the last run, if that run reported it (gl_spmspv_wait: the operator's last workgroup stores it to
+    // page-locked memory) and nothing has been enqueued by any module since.
+    uint32_t known_nnz_ = 0;
+    uint64_t known_stamp_ = 0;
+    // a blocking run waits for the operator's own completion record instead of the whole stream
+    void finish_run_() {
+        known_stamp_ = 0;
+        if (!blocking_) return;
+        uint32_t nnz = 0xffffffffu;
+        GRAPHLILY_CHECK(gl_spmspv_wait(plan_, &nnz));
+        if (nnz != 0xffffffffu) {
+            known_nnz_ = nnz;
+            known_stamp_ = calls_();
+        }
+    }
+
+public:
     // extension (gl_spmspv_run_assign): run() + AssignVectorSparseModule::run(val) with the results as its mask and
     // `inout` as its inout (the push iteration of app/bfs.h:146-148) in one call
     void run_assign(DeviceBuffer inout, vector_data_t val) {
@@ -191,7 +210,7 @@ public:
                                              mask_type_ == kNoMask ? nullptr : (const float *)mask_buf.ptr(),
                                              (gl_idx_val *)results_buf.ptr(), (int)semiring_.op, (float)semiring_.zero,
                                              (int)mask_type_, (float *)inout.ptr(), (float)val));
-        finish_();
+        finish_run_();
     }
 
     aligned_sparse_vec_t send_vector_device_to_host() { return download_sparse_(vector_buf); }
@@ -207,8 +226,13 @@ public:
     uint32_t get_results_nnz() {
         barrier_();
         if (hint_fresh_()) hint_stamp_ = calls_();   // (reads only)
-        uint32_t nnz = 0;
-        GRAPHLILY_CHECK(gl_sparse_nnz((const gl_idx_val *)results_buf.ptr(), &nnz));
+        if (known_stamp_ != 0 && known_stamp_ + 1 == calls_()) {   // the run itself reported the count: no copy
+            known_stamp_ = calls_();
+            return known_nnz_;
+        }
+        uint32_t nnz = 0xffffffffu;
+        if (!blocking_ && plan_) GRAPHLILY_CHECK(gl_spmspv_wait(plan_, &nnz));   // (the run's own record, if it kept one)
+        if (nnz == 0xffffffffu) GRAPHLILY_CHECK(gl_sparse_nnz((const gl_idx_val *)results_buf.ptr(), &nnz));
         return nnz;
     }
 

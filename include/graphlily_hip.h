@@ -290,6 +290,14 @@ int gl_spmspv_plan_info(gl_spmspv_plan plan, uint64_t *nnz, uint64_t *device_byt
  * at FLOAT_INF = 999999999 (hw/float_pe.h:24-33). */
 int gl_spmspv_run(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask,
                   gl_idx_val *d_result, int op, float zero, int mask_type);
+/* Blocks until the LAST gl_spmspv_run* enqueued on this plan has written its result list, and returns the result count
+ * (SpMSpVModule::run is blocking, and get_results_nnz follows it in every push loop: module/spmspv_module.h:436-441,
+ * :239-242).  The operator's last workgroup stores {sequence, count} to page-locked host memory once every result is in
+ * device memory, so the host neither waits for the stream's completion signal nor copies the head element back (~5 us
+ * + a 4-byte copy per call).  Runs that are gated, recorded into a graph or done by the one-launch kernel keep no record:
+ * the call is then gl_sync and *nnz = 0xffffffff (read the head element with gl_sparse_nnz).  Work enqueued on OTHER streams
+ * is not waited for. */
+int gl_spmspv_wait(gl_spmspv_plan plan, uint32_t *nnz);
 /* Extension: gl_spmspv_run followed by gl_assign_sparse(d_result, d_inout, val) -- the push iteration of BFS
  * (app/bfs.h:146-148: SpMSpV, then AssignVectorSparse::run(val) with the result as its mask) -- with the assign
  * done by the pass that writes the result list (one launch and one read of the list less).  d_inout may be the
