@@ -41,8 +41,7 @@ struct gl_spmspv_plan_s {
     uint32_t *d_cursor = nullptr;      // tiles, zero between runs
     uint32_t *d_state = nullptr;       // tiles, zero between runs
     uint32_t *d_sync = nullptr;        // gl::kSyncWords, zero between runs
-    unsigned long long *d_queue = nullptr;   // chunk descriptors of long columns (two words each)
-    uint32_t queue_capacity = 0;
+    unsigned long long *d_slices = nullptr;  // gl::kBinMaxSlices tagged slice sums of the bin kernel's rendezvous
     // a blocking caller's completion record: the fold's last workgroup stores seq << 32 | count (gl_spmspv_wait)
     unsigned long long *h_rec = nullptr;     // page-locked, device-visible
     uint32_t seq = 0;                        // of the last run that was given the record
@@ -909,14 +908,6 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     p->d_indptr = dev_indptr;   // (null unless the device built them)
     p->d_stream = dev_stream;
     const uint32_t nrows = row_end - row_begin;
-    // one slot per chunk of every long column: a column of deg >= kBigColumn entries yields ceil(deg / kChunk) chunks.  A vector
-    // that lists a column twice can still exceed it; the bin kernel then processes the surplus chunks itself.
-    uint64_t chunks = 0;
-    for (uint32_t c = 0; c < num_cols; c++) {
-        const uint32_t d = indptr[c + 1] - indptr[c];
-        if (d >= gl::kBigColumn) chunks += (d + gl::kChunk - 1u) / gl::kChunk;
-    }
-    p->queue_capacity = chunks ? (uint32_t)std::min<uint64_t>(chunks + 1u, 0x7fffffffu) : 0u;
     p->tiles = gl::choose_tiles(nrows, (uint32_t)gl::ctx().num_cus);
     p->binned = p->tiles.count <= gl::kBinMaxTiles;
     p->fold_tickets = p->tiles.count > (uint32_t)gl::ctx().num_cus;
@@ -936,14 +927,19 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     size_t b_acc = (size_t)(nrows ? nrows : 1) * sizeof(float);
     const uint32_t ntiles = p->tiles.count;
     size_t b_tiles = (size_t)(ntiles + 1u) * sizeof(uint32_t);
-    size_t b_queue = ((size_t)p->queue_capacity + 1u) * 2u * sizeof(unsigned long long);
+    size_t b_queue = (size_t)gl::kBinMaxSlices * sizeof(unsigned long long);
     size_t b_bins = (p->binned && kept) ? kept * sizeof(uint2) : 16;
     if (!on_device && (e = hipMalloc((void **)&p->d_indptr, b_indptr)) != hipSuccess) return fail(e);
     if (!on_device && (e = hipMalloc((void **)&p->d_stream, b_stream ? b_stream : 16)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_acc, b_acc)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc((void **)&p->d_queue, b_queue)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&p->d_slices, b_queue)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(p->d_slices, 0, b_queue)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_sync, gl::kSyncWords * sizeof(uint32_t))) != hipSuccess) return fail(e);
     if ((e = hipMemset(p->d_sync, 0, gl::kSyncWords * sizeof(uint32_t))) != hipSuccess) return fail(e);
+    {
+        const uint32_t one = 1u;   // the bin kernel's generation: tags of the (all-zero) slice words start at 1
+        if ((e = hipMemcpy(p->d_sync + gl::kSyncGen, &one, sizeof(one), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    }
     if ((e = hipMalloc((void **)&p->d_bins, b_bins)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_bin_base, b_tiles)) != hipSuccess) return fail(e);
     if ((e = hipMalloc((void **)&p->d_cursor, b_tiles)) != hipSuccess) return fail(e);
@@ -999,7 +995,7 @@ int gl_spmspv_plan_destroy(gl_spmspv_plan p) {
     (void)hipFree(p->d_indptr);
     (void)hipFree(p->d_stream);
     (void)hipFree(p->d_acc);
-    (void)hipFree(p->d_queue);
+    (void)hipFree(p->d_slices);
     (void)hipFree(p->d_sync);
     (void)hipFree(p->d_bins);
     (void)hipFree(p->d_bin_base);
@@ -1092,7 +1088,6 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     const bool tiny = p->tiny_hint && val_type == GL_VAL_FLOAT && nrows > 0 && gl::env_long("GRAPHLILY_SPMSPV_TINY", 1) != 0;
     p->tiny_hint = false;
     const uint64_t work_hint = gl::env_long("GRAPHLILY_SPMSPV_WORK_HINT", 1) != 0 ? p->work_hint : ~0ull;
-    const uint32_t longest_hint = p->longest_hint;
     p->work_hint = ~0ull;
     const uint32_t nnz_hint = p->nnz_hint;
     p->nnz_hint = ~0u;
@@ -1163,17 +1158,17 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     a.cursor = p->d_cursor;
     a.acc = p->d_acc;
     a.sync = p->d_sync;
-    a.queue = p->d_queue;
-    // (a caller that knows the vector's longest column spares the run the queue phase: one rendezvous of the grid)
-    a.queue_capacity = (work_hint != ~0ull && longest_hint < gl::kBigColumn) ? 0u : p->queue_capacity;
+    a.slices = p->d_slices;
     a.tiles = p->tiles;
     a.binned = p->binned ? 1u : 0u;
     a.row_begin = p->row_begin;
     a.num_cols = p->num_cols;
-    // at most one workgroup per compute unit (the queue phase waits for every workgroup of the grid: all must be resident),
-    // fewer when the caller has said how short the vector is
+    // at most one workgroup per compute unit (the kernel's rendezvous waits for every workgroup of the grid: all must be
+    // resident), fewer when the caller has said how short the vector is
     uint32_t grid = (uint32_t)gl::ctx().num_cus;
-    if (nnz_hint != ~0u) grid = std::min<uint32_t>(grid, std::max<uint32_t>(nnz_hint, 1u));
+    if (work_hint != ~0ull) grid = (uint32_t)std::min<uint64_t>(grid, std::max<uint64_t>((work_hint + 2047u) / 2048u, 1u));
+    else if (nnz_hint != ~0u && (uint64_t)nnz_hint * p->max_col_len < 2048ull * grid)
+        grid = (uint32_t)std::max<uint64_t>(((uint64_t)nnz_hint * p->max_col_len + 2047u) / 2048u, 1u);
     if (grid == 0) grid = 1;
     int rc = GL_OK;
     if (nrows > 0) {
@@ -1244,6 +1239,8 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     f.mode = may_pull ? p->d_mode : nullptr;
     f.gate = gate;
     f.dir = dir;
+    f.bin_vec = nrows > 0 ? d_vector : nullptr;
+    f.bin_grid = grid;
     // a run that is neither gated nor being recorded into a graph reports its completion to the host (gl_spmspv_wait)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);

@@ -4,14 +4,15 @@
 // write compaction).  hw/kernel_spmspv_impl.h:448-562 does the same two things per row tile of its output buffer: the PEs
 // accumulate a tile (:492-540), then checkout_results + write_back_gmem compact it behind the tiles before it (:150-289).
 //
-//   bin   (spmspv_bin_kernel)   workgroups of 1024 threads take slices of the sparse input vector, read the active columns'
-//         {row, value} runs coalesced (a lane per product, the lane's column found by a binary search in the slice's prefix
-//         of column lengths), form the products, and sort a batch of 8192 of them by ROW TILE in LDS (counting sort: LDS
-//         histogram, scan, one global reservation per tile that occurs, sorted staging buffer) -- the batch then leaves as
-//         one contiguous run per tile into that tile's BIN.  A bin holds as many records as its row tile holds non-zeros, so
-//         it cannot overflow unless the vector names a column twice; products that find no room go to the dense
-//         accumulator with global atomics (slow, never wrong).  Columns of 2048 entries and more are cut into chunks that
-//         all workgroups drain from a queue once every workgroup has queued its own.
+//   bin   (spmspv_bin_kernel)   the run's products, numbered in vector order, are cut into equal ranges, one per workgroup of
+//         1024 threads (one rendezvous of the grid gives every workgroup the prefix of the column lengths over the vector: a
+//         hub column is shared by as many workgroups as its length asks for).  A workgroup reads its range of the active
+//         columns' {row, value} runs coalesced (a lane per product, the lane's column found by a binary search in the staged
+//         prefix), forms the products, and sorts a batch of 8192 of them by ROW TILE in LDS (counting sort: LDS histogram,
+//         scan, one global reservation per tile that occurs, sorted staging buffer) -- the batch then leaves as one
+//         contiguous run per tile into that tile's BIN.  A bin holds as many records as its row tile holds non-zeros, so it
+//         cannot overflow unless the vector names a column twice; products that find no room go to the dense accumulator
+//         with global atomics (slow, never wrong).
 //   fold  (spmspv_fold_kernel)  one workgroup per row tile: the tile's accumulators live in LDS (Tile<OP>: f64 adds for
 //         (+,x), ordered-integer min, stores), the bin is streamed into them, rows with a result != zero that the mask
 //         (compared with `zero`, spmspv_module.h:499-516) allows are counted, the count is published, the workgroup adds up
@@ -37,15 +38,16 @@ constexpr uint32_t kBinItems = 8;                          // products per threa
 constexpr uint32_t kBinBatch = kBinThreads * kBinItems;    // 8192 products are sorted by tile at a time
 constexpr uint32_t kBinMaxTiles = 2048;                    // LDS counters of the bin kernel
 constexpr uint32_t kBinSlice = 1024;                       // vector entries a workgroup stages at a time
-constexpr uint32_t kBigColumn = 2048;                      // columns at least this long go to the chunk queue
-constexpr uint32_t kChunk = kBinBatch;                     // entries per queued chunk = one batch
+constexpr uint32_t kBinMaxSlices = 2048;                   // slices of the vector per rendezvous (two per thread)
 constexpr uint32_t kFoldThreads = 1024;
 constexpr uint32_t kFoldMaxRows = 16384;                   // rows per tile: 128 KB of 8-byte accumulators
 constexpr uint32_t kFoldWaves = kFoldThreads / 64;
 constexpr uint32_t kFoldMaxRounds = kFoldMaxRows / kFoldThreads;   // 16 rounds of 1024 rows
 
-// words of gl_spmspv_plan_s::d_sync, all zero between runs
-enum : uint32_t { kSyncQueued = 0, kSyncQueueHead = 1, kSyncProducers = 2, kSyncFoldDone = 3, kSyncFoldTicket = 4, kSyncTotal = 5, kSyncWords = 16 };
+// words of gl_spmspv_plan_s::d_sync.  kSyncGen: the generation that tags the bin kernel's slice sums and the fold kernel's tile
+// states, starts at 1 and only grows (the fold's last tile advances it); kSyncFoldTicket: tiles handed out so far (64 bits,
+// only grows); kSyncFoldDone: zero between runs
+enum : uint32_t { kSyncGen = 0, kSyncFoldDone = 3, kSyncTotal = 5, kSyncFoldTicket = 8 /* 64 bits */, kSyncWords = 16 };
 
 // row -> tile without a division: tile = (row * magic) >> (32 + shift), checked on the host for every tile boundary at plan
 // creation (the function is monotone, so exact boundaries make it exact everywhere); magic == 0: rows per tile is 1 << shift
@@ -69,8 +71,7 @@ struct BinArgs {
     uint32_t *cursor;           // records reserved per tile (may exceed the capacity: the surplus went to acc)
     float *acc;                 // dense accumulator of the shard's rows
     uint32_t *sync;
-    unsigned long long *queue;  // two words per chunk: {first entry | count << 32, value bits}
-    uint32_t queue_capacity;    // 0: the vector is known to name no long column (no queue phase)
+    unsigned long long *slices; // kBinMaxSlices words: tag << 32 | non-zeros in the columns of a slice of the vector
     TileMap tiles;
     uint32_t binned;            // 0: more tiles than the kernel has counters for -- every product goes to acc
     uint32_t row_begin, num_cols;
@@ -169,16 +170,24 @@ struct BinLds {
     uint32_t lbase[kBinMaxTiles];    // where the tile's records start in `sorted`
     uint32_t dest[kBinMaxTiles];     // bins index of sorted[i] = dest[tile] + i (mod 2^32)
     uint32_t lim[kBinMaxTiles];      // first bins index past the tile's bin
-    uint32_t aux[kBinSlice];         // (queue overflow only: the columns' queue slots)
     uint2 sorted[kBinBatch];
+    unsigned long long wave64[16];
+    unsigned long long pre0, r_P, r_lo, r_hi;   // the rendezvous' results, from the workgroup's first wavefront
     uint32_t wave[16];
-    uint32_t word;
+    uint32_t tab[kBinBatch / 64u + 4u];   // column of every 64th product of the batch
+    uint32_t word, r_over;
 };
 
+// batches of up to this many products skip the LDS staging: sorting pays once a tile's run is a few hundred bytes long
+__host__ __device__ inline uint32_t bin_direct_limit(uint32_t tiles) { return min(kBinBatch - 1u, max(3072u, 24u * tiles)); }
+
 // One batch: the thread's kBinItems products {row (shard-local), z} with their `ok` flags -> bins.
+// `sorted` (block-uniform): a well-filled batch goes through the LDS staging buffer and leaves as one run per tile; a batch of
+// a few thousand products (a latency-bound run: ~10 records per tile) is stored straight from the registers, each record at
+// its tile's reservation + its rank in the tile -- two barriers instead of five, no scan.
 template <int OP>
 __device__ __forceinline__ void bin_batch(const BinArgs &a, BinLds &L, const uint32_t (&row)[kBinItems], const float (&z)[kBinItems],
-                                          const bool (&ok)[kBinItems]) {
+                                          const bool (&ok)[kBinItems], bool sorted) {
     const uint32_t tid = threadIdx.x;
     if (!a.binned) {
 #pragma unroll
@@ -198,32 +207,53 @@ __device__ __forceinline__ void bin_batch(const BinArgs &a, BinLds &L, const uin
     const uint32_t t0 = 2u * tid;
     if (t0 < a.tiles.count) {
         c0 = L.cnt[t0];
-        b0 = a.bin_base[t0];
-        b1 = a.bin_base[t0 + 1u];
+        if (t0 + 1u < a.tiles.count) c1 = L.cnt[t0 + 1u];
+        if (c0 | c1) {
+            b0 = a.bin_base[t0];
+            b1 = a.bin_base[t0 + 1u];
+            if (t0 + 1u < a.tiles.count) b2 = a.bin_base[t0 + 2u];
+        }
         if (c0) {
             L.cnt[t0] = 0u;
             g0 = atomicAdd(&a.cursor[t0], c0);
         }
-        if (t0 + 1u < a.tiles.count) {
-            c1 = L.cnt[t0 + 1u];
-            b2 = a.bin_base[t0 + 2u];
-            if (c1) {
-                L.cnt[t0 + 1u] = 0u;
-                g1 = atomicAdd(&a.cursor[t0 + 1u], c1);
-            }
+        if (c1) {
+            L.cnt[t0 + 1u] = 0u;
+            g1 = atomicAdd(&a.cursor[t0 + 1u], c1);
         }
+    }
+    if (!sorted) {
+        if (c0) {
+            L.dest[t0] = b0 + g0;
+            L.lim[t0] = b1;
+        }
+        if (c1) {
+            L.dest[t0 + 1u] = b1 + g1;
+            L.lim[t0 + 1u] = b2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kBinItems; k++) {
+            if (!ok[k]) continue;
+            const uint32_t pos = L.dest[t[k]] + rank[k];
+            if (pos < L.lim[t[k]])
+                a.bins[pos] = make_uint2(row[k], fbits(z[k]));
+            else
+                spill_one<OP>(a.acc, row[k], z[k]);   // the bin is full (a column named twice): dense accumulator
+        }
+        return;   // (the next batch passes a barrier before it writes dest / lim again)
     }
     uint32_t total;
     const uint32_t before = block_exclusive_1024(c0 + c1, L.wave, &total);
-    if (t0 < a.tiles.count) {
+    if (c0) {
         L.lbase[t0] = before;
         L.dest[t0] = b0 + g0 - before;
         L.lim[t0] = b1;
-        if (t0 + 1u < a.tiles.count) {
-            L.lbase[t0 + 1u] = before + c0;
-            L.dest[t0 + 1u] = b1 + g1 - (before + c0);
-            L.lim[t0 + 1u] = b2;
-        }
+    }
+    if (c1) {
+        L.lbase[t0 + 1u] = before + c0;
+        L.dest[t0 + 1u] = b1 + g1 - (before + c0);
+        L.lim[t0 + 1u] = b2;
     }
     __syncthreads();
 #pragma unroll
@@ -241,13 +271,13 @@ __device__ __forceinline__ void bin_batch(const BinArgs &a, BinLds &L, const uin
             if (pos < L.lim[tt])
                 a.bins[pos] = e;
             else
-                spill_one<OP>(a.acc, e.x, bitsf(e.y));   // the bin is full (a column named twice): dense accumulator
+                spill_one<OP>(a.acc, e.x, bitsf(e.y));
         }
     }
     // (no barrier here: the next batch passes two barriers before it writes lbase / dest / lim and three before `sorted`)
 }
 
-// a queued chunk (or a long column's chunk that found no queue slot): `count` <= kChunk consecutive stream entries times xv
+// `count` <= kBinBatch consecutive stream entries of one column times xv (the overflow path's unit of work)
 template <int OP>
 __device__ __forceinline__ void bin_chunk(const BinArgs &a, BinLds &L, uint32_t first, uint32_t count, float xv) {
     uint32_t row[kBinItems];
@@ -265,136 +295,235 @@ __device__ __forceinline__ void bin_chunk(const BinArgs &a, BinLds &L, uint32_t 
         row[k] = rv[k].x - a.row_begin;
         ok[k] = ok[k] && spmspv_product<OP>(bitsf(rv[k].y), xv, z[k]);
     }
-    bin_batch<OP>(a, L, row, z, ok);
+    bin_batch<OP>(a, L, row, z, ok, count > bin_direct_limit(a.tiles.count));
 }
 
+// The products of a run are numbered 0 .. P - 1 in vector order and cut into EQUAL ranges, one per workgroup: a hub column is
+// shared by as many workgroups as its length asks for, a thousand short ones are one workgroup's batch -- no chunk queue, no
+// workgroup that runs four batches while the others wait.  P needs a prefix over the whole vector, so the kernel has ONE
+// rendezvous: the vector is cut into S <= 2048 slices of E entries; workgroup b adds up the column lengths of slices b,
+// b + G, ... and publishes each sum as a tagged word; every workgroup polls all S words (the grid is at most one workgroup
+// per compute unit: all are resident), scans them, finds the slice its range starts in and from there stages 1024 vector
+// entries at a time (their prefix of column lengths in LDS), a lane per product, the lane's column by binary search.
+// Tags: sync[kSyncGen] + round; the last workgroup to leave advances the generation, so the words need no reset.
 template <int OP>
 __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
     __shared__ BinLds L;
     if (a.gate.closed()) return;
     if (a.mode && a.mode[0]) return;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, G = gridDim.x, blk = blockIdx.x;
     for (uint32_t i = tid; i < kBinMaxTiles; i += kBinThreads) L.cnt[i] = 0u;
     const uint32_t vnnz = a.vec[0].index;
-    // a small vector is spread over the whole grid (E entries per workgroup, down to one)
-    const uint32_t E = min(kBinSlice, max(1u, (vnnz + gridDim.x - 1u) / gridDim.x));
-    uint32_t steps = 0;          // of the binary search: the slice holds E <= 2^steps columns
-    while ((1u << steps) < E) steps++;
+    const uint32_t E = min(kBinSlice, max(1u, (vnnz + G - 1u) / G));
+    const uint32_t gen0 = a.sync[kSyncGen];
+    uint32_t rounds = 0;
     __syncthreads();
-    for (uint32_t slice = blockIdx.x * E; slice < vnnz; slice += gridDim.x * E) {
-        uint32_t start = 0, deg = 0;
-        float xv = 0.0f;
-        if (tid < E && slice + tid < vnnz) {
-            const gl_idx_val iv = a.vec[1u + slice + tid];
-            if (iv.index < a.num_cols) {
-                start = a.indptr[iv.index];
-                deg = a.indptr[iv.index + 1u] - start;
-                xv = iv.val;
+    for (unsigned long long rbase = 0; rbase < vnnz; rbase += (unsigned long long)kBinMaxSlices * E, rounds++) {
+        const uint32_t nv = (uint32_t)min((unsigned long long)vnnz - rbase, (unsigned long long)kBinMaxSlices * E);
+        const uint32_t S = (nv + E - 1u) / E;
+        const uint32_t tag = gen0 + rounds;
+        const gl_idx_val *vec = a.vec + 1u + rbase;
+        // ---- 1. the non-zeros in the columns of my slices
+        for (uint32_t sl = blk; sl < S; sl += G) {
+            unsigned long long deg = 0ull;
+            const uint32_t e = sl * E + tid;
+            if (tid < E && e < nv) {
+                const uint32_t col = vec[e].index;
+                if (col < a.num_cols) deg = a.indptr[col + 1u] - a.indptr[col];
             }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) deg += __shfl_down(deg, d);
+            if ((tid & 63u) == 0u) L.wave64[tid >> 6] = deg;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long sum = 0ull;
+                for (uint32_t k = 0; k < 16u; k++) sum += L.wave64[k];
+                const unsigned long long word = ((unsigned long long)tag << 32) | (sum > 0xfffffffeull ? 0xffffffffull : sum);
+                __hip_atomic_store(&a.slices[sl], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
         }
-        const bool big = a.queue_capacity != 0u && deg >= kBigColumn;
-        if (a.queue_capacity) {
-            // long columns -> queue chunks (one atomic per workgroup reserves the slots)
-            const uint32_t nchunks = big ? (deg + kChunk - 1u) / kChunk : 0u;
-            uint32_t qtotal;
-            const uint32_t qoff = block_exclusive_1024(nchunks, L.wave, &qtotal);
-            if (qtotal) {   // block-uniform
-                if (tid == 0) L.word = atomicAdd(&a.sync[kSyncQueued], qtotal);
-                __syncthreads();
-                const uint32_t qb = L.word + qoff;
-                for (uint32_t c = 0; c < nchunks; c++) {
-                    if (qb + c < a.queue_capacity) {
-                        const unsigned long long d0 = (unsigned long long)(start + c * kChunk) |
-                                                      ((unsigned long long)min(kChunk, deg - c * kChunk) << 32);
-                        // (agent-scope stores: another compute unit reads them after the producers' counter, no fence)
-                        __hip_atomic_store(&a.queue[2ull * (qb + c)], d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&a.queue[2ull * (qb + c) + 1ull], (unsigned long long)fbits(xv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                // The queue holds one slot per chunk of every long column (exact, computed at plan creation), so it can only
-                // run out when the input vector names a column more than once.  Chunks without a slot are binned right
-                // here by this workgroup.
-                if (L.word + qtotal > a.queue_capacity) {   // block-uniform
-                    L.pref[tid] = nchunks ? deg : 0u;
-                    L.start[tid] = start;
-                    L.val[tid] = xv;
-                    L.aux[tid] = qb;
-                    __syncthreads();
-                    for (uint32_t j = 0; j < kBinSlice; j++) {
-                        const uint32_t dj = L.pref[j];
-                        if (!dj) continue;
-                        const uint32_t nj = (dj + kChunk - 1u) / kChunk, qj = L.aux[j];
-                        const uint32_t c0 = qj >= a.queue_capacity ? 0u : min(nj, a.queue_capacity - qj);   // first chunk without a slot
-                        const uint32_t sj = L.start[j];
-                        const float xj = L.val[j];
-                        for (uint32_t c = c0; c < nj; c++) {
-                            __syncthreads();
-                            bin_chunk<OP>(a, L, sj + c * kChunk, min(kChunk, dj - c * kChunk), xj);
+        // ---- 2. everybody's sums: total, overflow, my range's first slice.  ONE wavefront per workgroup polls the tagged
+        // words (sixteen wavefronts polling 250 words each queued up at the handful of lines the words live in: 5 us from the
+        // last publication to the release; one counter that every workgroup adds to and polls is slower still, same-box
+        // 8 us against 4) and scans them in registers; the results reach the other wavefronts through LDS.
+        if (tid < 64u) {
+            const uint32_t lane = tid;
+            unsigned long long P = 0ull, pre0 = 0ull, lo = 0ull, Q = 0ull;
+            uint32_t s0 = 0xffffffffu;
+            bool over = false;
+            for (uint32_t pass = 0; pass < 2u; pass++) {       // pass 0: the total; pass 1: the slice my range starts in
+                unsigned long long run = 0ull;
+                for (uint32_t q0 = 0; q0 < S; q0 += 64u) {
+                    const uint32_t sl = q0 + lane;
+                    unsigned long long v = 0ull;
+                    if (sl < S) {
+                        unsigned long long w;
+                        uint32_t spins = 0;
+                        while ((uint32_t)((w = __hip_atomic_load(&a.slices[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag && ++spins < (1u << 24))
+                            __builtin_amdgcn_s_sleep(1);
+                        v = w & 0xffffffffull;
+                        if (v == 0xffffffffull) {
+                            over = true;
+                            v = 1ull << 40;
                         }
                     }
+                    unsigned long long incl = v;
+#pragma unroll
+                    for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
+                        const unsigned long long up = __shfl_up(incl, dlt);
+                        if (lane >= dlt) incl += up;
+                    }
+                    if (pass == 1u) {
+                        const unsigned long long pre = run + incl - v;
+                        const unsigned long long hit = __ballot(pre <= lo && lo < pre + v);
+                        if (hit) {
+                            const int src = __ffsll((unsigned long long)hit) - 1;
+                            s0 = q0 + (uint32_t)src;
+                            pre0 = __shfl(pre, src);
+                        }
+                    }
+                    run += __shfl(incl, 63);
+                    if (s0 != 0xffffffffu) break;
+                }
+                if (pass == 0u) {
+                    P = run;
+                    over = __any(over) || P > 0xfffffffeull;
+                    // equal ranges of products, at least 2048 (a batch that small is mostly fixed cost), whole groups of 64
+                    Q = (max((P + G - 1u) / G, 2048ull) + 63ull) & ~63ull;
+                    lo = (unsigned long long)blk * Q;
+                    if (over || lo >= P) break;
+                }
+            }
+            if (lane == 0) {
+                L.r_P = P;
+                L.r_lo = lo;
+                L.r_hi = min(lo + Q, P);
+                L.pre0 = pre0;
+                L.word = s0;
+                L.r_over = over ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        const unsigned long long P = L.r_P, lo = L.r_lo, hi = L.r_hi, pre0 = L.pre0;
+        const uint32_t s0 = L.word;
+        const bool over = L.r_over != 0u;
+        if (over) {
+            // ---- a vector that names columns again and again (the total does not fit 32 bits): every workgroup takes its own
+            // slices, column by column -- slow, never wrong
+            for (uint32_t sl = blk; sl < S; sl += G) {
+                uint32_t start = 0, deg = 0;
+                float xv = 0.0f;
+                const uint32_t e = sl * E + tid;
+                if (tid < E && e < nv) {
+                    const gl_idx_val iv = vec[e];
+                    if (iv.index < a.num_cols) {
+                        start = a.indptr[iv.index];
+                        deg = a.indptr[iv.index + 1u] - start;
+                        xv = iv.val;
+                    }
                 }
                 __syncthreads();
-            }
-        }
-        // the rest: a lane per product
-        uint32_t W;
-        const uint32_t pre = block_exclusive_1024(big ? 0u : deg, L.wave, &W);
-        L.start[tid] = start;
-        L.pref[tid] = pre;
-        L.val[tid] = xv;
-        if (tid == kBinThreads - 1u) L.pref[kBinSlice] = W;
-        __syncthreads();
-        for (uint32_t w0 = 0; w0 < W; w0 += kBinBatch) {
-            uint32_t row[kBinItems];
-            float z[kBinItems], xs[kBinItems];
-            bool ok[kBinItems];
-            uint2 rv[kBinItems];
-#pragma unroll
-            for (uint32_t k = 0; k < kBinItems; k++) {
-                const uint32_t item = w0 + k * kBinThreads + tid;
-                ok[k] = item < W;
-                uint32_t lo = 0, hi = E - 1u;     // largest j with pref[j] <= item (zero-length columns share a prefix:
-                for (uint32_t it = 0; it < steps; it++) {   // the largest such j owns the item)
-                    const uint32_t mid = (lo + hi + 1u) >> 1;
-                    if (L.pref[mid] <= item) lo = mid; else hi = mid - 1u;
+                L.start[tid] = start;
+                L.pref[tid] = deg;
+                L.val[tid] = xv;
+                __syncthreads();
+                for (uint32_t j = 0; j < E; j++) {
+                    const uint32_t dj = L.pref[j], sj = L.start[j];
+                    const float xj = L.val[j];
+                    for (uint32_t c = 0; c < dj; c += kBinBatch) {
+                        __syncthreads();
+                        bin_chunk<OP>(a, L, sj + c, min(kBinBatch, dj - c), xj);
+                    }
                 }
-                xs[k] = L.val[lo];
-                rv[k] = ok[k] ? load_stream_nt(a.stream + L.start[lo] + (item - L.pref[lo])) : make_uint2(a.row_begin, 0u);
             }
+            __syncthreads();
+            continue;
+        }
+        // (equal ranges of products, at least 2048 -- a batch that small is mostly fixed cost --, whole groups of 64)
+        if (lo >= P) {                    // block-uniform: nothing left for this workgroup
+            __syncthreads();              // (the next round's rendezvous rewrites the results in LDS)
+            continue;
+        }
+        unsigned long long cur = pre0;                // products in front of the staged window
+        for (uint32_t ebase = s0 * E; cur < hi && ebase < nv; ebase += kBinSlice) {
+            // ---- stage up to 1024 vector entries: first stream entry, exclusive prefix of the lengths, value
+            const uint32_t nent = min(kBinSlice, nv - ebase);
+            uint32_t start = 0, deg = 0;
+            float xv = 0.0f;
+            if (tid < nent) {
+                const gl_idx_val iv = vec[ebase + tid];
+                if (iv.index < a.num_cols) {
+                    start = a.indptr[iv.index];
+                    deg = a.indptr[iv.index + 1u] - start;
+                    xv = iv.val;
+                }
+            }
+            uint32_t W;
+            const uint32_t pw = block_exclusive_1024(deg, L.wave, &W);
+            L.start[tid] = start;
+            L.pref[tid] = pw;
+            L.val[tid] = xv;
+            __syncthreads();
+            uint32_t steps = 0;          // of the binary search: nent <= 2^steps
+            while ((1u << steps) < nent) steps++;
+            const uint32_t direct_limit = bin_direct_limit(a.tiles.count);
+            // my products inside the window: [a0, a1) of its W
+            const uint32_t a0 = lo > cur ? (uint32_t)(lo - cur) : 0u;
+            const uint32_t a1 = (uint32_t)min((unsigned long long)W, hi - cur);
+            for (uint32_t w0 = a0; w0 < a1; w0 += kBinBatch) {
+                uint32_t row[kBinItems];
+                float z[kBinItems], xs[kBinItems];
+                bool ok[kBinItems];
+                uint2 rv[kBinItems];
+                // the column of every 64th product of the batch (129 ten-step searches by three wavefronts), so that the
+                // per-product search below only looks between its group's two marks -- a lane-wide ten-step search per
+                // product was 3-5 us of instruction issue per batch (16 wavefronts x 8 products x 10 steps x 6 instructions)
+                if (tid <= kBinBatch / 64u) {
+                    const uint32_t item = min(w0 + 64u * tid, a1 - 1u);
+                    uint32_t l2 = 0, h2 = nent - 1u;     // largest j with pref[j] <= item (zero-length columns share a prefix:
+                    for (uint32_t it = 0; it < steps; it++) {   // the largest such j owns the item)
+                        const uint32_t mid = (l2 + h2 + 1u) >> 1;
+                        if (L.pref[mid] <= item) l2 = mid; else h2 = mid - 1u;
+                    }
+                    L.tab[tid] = l2;
+                }
+                __syncthreads();
+                const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-            for (uint32_t k = 0; k < kBinItems; k++) {
-                row[k] = rv[k].x - a.row_begin;
-                ok[k] = ok[k] && spmspv_product<OP>(bitsf(rv[k].y), xs[k], z[k]);
+                for (uint32_t k = 0; k < kBinItems; k++) {
+                    const uint32_t item = w0 + k * kBinThreads + tid;
+                    ok[k] = item < a1;
+                    const uint32_t g = k * (kBinThreads / 64u) + wv;        // wave-uniform
+                    uint32_t l2 = L.tab[g], h2 = L.tab[g + 1u];
+                    const uint32_t span = __builtin_amdgcn_readfirstlane(h2 - l2);
+                    for (uint32_t rem = span; rem != 0u; rem >>= 1) {       // wave-uniform trip count
+                        const uint32_t mid = (l2 + h2 + 1u) >> 1;
+                        if (L.pref[mid] <= item) l2 = mid; else h2 = mid - 1u;
+                    }
+                    xs[k] = L.val[l2];
+                    rv[k] = ok[k] ? load_stream_nt(a.stream + L.start[l2] + (item - L.pref[l2])) : make_uint2(a.row_begin, 0u);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < kBinItems; k++) {
+                    row[k] = rv[k].x - a.row_begin;
+                    ok[k] = ok[k] && spmspv_product<OP>(bitsf(rv[k].y), xs[k], z[k]);
+                }
+                bin_batch<OP>(a, L, row, z, ok, a1 - w0 > direct_limit);
             }
-            bin_batch<OP>(a, L, row, z, ok);
+            cur += W;
+            __syncthreads();
         }
         __syncthreads();
     }
-    if (!a.queue_capacity) return;
-    // ---- the chunk queue: every workgroup has queued its chunks once it arrives here; when all have, all drain
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's descriptor stores have been performed
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(&a.sync[kSyncProducers], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (the grid is at most one workgroup per compute unit: all of them are resident)
-        uint32_t spins = 0;
-        while (__hip_atomic_load(&a.sync[kSyncProducers], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++spins < (1u << 24))
-            __builtin_amdgcn_s_sleep(2);
-        L.word = min(__hip_atomic_load(&a.sync[kSyncQueued], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.queue_capacity);
-    }
-    __syncthreads();
-    const uint32_t nq = L.word;
-    if (!nq) return;
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) L.word = atomicAdd(&a.sync[kSyncQueueHead], 1u);
-        __syncthreads();
-        const uint32_t q = L.word;
-        if (q >= nq) break;
-        const unsigned long long d0 = __hip_atomic_load(&a.queue[2ull * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long d1 = __hip_atomic_load(&a.queue[2ull * q + 1ull], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bin_chunk<OP>(a, L, (uint32_t)d0, (uint32_t)(d0 >> 32), bitsf((uint32_t)d1));
-    }
+    // (the fold kernel that follows advances the generation: spmspv_bin_rounds)
+}
+
+// rounds (rendezvous generations) a bin launch of `grid` workgroups uses on a vector of vnnz entries
+__host__ __device__ inline uint32_t spmspv_bin_rounds(uint32_t vnnz, uint32_t grid) {
+    const uint32_t E = min(kBinSlice, max(1u, (vnnz + grid - 1u) / grid));
+    const unsigned long long per = (unsigned long long)kBinMaxSlices * E;
+    return (uint32_t)max(1ull, ((unsigned long long)vnnz + per - 1ull) / per);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ fold
@@ -413,11 +542,13 @@ struct FoldArgs {
     float *assign;            // gl_spmspv_run_assign: assign[index] = assign_val for every emitted entry (or null)
     float assign_val;
     uint32_t *next_bits;      // the emitted rows also as a bit vector: every word of the shard's rows is written (or null)
-    uint32_t *state;          // tiles words: 1 << 31 | entries of the tile once it has counted; zero between runs
+    uint32_t *state;          // tiles words: (generation & 0xffff) << 16 | entries of the tile, once it has counted
     uint32_t *sync;
     uint32_t tickets;         // more tiles than resident workgroups: tiles are handed out in arrival order
     uint32_t merge_all;       // every tile also takes what the dense accumulator holds
     const uint32_t *mode;     // non-null: the same when mode[0] != 0 (the run went row-wise)
+    const gl_idx_val *bin_vec;      // the bin launch in front of this one: its vector and grid (the generation it used up)
+    uint32_t bin_grid;
     unsigned long long *host_rec;   // page-locked host word: seq << 32 | count when everything has been written (or null)
     uint32_t seq;
     Gate gate;
@@ -431,19 +562,21 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fold_lds_raw[];
     T *tile = reinterpret_cast<T *>(fold_lds_raw);
     __shared__ unsigned long long s_ball[kFoldMaxRounds * kFoldWaves];   // keep-ballot of (round, wavefront)
-    __shared__ uint32_t s_off[kFoldMaxRounds * kFoldWaves];              // entries in front of it inside the tile
-    __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_word;
     if (a.gate.closed()) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     constexpr bool BITS = OPX >= 3;   // the integer value types compare bit patterns (zero may be a NaN as a float)
+    const uint32_t T_ = a.tiles.count, R = a.tiles.rows;
     uint32_t t = blockIdx.x;
-    if (a.tickets) {
-        if (tid == 0) s_word = atomicAdd(&a.sync[kSyncFoldTicket], 1u);
+    if (a.tickets) {   // (every run takes exactly T_ tickets: the counter modulo T_ is the tile, in arrival order)
+        if (tid == 0)
+            s_word = (uint32_t)(__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.sync + kSyncFoldTicket), 1ull, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT) % T_);
         __syncthreads();
         t = s_word;
     }
-    const uint32_t T_ = a.tiles.count, R = a.tiles.rows;
+    // the tag of this run's tile states: every run rewrites every state, so the previous run's tag is all a reader can meet
+    const uint32_t gen0 = a.sync[kSyncGen], tag = (gen0 & 0xffffu) << 16;
     const uint32_t row0 = t * R;
     const uint32_t rows = a.nrows > row0 ? min(R, a.nrows - row0) : 0u;
     const uint32_t rounds = (rows + kFoldThreads - 1u) / kFoldThreads;
@@ -451,7 +584,7 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
     const uint32_t bb = a.bin_base[t], cap = a.bin_base[t + 1u] - bb;
     const uint32_t cnt = min(raw, cap);
     const bool merge = a.merge_all != 0u || (a.mode && a.mode[0]) || raw > cap;
-    uint32_t total = 0;
+    uint32_t total = 0, pre_c[4] = {0u, 0u, 0u, 0u};
     if (cnt || merge) {
         for (uint32_t i = tid; i < rows; i += kFoldThreads) tile[i] = TL::ident();
         __syncthreads();
@@ -497,43 +630,56 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
             if (lane == 0) s_ball[j * kFoldWaves + wave] = b;
         }
         __syncthreads();
-        // exclusive prefix of the (round, wavefront) counts: at most 256 of them
+        // entries in front of every (round, wavefront) ballot: each wavefront scans the at most 256 counts itself, four per lane
+        // (index 64 q + lane) -- one barrier instead of three
         {
-            const uint32_t c = tid < rounds * kFoldWaves ? (uint32_t)__popcll(s_ball[tid]) : 0u;
-            const uint32_t before = block_exclusive_1024(c, s_wave, &total);
-            if (tid < rounds * kFoldWaves) s_off[tid] = before;
+            const uint32_t nb = rounds * kFoldWaves;
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) {
+                const uint32_t i = 64u * q + lane;
+                const uint32_t c = i < nb ? (uint32_t)__popcll(s_ball[i]) : 0u;
+                uint32_t incl = c;
+#pragma unroll
+                for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
+                    const uint32_t up = __shfl_up(incl, dlt);
+                    if (lane >= dlt) incl += up;
+                }
+                pre_c[q] = total + incl - c;
+                total += __shfl(incl, 63);
+            }
         }
     }
-    // ---- publish the tile's count; entries of the tiles in front = this tile's place in the list
-    if (tid == 0) __hip_atomic_store(&a.state[t], 0x80000000u | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- publish the tile's count; entries of the tiles in front = this tile's place in the list.  The first wavefront
+    // polls the states in front (tiles handed out in arrival order have all started: nobody waits for a tile that has not).
     uint32_t before = 0;
-    for (uint32_t u = tid; u < t; u += kFoldThreads) {
-        uint32_t w, spins = 0;
-        while (!((w = __hip_atomic_load(&a.state[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 31) && ++spins < (1u << 24))
-            __builtin_amdgcn_s_sleep(1);
-        before += w & 0x7fffffffu;
-    }
-    if (t > 0u) {   // block-uniform
+    if (tid < 64u) {
+        if (tid == 0) __hip_atomic_store(&a.state[t], tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t u = lane; u < t; u += 64u) {
+            uint32_t w, spins = 0;
+            while (((w = __hip_atomic_load(&a.state[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff0000u) != tag && ++spins < (1u << 24))
+                __builtin_amdgcn_s_sleep(1);
+            before += w & 0xffffu;
+        }
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) before += __shfl_down(before, d);
-        __syncthreads();
-        if (lane == 0) s_wave[wave] = before;
-        __syncthreads();
-        before = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 16; k++) before += s_wave[k];
+        for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+        if (tid == 0) s_word = before;
     }
+    __syncthreads();
+    before = s_word;
     // ---- the write pass
     const uint32_t row_g0 = a.row_begin + row0;
     if (total) {
         for (uint32_t j = 0; j < rounds; j++) {
             const uint32_t r = j * kFoldThreads + tid;
-            const unsigned long long b = s_ball[j * kFoldWaves + wave];
+            const uint32_t bi = j * kFoldWaves + wave;       // this wavefront's ballot of the round
+            const unsigned long long b = s_ball[bi];
+            const uint32_t sel = (bi >> 6) == 0u ? pre_c[0] : (bi >> 6) == 1u ? pre_c[1] : (bi >> 6) == 2u ? pre_c[2] : pre_c[3];
+            const uint32_t off = __shfl(sel, (int)(bi & 63u));
             if ((b >> lane) & 1ull) {
                 gl_idx_val item;
                 item.index = row_g0 + r;
                 item.val = *reinterpret_cast<const float *>(&tile[r]);
-                a.out[1u + before + s_off[j * kFoldWaves + wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = item;
+                a.out[1u + before + off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = item;
                 if (a.assign) a.assign[item.index] = a.assign_val;   // the entry's own row: nobody else touches it
             }
         }
@@ -549,22 +695,23 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
         }
     }
     if (t == T_ - 1u && tid == 0) {
+        // the last tile has seen every other tile's state: the list's length, the driver's decision, and fresh tags for the next
+        // run (every workgroup of this launch has read the generation by now)
         a.out[0].index = before + total;
         a.out[0].val = a.head_val;
         a.dir.decide(before + total);
-        __hip_atomic_store(&a.sync[kSyncTotal], before + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.host_rec) __hip_atomic_store(&a.sync[kSyncTotal], before + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.sync[kSyncGen], gen0 + (a.bin_vec ? spmspv_bin_rounds(a.bin_vec[0].index, a.bin_grid) : 1u), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- the last workgroup to finish restores the "zero between runs" words and tells a blocking caller
+    if (!a.host_rec) return;
+    // ---- a blocking caller: the last workgroup to finish stores {sequence, count} to page-locked host memory
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have been performed
     __syncthreads();
-    if (tid == 0) s_word = __hip_atomic_fetch_add(&a.sync[kSyncFoldDone], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_word != T_ - 1u) return;
-    for (uint32_t u = tid; u < T_; u += kFoldThreads) __hip_atomic_store(&a.state[u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) {
-        const uint32_t all = __hip_atomic_load(&a.sync[kSyncTotal], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t k = 0; k < 6u; k++) __hip_atomic_store(&a.sync[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.host_rec) {
+        if (__hip_atomic_fetch_add(&a.sync[kSyncFoldDone], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == T_ - 1u) {
+            const uint32_t all = __hip_atomic_load(&a.sync[kSyncTotal], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.sync[kSyncFoldDone], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(a.host_rec, ((unsigned long long)a.seq << 32) | all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
