@@ -542,7 +542,17 @@ struct TinyArgs {
     float head_val;
     uint32_t zero_bits;
     uint32_t *next_bits;     // (also in the source functor) cleared here over the shard's rows before the emission ORs into it
+    unsigned long long *host_rec;   // a blocking caller's completion record (gl_spmspv_wait): seq << 32 | count, or null
+    uint32_t seq;
 };
+
+// the one workgroup has written everything: tell a blocking caller
+__device__ __forceinline__ void tiny_report(const TinyArgs &a, uint32_t count) {
+    if (!a.host_rec) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(a.host_rec, ((unsigned long long)a.seq << 32) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ uint32_t atomic_min_float_old(float *addr, float v) {
     if (!(__float_as_uint(v) >> 31)) return (uint32_t)atomicMin((int *)addr, __float_as_int(v));
@@ -660,6 +670,7 @@ __global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, S
             a.out[0].val = a.head_val;
             dir.decide(pos);
         }
+        tiny_report(a, pos);
         return;
     }
 
@@ -760,6 +771,7 @@ __global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, S
         a.out[0].val = a.head_val;
         dir.decide(pos);
     }
+    tiny_report(a, pos);
 }
 
 template <int OP, int MASK>
@@ -1108,6 +1120,14 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
         t.head_val = zero;
         t.zero_bits = __builtin_bit_cast(uint32_t, zero);
         t.next_bits = d_next_bits;
+        {   // (a run that is neither gated nor being recorded reports its completion to the host, as below)
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(s, &cap);
+            const bool report = d_gate == nullptr && cap == hipStreamCaptureStatusNone && p->h_rec != nullptr;
+            t.host_rec = report ? p->h_rec : nullptr;
+            t.seq = report ? ++p->seq : 0u;
+            p->rec_pending = report;
+        }
         switch (op) {
             case GL_OP_MULADD: return gl::launch_tiny_mask<GL_OP_MULADD>(mask_type, t, d_mask, zero, d_inout, val, d_next_bits, gate, dir, s);
             case GL_OP_ANDOR: return gl::launch_tiny_mask<GL_OP_ANDOR>(mask_type, t, d_mask, zero, d_inout, val, d_next_bits, gate, dir, s);
@@ -1116,7 +1136,7 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     }
 
     // (||,&&) with an attached boolean SpMV plan: decide on the device which way this run goes
-    const long div = gl::env_long("GRAPHLILY_SPMSPV_PULL_DIV", 32);
+    const long div = gl::env_long("GRAPHLILY_SPMSPV_PULL_DIV", 8);
     const uint64_t threshold = div > 0 ? p->nnz / (uint64_t)div : 0ull;
     // which attached plan can stand in for the scatter: (||,&&) and (+,x) need zero == 0 (the accumulator starts
     // at it); (min,+) needs zero <= FLOAT_INF -- the scatter's products saturate there, the SpMV's do not, and the
@@ -1163,6 +1183,7 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     a.binned = p->binned ? 1u : 0u;
     a.row_begin = p->row_begin;
     a.num_cols = p->num_cols;
+    a.max_col_len = p->max_col_len;
     // at most one workgroup per compute unit (the kernel's rendezvous waits for every workgroup of the grid: all must be
     // resident), fewer when the caller has said how short the vector is
     uint32_t grid = (uint32_t)gl::ctx().num_cus;

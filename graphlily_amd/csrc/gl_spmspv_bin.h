@@ -75,6 +75,7 @@ struct BinArgs {
     TileMap tiles;
     uint32_t binned;            // 0: more tiles than the kernel has counters for -- every product goes to acc
     uint32_t row_begin, num_cols;
+    uint32_t max_col_len;       // longest column of the shard
     const uint32_t *mode;       // non-null: skip when mode[0] != 0 (the run goes row-wise instead)
     Gate gate;
 };
@@ -298,6 +299,86 @@ __device__ __forceinline__ void bin_chunk(const BinArgs &a, BinLds &L, uint32_t 
     bin_batch<OP>(a, L, row, z, ok, count > bin_direct_limit(a.tiles.count));
 }
 
+// Stage `nent` <= 1024 vector entries (first stream entry, exclusive prefix of the column lengths, value) and bin the products
+// of the window that fall into [lo, hi) -- product numbers count from `cur` at the window's first entry.  grid != 0: the
+// window IS the vector (at most 1024 entries): the workgroup cuts [0, W) into equal ranges itself and takes range blockIdx.x of
+// `grid` -- no word has to travel between workgroups.  Returns the products of the window.
+template <int OP>
+__device__ __forceinline__ uint32_t bin_window(const BinArgs &a, BinLds &L, const gl_idx_val *vec, uint32_t nent, unsigned long long cur,
+                                               unsigned long long lo, unsigned long long hi, uint32_t grid) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t start = 0, deg = 0;
+    float xv = 0.0f;
+    if (tid < nent) {
+        const gl_idx_val iv = vec[tid];
+        if (iv.index < a.num_cols) {
+            start = a.indptr[iv.index];
+            deg = a.indptr[iv.index + 1u] - start;
+            xv = iv.val;
+        }
+    }
+    uint32_t W;
+    const uint32_t pw = block_exclusive_1024(deg, L.wave, &W);
+    L.start[tid] = start;
+    L.pref[tid] = pw;
+    L.val[tid] = xv;
+    __syncthreads();
+    if (grid) {
+        // equal ranges of products, at least 2048 (a batch that small is mostly fixed cost), whole groups of 64
+        const uint32_t Q = (max((W + grid - 1u) / grid, 2048u) + 63u) & ~63u;
+        lo = (unsigned long long)blockIdx.x * Q;
+        hi = min(lo + Q, (unsigned long long)W);
+        if (lo >= W) return W;
+    }
+    uint32_t steps = 0;          // of the binary search: nent <= 2^steps
+    while ((1u << steps) < nent) steps++;
+    const uint32_t direct_limit = bin_direct_limit(a.tiles.count);
+    // my products inside the window: [a0, a1) of its W
+    const uint32_t a0 = lo > cur ? (uint32_t)(lo - cur) : 0u;
+    const uint32_t a1 = (uint32_t)min((unsigned long long)W, hi - cur);
+    for (uint32_t w0 = a0; w0 < a1; w0 += kBinBatch) {
+        uint32_t row[kBinItems];
+        float z[kBinItems], xs[kBinItems];
+        bool ok[kBinItems];
+        uint2 rv[kBinItems];
+        // the column of every 64th product of the batch (129 ten-step searches by three wavefronts), so that the
+        // per-product search below only looks between its group's two marks -- a lane-wide ten-step search per
+        // product was 3-5 us of instruction issue per batch (16 wavefronts x 8 products x 10 steps x 6 instructions)
+        if (tid <= kBinBatch / 64u) {
+            const uint32_t item = min(w0 + 64u * tid, a1 - 1u);
+            uint32_t l2 = 0, h2 = nent - 1u;     // largest j with pref[j] <= item (zero-length columns share a prefix:
+            for (uint32_t it = 0; it < steps; it++) {   // the largest such j owns the item)
+                const uint32_t mid = (l2 + h2 + 1u) >> 1;
+                if (L.pref[mid] <= item) l2 = mid; else h2 = mid - 1u;
+            }
+            L.tab[tid] = l2;
+        }
+        __syncthreads();
+        const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (uint32_t k = 0; k < kBinItems; k++) {
+            const uint32_t item = w0 + k * kBinThreads + tid;
+            ok[k] = item < a1;
+            const uint32_t g = k * (kBinThreads / 64u) + wv;        // wave-uniform
+            uint32_t l2 = L.tab[g], h2 = L.tab[g + 1u];
+            const uint32_t span = __builtin_amdgcn_readfirstlane(h2 - l2);
+            for (uint32_t rem = span; rem != 0u; rem >>= 1) {       // wave-uniform trip count
+                const uint32_t mid = (l2 + h2 + 1u) >> 1;
+                if (L.pref[mid] <= item) l2 = mid; else h2 = mid - 1u;
+            }
+            xs[k] = L.val[l2];
+            rv[k] = ok[k] ? load_stream_nt(a.stream + L.start[l2] + (item - L.pref[l2])) : make_uint2(a.row_begin, 0u);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBinItems; k++) {
+            row[k] = rv[k].x - a.row_begin;
+            ok[k] = ok[k] && spmspv_product<OP>(bitsf(rv[k].y), xs[k], z[k]);
+        }
+        bin_batch<OP>(a, L, row, z, ok, a1 - w0 > direct_limit);
+    }
+    return W;
+}
+
 // The products of a run are numbered 0 .. P - 1 in vector order and cut into EQUAL ranges, one per workgroup: a hub column is
 // shared by as many workgroups as its length asks for, a thousand short ones are one workgroup's batch -- no chunk queue, no
 // workgroup that runs four batches while the others wait.  P needs a prefix over the whole vector, so the kernel has ONE
@@ -315,9 +396,15 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
     for (uint32_t i = tid; i < kBinMaxTiles; i += kBinThreads) L.cnt[i] = 0u;
     const uint32_t vnnz = a.vec[0].index;
     const uint32_t E = min(kBinSlice, max(1u, (vnnz + G - 1u) / G));
+    __syncthreads();
+    // a vector of at most 1024 entries (whose columns cannot hold 2^32 non-zeros): every workgroup stages ALL of it and cuts
+    // the products itself -- the rendezvous below (slice sums out, everybody's sums in: ~8 us of a 13 us launch) is not needed
+    if (vnnz <= kBinSlice && (unsigned long long)vnnz * a.max_col_len <= 0xfffffffeull) {
+        if (vnnz) (void)bin_window<OP>(a, L, a.vec + 1u, vnnz, 0ull, 0ull, 0ull, G);
+        return;
+    }
     const uint32_t gen0 = a.sync[kSyncGen];
     uint32_t rounds = 0;
-    __syncthreads();
     for (unsigned long long rbase = 0; rbase < vnnz; rbase += (unsigned long long)kBinMaxSlices * E, rounds++) {
         const uint32_t nv = (uint32_t)min((unsigned long long)vnnz - rbase, (unsigned long long)kBinMaxSlices * E);
         const uint32_t S = (nv + E - 1u) / E;
@@ -447,71 +534,7 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
         }
         unsigned long long cur = pre0;                // products in front of the staged window
         for (uint32_t ebase = s0 * E; cur < hi && ebase < nv; ebase += kBinSlice) {
-            // ---- stage up to 1024 vector entries: first stream entry, exclusive prefix of the lengths, value
-            const uint32_t nent = min(kBinSlice, nv - ebase);
-            uint32_t start = 0, deg = 0;
-            float xv = 0.0f;
-            if (tid < nent) {
-                const gl_idx_val iv = vec[ebase + tid];
-                if (iv.index < a.num_cols) {
-                    start = a.indptr[iv.index];
-                    deg = a.indptr[iv.index + 1u] - start;
-                    xv = iv.val;
-                }
-            }
-            uint32_t W;
-            const uint32_t pw = block_exclusive_1024(deg, L.wave, &W);
-            L.start[tid] = start;
-            L.pref[tid] = pw;
-            L.val[tid] = xv;
-            __syncthreads();
-            uint32_t steps = 0;          // of the binary search: nent <= 2^steps
-            while ((1u << steps) < nent) steps++;
-            const uint32_t direct_limit = bin_direct_limit(a.tiles.count);
-            // my products inside the window: [a0, a1) of its W
-            const uint32_t a0 = lo > cur ? (uint32_t)(lo - cur) : 0u;
-            const uint32_t a1 = (uint32_t)min((unsigned long long)W, hi - cur);
-            for (uint32_t w0 = a0; w0 < a1; w0 += kBinBatch) {
-                uint32_t row[kBinItems];
-                float z[kBinItems], xs[kBinItems];
-                bool ok[kBinItems];
-                uint2 rv[kBinItems];
-                // the column of every 64th product of the batch (129 ten-step searches by three wavefronts), so that the
-                // per-product search below only looks between its group's two marks -- a lane-wide ten-step search per
-                // product was 3-5 us of instruction issue per batch (16 wavefronts x 8 products x 10 steps x 6 instructions)
-                if (tid <= kBinBatch / 64u) {
-                    const uint32_t item = min(w0 + 64u * tid, a1 - 1u);
-                    uint32_t l2 = 0, h2 = nent - 1u;     // largest j with pref[j] <= item (zero-length columns share a prefix:
-                    for (uint32_t it = 0; it < steps; it++) {   // the largest such j owns the item)
-                        const uint32_t mid = (l2 + h2 + 1u) >> 1;
-                        if (L.pref[mid] <= item) l2 = mid; else h2 = mid - 1u;
-                    }
-                    L.tab[tid] = l2;
-                }
-                __syncthreads();
-                const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll
-                for (uint32_t k = 0; k < kBinItems; k++) {
-                    const uint32_t item = w0 + k * kBinThreads + tid;
-                    ok[k] = item < a1;
-                    const uint32_t g = k * (kBinThreads / 64u) + wv;        // wave-uniform
-                    uint32_t l2 = L.tab[g], h2 = L.tab[g + 1u];
-                    const uint32_t span = __builtin_amdgcn_readfirstlane(h2 - l2);
-                    for (uint32_t rem = span; rem != 0u; rem >>= 1) {       // wave-uniform trip count
-                        const uint32_t mid = (l2 + h2 + 1u) >> 1;
-                        if (L.pref[mid] <= item) l2 = mid; else h2 = mid - 1u;
-                    }
-                    xs[k] = L.val[l2];
-                    rv[k] = ok[k] ? load_stream_nt(a.stream + L.start[l2] + (item - L.pref[l2])) : make_uint2(a.row_begin, 0u);
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < kBinItems; k++) {
-                    row[k] = rv[k].x - a.row_begin;
-                    ok[k] = ok[k] && spmspv_product<OP>(bitsf(rv[k].y), xs[k], z[k]);
-                }
-                bin_batch<OP>(a, L, row, z, ok, a1 - w0 > direct_limit);
-            }
-            cur += W;
+            cur += bin_window<OP>(a, L, vec + ebase, min(kBinSlice, nv - ebase), cur, lo, hi, 0u);
             __syncthreads();
         }
         __syncthreads();

@@ -518,3 +518,116 @@ def test_vector_head_larger_than_the_vector_is_clamped(gpu):
     good = M.make_sparse_vec([3, 77, 4000], [1.0, 2.0, 3.0])
     ref = O.spmspv(to_oracle(csc), good, O.MULADD, 0.0)
     assert np.allclose(got, ref, rtol=1e-6, atol=0)
+
+
+# ------------------------------------------------------------------ round 4: the bin / fold kernels' other paths
+def _random_csc(n, avg, seed, hub=None):
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, 2 * avg + 1, size=n)
+    if hub:
+        deg[rng.choice(n, size=hub[0], replace=False)] = hub[1]
+    indptr = np.concatenate([[0], np.cumsum(deg)])
+    rows = np.concatenate([np.sort(rng.choice(n, size=int(d), replace=False)) for d in deg]).astype(np.uint32)
+    vals = rng.integers(1, 5, size=rows.shape[0]).astype(np.float32)
+    return io.CSCMatrix(n, n, vals, rows, indptr.astype(np.uint32))
+
+
+@pytest.mark.parametrize("sem", ["Arithmetic", "Logical", "Tropical"])
+@pytest.mark.parametrize("tile_rows,n", [(64, 40000), (64, 200000), (192, 40000)])
+def test_many_row_tiles(gpu, sem, tile_rows, n, monkeypatch):
+    """Tiles forced small (GRAPHLILY_SPMSPV_TILE_ROWS, read at plan creation): 625 tiles -- more than compute units, so the fold
+    hands them out by ticket and looks back over more tiles than one wavefront pass --, 3125 tiles -- more than the bin kernel
+    has counters for, so every product goes through the dense accumulator and the fold merges it --, and a tile height that is
+    not a power of two (row -> tile by multiplication).  Vectors: a few hundred entries (every workgroup cuts the products
+    itself) and tens of thousands (the rendezvous)."""
+    monkeypatch.setenv("GRAPHLILY_SPMSPV_TILE_ROWS", str(tile_rows))
+    csc = _random_csc(n, 6, 5, hub=(3, 5000))
+    op, zero = SEMIRINGS[sem]
+    mask = rand01(n, 3)
+    rng = np.random.default_rng(11)
+    for cnt in (300, n // 3):
+        cols = np.sort(rng.choice(n, size=cnt, replace=False)).astype(np.uint32)
+        v = M.make_sparse_vec(cols, rng.integers(1, 4, size=cnt).astype(np.float32))
+        for mask_name in ("NoMask", "WriteToZero"):
+            got, mod = _run(gpu, csc, sem, mask_name, v, mask)
+            ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS[mask_name])
+            assert_parity(got, ref, op, "tiles of %d rows, n %d, %s %s %d" % (tile_rows, n, sem, mask_name, cnt))
+            # and once more on the same plan: every between-runs invariant (cursors, tags, accumulator) was restored
+            mod.run()
+            again = M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), n, zero)
+            assert np.array_equal(again, got)
+
+
+def test_vector_longer_than_one_rendezvous_round(gpu):
+    """2.3 M vector entries: more than the 2048 slices of 1024 entries the bin kernel's rendezvous holds, so it runs two rounds
+    (two generations of tags).  One entry per column at row (7 c) mod n: the result is a permutation of the vector."""
+    n = 2300000
+    indptr = np.arange(n + 1, dtype=np.uint32)
+    rows = ((np.arange(n, dtype=np.int64) * 7) % n).astype(np.uint32)
+    csc = io.CSCMatrix(n, n, np.full(n, 2.0, np.float32), rows, indptr)
+    vals = (np.arange(n) % 5 + 1).astype(np.float32)
+    v = M.make_sparse_vec(np.arange(n, dtype=np.uint32), vals)
+    got, mod = _run(gpu, csc, "Arithmetic", "NoMask", v, np.zeros(n, np.float32))
+    ref = np.zeros(n, np.float32)
+    ref[rows] = 2.0 * vals
+    assert np.array_equal(got, ref)
+    mod.run()       # the generation moved on by two: the next run's tags are fresh
+    assert np.array_equal(M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), n, 0.0), ref)
+
+
+def test_duplicates_beyond_32_bits_of_products(gpu):
+    """A vector that names one dense column 70 000 times: 4.6e9 products, more than the kernel's 32-bit product numbers
+    hold -- it must notice (the slice sums saturate) and take the column-by-column path; the bins overflow into the dense
+    accumulator on the way.  (||,&&): the result is simply every row."""
+    n = 65536
+    indptr = np.zeros(n + 1, np.uint32)
+    indptr[1:] = n                                      # column 0 holds every row, the others are empty
+    csc = io.CSCMatrix(n, n, np.ones(n, np.float32), np.arange(n, dtype=np.uint32), indptr)
+    v = M.make_sparse_vec(np.zeros(70000, np.uint32), np.ones(70000, np.float32))
+    mod = M.SpMSpVModule(512)
+    mod.set_semiring(M.LogicalSemiring)
+    mod.set_mask_type(M.kNoMask)
+    mod.set_up_runtime()
+    mod.load_and_format_matrix(csc)
+    mod.send_matrix_host_to_device()
+    mod.send_mask_host_to_device(np.zeros(n, np.float32))
+    mod.vector_buf = None
+    from graphlily_amd import capi
+    mod.vector_buf = capi.DeviceBuffer(8 * v.shape[0])   # (send_vector_host_to_device truncates to num_cols + 1 entries)
+    mod.vector_buf.write(v)
+    mod.run()
+    res = mod.send_results_device_to_host()
+    assert int(res["index"][0]) == n
+    assert np.array_equal(res["index"][1:n + 1], np.arange(n, dtype=np.uint32)) and np.all(res["val"][1:n + 1] == 1.0)
+    # a normal run afterwards
+    mod.send_vector_host_to_device(M.make_sparse_vec([0], [1.0]))
+    mod.run()
+    assert mod.get_results_nnz() == n
+
+
+def test_wait_returns_the_count_without_a_copy(gpu):
+    """gl_spmspv_wait: the operator's own completion record.  A non-blocking run, then wait(): the count equals the head
+    element; a gated run keeps no record (wait() is gl_sync and says so)."""
+    from graphlily_amd import capi
+    csc = _random_csc(30000, 8, 21)
+    op, zero = SEMIRINGS["Arithmetic"]
+    rng = np.random.default_rng(2)
+    mod = M.SpMSpVModule(512)
+    mod.set_semiring(M.ArithmeticSemiring)
+    mod.set_mask_type(M.kNoMask)
+    mod.set_up_runtime()
+    mod.load_and_format_matrix(csc)
+    mod.send_matrix_host_to_device()
+    mod.blocking = False
+    for cnt in (5, 700, 9000):       # one launch of one workgroup / every workgroup cuts the products itself / the rendezvous
+        cols = np.sort(rng.choice(30000, size=cnt, replace=False)).astype(np.uint32)
+        mod.send_vector_host_to_device(M.make_sparse_vec(cols, np.ones(cnt, np.float32)))
+        for _ in range(3):
+            mod.run()
+            n = mod.plan_.wait()
+            assert n is not None and n == int(mod.send_results_device_to_host()["index"][0]) and n > 0
+            assert mod.get_results_nnz() == n
+    gate = capi.DeviceBuffer.from_host(np.array([1, 0, 0, 0], np.uint32))
+    mod.run_gated(mod.vector_buf, mod.results_buf, None, 0.0, None, gate, 1, capi.GL_GATE_EQ)
+    assert mod.plan_.wait() is None
+    capi.sync()
