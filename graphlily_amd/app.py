@@ -889,7 +889,11 @@ class SSSP(_GraphApp):
     #    iteration, app/sssp.h:221) ------------------------------------------------------------------------------------
     def _device_loop_ok(self):
         plan = getattr(self.SpMV_, "plan_", None)
-        return (not self.comm.distributed and os.environ.get("GRAPHLILY_SSSP_DEVICE_LOOP", "1") != "0"
+        # Off by default since round 4: the schedule enqueues BOTH steps of every slot and gates one of them off -- five no-op
+        # launches per slot, 0.4 ms of them on the ogbn-products stand-in's 23 slots (same-box A/B, profiles/r04_ab_schedules.txt:
+        # 3.60 ms against the host-driven loop's 3.18) -- while the host-driven loop now waits for the SpMSpV's own completion
+        # record (gl_spmspv_wait) behind the relax step instead of copying the count back.  GRAPHLILY_SSSP_DEVICE_LOOP=1: the schedule.
+        return (not self.comm.distributed and os.environ.get("GRAPHLILY_SSSP_DEVICE_LOOP", "0") != "0"
                 and hasattr(self.SpMSpV_, "run_gated") and plan is not None and hasattr(plan, "run_flagged")
                 and getattr(self.SpMSpV_, "plan_", None) is not None
                 and plan.info()["layout"] in ("general", "pattern") and plan.info()["num_units"] > 0)
@@ -962,7 +966,9 @@ class SSSP(_GraphApp):
         it = 1
         while True:
             self._push_iteration(frontier, local)
-            nnz = self.comm_sparse_count(candidates)            # app/sssp.h:221 (SpMSpV result size)
+            # app/sssp.h:221 (SpMSpV result size): the run's own completion record (the relax step is already enqueued behind
+            # it), or the head element's copy where there is none
+            nnz = self.SpMSpV_.get_results_nnz() if not self.comm.distributed and hasattr(self.SpMSpV_, "plan_") else self.comm_sparse_count(candidates)
             if self.comm.distributed:
                 import torch
                 gloo = self.comm.dist.get_backend(self.comm.group) == "gloo"

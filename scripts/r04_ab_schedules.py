@@ -23,9 +23,10 @@ BFS_VARIANTS = (
     ("no_graph", {"GRAPHLILY_BFS_GRAPH": "0"}),
 )
 SSSP_VARIANTS = (
-    ("device_schedule", {}),
-    ("host_loop (r02)", {"GRAPHLILY_SSSP_DEVICE_LOOP": "0"}),
-    ("device_schedule_no_graph", {"GRAPHLILY_SSSP_GRAPH": "0"}),
+    ("host_loop (default since r04)", {}),
+    ("device_schedule", {"GRAPHLILY_SSSP_DEVICE_LOOP": "1"}),
+
+
 )
 
 

@@ -367,6 +367,7 @@ def test_sssp_pull_push_device_loop_equals_host_loop(gpu, name, zero, monkeypatc
     dev.set_up_runtime()
     dev.load_and_format_matrix(m, True)
     dev.send_matrix_host_to_device()
+    monkeypatch.setenv("GRAPHLILY_SSSP_DEVICE_LOOP", "1")      # (opt-in since round 4: the host-driven loop is the default)
     assert dev._device_loop_ok()
     monkeypatch.setenv("GRAPHLILY_SSSP_DEVICE_LOOP", "0")
     host = app.SSSP(M.num_hbm_channels, 1024, 512, 256, semiring=sem)
