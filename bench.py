@@ -528,7 +528,8 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence, keep=None):
     res = {}
     for mode in ("pull_push", "pull"):
         fn = (lambda: bfs.pull_push(source, iters, 0.001)) if mode == "pull_push" else (lambda: bfs.pull(source, iters))
-        d = fn()
+        for _ in range(14):      # (the schedule is recorded on the third call; the driver then times both read-back ways)
+            d = fn()
         ts = []
         for _ in range(runs):
             fence()
@@ -545,6 +546,8 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence, keep=None):
             comm.dist.all_reduce(tt, group=comm.group)
             reached = int(tt.item())
         res[mode] = {"ms": round(t * 1e3, 4), "gteps": round(nnz * iters / t / 1e9, 3), "reached": reached}
+        if getattr(bfs, "readback_", None) is not None:
+            res[mode]["readback"] = dict(bfs.readback_)      # packed (host threads expand nibbles) or float, whichever measured faster
         if mode == "pull_push":
             res[mode]["push_iterations"] = bfs.push_iterations_
     res.update({"iters": iters, "nnz": nnz, "setup_s": round(setup, 2), "threshold": 0.001, "source": source})

@@ -128,9 +128,9 @@ def run_graph(name, raw, iters, dev, runs=5, spmv_steps=100, apps=("bfs", "pager
         bfs.set_up_runtime()
         bfs.load_and_format_matrix(raw, True)
         bfs.send_matrix_host_to_device()
-        t_pull, d_pull = timed(lambda: bfs.pull(src, iters), runs)
+        t_pull, d_pull = timed(lambda: bfs.pull(src, iters), runs, warm=14)
         e_pull = edges_traversed(bfs, raw, d_pull, iters) if getattr(bfs, "bfs_slot_modes_", None) is not None else None
-        t_pp, d_pp = timed(lambda: bfs.pull_push(src, iters, 0.001), runs)
+        t_pp, d_pp = timed(lambda: bfs.pull_push(src, iters, 0.001), runs, warm=14)
         e_pp = edges_traversed(bfs, raw, d_pp, iters) if getattr(bfs, "bfs_slot_modes_", None) is not None else None
         nnz = bfs.get_nnz()
         rec["bfs"] = {"source": src, "pull_ms": round(t_pull * 1e3, 3), "pull_gteps": round(nnz * iters / t_pull / 1e9, 1),

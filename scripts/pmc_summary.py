@@ -17,9 +17,12 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+GRAPH = sys.argv[2] if len(sys.argv) > 2 else "orkut"      # a second graph's passes: profile_bench.sh with GRAPH=<name>
+SRC = os.path.join(ROOT, "gpurun_out", "prof" if GRAPH == "orkut" else "prof_" + GRAPH)
+if GRAPH != "orkut":
+    TAG = TAG + "_" + GRAPH
 
 
 def mean_counter(path, kernel_substr):
@@ -34,7 +37,7 @@ def mean_counter(path, kernel_substr):
 
 def main():
     os.makedirs(DST, exist_ok=True)
-    out = {"tag": TAG, "graph": "orkut", "n_gpus": 1}
+    out = {"tag": TAG, "graph": GRAPH, "n_gpus": 1}
     stats = glob.glob(os.path.join(SRC, "*kernel_stats.csv")) + glob.glob(os.path.join(SRC, ".*kernel_stats.csv"))
     if stats:
         dst = os.path.join(DST, "%s_bench_kernel_stats.csv" % TAG)
@@ -76,7 +79,7 @@ def main():
             rows = {}
             for row in csv.DictReader(f):
                 for k in ("spmv_rbcs_kernel<0, 0, 3,", "spmv_bool_kernel<0, 4, 1>", "spmv_bool_kernel<0, 4, 0>", "spmv_prescale_kernel", "spmv_bool_pack_kernel",
-                          "spmv_hot_gather_kernel", "spmspv_scatter_kernel", "spmspv_queue_kernel", "spmspv_work_kernel"):
+                          "spmv_hot_gather_kernel", "spmspv_bin_kernel<0>", "spmspv_fold_kernel<0>", "spmspv_work_kernel", "bfs_shard_step_kernel"):
                     if k in row["Name"]:
                         rows[k] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
             out["kernel_avg_ns"] = rows
@@ -87,7 +90,8 @@ def main():
                               "FETCH_SIZE_KiB_mean": c, "expected_KiB": 1 << 20,
                               "measured_over_expected": c / float(1 << 20)}
         shutil.copy(calib, os.path.join(DST, "%s_pmc_fetch_calib.csv" % TAG))
-    with open(os.path.join(DST, "pmc_traffic.json"), "w") as f:
+    # (bench.py reads pmc_traffic.json for the bench graph; another graph's summary gets its own file)
+    with open(os.path.join(DST, "pmc_traffic.json" if GRAPH == "orkut" else "%s_pmc_traffic.json" % TAG), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 
