@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void sssp_begin_kernel(uint32_t *__restrict__ 
     const uint32_t src = ctl[2];
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
     for (uint32_t i = tid; i < n; i += stride) distance[i] = (i == src) ? 0.0f : zero;
-    if (tid < ctl_words && tid != 2u) ctl[tid] = tid == 0u ? 0xffffffffu : (tid == 4u ? 0xffffffffu : (tid == 15u ? ctl_words : 0u));
+    // (grid-stride: a small vector with many iteration slots has more control words than the launch has threads)
+    for (uint32_t w = tid; w < ctl_words; w += stride)
+        if (w != 2u) ctl[w] = w == 0u ? 0xffffffffu : (w == 4u ? 0xffffffffu : (w == 15u ? ctl_words : 0u));
     if (tid == 0) {
         frontier[0].index = 1u;
         frontier[0].val = 0.0f;
@@ -203,7 +205,8 @@ __global__ __launch_bounds__(256) void bfs_bits_begin_kernel(uint32_t *__restric
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
     for (uint32_t i = tid; i < n; i += stride) distance[i] = (i == src) ? 1.0f : 0.0f;      // app/bfs.h:168-171
     for (uint32_t w = tid; w < nvec * words; w += stride) bits[w] = (w == words + (src >> 5)) ? (1u << (src & 31u)) : 0u;
-    if (tid < ctl_words && tid != 2u) ctl[tid] = tid == 0u ? first_pull_slot : (tid == 4u ? 0xffffffffu : (tid == 15u ? ctl_words : 0u));
+    for (uint32_t w = tid; w < ctl_words; w += stride)     // (grid-stride: more slots than a small graph's launch has threads)
+        if (w != 2u) ctl[w] = w == 0u ? first_pull_slot : (w == 4u ? 0xffffffffu : (w == 15u ? ctl_words : 0u));
 }
 
 // the set bits of a frontier bit vector as list candidates (gl_bfs_pull_step_back): entry {row, 1}

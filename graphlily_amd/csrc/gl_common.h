@@ -93,6 +93,14 @@ int preload_format();
 
 #define GL_LAUNCH_CHECK() GL_HIP(hipGetLastError())
 
+// one device word into a host (stack) variable: the stream is waited for whether or not the copy could be enqueued, so no
+// return path leaves a copy into a dead stack frame pending
+static inline hipError_t d2h_word_sync(uint32_t *h_dst, const void *d_src, hipStream_t s) {
+    const hipError_t e = hipMemcpyAsync(h_dst, d_src, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    const hipError_t w = hipStreamSynchronize(s);
+    return e != hipSuccess ? e : w;
+}
+
 static inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------ semirings

@@ -823,8 +823,7 @@ int fmt_column_degrees(DevCsr *c, uint32_t num_cols, std::vector<uint32_t> &deg,
     deg.resize(num_cols);
     uint32_t bad = 0;
     GL_HIP(hipMemcpyAsync(deg.data(), d_deg.p, (size_t)num_cols * 4u, hipMemcpyDeviceToHost, s));
-    GL_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
-    GL_HIP(hipStreamSynchronize(s));
+    GL_HIP(d2h_word_sync(&bad, d_bad.p, s));
     *bad_col = bad ? 1 : 0;
     return GL_OK;
 }
@@ -1019,8 +1018,7 @@ int fmt_spmspv_stream(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_in
         GL_LAUNCH_CHECK();
     }
     uint32_t bad = 0;
-    GL_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
-    GL_HIP(hipStreamSynchronize(s));
+    GL_HIP(d2h_word_sync(&bad, d_bad.p, s));
     if (bad) return set_error(GL_ERR_INVALID_ARG, "gl_spmspv_plan_create: row index out of range (num_rows %u)", num_rows);
     guard.released = true;
     *d_indptr_out = out_ip;
@@ -1065,8 +1063,7 @@ int fmt_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *h_indptr, 
         GL_LAUNCH_CHECK();
     }
     uint32_t bad = 0;   // (read back at once: no early return below may leave a copy into this stack word pending)
-    GL_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
-    GL_HIP(hipStreamSynchronize(s));
+    GL_HIP(d2h_word_sync(&bad, d_bad.p, s));
     if (bad) return set_error(GL_ERR_INVALID_ARG, "gl_csr2csc: column index out of range (num_cols %u)", num_cols);
     // column pointers: exclusive scan of the degrees (num_cols + 1 entries, the last one being the total)
     {
@@ -1104,8 +1101,7 @@ int fmt_normalize_by_outdegree(uint32_t num_rows, uint32_t num_cols, const uint3
     fmt_degree_kernel<<<flat_grid(nnz), kFmtThreads, 0, s>>>(d_cols.as<uint32_t>(), nnz, num_cols, d_deg.as<uint32_t>(), d_bad.as<uint32_t>());
     GL_LAUNCH_CHECK();
     uint32_t bad = 0;
-    GL_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, s));
-    GL_HIP(hipStreamSynchronize(s));
+    GL_HIP(d2h_word_sync(&bad, d_bad.p, s));
     if (bad) return set_error(GL_ERR_INVALID_ARG, "gl_csr_normalize_by_outdegree: column index out of range (num_cols %u)", num_cols);
     fmt_normalize_kernel<<<flat_grid(nnz), kFmtThreads, 0, s>>>(d_cols.as<uint32_t>(), d_deg.as<uint32_t>(), nnz, d_out.as<float>());
     GL_LAUNCH_CHECK();

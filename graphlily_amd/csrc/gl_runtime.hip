@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <sched.h>
 #include <unordered_map>
 #include <vector>
 
@@ -842,9 +843,21 @@ int gl_levels_pack(const float *d_levels, uint32_t n, int bits, const uint32_t *
 // the host half: packed levels -> floats on a few cores (a 12 MB result is 1.5 or 3 MB over PCIe and ~30 us of this).
 // gl_host_threads_warm wakes the same threads up front -- call it between enqueueing the GPU work and waiting for it, so
 // that the wake-up of a sleeping OpenMP team (tens of microseconds) overlaps the kernels.
+static int allowed_cpus() {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        const int c = CPU_COUNT(&set);
+        if (c > 0) return std::min(c, omp_get_num_procs());
+    }
+    return omp_get_num_procs();
+}
+
 static int host_expand_threads(size_t n) {
+    // half of the processors this PROCESS may run on (its affinity mask -- a 2-CPU container on a 256-core host must not start 16
+    // spinning threads), at most 16
     static const int hw = getenv("GRAPHLILY_HOST_THREADS") ? std::max(1, atoi(getenv("GRAPHLILY_HOST_THREADS")))
-                                                             : std::max(1, std::min(16, omp_get_num_procs() / 2));   // (measured: 12 MB of
+                                                             : std::max(1, std::min(16, allowed_cpus() / 2));   // (measured: 12 MB of
     // floats from 1.5 MB of nibbles in 106 / 71 / 53 / 86 / 190 us on 4 / 8 / 16 / 32 / 64 threads of a box under load)
     return n >= (1u << 18) ? hw : (n >= (1u << 16) ? std::min(hw, 8) : 1);
 }
@@ -951,6 +964,8 @@ int gl_buf_d2h_levels(float *h_dst, const float *d_src, size_t n, float max_leve
     // one page-locked staging block of the library, grown on demand (this call is blocking: nobody else uses it meanwhile)
     static void *stage = nullptr;
     static size_t stage_bytes = 0;
+    static std::mutex stage_lock;                       // (two host threads downloading at once take turns)
+    std::lock_guard<std::mutex> hold(stage_lock);
     if (stage_bytes < total) {
         if (stage) (void)hipHostFree(stage);
         stage = nullptr, stage_bytes = 0;

@@ -1361,8 +1361,7 @@ int gl_spmspv_last_direction(gl_spmspv_plan p, int *row_wise) {
     uint32_t m = 0;
     if (p->last_decided_on_device) {
         hipStream_t s = gl::ctx().stream;
-        GL_HIP(hipMemcpyAsync(&m, p->d_mode, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        GL_HIP(hipStreamSynchronize(s));
+        GL_HIP(gl::d2h_word_sync(&m, p->d_mode, s));
     }
     *row_wise = ((p->pull != nullptr || p->pull_arith != nullptr) && m != 0u) ? 1 : 0;
     return GL_OK;

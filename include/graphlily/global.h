@@ -31,6 +31,19 @@
 // Blocks come from the library's host pool (gl_host_pool_alloc): 4 KiB aligned like the reference's and recycled
 // by size, so the n-element vectors the drivers build for every pull() / push() call (app/bfs.h:107-113) are not
 // mapped and page-faulted in afresh each time.
+namespace graphlily_detail {
+inline int &noinit_depth() {
+    static thread_local int depth = 0;
+    return depth;
+}
+struct NoInitScope {
+    NoInitScope() { ++noinit_depth(); }
+    ~NoInitScope() { --noinit_depth(); }
+    NoInitScope(const NoInitScope &) = delete;
+    NoInitScope &operator=(const NoInitScope &) = delete;
+};
+}  // namespace graphlily_detail
+
 template <typename T>
 struct aligned_allocator {
     using value_type = T;
@@ -43,11 +56,15 @@ struct aligned_allocator {
         return reinterpret_cast<T *>(ptr);
     }
     void deallocate(T *p, std::size_t) { gl_host_pool_free(p); }
-    // vector<T, aligned_allocator<T>>(n) default-initialises its elements (no zero fill for the plain element types of this
-    // API: the n-element vectors the module layer creates for downloads are overwritten at once); vector(n, value) and
-    // every other construction go through the general overload as usual
+    // vector<T, aligned_allocator<T>>(n) VALUE-initialises its elements, like the reference's allocator (xcl2.hpp:61-76 has
+    // no construct(): drivers rely on zeroed vectors, tests/test_module_spmv_spmspv.cpp:210-211 reads vector[0].index before
+    // writing it).  Only inside a graphlily_detail::NoInitScope -- the module layer's download helpers, whose vectors are
+    // overwritten at once -- the elements are left as they are (no 12 MB fill in front of a 12 MB copy).
     template <typename U>
-    void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    void construct(U *p) {
+        if (graphlily_detail::noinit_depth()) ::new (static_cast<void *>(p)) U;
+        else ::new (static_cast<void *>(p)) U();
+    }
     template <typename U, typename A0, typename... Args>
     void construct(U *p, A0 &&a0, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<A0>(a0), std::forward<Args>(args)...); }
     template <typename U>
@@ -183,7 +200,9 @@ dense_vec_t convert_sparse_vec_to_dense_vec(const sparse_vec_t &sparse_vector, u
     typedef typename dense_vec_t::value_type out_t;
     // large float vectors (the push -> pull switch of app/bfs.h:196-201: a 3 M-element fill and a million scattered
     // stores on the orkut stand-in) go to the library's few-thread host loop; same result, entry for entry
+    // (float values only: the fast path copies the 32-bit value words as they are)
     if (range >= (1u << 18) && sizeof(elem_t) == sizeof(gl_idx_val) && sizeof(out_t) == 4 && std::is_same<out_t, float>::value &&
+        std::is_same<decltype(elem_t::val), float>::value &&
         !sparse_vector.empty() && (size_t)sparse_vector[0].index + 1 <= sparse_vector.size()) {
         float z = (float)zero;
         uint32_t zb;

@@ -34,9 +34,18 @@ public:
         in_buf = DeviceBuffer(sizeof(float) * in.size());
         in_buf.upload(in.data(), sizeof(float) * in.size());
     }
-    void allocate_out_buf(uint32_t len) { out_buf = DeviceBuffer(sizeof(float) * len); }
-    void bind_in_buf(DeviceBuffer src_buf) { in_buf = src_buf; }
-    void bind_out_buf(DeviceBuffer src_buf) { out_buf = src_buf; }
+    void allocate_out_buf(uint32_t len) {
+        settle_deferred_();
+        out_buf = DeviceBuffer(sizeof(float) * len);
+    }
+    void bind_in_buf(DeviceBuffer src_buf) {
+        settle_deferred_();
+        in_buf = src_buf;
+    }
+    void bind_out_buf(DeviceBuffer src_buf) {
+        settle_deferred_();
+        out_buf = src_buf;
+    }
 
     void run(uint32_t len, vector_data_t val) {
         // the results -> vector copy of a BFS pull iteration whose SpMV is deferred?  Then it waits too (module/fusion.h)

@@ -44,8 +44,14 @@ public:
         inout_buf = DeviceBuffer(sizeof(float) * inout.size());
         inout_buf.upload(inout.data(), sizeof(float) * inout.size());
     }
-    void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }
-    void bind_inout_buf(DeviceBuffer src_buf) { inout_buf = src_buf; }
+    void bind_mask_buf(DeviceBuffer src_buf) {
+        settle_deferred_();
+        mask_buf = src_buf;
+    }
+    void bind_inout_buf(DeviceBuffer src_buf) {
+        settle_deferred_();
+        inout_buf = src_buf;
+    }
 
     void run(uint32_t len, vector_data_t val) {
         if (mask_type_ != graphlily::kMaskWriteToZero && mask_type_ != graphlily::kMaskWriteToOne) {

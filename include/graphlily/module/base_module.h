@@ -34,6 +34,9 @@ protected:
         ++calls_();
         detail::fusion().flush();
     }
+    // a setter or binder: deferred calls were made with the OLD state and must run with it (they read the module's members
+    // when they run, not when they were deferred); not a "call" for the bookkeeping below
+    static void settle_deferred_() { detail::fusion().flush(); }
     // module calls so far, whichever module: a module that has learnt something about a device buffer from the host (the
     // SpMSpV module: the work of the vector it uploaded) trusts it only while no other call has run in between
     static uint64_t &calls_() {

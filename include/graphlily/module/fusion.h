@@ -186,6 +186,10 @@ struct PullFusion {
             slot = 1;
             cur = 0;
         }
+        // buffers an EARLIER fused step left owed that are not this step's (a driver that rebinds its results or vector between
+        // iterations): their values are in the bit vector `cur`, which this step is about to rotate away from -- write them now
+        if (last_vec.valid() && last_vec.id() != vec.id() && last_vec.owed()) (void)last_vec.ptr();
+        if (last_res.valid() && last_res.id() != res.id() && last_res.owed()) (void)last_res.ptr();
         const uint32_t nxt = (cur + 1u) % 3u, spare = (cur + 2u) % 3u;
         float *d = (float *)dist.ptr();
         int rc = gl_bfs_bits_push_step(csc, plan, vecbits(cur), vecbits(nxt), vecbits(spare), (uint32_t)words, d, val, ctl(), slot, -1.0f, 2);
@@ -208,11 +212,11 @@ struct PullFusion {
         bits_for_vec = vec.id();
         // both float buffers now hold the PREVIOUS iteration's values: owed
         DeviceBuffer v = vec, r = res;
-        const uint32_t nn = n;
-        std::function<void()> settle = [this, v, r, nn] {
+        const uint32_t nn = n, at = cur;            // (the bit vector these two buffers' values are in: pinned, not "the current one")
+        std::function<void()> settle = [this, v, r, nn, at] {
             v.settle_quietly();
             r.settle_quietly();
-            const uint32_t *b = vecbits(cur);
+            const uint32_t *b = vecbits(at);
             GRAPHLILY_CHECK(gl_unpack_bits(b, nn, (float *)v.raw()));
             GRAPHLILY_CHECK(gl_unpack_bits(b, nn, (float *)r.raw()));
             bits_for_vec = nullptr;                 // whoever touched the vector may change it: pack again next time

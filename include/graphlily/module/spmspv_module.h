@@ -38,7 +38,8 @@ class SpMSpVModule : public BaseModule {
     // the head counts; only the head and those entries are transferred
     static aligned_sparse_vec_t download_sparse_(const DeviceBuffer &buf) {
         const size_t slots = buf.size() / sizeof(idx_val_t);
-        aligned_sparse_vec_t out(slots);   // (elements are not zero-filled: aligned_allocator::construct)
+        graphlily_detail::NoInitScope no_fill;   // (overwritten by the copy below)
+        aligned_sparse_vec_t out(slots);
         if (!slots) return out;
         uint32_t nnz = 0;
         GRAPHLILY_CHECK(gl_sparse_nnz((const gl_idx_val *)buf.ptr(), &nnz));
@@ -67,8 +68,14 @@ public:
     uint32_t get_num_cols() { return csc_matrix_float_.num_cols; }
     uint32_t get_nnz() { return csc_matrix_float_.adj_indptr[csc_matrix_float_.num_cols]; }
 
-    void set_semiring(SemiringType semiring) { semiring_ = semiring; }
-    void set_mask_type(MaskType mask_type) { mask_type_ = mask_type; }
+    void set_semiring(SemiringType semiring) {
+        settle_deferred_();
+        semiring_ = semiring;
+    }
+    void set_mask_type(MaskType mask_type) {
+        settle_deferred_();
+        mask_type_ = mask_type;
+    }
     void set_row_shard(uint32_t row_begin, uint32_t row_end) {
         row_begin_ = row_begin;
         row_end_ = row_end;
@@ -154,8 +161,12 @@ public:
         mask_buf.upload(mask.data(), sizeof(float) * mask.size());
     }
 
-    void bind_mask_buf(DeviceBuffer src_buf) { mask_buf = src_buf; }      // extension
+    void bind_mask_buf(DeviceBuffer src_buf) {                            // extension
+        settle_deferred_();
+        mask_buf = src_buf;
+    }
     void bind_vector_buf(DeviceBuffer src_buf) {                          // extension
+        settle_deferred_();
         vector_buf = src_buf;
         hint_stamp_ = 0;
     }
@@ -216,6 +227,7 @@ public:
     aligned_sparse_vec_t send_vector_device_to_host() { return download_sparse_(vector_buf); }
     aligned_dense_vec_t send_mask_device_to_host() {
         barrier_();
+        graphlily_detail::NoInitScope no_fill;
         aligned_dense_vec_t out(mask_buf.size() / sizeof(float));
         mask_buf.download(out.data(), sizeof(float) * out.size());
         return out;

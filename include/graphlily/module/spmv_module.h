@@ -51,6 +51,7 @@ class SpMVModule : public BaseModule {
         return buf;
     }
     static aligned_dense_vec_t download_dense_(const DeviceBuffer &buf, size_t n) {
+        graphlily_detail::NoInitScope no_fill;   // (overwritten by the copy below)
         aligned_dense_vec_t out(n);
         buf.download(out.data(), sizeof(float) * n);
         return out;
@@ -110,8 +111,14 @@ public:
         gl_spmv_plan_destroy(plan_);
     }
 
-    void set_semiring(SemiringType semiring) { semiring_ = semiring; }
-    void set_mask_type(MaskType mask_type) { mask_type_ = mask_type; }
+    void set_semiring(SemiringType semiring) {
+        settle_deferred_();     // (a deferred run() reads the semiring when it finally runs: module/fusion.h)
+        semiring_ = semiring;
+    }
+    void set_mask_type(MaskType mask_type) {
+        settle_deferred_();
+        mask_type_ = mask_type;
+    }
     // extension (multi-GPU): this device owns rows [row_begin, row_end)
     void set_row_shard(uint32_t row_begin, uint32_t row_end) {
         row_begin_ = row_begin;

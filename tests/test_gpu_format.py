@@ -205,3 +205,34 @@ def test_device_csr2csc_rejects_a_malformed_row_pointer_array(gpu, monkeypatch):
         capi.host_csr2csc(m.num_rows, m.num_cols, off, m.adj_indices, m.adj_data)
     c = io.csr2csc(m)                                  # the library is fine afterwards
     assert int(c.adj_indptr[-1]) == m.nnz
+
+
+@pytest.mark.parametrize("where", ["0", "1"])
+def test_plan_creation_refuses_a_malformed_matrix(gpu, where, monkeypatch):
+    """gl_spmv_plan_create_ex / gl_spmspv_plan_create on a row (column) pointer array that decreases, and on an index out of
+    range, with the host and with the device formatter: an error code, no crash, no plan -- and the library formats the
+    well-formed matrix afterwards."""
+    from graphlily_amd import capi
+    monkeypatch.setenv("GRAPHLILY_PLAN_DEVICE", where)
+    m = named_matrix("uniform_10K_10")
+    bad_ptr = m.adj_indptr.copy()
+    bad_ptr[5000], bad_ptr[5001] = bad_ptr[5001], bad_ptr[5000]
+    bad_idx = m.adj_indices.copy()
+    bad_idx[1234] = m.num_cols + 7
+    for flags in (0, capi.GL_PLAN_KEEP_VALUES, capi.GL_PLAN_BOOLEAN):
+        with pytest.raises(capi.GraphLilyError):
+            capi.SpMVPlan(m.num_rows, m.num_cols, bad_ptr, m.adj_indices, m.adj_data, flags=flags)
+        with pytest.raises(capi.GraphLilyError):
+            capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, bad_idx, m.adj_data, flags=flags)
+    c = io.csr2csc(m)
+    bad_cptr = c.adj_indptr.copy()
+    bad_cptr[100], bad_cptr[101] = bad_cptr[101], bad_cptr[100]
+    bad_rows = c.adj_indices.copy()
+    bad_rows[77] = c.num_rows
+    with pytest.raises(capi.GraphLilyError):
+        capi.SpMSpVPlan(c.num_rows, c.num_cols, bad_cptr, c.adj_indices, c.adj_data)
+    with pytest.raises(capi.GraphLilyError):
+        capi.SpMSpVPlan(c.num_rows, c.num_cols, c.adj_indptr, bad_rows, c.adj_data)
+    plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data)
+    assert plan.info()["nnz"] == m.nnz
+    assert capi.SpMSpVPlan(c.num_rows, c.num_cols, c.adj_indptr, c.adj_indices, c.adj_data).info()["nnz"] == m.nnz
