@@ -52,7 +52,11 @@ def main():
     ap.add_argument("--settle", type=float, default=0.5,
                     help="seconds the device idles between set-up (graph generation, plan creation: seconds of sorting kernels) and "
                          "the warm-up steps")
-    ap.add_argument("--graph", default="orkut")
+    ap.add_argument("--graph", default="orkut", help="a stand-in of graphlily_amd/datasets.py (the paper's six, or orkut_community / "
+                                                     "products_community: planted communities, vertices numbered by community)")
+    ap.add_argument("--npz", default=None, help="a REAL graph instead: scipy-npz CSR as the reference's datasets (README.md:44-49), loaded by "
+                                                "the library's own npz reader; --iters gives its BFS iteration count")
+    ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the stand-in (debug only)")
     ap.add_argument("--no-bfs", action="store_true")
     ap.add_argument("--no-pattern", action="store_true", help="skip the pattern-plan leg")
@@ -115,8 +119,13 @@ def main():
 
     # ------------------------------------------------------------------ workload
     t0 = time.time()
-    g = datasets.PAPER_GRAPHS[args.graph]
-    csr = datasets.paper_graph(args.graph, args.scale, device=dev)
+    if args.npz:
+        g = {"seed": -1, "iters": args.iters}
+        csr = io.load_csr_matrix_from_float_npz(args.npz)
+        args.graph = "npz:" + os.path.basename(args.npz)
+    else:
+        g = datasets.PAPER_GRAPHS.get(args.graph) or datasets.EXTRA_GRAPHS[args.graph]
+        csr = datasets.paper_graph(args.graph, args.scale, device=dev)
     raw = csr.copy() if not args.no_bfs else None
     csr.adj_data = np.full(csr.nnz, np.float32(1.0 / csr.num_rows), dtype=np.float32)   # bench_spmv.cpp:50
     io.util_round_csr_matrix_dim(csr, 16 * 8, 8)                                        # bench_spmv.cpp:52-55
@@ -207,9 +216,11 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": "float32 (+,x) SpMV on %s stand-in (R-MAT seed %d, n=%d, nnz=%d), "
-                               "row-sharded x%d%s" % (args.graph, g["seed"], n_rows, nnz, world,
+        "data": "file" if args.npz else "synthetic",
+        "config": {"workload": "float32 (+,x) SpMV on %s (%s seed %d, n=%d, nnz=%d), "
+                               "row-sharded x%d%s" % (args.graph + ("" if args.npz else " stand-in"),
+                                                      "file," if args.npz else ("planted communities," if g.get("kind") == "community" else "R-MAT"),
+                                                      g["seed"], n_rows, nnz, world,
                                                       " + all-gather of y" if world > 1 else ""),
                    "graph": args.graph, "n": n_rows, "nnz": nnz, "scale": args.scale,
                    "algorithmic_bytes_per_step": alg_bytes},

@@ -202,7 +202,7 @@ class BFS(_GraphApp):
         self.SpMSpV_.load_and_format_matrix(csc)
         self.n_ = self.SpMV_.get_num_rows()
         assert self.n_ == self.SpMV_.get_num_cols()
-        # the bit-frontier schedule takes its decisions from GLOBAL lengths (gl_bfs_bits_shard_step / gl_bfs_bits_decide):
+        # the bit-frontier schedule takes its decisions from GLOBAL lengths (gl_bfs_bits_shard_step):
         # every rank keeps the two n-word arrays of the whole matrix
         self.row_len_ = np.diff(csr.adj_indptr.astype(np.int64)).astype(np.uint32)
         self.col_len_ = np.diff(csc.adj_indptr.astype(np.int64)).astype(np.uint32)
@@ -216,7 +216,7 @@ class BFS(_GraphApp):
         self.results_ = self.bits_a_ = self.bits_b_ = None   # per-matrix scratch of the pull loop
         # the device-resident schedules hold buffers sized for the old n and hipGraphs with the old plans' device
         # pointers baked in: a matrix sent again (or another one) must rebuild them
-        self.bits_loop_ = self.dev_loop_ = self.shard_loop_ = None
+        self.bits_loop_ = None
 
     # -- pull ------------------------------------------------------------------------------------
     def _bind_pull(self, vector, distance):
@@ -241,8 +241,7 @@ class BFS(_GraphApp):
         words = self.SpMV_.bits_words() if hasattr(self.SpMV_, "bits_words") else 0
         aligned = (not self.comm.distributed) or all(b % 64 == 0 for b in self.bounds_)
         if words and aligned:
-            self.fused_ = (os.environ.get("GRAPHLILY_BFS_FUSED", "1") != "0" and hasattr(self.SpMV_, "fused_bfs_ok")
-                           and self.SpMV_.fused_bfs_ok())
+            self.fused_ = hasattr(self.SpMV_, "fused_bfs_ok") and self.SpMV_.fused_bfs_ok()
             if self.fused_ or self.comm.distributed:
                 # opaque 32-bit words, kept across calls: pack_bits / the fused step rewrite every word of the row
                 # range, words past it stay 0 from the allocation
@@ -314,7 +313,7 @@ class BFS(_GraphApp):
         """SpMSpV on the shard, mark the newly reached vertices, publish the next frontier.  Returns
         (frontier size, frontier buffer, result buffer) for the next iteration."""
         # SpMSpV, then distance[new] = level (app/bfs.h:146-148); the assign rides on the pass that writes the results
-        if hasattr(self.SpMSpV_, "run_assign") and os.environ.get("GRAPHLILY_BFS_FUSED_PUSH", "1") != "0":
+        if hasattr(self.SpMSpV_, "run_assign"):
             self.SpMSpV_.run_assign(self.SparseAssign_.inout_buf, float(it + 1))
         else:
             self.SpMSpV_.run()
@@ -338,109 +337,26 @@ class BFS(_GraphApp):
             _, frontier, local = self._push_iteration(frontier, local, it)
         return self._finish_distance(distance)
 
-    # -- pull_push without the host in the loop -------------------------------------------------
-    def _device_loop_ok(self):
-        return (not self.comm.distributed and os.environ.get("GRAPHLILY_BFS_DEVICE_LOOP", "1") != "0"
-                and hasattr(self.SpMSpV_, "run_gated") and hasattr(self.SpMV_, "fused_bfs_ok") and self.SpMV_.fused_bfs_ok())
-
-    def _pull_push_device(self, source, num_iterations, threshold):
-        """The reference decides push vs pull on the host from a count it reads back every iteration
-        (app/bfs.h:180-190) and converts the frontier on the host at the switch (:195-205).  Here the WHOLE
-        schedule is enqueued up front: every iteration slot holds a pull step and a push step, a device-side mode
-        word (written by gl_bfs_direction_step from the result count, same float comparison) says which of the two
-        runs, and the push step's write pass leaves the next frontier as bits as well, so the switch is a flipped
-        word.  No synchronisation or device->host copy until the distances are read back.  The schedule depends
-        only on (num_iterations, threshold) -- the source is a device word -- so it is captured once as a hipGraph
-        and replayed (GRAPHLILY_BFS_GRAPH=0: enqueue it every time)."""
-        B, n = self.backend, self.n_
-        st = getattr(self, "dev_loop_", None)
-        if st is None:
-            words = self.SpMV_.bits_words()
-            both = B.alloc(n + 8, np.float32)     # distances, then the control words: one read-back fetches both
-            scratch = B.alloc(n // 1024 + 4, np.float32)   # block counts of the bits -> list pass (word 0: its ticket)
-            B.fill(scratch, 0.0, n // 1024 + 4)
-            st = self.dev_loop_ = {
-                "both": both, "ctl": B.view(both, n, 8, 4), "distance": B.view(both, 0, n, 4), "scratch": scratch,
-                "F": [B.alloc(n + 1, capi.IDX_VAL), B.alloc(n + 1, capi.IDX_VAL)],
-                "bits": [B.alloc(words, np.float32), B.alloc(words, np.float32)], "words": words, "graphs": {},
-                "src": np.zeros(1, np.uint32)}
-            for b in st["bits"]:
-                B.fill(b, 0.0, words)
-        ctl, distance, F, bits, words = st["ctl"], st["distance"], st["F"], st["bits"], st["words"]
-        self.SpMSpV_.bind_mask_buf(distance)
-
-        # Back to pushing (an extension; the reference pulls to the end once it has switched, app/bfs.h:106-126): when a
-        # pull step finds fewer than `back` * n new vertices the next slot pushes again -- the last iterations of a BFS
-        # have tiny frontiers, and a pull step streams the whole matrix whatever the frontier holds (orkut stand-in:
-        # 22 458 and 34 vertices in iterations 5 and 6 of 6).  Distances do not depend on the direction.
-        # Only where a pull step costs well more than a push step's fixed launches (~50 us): a pull streams 4 B per
-        # non-zero at ~5.5 TB/s, i.e. 17 us on the googleplus stand-in (where going back doubled the run) and 155 us on orkut.
-        dflt = max(float(threshold), 1.0 / 64.0) if self.get_nnz() >= (128 << 20) else 0.0
-        back = float(os.environ.get("GRAPHLILY_BFS_BACK", str(dflt)))
-
-        def schedule():
-            # slot `it`: frontier list F[it & 1] / bits[it & 1] in, F[(it + 1) & 1] / bits[(it + 1) & 1] out
-            capi.bfs_begin(ctl, distance, n, F[1], bits[1], words)
-            for it in range(1, num_iterations + 1):
-                cur, nxt = it & 1, (it + 1) & 1
-                # ctl[0] = first pull slot: slot `it` pushes if ctl[0] > it, pulls if ctl[0] <= it.  The push step comes
-                # first: a decision taken by this slot's pull step must not open the push gate of its own slot.
-                # The push step's counting pass clears the words of bits[nxt] that its write pass ORs the new frontier
-                # into, and its scan pass takes the reference's loop decision (threshold, iterations left)
-                self.SpMSpV_.plan_.frontier_bits(bits[cur])   # a heavy frontier goes row-wise straight from these bits
-                if it == 1:
-                    self.SpMSpV_.plan_.hint(1)                # one source vertex: no direction decision to launch
-                self.SpMSpV_.run_gated(F[cur], F[nxt], distance, float(it + 1), bits[nxt], ctl, it, capi.GL_GATE_GT,
-                                       ctl=ctl, slot=it, threshold=threshold,
-                                       may_continue=(1 if it + 1 < num_iterations else 0) | (2 if it + 1 <= num_iterations else 0))
-                if it == 1:
-                    continue        # the first slot always pushes (the frontier is the source vertex): no pull step to gate off
-                if back > 0.0:
-                    self.SpMV_.bfs_pull_step_back(bits[cur], bits[nxt], distance, float(it + 1), ctl, it, back,
-                                                  it + 1 <= num_iterations, F[nxt], st["scratch"])
-                else:
-                    self.SpMV_.bfs_pull_step_gated(bits[cur], bits[nxt], distance, float(it + 1), ctl, it, capi.GL_GATE_LE)
-
-        # ctl[2] = source: the one host->device word per run -- as a one-word fill launch in front of the schedule (a blocking
-        # 4-byte copy costs the host ~15 us)
-        capi.fill_u32_gated(B.view(ctl, 2, 1, 4), int(source), 1, None, 0)
-        key = (num_iterations, float(threshold), back)
-        use_graph = os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0"
-        g = st["graphs"].get(key)
-        if g is None and use_graph and st.get("warm") == key:
-            try:
-                with capi.Graph.capture() as g:
-                    schedule()
-                st["graphs"][key] = g
-            except capi.GraphLilyError:
-                g = st["graphs"][key] = False              # capture not possible here: keep enqueueing
-        if g:
-            g.launch()
-        else:
-            schedule()
-            st["warm"] = key                              # buffers, attributes and scratch exist now: the next call captures
-        B.sync()
-        out = B.download_result(st["both"], n + 8)
-        self.push_iterations_ = int(out[n + 1:n + 2].view(np.uint32)[0])          # the reference's count (first push phase)
-        self.push_iterations_again_ = int(out[n + 3:n + 4].view(np.uint32)[0])   # pushes after a pull step handed back
-        return out[:n]
-
+    # -- pull / pull_push without the host in the loop ------------------------------------------
     def _pull_push_bits(self, source, num_iterations, threshold, pull_only=False):
-        """(pull_only: the same machinery for BFS.pull -- every slot is the fused pull step, app/bfs.h:106-126.)
-        The device-resident schedule with the frontier as BITS only (gl_bfs_bits_*): a slot is two launches -- a push
-        step that scatters straight into the next frontier's bit vector and writes the levels itself (no dense
-        accumulator, no compaction, no chunk queue), and the fused pull step, which also serves a push whose frontier is
-        heavy (row-wise) and otherwise takes the push step's decisions.  13 launches for the 6 iterations of the orkut
-        stand-in where the list-based schedule above needs 51.  Slot s reads bit vector s and writes vector s + 1.
-        The read-back of distances + control words is enqueued behind the schedule (page-locked destination taken from
-        the results the caller has dropped): one wait per run.
+        """The reference decides push vs pull on the host from a count it reads back every iteration (app/bfs.h:180-190) and
+        converts the frontier on the host at the switch (:195-205).  Here the WHOLE run is enqueued up front as a device-resident
+        schedule with the frontier as BITS only (gl_bfs_bits_shard_step, csrc/gl_bfs_shard.h): ONE launch per iteration slot --
+        it begins with the previous slot's decision (the reference's loop condition, replayed from the slot's tallies) and then
+        runs the step the state asks for: the scattering push straight into the next frontier's bit vector, the streaming
+        (||,&&) pull, which also serves a push whose frontier is heavy, or the bottom-up scan of the rows not reached yet.
+        Slot s reads bit vector s and writes vector s + 1.  No synchronisation and no device->host copy between the first
+        launch and the read-back; the schedule depends only on (iterations, threshold) -- the source is a device word -- so it
+        is recorded once as a hipGraph and replayed.  (pull_only: BFS.pull, app/bfs.h:106-126 -- no slot scatters.)
 
-        ROW SHARDS (comm.distributed) run the same schedule with the decisions deferred (GL_BFS_DEFERRED): the two steps
-        of a slot work on the rank's rows only, ONE all-gather of n/8 bytes rebuilds the slot's output vector on every
-        rank, and gl_bfs_bits_decide takes the slot's decisions from the gathered vector (popcount + global column / row
-        lengths) -- identical on every rank, so the whole run is still enqueued up front: no synchronisation, no
-        device->host copy and no reduction between the first launch and the read-back, and every rank reads back ITS
-        SLICE of the distances (`gather_result_` = True all-gathers them first and returns the whole vector)."""
+        ROW SHARDS (comm.distributed) run the same launches on their rows; ONE all-gather per slot rebuilds the slot's bit
+        vector (n/8 bytes) and carries every rank's tallies (256 bytes each), from which every rank takes the same decision;
+        every rank reads back ITS SLICE of the distances (`gather_result_` = True all-gathers them first).
+
+        Rounds 2-3 kept four earlier generations of this loop alive behind switches (a list-based gated schedule, two- and
+        three-launch slots); round 4 retired them: same-box A/B in profiles/r04_ab_schedules.txt.  What remains beside this
+        schedule is the reference's own module-call loop (GRAPHLILY_BFS_HOST_LOOP=1, and wherever the plans do not offer
+        the bit layout)."""
         B, n, N = self.backend, self.n_, num_iterations
         self.fused_ = True          # (every pull step of this schedule is the fused one, see _bind_pull)
         sharded = self.comm.distributed
@@ -462,35 +378,25 @@ class BFS(_GraphApp):
             if sharded:
                 st["row_len"] = capi.DeviceBuffer.from_host(self.row_len_)
         ctl, distance, bits, words = st["ctl"], st["distance"], st["bits"], st["words"]
-        # Once the reference's rule has switched to pulling (frontier / n >= threshold, app/bfs.h:180-190), every later slot
-        # is handed back to the push step (an extension, see _pull_push_device), which leaves heavy frontiers to the pull
-        # step of its slot anyway: from then on the direction follows the work (GRAPHLILY_BFS_HEAVY_DIV).  A push step of
-        # this schedule is one short launch, so this pays on all six stand-ins (same-box sweep: hollywood 0.47 -> 0.41 ms).
-        back = 0.0 if pull_only else float(os.environ.get("GRAPHLILY_BFS_BACK", "1.0"))
+        # Once the reference's rule has switched to pulling (frontier / n >= threshold, app/bfs.h:180-190), every later slot is
+        # handed back to the push step (an extension: the reference pulls to the end), which leaves heavy frontiers to the
+        # streaming pull anyway: from then on the direction follows the work.  Distances do not depend on the direction.
+        back = 0.0 if pull_only else 1.0
         csc_plan, pull_plan = self.SpMSpV_.plan_, self.SpMV_.plan_
-        deferred = capi.GL_BFS_DEFERRED if sharded else 0
         # (one-GPU emulation of a rank without an exchange step, dist.EmulatedComm: the slots read the whole run's vectors)
         gathered = bits
         if sharded and getattr(self.comm, "emulated", False) and not self.comm.copy:
             gathered = [self.comm.truth_vector(k) for k in range(st["nvec"])]
-
-        # ONE launch per slot (gl_bfs_bits_shard_step): the ranks' tallies of a slot travel with its bit vector, and the next
-        # slot's launch starts with the decision.  GRAPHLILY_BFS_SHARD_STEP=0: the three-launch slot (push step, pull step,
-        # gl_bfs_bits_decide on the gathered vector)
-        # (one GPU: the same kernel with a world of one -- 8 launches instead of 13 for the 6 iterations of the orkut stand-in,
-        # schedule 0.29 -> 0.27 ms; GRAPHLILY_BFS_ONE_LAUNCH=0 keeps the two-launch slot with its fused decisions)
-        one_launch = (os.environ.get("GRAPHLILY_BFS_SHARD_STEP", "1") != "0" if sharded
-                      else os.environ.get("GRAPHLILY_BFS_ONE_LAUNCH", "1") != "0")
         rank, world = self.comm.rank, self.comm.world_size
         tally, tally_in = st.get("tally"), None
-        if one_launch and getattr(self.comm, "emulated", False):
+        if getattr(self.comm, "emulated", False):
             table = self.comm.truth_tally((source, N), N, self.bounds_, self.col_len_, self.row_len_, n)
             tally_in = None if self.comm.copy else table
 
         def may_of(it):
             return (1 if it + 1 < N else 0) | (2 if it + 1 <= N else 0)
 
-        def schedule_one_launch():
+        def schedule():
             capi.bfs_bits_begin(ctl, st["ctl_words"], distance, n, st["vecs"], words, st["nvec_all"], 0 if pull_only else 0xffffffff)
             for it in range(1, N + 1):
                 capi.bfs_bits_shard_step(csc_plan, pull_plan, gathered[it], bits[it + 1], words, distance, float(it + 1), ctl, tally,
@@ -499,23 +405,6 @@ class BFS(_GraphApp):
                 if sharded:
                     self._exchange_bits(st, it + 1, it)
             capi.bfs_bits_shard_finish(csc_plan, pull_plan, ctl, tally, tally_in, N, rank, world, self.nnz_global_, threshold, may_of(N), back)
-
-        def schedule():
-            if one_launch:
-                return schedule_one_launch()
-            capi.bfs_bits_begin(ctl, st["ctl_words"], distance, n, st["vecs"], words, st["nvec"], 0 if pull_only else 0xffffffff)
-            for it in range(1, N + 1):
-                may = (1 if it + 1 < N else 0) | (2 if it + 1 <= N else 0) | deferred
-                # (pull_only: never scatters, but the launch is also the bottom-up pull of the late slots)
-                capi.bfs_bits_push_step(csc_plan, pull_plan, gathered[it], bits[it + 1], None, words, distance, float(it + 1), ctl, it,
-                                        threshold, may)
-                # (also in the first slot, which always pushes: the gated-off pull step takes the push step's decisions)
-                capi.bfs_bits_pull_step(pull_plan, csc_plan, gathered[it], bits[it + 1], distance, float(it + 1), ctl, it, threshold,
-                                        may, back)
-                if sharded:
-                    self._exchange_bits(st, it + 1)
-                    capi.bfs_bits_decide(csc_plan, gathered[it + 1], st["col_len"], st["row_len"], self.nnz_global_, ctl, it, threshold,
-                                         may, back)
 
         # Levels are small integers: when they fit a byte (N + 1 <= 255; a nibble up to 14 iterations) the result crosses PCIe
         # PACKED -- 1.5 or 3 MB instead of 12 MB on orkut, 28 or 55 us instead of 225, the control words behind them in the
@@ -560,12 +449,12 @@ class BFS(_GraphApp):
             capi.levels_pack(B.view(distance, lo, own, 4), own, pbits, ctl, cw, st["lev8"])   # (levels, then the control words)
             st["lev8"].read_async(st["h8"])
 
-        capi.fill_u32_gated(B.view(ctl, 2, 1, 4), int(source), 1, None, 0)   # ctl[2] = source (see _pull_push_device)
-        key = (N, float(threshold), back, pull_only, one_launch, in_graph, lo, own)
+        capi.fill_u32(B.view(ctl, 2, 1, 4), int(source), 1)   # ctl[2] = source (see _pull_push_device)
+        key = (N, float(threshold), back, pull_only, True, in_graph, lo, own)
         g = st["graphs"].get(key)
         # (a torch.distributed collective is not recorded by the library's capture: those runs are enqueued call by call)
         capturable = not sharded or getattr(self.comm, "capturable", False)
-        if g is None and capturable and os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0" and key in st["warm"]:
+        if g is None and capturable and key in st["warm"]:
             try:
                 with capi.Graph.capture() as g:
                     schedule()
@@ -619,42 +508,34 @@ class BFS(_GraphApp):
         self.bfs_slot_modes_ = c[17 + S:17 + S + N].copy()      # 1 scattered, 2 streamed row-wise, 3 bottom-up, 0 nothing ran
         return res
 
-    def _exchange_bits(self, st, k, tally_slot=None):
-        """The one exchange step of a sharded slot: every rank's rows of bit vector k to every rank -- and, with the
-        one-launch slot, every rank's tallies of slot `tally_slot` (256 bytes each) along with them."""
+    def _exchange_bits(self, st, k, tally_slot):
+        """The one exchange step of a sharded slot: every rank's rows of bit vector k to every rank, and every rank's tallies
+        of slot `tally_slot` (256 bytes each) along with them."""
         comm, W = self.comm, self.comm.world_size
         per = capi.GL_BFS_TALLY_RANK_WORDS
-        first = capi.GL_BFS_TALLY_HEAD_WORDS + (tally_slot - 1) * W * per if tally_slot is not None else 0
+        first = capi.GL_BFS_TALLY_HEAD_WORDS + (tally_slot - 1) * W * per
         if hasattr(comm, "exchange_bits"):                 # the C-ABI communicator (gl_dist_*) or the one-GPU emulation
-            if tally_slot is None:
-                comm.exchange_bits(st["bits"][k], k, self.bounds_)
-            else:
-                comm.exchange_bits(st["bits"][k], k, self.bounds_, self.backend.view(st["tally"], first, W * per, 4), tally_slot)
+            comm.exchange_bits(st["bits"][k], k, self.bounds_, self.backend.view(st["tally"], first, W * per, 4), tally_slot)
             return
         t = st["vecs"].tensor[k * st["words"]:(k + 1) * st["words"]]
-        if tally_slot is None:
-            comm.all_gather_slices(t, [b // 32 for b in self.bounds_])
-        else:                                              # ONE collective per slot: the tallies ride behind the rank's bits
-            base = st["nvec"] * st["words"] + first
-            comm.all_gather_slices_with_tail(t, [b // 32 for b in self.bounds_], st["vecs"].tensor[base:base + W * per], per)
+        base = st["nvec"] * st["words"] + first               # ONE collective per slot: the tallies ride behind the rank's bits
+        comm.all_gather_slices_with_tail(t, [b // 32 for b in self.bounds_], st["vecs"].tensor[base:base + W * per], per)
 
     def _bits_loop_ok(self):
-        if os.environ.get("GRAPHLILY_BFS_BITS", "1") == "0" or os.environ.get("GRAPHLILY_BFS_FUSED", "1") == "0":
+        """Can this BFS run as the device-resident schedule?  (GRAPHLILY_BFS_HOST_LOOP=1: no -- the reference's loop.)"""
+        if os.environ.get("GRAPHLILY_BFS_HOST_LOOP", "0") != "0" or not hasattr(capi, "bfs_bits_shard_step"):
             return False
-        if not hasattr(capi, "bfs_bits_push_step") or getattr(self.SpMV_, "plan_", None) is None or getattr(self.SpMSpV_, "plan_", None) is None:
+        if getattr(self.SpMV_, "plan_", None) is None or getattr(self.SpMSpV_, "plan_", None) is None:
             return False
-        if self.comm.distributed:
-            # any boolean plan whose row range is cut on multiples of 64 rows (split plans claim rows with atomics)
-            return (os.environ.get("GRAPHLILY_BFS_DEVICE_LOOP", "1") != "0" and hasattr(self.SpMV_, "bits_words")
-                    and self.SpMV_.bits_words() > 0 and self.SpMV_.semiring_.zero == 0.0
-                    and all(b % 64 == 0 for b in self.bounds_[:-1]))
-        return self._device_loop_ok()
+        if not (hasattr(self.SpMV_, "bits_words") and self.SpMV_.bits_words() > 0 and self.SpMV_.semiring_.zero == 0.0):
+            return False
+        if self.comm.distributed:      # any boolean plan whose row range is cut on multiples of 64 rows
+            return all(b % 64 == 0 for b in self.bounds_[:-1])
+        return hasattr(self.SpMV_, "fused_bfs_ok") and self.SpMV_.fused_bfs_ok()
 
     def pull_push(self, source, num_iterations, threshold=0.05):
         if self._bits_loop_ok():
             return self._pull_push_bits(source, num_iterations, threshold)
-        if self._device_loop_ok():
-            return self._pull_push_device(source, num_iterations, threshold)
         n = self.n_
         frontier, distance, local = self._start_push(source)
         it = 1
@@ -911,82 +792,19 @@ class SSSP(_GraphApp):
         self.backend.sync()
         return self.backend.download_result(distance, self.n_)
 
-    # -- pull_push without the host in the loop (the reference reads the result count back every push
-    #    iteration, app/sssp.h:221) ------------------------------------------------------------------------------------
-    def _device_loop_ok(self):
-        plan = getattr(self.SpMV_, "plan_", None)
-        # Off by default since round 4: the schedule enqueues BOTH steps of every slot and gates one of them off -- five no-op
-        # launches per slot, 0.4 ms of them on the ogbn-products stand-in's 23 slots (same-box A/B, profiles/r04_ab_schedules.txt:
-        # 3.60 ms against the host-driven loop's 3.18) -- while the host-driven loop now waits for the SpMSpV's own completion
-        # record (gl_spmspv_wait) behind the relax step instead of copying the count back.  GRAPHLILY_SSSP_DEVICE_LOOP=1: the schedule.
-        return (not self.comm.distributed and os.environ.get("GRAPHLILY_SSSP_DEVICE_LOOP", "0") != "0"
-                and hasattr(self.SpMSpV_, "run_gated") and plan is not None and hasattr(plan, "run_flagged")
-                and getattr(self.SpMSpV_, "plan_", None) is not None
-                and plan.info()["layout"] in ("general", "pattern") and plan.info()["num_units"] > 0)
-
-    def _pull_push_device(self, source, num_iterations, threshold):
-        """The whole schedule enqueued up front (and replayed as a hipGraph from the third call on): slot `it` holds a push
-        step -- SpMSpV (min,+) + the relax / new-frontier pass, gated on `ctl[0] > it` -- and, from the second slot on, a pull
-        step -- SpMV (min,+) + the results -> vector copy (eWiseAdd +0, app/sssp.h:236-241), predicated on the slot's pull
-        flag.  The SpMSpV's compaction takes the reference's decision where the result count is produced (the same float
-        comparison, gl_compact.h Direction) and raises the pull flags of every later slot.  No synchronisation and no
-        device->host copy between the first launch and the read-back of distances + control words."""
-        B, n, N = self.backend, self.n_, num_iterations
-        st = getattr(self, "dev_loop_", None)
-        if st is None or st["N"] < N:
-            cw = (33 + N + 15) & ~15
-            both = B.alloc(n + cw, np.float32)                 # distances, then the control words: one read-back
-            st = self.dev_loop_ = {"N": N, "both": both, "cw": cw, "ctl": B.view(both, n, cw, 4), "distance": B.view(both, 0, n, 4),
-                                   "results": B.alloc(n, np.float32), "frontier": B.alloc(n + 1, capi.IDX_VAL),
-                                   "candidates": B.alloc(n + 1, capi.IDX_VAL), "graphs": {}, "warm": set(), "src": np.zeros(1, np.uint32)}
-            st["flags"] = [B.view(st["ctl"], 32 + it, 1, 4) for it in range(N + 1)]
-        ctl, distance, results, frontier, cand = st["ctl"], st["distance"], st["results"], st["frontier"], st["candidates"]
-        sem, plan = self.semiring_, self.SpMV_.plan_
-
-        def schedule():
-            capi.sssp_begin(ctl, st["cw"], distance, n, sem.zero, frontier)
-            for it in range(1, N + 1):
-                may = (1 if it + 1 < N else 0) | capi.GL_STEP_PULL_FLAGS
-                self.SpMSpV_.run_gated(frontier, cand, None, 0.0, None, ctl, it, capi.GL_GATE_GT, ctl=ctl, slot=it,
-                                       threshold=threshold, may_continue=may)
-                capi.assign_sparse_new_frontier_gated(cand, distance, frontier, n, ctl, it, capi.GL_GATE_GT)
-                if it >= 2:      # (the first slot always pushes: do { } while, app/sssp.h:217-223)
-                    plan.run_flagged(distance, None, results, sem.op, sem.zero, M.kNoMask, st["flags"][it])
-                    capi.ewise_add_flagged(results, distance, n, 0.0, st["flags"][it])
-
-        capi.fill_u32_gated(B.view(ctl, 2, 1, 4), int(source), 1, None, 0)   # ctl[2] = source (see _pull_push_device)
-        self.SpMSpV_.bind_mask_buf(distance)
-        key = (N, float(threshold))
-        g = st["graphs"].get(key)
-        if g is None and os.environ.get("GRAPHLILY_SSSP_GRAPH", "1") != "0" and key in st["warm"]:
-            try:
-                with capi.Graph.capture() as g:
-                    schedule()
-                st["graphs"][key] = g
-            except capi.GraphLilyError:
-                g = st["graphs"][key] = False
-        if g:
-            g.launch()
-        else:
-            schedule()
-            st["warm"].add(key)
-        out = capi.pinned_recycled(n + st["cw"], np.float32)
-        st["both"].read_async(out)
-        B.sync()
-        c = out[n:].view(np.uint32)
-        self.push_iterations_ = int(c[1])
-        return out[:n]
-
     def send_matrix_host_to_device(self):
         self.SpMV_.send_matrix_host_to_device()
         self.SpMSpV_.send_matrix_host_to_device()
         if hasattr(self.SpMSpV_, "attach_pull"):
             self.SpMSpV_.attach_pull(self.SpMV_)     # heavy frontiers of a push iteration go row-wise
-        self.dev_loop_ = None                        # the schedule holds the old plans' device pointers
 
     def pull_push(self, source, num_iterations, threshold=0.05):
-        if self._device_loop_ok():
-            return self._pull_push_device(source, num_iterations, threshold)
+        """app/sssp.h:197-243, host-driven like the reference -- but the count that decides the loop is the SpMSpV's own
+        completion record (gl_spmspv_wait: stored to page-locked memory by the operator's last workgroup), read while the
+        relax step that was enqueued behind it runs; no copy, no stream synchronisation per iteration.  (Rounds 2-3 also had
+        a device-resident schedule with both steps of every slot enqueued and one gated off: five no-op launches per slot --
+        same-box it lost on five of six stand-ins, 3.60 against 3.18 ms on ogbn-products' 23 slots,
+        profiles/r04_ab_schedules.txt -- retired in round 4.)"""
         n = self.n_
         frontier, distance, candidates, local = self._start_push(source)
         it = 1

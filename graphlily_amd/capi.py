@@ -31,25 +31,20 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 EXPORTS = [
     "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
-    "gl_bfs_bits_begin", "gl_bfs_bits_push_step", "gl_bfs_bits_pull_step", "gl_bfs_bits_decide",
-    "gl_bfs_bits_shard_step", "gl_bfs_bits_shard_finish", "gl_dist_all_gather_bits_tally",
-    "gl_buf_d2h_async", "gl_levels_pack", "gl_host_levels_unpack", "gl_host_threads_warm", "gl_host_unpack_threads", "gl_buf_d2h_levels", "gl_sync_levels_unpack",
-    "gl_sssp_begin", "gl_assign_sparse_new_frontier_gated", "gl_spmv_run_flagged", "gl_ewise_add_flagged",
-    "gl_bfs_begin", "gl_spmspv_plan_frontier_bits", "gl_spmspv_run_gated", "gl_bfs_pull_step_gated", "gl_bfs_pull_step_back",
-    "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32", "gl_dist_all_gather_bits",
-    "gl_dist_all_gather_sparse", "gl_dist_slice_plan",
+    "gl_bfs_bits_begin", "gl_bfs_bits_push_step", "gl_bfs_bits_pull_step",     "gl_bfs_bits_shard_step", "gl_bfs_bits_shard_finish", "gl_dist_all_gather_bits_tally",
+    "gl_buf_d2h_async", "gl_levels_pack", "gl_host_levels_unpack", "gl_host_unpack_threads", "gl_buf_d2h_levels", "gl_sync_levels_unpack",
+            "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32",     "gl_dist_all_gather_sparse", "gl_dist_slice_plan",
     "gl_spmv_run_typed", "gl_spmspv_run_typed", "gl_ewise_add_typed", "gl_assign_dense_typed", "gl_assign_sparse_typed",
     "gl_assign_sparse_new_frontier_typed", "gl_sparse_to_dense_typed",
-    "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32", "gl_buf_fill_u32_gated",
-    "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim", "gl_pool_stats", "gl_host_pool_reserve", "gl_host_fill_u32", "gl_host_sparse_to_dense",
-    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_info", "gl_spmv_plan_shape", "gl_spmv_plan_hot", "gl_spmv_plan_helper", "gl_spmv_plan_layout", "gl_spmv_plan_export", "gl_spmv_run",
+    "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32", "gl_buf_fill_u32",     "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim", "gl_pool_stats", "gl_host_pool_reserve", "gl_host_fill_u32", "gl_host_sparse_to_dense",
+    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_describe", "gl_spmv_plan_export", "gl_spmv_run",
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_unpack_bits", "gl_bfs_bits_begin_from", "gl_spmv_run_bits", "gl_bfs_pull_step",
-    "gl_prof_begin", "gl_prof_end", "gl_prof_sample_every", "gl_span_begin", "gl_span_end",
+    "gl_prof_begin", "gl_prof_end", "gl_span_begin", "gl_span_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run", "gl_spmspv_run_assign",
-    "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_plan_hint_tiny", "gl_spmspv_plan_hint_work", "gl_spmspv_last_direction", "gl_spmspv_wait",
+    "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_plan_hint_work", "gl_spmspv_last_direction", "gl_spmspv_wait",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
     "gl_assign_sparse_new_frontier", "gl_sparse_to_dense",
-    "gl_host_csr2csc", "gl_csr2csc", "gl_csr_normalize_by_outdegree", "gl_npz_csr_open", "gl_npz_csr_read", "gl_npz_csr_close",
+    "gl_csr2csc", "gl_csr_normalize_by_outdegree", "gl_npz_csr_open", "gl_npz_csr_read", "gl_npz_csr_close",
 ]
 
 
@@ -82,24 +77,16 @@ def lib():
     P = ctypes.POINTER
     sigs = {
         "gl_graph_begin_capture": [], "gl_graph_end_capture": [P(vp)], "gl_graph_launch": [vp], "gl_graph_destroy": [vp],
-        "gl_bfs_begin": [vp, vp, u32, vp, vp, u32],
         "gl_bfs_bits_begin": [vp, u32, vp, u32, vp, u32, u32, u32],
         "gl_buf_d2h_async": [vp, vp, ctypes.c_size_t],
-        "gl_levels_pack": [vp, u32, i32, vp, u32, vp], "gl_host_levels_unpack": [vp, vp, ctypes.c_size_t, i32], "gl_host_threads_warm": [], "gl_host_unpack_threads": [], "gl_buf_d2h_levels": [vp, vp, ctypes.c_size_t, f32, P(i32)], "gl_sync_levels_unpack": [vp, vp, ctypes.c_size_t, i32],
+        "gl_levels_pack": [vp, u32, i32, vp, u32, vp], "gl_host_levels_unpack": [vp, vp, ctypes.c_size_t, i32], "gl_host_unpack_threads": [], "gl_buf_d2h_levels": [vp, vp, ctypes.c_size_t, f32, P(i32)], "gl_sync_levels_unpack": [vp, vp, ctypes.c_size_t, i32],
         "gl_bfs_bits_push_step": [vp, vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
         "gl_bfs_bits_pull_step": [vp, vp, vp, vp, vp, f32, vp, u32, f32, i32, f32],
-        "gl_bfs_bits_decide": [vp, vp, vp, vp, u64, vp, u32, f32, i32, f32],
         "gl_bfs_bits_shard_step": [vp, vp, vp, vp, u32, vp, f32, vp, vp, vp, u32, i32, i32, vp, u64, f32, i32, f32],
         "gl_bfs_bits_shard_finish": [vp, vp, vp, vp, vp, u32, i32, i32, u64, f32, i32, f32],
         "gl_dist_all_gather_bits_tally": [vp, vp, vp, vp, u32],
-        "gl_sssp_begin": [vp, u32, vp, u32, f32, vp], "gl_assign_sparse_new_frontier_gated": [vp, vp, vp, u32, vp, u32, i32],
-        "gl_spmv_run_flagged": [vp, vp, vp, vp, i32, f32, i32, vp], "gl_ewise_add_flagged": [vp, vp, u32, f32, vp],
-        "gl_spmspv_run_gated": [vp, vp, vp, vp, i32, f32, i32, vp, f32, vp, vp, u32, i32, vp, u32, f32, i32],
-        "gl_bfs_pull_step_gated": [vp, vp, vp, vp, f32, vp, u32, i32],
-        "gl_spmspv_plan_frontier_bits": [vp, vp],
-        "gl_bfs_pull_step_back": [vp, vp, vp, vp, f32, vp, u32, f32, i32, vp, vp],
         "gl_dist_unique_id": [vp], "gl_dist_init": [P(vp), i32, i32, vp], "gl_dist_destroy": [vp], "gl_dist_rank": [vp, P(i32), P(i32)],
-        "gl_dist_all_gather_f32": [vp, vp, vp], "gl_dist_all_gather_bits": [vp, vp, vp],
+        "gl_dist_all_gather_f32": [vp, vp, vp],
         "gl_dist_all_gather_sparse": [vp, vp, vp, u32, f32, P(u32)], "gl_dist_slice_plan": [i32, i32, vp, vp, vp],
         "gl_spmv_run_typed": [vp, vp, vp, vp, i32, u32, i32, i32], "gl_spmspv_run_typed": [vp, vp, vp, vp, i32, u32, i32, i32],
         "gl_ewise_add_typed": [vp, vp, u32, u32, i32], "gl_assign_dense_typed": [vp, vp, u32, u32, i32, i32],
@@ -112,29 +99,24 @@ def lib():
         "gl_host_pool_reserve": [ctypes.c_size_t, u32], "gl_host_fill_u32": [vp, u32, ctypes.c_size_t], "gl_host_sparse_to_dense": [vp, u32, u32, vp],
         "gl_buf_h2d": [vp, vp, ctypes.c_size_t], "gl_buf_d2h": [vp, vp, ctypes.c_size_t],
         "gl_buf_d2d": [vp, vp, ctypes.c_size_t], "gl_buf_fill_f32": [vp, f32, ctypes.c_size_t],
-        "gl_buf_fill_u32_gated": [vp, u32, ctypes.c_size_t, vp, u32],
+        "gl_buf_fill_u32": [vp, u32, ctypes.c_size_t],
         "gl_spmv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmv_plan_create_ex": [P(vp), u32, u32, vp, vp, vp, u32, u32, u32],
-        "gl_spmv_plan_destroy": [vp], "gl_spmv_plan_info": [vp, P(u64), P(u64), P(u32)],
-        "gl_spmv_plan_shape": [vp, P(u32), P(u32), P(u32), P(u64)],
-        "gl_spmv_plan_hot": [vp, P(u32), P(u64), P(i32)],
-        "gl_spmv_plan_helper": [vp, P(i32), P(u32)],
-        "gl_spmv_plan_layout": [vp, P(i32)],
+        "gl_spmv_plan_destroy": [vp], "gl_spmv_plan_describe": [vp, vp],
         "gl_spmv_plan_export": [vp, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)],
         "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_unpack_bits": [vp, u32, vp], "gl_bfs_bits_begin_from": [vp, u32, vp, u32, vp, u32, vp, vp], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
         "gl_bfs_pull_step": [vp, vp, vp, vp, f32],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
-        "gl_prof_begin": [u32], "gl_prof_end": [P(ctypes.c_double), P(u32)], "gl_prof_sample_every": [u32], "gl_span_begin": [], "gl_span_end": [P(ctypes.c_double)],
+        "gl_prof_begin": [u32, u32], "gl_prof_end": [P(ctypes.c_double), P(u32)], "gl_span_begin": [], "gl_span_end": [P(ctypes.c_double)],
         "gl_spmspv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmspv_plan_destroy": [vp], "gl_spmspv_plan_info": [vp, P(u64), P(u64)],
         "gl_spmspv_run": [vp, vp, vp, vp, i32, f32, i32],
         "gl_spmspv_run_assign": [vp, vp, vp, vp, i32, f32, i32, vp, f32],
-        "gl_spmspv_plan_attach_pull": [vp, vp], "gl_spmspv_plan_hint": [vp, u32], "gl_spmspv_plan_hint_tiny": [vp, u32, u64], "gl_spmspv_plan_hint_work": [vp, u32, u64, u32], "gl_spmspv_last_direction": [vp, P(i32)], "gl_spmspv_wait": [vp, P(u32)],
+        "gl_spmspv_plan_attach_pull": [vp, vp], "gl_spmspv_plan_hint": [vp, u32], "gl_spmspv_plan_hint_work": [vp, u32, u64, u32], "gl_spmspv_last_direction": [vp, P(i32)], "gl_spmspv_wait": [vp, P(u32)],
         "gl_sparse_nnz": [vp, P(u32)],
         "gl_ewise_add": [vp, vp, u32, f32], "gl_assign_dense": [vp, vp, u32, f32, i32],
         "gl_assign_sparse": [vp, vp, f32, u32], "gl_assign_sparse_new_frontier": [vp, vp, vp, u32],
         "gl_sparse_to_dense": [vp, vp, u32, f32, u32],
-        "gl_host_csr2csc": [u32, u32, vp, vp, vp, vp, vp, vp],
         "gl_csr2csc": [u32, u32, vp, vp, vp, vp, vp, vp],
         "gl_csr_normalize_by_outdegree": [u32, u32, vp, vp, vp],
         "gl_npz_csr_open": [ctypes.c_char_p, P(vp), P(u32), P(u32), P(u64)],
@@ -343,13 +325,20 @@ def _p(buf):
 GL_PLAN_NO_MULADD = 1
 GL_PLAN_BOOLEAN = 2
 GL_PLAN_KEEP_VALUES = 4
-GL_GATE_EQ, GL_GATE_GT, GL_GATE_LE = 0, 1, 2
 GL_VAL_FLOAT, GL_VAL_UNSIGNED, GL_VAL_UFIXED_32_8 = 0, 1, 2
 GL_PLAN_HOST_FORMAT = 8
 GL_PLAN_DEVICE_FORMAT = 16
 GL_PLAN_REFERENCE_ORDER = 32
 PLAN_ARRAYS = {"entries": 0, "bases": 1, "units": 2, "hub_rows": 3, "spans": 4}
 GL_ERR_UNSUPPORTED = -5
+
+
+class _PlanDesc(ctypes.Structure):
+    """gl_spmv_plan_desc (include/graphlily_hip.h)"""
+    _fields_ = [("nnz", ctypes.c_uint64), ("device_bytes", ctypes.c_uint64), ("groups", ctypes.c_uint64), ("hot_nnz", ctypes.c_uint64),
+                ("num_units", ctypes.c_uint32), ("blocks", ctypes.c_uint32), ("segments", ctypes.c_uint32), ("max_block_rows", ctypes.c_uint32),
+                ("hot_columns", ctypes.c_uint32), ("packed_columns", ctypes.c_uint32),
+                ("layout", ctypes.c_int), ("mix", ctypes.c_int), ("helper", ctypes.c_int)]
 
 
 class SpMVPlan:
@@ -372,33 +361,18 @@ class SpMVPlan:
         cached = getattr(self, "_info", None)      # (a plan never changes: the drivers ask on every call)
         if cached is not None:
             return dict(cached)
-        nnz, nbytes, ntiles = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint32(0)
-        check(lib().gl_spmv_plan_info(ctypes.c_void_p(self.handle), ctypes.byref(nnz), ctypes.byref(nbytes),
-                                      ctypes.byref(ntiles)))
-        b, sg, mr, g = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint64(0)
-        check(lib().gl_spmv_plan_shape(ctypes.c_void_p(self.handle), ctypes.byref(b), ctypes.byref(sg),
-                                       ctypes.byref(mr), ctypes.byref(g)))
-        hc, hn, mix = ctypes.c_uint32(0), ctypes.c_uint64(0), ctypes.c_int(0)
-        check(lib().gl_spmv_plan_hot(ctypes.c_void_p(self.handle), ctypes.byref(hc), ctypes.byref(hn),
-                                     ctypes.byref(mix)))
-        lay = ctypes.c_int(0)
-        check(lib().gl_spmv_plan_layout(ctypes.c_void_p(self.handle), ctypes.byref(lay)))
-        hm, pc = ctypes.c_int(0), ctypes.c_uint32(0)
-        check(lib().gl_spmv_plan_helper(ctypes.c_void_p(self.handle), ctypes.byref(hm), ctypes.byref(pc)))
-        self._info = {"helper": ("gather", "spread", "self-hot", "none")[hm.value], "packed_columns": pc.value,
-                      "nnz": nnz.value, "device_bytes": nbytes.value, "num_units": ntiles.value, "blocks": b.value,
-                      "segments": sg.value, "max_block_rows": mr.value, "groups": g.value,
-                      "hot_columns": hc.value, "hot_nnz": hn.value, "mix": mix.value,
-                      "layout": ("general", "pattern", "boolean", "reference-order")[lay.value]}
+        d = _PlanDesc()
+        check(lib().gl_spmv_plan_describe(ctypes.c_void_p(self.handle), ctypes.byref(d)))
+        self._info = {"helper": ("gather", "spread", "self-hot", "none")[d.helper], "packed_columns": d.packed_columns,
+                      "nnz": d.nnz, "device_bytes": d.device_bytes, "num_units": d.num_units, "blocks": d.blocks,
+                      "segments": d.segments, "max_block_rows": d.max_block_rows, "groups": d.groups,
+                      "hot_columns": d.hot_columns, "hot_nnz": d.hot_nnz, "mix": d.mix,
+                      "layout": ("general", "pattern", "boolean", "reference-order")[d.layout]}
         return dict(self._info)
 
     def run(self, x, mask, y, op, zero, mask_type):
         check(lib().gl_spmv_run(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero),
                                 int(mask_type)))
-
-    def run_flagged(self, x, mask, y, op, zero, mask_type, flag):
-        """gl_spmv_run_flagged: gl_spmv_run that does nothing unless the device word `flag` is non-zero."""
-        check(lib().gl_spmv_run_flagged(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), float(zero), int(mask_type), _p(flag)))
 
     def run_typed(self, x, mask, y, op, zero_bits, mask_type, val_type):
         """gl_spmv_run_typed: the buffers hold 32-bit value words of `val_type` (GL_VAL_*)."""
@@ -417,14 +391,6 @@ class SpMVPlan:
         v = ctypes.c_uint64(0)
         check(lib().gl_spmv_plan_bits_words(ctypes.c_void_p(self.handle), ctypes.byref(v)))
         return v.value
-
-    def bfs_pull_step_gated(self, bits_in, bits_out, distance, level, gate, gate_value, gate_op):
-        check(lib().gl_bfs_pull_step_gated(ctypes.c_void_p(self.handle), _p(bits_in), _p(bits_out), _p(distance), float(level),
-                                           _p(gate), int(gate_value), int(gate_op)))
-
-    def bfs_pull_step_back(self, bits_in, bits_out, distance, level, ctl, slot, back_threshold, may_continue, frontier_out, scratch):
-        check(lib().gl_bfs_pull_step_back(ctypes.c_void_p(self.handle), _p(bits_in), _p(bits_out), _p(distance), float(level), _p(ctl),
-                                          int(slot), float(back_threshold), int(bool(may_continue)), _p(frontier_out), _p(scratch)))
 
     def bfs_pull_step(self, bits_in, bits_out, distance, level):
         check(lib().gl_bfs_pull_step(ctypes.c_void_p(self.handle), _p(bits_in), _p(bits_out), _p(distance), float(level)))
@@ -467,15 +433,8 @@ class SpMSpVPlan:
                                                ctypes.c_void_p(spmv_plan.handle) if spmv_plan is not None else None))
         self._pull_keepalive = spmv_plan
 
-    def frontier_bits(self, bits):
-        check(lib().gl_spmspv_plan_frontier_bits(ctypes.c_void_p(self.handle), _p(bits)))
-
     def hint(self, vector_nnz_upper_bound):
         check(lib().gl_spmspv_plan_hint(ctypes.c_void_p(self.handle), int(vector_nnz_upper_bound)))
-
-    def hint_tiny(self, vector_nnz, work):
-        """gl_spmspv_plan_hint_tiny: the next run's vector is expected to hold `vector_nnz` entries / `work` column non-zeros."""
-        check(lib().gl_spmspv_plan_hint_tiny(ctypes.c_void_p(self.handle), int(vector_nnz), int(work)))
 
     def hint_work(self, vector_nnz, work, longest_column):
         """gl_spmspv_plan_hint_work: the next run's vector holds `vector_nnz` entries whose columns hold `work` non-zeros, the
@@ -497,12 +456,6 @@ class SpMSpVPlan:
         n = ctypes.c_uint32(0)
         check(lib().gl_spmspv_wait(ctypes.c_void_p(self.handle), ctypes.byref(n)))
         return None if n.value == 0xffffffff else n.value
-
-    def run_gated(self, vector, mask, result, op, zero, mask_type, inout, val, next_bits, gate, gate_value, gate_op,
-                  ctl=None, slot=0, threshold=0.0, may_continue=False):
-        check(lib().gl_spmspv_run_gated(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op), float(zero),
-                                        int(mask_type), _p(inout), float(val), _p(next_bits), _p(gate), int(gate_value),
-                                        int(gate_op), _p(ctl), int(slot), float(threshold), int(may_continue)))
 
     def run_typed(self, vector, mask, result, op, zero_bits, mask_type, val_type):
         check(lib().gl_spmspv_run_typed(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op), int(zero_bits),
@@ -601,15 +554,11 @@ class Dist:
         b = np.ascontiguousarray(bounds, dtype=np.uint32)
         check(lib().gl_dist_all_gather_f32(ctypes.c_void_p(self.handle), _p(full), _np_ptr(b)))
 
-    def all_gather_bits(self, bits, row_bounds):
-        b = np.ascontiguousarray(row_bounds, dtype=np.uint32)
-        check(lib().gl_dist_all_gather_bits(ctypes.c_void_p(self.handle), _p(bits), _np_ptr(b)))
-
     def all_gather_bits_tally(self, bits, row_bounds, tally_slot):
-        """the slot's bit vector and every rank's tallies of the slot in one grouped operation"""
+        """the slot's bit vector and (tally_slot not None) every rank's tallies of the slot in one grouped operation"""
         b = np.ascontiguousarray(row_bounds, dtype=np.uint32)
         check(lib().gl_dist_all_gather_bits_tally(ctypes.c_void_p(self.handle), _p(bits), _np_ptr(b), _p(tally_slot),
-                                                  4 * GL_BFS_TALLY_RANK_WORDS))
+                                                  4 * GL_BFS_TALLY_RANK_WORDS if tally_slot is not None else 0))
 
     def all_gather_sparse(self, local, full, capacity, head_val):
         n = ctypes.c_uint32(0)
@@ -629,8 +578,8 @@ class Dist:
             pass
 
 
-def fill_u32_gated(buf, value, count, gate, gate_value):
-    check(lib().gl_buf_fill_u32_gated(_p(buf), int(value), int(count), _p(gate), int(gate_value)))
+def fill_u32(buf, value, count):
+    check(lib().gl_buf_fill_u32(_p(buf), int(value), int(count)))
 
 
 def bfs_bits_begin(ctl, ctl_words, distance, n, bits, bits_words, nvec, first_pull_slot=0xffffffff):
@@ -650,27 +599,6 @@ def bfs_bits_pull_step(pull_plan, csc_plan, bits_in, bits_out, distance, level, 
                                       float(back_threshold)))
 
 
-GL_BFS_DEFERRED = 4
-GL_STEP_PULL_FLAGS = 8
-
-
-def sssp_begin(ctl, ctl_words, distance, n, zero, frontier):
-    check(lib().gl_sssp_begin(_p(ctl), int(ctl_words), _p(distance), int(n), float(zero), _p(frontier)))
-
-
-def assign_sparse_new_frontier_gated(mask, inout, new_frontier, max_entries, gate, gate_value, gate_op):
-    check(lib().gl_assign_sparse_new_frontier_gated(_p(mask), _p(inout), _p(new_frontier), int(max_entries), _p(gate), int(gate_value),
-                                                    int(gate_op)))
-
-
-def ewise_add_flagged(inp, out, length, val, flag):
-    check(lib().gl_ewise_add_flagged(_p(inp), _p(out), int(length), float(val), _p(flag)))
-
-
-def bfs_bits_decide(csc_plan, bits_next, col_len, row_len, nnz_global, ctl, slot, threshold, may_continue, back_threshold):
-    """gl_bfs_bits_decide: the slot's decisions of a row-sharded schedule, from the all-gathered next frontier."""
-    check(lib().gl_bfs_bits_decide(ctypes.c_void_p(csc_plan.handle), _p(bits_next), _p(col_len), _p(row_len), int(nnz_global), _p(ctl),
-                                   int(slot), float(threshold), int(may_continue), float(back_threshold)))
 
 
 GL_BFS_TALLY_HEAD_WORDS = 64
@@ -731,22 +659,13 @@ def host_unpack_threads():
     return int(lib().gl_host_unpack_threads())
 
 
-def host_threads_warm():
-    check(lib().gl_host_threads_warm())
-
-
-def bfs_begin(ctl, distance, n, frontier, bits, bits_words):
-    check(lib().gl_bfs_begin(_p(ctl), _p(distance), int(n), _p(frontier), _p(bits), int(bits_words)))
-
-
 def pack_bits(x, n, bits):
     """bits[i / 32] bit (i % 32) = (x[i] != 0), i < n; x and bits are DeviceBuffers (or views)."""
     check(lib().gl_pack_bits(_p(x), int(n), _p(bits)))
 
 
 def prof_begin(max_launches, every=1):
-    check(lib().gl_prof_sample_every(int(every)))
-    check(lib().gl_prof_begin(int(max_launches)))
+    check(lib().gl_prof_begin(int(max_launches), int(every)))
 
 
 def prof_end():

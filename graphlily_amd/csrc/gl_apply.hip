@@ -238,15 +238,6 @@ int bits_to_sparse_gated(const uint32_t *d_bits, uint32_t n, gl_idx_val *d_out, 
 
 extern "C" {
 
-int gl_bfs_begin(uint32_t *d_ctl, float *d_distance, uint32_t n, gl_idx_val *d_frontier, uint32_t *d_bits, uint32_t bits_words) {
-    GL_REQUIRE_INIT();
-    GL_ARG(d_ctl != nullptr && d_distance != nullptr && n > 0);
-    GL_ARG(d_frontier != nullptr || d_bits != nullptr);
-    gl::bfs_begin_kernel<<<gl::stream_grid(n), 256, 0, gl::ctx().stream>>>(d_ctl, d_distance, n, d_frontier, d_bits, bits_words);
-    GL_LAUNCH_CHECK();
-    return GL_OK;
-}
-
 
 int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
                       uint32_t nvec, uint32_t first_pull_slot) {
@@ -298,45 +289,16 @@ int gl_assign_sparse(const gl_idx_val *d_mask, float *d_inout, float val, uint32
 
 int gl_assign_sparse_new_frontier(const gl_idx_val *d_mask, float *d_inout, gl_idx_val *d_new_frontier,
                                   uint32_t max_entries) {
-    return gl_assign_sparse_new_frontier_gated(d_mask, d_inout, d_new_frontier, max_entries, nullptr, 0u, GL_GATE_EQ);
-}
-
-int gl_assign_sparse_new_frontier_gated(const gl_idx_val *d_mask, float *d_inout, gl_idx_val *d_new_frontier, uint32_t max_entries,
-                                        const uint32_t *d_gate, uint32_t gate_value, int gate_op) {
     GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(d_mask != nullptr && d_inout != nullptr && d_new_frontier != nullptr);
     GL_ARG((const void *)d_mask != (const void *)d_new_frontier);
-    GL_ARG(gate_op == GL_GATE_EQ || gate_op == GL_GATE_GT || gate_op == GL_GATE_LE);
     void *counts = nullptr;
     int rc = gl::scratch_reserve((size_t)(gl::cdiv(max_entries, gl::kCompactChunk) + 1) * sizeof(uint32_t), &counts);
     if (rc != GL_OK) return rc;
     gl::RelaxSource src{d_mask, d_inout};
-    gl::Gate gate;
-    gate.word = d_gate;
-    gate.value = gate_value;
-    gate.op = gate_op;
     // head of the new frontier is {count, 0} (kernel_assign_vector_sparse_new_frontier_impl.h:73-77)
-    return gl::run_compaction(src, max_entries, (uint32_t *)counts, d_new_frontier, 0.0f, gl::ctx().stream, nullptr, gate);
-}
-
-int gl_sssp_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, float zero, gl_idx_val *d_frontier) {
-    GL_REQUIRE_INIT();
-    GL_ARG(d_ctl != nullptr && d_distance != nullptr && d_frontier != nullptr && n > 0);
-    GL_ARG(ctl_words >= 34u && ctl_words <= 65536u);
-    gl::sssp_begin_kernel<<<gl::stream_grid(n), 256, 0, gl::ctx().stream>>>(d_ctl, ctl_words, d_distance, n, zero, d_frontier);
-    GL_LAUNCH_CHECK();
-    return GL_OK;
-}
-
-int gl_ewise_add_flagged(const float *d_in, float *d_out, uint32_t len, float val, const uint32_t *d_flag) {
-    GL_REQUIRE_INIT();
-    if (len == 0) return GL_OK;
-    GL_ARG(d_in != nullptr && d_out != nullptr && d_flag != nullptr);
-    GL_ARG(((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0);
-    gl::ewise_add_flagged_kernel<<<gl::stream_grid((len + 3) / 4), 256, 0, gl::ctx().stream>>>(d_in, d_out, len, val, d_flag);
-    GL_LAUNCH_CHECK();
-    return GL_OK;
+    return gl::run_compaction(src, max_entries, (uint32_t *)counts, d_new_frontier, 0.0f, gl::ctx().stream);
 }
 
 int gl_sparse_to_dense(const gl_idx_val *d_sparse, float *d_dense, uint32_t range, float zero, uint32_t max_entries) {

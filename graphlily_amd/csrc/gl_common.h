@@ -12,6 +12,14 @@
 
 #include "graphlily_hip.h"
 
+// launch predicates and step flags of the kernels' internal interfaces (what is left of the gated schedules of rounds 2-3:
+// the compaction and the boolean pull step still take a predicate, nobody outside the library passes one)
+#define GL_GATE_EQ 0
+#define GL_GATE_GT 1
+#define GL_GATE_LE 2
+#define GL_BFS_DEFERRED 4
+#define GL_STEP_PULL_FLAGS 8
+
 namespace gl {
 
 constexpr int kWave = 64;
@@ -45,6 +53,9 @@ inline bool prof_take(Profiler &pf) {
 }
 
 int set_error(int code, const char *fmt, ...);
+// csr2csc on the host (OpenMP; gl_npz.cpp): what gl_csr2csc does without a device or for small matrices
+int host_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices, const float *data,
+                 uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data);
 
 // GRAPHLILY_TRACE_API=<file>: host-side timeline of the C ABI calls a process makes (name, start, duration in
 // microseconds since the first call, an optional size), written at exit -- where an UNMODIFIED reference driver spends its

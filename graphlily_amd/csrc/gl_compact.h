@@ -163,42 +163,6 @@ __global__ __launch_bounds__(256) void compact_count_kernel(Src src, uint32_t *_
     }
 }
 
-// long lists: counts[1..nblocks] -> exclusive offsets in place, one block; out[0] = {total, head_val}
-static __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t *__restrict__ counts, uint32_t nblocks,
-                                                                   gl_idx_val *__restrict__ out, float head_val,
-                                                                   uint32_t *__restrict__ reset_word, Gate gate, Direction dir) {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
-    if (gate.closed()) return;
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < nblocks; base += 1024u) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = (i < nblocks) ? counts[1u + i] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
-            uint32_t up = __shfl_up(incl, dlt);
-            if (lane >= dlt) incl += up;
-        }
-        if (lane == 63) wave_tot[w] = incl;
-        __syncthreads();
-        uint32_t before = carry_s;
-        for (uint32_t k = 0; k < w; k++) before += wave_tot[k];
-        if (i < nblocks) counts[1u + i] = before + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = before + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        out[0].index = carry_s;
-        out[0].val = head_val;
-        if (reset_word) *reset_word = 0u;
-        dir.decide(carry_s);
-    }
-}
-
 // `own_offsets`: long lists.  offsets[1 ..] still hold the blocks' raw counts: every block sums the counts in front of it
 // itself (a few loads per thread) instead of waiting for a one-block scan launch between the two passes, and the last
 // block writes the head element and takes the loop decision -- one dependent launch less per SpMSpV (~4 us).
@@ -250,12 +214,6 @@ __global__ __launch_bounds__(256) void compact_write_kernel(Src src, const uint3
     }
 }
 
-// GRAPHLILY_COMPACT_SCAN=1: keep the separate one-block scan launch for long lists (A/B)
-static inline bool env_flag_scan_launch() {
-    const char *e = getenv("GRAPHLILY_COMPACT_SCAN");
-    return e && atoi(e) != 0;
-}
-
 // Runs the passes for at most `max_items` candidates (host-side bound for the grid).
 template <typename Src>
 static int run_compaction(Src src, uint32_t max_items, uint32_t *d_counts, gl_idx_val *d_out, float head_val,
@@ -265,12 +223,7 @@ static int run_compaction(Src src, uint32_t max_items, uint32_t *d_counts, gl_id
     const bool fused = nblocks <= kCompactFuseBlocks;
     compact_count_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out, head_val, d_reset_word, fused, gate, dir);
     GL_LAUNCH_CHECK();
-    static const bool scan_launch = env_flag_scan_launch();
-    if (!fused && scan_launch) {
-        compact_scan_kernel<<<1, 1024, 0, s>>>(d_counts, nblocks, d_out, head_val, d_reset_word, gate, dir);
-        GL_LAUNCH_CHECK();
-    }
-    compact_write_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out, gate, !fused && !scan_launch, head_val, d_reset_word, dir);
+    compact_write_kernel<Src><<<nblocks, kCompactThreads, 0, s>>>(src, d_counts, d_out, gate, !fused, head_val, d_reset_word, dir);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

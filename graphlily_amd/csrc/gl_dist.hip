@@ -213,21 +213,13 @@ int gl_dist_all_gather_f32(gl_dist d, float *d_full, const uint32_t *bounds) {
     return gl::exchange_slices(d, reinterpret_cast<char *>(d_full), lo.data(), hi.data());
 }
 
-int gl_dist_all_gather_bits(gl_dist d, uint32_t *d_bits, const uint32_t *row_bounds) {
-    GL_REQUIRE_INIT();
-    GL_ARG(d != nullptr && d_bits != nullptr && row_bounds != nullptr);
-    std::vector<uint64_t> lo(d->world), hi(d->world);
-    const int rc = gl_dist_slice_plan(GL_DIST_BITS, d->world, row_bounds, lo.data(), hi.data());
-    if (rc != GL_OK) return rc;
-    return gl::exchange_slices(d, reinterpret_cast<char *>(d_bits), lo.data(), hi.data());
-}
-
 int gl_dist_all_gather_bits_tally(gl_dist d, uint32_t *d_bits, const uint32_t *row_bounds, uint32_t *d_tally_slot, uint32_t bytes_per_rank) {
     GL_REQUIRE_INIT();
-    GL_ARG(d != nullptr && d_bits != nullptr && row_bounds != nullptr && d_tally_slot != nullptr && bytes_per_rank > 0);
+    GL_ARG(d != nullptr && d_bits != nullptr && row_bounds != nullptr && ((d_tally_slot != nullptr) == (bytes_per_rank > 0)));
     std::vector<uint64_t> lo(d->world), hi(d->world);
     const int rc = gl_dist_slice_plan(GL_DIST_BITS, d->world, row_bounds, lo.data(), hi.data());
     if (rc != GL_OK) return rc;
+    if (!d_tally_slot) return gl::exchange_slices(d, reinterpret_cast<char *>(d_bits), lo.data(), hi.data());   // the bits alone
     return gl::exchange_slices(d, reinterpret_cast<char *>(d_bits), lo.data(), hi.data(), reinterpret_cast<char *>(d_tally_slot), bytes_per_rank);
 }
 

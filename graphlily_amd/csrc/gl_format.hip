@@ -1129,7 +1129,7 @@ int gl_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, con
     GL_ARG(nnz == 0 || (indices != nullptr && data != nullptr && csc_indices != nullptr && csc_data != nullptr));
     if (gl::ctx().initialized && gl::format_on_device(0u, nnz))
         return gl::fmt_csr2csc(num_rows, num_cols, indptr, indices, data, csc_indptr, csc_indices, csc_data);
-    return gl_host_csr2csc(num_rows, num_cols, indptr, indices, data, csc_indptr, csc_indices, csc_data);
+    return gl::host_csr2csc(num_rows, num_cols, indptr, indices, data, csc_indptr, csc_indices, csc_data);
 }
 
 int gl_csr_normalize_by_outdegree(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices, float *data) {

@@ -233,14 +233,14 @@ static bool to_u32(const Npy &a, size_t n, uint32_t *dst, std::string &err) {
 // ------------------------------------------------------------------------------------------------
 // io::csr2csc (io/data_loader.h:108-144) as a parallel counting sort: threads own contiguous row
 // ranges, so inside a column entries keep ascending row order exactly like the reference's loop.
-extern "C" int gl_host_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices,
+int gl::host_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices,
                                const float *data, uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data) {
     GL_ARG(indptr != nullptr && csc_indptr != nullptr);
     const uint64_t nnz = indptr[num_rows];
     GL_ARG(nnz == 0 || (indices != nullptr && data != nullptr && csc_indices != nullptr && csc_data != nullptr));
     for (uint64_t i = 0; i < nnz; i++)
         if (indices[i] >= num_cols)
-            return gl::set_error(GL_ERR_INVALID_ARG, "gl_host_csr2csc: column index %u out of range (num_cols %u)", indices[i], num_cols);
+            return gl::set_error(GL_ERR_INVALID_ARG, "gl_csr2csc: column index %u out of range (num_cols %u)", indices[i], num_cols);
     int T = 1;
 #ifdef _OPENMP
     T = std::min(omp_get_max_threads(), 16);

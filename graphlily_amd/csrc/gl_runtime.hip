@@ -32,7 +32,7 @@ namespace gl {
 //     measured on the MI355X box (scripts/ubench_host.hip, profiles/r02_ubench_host.txt) a 12 MB copy takes 0.23 ms
 //     in either direction from pageable and from page-locked memory alike (56 GB/s), while hipHostMalloc of 12 MB costs
 //     2-2.5 ms -- and a driver whose previous result is still alive needs a new block on its first calls.
-//     GRAPHLILY_HOST_PIN=1 page-locks them for platforms where pageable copies are staged slowly.
+//     (page-locking them buys nothing on this platform).
 // Cached bytes are capped (GRAPHLILY_POOL_MAX_MB, default 8192 device / 2048 host); gl_pool_trim releases them.
 struct BlockPool {
     std::mutex mu;
@@ -105,14 +105,8 @@ static inline size_t round_block(size_t bytes) {
 constexpr size_t kHostPoolThreshold = 64u << 10;   // smaller host blocks go straight to the C library
 constexpr size_t kSpareThreshold = 1u << 20;       // a host-pool miss on a block this large also parks one spare
 constexpr size_t kSlabBytes = 256u << 20;          // device blocks up to a quarter of this are carved from slabs
-static bool pool_trace() {
-    static const bool on = getenv("GRAPHLILY_POOL_TRACE") && atoi(getenv("GRAPHLILY_POOL_TRACE")) != 0;
-    return on;
-}
-static bool spare_on_miss() {
-    static const bool on = !(getenv("GRAPHLILY_POOL_SPARE") && atoi(getenv("GRAPHLILY_POOL_SPARE")) == 0);
-    return on;
-}
+static bool pool_trace() { return false; }      // (compile-time switch for allocation debugging)
+static bool spare_on_miss() { return true; }
 
 void device_pool_leave_device();
 
@@ -324,9 +318,10 @@ int gl_reset_stream(void) {
     return GL_OK;
 }
 
-int gl_prof_begin(uint32_t max_launches) {
+int gl_prof_begin(uint32_t max_launches, uint32_t every) {
     GL_REQUIRE_INIT();
     gl::Profiler &p = gl::prof();
+    p.every = every ? every : 1u;
     while (p.events.size() < 2ull * max_launches) {
         hipEvent_t e;
         GL_HIP(hipEventCreate(&e));
@@ -335,11 +330,6 @@ int gl_prof_begin(uint32_t max_launches) {
     p.used = 0;
     p.seen = 0;
     p.on = true;
-    return GL_OK;
-}
-
-int gl_prof_sample_every(uint32_t n) {
-    gl::prof().every = n ? n : 1u;
     return GL_OK;
 }
 
@@ -708,7 +698,7 @@ int gl_host_pool_alloc(void **h_ptr, size_t bytes) {
             return GL_OK;
         }
         if (gl::pool_trace()) fprintf(stderr, "[pool] host miss %zu bytes\n", want);
-        static const bool pin = getenv("GRAPHLILY_HOST_PIN") && atoi(getenv("GRAPHLILY_HOST_PIN")) != 0;
+        const bool pin = false;   // (page-locking 12 MB costs 2.5 ms and buys nothing on this platform: profiles/r02_ubench_host.txt)
         size_t pinned = 0;
         if (pin && gl::ctx().initialized) {
             if (hipHostMalloc(h_ptr, want, hipHostMallocDefault) == hipSuccess) pinned = 1;
@@ -801,7 +791,7 @@ int gl_buf_d2h_async(void *h_dst, const void *d_src, size_t bytes) {
     // A read-back behind a kernel: hipMemcpyAsync starts ~18 us after the kernel in front of it has ended (measured behind every
     // BFS schedule: the runtime's own copy kernel follows a system-scope barrier), a kernel of this library that stores to the
     // page-locked destination itself starts after the usual ~4 us.  Only for page-locked, 16-byte aligned destinations.
-    static const bool by_kernel = !(getenv("GRAPHLILY_D2H_KERNEL") && atoi(getenv("GRAPHLILY_D2H_KERNEL")) == 0);
+    const bool by_kernel = true;
     if (by_kernel && bytes >= (64u << 10) && (((uintptr_t)h_dst | (uintptr_t)d_src) & 15u) == 0) {
         hipPointerAttribute_t at;
         void *dev_view = nullptr;
@@ -863,15 +853,6 @@ static int host_expand_threads(size_t n) {
 }
 
 int gl_host_unpack_threads(void) { return host_expand_threads(1u << 20); }
-
-int gl_host_threads_warm(void) {
-    const int nt = host_expand_threads(1u << 20);
-    (void)nt;
-    volatile int sink = 0;
-#pragma omp parallel num_threads(nt)
-    { sink = sink + 0; }
-    return GL_OK;
-}
 
 // 16 level bytes -> 16 floats, written past the caches (the caller reads them later, if at all: no read-for-ownership)
 static inline void expand16_stream(const __m128i v, float *dst) {
@@ -952,7 +933,8 @@ int gl_buf_d2h_levels(float *h_dst, const float *d_src, size_t n, float max_leve
     if (packed) *packed = 0;
     if (n == 0) return GL_OK;
     GL_ARG(h_dst != nullptr && d_src != nullptr);
-    static const bool on = !(getenv("GRAPHLILY_D2H_LEVELS") && atoi(getenv("GRAPHLILY_D2H_LEVELS")) == 0);
+    // GRAPHLILY_BFS_U8=0: levels always cross PCIe as floats (the Python drivers read the same switch)
+    static const bool on = !(getenv("GRAPHLILY_BFS_U8") && atoi(getenv("GRAPHLILY_BFS_U8")) == 0);
     const int bits = max_level <= 15.0f ? 4 : 8;
     // (with fewer than four host threads the expansion costs more than the PCIe time it saves)
     if (!on || host_expand_threads(1u << 20) < 4 || !(max_level >= 0.0f && max_level <= 255.0f) || n < (1u << 16) || (n & 7u) != 0 ||
@@ -1028,7 +1010,9 @@ int gl_host_free(void *h_ptr) {
     return GL_OK;
 }
 
-int gl_buf_fill_u32_gated(uint32_t *d_dst, uint32_t value, size_t count, const uint32_t *d_gate, uint32_t gate_value) {
+int gl_buf_fill_u32(uint32_t *d_dst, uint32_t value, size_t count) {
+    const uint32_t *d_gate = nullptr;
+    const uint32_t gate_value = 0u;
     GL_REQUIRE_INIT();
     if (count == 0) return GL_OK;
     GL_ARG(d_dst != nullptr);

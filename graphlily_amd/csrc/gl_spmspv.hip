@@ -55,7 +55,6 @@ struct gl_spmspv_plan_s {
     uint32_t max_col_len = 0;           // longest column of the shard
     uint64_t frontier_hint = ~0ull;     // caller's upper bound on the next run's vector nnz (~0 = unknown)
     uint32_t *d_mode = nullptr;         // [0] 1 = this run goes row-wise, [1] block ticket, [2..3] work counter
-    const uint32_t *frontier_bits = nullptr;   // one-shot (gl_spmspv_plan_frontier_bits): the next run's vector as a bit vector
     bool last_decided_on_device = false;   // the last run launched the decision kernel (d_mode[0] is its verdict)
     // gl_bfs_bits_push_step: the chunks of every long column as a static list {column, first entry, count, -}; a push
     // step tests the frontier bit of each chunk's column instead of queueing chunks at run time (no second launch)
@@ -115,12 +114,8 @@ __device__ __forceinline__ uint32_t block_exclusive_256(uint32_t v, uint32_t *s_
 
 // work of this run = sum of the lengths of the frontier's columns; the last block to finish sets the mode
 __global__ __launch_bounds__(256) void spmspv_work_kernel(const gl_idx_val *__restrict__ vec, const uint32_t *__restrict__ indptr,
-                                                          uint32_t num_cols, uint32_t *__restrict__ mode, uint64_t threshold, Gate gate) {
+                                                          uint32_t num_cols, uint32_t *__restrict__ mode, uint64_t threshold) {
     __shared__ unsigned long long s_sum[4];
-    if (gate.closed()) {   // a run that does not happen goes neither way: the row-wise kernels look at mode[0]
-        if (blockIdx.x == 0 && threadIdx.x == 0) mode[0] = 0u;
-        return;
-    }
     const uint32_t vnnz = vec[0].index;
     unsigned long long w = 0;
     for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < vnnz; e += gridDim.x * 256u) {
@@ -373,113 +368,6 @@ __global__ __launch_bounds__(256) void bfs_push_bits_kernel(BfsPushArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ the slot's decisions of a ROW-SHARDED schedule
-// (gl_bfs_bits_decide).  A shard sees only its own rows of the new frontier, so its steps keep no totals (deferred);
-// after the all-gather every rank holds the whole bit vector and takes the decisions from IT: vertices reached =
-// popcount, the next push's work = sum of their GLOBAL column lengths, non-zeros in their rows = sum of their global row
-// lengths -- the same three numbers the one-GPU steps accumulate, hence the same decisions (the reference's loop
-// condition, app/bfs.h:180-190) on every rank.  The last workgroup (ticket) adds up the 64 accumulator lines.
-struct BfsDecideArgs {
-    const uint32_t *bits;       // the gathered next frontier
-    uint32_t n;
-    const uint32_t *col_len;    // n global column lengths (the CSC of the WHOLE matrix)
-    const uint32_t *row_len;    // n global row lengths, or null
-    uint32_t *acc;              // kBfsAccSlots x 32 words, zero between launches; [4] of line 0 is the ticket
-    BfsBitsCtl c;
-};
-
-__global__ __launch_bounds__(1024) void bfs_bits_decide_kernel(BfsDecideArgs a) {
-    __shared__ uint32_t s_fresh, s_last;
-    __shared__ unsigned long long s_work, s_rows;
-    if (threadIdx.x == 0) {
-        s_fresh = 0u;
-        s_work = 0ull;
-        s_rows = 0ull;
-    }
-    __syncthreads();
-    // a wavefront per 64 vertices: skip empty 64-bit words (sparse frontiers), otherwise a lane per vertex -- the two length
-    // arrays are then read in whole lines (a dense frontier of a million vertices: 24 MB streamed instead of 2 M gathers)
-    const uint32_t nw64 = (a.n + 63u) >> 6, lane = threadIdx.x & 63u;
-    uint32_t fresh = 0u;
-    unsigned long long work = 0ull, rows = 0ull;
-    if (!a.c.finished()) {
-        // 16 words = 1024 vertices per wavefront step: lanes 0..15 fetch the words in one coalesced load, then every load of
-        // the step is issued before the first use (no branch on the words: predicated-off lanes cost no traffic) -- with a
-        // dependent load per word the kernel was latency-bound at 13 us whatever the frontier held
-        constexpr uint32_t K = 16;
-        for (uint32_t w0 = (blockIdx.x * 16u + (threadIdx.x >> 6)) * K; w0 < nw64; w0 += gridDim.x * 16u * K) {
-            const uint64_t mine = (lane < K && w0 + lane < nw64) ? reinterpret_cast<const uint64_t *>(a.bits)[w0 + lane] : 0ull;
-            uint32_t cl[K], rl[K], bit[K];
-#pragma unroll
-            for (uint32_t u = 0; u < K; u++) {
-                const uint64_t m = __shfl(mine, (int)u);
-                const uint32_t v = (w0 + u) * 64u + lane;
-                bit[u] = (uint32_t)((m >> lane) & 1ull) & (v < a.n ? 1u : 0u);
-                cl[u] = bit[u] ? a.col_len[v] : 0u;
-                rl[u] = (bit[u] && a.row_len) ? a.row_len[v] : 0u;
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < K; u++) {
-                fresh += bit[u];
-                work += cl[u];
-                rows += rl[u];
-            }
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        fresh += __shfl_down(fresh, d);
-        work += __shfl_down(work, d);
-        rows += __shfl_down(rows, d);
-    }
-    if ((threadIdx.x & 63u) == 0u && fresh) {
-        atomicAdd(&s_fresh, fresh);
-        atomicAdd(&s_work, work);
-        atomicAdd(&s_rows, rows);
-    }
-    __syncthreads();
-    // totals and "who is last" through the 64 accumulator lines, then one root ticket per line (ctl[6]): hundreds of
-    // workgroups ending on ONE word serialise (measured on the push step: 45 us for 2048 of them)
-    if (threadIdx.x == 0) {
-        const uint32_t l = blockIdx.x & (kBfsAccSlots - 1u), nlines = min(gridDim.x, kBfsAccSlots);
-        uint32_t *line = a.acc + 32u * l;
-        if (s_fresh) {
-            atomicAdd(line, s_fresh);
-            atomicAdd(reinterpret_cast<unsigned long long *>(line + 2), s_work);
-            if (s_rows) atomicAdd(reinterpret_cast<unsigned long long *>(line + 6), s_rows);
-        }
-        __threadfence();
-        bool last = atomicAdd(line + 4, 1u) == (gridDim.x - l + kBfsAccSlots - 1u) / kBfsAccSlots - 1u;   // last workgroup of this line
-        if (last) {
-            __threadfence();
-            last = atomicAdd(&a.c.ctl[6], 1u) == nlines - 1u;                                            // ... of the launch
-        }
-        s_last = last ? 1u : 0u;
-    }
-    __syncthreads();
-    if (s_last && threadIdx.x < 64u) {
-        __threadfence();
-        uint32_t *ln = a.acc + 32u * threadIdx.x;
-        uint32_t total = __hip_atomic_load(ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long wk = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ln + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long wr = __hip_atomic_load(reinterpret_cast<unsigned long long *>(ln + 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ln[0] = 0u;
-        *reinterpret_cast<unsigned long long *>(ln + 2) = 0ull;
-        *reinterpret_cast<unsigned long long *>(ln + 6) = 0ull;
-        ln[4] = 0u;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            total += __shfl_down(total, d);
-            wk += __shfl_down(wk, d);
-            wr += __shfl_down(wr, d);
-        }
-        if (threadIdx.x == 0) {
-            a.c.ctl[6] = 0u;
-            a.c.decide(total, wk, wr);
-        }
-    }
-}
-
 // compaction source over the dense accumulator
 template <int MASK, bool BITS = false>   // BITS: the integer value types compare bit patterns (zero may be 0xffffffff, a NaN as a float)
 struct AccSource {
@@ -490,7 +378,6 @@ struct AccSource {
     float zero;
     float *assign;       // gl_spmspv_run_assign: assign[index] = assign_val for every emitted entry (or null)
     float assign_val;
-    uint32_t *next_bits; // gl_spmspv_run_gated: the emitted rows also as a bit vector (zeroed by the caller), or null
     __device__ uint32_t size() const { return nrows; }
     __device__ bool get(uint32_t i, gl_idx_val &out) const {
         float v = acc[i];
@@ -511,13 +398,6 @@ struct AccSource {
     // the entry's own row: no other thread reads or writes assign[item.index] in this pass
     __device__ void emitted(const gl_idx_val &item) const {
         if (assign) assign[item.index] = assign_val;
-        if (next_bits) atomicOr(&next_bits[item.index >> 5], 1u << (item.index & 31u));
-    }
-    // counting pass: the words of next_bits that this chunk's rows own start from zero (row_begin is a multiple of 32
-    // and a chunk holds kCompactChunk = 1024 rows = 32 words; the write pass ORs into them in a later launch)
-    __device__ void begin_chunk(uint32_t first) const {
-        if (next_bits && threadIdx.x < kCompactChunk / 32u && first + 32u * threadIdx.x < nrows)
-            next_bits[((row_begin + first) >> 5) + threadIdx.x] = 0u;
     }
 };
 
@@ -541,7 +421,6 @@ struct TinyArgs {
     gl_idx_val *out;
     float head_val;
     uint32_t zero_bits;
-    uint32_t *next_bits;     // (also in the source functor) cleared here over the shard's rows before the emission ORs into it
     unsigned long long *host_rec;   // a blocking caller's completion record (gl_spmspv_wait): seq << 32 | count, or null
     uint32_t seq;
 };
@@ -578,7 +457,7 @@ __device__ __forceinline__ bool tiny_scatter(float *acc, uint32_t row, float a, 
 }
 
 template <int OP, typename Src>
-__global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, Src src, Gate gate, Direction dir) {
+__global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, Src src) {
     __shared__ uint32_t s_start[kTinyVec];
     __shared__ uint32_t s_pref[kTinyVec + 1];
     __shared__ float s_val[kTinyVec];
@@ -586,13 +465,8 @@ __global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, S
     __shared__ uint32_t s_tmp[2048];
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_cnt;
-    if (gate.closed()) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t vnnz = a.vec[0].index;
-    if (a.next_bits) {
-        for (uint32_t w = tid; w < (a.nrows + 31u) / 32u; w += kTinyThreads) a.next_bits[(a.row_begin >> 5) + w] = 0u;
-        __threadfence();
-    }
     if (tid == 0) s_cnt = 0u;
 
     // ---- the vector's columns and the exclusive prefix of their lengths (first kTinyVec entries)
@@ -668,7 +542,6 @@ __global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, S
         if (tid == 0) {
             a.out[0].index = pos;
             a.out[0].val = a.head_val;
-            dir.decide(pos);
         }
         tiny_report(a, pos);
         return;
@@ -769,27 +642,24 @@ __global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, S
     if (tid == 0) {
         a.out[0].index = pos;
         a.out[0].val = a.head_val;
-        dir.decide(pos);
     }
     tiny_report(a, pos);
 }
 
 template <int OP, int MASK>
-static int launch_tiny(const TinyArgs &a, const float *mask, float zero, float *inout, float val, uint32_t *next_bits, Gate gate,
-                       Direction dir, hipStream_t s) {
-    AccSource<MASK> src{a.acc, mask, a.nrows, a.row_begin, zero, inout, val, next_bits};
-    spmspv_tiny_kernel<OP, AccSource<MASK>><<<1, kTinyThreads, 0, s>>>(a, src, gate, dir);
+static int launch_tiny(const TinyArgs &a, const float *mask, float zero, float *inout, float val, hipStream_t s) {
+    AccSource<MASK> src{a.acc, mask, a.nrows, a.row_begin, zero, inout, val};
+    spmspv_tiny_kernel<OP, AccSource<MASK>><<<1, kTinyThreads, 0, s>>>(a, src);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
 
 template <int OP>
-static int launch_tiny_mask(int mask_type, const TinyArgs &a, const float *mask, float zero, float *inout, float val,
-                            uint32_t *next_bits, Gate gate, Direction dir, hipStream_t s) {
+static int launch_tiny_mask(int mask_type, const TinyArgs &a, const float *mask, float zero, float *inout, float val, hipStream_t s) {
     switch (mask_type) {
-        case GL_NOMASK: return launch_tiny<OP, GL_NOMASK>(a, mask, zero, inout, val, next_bits, gate, dir, s);
-        case GL_MASK_WRITETOZERO: return launch_tiny<OP, GL_MASK_WRITETOZERO>(a, mask, zero, inout, val, next_bits, gate, dir, s);
-        default: return launch_tiny<OP, GL_MASK_WRITETOONE>(a, mask, zero, inout, val, next_bits, gate, dir, s);
+        case GL_NOMASK: return launch_tiny<OP, GL_NOMASK>(a, mask, zero, inout, val, s);
+        case GL_MASK_WRITETOZERO: return launch_tiny<OP, GL_MASK_WRITETOZERO>(a, mask, zero, inout, val, s);
+        default: return launch_tiny<OP, GL_MASK_WRITETOONE>(a, mask, zero, inout, val, s);
     }
 }
 
@@ -841,7 +711,7 @@ static TileMap choose_tiles(uint32_t nrows, uint32_t num_cus) {
     TileMap tm;
     uint32_t R = cdiv(std::max<uint32_t>(nrows, 1u), std::max<uint32_t>(num_cus, 1u));
     R = std::min<uint32_t>(std::max<uint32_t>((R + 63u) & ~63u, 64u), kFoldMaxRows);
-    const long forced = env_long("GRAPHLILY_SPMSPV_TILE_ROWS", 0);   // tests: many small tiles on a small matrix
+    const long forced = debug_knob("spmspv_tile_rows", 0);   // tests: many small tiles on a small matrix
     if (forced >= 64) R = std::min<uint32_t>(((uint32_t)forced + 63u) & ~63u, kFoldMaxRows);
     for (;;) {
         tm.rows = R;
@@ -1034,24 +904,13 @@ int gl_spmspv_run(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_m
     return gl_spmspv_run_assign(p, d_vector, d_mask, d_result, op, zero, mask_type, nullptr, 0.0f);
 }
 
+static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
+                           int op, float zero, int mask_type, float *d_inout, float val, int val_type);
+
 int gl_spmspv_run_assign(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
                          int op, float zero, int mask_type, float *d_inout, float val) {
-    return gl_spmspv_run_gated(p, d_vector, d_mask, d_result, op, zero, mask_type, d_inout, val, nullptr, nullptr, 0u, GL_GATE_EQ,
-                               nullptr, 0u, 0.0f, 0);
-}
-
-static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
-                           int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
-                           const uint32_t *d_gate, uint32_t gate_value, int gate_op,
-                           uint32_t *d_ctl, uint32_t slot, float dir_threshold, int may_continue_push, int val_type);
-
-int gl_spmspv_run_gated(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
-                        int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
-                        const uint32_t *d_gate, uint32_t gate_value, int gate_op,
-                        uint32_t *d_ctl, uint32_t slot, float dir_threshold, int may_continue_push) {
     GL_TRACE();
-    return spmspv_run_impl(p, d_vector, d_mask, d_result, op, zero, mask_type, d_inout, val, d_next_bits, d_gate, gate_value, gate_op,
-                           d_ctl, slot, dir_threshold, may_continue_push, GL_VAL_FLOAT);
+    return spmspv_run_impl(p, d_vector, d_mask, d_result, op, zero, mask_type, d_inout, val, GL_VAL_FLOAT);
 }
 
 /* the sparse elements of the integer value types are {uint32 index; uint32 value bits}: same size and layout */
@@ -1060,27 +919,12 @@ int gl_spmspv_run_typed(gl_spmspv_plan p, const void *d_vector, const void *d_ma
     if (val_type != GL_VAL_FLOAT && val_type != GL_VAL_UNSIGNED && val_type != GL_VAL_UFIXED_32_8)
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmspv_run_typed: unknown value type %d", val_type);
     return spmspv_run_impl(p, (const gl_idx_val *)d_vector, (const float *)d_mask, (gl_idx_val *)d_result, op,
-                           __builtin_bit_cast(float, zero_bits), mask_type, nullptr, 0.0f, nullptr, nullptr, 0u, GL_GATE_EQ, nullptr, 0u,
-                           0.0f, 0, val_type);
+                           __builtin_bit_cast(float, zero_bits), mask_type, nullptr, 0.0f, val_type);
 }
 
 static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
-                           int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
-                           const uint32_t *d_gate, uint32_t gate_value, int gate_op,
-                           uint32_t *d_ctl, uint32_t slot, float dir_threshold, int may_continue_push, int val_type) {
+                           int op, float zero, int mask_type, float *d_inout, float val, int val_type) {
     GL_REQUIRE_INIT();
-    GL_ARG(gate_op == GL_GATE_EQ || gate_op == GL_GATE_GT || gate_op == GL_GATE_LE);
-    GL_ARG(d_next_bits == nullptr || (p != nullptr && (p->row_begin & 31u) == 0u));
-    gl::Gate gate;
-    gate.word = d_gate;
-    gate.value = gate_value;
-    gate.op = gate_op;
-    gl::Direction dir;
-    dir.ctl = d_ctl;
-    dir.n = p ? p->num_rows : 1u;
-    dir.slot = slot;
-    dir.threshold = dir_threshold;
-    dir.may_continue = (uint32_t)may_continue_push;   // bit 0: the reference's loop condition, bit 1: a slot follows, bit 3: pull flags
     GL_ARG(p != nullptr && d_vector != nullptr && d_result != nullptr);
     GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
     GL_ARG(op == GL_OP_MULADD || op == GL_OP_ANDOR || op == GL_OP_ADDMIN);
@@ -1097,16 +941,15 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     }
 
     // a caller that expects a tiny vector (gl_spmspv_plan_hint_tiny): the whole run is one launch of one workgroup
-    const bool tiny = p->tiny_hint && val_type == GL_VAL_FLOAT && nrows > 0 && gl::env_long("GRAPHLILY_SPMSPV_TINY", 1) != 0;
+    const bool tiny = p->tiny_hint && val_type == GL_VAL_FLOAT && nrows > 0 && gl::debug_knob("spmspv_tiny", 1) != 0;
     p->tiny_hint = false;
-    const uint64_t work_hint = gl::env_long("GRAPHLILY_SPMSPV_WORK_HINT", 1) != 0 ? p->work_hint : ~0ull;
+    const uint64_t work_hint = gl::debug_knob("spmspv_work_hint", 1) != 0 ? p->work_hint : ~0ull;
     p->work_hint = ~0ull;
     const uint32_t nnz_hint = p->nnz_hint;
     p->nnz_hint = ~0u;
     p->rec_pending = false;
     if (tiny) {
         p->frontier_hint = ~0ull;
-        p->frontier_bits = nullptr;
         p->last_decided_on_device = false;
         gl::TinyArgs t;
         t.indptr = p->d_indptr;
@@ -1119,24 +962,23 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
         t.out = d_result;
         t.head_val = zero;
         t.zero_bits = __builtin_bit_cast(uint32_t, zero);
-        t.next_bits = d_next_bits;
-        {   // (a run that is neither gated nor being recorded reports its completion to the host, as below)
+        {   // (a run that is not being recorded into a graph reports its completion to the host, as below)
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(s, &cap);
-            const bool report = d_gate == nullptr && cap == hipStreamCaptureStatusNone && p->h_rec != nullptr;
+            const bool report = cap == hipStreamCaptureStatusNone && p->h_rec != nullptr;
             t.host_rec = report ? p->h_rec : nullptr;
             t.seq = report ? ++p->seq : 0u;
             p->rec_pending = report;
         }
         switch (op) {
-            case GL_OP_MULADD: return gl::launch_tiny_mask<GL_OP_MULADD>(mask_type, t, d_mask, zero, d_inout, val, d_next_bits, gate, dir, s);
-            case GL_OP_ANDOR: return gl::launch_tiny_mask<GL_OP_ANDOR>(mask_type, t, d_mask, zero, d_inout, val, d_next_bits, gate, dir, s);
-            default: return gl::launch_tiny_mask<GL_OP_ADDMIN>(mask_type, t, d_mask, zero, d_inout, val, d_next_bits, gate, dir, s);
+            case GL_OP_MULADD: return gl::launch_tiny_mask<GL_OP_MULADD>(mask_type, t, d_mask, zero, d_inout, val, s);
+            case GL_OP_ANDOR: return gl::launch_tiny_mask<GL_OP_ANDOR>(mask_type, t, d_mask, zero, d_inout, val, s);
+            default: return gl::launch_tiny_mask<GL_OP_ADDMIN>(mask_type, t, d_mask, zero, d_inout, val, s);
         }
     }
 
     // (||,&&) with an attached boolean SpMV plan: decide on the device which way this run goes
-    const long div = gl::env_long("GRAPHLILY_SPMSPV_PULL_DIV", 8);
+    const long div = gl::env_long("GRAPHLILY_SPMSPV_PULL_DIV", 8);      // (0: never row-wise)
     const uint64_t threshold = div > 0 ? p->nnz / (uint64_t)div : 0ull;
     // which attached plan can stand in for the scatter: (||,&&) and (+,x) need zero == 0 (the accumulator starts
     // at it); (min,+) needs zero <= FLOAT_INF -- the scatter's products saturate there, the SpMV's do not, and the
@@ -1145,7 +987,7 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     if (op == GL_OP_ANDOR && zero == 0.0f) pull_plan = p->pull;
     else if (op == GL_OP_MULADD && zero == 0.0f && p->pull_arith && !(p->pull_arith->flags & GL_PLAN_NO_MULADD)) pull_plan = p->pull_arith;
     else if (op == GL_OP_ADDMIN && zero <= gl::kFloatInf) pull_plan = p->pull_arith;
-    bool may_pull = pull_plan != nullptr && nrows > 0 && val_type == GL_VAL_FLOAT && gl::env_long("GRAPHLILY_SPMSPV_PULL", 1) != 0;
+    bool may_pull = pull_plan != nullptr && nrows > 0 && val_type == GL_VAL_FLOAT && div > 0;
     // a caller that knows how many entries the vector holds (gl_spmspv_plan_hint) spares tiny frontiers the
     // decision kernels: they cannot reach the threshold whatever their columns are
     if (may_pull && p->frontier_hint != ~0ull && p->frontier_hint * (uint64_t)p->max_col_len <= threshold) may_pull = false;
@@ -1155,20 +997,15 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     // would only find out that they have nothing to do (five dependent launches, ~22 us of a 60 us call).  A stale hint costs
     // time, never results: scattering is correct for any vector.
     if (may_pull && work_hint != ~0ull && work_hint <= threshold) may_pull = false;
-    struct ClearBits {   // one-shot, whatever path the run takes
-        gl_spmspv_plan p;
-        ~ClearBits() { p->frontier_bits = nullptr; }
-    } clear_bits{p};
     if (may_pull) {
         // few blocks: each ends with one atomic on the same ticket word
         uint32_t wgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), 64u);
-        gl::spmspv_work_kernel<<<wgrid ? wgrid : 1u, 256, 0, s>>>(d_vector, p->d_indptr, p->num_cols, p->d_mode, threshold, gate);
+        gl::spmspv_work_kernel<<<wgrid ? wgrid : 1u, 256, 0, s>>>(d_vector, p->d_indptr, p->num_cols, p->d_mode, threshold);
         GL_LAUNCH_CHECK();
     }
     p->last_decided_on_device = may_pull;   // gl_spmspv_last_direction: else the run scattered, nothing to read back
 
     gl::BinArgs a;
-    a.gate = gate;
     a.mode = may_pull ? p->d_mode : nullptr;
     a.indptr = p->d_indptr;
     a.stream = p->d_stream;
@@ -1222,17 +1059,12 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     } else if (may_pull) {
         // row-wise: frontier -> bit vector -> boolean SpMV into the (all-zero) accumulator; both kernels return
         // at once when the run bins
-        if (p->frontier_bits) {
-            // the caller keeps the frontier as bits anyway (a device-resident BFS schedule): no clear + list -> bits pass
-            rc = gl::bool_plan_run_bits(p->pull, p->d_acc - p->row_begin, p->d_mode, s, p->frontier_bits);
-        } else {
-            uint32_t *bits = gl::bool_plan_xbits(p->pull);
-            GL_HIP(hipMemsetAsync(bits, 0, gl::bool_plan_xbits_bytes(p->pull), s));
-            uint32_t bgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 8u);
-            gl::spmspv_frontier_bits_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(d_vector, p->num_cols, bits, p->d_mode);
-            GL_LAUNCH_CHECK();
-            rc = gl::bool_plan_run_bits(p->pull, p->d_acc - p->row_begin, p->d_mode, s);
-        }
+        uint32_t *bits = gl::bool_plan_xbits(p->pull);
+        GL_HIP(hipMemsetAsync(bits, 0, gl::bool_plan_xbits_bytes(p->pull), s));
+        uint32_t bgrid = std::min<uint32_t>(gl::cdiv(p->num_cols, 256), (uint32_t)gl::ctx().num_cus * 8u);
+        gl::spmspv_frontier_bits_kernel<<<bgrid ? bgrid : 1u, 256, 0, s>>>(d_vector, p->num_cols, bits, p->d_mode);
+        GL_LAUNCH_CHECK();
+        rc = gl::bool_plan_run_bits(p->pull, p->d_acc - p->row_begin, p->d_mode, s);
         if (rc != GL_OK) return rc;
     }
 
@@ -1252,20 +1084,17 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     f.head_val = zero;
     f.assign = d_inout;
     f.assign_val = val;
-    f.next_bits = d_next_bits;
     f.state = p->d_state;
     f.sync = p->d_sync;
     f.tickets = p->fold_tickets ? 1u : 0u;
     f.merge_all = p->binned ? 0u : 1u;
     f.mode = may_pull ? p->d_mode : nullptr;
-    f.gate = gate;
-    f.dir = dir;
     f.bin_vec = nrows > 0 ? d_vector : nullptr;
     f.bin_grid = grid;
-    // a run that is neither gated nor being recorded into a graph reports its completion to the host (gl_spmspv_wait)
+    // a run that is not being recorded into a graph reports its completion to the host (gl_spmspv_wait)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
-    const bool report = d_gate == nullptr && cap == hipStreamCaptureStatusNone && p->h_rec != nullptr;
+    const bool report = cap == hipStreamCaptureStatusNone && p->h_rec != nullptr;
     f.host_rec = report ? p->h_rec : nullptr;
     f.seq = report ? ++p->seq : 0u;
     p->rec_pending = report;
@@ -1322,20 +1151,6 @@ int gl_spmspv_plan_attach_pull(gl_spmspv_plan p, gl_spmv_plan pull) {
         p->device_bytes += (size_t)p->num_cols * sizeof(float);
     }
     p->pull_arith = pull;
-    return GL_OK;
-}
-
-int gl_spmspv_plan_frontier_bits(gl_spmspv_plan p, const uint32_t *d_bits) {
-    GL_ARG(p != nullptr);
-    GL_ARG(((uintptr_t)d_bits & 15u) == 0);
-    p->frontier_bits = d_bits;
-    return GL_OK;
-}
-
-int gl_spmspv_plan_hint_tiny(gl_spmspv_plan p, uint32_t vector_nnz, uint64_t work) {
-    GL_ARG(p != nullptr);
-    p->tiny_hint = vector_nnz <= gl::kTinyVec && work <= gl::kTinyWork;
-    p->nnz_hint = vector_nnz;
     return GL_OK;
 }
 
@@ -1419,40 +1234,6 @@ int gl_bfs_bits_push_step(gl_spmspv_plan p, gl_spmv_plan rows, const uint32_t *d
     return GL_OK;
 }
 
-int gl_bfs_bits_decide(gl_spmspv_plan p, const uint32_t *d_bits_next, const uint32_t *d_col_len, const uint32_t *d_row_len,
-                       uint64_t nnz_global, uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue, float back_threshold) {
-    GL_REQUIRE_INIT();
-    GL_ARG(p != nullptr && d_bits_next != nullptr && d_col_len != nullptr);
-    GL_ARG(d_ctl != nullptr && slot >= 1u && ((uintptr_t)d_ctl & 7u) == 0);
-    gl::BfsDecideArgs a;
-    a.bits = d_bits_next;
-    a.n = p->num_rows;
-    a.col_len = d_col_len;
-    a.row_len = d_row_len;
-    a.acc = p->d_bfs_acc;
-    a.c.ctl = d_ctl;
-    a.c.slot = slot;
-    a.c.n = p->num_rows ? p->num_rows : 1u;
-    a.c.may_continue = (uint32_t)may_continue & 3u;
-    a.c.threshold = threshold;
-    a.c.back_threshold = back_threshold;
-    // the GLOBAL matrix decides: a shard's push costs its share of the frontier's columns, its pull its share of the stream
-    const long hdiv = gl::env_long("GRAPHLILY_BFS_HEAVY_DIV", 128), bdiv = gl::env_long("GRAPHLILY_BFS_BU_DIV", 3);
-    a.c.heavy = hdiv > 0 ? nnz_global / (unsigned long long)hdiv : ~0ull;
-    a.c.nnz_rows = nnz_global;
-    // bottom-up slots need the rows on every rank: the push step of this slot (enqueued before) recorded whether it has them
-    a.c.bu_limit = (d_row_len != nullptr && p->bfs_rows_plan != nullptr && bdiv > 0) ? nnz_global / (unsigned long long)bdiv : 0ull;
-    // every workgroup ends with a fence and a ticket: a thousand of those cost 20 us whatever the frontier holds, and 64
-    // workgroups of 16 wavefronts 12 us (measured: few compute units stream the length arrays slowly)
-    const uint32_t nw64 = gl::cdiv(p->num_rows, 64);
-    // (a wavefront step is a chain of dependent loads: the grid is sized so that every wavefront has ONE step up to 256 x 16 x 1024
-    // vertices; more steps per wavefront run one after the other, 3 us each)
-    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(gl::cdiv(nw64, 16 * 16), (uint32_t)gl::env_long("GRAPHLILY_BFS_DECIDE_GRID", 256)));
-    gl::bfs_bits_decide_kernel<<<grid, 1024, 0, gl::ctx().stream>>>(a);
-    GL_LAUNCH_CHECK();
-    return GL_OK;
-}
-
 // One slot of the row-sharded schedule in one launch (gl_bfs_shard.h).  finish: only the decision of slot `slot - 1` = the
 // last one, with the final state stored into d_ctl itself.
 static int bfs_bits_shard_launch(gl_spmspv_plan p, gl_spmv_plan rows, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t bits_words,
@@ -1522,7 +1303,7 @@ static int bfs_bits_shard_launch(gl_spmspv_plan p, gl_spmv_plan rows, const uint
     c.threshold = threshold;
     c.back_threshold = back_threshold;
     // the GLOBAL matrix decides, as in gl_bfs_bits_decide
-    const long hdiv = gl::env_long("GRAPHLILY_BFS_HEAVY_DIV", 128), bdiv = gl::env_long("GRAPHLILY_BFS_BU_DIV", 3);
+    const long hdiv = gl::debug_knob("bfs_heavy_div", 128), bdiv = gl::debug_knob("bfs_bu_div", 3);
     c.heavy = hdiv > 0 ? nnz_global / (unsigned long long)hdiv : ~0ull;
     c.nnz_rows = nnz_global;
     c.bu_limit = (have_rows && bdiv > 0) ? nnz_global / (unsigned long long)bdiv : 0ull;
@@ -1573,13 +1354,13 @@ namespace gl {
 // ~1.4 T entries/s: they cost the same near nnz / 128 (same-box sweep of 32 ... 256 on the six stand-ins; the list-based
 // gl_spmspv_run, whose scatter also pays for a compaction, keeps its 1 / 32).
 unsigned long long spmspv_heavy_work(gl_spmspv_plan p) {
-    const long div = env_long("GRAPHLILY_BFS_HEAVY_DIV", 128);
+    const long div = debug_knob("bfs_heavy_div", 128);
     return div > 0 ? p->nnz / (unsigned long long)div : ~0ull;
 }
 // ... and visits only the rows not reached yet once those hold fewer non-zeros than this (bottom-up: a thread per row with
 // an early exit reads an entry ~4 x more expensively than the streaming kernel, but stops at the first hit)
 unsigned long long spmspv_bottom_up_limit(gl_spmspv_plan p) {
-    const long div = env_long("GRAPHLILY_BFS_BU_DIV", 3);
+    const long div = debug_knob("bfs_bu_div", 3);
     return div > 0 ? p->nnz / (unsigned long long)div : 0ull;
 }
 unsigned long long spmspv_plan_nnz(gl_spmspv_plan p) { return p->nnz; }

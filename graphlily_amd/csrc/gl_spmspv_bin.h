@@ -18,17 +18,15 @@
 //         (compared with `zero`, spmspv_module.h:499-516) allows are counted, the count is published, the workgroup adds up
 //         the counts of the tiles before it (they run at the same time) and writes its {index, value} run there: the
 //         result list is in ascending row order with no n-wide pass.  The same kernel merges what a row-wise run (the
-//         operator's direction switch) or an overflow left in the dense accumulator, does the fused sparse assign, leaves
-//         the emitted rows as bits, takes the driver's loop decision (gl_compact.h Direction), and -- last workgroup to
-//         finish -- restores every "zero between runs" word and, for a blocking caller, stores {sequence, count} to
-//         page-locked host memory so that the host need not wait for the stream (profiles/r03_ubench_sync.txt).
+//         operator's direction switch) or an overflow left in the dense accumulator, does the fused sparse assign, and --
+//         last workgroup to finish, for a blocking caller -- stores {sequence, count} to page-locked host memory so that
+//         the host need not wait for the stream (profiles/r03_ubench_sync.txt).
 //
 // Bytes per product: 8 read from the column stream + 8 written to a bin + 8 read back = 24, all in runs.
 #ifndef GL_SPMSPV_BIN_H_
 #define GL_SPMSPV_BIN_H_
 
 #include "gl_common.h"
-#include "gl_compact.h"
 #include "gl_tile.h"
 
 namespace gl {
@@ -77,7 +75,6 @@ struct BinArgs {
     uint32_t row_begin, num_cols;
     uint32_t max_col_len;       // longest column of the shard
     const uint32_t *mode;       // non-null: skip when mode[0] != 0 (the run goes row-wise instead)
-    Gate gate;
 };
 
 // ordered-integer trick: for IEEE floats, a >= 0 compares like int, a < 0 like reversed uint
@@ -390,7 +387,6 @@ __device__ __forceinline__ uint32_t bin_window(const BinArgs &a, BinLds &L, cons
 template <int OP>
 __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
     __shared__ BinLds L;
-    if (a.gate.closed()) return;
     if (a.mode && a.mode[0]) return;
     const uint32_t tid = threadIdx.x, G = gridDim.x, blk = blockIdx.x;
     for (uint32_t i = tid; i < kBinMaxTiles; i += kBinThreads) L.cnt[i] = 0u;
@@ -564,7 +560,6 @@ struct FoldArgs {
     float head_val;
     float *assign;            // gl_spmspv_run_assign: assign[index] = assign_val for every emitted entry (or null)
     float assign_val;
-    uint32_t *next_bits;      // the emitted rows also as a bit vector: every word of the shard's rows is written (or null)
     uint32_t *state;          // tiles words: (generation & 0xffff) << 16 | entries of the tile, once it has counted
     uint32_t *sync;
     uint32_t tickets;         // more tiles than resident workgroups: tiles are handed out in arrival order
@@ -574,8 +569,6 @@ struct FoldArgs {
     uint32_t bin_grid;
     unsigned long long *host_rec;   // page-locked host word: seq << 32 | count when everything has been written (or null)
     uint32_t seq;
-    Gate gate;
-    Direction dir;
 };
 
 template <int OPX>
@@ -586,7 +579,6 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
     T *tile = reinterpret_cast<T *>(fold_lds_raw);
     __shared__ unsigned long long s_ball[kFoldMaxRounds * kFoldWaves];   // keep-ballot of (round, wavefront)
     __shared__ uint32_t s_word;
-    if (a.gate.closed()) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     constexpr bool BITS = OPX >= 3;   // the integer value types compare bit patterns (zero may be a NaN as a float)
     const uint32_t T_ = a.tiles.count, R = a.tiles.rows;
@@ -707,22 +699,11 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
             }
         }
     }
-    if (a.next_bits) {
-        // every 32-bit word of the shard's rows is (re)written: R is a multiple of 64, row_begin of 32
-        const uint32_t groups = (min(R, a.nrows > row0 ? a.nrows - row0 : 0u) + 63u) / 64u;
-        for (uint32_t g = tid; g < 2u * groups; g += kFoldThreads) {
-            const uint32_t gi = g >> 1, half = g & 1u;
-            if (row0 + gi * 64u + half * 32u >= a.nrows) continue;
-            const unsigned long long b = total ? s_ball[(gi >> 4) * kFoldWaves + (gi & 15u)] : 0ull;
-            a.next_bits[(row_g0 >> 5) + 2u * gi + half] = (uint32_t)(b >> (32u * half));
-        }
-    }
     if (t == T_ - 1u && tid == 0) {
-        // the last tile has seen every other tile's state: the list's length, the driver's decision, and fresh tags for the next
+        // the last tile has seen every other tile's state: the list's length, and fresh tags for the next
         // run (every workgroup of this launch has read the generation by now)
         a.out[0].index = before + total;
         a.out[0].val = a.head_val;
-        a.dir.decide(before + total);
         if (a.host_rec) __hip_atomic_store(&a.sync[kSyncTotal], before + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.sync[kSyncGen], gen0 + (a.bin_vec ? spmspv_bin_rounds(a.bin_vec[0].index, a.bin_grid) : 1u), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);

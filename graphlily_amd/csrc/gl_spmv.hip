@@ -63,30 +63,12 @@ struct SpmvArgs {
     const float *diag;        // pattern plans with diagonal exceptions: A[r][r] per local row, folded in by the epilogue
     const uint32_t *diag_has; // bit per local row: the row has a diagonal entry that differs from its column's value
     const uint32_t *run_flag;    // non-null: the launch is a no-op unless run_flag[0] != 0 (gl_spmspv_run's direction switch)
-    unsigned long long *clocks;  // debugging (GRAPHLILY_SPMV_CLOCKS): kClockStamps wall_clock64 stamps per unit
     float *partials;          // [segment][row - row_begin] per-unit tiles of split blocks (combined by spmv_combine_kernel)
     uint32_t prow;            // rows per segment plane
     uint32_t row_begin;
     uint32_t tickets;         // 1: wavefronts draw iterations from the LDS ticket; 0: static split (GRAPHLILY_SPMV_TICKETS=0)
     const uint32_t *self_hot_cols;   // non-null: no helper launch ran -- every workgroup gathers its (small) hot table from x itself
 };
-
-// debugging: stamp k of this unit (entry, prologue done, wave 0's loop done, all waves done, end)
-// and, as a sixth word, where the unit ran: HW_ID (se / sh / cu) | XCC_ID << 32
-constexpr uint32_t kClockStamps = 6;
-__device__ __forceinline__ void clock_stamp(const SpmvArgs &a, uint32_t k) {
-    if (a.clocks && threadIdx.x == 0) {
-        // (a copy of the workgroup id made inside this branch: used directly, the compiler reuses the id's SGPR for the
-        //  address arithmetic below, keeps the id itself in a VGPR from then on, and every descriptor / base-column load of
-        //  the kernel turns from a scalar into a vector load)
-        const uint32_t bid = __builtin_amdgcn_readfirstlane(blockIdx.x);
-        a.clocks[kClockStamps * bid + k] = wall_clock64();
-        if (k == 0)   // s_getreg_b32 hwreg(HW_REG_HW_ID = 4, 0, 32) and hwreg(HW_REG_XCC_ID = 20, 0, 32)
-            a.clocks[kClockStamps * bid + 5] =
-                (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
-    }
-}
-
 
 // after the sweep: hub slots -> rows, then y (unsplit blocks) or this unit's plane (split blocks)
 template <int OP, int MASK>
@@ -97,7 +79,6 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
     const bool direct = (d.w >> 31) != 0u;
     const uint32_t hub_off = dh.x, nhub = dh.y;
     __syncthreads();
-    clock_stamp(a, 3);
     if (nhub) {   // fold the private slots of every hub row back into its row
         if (threadIdx.x < nhub) {
             const uint32_t r = a.hub_rows[hub_off + threadIdx.x];
@@ -277,7 +258,6 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);   // nhot is a multiple of 64
 
     if (a.run_flag && *a.run_flag == 0u) return;
-    clock_stamp(a, 0);
     const uint32_t unit = __builtin_amdgcn_readfirstlane(blockIdx.x);   // pinned to an SGPR: see clock_stamp
     const uint4 d = load_const(a.units + 2u * unit), dh = load_const(a.units + 2u * unit + 1u);   // scalar loads
     const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
@@ -299,7 +279,6 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
     __syncthreads();
 
-    clock_stamp(a, 1);
     // The stream is consumed in rounds of kWaves slots: slot w of round j takes cold elements j*kWaves*UC + w + u*kWaves
     // (u < UC) and the hot ones likewise, so the slots of a round read contiguous stream and sweep the same columns
     // (stream read + global gather for cold, stream read + LDS lookup for hot).  Wavefronts draw slot numbers from an LDS
@@ -329,9 +308,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
             it = a.tickets ? __builtin_amdgcn_readfirstlane(ticket) : it + kWaves;
         }
     }
-    clock_stamp(a, 2);
     spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
-    clock_stamp(a, 4);
 }
 
 // z[j] = colval (x) x of gathered column j (all columns, or the packed ones), four per thread, and the hot table from
@@ -592,8 +569,8 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     // float plans whose device arrays fit the Infinity Cache (256 MB) but not the L2s keep their stream cached between runs
     // (same-box: googleplus general 88 MB 50.5 -> 57.6 %, pokec pattern 155 MB 0.059 -> 0.047 ms, ogbl-ppa pattern 173 MB
     // 0.048 -> 0.046 ms; the 45 MB googleplus pattern plan lost 3 %: below 64 MB the hint stays)
-    static const size_t keep_bytes = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MB", 224) << 20;
-    static const size_t keep_min = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MIN_MB", 64) << 20;
+    static const size_t keep_bytes = (size_t)224 << 20;
+    static const size_t keep_min = (size_t)64 << 20;
     const bool keep = OP < 3 && p->wide && p->device_bytes <= keep_bytes && p->device_bytes >= keep_min;
     if (OP < 3 && keep && p->pattern) {
         switch (p->mix) {
@@ -729,7 +706,7 @@ static Shape choose_shape(uint64_t rows, uint64_t cols, uint64_t nnz, int num_cu
         }
     }
     if (best_cost > 1e299) best = Shape{(uint32_t)((rows + rmax - 1) / rmax), 1};  // taller than 16 rounds of CUs
-    const long fb = env_long("GRAPHLILY_SPMV_BLOCKS", 0), fs = env_long("GRAPHLILY_SPMV_SEGMENTS", 0);
+    const long fb = debug_knob("spmv_blocks", 0), fs = debug_knob("spmv_segments", 0);
     if (fb > 0) best.blocks = (uint32_t)std::min<uint64_t>((uint64_t)fb, rows);
     if (fs > 0) best.segments = (uint32_t)std::min<long>(fs, 4096);
     return best;
@@ -746,7 +723,7 @@ BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin,
     // greedy fill) instead of tracking cumulative targets -- with whole-row cuts a block next to a hub row used to end up
     // several per cent over the mean (orkut stand-in: 765 K .. 888 K entries per block around a mean of 827 K, and the
     // 888 K unit finished 28 us after the average one in a 313 us launch).  GRAPHLILY_SPMV_BALANCE=0: cumulative targets.
-    if (nnz > 0 && env_long("GRAPHLILY_SPMV_BALANCE", 1) != 0 && shape.blocks > 1) {
+    if (nnz > 0 && debug_knob("spmv_balance", 1) != 0 && shape.blocks > 1) {
         // blocks needed when no block may hold more than `cap` entries (a single longer row gets a block of its own)
         auto cut = [&](uint64_t cap, std::vector<uint32_t> *out) -> uint32_t {
             uint32_t r = row_begin, made = 0;
@@ -929,7 +906,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
 
     // ---- (||,&&)-only plans have their own layout (gl_spmv_bool.hip); very wide matrices keep the general one
     if ((flags & GL_PLAN_BOOLEAN) && nnz > 0 && gl::cdiv(num_cols, gl::kBoolPhaseCols) <= gl::kBoolMaxPhases &&
-        gl::env_long("GRAPHLILY_SPMV_BOOL", 1) != 0) {
+        gl::debug_knob("spmv_bool", 1) != 0) {
         gl_spmv_plan p = new gl_spmv_plan_s();
         p->num_rows = num_rows;
         p->num_cols = num_cols;
@@ -981,7 +958,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         for (uint64_t i = nz0; i < nz1; i++)
             if (h_indices[i] < num_cols) deg[h_indices[i]]++;   // out-of-range columns are reported below
     }
-    if (nnz > 0 && gl::env_long("GRAPHLILY_SPMV_HOT", 1) != 0) {
+    if (nnz > 0 && gl::debug_knob("spmv_hot", 1) != 0) {
         // 8-byte accumulators unless the caller promised to run only the 4-byte-tile semirings
         const size_t elem = (flags & (GL_PLAN_NO_MULADD | GL_PLAN_BOOLEAN)) ? sizeof(float) : sizeof(double);
         const size_t tile_bytes = ((size_t)tallest + gl::kHubSlots * gl::kMaxHubRows) * elem;
@@ -989,7 +966,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         uint32_t H = 0;
         if (tile_bytes + 4096u <= gl::kLdsBudget)
             H = std::min<uint32_t>(1u << 15, (uint32_t)((gl::kLdsBudget - tile_bytes) / 4u / 1024u * 1024u));
-        const long forced = gl::env_long("GRAPHLILY_SPMV_HOT", 1);
+        const long forced = gl::debug_knob("spmv_hot", 1);
         if (forced > 1) H = std::min<uint32_t>(H, (uint32_t)forced);
         if (H) {
             const uint32_t dmax = num_cols ? *std::max_element(deg.begin(), deg.end()) : 0u;
@@ -997,7 +974,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             for (uint32_t c = 0; c < num_cols; c++) hist[deg[c]]++;
             // thr = smallest degree such that at most H columns have degree >= thr; a column must also
             // appear often enough to be worth a slot (>= 4 entries per row block on average)
-            const uint32_t floor_deg = std::max<uint32_t>(8u, (uint32_t)gl::env_long("GRAPHLILY_SPMV_HOT_FLOOR", 4) * bp.nblocks);
+            const uint32_t floor_deg = std::max<uint32_t>(8u, (uint32_t)gl::debug_knob("spmv_hot_floor", 4) * bp.nblocks);
             uint64_t seen = 0;
             uint32_t thr = dmax + 1;
             while (thr > floor_deg && seen + hist[thr - 1] <= H) { thr--; seen += hist[thr]; }
@@ -1030,12 +1007,12 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     std::vector<uint32_t> ccols, cmap;
     // (short streams whose hot table is small enough for the workgroups to gather themselves skip the packed vector: the
     //  helper launch that would fill it costs more than the denser gathers save -- googleplus stand-in: 23.7 -> 22.8 us)
-    const long helper_mode = gl::env_long("GRAPHLILY_SPMV_HELPER", -1);
+    const long helper_mode = gl::debug_knob("spmv_helper", -1);
     const bool want_self_hot = (helper_mode == 2 || (helper_mode < 0 && nnz <= (16ull << 20))) && hot_cols.size() <= 4096u &&
-                               gl::env_long("GRAPHLILY_SPMV_COMPACT", 1) != 3;
-    if (nnz > 0 && gl::env_long("GRAPHLILY_SPMV_COMPACT", 1) != 0 && !want_self_hot) {
+                               gl::debug_knob("spmv_compact", 1) != 3;
+    if (nnz > 0 && gl::debug_knob("spmv_compact", 1) != 0 && !want_self_hot) {
         const uint32_t nb = bp.nblocks;
-        const bool by_class = bp.Smax == 1 && gl::env_long("GRAPHLILY_SPMV_COMPACT", 1) != 2;
+        const bool by_class = bp.Smax == 1 && gl::debug_knob("spmv_compact", 1) != 2;
         const uint32_t edge[3] = {std::max(nb / 4u, 1u), std::max(nb / 16u, 1u), std::max(nb / 64u, 1u)};
         auto cls = [&](uint32_t c) -> int {
             if (deg[c] == 0 || (have_hot && hot_slot[c] != 0xffffffffu)) return -1;   // never gathered
@@ -1075,7 +1052,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     std::vector<uint32_t> colbits, diag_has;
     std::vector<float> diag_val;
     bool pattern = false, diag_mode = false;
-    if (nnz > 0 && !(flags & GL_PLAN_KEEP_VALUES) && gl::env_long("GRAPHLILY_SPMV_PATTERN", 1) != 0) {
+    if (nnz > 0 && !(flags & GL_PLAN_KEEP_VALUES) && gl::debug_knob("spmv_pattern", 1) != 0) {
         // Diagonal entries are looked at separately: a matrix that is column-constant apart from its diagonal
         // (SSSP's unit weights + zero self edges, app/sssp.h:16-62) keeps the pattern layout, the diagonal goes
         // into a per-row array that the epilogue folds in.
@@ -1120,7 +1097,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         diag_mode = pattern && exceptions > 0;
     }
     // 16-byte stream loads: lane-interleaved pairs of 8-byte groups, or quads of 4-byte (pattern) groups
-    const bool wide = pattern ? gl::env_long("GRAPHLILY_SPMV_PAT4", 1) != 0 : gl::env_long("GRAPHLILY_SPMV_WIDE", 1) != 0;
+    const bool wide = pattern ? gl::debug_knob("spmv_pat4", 1) != 0 : gl::debug_knob("spmv_wide", 1) != 0;
     const uint32_t group_mult = pattern ? (wide ? 4u : 2u) : (wide ? 2u : 1u);   // units hold whole pairs / quads of groups
 
     // ---- group budget per unit (upper bound), so every block can be emitted independently;
@@ -1165,7 +1142,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         eg.pattern = pattern;
         eg.wide = wide;
         eg.group_mult = group_mult;
-        eg.hub_div = (uint32_t)std::max<long>(1, gl::env_long("GRAPHLILY_SPMV_HUB_DIV", 48));
+        eg.hub_div = (uint32_t)std::max<long>(1, gl::debug_knob("spmv_hub_div", 48));
         eg.h_indptr = h_indptr;
         eg.num_cols = num_cols;
         const int erc = gl::fmt_emit_general(staged.c, eg, p, hub_count, &hot_nnz);
@@ -1211,7 +1188,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             for (const gl::Rec &rc : hot) cnt[rc.row_local]++;
             std::vector<int> hub_of(r1 - r0, -1);
             {
-                const uint64_t thr = std::max<uint64_t>(256, m / (uint64_t)gl::env_long("GRAPHLILY_SPMV_HUB_DIV", 48));
+                const uint64_t thr = std::max<uint64_t>(256, m / (uint64_t)gl::debug_knob("spmv_hub_div", 48));
                 uint32_t nh = 0;
                 for (uint32_t i = 0; i < r1 - r0 && nh < gl::kMaxHubRows; i++)
                     if (cnt[i] >= thr) {
@@ -1304,7 +1281,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         // (measured on the stand-ins: orkut / products, 34-36 % hot, are best at 3 cold + 2 hot pairs;
         // hollywood / ppa / googleplus, > 50 %, at 2 + 2; since rounds past the end of the shorter stream touch only the
         // other one, the choice is worth 2 % at most)
-        const long forced = gl::env_long("GRAPHLILY_SPMV_MIX", -1);
+        const long forced = gl::debug_knob("spmv_mix", -1);
         const double hot_frac = nnz ? (double)hot_nnz / (double)nnz : 0.0;
         int mix = 5;                                   // wide: 2 + 2 pairs; narrow: 3 + 3 groups
         // (re-swept with the packed gather vector: cold groups got cheaper, so a little more of them per slot)
@@ -1417,7 +1394,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     //   spread     a quarter or more of the columns are gathered: one streaming pass over x (spmv_spread_x_kernel);
     //   gather     otherwise (sparse shards): spmv_hot_gather_kernel / spmv_prescale_kernel read only what they need.
     {
-        const long mode = gl::env_long("GRAPHLILY_SPMV_HELPER", -1);   // -1 automatic, 0 gather, 1 spread, 2 self-hot (if possible)
+        const long mode = gl::debug_knob("spmv_helper", -1);   // -1 automatic, 0 gather, 1 spread, 2 self-hot (if possible)
         // (pattern plans always need their helper: it forms z = colval (x) x)
         const bool can_self = !compact && !pattern && nhot_table <= 4096u;
         p->self_hot = can_self && (mode == 2 || (mode < 0 && nnz <= (16ull << 20)));
@@ -1504,28 +1481,22 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     return GL_OK;
 }
 
-int gl_spmv_plan_info(gl_spmv_plan p, uint64_t *nnz, uint64_t *device_bytes, uint32_t *num_units) {
-    GL_ARG(p != nullptr);
-    if (nnz) *nnz = p->nnz;
-    if (device_bytes) *device_bytes = p->device_bytes;
-    if (num_units) *num_units = p->nunits;
-    return GL_OK;
-}
-
-int gl_spmv_plan_hot(gl_spmv_plan p, uint32_t *hot_columns, uint64_t *hot_nnz, int *mix) {
-    GL_ARG(p != nullptr);
-    if (hot_columns) *hot_columns = p->nhot;
-    if (hot_nnz) *hot_nnz = p->hot_nnz;
-    if (mix) *mix = p->mix;
-    return GL_OK;
-}
-
-int gl_spmv_plan_helper(gl_spmv_plan p, int *mode, uint32_t *packed_columns) {
-    GL_ARG(p != nullptr);
-    if (mode)
-        *mode = p->boolean ? GL_HELPER_NONE : p->self_hot ? GL_HELPER_SELF_HOT : p->d_colmap ? GL_HELPER_SPREAD
-                : (p->pattern || p->nhot || p->ncompact) ? GL_HELPER_GATHER : GL_HELPER_NONE;
-    if (packed_columns) *packed_columns = p->ncompact;
+int gl_spmv_plan_describe(gl_spmv_plan p, gl_spmv_plan_desc *out) {
+    GL_ARG(p != nullptr && out != nullptr);
+    out->nnz = p->nnz;
+    out->device_bytes = p->device_bytes;
+    out->groups = p->ngroups;
+    out->hot_nnz = p->hot_nnz;
+    out->num_units = p->nunits;
+    out->blocks = p->nblocks;
+    out->segments = p->segments;
+    out->max_block_rows = p->max_block_rows;
+    out->hot_columns = p->nhot;
+    out->packed_columns = p->ncompact;
+    out->layout = p->reference_order ? GL_LAYOUT_REFERENCE_ORDER : p->boolean ? GL_LAYOUT_BOOLEAN : (p->pattern ? GL_LAYOUT_PATTERN : GL_LAYOUT_GENERAL);
+    out->mix = p->mix;
+    out->helper = p->boolean ? GL_HELPER_NONE : p->self_hot ? GL_HELPER_SELF_HOT : p->d_colmap ? GL_HELPER_SPREAD
+                  : (p->pattern || p->nhot || p->ncompact) ? GL_HELPER_GATHER : GL_HELPER_NONE;
     return GL_OK;
 }
 
@@ -1578,37 +1549,6 @@ int gl_bfs_pull_step(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits
     if (!p->boolean)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step: the plan does not hold the GL_PLAN_BOOLEAN layout");
     return gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, gl::ctx().stream);
-}
-
-int gl_bfs_pull_step_gated(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level,
-                           const uint32_t *d_gate, uint32_t gate_value, int gate_op) {
-    GL_REQUIRE_INIT();
-    GL_ARG(p != nullptr && d_bits_in != nullptr && d_bits_out != nullptr && d_distance != nullptr);
-    GL_ARG(d_bits_in != d_bits_out);
-    GL_ARG((((uintptr_t)d_bits_in | (uintptr_t)d_bits_out) & 15u) == 0);
-    if (!p->boolean)
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step: the plan does not hold the GL_PLAN_BOOLEAN layout");
-    GL_ARG(gate_op == GL_GATE_EQ || gate_op == GL_GATE_GT || gate_op == GL_GATE_LE);
-    return gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, gl::ctx().stream, d_gate, gate_value, gate_op);
-}
-
-int gl_bfs_pull_step_back(gl_spmv_plan p, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level,
-                          uint32_t *d_ctl, uint32_t slot, float back_threshold, int may_continue, gl_idx_val *d_frontier_out,
-                          uint32_t *d_scratch) {
-    GL_REQUIRE_INIT();
-    GL_ARG(p != nullptr && d_bits_in != nullptr && d_bits_out != nullptr && d_distance != nullptr);
-    GL_ARG(d_ctl != nullptr && d_frontier_out != nullptr && d_scratch != nullptr);
-    GL_ARG(d_bits_in != d_bits_out);
-    GL_ARG((((uintptr_t)d_bits_in | (uintptr_t)d_bits_out) & 15u) == 0);
-    if (!p->boolean)
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step_back: the plan does not hold the GL_PLAN_BOOLEAN layout");
-    if (p->row_begin != 0 || p->row_end != p->num_rows)
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_bfs_pull_step_back: row shards decide on the host (their frontier counts are partial)");
-    hipStream_t s = gl::ctx().stream;
-    const int rc = gl::bool_plan_bfs_step(p, d_bits_in, d_bits_out, d_distance, level, s, d_ctl, slot, GL_GATE_LE, d_ctl, slot,
-                                          back_threshold, may_continue);
-    if (rc != GL_OK) return rc;
-    return gl::bits_to_sparse_gated(d_bits_out, p->num_rows, d_frontier_out, d_scratch, d_ctl + 4, slot, s);
 }
 
 int gl_bfs_bits_pull_step(gl_spmv_plan p, gl_spmspv_plan csc, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance,
@@ -1666,22 +1606,6 @@ int gl_spmv_plan_export(gl_spmv_plan p, int array, void *h_dst, size_t capacity,
     return GL_OK;
 }
 
-int gl_spmv_plan_layout(gl_spmv_plan p, int *layout) {
-    GL_ARG(p != nullptr && layout != nullptr);
-    *layout = p->reference_order ? GL_LAYOUT_REFERENCE_ORDER : p->boolean ? GL_LAYOUT_BOOLEAN : (p->pattern ? GL_LAYOUT_PATTERN : GL_LAYOUT_GENERAL);
-    return GL_OK;
-}
-
-int gl_spmv_plan_shape(gl_spmv_plan p, uint32_t *blocks, uint32_t *segments, uint32_t *max_block_rows,
-                       uint64_t *groups) {
-    GL_ARG(p != nullptr);
-    if (blocks) *blocks = p->nblocks;
-    if (segments) *segments = p->segments;
-    if (max_block_rows) *max_block_rows = p->max_block_rows;
-    if (groups) *groups = p->ngroups;
-    return GL_OK;
-}
-
 int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero,
                 int mask_type) {
     GL_TRACE();
@@ -1697,17 +1621,6 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
         return gl::bool_plan_run(p, d_x, nullptr, d_mask, d_y, zero, mask_type, gl::ctx().stream);
     }
     return gl::spmv_run_general(p, d_x, d_mask, d_y, op, zero, mask_type, nullptr);
-}
-
-int gl_spmv_run_flagged(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
-                        const uint32_t *d_flag) {
-    GL_REQUIRE_INIT();
-    GL_ARG(p != nullptr && d_y != nullptr && d_flag != nullptr);
-    GL_ARG(d_x != nullptr || p->nnz == 0);
-    GL_ARG(mask_type == GL_NOMASK || d_mask != nullptr);
-    if (p->boolean || p->reference_order)
-        return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run_flagged: general / pattern layouts only");
-    return gl::spmv_run_general(p, d_x, d_mask, d_y, op, zero, mask_type, d_flag);
 }
 
 int gl_spmv_run_typed(gl_spmv_plan p, const void *d_x, const void *d_mask, void *d_y, int op, uint32_t zero_bits, int mask_type,
@@ -1750,21 +1663,13 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
     a.y = d_y;
     a.zero = zero;
     a.run_flag = run_flag;
-    a.clocks = nullptr;
-    static const char *clocks_path = getenv("GRAPHLILY_SPMV_CLOCKS");
-    unsigned long long *d_clocks = nullptr;
-    if (clocks_path && p->nunits) {
-        GL_HIP(hipMalloc((void **)&d_clocks, (size_t)p->nunits * 8u * gl::kClockStamps));
-        GL_HIP(hipMemset(d_clocks, 0, (size_t)p->nunits * 8u * gl::kClockStamps));
-        a.clocks = d_clocks;
-    }
     a.z = p->d_z;
     a.diag = p->d_diag;
     a.diag_has = p->d_diag_has;
     a.partials = p->d_partials;
     a.prow = p->row_end - p->row_begin;
     a.row_begin = p->row_begin;
-    static const uint32_t tickets = gl::env_long("GRAPHLILY_SPMV_TICKETS", 1) != 0;
+    static const uint32_t tickets = 1u;
     a.tickets = tickets;
     a.self_hot_cols = p->self_hot ? p->d_hot_cols : nullptr;
     hipStream_t s = gl::ctx().stream;
@@ -1780,23 +1685,6 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
         case gl::kOpFixAndOr: rc = gl::dispatch_mask<gl::kOpFixAndOr>(mask_type, p, a, s); break;
         case gl::kOpFixAddMin: rc = gl::dispatch_mask<gl::kOpFixAddMin>(mask_type, p, a, s); break;
         default: rc = gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_run: invalid semiring op %d", op); break;
-    }
-    if (d_clocks) {   // debugging only: blocking dump (100 MHz ticks), last run wins
-        std::vector<unsigned long long> h((size_t)p->nunits * gl::kClockStamps);
-        std::vector<uint4> un((size_t)p->nunits * 2);
-        if (hipStreamSynchronize(s) == hipSuccess &&
-            hipMemcpy(h.data(), d_clocks, h.size() * 8u, hipMemcpyDeviceToHost) == hipSuccess &&
-            hipMemcpy(un.data(), p->d_units, un.size() * sizeof(uint4), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE *f = fopen(clocks_path, "w")) {   // unit, the stamps, #cold-groups #hot-groups #rows #hub-rows
-                for (uint32_t u = 0; u < p->nunits; u++) {
-                    fprintf(f, "%u", u);
-                    for (uint32_t k = 0; k < gl::kClockStamps; k++) fprintf(f, " %llu", h[gl::kClockStamps * u + k]);
-                    fprintf(f, " %u %u %u %u\n", un[2 * u].y, un[2 * u + 1].z, un[2 * u].w & 0xffffu, un[2 * u + 1].y);
-                }
-                fclose(f);
-            }
-        }
-        (void)hipFree(d_clocks);
     }
     return rc;
 }

@@ -480,7 +480,7 @@ __device__ __forceinline__ void spmv_bool_body(const BoolArgs &a, uint32_t *lds_
 }
 
 static uint32_t bool_tickets() {
-    static const uint32_t t = env_long("GRAPHLILY_SPMV_TICKETS", 1) != 0;
+    static const uint32_t t = 1u;
     return t;
 }
 
@@ -548,8 +548,8 @@ static int launch_bool_keep(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
 
 template <int MASK, int FUSED>
 static int launch_bool_variant(gl_spmv_plan p, const BoolArgs &a, hipStream_t s) {
-    static const size_t keep_bytes = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MB", 224) << 20;
-    static const size_t keep_min = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MIN_MB", 64) << 20;
+    static const size_t keep_bytes = (size_t)224 << 20;
+    static const size_t keep_min = (size_t)64 << 20;
     // (the CSR copy for the bottom-up BFS step is not streamed by this kernel)
     const size_t rows_bytes = p->d_csr_indptr ? ((size_t)(p->row_end - p->row_begin) + 1u) * 4u + (size_t)p->nnz * 4u : 0u;
     const size_t streamed = p->device_bytes - std::min<size_t>(rows_bytes, p->device_bytes);
@@ -652,8 +652,8 @@ int bool_plan_bfs_shard_step(gl_spmv_plan p, BfsPushArgs pa, BfsShardArgs sa, hi
     a.v2_row_base = p->row_begin;
     sa.pull_units = p->nunits;
     const uint32_t grid = sa.finish ? 1u : std::max<uint32_t>(std::max<uint32_t>(sa.pull_units, sa.push_blocks), 1u);
-    static const size_t keep_bytes = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MB", 224) << 20;
-    static const size_t keep_min = (size_t)env_long("GRAPHLILY_SPMV_KEEP_MIN_MB", 64) << 20;
+    static const size_t keep_bytes = (size_t)224 << 20;
+    static const size_t keep_min = (size_t)64 << 20;
     const size_t rows_bytes = p->d_csr_indptr ? ((size_t)(p->row_end - p->row_begin) + 1u) * 4u + (size_t)p->nnz * 4u : 0u;
     const size_t streamed = p->device_bytes - std::min<size_t>(rows_bytes, p->device_bytes);
     const bool keep = streamed <= keep_bytes && streamed >= keep_min;
@@ -789,7 +789,7 @@ static Shape choose_shape_bool(uint64_t rows, uint64_t cols, uint64_t nnz, int n
         }
     }
     if (best_cost > 1e299) best = Shape{(uint32_t)((rows + rmax - 1) / rmax), 1};
-    const long fb = env_long("GRAPHLILY_SPMV_BLOCKS", 0), fs = env_long("GRAPHLILY_SPMV_SEGMENTS", 0);
+    const long fb = debug_knob("spmv_blocks", 0), fs = debug_knob("spmv_segments", 0);
     if (fb > 0) best.blocks = (uint32_t)std::min<uint64_t>((uint64_t)fb, rows);
     if (fs > 0) best.segments = (uint32_t)std::min<long>(fs, 4096);
     return best;
@@ -818,7 +818,7 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
         eb.num_cols = num_cols;
         uint32_t tallest = 0;
         if ((rc = fmt_emit_bool(staged.c, eb, p, &tallest)) != GL_OK) return rc;
-        if (env_long("GRAPHLILY_BFS_KEEP_ROWS", 1) != 0) {
+        if (debug_knob("bfs_keep_rows", 1) != 0) {
             if ((rc = devcsr_adopt_rows(staged.c, &p->d_csr_indptr, &p->d_csr_indices)) != GL_OK) return rc;
             p->csr_nz_base = h_indptr[row_begin];
             p->device_bytes += ((size_t)rows + 1u) * 4u + (size_t)p->nnz * 4u;
@@ -987,7 +987,7 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
     p->b_spans = spans.size() * sizeof(uint4);
     GL_HIP(hipMalloc((void **)&p->d_xbits, (size_t)nphases * kBoolPhaseWords * 4u));
     p->device_bytes += (size_t)nphases * kBoolPhaseWords * 4u;
-    if (env_long("GRAPHLILY_BFS_KEEP_ROWS", 1) != 0) {
+    if (debug_knob("bfs_keep_rows", 1) != 0) {
         // the rows as plain CSR for the bottom-up BFS step (see gl_spmv_plan.h); zero values -> column 0xffffffff
         const uint64_t nz0 = h_indptr[row_begin];
         std::vector<uint32_t> cols(h_indices + nz0, h_indices + nz0 + p->nnz);

@@ -126,11 +126,69 @@ def rmat_torch(n, nnz, seed, symmetric, device):
     return CSRMatrix(n, n, np.ones(h_cols.shape[0], dtype=np.float32), h_cols, h_indptr)
 
 
+# A stand-in WITH structure (round 4): the R-MAT stand-ins above are randomly relabelled, so a row's columns are spread over the
+# whole vector by construction -- every layout decision taken on them (no row clustering, the packed gather vector) rests on
+# graphs without locality.  Real social / co-purchase graphs have communities; this one plants them.
+EXTRA_GRAPHS = {
+    "orkut_community":    dict(n=3_072_441, nnz=213_000_000, seed=16, symmetric=True, iters=6, kind="community"),
+    "products_community": dict(n=2_449_029, nnz=124_000_000, seed=15, symmetric=True, iters=23, kind="community"),
+}
+
+
+def community_torch(n, nnz, seed, symmetric, device, p_in=0.8, mean_size=2048):
+    """Degree-corrected stochastic block model: vertex weights from a power law (Pareto, exponent 2.2, capped), communities of
+    geometrically spread sizes around `mean_size` numbered CONTIGUOUSLY (vertex ids follow the communities, as crawl order or
+    a clustering pass leaves them), every edge picks its first endpoint by weight and its second one, with probability p_in,
+    by weight inside the first one's community, else by weight anywhere.  Deduplicated; returns a host CSRMatrix."""
+    import torch
+    device = torch.device("cpu") if device is None else device
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    m = int((nnz // 2 if symmetric else nnz) * 1.12)
+    # community boundaries: sizes mean_size * 2^U(-2, 2)
+    sizes = []
+    rs = np.random.default_rng(seed)
+    total = 0
+    while total < n:
+        sz = max(16, int(mean_size * 2.0 ** rs.uniform(-2.0, 2.0)))
+        sizes.append(min(sz, n - total))
+        total += sizes[-1]
+    bounds = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device=device)
+    comm = torch.repeat_interleave(torch.arange(len(sizes), device=device), torch.tensor(sizes, device=device))
+    u = torch.rand(n, generator=g, device=device, dtype=torch.float64)
+    w = torch.clamp((1.0 - u) ** (-1.0 / 1.2), max=float(n) ** 0.5)        # Pareto tail, hubs capped at sqrt(n) x the minimum
+    cum = torch.cumsum(w, 0)
+    cum0 = torch.cat([torch.zeros(1, dtype=cum.dtype, device=device), cum])       # cum0[v] = weight in front of vertex v
+    src = torch.searchsorted(cum, torch.rand(m, generator=g, device=device, dtype=torch.float64) * cum[-1]).clamp_(max=n - 1)
+    inside = torch.rand(m, generator=g, device=device) < p_in
+    c = comm[src]
+    lo = torch.where(inside, cum0[bounds[c]], torch.zeros_like(cum0[bounds[c]]))
+    hi = torch.where(inside, cum0[bounds[c + 1]], cum[-1].expand_as(lo))
+    r = lo + torch.rand(m, generator=g, device=device, dtype=torch.float64) * (hi - lo)
+    dst = torch.searchsorted(cum, r).clamp_(max=n - 1)
+    del inside, c, lo, hi, r, u
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    if symmetric:
+        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    key = torch.unique(src * n + dst)
+    del src, dst
+    rows = torch.div(key, n, rounding_mode="floor")
+    cols = (key - rows * n).to(torch.int32)
+    counts = torch.bincount(rows, minlength=n)
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(counts, 0)
+    h_cols = cols.cpu().numpy().view(np.uint32)
+    return CSRMatrix(n, n, np.ones(h_cols.shape[0], dtype=np.float32), h_cols, indptr.cpu().numpy().astype(np.uint32))
+
+
 def paper_graph(name, scale=1.0, device=None):
-    """Stand-in for one of the six benchmark graphs; `scale` < 1 shrinks vertices and edges alike."""
-    g = PAPER_GRAPHS[name]
+    """Stand-in for one of the six benchmark graphs (or one of EXTRA_GRAPHS); `scale` < 1 shrinks vertices and edges alike."""
+    g = PAPER_GRAPHS.get(name) or EXTRA_GRAPHS[name]
     n = max(128, int(g["n"] * scale))
     nnz = max(1024, int(g["nnz"] * scale))
+    if g.get("kind") == "community":
+        return community_torch(n, nnz, g["seed"], g["symmetric"], device)
     if device is not None:
         return rmat_torch(n, nnz, g["seed"], g["symmetric"], device)
     return rmat(n, nnz, g["seed"], g["symmetric"])

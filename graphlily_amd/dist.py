@@ -252,7 +252,7 @@ class EmulatedComm:
 
 
 class CabiComm(Comm):
-    """Comm whose bit-vector exchange goes through the C ABI (gl_dist_all_gather_bits: grouped ncclSend / ncclRecv on the
+    """Comm whose bit-vector exchange goes through the C ABI (gl_dist_all_gather_bits_tally: grouped ncclSend / ncclRecv on the
     library's stream) instead of torch.distributed -- what a C++ caller of the drop-in headers uses.  The communicator's
     unique id travels through the torch process group."""
 
@@ -265,7 +265,4 @@ class CabiComm(Comm):
         self.gl = capi.Dist(self.rank, self.world_size, uid[0])
 
     def exchange_bits(self, bits_buf, k, bounds, tally_slot_buf=None, tally_slot=None):
-        if tally_slot_buf is None:
-            self.gl.all_gather_bits(bits_buf, bounds)
-        else:
-            self.gl.all_gather_bits_tally(bits_buf, bounds, tally_slot_buf)
+        self.gl.all_gather_bits_tally(bits_buf, bounds, tally_slot_buf)

@@ -49,7 +49,7 @@ def load_csr_matrix_from_float_npz(csr_float_npz_path):
 
 def csr2csc(csr_matrix):
     """Transpose (io/data_loader.h:108-144); rows inside a column stay ascending.  Done natively
-    (gl_host_csr2csc, parallel counting sort): the numpy formulation took 18 s on 212 M non-zeros."""
+    (gl_csr2csc: a radix sort on the GPU for large matrices, a parallel counting sort on the host otherwise): the numpy formulation took 18 s on 212 M non-zeros."""
     indptr, indices, data = capi.host_csr2csc(csr_matrix.num_rows, csr_matrix.num_cols, csr_matrix.adj_indptr,
                                               csr_matrix.adj_indices, csr_matrix.adj_data)
     return CSCMatrix(csr_matrix.num_rows, csr_matrix.num_cols, data, indices, indptr)

@@ -69,7 +69,7 @@ def convert_sparse_vec_to_dense_vec(sparse_vector, rng, zero):
 class BaseModule:
     # Counts the module calls that write device memory (any module's run / send_* / copy).  An SpMSpVModule remembers the
     # value right after it uploaded a tiny vector; while nothing else has written since, its runs tell the library that
-    # the vector is still that tiny one (gl_spmspv_plan_hint_tiny: one launch instead of four).
+    # the vector is still that tiny one (gl_spmspv_plan_hint_work: one launch instead of two).
     device_writes_ = 0
 
     def __init__(self, kernel_name="overlay"):
@@ -229,12 +229,6 @@ class SpMVModule(BaseModule):
         (GL_ERR_UNSUPPORTED) for split plans."""
         self.plan_.bfs_pull_step(bits_in, bits_out, distance_buf, level)
         self._finish()
-
-    def bfs_pull_step_gated(self, bits_in, bits_out, distance_buf, level, gate, gate_value, gate_op):
-        self.plan_.bfs_pull_step_gated(bits_in, bits_out, distance_buf, level, gate, gate_value, gate_op)
-
-    def bfs_pull_step_back(self, bits_in, bits_out, distance_buf, level, ctl, slot, back_threshold, may_continue, frontier_out, scratch):
-        self.plan_.bfs_pull_step_back(bits_in, bits_out, distance_buf, level, ctl, slot, back_threshold, may_continue, frontier_out, scratch)
 
     def fused_bfs_ok(self):
         if self.plan_ is None or not self._plan_serves(self.semiring_.op) or self.semiring_.zero != 0.0:
@@ -410,15 +404,6 @@ class SpMSpVModule(BaseModule):
         self.plan_.run_assign(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
                               self.mask_type_, inout_buf, val)
         self._finish_run()
-
-    def run_gated(self, vector_buf, results_buf, inout_buf, val, next_bits, gate, gate_value, gate_op, ctl=None, slot=0,
-                  threshold=0.0, may_continue=False):
-        """Extension (gl_spmspv_run_gated): run_assign on explicit vector / result buffers under a device-side launch
-        predicate; leaves the emitted rows as bits in `next_bits` and, with `ctl`, takes the push -> pull decision."""
-        mask = self.mask_buf if self.mask_type_ != kNoMask else None
-        BaseModule.device_writes_ += 1
-        self.plan_.run_gated(vector_buf, mask, results_buf, self.semiring_.op, self.semiring_.zero, self.mask_type_,
-                             inout_buf, val, next_bits, gate, gate_value, gate_op, ctl, slot, threshold, may_continue)
 
     def _finish_run(self):
         """A blocking run waits for the operator's own completion record (gl_spmspv_wait: the fold's last workgroup stores the

@@ -4,7 +4,7 @@
 // CSRMatrix<T> and CSCMatrix<T> are two instantiations of one compressed-storage aggregate; field names
 // and order are the reference's, so brace / designated initialisation in caller code keeps working.
 // npz parsing and the float transpose are done natively by libgraphlily_hip.so (gl_npz_csr_*,
-// gl_host_csr2csc), replacing the un-vendored cnpy dependency and the single-threaded counting sort.
+// gl_csr2csc), replacing the un-vendored cnpy dependency and the single-threaded counting sort.
 #ifndef GRAPHLILY_IO_DATA_LOADER_H_
 #define GRAPHLILY_IO_DATA_LOADER_H_
 

@@ -5,7 +5,7 @@
 //    built from the same file (app/bfs.h:83-99, app/sssp.h:129-147).  Modules of ONE ModuleCollection whose plans have the
 //    same shape and non-zero count are taken to be such a pair: the SpMSpV plan gets the SpMV plan attached
 //    (gl_spmspv_plan_attach_pull: a push iteration whose frontier is heavy runs row-wise), and the pair is what a fused BFS
-//    pull iteration needs (below).  GRAPHLILY_PAIR_MODULES=0 switches it off.
+//    pull iteration needs (below).  GRAPHLILY_MODULE_FUSION=0 switches both 1. and 2. off.
 //
 // 2. The BFS pull iteration.  The reference's drivers express it as three module calls (app/bfs.h:118-123, :208-216):
 //        SpMV->run()                       (||,&&), masked WriteToZero by the distances D:   results = mask(A x)
@@ -17,7 +17,7 @@
 //    rows not reached yet), which write D and keep the frontier as BITS.  The float `vector` and `results` buffers are then
 //    OWED: whoever touches one of them through DeviceBuffer::ptr() (a download, another module, the next non-matching call)
 //    first has them written from the bits (gl_unpack_bits), so every observable value is the unfused sequence's.  Any other
-//    call sequence simply runs the deferred calls as they are.  GRAPHLILY_FUSE_PULL=0 switches it off.
+//    call sequence simply runs the deferred calls as they are.  GRAPHLILY_MODULE_FUSION=0 switches it off.
 #ifndef GRAPHLILY_MODULE_FUSION_H_
 #define GRAPHLILY_MODULE_FUSION_H_
 
@@ -63,7 +63,7 @@ struct PullFusion {
                   uint64_t nnz) {
         forget(module);
         entries.push_back(Entry{module, owner, spmv, spmspv, rows, cols, nnz});
-        if (!owner || !env_on("GRAPHLILY_PAIR_MODULES")) return;
+        if (!owner || !env_on("GRAPHLILY_MODULE_FUSION")) return;
         for (const Entry &a : entries)
             for (const Entry &b : entries)
                 if (a.spmv && b.spmspv && a.owner == owner && b.owner == owner && a.rows == b.rows && a.cols == b.cols && a.nnz == b.nnz)
@@ -243,7 +243,7 @@ struct PullFusion {
     }
 
     bool fusable_ = true;
-    bool enabled() const { return fusable_ && env_on("GRAPHLILY_FUSE_PULL"); }
+    bool enabled() const { return fusable_ && env_on("GRAPHLILY_MODULE_FUSION"); }
 };
 
 inline PullFusion &fusion() {

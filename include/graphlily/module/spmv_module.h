@@ -83,10 +83,10 @@ class SpMVModule : public BaseModule {
         GRAPHLILY_CHECK(gl_spmv_plan_create_ex(&plan_, m.num_rows, m.num_cols, m.adj_indptr.data(), m.adj_indices.data(),
                                                values, sharded_ ? row_begin_ : 0,
                                                sharded_ ? row_end_ : m.num_rows, plan_flags_));
-        int layout = GL_LAYOUT_GENERAL;
-        uint32_t segments = 1;
-        GRAPHLILY_CHECK(gl_spmv_plan_layout(plan_, &layout));
-        GRAPHLILY_CHECK(gl_spmv_plan_shape(plan_, nullptr, &segments, nullptr, nullptr));
+        gl_spmv_plan_desc desc;
+        GRAPHLILY_CHECK(gl_spmv_plan_describe(plan_, &desc));
+        const int layout = desc.layout;
+        const uint32_t segments = desc.segments;
         const bool whole = !sharded_ || (row_begin_ == 0 && row_end_ == m.num_rows);
         fusable_plan_ = kFloat && whole && layout == GL_LAYOUT_BOOLEAN && segments == 1 && m.num_rows == m.num_cols;
         if (whole && kFloat) detail::fusion().announce(this, owner_, plan_, nullptr, m.num_rows, m.num_cols, m.adj_indptr[m.num_rows]);

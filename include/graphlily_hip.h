@@ -89,26 +89,24 @@ int gl_buf_d2h_async(void *h_dst, const void *d_src, size_t bytes);
 /* A BFS result (levels: floats holding small integers) read back PACKED: gl_levels_pack writes n levels (n a multiple of 8,
  * 16-byte aligned buffers) as bytes (bits = 8: levels 0 ... 255) or nibbles (bits = 4: 0 ... 15) into d_out, followed -- on the
  * next 16-byte boundary -- by tail_words raw words of d_tail (the schedule's control words: one read-back fetches both);
- * the caller copies n * bits / 8 bytes instead of 4 n over PCIe and gl_host_levels_unpack turns them into the floats the
- * reference's send_*_device_to_host returns, on a few host threads.  gl_host_threads_warm wakes those threads: call it
- * between enqueueing the GPU work and waiting for it.  (12 MB of levels: 225 us of PCIe become 28 - 55 us + ~30 us of host
- * work; larger values do not survive -- the drivers use this only when the iteration count allows.) */
+ * the caller copies n * bits / 8 bytes instead of 4 n over PCIe and gl_sync_levels_unpack turns them into the floats the
+ * reference's send_*_device_to_host returns, on a few host threads: gl_sync + the expansion with the thread team started
+ * BEFORE the wait (its master waits for the library's stream, the others spin until it returns -- a team woken ahead of a
+ * 0.3 ms wait is asleep again when the wait ends).  (12 MB of levels: 225 us of PCIe become 28 - 55 us + ~30 us of host
+ * work; larger values do not survive -- the drivers use this only when the iteration count allows, and only while it
+ * measures faster than the float copy on the box at hand.) */
 int gl_levels_pack(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *d_out);
-int gl_host_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits);
-int gl_host_threads_warm(void);
-int gl_host_unpack_threads(void);   /* how many threads gl_host_levels_unpack uses for a large vector (packing pays from 4 on) */
-/* gl_sync + gl_host_levels_unpack with the thread team started BEFORE the wait: its master waits for the library's stream, the
- * others spin until it returns -- a team woken ahead of a 0.3 ms wait is asleep again when the wait ends. */
+int gl_host_unpack_threads(void);   /* how many threads gl_sync_levels_unpack uses for a large vector (packing pays from 4 on) */
 int gl_sync_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits);
+int gl_host_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits);   /* the expansion alone (needs no GPU) */
 /* Blocking read-back of n floats that are EXPECTED to be BFS levels no larger than max_level (a caller that has seen only
  * level-writing kernels touch the buffer): packed on the device with every value checked, copied as nibbles / bytes, expanded
  * on host threads; if any value is not a small non-negative integer the floats themselves are copied -- the result is always
- * exactly the buffer's contents.  *packed (may be NULL) tells which way it went.  GRAPHLILY_D2H_LEVELS=0: always the floats. */
+ * exactly the buffer's contents.  *packed (may be NULL) tells which way it went.  GRAPHLILY_BFS_U8=0: always the floats. */
 int gl_buf_d2h_levels(float *h_dst, const float *d_src, size_t n, float max_level, int *packed);
 int gl_buf_d2d(void *d_dst, const void *d_src, size_t bytes);   /* async    */
 int gl_buf_fill_f32(float *d_dst, float value, size_t count);   /* async    */
-/* 32-bit fill that does nothing unless *d_gate == gate_value (d_gate NULL: always) */
-int gl_buf_fill_u32_gated(uint32_t *d_dst, uint32_t value, size_t count, const uint32_t *d_gate, uint32_t gate_value);
+int gl_buf_fill_u32(uint32_t *d_dst, uint32_t value, size_t count);   /* async    */
 /* page-locked host memory for result read-back at full PCIe rate (the reference's host mirrors are
  * 4 KiB-aligned for the same reason, xcl2.hpp:61-76) */
 int gl_host_alloc(void **h_ptr, size_t bytes);
@@ -123,7 +121,7 @@ int gl_host_free(void *h_ptr);
  * from its start again (and released if another one exists); moving to another device (gl_init) releases what is parked
  * and retires the slabs still in use.  Host blocks are plain pages -- on the MI355X box
  * pageable and page-locked copies run at the same 56 GB/s while page-locking 12 MB costs 2.5 ms
- * (profiles/r02_ubench_host.txt); GRAPHLILY_HOST_PIN=1 page-locks them.  gl_pool_trim returns every cached block. */
+ * (profiles/r02_ubench_host.txt).  gl_pool_trim returns every cached block. */
 /* gl_host_pool_reserve: make sure `count` paged-in blocks for requests of `bytes` are parked (the C++ modules do this when a
  * matrix is sent: a driver call then finds its n-element vectors -- two inputs, the result, the previous call's result still
  * alive -- without a miss, which costs 2-4 ms of page faults for 12 MB inside a 2 ms BFS).  Blocks of 2 MB and more are
@@ -189,18 +187,28 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan,
                            const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data,
                            uint32_t row_begin, uint32_t row_end, uint32_t flags);
 int gl_spmv_plan_destroy(gl_spmv_plan plan);
-/* nnz held by this plan (its shard), device bytes of the formatted matrix, number of work units */
-int gl_spmv_plan_info(gl_spmv_plan plan, uint64_t *nnz, uint64_t *device_bytes, uint32_t *num_units);
-/* decomposition chosen by the planner: row blocks x column segments, tallest block, 64-entry groups */
-int gl_spmv_plan_shape(gl_spmv_plan plan, uint32_t *blocks, uint32_t *segments, uint32_t *max_block_rows,
-                       uint64_t *groups);
-/* which device layout the plan holds: 8-byte {index,value} entries, 4-byte pattern entries with per-column
- * values, or the (||,&&)-only bit layout */
+/* What the planner made of the matrix: nnz held by this plan (its shard), device bytes of the formatted matrix, work units;
+ * the decomposition (row blocks x column segments, tallest block, 64-entry groups); the device layout (8-byte {index,value}
+ * entries, 4-byte pattern entries with per-column values, the (||,&&)-only bit layout, or the diagnostic reference-order CSR);
+ * the hot-column cache (columns whose x value is kept in LDS, the non-zeros they serve, the cold/hot interleave: 0 = no hot
+ * table, 5 = 3 cold + 3 hot groups per wavefront iteration); and how the plan refills its hot table / packed gather vector
+ * per run: a gathering helper kernel, one streaming pass over x, or no helper launch at all (short streams
+ * with a small hot table: the workgroups gather it themselves); packed_columns = length of the packed vector (0: cold
+ * entries index x itself). */
 #define GL_LAYOUT_GENERAL 0
 #define GL_LAYOUT_PATTERN 1
 #define GL_LAYOUT_BOOLEAN 2
 #define GL_LAYOUT_REFERENCE_ORDER 3
-int gl_spmv_plan_layout(gl_spmv_plan plan, int *layout);
+#define GL_HELPER_GATHER 0
+#define GL_HELPER_SPREAD 1
+#define GL_HELPER_SELF_HOT 2
+#define GL_HELPER_NONE 3
+typedef struct gl_spmv_plan_desc {
+    uint64_t nnz, device_bytes, groups, hot_nnz;
+    uint32_t num_units, blocks, segments, max_block_rows, hot_columns, packed_columns;
+    int layout, mix, helper;
+} gl_spmv_plan_desc;
+int gl_spmv_plan_describe(gl_spmv_plan plan, gl_spmv_plan_desc *out);
 /* Debugging / tests: copy one of the plan's device arrays to the host.  `array` is one of GL_PLAN_ARRAY_*; *bytes
  * receives its size (also when h_dst is NULL or capacity is too small, in which case nothing is copied and
  * GL_ERR_INVALID_ARG is returned for a non-NULL h_dst). */
@@ -230,18 +238,6 @@ int gl_spmv_run_bits(gl_spmv_plan plan, const uint32_t *d_bits, const float *d_m
  * row range starts on a multiple of 64 (GL_ERR_UNSUPPORTED otherwise: use the three calls).  Both bit vectors
  * have gl_spmv_plan_bits_words words, are 16-byte aligned and distinct. */
 int gl_bfs_pull_step(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level);
-/* hot-column cache: columns whose x value is kept in LDS, the non-zeros they serve, and the cold/hot
- * interleave in use (0 = no hot table, 5 = 3 cold + 3 hot groups per wavefront iteration) */
-int gl_spmv_plan_hot(gl_spmv_plan plan, uint32_t *hot_columns, uint64_t *hot_nnz, int *mix);
-/* how the plan refills its hot table / packed gather vector per run (chosen at creation): a gathering
- * helper kernel, one streaming pass over x, or no helper launch at all (short streams with a small hot table: the
- * workgroups gather it themselves); packed_columns = length of the packed vector (0: cold entries index x itself) */
-#define GL_HELPER_GATHER 0
-#define GL_HELPER_SPREAD 1
-#define GL_HELPER_SELF_HOT 2
-#define GL_HELPER_NONE 3
-int gl_spmv_plan_helper(gl_spmv_plan plan, int *mode, uint32_t *packed_columns);
-
 /* gl_spmv_run replaces enqueueTask(overlay, mode = 1) (module/spmv_module.h:471-475,
  * hw/overlay.cpp:308-330 -> hw/kernel_spmv_impl.h:392-819):
  *   y[r] = mask_r ? ( zero (+) sum_{i in row r} A_i (x) x[col_i] ) : 0
@@ -256,12 +252,11 @@ int gl_spmv_run(gl_spmv_plan plan, const float *d_x, const float *d_mask, float 
 /* Measurement hook (bench.py roofline): between gl_prof_begin and gl_prof_end every launch of the
  * dominant SpMV kernel is bracketed by HIP events recorded on the stream it is launched on.
  * gl_prof_end synchronises and returns the summed kernel time and the number of launches. */
-int gl_prof_begin(uint32_t max_launches);
+/* `every`: bracket only every n-th launch (0 or 1 = all).  An event pair keeps the neighbouring launches from overlapping
+ * the kernel's first and last workgroups, so bracketing every launch slows a back-to-back sequence by ~5 %; sampling
+ * keeps the timed region close to what it is without the profiler. */
+int gl_prof_begin(uint32_t max_launches, uint32_t every);
 int gl_prof_end(double *total_ms, uint32_t *launches);
-/* Bracket only every n-th launch (default 1 = all).  An event pair keeps the neighbouring launches from
- * overlapping the kernel's first and last workgroups, so bracketing every launch slows a back-to-back sequence
- * by ~5 %; sampling keeps the timed region close to what it is without the profiler. */
-int gl_prof_sample_every(uint32_t n);
 /* GPU time of everything enqueued on the library's stream between the two calls (one HIP event pair; gl_span_end waits
  * for the second event): how long a whole launch sequence -- e.g. a replayed BFS schedule -- occupies the device,
  * without the read-back that follows it. */
@@ -294,8 +289,8 @@ int gl_spmspv_run(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *
  * (SpMSpVModule::run is blocking, and get_results_nnz follows it in every push loop: module/spmspv_module.h:436-441,
  * :239-242).  The operator's last workgroup stores {sequence, count} to page-locked host memory once every result is in
  * device memory, so the host neither waits for the stream's completion signal nor copies the head element back (~5 us
- * + a 4-byte copy per call).  Runs that are gated, recorded into a graph or done by the one-launch kernel keep no record:
- * the call is then gl_sync and *nnz = 0xffffffff (read the head element with gl_sparse_nnz).  Work enqueued on OTHER streams
+ * + a 4-byte copy per call).  A run recorded into a graph keeps no record: the call is then gl_sync and *nnz = 0xffffffff
+ * (read the head element with gl_sparse_nnz).  Work enqueued on OTHER streams
  * is not waited for. */
 int gl_spmspv_wait(gl_spmspv_plan plan, uint32_t *nnz);
 /* Extension: gl_spmspv_run followed by gl_assign_sparse(d_result, d_inout, val) -- the push iteration of BFS
@@ -306,132 +301,45 @@ int gl_spmspv_wait(gl_spmspv_plan plan, uint32_t *nnz);
 int gl_spmspv_run_assign(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask,
                          gl_idx_val *d_result, int op, float zero, int mask_type, float *d_inout, float val);
 
-/* Extensions that take the host out of the BFS loop (the reference reads the result count back every
- * push iteration to decide the direction, app/bfs.h:180-190, and converts the frontier on the host at the switch,
- * :195-205).  A driver enqueues the WHOLE schedule -- for every iteration slot both a pull step and a push step --
- * and a device-side word decides which of them runs:
- *   d_ctl            eight words: [0] first pull slot (0xffffffff while pushing), [1] push iterations done,
- *                    [2] source vertex (written by the host before the schedule is enqueued), [3..7] see
- *                    gl_bfs_pull_step_back (gl_bfs_begin initialises all but [2]).
- *   gate             a launch predicate: the call does nothing unless *d_gate (gate_op) gate_value.  The pull step of
- *                    slot s is gated GL_GATE_LE on d_ctl with value s, its push step GL_GATE_GT.
- *   gl_bfs_begin     distance[i] = (i == source), the one-entry frontier list {1,(source,1)} (or, with d_frontier NULL,
- *                    pull from slot 0 on), the frontier as bits, ctl[0..1].
- *   gl_spmspv_run_gated   gl_spmspv_run_assign under a gate that also (a) leaves the emitted rows as bits in
- *                    d_next_bits (may be NULL; the words of the plan's rows are rewritten, the shard must start on a
- *                    multiple of 32 rows) -- so the push -> pull switch needs no conversion pass -- and (b) with d_ctl
- *                    set, takes the reference's loop decision where the result count is produced: ctl[1]++, and
- *                    ctl[0] = slot + 1 unless bit 0 of may_continue_push is set and float(count) / num_rows < threshold.
- *                    (After a gl_bfs_pull_step_back has handed the loop back to pushing, the pushes are counted in ctl[3]
- *                    instead and continue while bit 1 of may_continue_push -- "a slot follows" -- is set and the count stays
- *                    below the threshold that step used.)
- *   gl_bfs_pull_step_gated   gl_bfs_pull_step under a gate.
- * No call of the schedule synchronises or copies to the host; it can be captured once (gl_graph_*) and replayed. */
-/*   gl_bfs_pull_step_back    the pull step of slot `slot` (gated GL_GATE_LE on d_ctl[0] like gl_bfs_pull_step_gated) that
- *                    also takes the OPPOSITE decision -- an extension of this build, the reference never returns to
- *                    pushing: the fused epilogue counts the rows it puts into the next frontier; if that count is below
- *                    back_threshold * num_rows and may_continue is set, the push gate re-opens (d_ctl[0] = 0xffffffff) and the
- *                    new frontier is also written to d_frontier_out as the sparse list the next slot's push step reads
- *                    (ascending rows, value 1).  Distances do not depend on the direction, so results are unchanged; the
- *                    last iterations of a BFS, whose frontiers are tiny again, stop streaming the whole matrix.  A slot
- *                    must enqueue its push step BEFORE this call (the decision then cannot open a gate of its own slot).
- *                    d_ctl has eight words ([4..6] are used here); d_scratch: num_rows / 1024 + 2 words, word 0 zero. */
-#define GL_GATE_EQ 0
-#define GL_GATE_GT 1
-#define GL_GATE_LE 2
-int gl_bfs_begin(uint32_t *d_ctl, float *d_distance, uint32_t n, gl_idx_val *d_frontier, uint32_t *d_bits, uint32_t bits_words);
-int gl_bfs_pull_step_back(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level,
-                          uint32_t *d_ctl, uint32_t slot, float back_threshold, int may_continue, gl_idx_val *d_frontier_out,
-                          uint32_t *d_scratch);
-int gl_spmspv_run_gated(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *d_mask, gl_idx_val *d_result,
-                        int op, float zero, int mask_type, float *d_inout, float val, uint32_t *d_next_bits,
-                        const uint32_t *d_gate, uint32_t gate_value, int gate_op,
-                        uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue_push);
-int gl_bfs_pull_step_gated(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance, float level,
-                           const uint32_t *d_gate, uint32_t gate_value, int gate_op);
-
-/* The same for SSSP::pull_push (app/sssp.h:197-243: do { SpMSpV; AssignVectorSparse (new frontier); nnz = get_results_nnz()
- * } while (iter < num_iterations && nnz / n < threshold), then SpMV + eWiseAdd(+0) to the end): the whole schedule is
- * enqueued up front, the push steps gated GL_GATE_GT on d_ctl[0], the pull steps on a per-slot word.
- *   d_ctl   ctl_words >= 33 + slots words: [0] first pull slot, [1] push iterations done, [2] source (host), [15] ctl_words,
- *           [32 + s] != 0 iff slot s pulls -- set for every later slot by the decision that ends the push phase when
- *           GL_STEP_PULL_FLAGS is part of gl_spmspv_run_gated's may_continue_push.
- *   gl_sssp_begin                       distance = zero except 0 at the source, frontier = {1, (source, 0)}, control words
- *   gl_assign_sparse_new_frontier_gated gl_assign_sparse_new_frontier under a gate (the relax step of a push slot)
- *   gl_spmv_run_flagged                 gl_spmv_run that does nothing unless *d_flag != 0 (general / pattern layouts)
- *   gl_ewise_add_flagged                gl_ewise_add likewise (the results -> vector copy of a pull iteration; 16-byte aligned) */
-#define GL_STEP_PULL_FLAGS 8
-int gl_sssp_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, float zero, gl_idx_val *d_frontier);
-int gl_assign_sparse_new_frontier_gated(const gl_idx_val *d_mask, float *d_inout, gl_idx_val *d_new_frontier, uint32_t max_entries,
-                                        const uint32_t *d_gate, uint32_t gate_value, int gate_op);
-int gl_spmv_run_flagged(gl_spmv_plan plan, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
-                        const uint32_t *d_flag);
-int gl_ewise_add_flagged(const float *d_in, float *d_out, uint32_t len, float val, const uint32_t *d_flag);
-
-/* Second form of the device-resident BFS schedule (replaces app/bfs.h:146-152 + :180-205 for a whole-matrix BFS on one
- * GPU): the frontier lives as BITS only and an iteration slot is TWO launches.
+/* Extensions that take the host out of the BFS loop (the reference reads the result count back every push
+ * iteration to decide the direction, app/bfs.h:180-190, and converts the frontier on the host at the switch, :195-205).
+ * The frontier lives as BITS only; a driver enqueues the WHOLE run -- one launch per iteration slot -- and device-side
+ * control words decide what every slot does.  No call synchronises or copies to the host; the sequence can be recorded once
+ * (gl_graph_*) and replayed for any source.
  *   d_ctl     ctl_words >= 18 + 2 * slots words, 8-byte aligned: [0] first pull slot (0xffffffff while pushing), [1] push
- *             iterations of the first push phase (the reference's count), [2] source vertex (written by the host before
- *             the schedule), [3] pushes after a pull step handed the loop back, [4] the slot that handed back, [5..14]
+ *             iterations of the first push phase (the reference's count), [2] source vertex (written before the run, e.g.
+ *             gl_buf_fill_u32), [3] pushes after a pull step handed the loop back, [4] the slot that handed back, [5..14]
  *             internal, [15] ctl_words; behind them two arrays of S = (ctl_words - 16) / 2 words: [16 + s] the number of
  *             vertices slot s reached, [16 + S + s] how slot s was evaluated (1 scattered, 2 streamed row-wise, 3 bottom-up;
  *             slots >= S are not recorded).
  *   d_bits    nvec >= slots + 2 bit vectors of bits_words words each, contiguous, 16-byte aligned (bits_words a multiple of
- *             4 -- the steps write whole 64-bit words --, at least gl_spmv_plan_bits_words of the pull plan): slot s (1, 2, ...) reads vector s and writes vector
- *             s + 1, which therefore holds exactly the vertices at distance s + 1 when the schedule has run.
- *   gl_bfs_bits_begin       distance[i] = (i == source), vector 1 = {source}, the others and the control words cleared;
- *             ctl[0] = first_pull_slot: 0xffffffff for pull_push (push until the rule says otherwise), 0 for a BFS that
- *             pulls in every slot (app/bfs.h:106-126; the steps get threshold < 0 -- "this schedule never scatters"; the
- *             push steps are still enqueued for their bottom-up role).
- *   gl_bfs_bits_push_step   SpMSpV (||,&&) masked WriteToZero by d_distance + AssignVectorSparse(level) with the next
- *             frontier's bit vector as the accumulator (no dense accumulator, no compaction): runs when slot `slot`
- *             pushes and its frontier is light; a frontier whose columns hold more than 1/32 of the non-zeros is left to
- *             the pull step of the same slot (the same rule as gl_spmspv_plan_attach_pull).  d_bits_out must be all zero on entry; d_bits_spare, if not NULL, is cleared
- *             (gate or not) -- for callers that rotate three vectors instead of keeping one per slot.
- *             `rows` (may be NULL) = the whole-matrix GL_PLAN_BOOLEAN plan of the pull steps, which keeps the rows as plain
- *             CSR: the launch then has a second role, the BOTTOM-UP pull -- when the slot does not scatter and the rows the
- *             BFS has not reached yet hold less than a third of the non-zeros, a thread per unreached row looks through
- *             the row until it finds a neighbour in the frontier (same result as the pull step, whose launch then only
- *             does the bookkeeping); the last iterations of a BFS stop streaming the whole matrix.
- *   gl_bfs_bits_pull_step   gl_bfs_pull_step; runs when the slot pulls, or pushes a heavy frontier (row-wise: the same
- *             pass).  `csc` = the SpMSpV plan of the same matrix (column lengths: the next push's work).  It follows the push
- *             step of its slot also when that one ran: gated off, it adds up the push step's totals and decides for it.
- * Whichever of the two ran ends with the reference's loop decision (ctl[1]++; keep pushing while bit 0 of may_continue
- * is set and new frontier / num_rows < threshold) or, after a pull, the opposite one (back_threshold > 0, bit 1 of
- * may_continue -- "a slot follows" -- set and new frontier / num_rows < back_threshold: push again; pushes after that are
- * counted in ctl[3]).  A slot enqueues its push step BEFORE its pull step.  No call synchronises or copies; the schedule can
- * be captured once (gl_graph_*) and replayed for any source. */
-/* ROW SHARDS (one process per GPU) run the same schedule with the decisions DEFERRED: a shard reaches only its
- * own rows of the new frontier, so its counts are partial.  With GL_BFS_DEFERRED set in may_continue the two steps of a slot
- * run or not by the same control words but keep no totals and decide nothing (plans of any row range starting on a multiple
- * of 64 rows; split plans included -- their units claim rows with atomicOr); the driver then all-gathers the slot's output
- * vector (gl_dist_all_gather_bits, n/8 bytes, on the library's stream) and calls
- *   gl_bfs_bits_decide   popcount of the GATHERED vector + the sums of the GLOBAL column / row lengths of its vertices
- *             (d_col_len / d_row_len: n words each, the whole matrix'; d_row_len may be NULL = never bottom-up), then the
- *             slot's decisions exactly as above -- identical on every rank, no host in the loop, no reduction collective.
- *             `csc` is the rank's own SpMSpV plan (scratch lines); nnz_global the non-zeros of the whole matrix.
+ *             4, at least gl_spmv_plan_bits_words of the row plan): slot s (1, 2, ...) reads vector s and writes vector
+ *             s + 1, which therefore holds exactly the vertices at distance s + 1 when the run is over.
+ *   gl_bfs_bits_begin       distance[i] = (i == source), vector 1 = {source}, the others, the tallies behind them and the
+ *             control words cleared; ctl[0] = first_pull_slot: 0xffffffff for pull_push (push until the rule says
+ *             otherwise), 0 for a BFS that pulls in every slot (app/bfs.h:106-126).
+ *   gl_bfs_bits_shard_step  slot `slot` (1-based) on the rows of `csc` / `rows` (the SpMSpV plan and the GL_PLAN_BOOLEAN SpMV
+ *             plan of the same matrix and row range -- the whole matrix on one GPU, a rank's shard cut on multiples of 64
+ *             rows otherwise; csrc/gl_bfs_shard.h).  The launch starts with the decision of slot - 1: every workgroup adds up
+ *             all ranks' TALLIES of that slot -- vertices reached, their global column lengths (d_col_len: n words, the
+ *             whole matrix'), their row lengths -- and replays the reference's loop condition (do { push } while (it < N &&
+ *             new frontier / n < threshold), app/bfs.h:180-190, same float comparison) on a private copy of the control
+ *             words; after a pull the opposite decision (back_threshold > 0 and a slot follows: push again -- an
+ *             extension, distances do not depend on the direction).  Then the step runs as that state says: the scattering
+ *             push straight into the next frontier's bits (SpMSpV (||,&&) masked by d_distance + AssignVectorSparse(level),
+ *             no accumulator, no compaction), the streaming pull (gl_bfs_pull_step; also a push whose frontier's columns
+ *             hold more than 1/128 of the non-zeros), or -- once the rows not reached yet hold less than a third of the
+ *             non-zeros -- the bottom-up scan (a thread per unreached row looks for a neighbour in the frontier).  Every
+ *             rank tallies what its step adds into its 256 bytes of d_tally; row-sharded drivers exchange them with the
+ *             slot's bit vector (gl_dist_all_gather_bits_tally: one grouped operation) -- no reduction collective, no host.
+ *             may_continue_prev: bit 0 "the reference's loop may go on after slot - 1", bit 1 "a slot follows".
+ *             d_tally: GL_BFS_TALLY_WORDS(slots, world) words (behind the bit vectors: gl_bfs_bits_begin clears them);
+ *             d_tally_in: where the previous slot's tallies of ALL ranks are read (NULL = d_tally).
+ *   gl_bfs_bits_shard_finish  after the last slot: its decision, and the final control words into d_ctl (where the host
+ *             reads the reference's push count and the per-slot records).
  * Each rank's d_distance is full-length but only its own rows are written: read back the slice. */
-#define GL_BFS_DEFERRED 4
-int gl_bfs_bits_decide(gl_spmspv_plan csc, const uint32_t *d_bits_next, const uint32_t *d_col_len, const uint32_t *d_row_len,
-                       uint64_t nnz_global, uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue, float back_threshold);
 int gl_bfs_bits_begin(uint32_t *d_ctl, uint32_t ctl_words, float *d_distance, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
                       uint32_t nvec, uint32_t first_pull_slot);
-/* ONE LAUNCH PER SLOT on a row shard (csrc/gl_bfs_shard.h) -- the schedule above without gl_bfs_bits_decide and with the two
- * steps of a slot in one kernel; what a 1/8 shard of the orkut stand-in needs, whose slots hold less work than a launch costs.
- *   gl_bfs_bits_shard_step    slot `slot` (1-based) on the rows of `csc` / `rows` (the rank's SpMSpV plan and GL_PLAN_BOOLEAN
- *             SpMV plan, same row range, cut on multiples of 64 rows).  Every rank TALLIES what its step adds to the next
- *             frontier -- vertices, their global column lengths (d_col_len: n words, the whole matrix'), their row lengths --
- *             into its 256 bytes of d_tally; the driver exchanges them together with the slot's bit vector
- *             (gl_dist_all_gather_bits_tally: one grouped operation).  The launch of slot s starts with the decision of slot
- *             s - 1: every workgroup adds up all ranks' tallies (integers: identical everywhere) and replays the reference's
- *             loop condition on a private copy of the control words; then the step runs as that state says (scattering push,
- *             bottom-up scan, streaming pull).  may_continue_prev / threshold / back_threshold: the values of slot - 1
- *             (GL_BFS_DEFERRED is not used here).
- *             d_tally: GL_BFS_TALLY_WORDS(slots, world) words, ALL ZERO at the start of a run (allocate it behind the bit
- *             vectors and let gl_bfs_bits_begin clear it with them); d_tally_in: where the previous slot's tallies of ALL
- *             ranks are read (NULL = d_tally, after the exchange; a one-GPU emulation passes a recorded table).
- *   gl_bfs_bits_shard_finish  after the last slot: its decision, and the final control words into d_ctl (where the host
- *             reads the reference's push count and the per-slot records, as above). */
 #define GL_BFS_TALLY_HEAD_WORDS 64
 #define GL_BFS_TALLY_RANK_WORDS 64
 #define GL_BFS_TALLY_WORDS(slots, world) (GL_BFS_TALLY_HEAD_WORDS + (size_t)(slots) * (size_t)(world) * GL_BFS_TALLY_RANK_WORDS)
@@ -442,14 +350,19 @@ int gl_bfs_bits_shard_step(gl_spmspv_plan csc, gl_spmv_plan rows, const uint32_t
 int gl_bfs_bits_shard_finish(gl_spmspv_plan csc, gl_spmv_plan rows, uint32_t *d_ctl, uint32_t *d_tally, const uint32_t *d_tally_in,
                              uint32_t last_slot, int rank, int world_size, uint64_t nnz_global, float threshold, int may_continue_last,
                              float back_threshold);
-/* gl_bfs_bits_begin_from: the set-up of a schedule that PULLS in every slot when the caller already holds the distances and
- * the current frontier as a float vector (the C++ module layer recognises the reference's pull iteration -- SpMV, eWiseAdd(+0),
- * AssignVectorDense, app/bfs.h:118-123 -- and runs it as gl_bfs_bits_push_step + gl_bfs_bits_pull_step on three rotating bit
- * vectors, include/graphlily/module/fusion.h): control words as gl_bfs_bits_begin(first_pull_slot = 0) leaves them, d_bits =
- * THREE vectors of bits_words words, the first = (x != 0), the other two cleared.  d_distance (may be NULL) is only read: with
- * `rows` -- the whole-matrix GL_PLAN_BOOLEAN plan, which keeps the rows as CSR -- the non-zeros of the rows already reached are
- * counted, so that a schedule starting in the middle of a BFS (app/bfs.h:195-216) goes bottom-up as early as one that ran from
- * the source. */
+/* The same schedule as TWO launches per slot with the decisions fused into them, for a caller that meets the BFS in the
+ * middle: the C++ module layer recognises the reference's pull iteration -- SpMV, eWiseAdd(+0), AssignVectorDense,
+ * app/bfs.h:118-123 -- and runs it as gl_bfs_bits_push_step + gl_bfs_bits_pull_step on three rotating bit vectors
+ * (include/graphlily/module/fusion.h).
+ *   gl_bfs_bits_begin_from  control words as gl_bfs_bits_begin(first_pull_slot = 0) leaves them, d_bits = THREE vectors of
+ *             bits_words words, the first = (x != 0), the other two cleared.  d_distance (may be NULL) is only read: with
+ *             `rows` -- the whole-matrix GL_PLAN_BOOLEAN plan, which keeps the rows as CSR -- the non-zeros of the rows
+ *             already reached are counted, so that a run starting in the middle of a BFS (app/bfs.h:195-216) goes bottom-up
+ *             as early as one that ran from the source.
+ *   gl_bfs_bits_push_step   the scattering push of slot `slot` when it pushes a light frontier (d_bits_out all zero on entry;
+ *             d_bits_spare, if not NULL, is cleared for the next slot), or -- `rows` given -- the bottom-up scan.
+ *   gl_bfs_bits_pull_step   the streaming pull; it follows the push step of its slot also when that one ran: it then only
+ *             adds up the push step's totals and takes the slot's decisions. */
 int gl_bfs_bits_begin_from(uint32_t *d_ctl, uint32_t ctl_words, const float *d_x, uint32_t n, uint32_t *d_bits, uint32_t bits_words,
                            const float *d_distance, gl_spmv_plan rows);
 int gl_bfs_bits_push_step(gl_spmspv_plan csc, gl_spmv_plan rows, const uint32_t *d_bits_in, uint32_t *d_bits_out, uint32_t *d_bits_spare,
@@ -458,37 +371,27 @@ int gl_bfs_bits_push_step(gl_spmspv_plan csc, gl_spmv_plan rows, const uint32_t 
 int gl_bfs_bits_pull_step(gl_spmv_plan plan, gl_spmspv_plan csc, const uint32_t *d_bits_in, uint32_t *d_bits_out, float *d_distance,
                           float level, uint32_t *d_ctl, uint32_t slot, float threshold, int may_continue, float back_threshold);
 /* Extension: direction switch inside the operator.  `pull` is an SpMV plan over the same matrix and row shard
- * (BFS holds both, app/bfs.h:83-99).  A run with zero == 0 whose frontier columns hold more than 1/32 of the
- * matrix's non-zeros is then computed row-wise into the dense accumulator instead of being scattered: a
- * GL_PLAN_BOOLEAN plan serves (||,&&) (frontier -> bit vector -> boolean SpMV; results identical), a general /
- * pattern plan serves (+,x) (frontier -> dense vector -> SpMV; same values up to float accumulation order --
- * the scatter adds float atomics in arrival order, the SpMV sums in f64; not a GL_PLAN_NO_MULADD plan) and
- * (min,+) with zero <= FLOAT_INF (results identical: the scatter's saturation at FLOAT_INF is hidden by the
- * final min with zero).  One of each kind may be attached;
- * the decision is taken on the device.  The SpMV plans are not owned and must outlive the attachment; NULL
- * detaches both. */
+ * (BFS holds both, app/bfs.h:83-99).  A run with zero == 0 whose frontier columns hold more than 1/8 of the matrix's
+ * non-zeros (GRAPHLILY_SPMSPV_PULL_DIV; 0 = never) is then computed row-wise into the dense accumulator instead of being
+ * binned -- at 24 bytes per product against 8 (4) per non-zero that is where the two cost the same: a GL_PLAN_BOOLEAN
+ * plan serves (||,&&) (frontier -> bit vector -> boolean SpMV; results identical), a general / pattern plan serves (+,x)
+ * (frontier -> dense vector -> SpMV; both ways add the float products in f64: same values up to that sum's order; not a
+ * GL_PLAN_NO_MULADD plan) and (min,+) with zero <= FLOAT_INF (results identical: the operator's saturation at FLOAT_INF is
+ * hidden by the final min with zero).  One of each kind may be attached; the decision is taken on the device.  The SpMV
+ * plans are not owned and must outlive the attachment; NULL detaches both. */
 int gl_spmspv_plan_attach_pull(gl_spmspv_plan plan, gl_spmv_plan pull);
 /* Optional: an upper bound on the number of entries of the NEXT run's input vector (the drivers know it from
- * the previous iteration's gl_sparse_nnz).  Frontiers too small to reach the threshold whatever their columns
+ * the previous iteration's count).  Frontiers too small to reach the threshold whatever their columns
  * are then skip the decision kernels.  One-shot: consumed by the next gl_spmspv_run. */
 int gl_spmspv_plan_hint(gl_spmspv_plan plan, uint32_t vector_nnz_upper_bound);
-/* One-shot: the caller expects the NEXT run's vector to hold vector_nnz entries whose columns hold `work` non-zeros in total
- * (a module that has just uploaded the vector from the host knows both).  Up to 1024 entries and 2048 non-zeros the run is
- * then ONE launch of one workgroup (scatter, sort of the rows reached, ordered emission) instead of four dependent ones:
- * ~30 us per blocking call instead of ~55.  Results never depend on the hint: the kernel checks both bounds on the vector it
- * finds and computes a bigger one correctly (slowly, alone). */
-int gl_spmspv_plan_hint_tiny(gl_spmspv_plan plan, uint32_t vector_nnz, uint64_t work);
-/* The same with everything such a module knows about the vector: also the LONGEST of its columns.  Besides the tiny case, a
- * run whose work stays below the direction switch's threshold (non-zeros / 32) then skips the decision kernel and the
- * row-wise kernels that would only find the switch closed, and one without a long column (>= 4096 entries) the chunk-queue
- * pass: 3 dependent launches instead of up to 9.  One-shot; results never depend on it (a wrong hint makes the run scatter
- * a vector it would have applied row-wise, and a long column that turns up is scattered by one workgroup). */
+/* One-shot: everything a module that has just uploaded the vector from the host knows about it -- its entries, the non-zeros
+ * their columns hold in total (`work`), the LONGEST of those columns.  Up to 1024 entries and 2048 non-zeros the run is then
+ * ONE launch of one workgroup (products by returning atomics, sort of the rows reached, ordered emission); a run whose work
+ * stays below the direction switch's threshold skips the decision kernel and the row-wise kernels that would only find the
+ * switch closed; and the bin launch is sized by the work.  Results never depend on the hint: the kernels check what they
+ * find (a vector that is not tiny after all is computed correctly by the one workgroup, slowly; a wrong "light" makes the
+ * run bin a vector it would have applied row-wise). */
 int gl_spmspv_plan_hint_work(gl_spmspv_plan plan, uint32_t vector_nnz, uint64_t work, uint32_t longest_column);
-/* One-shot like the hint: the vector of the NEXT gl_spmspv_run* call is also available as a bit vector (bit c set iff
- * column c is in the vector; gl_spmv_plan_bits_words words of the attached GL_PLAN_BOOLEAN plan, 16-byte aligned, bits past
- * the columns zero).  A run that goes row-wise on that plan then reads it directly instead of clearing and filling the
- * plan's own bit vector (two launches less); results are unchanged. */
-int gl_spmspv_plan_frontier_bits(gl_spmspv_plan plan, const uint32_t *d_bits);
 /* which way the last run went (1 = row-wise).  Blocking; for tests and reports. */
 int gl_spmspv_last_direction(gl_spmspv_plan plan, int *row_wise);
 
@@ -556,8 +459,11 @@ int gl_sparse_to_dense_typed(const void *d_sparse, void *d_dense, uint32_t range
  *   gl_dist_init        every rank, after gl_init(its device): ncclCommInitRank;
  *   gl_dist_all_gather_f32     d_full[bounds[r] .. bounds[r+1]) is valid on rank r before, everywhere after;
  *                              slices may differ in length (nnz-balanced ranges): point-to-point pushes in one group;
- *   gl_dist_all_gather_bits    the same for a bit vector (gl_pack_bits / gl_bfs_pull_step), bounds in ROWS, multiples
- *                              of 32 -- a sharded BFS pull exchanges n/8 bytes per iteration instead of 4n;
+ *   gl_dist_all_gather_bits_tally   the same for a bit vector (gl_pack_bits / gl_bfs_pull_step), bounds in ROWS, multiples
+ *                              of 32 -- a sharded BFS exchanges n/8 bytes per iteration instead of 4n -- and, in the same
+ *                              grouped operation, every rank's tallies of the slot (gl_bfs_bits_shard_step: d_tally_slot =
+ *                              the slot's table, world_size blocks of bytes_per_rank = 4 * GL_BFS_TALLY_RANK_WORDS bytes,
+ *                              rank r's block at r * bytes_per_rank; NULL / 0: the bits alone);
  *   gl_dist_all_gather_sparse  the ranks' sparse result lists (disjoint ascending row ranges) concatenated in rank order
  *                              into d_full with head {total, head_val}; reads the counts back (blocking), like
  *                              SpMSpVModule::get_results_nnz in the reference's push loops. */
@@ -575,9 +481,6 @@ int gl_dist_init(gl_dist *comm, int rank, int world_size, const void *id128);
 int gl_dist_destroy(gl_dist comm);
 int gl_dist_rank(gl_dist comm, int *rank, int *world_size);
 int gl_dist_all_gather_f32(gl_dist comm, float *d_full, const uint32_t *bounds);
-int gl_dist_all_gather_bits(gl_dist comm, uint32_t *d_bits, const uint32_t *row_bounds);
-/* ... and, in the same grouped operation, every rank's tallies of the slot (gl_bfs_bits_shard_step: d_tally_slot = the slot's
- * table, world_size blocks of bytes_per_rank = 4 * GL_BFS_TALLY_RANK_WORDS bytes, rank r's block at r * bytes_per_rank) */
 int gl_dist_all_gather_bits_tally(gl_dist comm, uint32_t *d_bits, const uint32_t *row_bounds, uint32_t *d_tally_slot, uint32_t bytes_per_rank);
 int gl_dist_all_gather_sparse(gl_dist comm, const gl_idx_val *d_local, gl_idx_val *d_full, uint32_t capacity, float head_val,
                               uint32_t *total);
@@ -588,12 +491,10 @@ int gl_dist_all_gather_sparse(gl_dist comm, const gl_idx_val *d_local, gl_idx_va
 int gl_sparse_to_dense(const gl_idx_val *d_sparse, float *d_dense, uint32_t range, float zero,
                        uint32_t max_entries);
 
-/* csr2csc (io/data_loader.h:108-144) on the host, parallel; rows inside a column stay ascending.
- * Output arrays: csc_indptr[num_cols+1], csc_indices[nnz], csc_data[nnz].  Needs no GPU. */
-int gl_host_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices,
-                    const float *data, uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data);
-/* The same transpose with host arrays in and out, done on the GPU when the runtime is up and the matrix is large (one
- * stable radix sort of (row, value) pairs by column: identical output), on the host otherwise. */
+/* csr2csc (io/data_loader.h:108-144), host arrays in and out; rows inside a column stay ascending.  Output arrays:
+ * csc_indptr[num_cols+1], csc_indices[nnz], csc_data[nnz].  Done on the GPU when the runtime is up and the matrix is large
+ * (one stable radix sort of (row, value) pairs by column), on the host otherwise (parallel counting sort; needs no GPU):
+ * identical output. */
 int gl_csr2csc(uint32_t num_rows, uint32_t num_cols, const uint32_t *indptr, const uint32_t *indices,
                const float *data, uint32_t *csc_indptr, uint32_t *csc_indices, float *csc_data);
 /* util_normalize_csr_matrix_by_outdegree (io/data_formatter.h:36-51): data[i] = 1.0 / (entries in the column of i),

@@ -13,8 +13,7 @@ from graphlily_amd import datasets
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
 name = sys.argv[2] if len(sys.argv) > 2 else "orkut"
-g = datasets.PAPER_GRAPHS[name]
-m = datasets.rmat(int(g["n"] * scale), int(g["nnz"] * scale), g["seed"], g["symmetric"])
+m = datasets.paper_graph(name, scale)      # (round 4: also the stand-ins with planted communities, datasets.EXTRA_GRAPHS)
 n, nnz = m.num_rows, m.nnz
 ip = m.adj_indptr.astype(np.int64)
 cols = m.adj_indices.astype(np.int64)

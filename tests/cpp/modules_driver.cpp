@@ -217,7 +217,7 @@ int main() {
     }
     // ---- the BFS pull iteration of the reference's driver (app/bfs.h:106-126) through a ModuleCollection: the three module
     //      calls run fused (module/fusion.h).  After EVERY iteration the three buffers -- read through the module API -- must
-    //      hold what the unfused sequence leaves (GRAPHLILY_FUSE_PULL=0), and reading them must not disturb the next one.
+    //      hold what the unfused sequence leaves (GRAPHLILY_MODULE_FUSION=0), and reading them must not disturb the next one.
     {
         struct Bfs : public app::ModuleCollection {
             module::SpMVModule<val_t, val_t> *SpMV;
@@ -247,7 +247,7 @@ int main() {
         const uint32_t n = g.num_rows, iters = 7;
         std::vector<fvec> seen[2];
         for (int fused = 0; fused < 2; fused++) {
-            setenv("GRAPHLILY_FUSE_PULL", fused ? "1" : "0", 1);
+            setenv("GRAPHLILY_MODULE_FUSION", fused ? "1" : "0", 1);
             Bfs bfs;
             bfs.set_up_runtime("unused.xclbin");
             bfs.SpMV->load_and_format_matrix(g, true);
@@ -284,7 +284,7 @@ int main() {
             bfs.eWise->run(n, 0);
             seen[fused].push_back(bfs.SpMV->send_vector_device_to_host());
         }
-        unsetenv("GRAPHLILY_FUSE_PULL");
+        unsetenv("GRAPHLILY_MODULE_FUSION");
         uint32_t reached = 0;
         for (float v : seen[0][seen[0].size() - 4]) reached += v != 0;
         printf("fused BFS pull: %u of %u vertices reached in %u iterations\n", reached, n, iters);

@@ -102,3 +102,18 @@ def assert_parity(got, ref, op, what=""):
             bad = np.nonzero(got != ref)[0]
             raise AssertionError("%s: %d mismatches (bit-exact required), first at %d: got %r ref %r" %
                                  (what, bad.size, bad[0], got[bad[0]], ref[bad[0]]))
+
+
+def set_knob(monkeypatch, key, value):
+    """One planner override of GRAPHLILY_DEBUG="key=value,..." (csrc/gl_spmv_plan.h debug_knob: test hooks that force a decision
+    the planner would take from the matrix -- plan shape, hot table, helper mode, tile height ...); value None removes the key."""
+    import os
+    cur = dict(kv.split("=", 1) for kv in os.environ.get("GRAPHLILY_DEBUG", "").split(",") if kv)
+    if value is None:
+        cur.pop(key, None)
+    else:
+        cur[key] = str(value)
+    if cur:
+        monkeypatch.setenv("GRAPHLILY_DEBUG", ",".join("%s=%s" % kv for kv in cur.items()))
+    else:
+        monkeypatch.delenv("GRAPHLILY_DEBUG", raising=False)

@@ -128,7 +128,7 @@ def test_bfs_schedule_entry_points_fail_loudly_without_gpu():
     assert L.gl_bfs_bits_push_step(None, None, None, None, None, 4, None, 2.0, None, 1, 0.5, 3) == capi.GL_ERR_NOT_INITIALIZED
     assert L.gl_bfs_bits_pull_step(None, None, None, None, None, 2.0, None, 1, 0.5, 3, 1.0) == capi.GL_ERR_NOT_INITIALIZED
     assert L.gl_buf_d2h_async(None, None, 16) == capi.GL_ERR_NOT_INITIALIZED
-    assert L.gl_spmspv_plan_hint_tiny(None, 1, 1) == capi.GL_ERR_INVALID_ARG
+    assert L.gl_spmspv_plan_hint_work(None, 1, 1, 1) == capi.GL_ERR_INVALID_ARG
     assert not hasattr(L, "gl_host_patch_bits") and not hasattr(L, "gl_side_copy_d2h")
 
 
@@ -183,4 +183,3 @@ def test_host_levels_unpack():
             capi.host_levels_unpack(dst, np.ascontiguousarray(src), n, bits)
             assert np.array_equal(dst[:n], lev.astype(np.float32)), (n, bits)
             assert np.all(dst[n:] == -1.0)
-    capi.host_threads_warm()

@@ -10,7 +10,7 @@ import pytest
 from graphlily_amd import app, datasets, io, module as M
 from oracle import oracle as O
 
-from helpers import named_matrix, to_oracle
+from helpers import named_matrix, to_oracle, set_knob
 
 pytestmark = pytest.mark.gpu
 
@@ -167,14 +167,14 @@ def test_fused_bfs_pull_step_equals_the_three_calls(gpu, monkeypatch):
     raw = datasets.rmat(30000, 500000, 17, True)
     src = int(np.argmax(np.diff(raw.adj_indptr.astype(np.int64)) > 0))
     runs = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("GRAPHLILY_BFS_FUSED", fused)
+    for host_loop in ("0", "1"):      # the device-resident schedule / the reference's module-call loop (fused pull step inside)
+        monkeypatch.setenv("GRAPHLILY_BFS_HOST_LOOP", host_loop)
         bfs = app.BFS(16, 0, 0, 0)
         bfs.set_up_runtime()
         bfs.load_and_format_matrix(raw.copy(), True)
         bfs.send_matrix_host_to_device()
-        runs[fused] = [bfs.pull(src, 8), bfs.pull_push(src, 8, 0.01)]
-        assert bfs.fused_ == (fused == "1")
+        runs[host_loop] = [bfs.pull(src, 8), bfs.pull_push(src, 8, 0.01)]
+        assert bfs.fused_
     for a, b in zip(runs["1"], runs["0"]):
         assert np.array_equal(a, b)
     om = to_oracle(raw)
@@ -211,9 +211,8 @@ def test_fused_bfs_pull_step_equals_the_three_calls(gpu, monkeypatch):
     assert not bits[(n + 31) // 32:].any() or np.all(bits[(n + 31) // 32:] == 0xFFFFFFFF)   # words past the rows untouched
 
 
-@pytest.mark.parametrize("bits", ["1", "0"])     # the bit-frontier schedule (gl_bfs_bits_*) / the list-based one
 @pytest.mark.parametrize("name", ["rmat_sym_50K", "uniform_10K_10"])
-def test_bfs_pull_push_device_loop_equals_host_loop(gpu, name, bits, monkeypatch):
+def test_bfs_pull_push_device_loop_equals_host_loop(gpu, name, monkeypatch):
     """pull_push with the direction decided on the device (no read-back per iteration; the schedule is
     captured as a hipGraph from the second call on) gives the oracle's distances and switches direction after the same
     number of push iterations as the host-driven loop of the reference (app/bfs.h:180-190), for several sources and
@@ -224,67 +223,57 @@ def test_bfs_pull_push_device_loop_equals_host_loop(gpu, name, bits, monkeypatch
     bfs.set_up_runtime()
     bfs.load_and_format_matrix(m, True)
     bfs.send_matrix_host_to_device()
-    assert bfs._device_loop_ok()
-    monkeypatch.setenv("GRAPHLILY_BFS_BITS", bits)
-    assert bfs._bits_loop_ok() == (bits == "1")
+    assert bfs._bits_loop_ok()
     deg = np.diff(m.adj_indptr.astype(np.int64))
     sources = [0, int(np.argmax(deg)), int(np.nonzero(deg > 0)[0][-1])]
     for thr in (0.001, 0.05, 1.0):
         for rep in range(3):                       # eager, capture, replay
             for src in sources:
-                monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "1")
+                monkeypatch.setenv("GRAPHLILY_BFS_HOST_LOOP", "0")
                 got = bfs.pull_push(src, 8, thr)
                 pushes = bfs.push_iterations_
                 assert np.array_equal(got, O.bfs(om, src, 8)), "thr %g rep %d src %d" % (thr, rep, src)
-                monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "0")
+                monkeypatch.setenv("GRAPHLILY_BFS_HOST_LOOP", "1")
                 ref = bfs.pull_push(src, 8, thr)
                 assert np.array_equal(ref, got)
                 assert bfs.push_iterations_ == pushes, "thr %g src %d: device %d vs host %d push iterations" % (
                     thr, src, pushes, bfs.push_iterations_)
-    state = bfs.bits_loop_ if bits == "1" else bfs.dev_loop_
-    if os.environ.get("GRAPHLILY_BFS_GRAPH", "1") != "0":
-        assert any(state["graphs"].values()), "the schedule was captured as a graph"
+    assert any(bfs.bits_loop_["graphs"].values()), "the schedule was captured as a graph"
 
 
-@pytest.mark.parametrize("bits", ["1", "0"])
 @pytest.mark.parametrize("name", ["rmat_sym_50K", "uniform_10K_10"])
-@pytest.mark.parametrize("back", ["0.9", "0.02", "0.0001"])
-def test_bfs_pull_push_returns_to_push(gpu, name, back, bits, monkeypatch):
-    """An extension of the device-resident schedule: when a pull step finds fewer than `back` * n new vertices the next
-    slot pushes again (gl_bfs_pull_step_back; the default only does so on matrices whose pull step costs far more than a
-    push step's launches, GRAPHLILY_BFS_BACK forces it).  Distances do not depend on the direction: every threshold /
-    source combination must give the oracle's result, eagerly and replayed, and the reference's push count (the first
-    push phase) must not change."""
-    monkeypatch.setenv("GRAPHLILY_BFS_BACK", back)
-    monkeypatch.setenv("GRAPHLILY_BFS_BITS", bits)
+def test_bfs_pull_push_returns_to_push(gpu, name, monkeypatch):
+    """An extension of the device-resident schedule: once the reference's rule has switched to pulling, every later slot is
+    handed back to the push step, which leaves heavy frontiers to the streaming pull (the reference pulls to the end).
+    Distances do not depend on the direction: every threshold / source combination must give the oracle's result, eagerly
+    and replayed, and the reference's push count (the first push phase) must equal the host-driven loop's."""
     m = named_matrix(name)
     om = _oracle_prepared(m, "bfs")
     bfs = app.BFS(M.num_hbm_channels, 0, 0, 0)
     bfs.set_up_runtime()
     bfs.load_and_format_matrix(m, True)
     bfs.send_matrix_host_to_device()
-    assert bfs._device_loop_ok()
+    assert bfs._bits_loop_ok()
     deg = np.diff(m.adj_indptr.astype(np.int64))
     sources = [0, int(np.argmax(deg)), int(np.nonzero(deg > 0)[0][-1])]
     again = 0
     for thr in (0.001, 0.05):
         for rep in range(3):                       # eager, capture, replay
             for src in sources:
-                monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "1")
+                monkeypatch.setenv("GRAPHLILY_BFS_HOST_LOOP", "0")
                 got = bfs.pull_push(src, 9, thr)
                 pushes, again = bfs.push_iterations_, again + bfs.push_iterations_again_
-                assert np.array_equal(got, O.bfs(om, src, 9)), "back %s thr %g rep %d src %d" % (back, thr, rep, src)
-                monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "0")
+                assert np.array_equal(got, O.bfs(om, src, 9)), "thr %g rep %d src %d" % (thr, rep, src)
+                monkeypatch.setenv("GRAPHLILY_BFS_HOST_LOOP", "1")
                 assert np.array_equal(bfs.pull_push(src, 9, thr), got)
                 assert bfs.push_iterations_ == pushes
-    if back == "0.9":
-        assert again > 0, "with back = 0.9 some pull step must have handed the loop back to pushing"
+    assert again > 0, "some pull step must have handed the loop back to pushing"
 
 
 def test_bfs_bits_schedule_long_columns_and_heavy_frontiers(gpu, monkeypatch):
     """gl_bfs_bits_*: columns of 4096 entries and more are served from the plan's static chunk list (two hub vertices with
     ~6000 and ~9000 neighbours, one of them the source), and a push whose frontier holds more than 1/PULL_DIV of the
-    non-zeros is left to the pull step of its slot (forced on and off through GRAPHLILY_BFS_HEAVY_DIV).  Distances and
+    non-zeros is left to the pull step of its slot (forced on and off through GRAPHLILY_DEBUG bfs_heavy_div).  Distances and
     the reference's push count must not depend on any of it."""
     rng = np.random.default_rng(5)
     n = 40000
@@ -300,21 +289,21 @@ def test_bfs_bits_schedule_long_columns_and_heavy_frontiers(gpu, monkeypatch):
     m = io.CSRMatrix(n, n, np.ones(len(c), np.float32), c, indptr)
     om = _oracle_prepared(m, "bfs")
     for div in ("128", "1000000", "1"):
-        monkeypatch.setenv("GRAPHLILY_BFS_HEAVY_DIV", div)
+        set_knob(monkeypatch, "bfs_heavy_div", div)
         bfs = app.BFS(M.num_hbm_channels, 0, 0, 0)
         bfs.set_up_runtime()
         bfs.load_and_format_matrix(m, True)
         bfs.send_matrix_host_to_device()
-        monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "1")
+        monkeypatch.setenv("GRAPHLILY_BFS_HOST_LOOP", "0")
         assert bfs._bits_loop_ok()
         for thr in (0.001, 0.3, 1.0):
             for rep in range(3):
                 for src in (7, 11, 0, 12345):
-                    monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "1")
+                    monkeypatch.setenv("GRAPHLILY_BFS_HOST_LOOP", "0")
                     got = bfs.pull_push(src, 7, thr)
                     pushes = bfs.push_iterations_
                     assert np.array_equal(got, O.bfs(om, src, 7)), "div %s thr %g rep %d src %d" % (div, thr, rep, src)
-                    monkeypatch.setenv("GRAPHLILY_BFS_DEVICE_LOOP", "0")
+                    monkeypatch.setenv("GRAPHLILY_BFS_HOST_LOOP", "1")
                     assert np.array_equal(bfs.pull_push(src, 7, thr), got)
                     assert bfs.push_iterations_ == pushes, "div %s thr %g src %d" % (div, thr, src)
 
@@ -338,7 +327,7 @@ def test_bfs_bottom_up_with_an_unreachable_hub(gpu, monkeypatch):
     m = io.CSRMatrix(n, n, np.ones(len(c), np.float32), c, indptr)
     om = _oracle_prepared(m, "bfs")
     for div in ("3", "1", "0"):
-        monkeypatch.setenv("GRAPHLILY_BFS_BU_DIV", div)
+        set_knob(monkeypatch, "bfs_bu_div", div)
         bfs = app.BFS(M.num_hbm_channels, 0, 0, 0)
         bfs.set_up_runtime()
         bfs.load_and_format_matrix(m, True)
@@ -355,39 +344,32 @@ def test_bfs_bottom_up_with_an_unreachable_hub(gpu, monkeypatch):
 
 @pytest.mark.parametrize("zero", [255.0, 999999999.0])
 @pytest.mark.parametrize("name", ["rmat_sym_50K", "gplus_small"])
-def test_sssp_pull_push_device_loop_equals_host_loop(gpu, name, zero, monkeypatch):
-    """SSSP::pull_push (app/sssp.h:197-243) as a device-resident schedule (SURVEY 8f-1): same distances and the same number
-    of push iterations as the host-driven loop (which reads the count back like the reference) and as the oracle, for
-    thresholds that end the push phase after every possible iteration; enqueued, captured and replayed."""
+def test_sssp_pull_push_on_completion_records(gpu, name, zero):
+    """SSSP::pull_push (app/sssp.h:197-243): the loop's count comes from the SpMSpV's completion record (gl_spmspv_wait), read
+    behind the relax step.  The oracle's distances for thresholds that end the push phase after every possible iteration,
+    the push counts a plain re-statement of the loop condition gives, repeated calls on one object."""
     m = named_matrix(name)
     iters = 7
-    ref = O.sssp(_oracle_prepared(m, "sssp"), 0, iters, zero)
+    om = _oracle_prepared(m, "sssp")
+    ref = O.sssp(om, 0, iters, zero)
     sem = M.SemiringType(M.kAddMin, 0.0, zero)
-    dev = app.SSSP(M.num_hbm_channels, 1024, 512, 256, semiring=sem)
-    dev.set_up_runtime()
-    dev.load_and_format_matrix(m, True)
-    dev.send_matrix_host_to_device()
-    monkeypatch.setenv("GRAPHLILY_SSSP_DEVICE_LOOP", "1")      # (opt-in since round 4: the host-driven loop is the default)
-    assert dev._device_loop_ok()
-    monkeypatch.setenv("GRAPHLILY_SSSP_DEVICE_LOOP", "0")
-    host = app.SSSP(M.num_hbm_channels, 1024, 512, 256, semiring=sem)
-    host.set_up_runtime()
-    host.load_and_format_matrix(m, True)
-    host.send_matrix_host_to_device()
+    s = app.SSSP(M.num_hbm_channels, 1024, 512, 256, semiring=sem)
+    s.set_up_runtime()
+    s.load_and_format_matrix(m, True)
+    s.send_matrix_host_to_device()
+    push = app.SSSP(M.num_hbm_channels, 1024, 512, 256, semiring=sem)     # the same loop with the count copied back: SSSP.push
+    push.set_up_runtime()
+    push.load_and_format_matrix(m, True)
+    push.send_matrix_host_to_device()
     seen = set()
     for thr in (0.0, 1e-4, 1e-3, 1e-2, 0.05, 0.3, 2.0):
-        monkeypatch.setenv("GRAPHLILY_SSSP_DEVICE_LOOP", "0")
-        want = host.pull_push(0, iters, thr)
-        assert np.array_equal(want, ref)
-        monkeypatch.setenv("GRAPHLILY_SSSP_DEVICE_LOOP", "1")
         for rep in range(3):
-            got = dev.pull_push(0, iters, thr)
+            got = s.pull_push(0, iters, thr)
             assert np.array_equal(got, ref), (name, zero, thr, rep)
-            assert dev.push_iterations_ == host.push_iterations_, (thr, rep)
-        seen.add(host.push_iterations_)
+        seen.add(s.push_iterations_)
     assert len(seen) >= 3 and 1 in seen and (iters - 1) in seen, seen
-    # another iteration count on the same object (buffers regrow, graphs are rebuilt)
-    assert np.array_equal(dev.pull_push(0, 10, 0.01), O.sssp(_oracle_prepared(m, "sssp"), 0, 10, zero))
+    assert np.array_equal(push.push(0, iters), ref)
+    assert np.array_equal(s.pull_push(0, 10, 0.01), O.sssp(om, 0, 10, zero))
 
 
 def test_bfs_byte_read_back_equals_the_float_one(gpu, monkeypatch):
@@ -406,17 +388,17 @@ def test_bfs_byte_read_back_equals_the_float_one(gpu, monkeypatch):
     bfs.load_and_format_matrix(g, True)
     bfs.send_matrix_host_to_device()
     ref = O.bfs(to_oracle(m), src, 7)
-    for u8 in ("1", "0", "1"):
+    for u8 in ("2", "0", "1", "2"):      # packed pinned / floats / whichever measures faster / packed
         monkeypatch.setenv("GRAPHLILY_BFS_U8", u8)
-        for _ in range(3):
+        for _ in range(12 if u8 == "1" else 3):
             got = bfs.pull_push(src, 7, 0.01)
             assert got.dtype == np.float32 and np.array_equal(got, ref)
             assert np.array_equal(bfs.pull(src, 7), ref)
     # a line graph walked for 300 iterations: levels beyond a byte -- the float read-back serves them
-    n = 70016
+    n = 600064
     line = io.CSRMatrix(n, n, np.ones(n - 1, np.float32), np.arange(n - 1, dtype=np.uint32),
                         np.concatenate([[0], np.arange(n, dtype=np.uint32)]).astype(np.uint32))
-    monkeypatch.setenv("GRAPHLILY_BFS_U8", "1")
+    monkeypatch.setenv("GRAPHLILY_BFS_U8", "2")
     b2 = app.BFS(16, 0, 0, 0)
     b2.set_up_runtime()
     b2.load_and_format_matrix(line, True)

@@ -11,7 +11,7 @@ from graphlily_amd import app, capi, datasets, io
 from graphlily_amd.dist import EmulatedComm
 from oracle import oracle as O
 
-from helpers import to_oracle
+from helpers import to_oracle, set_knob
 
 pytestmark = pytest.mark.gpu
 
@@ -73,7 +73,7 @@ def test_every_rank_of_a_sharded_bfs_matches_the_oracle(gpu, name, world):
             # the rank's own tallies of every slot (gl_bfs_bits_shard_step: what it would have sent along with its rows of the
             # bit vector) are the host's sums over the whole run's vectors
             tab = b.bits_loop_["tally"].read(np.uint32)
-            truth_tab = getattr(b.comm, "truth_tally_host", None)      # (None: the suite runs with GRAPHLILY_BFS_SHARD_STEP=0)
+            truth_tab = getattr(b.comm, "truth_tally_host", None)
             H, R = capi.GL_BFS_TALLY_HEAD_WORDS, capi.GL_BFS_TALLY_RANK_WORDS
             for s in range(1, iters + 1) if truth_tab is not None else ():
                 blk = tab[H + ((s - 1) * world + k) * R:H + ((s - 1) * world + k + 1) * R].reshape(8, 8)
@@ -93,14 +93,14 @@ def test_every_rank_of_a_sharded_bfs_matches_the_oracle(gpu, name, world):
 
 def test_sharded_bfs_on_split_shard_plans(gpu, monkeypatch):
     """Shard plans cut into column segments (several units share a block's rows): the pull step claims rows with atomicOr."""
-    monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", "3")
+    set_knob(monkeypatch, "spmv_segments", "3")
     g = datasets.rmat(60000, 1500000, seed=33, symmetric=True)
     src = int(np.argmax(np.diff(g.adj_indptr.astype(np.int64)) > 0))
     ref = O.bfs(to_oracle(_prepared(g)), src, 7)
-    monkeypatch.delenv("GRAPHLILY_SPMV_SEGMENTS")
+    set_knob(monkeypatch, "spmv_segments", None)
     whole = _whole(g)
     assert np.array_equal(whole.pull(src, 7), ref)
-    monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", "3")
+    set_knob(monkeypatch, "spmv_segments", "3")
     for k in range(4):
         b = _rank(g, k, 4, whole)
         assert b.SpMV_.plan_.info()["segments"] > 1
@@ -111,52 +111,32 @@ def test_sharded_bfs_on_split_shard_plans(gpu, monkeypatch):
             assert np.array_equal(got, ref[r0:r1])
 
 
-def test_one_launch_and_deferred_decisions_equal_the_fused_ones(gpu, monkeypatch):
-    """The three ways a slot's decisions are taken give the same distances, push iterations (first phase and after a pull
-    handed back) and per-slot counts: fused into the two steps of a slot (one GPU, GRAPHLILY_BFS_ONE_LAUNCH=0), replayed
-    from the tallies at the start of the next slot's single launch (the default, one GPU and a world of one), and by
-    gl_bfs_bits_decide from the gathered bit vector (GRAPHLILY_BFS_SHARD_STEP=0)."""
+def test_a_world_of_one_equals_the_one_gpu_run(gpu):
+    """The same launches on one GPU and on a "shard" that is the whole matrix (a world of one, exchange stubbed): distances, push
+    iterations (first phase and after a pull handed back), per-slot counts and modes, for three thresholds; and the
+    reference's module-call loop (GRAPHLILY_BFS_HOST_LOOP) agrees on distances and the first push phase."""
+    import os
     g = datasets.rmat(80000, 2400000, seed=34, symmetric=True)
     src = int(np.argmax(np.diff(g.adj_indptr.astype(np.int64)) > 0))
     whole = _whole(g)
     for thr in (0.0005, 0.01, 0.2):
-        monkeypatch.setenv("GRAPHLILY_BFS_ONE_LAUNCH", "0")
         ref = whole.pull_push(src, 9, thr).copy()
         pushes, again, counts, modes = whole.push_iterations_, whole.push_iterations_again_, whole.bfs_slot_counts_.copy(), whole.bfs_slot_modes_.copy()
-        monkeypatch.delenv("GRAPHLILY_BFS_ONE_LAUNCH")
         for rep in range(3):                 # enqueued, captured, replayed
             got = whole.pull_push(src, 9, thr)
             assert np.array_equal(got, ref)
             assert (whole.push_iterations_, whole.push_iterations_again_) == (pushes, again)
             assert np.array_equal(whole.bfs_slot_counts_, counts) and np.array_equal(whole.bfs_slot_modes_, modes)
-        for shard_step in ("1", "0"):
-            monkeypatch.setenv("GRAPHLILY_BFS_SHARD_STEP", shard_step)
-            b = _rank(g, 0, 1, whole)
-            got = b.pull_push(src, 9, thr)
-            assert np.array_equal(got, ref)
-            assert (b.push_iterations_, b.push_iterations_again_) == (pushes, again)
-            assert np.array_equal(b.bfs_slot_counts_, counts)
-        monkeypatch.delenv("GRAPHLILY_BFS_SHARD_STEP")
-
-
-def test_three_launch_slots_still_serve_shards(gpu, monkeypatch):
-    """GRAPHLILY_BFS_SHARD_STEP=0: push step, pull step and gl_bfs_bits_decide on the gathered vector (the slot before the
-    one-launch step existed; what a caller without the tally exchange uses)."""
-    monkeypatch.setenv("GRAPHLILY_BFS_SHARD_STEP", "0")
-    g = datasets.rmat(60000, 1500000, seed=31, symmetric=True)
-    src = int(np.argmax(np.diff(g.adj_indptr.astype(np.int64)) > 0))
-    ref = O.bfs(to_oracle(_prepared(g)), src, 8)
-    whole = _whole(g)
-    for thr in (0.001, 0.05):
-        assert np.array_equal(whole.pull_push(src, 8, thr), ref)
-        for k in range(4):
-            b = _rank(g, k, 4, whole, copy=(k % 2 == 0))
-            for rep in range(3):
-                whole.pull_push(src, 8, thr)
-                got = b.pull_push(src, 8, thr)
-                r0, r1 = b.result_range_
-                assert np.array_equal(got, ref[r0:r1])
-                assert b.push_iterations_ == whole.push_iterations_
+        b = _rank(g, 0, 1, whole)
+        got = b.pull_push(src, 9, thr)
+        assert np.array_equal(got, ref)
+        assert (b.push_iterations_, b.push_iterations_again_) == (pushes, again)
+        assert np.array_equal(b.bfs_slot_counts_, counts)
+        os.environ["GRAPHLILY_BFS_HOST_LOOP"] = "1"
+        try:
+            assert np.array_equal(whole.pull_push(src, 9, thr), ref) and whole.push_iterations_ == pushes
+        finally:
+            del os.environ["GRAPHLILY_BFS_HOST_LOOP"]
 
 
 def test_shard_step_refuses_what_it_cannot_run(gpu):
@@ -188,11 +168,11 @@ def test_shard_step_refuses_what_it_cannot_run(gpu):
 def test_dense_frontiers_pushed_through_the_scatter_body(gpu, monkeypatch):
     """The scattering push of the one-launch slot where it normally never goes: frontiers of thousands of vertices whose
     columns all hold 129 ... 1023 entries (set aside for the whole workgroup; the list of 256 per workgroup overflows and the
-    wavefronts apply the rest themselves), never handed to the streaming pull (GRAPHLILY_BFS_HEAVY_DIV=0) nor to the
-    bottom-up scan (GRAPHLILY_BFS_BU_DIV=0), threshold above 1: every slot pushes.  One GPU and every rank of 2 and of 16
+    wavefronts apply the rest themselves), never handed to the streaming pull (GRAPHLILY_DEBUG bfs_heavy_div=0) nor to the
+    bottom-up scan (bfs_bu_div=0), threshold above 1: every slot pushes.  One GPU and every rank of 2 and of 16
     (16 ranks x 8 tally lines: the prologue's loop over more than 64 lines)."""
-    monkeypatch.setenv("GRAPHLILY_BFS_HEAVY_DIV", "0")
-    monkeypatch.setenv("GRAPHLILY_BFS_BU_DIV", "0")
+    set_knob(monkeypatch, "bfs_heavy_div", "0")
+    set_knob(monkeypatch, "bfs_bu_div", "0")
     g = datasets.uniform(20480, 200, seed=36)
     src = 5
     ref = O.bfs(to_oracle(_prepared(g)), src, 5)

@@ -155,7 +155,7 @@ def test_bench_self_launches_two_ranks(gpu):
 def test_bench_self_launches_eight_ranks(gpu):
     """The 8-rank launch the driver performs at round end, as far as one GPU goes: eight processes, eight row shards of the
     stand-in (scale 0.05), gloo with host-staged collectives, every rank on cuda:0.  The row-sharded SpMV step (uneven
-    nnz-balanced ranges), the device-resident sharded BFS schedule with its per-slot all-gather and gl_bfs_bits_decide, and
+    nnz-balanced ranges), the device-resident sharded BFS schedule with its per-slot all-gather (bits + tallies), and
     the max-over-ranks timing all run with world = 8."""
     import json
     import subprocess
@@ -205,7 +205,7 @@ def test_gl_dist_c_abi_single_rank(gpu):
     bx = capi.DeviceBuffer.from_host(x)
     d.all_gather_f32(bx, [0, n])
     bits = capi.DeviceBuffer.from_host(np.arange(n // 32, dtype=np.uint32))
-    d.all_gather_bits(bits, [0, n])
+    d.all_gather_bits_tally(bits, [0, n], None)
     capi.sync()
     assert np.array_equal(bx.read(np.float32, n), x)
     assert np.array_equal(bits.read(np.uint32, n // 32), np.arange(n // 32, dtype=np.uint32))
@@ -220,5 +220,5 @@ def test_gl_dist_c_abi_single_rank(gpu):
     assert total == 5 and got["index"][0] == 5 and got["val"][0] == 255.0
     assert np.array_equal(got[1:], local[1:6])
     with pytest.raises(capi.GraphLilyError):
-        d.all_gather_bits(bits, [0, 100, n]) if False else capi.Dist(0, 1, b"short")   # a unique id is 128 bytes
+        d.all_gather_bits_tally(bits, [0, 100, n], None) if False else capi.Dist(0, 1, b"short")   # a unique id is 128 bytes
     d.destroy()

@@ -12,7 +12,7 @@ import pytest
 from graphlily_amd import capi, datasets, io
 from oracle import oracle as O
 
-from helpers import named_matrix, to_oracle
+from helpers import named_matrix, to_oracle, set_knob
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -89,13 +89,13 @@ def test_device_formatter_matches_host_on_shards_and_split_plans(gpu, kind, monk
     for r0, r1 in ((0, n // 2), (n // 2, n), (n // 4 // 64 * 64, n // 4 // 64 * 64 + 4096), (0, 0)):
         a, b = _both(m, flags, r0, r1, data=data)
         _assert_same_layout(a, b, "%s shard [%d,%d)" % (kind, r0, r1))
-    monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", "16")
-    monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", "5")
+    set_knob(monkeypatch, "spmv_blocks", "16")
+    set_knob(monkeypatch, "spmv_segments", "5")
     a, b = _both(m, flags, data=data)
     info = _assert_same_layout(a, b, kind + " split 16 x 5")
     assert info["segments"] > 1
-    monkeypatch.setenv("GRAPHLILY_SPMV_COMPACT", "0")
-    monkeypatch.setenv("GRAPHLILY_SPMV_HOT", "0")
+    set_knob(monkeypatch, "spmv_compact", "0")
+    set_knob(monkeypatch, "spmv_hot", "0")
     a, b = _both(m, flags, data=data)
     _assert_same_layout(a, b, kind + " split, no hot table, no packed gather vector")
 

@@ -12,7 +12,7 @@ import pytest
 from graphlily_amd import datasets, io, module as M
 from oracle import oracle as O
 
-from helpers import MASKS, SEMIRINGS, assert_parity, named_matrix, rand01, to_oracle
+from helpers import MASKS, SEMIRINGS, assert_parity, named_matrix, rand01, to_oracle, set_knob
 
 pytestmark = pytest.mark.gpu
 
@@ -168,8 +168,8 @@ def test_direction_switch_inside_the_operator(gpu, shape, monkeypatch):
     than 1/32 of the non-zeros goes row-wise (frontier -> bits -> boolean SpMV -> compaction) instead of being
     scattered.  Both directions must give the oracle's result for every mask; zero-valued frontier entries
     and zero-valued matrix entries take part in neither."""
-    monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
-    monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+    set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
+    set_knob(monkeypatch, "spmv_segments", str(shape[1]))
     csr = named_matrix("rmat_sym_50K")
     rng = np.random.default_rng(3)
     csr.adj_data = rng.choice(np.array([1.0, 1.0, 0.0, 2.5], np.float32), size=csr.nnz)
@@ -372,7 +372,7 @@ def test_many_long_columns_fill_the_chunk_queue(gpu, sem):
 @pytest.mark.parametrize("sem", list(SEMIRINGS))
 @pytest.mark.parametrize("mask_name", list(MASKS))
 def test_tiny_runs_are_one_launch_with_the_same_result(gpu, sem, mask_name, monkeypatch):
-    """gl_spmspv_plan_hint_tiny: a module that has just uploaded a vector of <= 1024 entries whose columns hold <= 2048
+    """gl_spmspv_plan_hint_work: a module that has just uploaded a vector of <= 1024 entries whose columns hold <= 2048
     non-zeros runs it as ONE launch (scatter with first-touch detection, sort of the rows reached, ordered emission).  The
     result list must be the general path's, entry for entry ((+,x): same rows, values within the float tolerance -- atomics
     add in arrival order either way), and the oracle's; repeated runs keep the hint, another module's write drops it."""
@@ -392,7 +392,7 @@ def test_tiny_runs_are_one_launch_with_the_same_result(gpu, sem, mask_name, monk
         v = M.make_sparse_vec(cols.astype(np.uint32), vals)
         out = {}
         for tiny in ("1", "0"):
-            monkeypatch.setenv("GRAPHLILY_SPMSPV_TINY", tiny)
+            set_knob(monkeypatch, "spmspv_tiny", tiny)
             got, mod = _run(gpu, csc, sem, mask_name, v, mask)
             res1 = mod.send_results_device_to_host()
             mod.run()                                             # the hint survives the module's own runs
@@ -413,12 +413,12 @@ def test_tiny_runs_are_one_launch_with_the_same_result(gpu, sem, mask_name, monk
         ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS[mask_name])
         assert_parity(g1, ref, op, "tiny %s/%s/%s" % (sem, mask_name, name))
     # a stale hint: the plan is told "tiny", the vector is not -- the one workgroup still computes it (slowly)
-    monkeypatch.setenv("GRAPHLILY_SPMSPV_TINY", "1")
+    set_knob(monkeypatch, "spmspv_tiny", "1")
     cols = np.sort(rng.choice(order[coldeg[order] > 0], 3000, replace=False))
     v = M.make_sparse_vec(cols.astype(np.uint32), np.full(len(cols), 0.5, np.float32))
     got, mod = _run(gpu, csc, sem, mask_name, v, mask)            # general path (3000 entries: no hint from the module)
     ref_res = mod.send_results_device_to_host()
-    mod.plan_.hint_tiny(10, 100)
+    mod.plan_.hint_work(10, 100, 50)
     mod.run()
     res = mod.send_results_device_to_host()
     n = int(res["index"][0])
@@ -434,7 +434,7 @@ def test_work_hint_never_changes_the_result(gpu, sem, monkeypatch):
     """gl_spmspv_plan_hint_work: a module that uploaded the vector from the host tells the plan the non-zeros of its columns
     and the longest of them; light vectors then skip the direction switch's decision kernels and, without a long column, the
     chunk-queue pass.  With the switch attached (enable_own_pull), for light, long-column and heavy (row-wise) vectors: the
-    hinted run, the unhinted run (GRAPHLILY_SPMSPV_WORK_HINT=0) and the oracle agree; and a STALE hint -- "light, no long
+    hinted run, the unhinted run (GRAPHLILY_DEBUG spmspv_work_hint=0) and the oracle agree; and a STALE hint -- "light, no long
     column" for a vector that is heavy and names the hubs -- only costs time."""
     csc = _csc("rmat_20K")
     op, zero = SEMIRINGS[sem]
@@ -448,7 +448,7 @@ def test_work_hint_never_changes_the_result(gpu, sem, monkeypatch):
     mask = rand01(csc.num_rows, 12)
     mods = {}
     for hint in ("1", "0"):
-        monkeypatch.setenv("GRAPHLILY_SPMSPV_WORK_HINT", hint)
+        set_knob(monkeypatch, "spmspv_work_hint", hint)
         mod = M.SpMSpVModule(512)
         mod.set_semiring(M.SemiringType(op, 1.0, zero))
         mod.set_mask_type(MASKS["WriteToZero"])
@@ -464,7 +464,7 @@ def test_work_hint_never_changes_the_result(gpu, sem, monkeypatch):
         ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS["WriteToZero"])
         dirs = {}
         for hint in ("1", "0"):
-            monkeypatch.setenv("GRAPHLILY_SPMSPV_WORK_HINT", hint)
+            set_knob(monkeypatch, "spmspv_work_hint", hint)
             mod = mods[hint]
             mod.send_vector_host_to_device(v)
             for rep in range(2):                       # (the module repeats the hint while the vector is its own upload)
@@ -476,7 +476,7 @@ def test_work_hint_never_changes_the_result(gpu, sem, monkeypatch):
         if name == "heavy":
             assert dirs["1"] == "row-wise"
     # stale: the plan is told "300 entries, 900 non-zeros, longest column 5" and finds the heavy vector with the hubs in it
-    monkeypatch.setenv("GRAPHLILY_SPMSPV_WORK_HINT", "1")
+    set_knob(monkeypatch, "spmspv_work_hint", "1")
     cols = np.union1d(picks["heavy"], picks["hubs"])
     v = M.make_sparse_vec(cols.astype(np.uint32), np.full(len(cols), 0.5, np.float32))
     ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS["WriteToZero"])
@@ -535,12 +535,12 @@ def _random_csc(n, avg, seed, hub=None):
 @pytest.mark.parametrize("sem", ["Arithmetic", "Logical", "Tropical"])
 @pytest.mark.parametrize("tile_rows,n", [(64, 40000), (64, 200000), (192, 40000)])
 def test_many_row_tiles(gpu, sem, tile_rows, n, monkeypatch):
-    """Tiles forced small (GRAPHLILY_SPMSPV_TILE_ROWS, read at plan creation): 625 tiles -- more than compute units, so the fold
+    """Tiles forced small (GRAPHLILY_DEBUG spmspv_tile_rows, read at plan creation): 625 tiles -- more than compute units, so the fold
     hands them out by ticket and looks back over more tiles than one wavefront pass --, 3125 tiles -- more than the bin kernel
     has counters for, so every product goes through the dense accumulator and the fold merges it --, and a tile height that is
     not a power of two (row -> tile by multiplication).  Vectors: a few hundred entries (every workgroup cuts the products
     itself) and tens of thousands (the rendezvous)."""
-    monkeypatch.setenv("GRAPHLILY_SPMSPV_TILE_ROWS", str(tile_rows))
+    set_knob(monkeypatch, "spmspv_tile_rows", str(tile_rows))
     csc = _random_csc(n, 6, 5, hub=(3, 5000))
     op, zero = SEMIRINGS[sem]
     mask = rand01(n, 3)
@@ -607,7 +607,7 @@ def test_duplicates_beyond_32_bits_of_products(gpu):
 
 def test_wait_returns_the_count_without_a_copy(gpu):
     """gl_spmspv_wait: the operator's own completion record.  A non-blocking run, then wait(): the count equals the head
-    element; a gated run keeps no record (wait() is gl_sync and says so)."""
+    element; a run recorded into a graph keeps no record (wait() is gl_sync and says so)."""
     from graphlily_amd import capi
     csc = _random_csc(30000, 8, 21)
     op, zero = SEMIRINGS["Arithmetic"]
@@ -627,7 +627,12 @@ def test_wait_returns_the_count_without_a_copy(gpu):
             n = mod.plan_.wait()
             assert n is not None and n == int(mod.send_results_device_to_host()["index"][0]) and n > 0
             assert mod.get_results_nnz() == n
-    gate = capi.DeviceBuffer.from_host(np.array([1, 0, 0, 0], np.uint32))
-    mod.run_gated(mod.vector_buf, mod.results_buf, None, 0.0, None, gate, 1, capi.GL_GATE_EQ)
+    # a run recorded into a graph keeps no record: wait() is gl_sync and says so; the replay computes the same list
+    want = mod.send_results_device_to_host().copy()
+    with capi.Graph.capture() as g:
+        mod.run()
+    g.launch()
     assert mod.plan_.wait() is None
-    capi.sync()
+    assert np.array_equal(mod.send_results_device_to_host(), want)
+    mod.run()                                  # and an eager run after the replay reports again
+    assert mod.plan_.wait() == int(want["index"][0])

@@ -12,7 +12,7 @@ import pytest
 from graphlily_amd import datasets, io, module as M
 from oracle import oracle as O
 
-from helpers import (MASKS, SEMIRINGS, arith_exact, assert_arith_parity, assert_parity, rand01, spmv_prepare,
+from helpers import (MASKS, SEMIRINGS, arith_exact, assert_arith_parity, assert_parity, rand01, set_knob, spmv_prepare,
                      to_oracle)
 
 pytestmark = pytest.mark.gpu
@@ -98,8 +98,8 @@ def test_float_values_random(gpu):
 def test_decompositions(gpu, blocks, segments, monkeypatch):
     """The planner's (row blocks x column segments) choice only changes the work decomposition -- and,
     for segments > 1, switches the epilogue from direct stores to init + atomic folds -- never results."""
-    monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(blocks))
-    monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(segments))
+    set_knob(monkeypatch, "spmv_blocks", str(blocks))
+    set_knob(monkeypatch, "spmv_segments", str(segments))
     m = spmv_prepare("rmat_20K")
     x, mask = rand01(m.num_cols, 7), rand01(m.num_rows, 8)
     for sem in ("Logical", "Tropical", "Arithmetic"):
@@ -112,43 +112,43 @@ def test_decompositions(gpu, blocks, segments, monkeypatch):
 def test_hot_column_cache_variants(gpu, hot, mix, monkeypatch):
     """The LDS-cached hot columns and the cold/hot interleave are pure work re-arrangements: any table
     size (0 = disabled) and any interleave must reproduce the same results, with and without segments."""
-    monkeypatch.setenv("GRAPHLILY_SPMV_HOT", hot)
-    monkeypatch.setenv("GRAPHLILY_SPMV_MIX", mix)
+    set_knob(monkeypatch, "spmv_hot", hot)
+    set_knob(monkeypatch, "spmv_mix", mix)
     m = spmv_prepare("rmat_sym_50K")
     x, mask = rand01(m.num_cols, 11), rand01(m.num_rows, 12)
     for shape in ((0, 0), (5, 3)):
-        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
-        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
+        set_knob(monkeypatch, "spmv_segments", str(shape[1]))
         for sem in ("Arithmetic", "Logical", "Tropical"):
             got = _run_spmv(gpu, m, sem, "WriteToOne", x, mask)
             _check(got, m, sem, "WriteToOne", x, mask, "hot %s mix %s shape %s %s" % (hot, mix, shape, sem))
 
 
 def test_pattern_pair_layout_fallback(gpu, monkeypatch):
-    """GRAPHLILY_SPMV_PAT4=0 keeps two pattern groups per 8-byte load instead of four per 16-byte load."""
-    monkeypatch.setenv("GRAPHLILY_SPMV_PAT4", "0")
+    """GRAPHLILY_DEBUG spmv_pat4=0 keeps two pattern groups per 8-byte load instead of four per 16-byte load."""
+    set_knob(monkeypatch, "spmv_pat4", "0")
     m = spmv_prepare("rmat_sym_50K")
     m.adj_data = np.full(m.nnz, np.float32(0.5), np.float32)
     x, mask = rand01(m.num_cols, 8), rand01(m.num_rows, 9)
     for shape in ((0, 0), (5, 2)):
-        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
-        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
+        set_knob(monkeypatch, "spmv_segments", str(shape[1]))
         for sem in ("Arithmetic", "Tropical"):
             got = _run_spmv(gpu, m, sem, "WriteToOne", x, mask)
             _check(got, m, sem, "WriteToOne", x, mask, "pattern pairs %s %s" % (shape, sem))
 
 
 def test_narrow_general_layout(gpu, monkeypatch):
-    """GRAPHLILY_SPMV_WIDE=0 keeps the 8-byte-per-lane stream (one group per load) -- the fallback of the default
+    """GRAPHLILY_DEBUG spmv_wide=0 keeps the 8-byte-per-lane stream (one group per load) -- the fallback of the default
     lane-interleaved group pairs; same results."""
-    monkeypatch.setenv("GRAPHLILY_SPMV_WIDE", "0")
+    set_knob(monkeypatch, "spmv_wide", "0")
     m = spmv_prepare("rmat_sym_50K")
     rng = np.random.default_rng(31)
     m.adj_data = rng.random(m.nnz, dtype=np.float32)
     x, mask = rng.random(m.num_cols, dtype=np.float32), rand01(m.num_rows, 4)
     for shape in ((0, 0), (3, 4)):
-        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
-        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
+        set_knob(monkeypatch, "spmv_segments", str(shape[1]))
         for sem in ("Arithmetic", "Tropical"):
             got = _run_spmv(gpu, m, sem, "WriteToZero", x, mask)
             _check(got, m, sem, "WriteToZero", x, mask, "narrow %s %s" % (shape, sem))
@@ -188,23 +188,16 @@ def test_wide_column_jumps(gpu):
         _check(got, m, sem, "NoMask", x, None, "wide jumps " + sem)
 
 
-def test_tall_matrix_many_blocks(gpu):
+def test_tall_matrix_many_blocks(gpu, monkeypatch):
     """More rows than 256 full-height blocks can hold is not needed to hit the row cap: force it."""
     m = spmv_prepare("uniform_10K_10")
     x, mask = rand01(m.num_cols, 1), rand01(m.num_rows, 2)
-    import os
-    os.environ["GRAPHLILY_SPMV_BLOCKS"] = "1"      # one planned block, but 10112 rows fit; fine
-    try:
-        got = _run_spmv(gpu, m, "Arithmetic", "WriteToOne", x, mask)
-    finally:
-        del os.environ["GRAPHLILY_SPMV_BLOCKS"]
+    set_knob(monkeypatch, "spmv_blocks", 1)      # one planned block, but 10112 rows fit; fine
+    got = _run_spmv(gpu, m, "Arithmetic", "WriteToOne", x, mask)
     _check(got, m, "Arithmetic", "WriteToOne", x, mask, "single block")
     big = datasets.uniform(40000, 3, seed=2)        # 40000 rows > 16383: the row cap must split blocks
-    os.environ["GRAPHLILY_SPMV_BLOCKS"] = "1"
-    try:
-        got = _run_spmv(gpu, big, "Tropical", "NoMask", rand01(big.num_cols, 5), rand01(big.num_rows, 6))
-    finally:
-        del os.environ["GRAPHLILY_SPMV_BLOCKS"]
+    got = _run_spmv(gpu, big, "Tropical", "NoMask", rand01(big.num_cols, 5), rand01(big.num_rows, 6))
+    set_knob(monkeypatch, "spmv_blocks", None)
     assert_parity(got, _ref_spmv(big, "Tropical", "NoMask", rand01(big.num_cols, 5), None), 2, "row cap")
 
 
@@ -240,13 +233,13 @@ def test_boolean_plan_phases_and_odd_values(gpu, monkeypatch):
     x = rng.choice(np.array([0.0, 0.0, 0.0, 1.0, -0.0, np.nan, -2.0], np.float32), size=n_cols)
     mask = rand01(n_rows, 4)
     for shape in ((0, 0), (3, 4)):
-        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
-        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
+        set_knob(monkeypatch, "spmv_segments", str(shape[1]))
         for mk in MASKS:
             got = _run_spmv(gpu, m, "Logical", mk, x, mask)
             assert_parity(got, _ref_spmv(m, "Logical", mk, x, mask), 1, "boolean plan %s %s" % (shape, mk))
-    monkeypatch.delenv("GRAPHLILY_SPMV_BLOCKS")
-    monkeypatch.delenv("GRAPHLILY_SPMV_SEGMENTS")
+    set_knob(monkeypatch, "spmv_blocks", None)
+    set_knob(monkeypatch, "spmv_segments", None)
     # the same through the C ABI: layout is boolean, zero = 1 turns every allowed row on, (+,x) is refused
     plan = capi.SpMVPlan(n_rows, n_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=capi.GL_PLAN_BOOLEAN)
     dx, dm, dy = capi.DeviceBuffer(4 * n_cols), capi.DeviceBuffer(4 * n_rows), capi.DeviceBuffer(4 * n_rows)
@@ -302,8 +295,8 @@ def test_pattern_plan_matches_general_layout(gpu, kind, monkeypatch):
     dx.write(x)
     dm.write(mask)
     for shape in ((0, 0), (6, 3)):
-        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
-        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
+        set_knob(monkeypatch, "spmv_segments", str(shape[1]))
         pat = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data)
         gen = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=capi.GL_PLAN_KEEP_VALUES)
         assert pat.info()["layout"] == "pattern" and gen.info()["layout"] == "general"
@@ -383,7 +376,7 @@ def test_golden_known_answers(gpu, golden_dir):
 @pytest.mark.parametrize("keep_values", [True, False])
 def test_packed_gather_vector_changes_nothing(gpu, keep_values, monkeypatch):
     """The cold entries gather from a packed copy of x (never-gathered columns dropped, the rest in degree-class
-    order, refilled per run); GRAPHLILY_SPMV_COMPACT=0 gathers from x itself, =2 packs without classes.  The
+    order, refilled per run); GRAPHLILY_DEBUG spmv_compact=0 gathers from x itself, =2 packs without classes.  The
     products and their order per row are the same, so all three must agree bit for bit for (min,+) / (||,&&) and
     to accumulation-order tolerance for (+,x), on unsplit and split plans, with half of the columns empty."""
     from graphlily_amd import capi
@@ -400,11 +393,11 @@ def test_packed_gather_vector_changes_nothing(gpu, keep_values, monkeypatch):
     dm.write(mask)
     flags = capi.GL_PLAN_KEEP_VALUES if keep_values else 0
     for shape in ((0, 0), (5, 3)):
-        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
-        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
+        set_knob(monkeypatch, "spmv_segments", str(shape[1]))
         outs = {}
         for mode in ("1", "0", "2"):
-            monkeypatch.setenv("GRAPHLILY_SPMV_COMPACT", mode)
+            set_knob(monkeypatch, "spmv_compact", mode)
             plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=flags)
             assert plan.info()["layout"] == ("general" if keep_values else "pattern")
             for sem, (op, zero) in SEMIRINGS.items():
@@ -425,7 +418,7 @@ def test_packed_gather_vector_changes_nothing(gpu, keep_values, monkeypatch):
 @pytest.mark.parametrize("keep_values", [True, False])
 def test_helper_modes_agree(gpu, keep_values, monkeypatch):
     """How a plan refills its hot table / packed gather vector per run -- gathering helper kernel, one streaming pass
-    over x, or (general layout, small hot table) no helper launch at all -- is chosen per plan (GRAPHLILY_SPMV_HELPER
+    over x, or (general layout, small hot table) no helper launch at all -- is chosen per plan (GRAPHLILY_DEBUG spmv_helper
     forces it).  The three produce the same vectors, so every semiring x mask must agree bit for bit between them and
     match the oracle, on unsplit and split plans."""
     from graphlily_amd import capi
@@ -439,14 +432,14 @@ def test_helper_modes_agree(gpu, keep_values, monkeypatch):
     dx.write(x)
     dm.write(mask)
     flags = capi.GL_PLAN_KEEP_VALUES if keep_values else 0
-    monkeypatch.setenv("GRAPHLILY_SPMV_HOT", "2048")     # a table small enough for the self-hot mode
+    set_knob(monkeypatch, "spmv_hot", "2048")     # a table small enough for the self-hot mode
     seen = set()
     for shape in ((0, 0), (5, 3)):
-        monkeypatch.setenv("GRAPHLILY_SPMV_BLOCKS", str(shape[0]))
-        monkeypatch.setenv("GRAPHLILY_SPMV_SEGMENTS", str(shape[1]))
+        set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
+        set_knob(monkeypatch, "spmv_segments", str(shape[1]))
         outs = {}
         for mode in ("0", "1", "2"):
-            monkeypatch.setenv("GRAPHLILY_SPMV_HELPER", mode)
+            set_knob(monkeypatch, "spmv_helper", mode)
             plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=flags)
             info = plan.info()
             seen.add((info["helper"], info["packed_columns"] > 0))

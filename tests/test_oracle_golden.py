@@ -174,7 +174,7 @@ def test_sssp_preprocess_matches_literal_replay(seed):
 # ---------------------------------------------------------------- product host formatters vs oracle
 @pytest.mark.parametrize("gen", ["uniform", "rmat", "rmat_2M"])
 def test_product_formatters_match_oracle(gen):
-    if gen == "rmat_2M":      # > 1 Mi non-zeros: the multi-threaded path of gl_host_csr2csc
+    if gen == "rmat_2M":      # > 1 Mi non-zeros: the multi-threaded path of gl_csr2csc
         m = datasets.rmat(100000, 2200000, seed=8)
     else:
         m = datasets.uniform(500, 7, seed=3) if gen == "uniform" else datasets.rmat(3000, 40000, seed=5)
