@@ -36,6 +36,7 @@ constexpr uint32_t kBinItems = 8;                          // products per threa
 constexpr uint32_t kBinBatch = kBinThreads * kBinItems;    // 8192 products are sorted by tile at a time
 constexpr uint32_t kBinMaxTiles = 2048;                    // LDS counters of the bin kernel
 constexpr uint32_t kBinSlice = 1024;                       // vector entries a workgroup stages at a time
+constexpr uint32_t kBinLocalWindows = 4;                     // vectors of up to 4 x 1024 entries need no rendezvous
 constexpr uint32_t kBinMaxSlices = 2048;                   // slices of the vector per rendezvous (two per thread)
 constexpr uint32_t kFoldThreads = 1024;
 constexpr uint32_t kFoldMaxRows = 16384;                   // rows per tile: 128 KB of 8-byte accumulators
@@ -397,6 +398,46 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
     // the products itself -- the rendezvous below (slice sums out, everybody's sums in: ~8 us of a 13 us launch) is not needed
     if (vnnz <= kBinSlice && (unsigned long long)vnnz * a.max_col_len <= 0xfffffffeull) {
         if (vnnz) (void)bin_window<OP>(a, L, a.vec + 1u, vnnz, 0ull, 0ull, 0ull, G);
+        return;
+    }
+    // up to four windows of 1024 entries: still no rendezvous -- every workgroup adds up the column lengths of ALL entries itself
+    // (four entries per thread, one round of loads), cuts the products, and stages only the windows its range touches
+    if (vnnz <= kBinLocalWindows * kBinSlice && (unsigned long long)vnnz * a.max_col_len <= 0xfffffffeull) {
+        uint32_t deg[kBinLocalWindows];
+#pragma unroll
+        for (uint32_t w = 0; w < kBinLocalWindows; w++) {
+            const uint32_t e = w * kBinSlice + tid;
+            uint32_t col = 0xffffffffu;
+            if (e < vnnz) col = a.vec[1u + e].index;
+            deg[w] = col < a.num_cols ? a.indptr[col + 1u] - a.indptr[col] : 0u;
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < kBinLocalWindows; w++) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) deg[w] += __shfl_down(deg[w], d);
+            if ((tid & 63u) == 0u) L.tab[(tid >> 6) * kBinLocalWindows + w] = deg[w];     // (tab: 16 x 4 words here)
+        }
+        __syncthreads();
+        uint32_t tot[kBinLocalWindows], P = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kBinLocalWindows; w++) {
+            tot[w] = 0u;
+            for (uint32_t k = 0; k < kBinThreads / 64u; k++) tot[w] += L.tab[k * kBinLocalWindows + w];
+            P += tot[w];
+        }
+        __syncthreads();
+        const uint32_t Q = (max((P + G - 1u) / G, 2048u) + 63u) & ~63u;
+        const unsigned long long lo = (unsigned long long)blk * Q, hi = min(lo + Q, (unsigned long long)P);
+        if (lo >= P) return;
+        unsigned long long cur = 0ull;
+#pragma unroll
+        for (uint32_t w = 0; w < kBinLocalWindows; w++) {
+            if (w * kBinSlice < vnnz && cur + tot[w] > lo && cur < hi) {      // block-uniform
+                (void)bin_window<OP>(a, L, a.vec + 1u + w * kBinSlice, min(kBinSlice, vnnz - w * kBinSlice), cur, lo, hi, 0u);
+                __syncthreads();
+            }
+            cur += tot[w];
+        }
         return;
     }
     const uint32_t gen0 = a.sync[kSyncGen];

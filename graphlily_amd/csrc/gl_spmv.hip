@@ -66,7 +66,7 @@ struct SpmvArgs {
     float *partials;          // [segment][row - row_begin] per-unit tiles of split blocks (combined by spmv_combine_kernel)
     uint32_t prow;            // rows per segment plane
     uint32_t row_begin;
-    uint32_t tickets;         // 1: wavefronts draw iterations from the LDS ticket; 0: static split (GRAPHLILY_SPMV_TICKETS=0)
+    uint32_t tickets;         // 1: wavefronts draw iterations from the LDS ticket; 0: static split (A/B builds)
     const uint32_t *self_hot_cols;   // non-null: no helper launch ran -- every workgroup gathers its (small) hot table from x itself
 };
 
@@ -118,10 +118,10 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
 // One kernel body serves the four stream layouts; a layout says what one lane reads per load instruction
 // (8 or 16 bytes), how many consecutive 64-entry groups that read covers (stored lane-interleaved: lane L's
 // element holds entry L of each of the G groups) and whether values travel with the indices.
-//   NARROW  8 B: { index, value }                        1 group   (GRAPHLILY_SPMV_WIDE=0)
+//   NARROW  8 B: { index, value }                        1 group   (GRAPHLILY_DEBUG spmv_wide=0)
 //   WIDE   16 B: { A.index, A.value, B.index, B.value }  2 groups  (default general layout; scripts/ubench_mix:
 //                                                        half as many stream instructions per byte, -5 %)
-//   PAIR    8 B: { A.index, B.index }                    2 groups  (pattern plans, GRAPHLILY_SPMV_PAT4=0)
+//   PAIR    8 B: { A.index, B.index }                    2 groups  (pattern plans, GRAPHLILY_DEBUG spmv_pat4=0)
 //   QUAD   16 B: { A.index .. D.index }                  4 groups  (default pattern layout)
 // index = (col - group_base) << 14 | slot.  Pattern plans (every column's stored values are equal) fold the
 // value into z[c] = colval[c] (x) x[c] once per run (spmv_prescale_kernel) and gather z instead of x.
@@ -722,7 +722,7 @@ BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin,
     // Balance: the launch ends with its slowest unit, so the cuts minimise the LARGEST block (binary search on its size,
     // greedy fill) instead of tracking cumulative targets -- with whole-row cuts a block next to a hub row used to end up
     // several per cent over the mean (orkut stand-in: 765 K .. 888 K entries per block around a mean of 827 K, and the
-    // 888 K unit finished 28 us after the average one in a 313 us launch).  GRAPHLILY_SPMV_BALANCE=0: cumulative targets.
+    // 888 K unit finished 28 us after the average one in a 313 us launch).  GRAPHLILY_DEBUG spmv_balance=0: cumulative targets.
     if (nnz > 0 && debug_knob("spmv_balance", 1) != 0 && shape.blocks > 1) {
         // blocks needed when no block may hold more than `cap` entries (a single longer row gets a block of its own)
         auto cut = [&](uint64_t cap, std::vector<uint32_t> *out) -> uint32_t {

@@ -33,7 +33,7 @@ struct BoolArgs {
     uint32_t *bits_out;
     float *dist;
     float level;
-    uint32_t tickets;          // 1: ring slots are refilled from an LDS ticket per span; 0: static split (GRAPHLILY_SPMV_TICKETS=0)
+    uint32_t tickets;          // 1: ring slots are refilled from an LDS ticket per span; 0: static split (A/B builds)
     const uint32_t *gate = nullptr;   // non-null: the launch is a no-op unless gate[0] (gate_op) gate_value (gl_bfs_pull_step_gated)
     uint32_t gate_value = 0;
     int gate_op = GL_GATE_EQ;

@@ -132,10 +132,12 @@ def rmat_torch(n, nnz, seed, symmetric, device):
 EXTRA_GRAPHS = {
     "orkut_community":    dict(n=3_072_441, nnz=213_000_000, seed=16, symmetric=True, iters=6, kind="community"),
     "products_community": dict(n=2_449_029, nnz=124_000_000, seed=15, symmetric=True, iters=23, kind="community"),
+    # the SAME graph with its vertices relabelled at random: what the community numbering is worth to a layout
+    "orkut_community_shuffled": dict(n=3_072_441, nnz=213_000_000, seed=16, symmetric=True, iters=6, kind="community", shuffle=True),
 }
 
 
-def community_torch(n, nnz, seed, symmetric, device, p_in=0.8, mean_size=2048):
+def community_torch(n, nnz, seed, symmetric, device, p_in=0.8, mean_size=2048, shuffle=False):
     """Degree-corrected stochastic block model: vertex weights from a power law (Pareto, exponent 2.2, capped), communities of
     geometrically spread sizes around `mean_size` numbered CONTIGUOUSLY (vertex ids follow the communities, as crawl order or
     a clustering pass leaves them), every edge picks its first endpoint by weight and its second one, with probability p_in,
@@ -169,6 +171,9 @@ def community_torch(n, nnz, seed, symmetric, device, p_in=0.8, mean_size=2048):
     del inside, c, lo, hi, r, u
     keep = src != dst
     src, dst = src[keep], dst[keep]
+    if shuffle:
+        perm = torch.randperm(n, generator=g, device=device)
+        src, dst = perm[src], perm[dst]
     if symmetric:
         src, dst = torch.cat([src, dst]), torch.cat([dst, src])
     key = torch.unique(src * n + dst)
@@ -188,7 +193,7 @@ def paper_graph(name, scale=1.0, device=None):
     n = max(128, int(g["n"] * scale))
     nnz = max(1024, int(g["nnz"] * scale))
     if g.get("kind") == "community":
-        return community_torch(n, nnz, g["seed"], g["symmetric"], device)
+        return community_torch(n, nnz, g["seed"], g["symmetric"], device, shuffle=bool(g.get("shuffle")))
     if device is not None:
         return rmat_torch(n, nnz, g["seed"], g["symmetric"], device)
     return rmat(n, nnz, g["seed"], g["symmetric"])

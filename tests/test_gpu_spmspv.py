@@ -545,7 +545,7 @@ def test_many_row_tiles(gpu, sem, tile_rows, n, monkeypatch):
     op, zero = SEMIRINGS[sem]
     mask = rand01(n, 3)
     rng = np.random.default_rng(11)
-    for cnt in (300, n // 3):
+    for cnt in (300, 3000, n // 3):
         cols = np.sort(rng.choice(n, size=cnt, replace=False)).astype(np.uint32)
         v = M.make_sparse_vec(cols, rng.integers(1, 4, size=cnt).astype(np.float32))
         for mask_name in ("NoMask", "WriteToZero"):
@@ -619,7 +619,7 @@ def test_wait_returns_the_count_without_a_copy(gpu):
     mod.load_and_format_matrix(csc)
     mod.send_matrix_host_to_device()
     mod.blocking = False
-    for cnt in (5, 700, 9000):       # one launch of one workgroup / every workgroup cuts the products itself / the rendezvous
+    for cnt in (5, 700, 2500, 9000):     # one workgroup / one window / three windows (no rendezvous) / the rendezvous
         cols = np.sort(rng.choice(30000, size=cnt, replace=False)).astype(np.uint32)
         mod.send_vector_host_to_device(M.make_sparse_vec(cols, np.ones(cnt, np.float32)))
         for _ in range(3):
