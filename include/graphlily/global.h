@@ -286,6 +286,12 @@ public:
     bool owed() const { return impl_ && (bool)impl_->on_access; }
     void owe(std::function<void()> f) const { if (impl_) impl_->on_access = std::move(f); }
     void settle_quietly() const { if (impl_) impl_->on_access = nullptr; }
+    // exchange the device blocks of two buffers of equal size: every handle of `this` then names what `o`'s handles named and
+    // vice versa (module/fusion.h: results -> vector "copies" of the pull loops become a swap)
+    void swap_storage(const DeviceBuffer &o) const {
+        assert(impl_ && o.impl_ && impl_->bytes == o.impl_->bytes);
+        std::swap(impl_->ptr, o.impl_->ptr);
+    }
     std::function<void()> take_debt() const {
         std::function<void()> f;
         if (impl_) f.swap(impl_->on_access);

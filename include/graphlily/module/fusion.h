@@ -18,6 +18,16 @@
 //    OWED: whoever touches one of them through DeviceBuffer::ptr() (a download, another module, the next non-matching call)
 //    first has them written from the bits (gl_unpack_bits), so every observable value is the unfused sequence's.  Any other
 //    call sequence simply runs the deferred calls as they are.  GRAPHLILY_MODULE_FUSION=0 switches it off.
+//
+// 3. The pull loops of SSSP and PageRank.  The reference's drivers express an iteration as two module calls:
+//        SpMV->run()                 no mask:                         results = A x          (app/sssp.h:160-163, app/pagerank.h:85-87)
+//        eWiseAdd->run(n, val)       in = results, out = vector:       vector = results + val (val = 0: a copy; PageRank: the teleport term)
+//    On non-blocking modules the first is deferred; when the second arrives with exactly those bindings the SpMV runs with
+//    `val` folded into its epilogue -- zero + sum + val is computed as (val) + sum, which is the same float when zero is 0 (the
+//    only case taken for val != 0); for val == 0 nothing changes -- and the two buffers SWAP their device blocks instead of
+//    being copied: `vector` holds what the copy would have left, 8 n bytes and one launch less per iteration.  `results` is
+//    then OWED: whoever reads it before the next SpMV overwrites it gets it written first (val == 0: a copy of vector; else
+//    the SpMV once more on the old vector, which the swap left in results' block).
 #ifndef GRAPHLILY_MODULE_FUSION_H_
 #define GRAPHLILY_MODULE_FUSION_H_
 
@@ -49,6 +59,12 @@ struct PullFusion {
 
     void forget(const void *module) {
         flush();
+        if (copy_module == module) {                // its plan is about to change or go: what a swap left owed is written now
+            if (last_copy_res.owed()) (void)last_copy_res.ptr();
+            last_copy_res = DeviceBuffer();
+            rerun_spmv = nullptr;
+            copy_module = nullptr;
+        }
         for (size_t i = 0; i < entries.size();)
             if (entries[i].module == module) entries.erase(entries.begin() + i);
             else i++;
@@ -101,6 +117,16 @@ struct PullFusion {
     // run whatever is deferred, as it is
     void flush() {
         if (!stage) return;
+        if (copy_kind) {                            // a deferred no-mask SpMV that no matching eWiseAdd followed: as it is
+            stage = 0;
+            copy_kind = false;
+            std::function<void(float, bool)> r;
+            r.swap(run_copy_spmv);
+            res.settle_quietly();
+            vec = res = DeviceBuffer();
+            if (r) r(0.0f, false);
+            return;
+        }
         const int st = stage;
         stage = 0;
         res.settle_quietly();
@@ -138,6 +164,7 @@ struct PullFusion {
 
     // eWiseAddModule::run: does it continue the chain?
     bool defer_ewise(const DeviceBuffer &in, const DeviceBuffer &out, uint32_t len, float val, std::function<void()> run_now) {
+        if (stage == 1 && copy_kind) return complete_copy(in, out, len, val);
         if (stage != 1 || in.id() != res.id() || out.id() != vec.id() || len != n || val != 0.0f) return false;
         stage = 2;
         run_ewise = std::move(run_now);
@@ -159,6 +186,62 @@ struct PullFusion {
     }
 
     static std::function<void()> take_debt(const DeviceBuffer &b) { return b.take_debt(); }
+
+    // ---------------------------------------------------------------- SpMV + eWiseAdd(n, val) of the SSSP / PageRank pull loops
+    bool copy_kind = false;
+    bool copy_zero_is_0 = false, copy_muladd = false;
+    std::function<void(float, bool)> run_copy_spmv;   // (extra term, fold it into the epilogue?) -> the SpMV on the bound buffers
+    std::function<void(const DeviceBuffer &, const DeviceBuffer &)> rerun_spmv;   // (x, y): the plain SpMV on explicit buffers
+    DeviceBuffer last_copy_res;                     // the results buffer the last swap left owed
+    const void *copy_module = nullptr;
+
+    // SpMVModule::run on a non-blocking module, no mask, whole square matrix, general / pattern layout: do not launch yet
+    void defer_copy_spmv(const void *module, uint32_t n_, DeviceBuffer vector, DeviceBuffer results, bool zero_is_0, bool muladd,
+                         std::function<void(float, bool)> run_now, std::function<void(const DeviceBuffer &, const DeviceBuffer &)> rerun) {
+        flush();
+        stage = 1;
+        copy_kind = true;
+        copy_module = module;
+        n = n_;
+        vec = vector;
+        res = results;
+        copy_zero_is_0 = zero_is_0;
+        copy_muladd = muladd;
+        run_copy_spmv = std::move(run_now);
+        rerun_spmv = std::move(rerun);
+        res.owe([this] { flush(); });               // a reader of the results gets them
+    }
+
+    bool complete_copy(const DeviceBuffer &in, const DeviceBuffer &out, uint32_t len, float val) {
+        const bool fold = val != 0.0f;
+        if (in.id() != res.id() || out.id() != vec.id() || len != n || vec.size() != res.size() || (fold && !(copy_muladd && copy_zero_is_0)))
+            return false;                           // (the caller's barrier_() runs the deferred SpMV as it is)
+        stage = 0;
+        copy_kind = false;
+        res.settle_quietly();
+        (void)vec.ptr();                            // (whatever the vector itself still owed)
+        if (last_copy_res.valid() && last_copy_res.id() != res.id() && last_copy_res.owed()) (void)last_copy_res.ptr();
+        std::function<void(float, bool)> r;
+        r.swap(run_copy_spmv);
+        r(val, fold);                               // results' block = A x (+ val)
+        vec.swap_storage(res);                      // `vector` now names it; `results` names the old x
+        DeviceBuffer v = vec, rr = res;
+        std::function<void(const DeviceBuffer &, const DeviceBuffer &)> again = rerun_spmv;
+        if (!fold) {
+            rr.owe([v, rr] {                        // results = vector (what the copy would have left in both)
+                GRAPHLILY_CHECK(gl_buf_d2d(rr.raw(), v.raw(), rr.size()));
+            });
+        } else {
+            rr.owe([rr, again] {                    // results = A x_old, and x_old is what results' block holds
+                DeviceBuffer tmp(rr.size());
+                again(rr, tmp);
+                GRAPHLILY_CHECK(gl_buf_d2d(rr.raw(), tmp.raw(), rr.size()));
+            });
+        }
+        last_copy_res = rr;
+        vec = res = DeviceBuffer();
+        return true;
+    }
 
     // AssignVectorDenseModule::run: does it complete the chain?  Then run the three calls as the fused step.
     bool fire(const DeviceBuffer &mask, const DeviceBuffer &inout, uint32_t len, float val, int mask_type) {

@@ -213,8 +213,30 @@ public:
                 return;
             }
         }
+        // the first call of an SSSP / PageRank pull iteration (SpMV, then eWiseAdd(n, val) results -> vector)?  It waits for the
+        // second one (module/fusion.h 3.)
+        if (!blocking_ && kFloat && F.enabled() && mask_type_ == kNoMask && !sharded_ && get_num_rows() == get_num_cols() &&
+            !(plan_flags_ & GL_PLAN_BOOLEAN) && vector_buf.valid() && results_buf.valid() && vector_buf.id() != results_buf.id()) {
+            F.defer_copy_spmv(this, get_num_rows(), vector_buf, results_buf, VK::bits(semiring_.zero) == 0u, semiring_.op == kMulAdd,
+                              [this](float extra, bool fold) { run_now_plus_(extra, fold); },
+                              [this](const DeviceBuffer &x, const DeviceBuffer &y) {
+                                  GRAPHLILY_CHECK(gl_spmv_run_typed(plan_, x.raw(), nullptr, y.raw(), (int)semiring_.op, VK::bits(semiring_.zero),
+                                                                    (int)kNoMask, VK::kind));
+                              });
+            return;
+        }
         run_now_();
         finish_();
+    }
+    // the SpMV with `extra` as the semiring's zero (only when the module's own zero is 0: zero + sum + extra == extra + sum)
+    void run_now_plus_(float extra, bool fold) {
+        if (!fold) {
+            run_now_();
+            return;
+        }
+        uint32_t zb;
+        memcpy(&zb, &extra, 4);
+        GRAPHLILY_CHECK(gl_spmv_run_typed(plan_, vector_buf.ptr(), nullptr, results_buf.ptr(), (int)semiring_.op, zb, (int)kNoMask, VK::kind));
     }
 
     // (a download of a buffer that a deferred / fused call still owes settles the debt first: DeviceBuffer::ptr)

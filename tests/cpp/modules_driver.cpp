@@ -294,6 +294,63 @@ int main() {
             verify(seen[0][k], seen[1][k], name, true);
         }
     }
+    // ---- the pull loops of the reference's SSSP and PageRank drivers (app/sssp.h:152-166, app/pagerank.h:80-90) through a
+    //      ModuleCollection: SpMV->run(); eWiseAdd->run(n, val) run as one SpMV whose result block SWAPS places with the vector's
+    //      (module/fusion.h 3.).  Vector and results -- read through the module API at every iteration or only at the end -- must
+    //      be what the two calls leave with the fusion off; (min,+) bit for bit, (+,x) to the f64-accumulated sum's rounding.
+    for (int which = 0; which < 2; which++) {
+        struct Pull : public app::ModuleCollection {
+            module::SpMVModule<val_t, val_t> *SpMV;
+            module::eWiseAddModule<val_t> *eWise;
+            Pull(SemiringType sem) {
+                SpMV = new module::SpMVModule<val_t, val_t>(16, 1024, 256);
+                SpMV->set_semiring(sem);
+                SpMV->set_mask_type(kNoMask);
+                eWise = new module::eWiseAddModule<val_t>();
+                add_module(SpMV);
+                add_module(eWise);
+            }
+        };
+        CSRMatrix<float> g = uniform_csr(20000, 6, 23);
+        io::util_round_csr_matrix_dim(g, 128, 128);
+        const uint32_t n = g.num_rows, iters = 6;
+        const bool sssp = which == 0;
+        const float val = sssp ? 0.0f : 0.1f / n;
+        for (size_t i = 0; i < g.adj_data.size(); i++) g.adj_data[i] = sssp ? float(1 + i % 3) : 0.9f / 6.0f;
+        std::vector<fvec> seen[2];
+        for (int fused = 0; fused < 2; fused++) {
+            setenv("GRAPHLILY_MODULE_FUSION", fused ? "1" : "0", 1);
+            Pull p(sssp ? TropicalSemiring : ArithmeticSemiring);
+            p.set_up_runtime("unused.xclbin");
+            p.SpMV->load_and_format_matrix(g, true);
+            p.SpMV->send_matrix_host_to_device();
+            aligned_dense_vec_t x(n, sssp ? (float)TropicalSemiring.zero : 1.0f / n);
+            if (sssp) x[3] = 0;
+            p.SpMV->send_vector_host_to_device(x);
+            p.eWise->bind_in_buf(p.SpMV->results_buf);
+            p.eWise->bind_out_buf(p.SpMV->vector_buf);
+            for (uint32_t it = 1; it <= iters; it++) {
+                p.SpMV->run();
+                p.eWise->run(n, val);
+                if (it == 2) seen[fused].push_back(p.SpMV->send_results_device_to_host());   // a reader of the owed results, mid-run
+                if (it == 3) seen[fused].push_back(p.SpMV->send_vector_device_to_host());
+            }
+            seen[fused].push_back(p.SpMV->send_vector_device_to_host());
+            seen[fused].push_back(p.SpMV->send_results_device_to_host());
+            // a lone run() afterwards, and a run() + an eWiseAdd that does NOT match the pattern (another length)
+            p.SpMV->run();
+            seen[fused].push_back(p.SpMV->send_results_device_to_host());
+            p.SpMV->run();
+            p.eWise->run(n / 2, val);
+            seen[fused].push_back(p.SpMV->send_results_device_to_host());
+            seen[fused].push_back(p.SpMV->send_vector_device_to_host());
+        }
+        unsetenv("GRAPHLILY_MODULE_FUSION");
+        for (size_t k = 0; k < seen[0].size(); k++) {
+            snprintf(name, sizeof(name), "%s pull loop: SpMV + eWiseAdd as a swap == the two calls (read %zu)", sssp ? "SSSP" : "PageRank", k);
+            verify(seen[0][k], seen[1][k], name, sssp);
+        }
+    }
     printf("%s\n", failures ? "SOME CHECKS FAILED" : "ALL CHECKS PASSED");
     return failures ? 1 : 0;
 }
