@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--emulate-rank", default="",
                     help="k/N[,k/N...]: after the one-GPU BFS leg, build rank k's row shard of an N-rank run on this GPU and "
                          "time its bit-frontier BFS schedule with the exchange stubbed (graphlily_amd.dist.EmulatedComm)")
+    ap.add_argument("--cabi-comm", action="store_true",
+                    help="row-sharded BFS: exchange bits + tallies through the C ABI (gl_dist_all_gather_bits_tally on the library's stream, "
+                         "recorded into the schedule's hipGraph) instead of torch.distributed")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still create the process group and run every collective (one-rank RCCL on one GPU)")
     args = ap.parse_args()
@@ -116,6 +119,9 @@ def main():
 
     capi.init(local_rank)
     capi.set_stream(torch.cuda.current_stream().cuda_stream)   # library kernels on torch's stream
+    if use_dist and args.cabi_comm:
+        from graphlily_amd.dist import CabiComm
+        bfs_comm = CabiComm(True, force=args.force_dist)       # the BFS exchange through gl_dist_*: recordable into the hipGraph
 
     # ------------------------------------------------------------------ workload
     t0 = time.time()
@@ -280,7 +286,8 @@ def main():
     if not args.no_bfs:
         try:
             keep = {}
-            out["bfs"] = _bench_bfs(app, capi, comm, raw, g["iters"], local_rank, args.bfs_runs, fence, keep)
+            out["bfs"] = _bench_bfs(app, capi, bfs_comm if (use_dist and args.cabi_comm) else comm, raw, g["iters"], local_rank, args.bfs_runs,
+                                    fence, keep)
             if args.emulate_rank and world == 1:
                 out["bfs_emulated_ranks"] = _bench_emulated(app, capi, raw, g["iters"], local_rank, args.bfs_runs, args.emulate_rank,
                                                             keep["bfs"], out["bfs"]["source"])
@@ -310,6 +317,8 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
+        if args.cabi_comm:
+            bfs_comm.gl.destroy()        # (ends the graphs that recorded its exchanges first)
         dist.destroy_process_group()
 
 
@@ -521,9 +530,10 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence, keep=None):
     # One GPU: the library goes back to its own stream -- torch's current stream is the NULL stream, on which the BFS
     # schedule cannot be recorded as a hipGraph (it would be enqueued launch by launch: ~5 % slower).  Row-sharded runs
     # keep torch's stream: their collectives are torch.distributed calls on it.
-    if not comm.distributed:
+    own_stream = not comm.distributed or getattr(comm, "capturable", False)
+    if own_stream:
         capi.reset_stream()
-    bfs = app.BFS(16, 0, 0, 0, comm=comm, backend=app.HipBackend(device, use_torch=comm.distributed))
+    bfs = app.BFS(16, 0, 0, 0, comm=comm, backend=app.HipBackend(device, use_torch=not own_stream))
     bfs.set_up_runtime()
     bfs.load_and_format_matrix(raw, True)
     bfs.send_matrix_host_to_device()
@@ -562,6 +572,12 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence, keep=None):
         if mode == "pull_push":
             res[mode]["push_iterations"] = bfs.push_iterations_
     res.update({"iters": iters, "nnz": nnz, "setup_s": round(setup, 2), "threshold": 0.001, "source": source})
+    st = getattr(bfs, "bits_loop_", None)
+    res["schedule"] = ("device-resident, one launch per slot" + (", replayed as a hipGraph" if st and any(st["graphs"].values()) else ", enqueued per call")
+                       if st else "the reference's module-call loop")
+    res["exchange"] = type(comm).__name__ if comm.distributed else None
+    if st and st.get("graph_error"):
+        res["graph_error"] = st["graph_error"]
     res["gteps_definition"] = "nnz x iterations / time (bench_bfs.cpp:68-71): NOMINAL edges, whatever the direction touched"
     if not comm.distributed and getattr(bfs, "bfs_slot_modes_", None) is not None:
         try:

@@ -461,8 +461,9 @@ class BFS(_GraphApp):
                     if in_graph:
                         packed_read_back()
                 st["graphs"][key] = g
-            except capi.GraphLilyError:
+            except capi.GraphLilyError as e:
                 g = st["graphs"][key] = False              # capture not possible here: keep enqueueing
+                st["graph_error"] = str(e)
         if timed:
             capi.span_begin()
         if g:

@@ -481,8 +481,19 @@ class SpMSpVPlan:
 class Graph:
     """A recorded launch sequence (gl_graph_*): `with Graph.capture() as g: ...enqueue...`, then g.launch()."""
 
+    live = None      # weak set of the graphs alive (Dist.destroy ends them first: RCCL waits for graphs holding its operations)
+
     def __init__(self):
+        import weakref
         self.handle = None
+        if Graph.live is None:
+            Graph.live = weakref.WeakSet()
+        Graph.live.add(self)
+
+    def destroy(self):
+        h, self.handle = self.handle, None
+        if h:
+            lib().gl_graph_destroy(ctypes.c_void_p(h))
 
     @classmethod
     def capture(cls):
@@ -517,12 +528,13 @@ class Graph:
         return False
 
     def launch(self):
+        if not self.handle:
+            raise GraphLilyError(GL_ERR_INVALID_ARG, "Graph.launch: the graph has been destroyed")
         check(lib().gl_graph_launch(ctypes.c_void_p(self.handle)))
 
     def __del__(self):
         try:
-            if self.handle:
-                lib().gl_graph_destroy(ctypes.c_void_p(self.handle))
+            self.destroy()
         except Exception:
             pass
 
@@ -568,7 +580,10 @@ class Dist:
 
     def destroy(self):
         if getattr(self, "handle", None):
-            lib().gl_dist_destroy(ctypes.c_void_p(self.handle))
+            # (graphs that recorded an exchange hold RCCL operations: the communicator's destroy would wait for them)
+            for g in list(Graph.live or ()):
+                g.destroy()
+            check(lib().gl_dist_destroy(ctypes.c_void_p(self.handle)))
             self.handle = None
 
     def __del__(self):

@@ -8,6 +8,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "graphlily_hip.h"
@@ -22,6 +24,30 @@
 
 namespace gl {
 
+static inline long env_long(const char *name, long dflt) {
+    const char *e = getenv(name);
+    return e ? atol(e) : dflt;
+}
+
+// Planner overrides for tests and same-box A/B runs -- NOT feature switches: GRAPHLILY_DEBUG="key=value,key=value" forces a
+// decision the planner would otherwise take from the matrix (row blocks x column segments, hot table size, helper mode, load
+// width, SpMSpV tile height, the BFS schedule's work thresholds ...), so that a test can drive every code path on one small
+// matrix.  Read at the call that takes the decision (plan creation, mostly).
+static inline long debug_knob(const char *key, long dflt) {
+    const char *e = getenv("GRAPHLILY_DEBUG");
+    if (!e) return dflt;
+    const size_t klen = strlen(key);
+    for (const char *p = e; *p;) {
+        const char *end = strchr(p, ',');
+        const size_t len = end ? (size_t)(end - p) : strlen(p);
+        if (len > klen && strncmp(p, key, klen) == 0 && p[klen] == '=') return atol(p + klen + 1);
+        if (!end) break;
+        p = end + 1;
+    }
+    return dflt;
+}
+
+
 constexpr int kWave = 64;
 
 // graphlily/global.h:80 / hw/math_constants.h: FLOAT_INF
@@ -34,6 +60,11 @@ struct Context {
     hipStream_t stream = nullptr;  // current stream (own or adopted)
     int num_cus = 256;
     uint32_t *pinned_word = nullptr;   // page-locked staging word for small device->host control reads
+    // gl_graph_begin_capture .. gl_graph_end_capture: the communicators (their counters of recorded graphs) whose exchanges
+    // were recorded -- RCCL's communicator destroy WAITS for every graph holding its operations, so gl_dist_destroy refuses
+    // while such a graph is alive instead of hanging
+    bool capturing = false;
+    std::vector<int *> capture_refs;
 };
 
 Context &ctx();

@@ -21,6 +21,7 @@
 struct gl_dist_s {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    int recorded = 0;                 // live gl_graphs that replay this communicator's exchanges (see gl_dist_destroy)
     uint32_t *d_counts = nullptr;     // world sparse-list heads (8 bytes each) for gl_dist_all_gather_sparse
     uint32_t *h_counts = nullptr;     // page-locked mirror
 };
@@ -88,9 +89,27 @@ int need_rccl(const char *who) {
 // every rank's slice [lo[r], hi[r]) (BYTE offsets into `buf`, gl_dist_slice_plan) to every other rank, in place
 // (buf2: a second vector of equal slices -- `each2` bytes per rank, rank r's at r * each2 -- in the SAME group: one operation)
 int exchange_slices(gl_dist d, char *buf, const uint64_t *lo, const uint64_t *hi, char *buf2 = nullptr, uint64_t each2 = 0) {
-    if (d->world == 1) return GL_OK;
     Rccl &R = rccl();
     hipStream_t s = ctx().stream;
+    if (ctx().capturing) {
+        std::vector<int *> &refs = ctx().capture_refs;
+        bool seen = false;
+        for (int *r : refs) seen |= r == &d->recorded;
+        if (!seen) refs.push_back(&d->recorded);
+    }
+    if (d->world == 1) {
+        // One GPU holds a world of one: nothing to exchange.  GRAPHLILY_DEBUG=dist_self_probe=1 still puts one RCCL
+        // operation on the stream here (8 bytes of the slice sent to this same rank, into the communicator's scratch), so
+        // that a one-GPU box exercises what a world of N relies on: RCCL calls recorded by a stream capture and replayed.
+        static const bool probe = debug_knob("dist_self_probe", 0) != 0;
+        if (probe && hi[0] - lo[0] >= 8) {
+            GL_NCCL(R.GroupStart());
+            GL_NCCL(R.Send(buf + lo[0], 8, ncclUint8, 0, d->comm, s));
+            GL_NCCL(R.Recv(d->d_counts, 8, ncclUint8, 0, d->comm, s));
+            GL_NCCL(R.GroupEnd());
+        }
+        return GL_OK;
+    }
     const uint64_t mine = hi[d->rank] - lo[d->rank];
     GL_NCCL(R.GroupStart());
     for (int p = 0; p < d->world; p++) {
@@ -154,6 +173,9 @@ int gl_dist_init(gl_dist *comm, int rank, int world_size, const void *id128) {
 
 int gl_dist_destroy(gl_dist d) {
     if (!d) return GL_OK;
+    if (d->recorded > 0)
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_dist_destroy: %d recorded graph(s) still replay this communicator's exchanges: "
+                             "gl_graph_destroy them first (RCCL's destroy waits for them)", d->recorded);
     if (gl::ctx().initialized) (void)hipStreamSynchronize(gl::ctx().stream);
     if (d->comm && gl::rccl().ok) (void)gl::rccl().CommDestroy(d->comm);
     (void)hipFree(d->d_counts);

@@ -371,12 +371,19 @@ int gl_span_end(double *ms) {
 }
 
 // ---- hipGraph capture of a launch sequence on the library's stream
+struct gl_graph_s {
+    hipGraphExec_t exec = nullptr;
+    std::vector<int *> comm_refs;   // counters of the communicators whose exchanges this graph replays
+};
+
 int gl_graph_begin_capture(void) {
     GL_REQUIRE_INIT();
     if (gl::ctx().stream == nullptr)   // an adopted NULL stream: HIP's legacy default stream cannot be captured
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_graph_begin_capture: the library is on the NULL stream (gl_set_stream(NULL)); "
                              "capture needs a created stream (gl_reset_stream)");
     GL_HIP(hipStreamBeginCapture(gl::ctx().stream, hipStreamCaptureModeThreadLocal));
+    gl::ctx().capturing = true;
+    gl::ctx().capture_refs.clear();
     return GL_OK;
 }
 
@@ -384,25 +391,34 @@ int gl_graph_end_capture(gl_graph *graph) {
     GL_REQUIRE_INIT();
     GL_ARG(graph != nullptr);
     *graph = nullptr;
+    gl::ctx().capturing = false;
     hipGraph_t g = nullptr;
     GL_HIP(hipStreamEndCapture(gl::ctx().stream, &g));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) return gl::set_error(GL_ERR_HIP, "gl_graph_end_capture: hipGraphInstantiate: %s", hipGetErrorString(e));
-    *graph = reinterpret_cast<gl_graph>(exec);
+    gl_graph_s *G = new gl_graph_s;
+    G->exec = exec;
+    G->comm_refs.swap(gl::ctx().capture_refs);
+    for (int *r : G->comm_refs) ++*r;
+    *graph = G;
     return GL_OK;
 }
 
 int gl_graph_launch(gl_graph graph) {
     GL_REQUIRE_INIT();
     GL_ARG(graph != nullptr);
-    GL_HIP(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph), gl::ctx().stream));
+    GL_HIP(hipGraphLaunch(graph->exec, gl::ctx().stream));
     return GL_OK;
 }
 
 int gl_graph_destroy(gl_graph graph) {
-    if (graph) GL_HIP(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph)));
+    if (!graph) return GL_OK;
+    const hipError_t e = hipGraphExecDestroy(graph->exec);
+    for (int *r : graph->comm_refs) --*r;
+    delete graph;
+    if (e != hipSuccess) return gl::set_error(GL_ERR_HIP, "gl_graph_destroy: %s", hipGetErrorString(e));
     return GL_OK;
 }
 

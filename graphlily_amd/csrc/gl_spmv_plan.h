@@ -37,29 +37,6 @@ constexpr uint32_t kBoolHubSlots = 32;                        // private bits pe
 constexpr uint32_t kBoolHubMax = 31;                          // hub rows per block (bit 31 of word 511 is the padding slot)
 constexpr uint32_t kBoolHubBit0 = (kBoolTileWords - kBoolHubSlots) * 32u;   // 15360: plain rows use the bits below
 
-static inline long env_long(const char *name, long dflt) {
-    const char *e = getenv(name);
-    return e ? atol(e) : dflt;
-}
-
-// Planner overrides for tests and same-box A/B runs -- NOT feature switches: GRAPHLILY_DEBUG="key=value,key=value" forces a
-// decision the planner would otherwise take from the matrix (row blocks x column segments, hot table size, helper mode, load
-// width, SpMSpV tile height, the BFS schedule's work thresholds ...), so that a test can drive every code path on one small
-// matrix.  Read at the call that takes the decision (plan creation, mostly).
-static inline long debug_knob(const char *key, long dflt) {
-    const char *e = getenv("GRAPHLILY_DEBUG");
-    if (!e) return dflt;
-    const size_t klen = strlen(key);
-    for (const char *p = e; *p;) {
-        const char *end = strchr(p, ',');
-        const size_t len = end ? (size_t)(end - p) : strlen(p);
-        if (len > klen && strncmp(p, key, klen) == 0 && p[klen] == '=') return atol(p + klen + 1);
-        if (!end) break;
-        p = end + 1;
-    }
-    return dflt;
-}
-
 struct Shape {
     uint32_t blocks, segments;
 };

@@ -256,8 +256,12 @@ class CabiComm(Comm):
     library's stream) instead of torch.distributed -- what a C++ caller of the drop-in headers uses.  The communicator's
     unique id travels through the torch process group."""
 
-    def __init__(self, group=True):
-        super().__init__(group)
+    # the exchange is a grouped ncclSend / ncclRecv on the library's own stream: it is recorded INTO the BFS schedule's hipGraph
+    # (one launch + one exchange per slot replayed with a single call), which torch.distributed's collectives are not
+    capturable = True
+
+    def __init__(self, group=True, force=False):
+        super().__init__(group, force=force)
         from . import capi
         import torch.distributed as dist
         uid = [capi.Dist.unique_id() if self.rank == 0 else None]

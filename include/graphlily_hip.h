@@ -478,7 +478,7 @@ typedef struct gl_dist_s *gl_dist;
 int gl_dist_slice_plan(int kind, int world_size, const uint32_t *in, uint64_t *lo_bytes, uint64_t *hi_bytes);
 int gl_dist_unique_id(void *id128);
 int gl_dist_init(gl_dist *comm, int rank, int world_size, const void *id128);
-int gl_dist_destroy(gl_dist comm);
+int gl_dist_destroy(gl_dist comm);      /* GL_ERR_INVALID_ARG while a gl_graph that recorded one of its exchanges is alive */
 int gl_dist_rank(gl_dist comm, int *rank, int *world_size);
 int gl_dist_all_gather_f32(gl_dist comm, float *d_full, const uint32_t *bounds);
 int gl_dist_all_gather_bits_tally(gl_dist comm, uint32_t *d_bits, const uint32_t *row_bounds, uint32_t *d_tally_slot, uint32_t bytes_per_rank);

@@ -194,6 +194,49 @@ def test_bench_one_rank_rccl(gpu):
     assert rec["bfs"]["pull"]["reached"] == rec["bfs"]["pull_push"]["reached"] > 0
 
 
+def test_bench_one_rank_rccl_exchange_inside_the_graph(gpu):
+    """`--cabi-comm`: the sharded BFS exchanges bits + tallies through the C ABI (gl_dist_all_gather_bits_tally: grouped
+    ncclSend / ncclRecv on the library's stream), so the exchange is recorded INTO the schedule's hipGraph -- one launch and
+    one exchange per slot, replayed with one call.  One GPU allows a world of one, whose exchange is empty; the planner
+    override dist_self_probe=1 makes every exchange call put one grouped ncclSend / ncclRecv (to this same rank) on the stream,
+    so that RCCL operations ARE recorded by the capture and replayed -- what a world of N relies on."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["GRAPHLILY_DEBUG"] = "dist_self_probe=1"
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--cabi-comm", "--no-six-graphs", "--no-spmspv", "--steps", "10", "--warmup", "2",
+                        "--scale", "0.1", "--bfs-runs", "1", "--no-cpu-baseline", "--no-pattern"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert "error" not in rec.get("bfs", {}), rec["bfs"]
+    assert rec["bfs"]["exchange"] == "CabiComm" and "hipGraph" in rec["bfs"]["schedule"], rec["bfs"]
+    assert rec["bfs"]["pull"]["reached"] == rec["bfs"]["pull_push"]["reached"] > 0
+
+
+def test_a_communicator_outlives_the_graphs_that_recorded_it(gpu):
+    """RCCL's communicator destroy waits for every graph that holds its operations: gl_dist_destroy refuses (instead of
+    hanging) while a gl_graph that recorded one of the communicator's exchanges is alive."""
+    import ctypes
+    from graphlily_amd import capi
+    d = capi.Dist(0, 1, capi.Dist.unique_id())
+    n = 1 << 12
+    bits = capi.DeviceBuffer.from_host(np.arange(n // 32, dtype=np.uint32))
+    capi.reset_stream()
+    with capi.Graph.capture() as g:
+        d.all_gather_bits_tally(bits, [0, n], None)
+    g.launch()
+    capi.sync()
+    rc = capi.lib().gl_dist_destroy(ctypes.c_void_p(d.handle))
+    assert rc == capi.GL_ERR_INVALID_ARG and b"recorded graph" in capi.lib().gl_last_error()
+    d.destroy()                          # (the wrapper ends the live graphs first)
+    assert d.handle is None and g.handle is None
+    with pytest.raises(capi.GraphLilyError):
+        g.launch()
+
+
 def test_gl_dist_c_abi_single_rank(gpu):
     """gl_dist_* (the RCCL exchange step in the C ABI): the box has one GPU, so this is a world of one -- RCCL loads at
     run time, ncclCommInitRank succeeds on the device, the dense / bit gathers leave the vector alone and the sparse gather
