@@ -963,11 +963,19 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         const size_t elem = (flags & (GL_PLAN_NO_MULADD | GL_PLAN_BOOLEAN)) ? sizeof(float) : sizeof(double);
         const size_t tile_bytes = ((size_t)tallest + gl::kHubSlots * gl::kMaxHubRows) * elem;
         // as many columns as fit next to the tallest tile, in steps of 1024, at most 32 K
-        uint32_t H = 0;
+        uint32_t room = 0;
         if (tile_bytes + 4096u <= gl::kLdsBudget)
-            H = std::min<uint32_t>(1u << 15, (uint32_t)((gl::kLdsBudget - tile_bytes) / 4u / 1024u * 1024u));
+            room = std::min<uint32_t>(1u << 15, (uint32_t)((gl::kLdsBudget - tile_bytes) / 4u / 1024u * 1024u));
+        uint32_t H = room;
+        // Round 4, same-box sweeps of the table size (profiles/r04_small_graph_ab.txt): with the packed gather vector ordered by
+        // degree class the popular columns are cheap to gather anyway, and the table has a price per workgroup (its copy in the
+        // prologue, an LDS look-up per entry).  From 100 M non-zeros on the size hardly matters (+-1 %); below 64 M the first
+        // 1-2 K columns are all that pays (ogbl-ppa stand-in 61.8 -> 64.4 % of peak, pokec 49.8 -> 49.8); and a short stream
+        // whose whole x fits a corner of the L2 (googleplus stand-in: 432 KB) runs fastest with no table (57.5 -> 65.2 %).
+        if (nnz < (64ull << 20)) H = std::min<uint32_t>(H, 2048u);
+        if (nnz <= (16ull << 20) && (uint64_t)num_cols * 4u <= (1ull << 20)) H = 0;
         const long forced = gl::debug_knob("spmv_hot", 1);
-        if (forced > 1) H = std::min<uint32_t>(H, (uint32_t)forced);
+        if (forced > 1) H = std::min<uint32_t>(room, (uint32_t)forced);
         if (H) {
             const uint32_t dmax = num_cols ? *std::max_element(deg.begin(), deg.end()) : 0u;
             std::vector<uint32_t> hist((size_t)dmax + 2, 0);
