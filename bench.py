@@ -520,6 +520,36 @@ def _bench_emulated(app, capi, raw, iters, device, runs, specs, whole, source):
                            "slice_equals_one_gpu_run": ok, "push_iterations": b.push_iterations_}
         res.append(entry)
         del b
+        # ---- the dense pull loops of the same rank (configs 4 and 5: PageRank, SSSP pull): the rank's SpMV over its row shard
+        # with the semiring's finish fused, no exchange step (EmulatedComm.all_gather_slices is a stub: the values of the other
+        # ranks' rows are stale, the time is not affected).  ms per iteration = (t(25 iterations) - t(5)) / 20: the set-up
+        # and the download of the result drop out.  `all_gather_bytes` = what the rank would receive per iteration.
+        for label, make in (("pagerank", lambda: app.PageRank(16, 0, 0, comm=comm, backend=app.HipBackend(device))),
+                            ("sssp_pull", lambda: app.SSSP(16, 0, 0, 0, comm=comm, backend=app.HipBackend(device)))):
+            a = make()
+            a.set_up_runtime()
+            if label == "pagerank":
+                a.load_and_format_matrix(raw, 0.85, True)
+                fn = lambda k: a.pull(0.85, k)     # noqa: E731
+            else:
+                a.load_and_format_matrix(raw, True)
+                fn = lambda k: a.pull(source, k)   # noqa: E731
+            a.send_matrix_host_to_device()
+            fn(3)
+            t = {}
+            for k in (5, 25):
+                best = []
+                for _ in range(max(runs, 3)):
+                    capi.sync()
+                    t0 = time.perf_counter()
+                    fn(k)
+                    best.append(time.perf_counter() - t0)
+                t[k] = float(np.median(best))
+            n_rows = int(a.n_)
+            entry[label] = {"ms_per_iteration": round((t[25] - t[5]) / 20 * 1e3, 4), "shard_nnz": int(a.SpMV_.plan_.info()["nnz"]),
+                            "layout": a.SpMV_.plan_.info()["layout"],
+                            "all_gather_bytes": int(4 * (n_rows - (a.r1_ - a.r0_)))}
+            del a
     return res
 
 

@@ -45,8 +45,8 @@ constexpr uint32_t kFoldMaxRounds = kFoldMaxRows / kFoldThreads;   // 16 rounds 
 
 // words of gl_spmspv_plan_s::d_sync.  kSyncGen: the generation that tags the bin kernel's slice sums and the fold kernel's tile
 // states, starts at 1 and only grows (the fold's last tile advances it); kSyncFoldTicket: tiles handed out so far (64 bits,
-// only grows); kSyncFoldDone: zero between runs
-enum : uint32_t { kSyncGen = 0, kSyncFoldDone = 3, kSyncTotal = 5, kSyncFoldTicket = 8 /* 64 bits */, kSyncWords = 16 };
+// only grows); kSyncFoldDone: finished workgroups << 32 | their entries (64 bits), zero between runs
+enum : uint32_t { kSyncGen = 0, kSyncFoldDone = 4 /* 64 bits */, kSyncFoldTicket = 8 /* 64 bits */, kSyncWords = 16 };
 
 // row -> tile without a division: tile = (row * magic) >> (32 + shift), checked on the host for every tile boundary at plan
 // creation (the function is monotone, so exact boundaries make it exact everywhere); magic == 0: rows per tile is 1 << shift
@@ -745,20 +745,22 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
         // run (every workgroup of this launch has read the generation by now)
         a.out[0].index = before + total;
         a.out[0].val = a.head_val;
-        if (a.host_rec) __hip_atomic_store(&a.sync[kSyncTotal], before + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.sync[kSyncGen], gen0 + (a.bin_vec ? spmspv_bin_rounds(a.bin_vec[0].index, a.bin_grid) : 1u), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!a.host_rec) return;
-    // ---- a blocking caller: the last workgroup to finish stores {sequence, count} to page-locked host memory
+    // ---- a blocking caller: the last workgroup to finish stores {sequence, count} to page-locked host memory.  ONE atomic
+    // per workgroup: the 64-bit word counts the finished workgroups in its high half and sums their entries in the low one, so
+    // the last one to arrive has the list's length in the value the atomic returns (no second trip to read it)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have been performed
     __syncthreads();
     if (tid == 0) {
-        if (__hip_atomic_fetch_add(&a.sync[kSyncFoldDone], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == T_ - 1u) {
-            const uint32_t all = __hip_atomic_load(&a.sync[kSyncTotal], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.sync[kSyncFoldDone], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *done = reinterpret_cast<unsigned long long *>(a.sync + kSyncFoldDone);
+        const unsigned long long old = __hip_atomic_fetch_add(done, (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(old >> 32) == T_ - 1u) {
+            const uint32_t all = (uint32_t)old + total;
             __hip_atomic_store(a.host_rec, ((unsigned long long)a.seq << 32) | all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next run's first arrival is a launch away)
         }
     }
 }

@@ -214,6 +214,12 @@ class EmulatedComm:
                     src = capi.DeviceBuffer(b - a, ptr=self._tally.ptr + tbase + a, keepalive=self._tally)
                     capi.copy_d2d(dst, src, b - a)
 
+    def all_gather_slices(self, tensor_or_buf, bounds):
+        """The dense exchange of the pull loops (PageRank, SSSP pull: every rank's rows of the result vector) -- stubbed out:
+        the rank's SpMV reads whatever the other rows hold, which changes its values and not its time (the dense kernels
+        stream the same entries whatever x is).  The time of the all-gather itself is tabulated, not measured."""
+        return
+
     def truth_tally(self, key, slots, bounds, col_len, row_len, n):
         """Every rank's tallies of every slot of the whole-matrix run (gl_bfs_bits_shard_step's table: per slot and rank
         {vertices reached in the rank's rows, their global column lengths, their row lengths}), computed on the host from
