@@ -92,18 +92,27 @@ def run_graph(name, raw, iters, dev, runs=5, spmv_steps=100, apps=("bfs", "pager
     def spmv_line(flags, op, zero, mask_type, prof=False):
         plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=flags)
         mk = bm if mask_type else None
+        # Warm-up, a short idle (the seconds of formatting kernels that plan creation has just run leave the first tens of
+        # milliseconds slower than the steady state: bench.py --settle), then a timed region of >= ~60 ms sized from a probe.
+        t0 = time.perf_counter()
+        for _ in range(10):
+            plan.run(bx, mk, by, op, zero, mask_type)
+        capi.sync()
+        est = (time.perf_counter() - t0) / 10
+        time.sleep(0.25)
         for _ in range(3):
             plan.run(bx, mk, by, op, zero, mask_type)
         capi.sync()
+        steps = int(min(max(spmv_steps, 0.06 / max(est, 1e-6)), 2000))
         if prof:
-            capi.prof_begin(spmv_steps, every=4)
+            capi.prof_begin(steps, every=4)
         t0 = time.perf_counter()
-        for _ in range(spmv_steps):
+        for _ in range(steps):
             plan.run(bx, mk, by, op, zero, mask_type)
         capi.sync()
-        ms = (time.perf_counter() - t0) * 1e3 / spmv_steps
+        ms = (time.perf_counter() - t0) * 1e3 / steps
         info = plan.info()
-        line = {"ms": round(ms, 4), "gteps": round(m.nnz / ms / 1e6, 1), "layout": info["layout"]}
+        line = {"ms": round(ms, 4), "gteps": round(m.nnz / ms / 1e6, 1), "layout": info["layout"], "steps": steps}
         if prof:
             total, launches = capi.prof_end()
             line["kernel_ms"] = round(total / max(launches, 1), 4)
