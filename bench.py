@@ -49,6 +49,9 @@ def main():
                     help="timed steps; 0 (default) = as many as make the timed region last ~1 s (bench_spmv.cpp:96 runs 100: "
                          "at 0.3 ms per step that is a 30 ms region, too short for SMI sampling to see)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--condition-ms", type=float, default=0.0,
+                    help="run the step untimed for this long BEFORE the idle / warm-up / timed steps (a GPU's clocks ramp over the first "
+                         "~100 ms of sustained work; reported as `conditioning`)")
     ap.add_argument("--settle", type=float, default=0.5,
                     help="seconds the device idles between set-up (graph generation, plan creation: seconds of sorting kernels) and "
                          "the warm-up steps")
@@ -167,6 +170,14 @@ def main():
     # state (scripts/r03_step_ramp.py).  A short idle in between separates the two; it matters to short timed regions only.
     fence()
     time.sleep(max(0.0, args.settle))
+    cond_steps = 0
+    if args.condition_ms > 0:
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < args.condition_ms:
+            for _ in range(10):
+                step()
+            fence()
+            cond_steps += 10
     for _ in range(args.warmup):
         step()
     fence()
@@ -233,6 +244,7 @@ def main():
         "gteps": round(nnz * args.steps / wall / 1e9, 3),
         "frac_hbm_peak": round(value / (HBM_PEAK_GBPS * world), 4),
         "selfcheck_ok": ok,
+        "conditioning": {"untimed_steps_before_warmup": cond_steps, "ms": args.condition_ms, "idle_s_before": args.settle},
         "setup_s": {"graph": round(t_gen, 2), "plan": round(t_plan, 2)},
         "roofline": {
             "bound": "hbm", "kernel": "spmv_rbcs_kernel<MULADD,NOMASK,WIDE>",
