@@ -1,0 +1,104 @@
+// SpMSpV vector-sparsity sweep through the C++ module layer (include/graphlily/module/spmspv_module.h on the HIP library),
+// following the measurement protocol of the reference's benchmark/bench_spmspv.cpp: matrix values 1 / num_rows (:157),
+// vector entries at a constant index stride with values (k % 99 + 1) / 100 (:160-185), one warm-up run verified against
+// SpMSpVModule::compute_reference_results (:203-225), then 20 blocking run() calls timed with std::chrono (:228-236);
+// throughput = 8 B x sum of nnz(active columns) / time (:61-76, :237-240).  The reference's own file cannot be compiled here
+// unmodified (hard-coded dataset directory, the overlay synthesizer's headers); this driver is what a C++ caller of the drop-in
+// headers sees -- no Python, no ctypes between the timer and the library.
+//
+//   bench_spmspv_cpp <name> <csr_float32.npz> [sparsity ...]        one JSON line per (sparsity, semiring)
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "graphlily/io/data_loader.h"
+#include "graphlily/io/data_formatter.h"
+#include "graphlily/module/spmspv_module.h"
+
+using graphlily::idx_val_t;
+using graphlily::val_t;
+typedef std::vector<idx_val_t, aligned_allocator<idx_val_t>> sparse_vec_t;
+typedef std::vector<val_t, aligned_allocator<val_t>> dense_vec_t;
+
+int main(int argc, char **argv) {
+    if (argc < 3) {
+        fprintf(stderr, "usage: %s <name> <csr_float32.npz> [sparsity ...]\n", argv[0]);
+        return 2;
+    }
+    const std::string name = argv[1];
+    std::vector<double> sparsities;
+    for (int i = 3; i < argc; i++) sparsities.push_back(atof(argv[i]));
+    if (sparsities.empty()) sparsities = {0.90, 0.95, 0.99, 0.995, 0.999, 0.9995, 0.9999};   // bench_spmspv.cpp:264-270
+
+    graphlily::io::CSCMatrix<float> matrix = graphlily::io::csr2csc<float>(graphlily::io::load_csr_matrix_from_float_npz(argv[2]));
+    for (auto &x : matrix.adj_data) x = 1.0f / matrix.num_rows;
+
+    struct Sem { const char *label; graphlily::SemiringType s; };
+    const Sem sems[2] = {{"Arithmetic", graphlily::ArithmeticSemiring}, {"Tropical", graphlily::TropicalSemiring}};
+    int bad = 0;
+    for (const Sem &sem : sems) {
+        graphlily::module::SpMSpVModule<val_t, val_t, idx_val_t> spmspv(512 * 1024);
+        spmspv.set_semiring(sem.s);
+        spmspv.set_mask_type(graphlily::kNoMask);
+        spmspv.set_up_runtime("unused.xclbin");
+        spmspv.load_and_format_matrix(matrix);
+        spmspv.send_matrix_host_to_device();
+        dense_vec_t mask(matrix.num_rows, 0);
+        graphlily::aligned_dense_float_vec_t mask_float(matrix.num_rows, 0.0f);
+        spmspv.send_mask_host_to_device(mask);
+        for (double sparsity : sparsities) {
+            const unsigned cnt = (unsigned)floor((1 - sparsity) * matrix.num_cols);
+            if (cnt == 0) continue;
+            const unsigned incr = matrix.num_cols / cnt;
+            sparse_vec_t vector(cnt + 1);
+            graphlily::aligned_sparse_float_vec_t vector_float(cnt + 1);
+            vector[0].index = vector_float[0].index = cnt;
+            vector[0].val = vector_float[0].val = 0;
+            double active = 0;
+            for (unsigned i = 1; i <= cnt; i++) {
+                const float v = (float)(((i * 7919u) % 99u) + 1u) / 100.0f;
+                vector[i].index = vector_float[i].index = (i - 1) * incr;
+                vector[i].val = vector_float[i].val = v;
+                active += matrix.adj_indptr[vector[i].index + 1] - matrix.adj_indptr[vector[i].index];
+            }
+            spmspv.send_vector_host_to_device(vector);
+            spmspv.run();                                               // warm-up, verified
+            sparse_vec_t res = spmspv.send_results_device_to_host();
+            graphlily::aligned_dense_float_vec_t ref = spmspv.compute_reference_results(vector_float, mask_float);
+            std::vector<float> got(matrix.num_rows, sem.s.zero);
+            for (size_t i = 1; i < (size_t)res[0].index + 1; i++) got[res[i].index] = res[i].val;
+            bool ok = ref.size() == got.size();
+            for (size_t i = 0; ok && i < got.size(); i++) {
+                const float tol = sem.s.op == graphlily::kMulAdd ? 1e-5f * std::fabs(ref[i]) + 1e-12f : 0.0f;
+                ok = std::fabs(got[i] - ref[i]) <= tol;
+            }
+            if (!ok) bad++;
+            spmspv.run();     // (the host-side verification left the GPU idle for milliseconds; the reference times right
+                              //  behind its warm-up run)
+            const int num_runs = 20;
+            std::vector<double> us(num_runs);
+            double total = 0;
+            for (int i = 0; i < num_runs; i++) {
+                auto t1 = std::chrono::high_resolution_clock::now();
+                spmspv.run();
+                auto t2 = std::chrono::high_resolution_clock::now();
+                us[i] = std::chrono::duration<double, std::micro>(t2 - t1).count();
+                total += us[i];
+            }
+            std::vector<double> sorted(us);
+            std::sort(sorted.begin(), sorted.end());
+            const double ms = total / num_runs / 1000.0;
+            printf("{\"graph\": \"%s\", \"semiring\": \"%s\", \"caller\": \"C++ module layer\", \"vector_sparsity\": %g, \"vector_nnz\": %u, "
+                   "\"active_nnz\": %.0f, \"result_nnz\": %u, \"ms\": %.4f, \"ms_median\": %.4f, \"ms_max\": %.4f, \"gbps\": %.2f, "
+                   "\"gteps\": %.3f, \"verified\": %s}\n",
+                   name.c_str(), sem.label, sparsity, cnt, active, (unsigned)res[0].index, ms, sorted[num_runs / 2] / 1000.0,
+                   sorted[num_runs - 1] / 1000.0, 8.0 * active / ms / 1e6, active / ms / 1e6, ok ? "true" : "false");
+            fflush(stdout);
+        }
+    }
+    return bad ? 1 : 0;
+}

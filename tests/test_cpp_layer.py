@@ -7,6 +7,7 @@ GPU: the parity driver runs every module against its compute_reference_results; 
 drivers (if they travelled with the snapshot) run BFS / PageRank / SSSP end to end on the HIP backend."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -176,3 +177,25 @@ def test_reference_benchmark_drivers_run_on_hip_backend(gpu):
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("GTEPS") >= 5      # BFS pull + pull-push, PageRank, SSSP pull + pull-push
+
+
+@pytest.mark.gpu
+def test_cpp_spmspv_sweep_driver(gpu, tmp_path):
+    """benchmarks/bench_spmspv_cpp.cpp: the reference's bench_spmspv.cpp protocol through the C++ module layer (blocking run()
+    on the operator's completion record); every case is verified against SpMSpVModule::compute_reference_results."""
+    import json
+    import scipy.sparse as sp
+    from graphlily_amd import datasets
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+    import run_spmspv_cpp
+    exe = run_spmspv_cpp.build()
+    m = datasets.rmat(30000, 400000, seed=3)
+    A = sp.csr_matrix((m.adj_data, m.adj_indices.astype(np.int32), m.adj_indptr.astype(np.int32)), shape=(m.num_rows, m.num_cols),
+                      dtype=np.float32)
+    p = str(tmp_path / "rmat_csr_float32.npz")
+    sp.save_npz(p, A, compressed=False)
+    r = subprocess.run([exe, "rmat", p, "0.9", "0.99", "0.999", "0.9999"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(rows) == 8 and all(x["verified"] for x in rows)
+    assert {x["semiring"] for x in rows} == {"Arithmetic", "Tropical"}
