@@ -692,6 +692,7 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
             const uint32_t nb = rounds * kFoldWaves;
 #pragma unroll
             for (uint32_t q = 0; q < 4u; q++) {
+                if (64u * q >= nb) break;      // (tiles of <= 4096 rows have 64 ballots: one of the four scans; block-uniform)
                 const uint32_t i = 64u * q + lane;
                 const uint32_t c = i < nb ? (uint32_t)__popcll(s_ball[i]) : 0u;
                 uint32_t incl = c;
