@@ -423,6 +423,7 @@ struct TinyArgs {
     uint32_t zero_bits;
     unsigned long long *host_rec;   // a blocking caller's completion record (gl_spmspv_wait): seq << 32 | count, or null
     uint32_t seq;
+    uint32_t bucket_shift;          // (nrows - 1) >> bucket_shift < 2048: the sort's buckets
 };
 
 // the one workgroup has written everything: tell a blocking caller
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, S
     __shared__ float s_val[kTinyVec];
     __shared__ __attribute__((aligned(16))) uint32_t s_key[kTinyWork + 4];
     __shared__ uint32_t s_tmp[2048];
+    __shared__ uint32_t s_hist[2048], s_base[2048];
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_cnt;
     const uint32_t tid = threadIdx.x;
@@ -576,46 +578,50 @@ __global__ __launch_bounds__(kTinyThreads) void spmspv_tiny_kernel(TinyArgs a, S
     __syncthreads();
     const uint32_t C = s_cnt;
 
-    // ---- ascending rows.  Short lists by rank (a thread counts the keys in front of its own: C^2 compares, ~5 us at 512 on
-    // the one compute unit this kernel has), longer ones by a bitonic network in LDS (~10 us at 2048)
-    if (C <= 512u) {
-        for (uint32_t i = C + tid; i < ((C + 3u) & ~3u); i += kTinyThreads) s_key[i] = 0xffffffffu;
+    // ---- ascending rows.  One counting pass over 2048 buckets of 1 << bucket_shift consecutive rows -- the rows a tiny run reaches
+    // are spread out, a bucket holds a key or two --, then every key ranks itself among its bucket's keys: five barriers and a
+    // few dozen instructions per thread.  (Round 4's phase stamps: the O(C^2) rank sort this replaces was 13 us of the kernel's
+    // 20 on 394 keys -- the GPU's clocks are low between blocking calls, instructions are what costs.)  Worst case, every key in
+    // one bucket (millions of rows, all touched rows adjacent): the same C^2 compares as before.
+    {
+        const uint32_t sh = a.bucket_shift;
+        s_hist[tid] = 0u;
+        s_hist[tid + kTinyThreads] = 0u;
         __syncthreads();
-        if (tid < C) {     // (wavefronts without a key skip the loop)
-            const uint32_t k = s_key[tid];
-            uint32_t r = 0;
-            const uint4 *keys4 = reinterpret_cast<const uint4 *>(s_key);
-#pragma unroll 4
-            for (uint32_t j4 = 0; j4 < (C + 3u) / 4u; j4++) {
-                const uint4 q = keys4[j4];
-                const uint32_t j = 4u * j4;
-                r += (q.x < k || (q.x == k && j < tid)) ? 1u : 0u;
-                r += (q.y < k || (q.y == k && j + 1u < tid)) ? 1u : 0u;
-                r += (q.z < k || (q.z == k && j + 2u < tid)) ? 1u : 0u;
-                r += (q.w < k || (q.w == k && j + 3u < tid)) ? 1u : 0u;
+        uint32_t kk[2] = {0u, 0u}, rr[2] = {0u, 0u};
+#pragma unroll
+        for (uint32_t u = 0; u < 2u; u++) {
+            const uint32_t idx = tid + u * kTinyThreads;
+            if (idx < C) {
+                kk[u] = s_key[idx];
+                rr[u] = atomicAdd(&s_hist[kk[u] >> sh], 1u);
             }
-            s_tmp[r] = k;
         }
         __syncthreads();
-        if (tid < C) s_key[tid] = s_tmp[tid];
+        const uint32_t c0 = s_hist[2u * tid], c1 = s_hist[2u * tid + 1u];
+        uint32_t tot;
+        const uint32_t before = block_exclusive_1024(c0 + c1, s_wave, &tot);
+        s_base[2u * tid] = before;
+        s_base[2u * tid + 1u] = before + c0;
         __syncthreads();
-    } else {
-        const uint32_t P = C <= 1024u ? 1024u : 2048u;
-        for (uint32_t i = C + tid; i < P; i += kTinyThreads) s_key[i] = 0xffffffffu;
+#pragma unroll
+        for (uint32_t u = 0; u < 2u; u++)
+            if (tid + u * kTinyThreads < C) s_tmp[s_base[kk[u] >> sh] + rr[u]] = kk[u];
         __syncthreads();
-        for (uint32_t k = 2; k <= P; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                if (tid < (P >> 1)) {
-                    const uint32_t i = ((tid & ~(j - 1u)) << 1) | (tid & (j - 1u)), l = i | j;
-                    const uint32_t x = s_key[i], y = s_key[l];
-                    if ((x > y) == ((i & k) == 0u)) {
-                        s_key[i] = y;
-                        s_key[l] = x;
-                    }
+#pragma unroll
+        for (uint32_t u = 0; u < 2u; u++) {
+            const uint32_t idx = tid + u * kTinyThreads;
+            if (idx < C) {
+                const uint32_t k = s_tmp[idx], b = k >> sh, lo = s_base[b], n = s_hist[b];
+                uint32_t r = 0;
+                for (uint32_t q = lo; q < lo + n; q++) {
+                    const uint32_t o = s_tmp[q];
+                    r += (o < k || (o == k && q < idx)) ? 1u : 0u;
                 }
-                __syncthreads();
+                s_key[lo + r] = k;
             }
         }
+        __syncthreads();
     }
 
     // ---- emission in row order: duplicates (a row that went back to the fill value and was reached again) are neighbours
@@ -962,6 +968,8 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
         t.out = d_result;
         t.head_val = zero;
         t.zero_bits = __builtin_bit_cast(uint32_t, zero);
+        t.bucket_shift = 0u;
+        while (((nrows - 1u) >> t.bucket_shift) >= 2048u) t.bucket_shift++;
         {   // (a run that is not being recorded into a graph reports its completion to the host, as below)
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(s, &cap);

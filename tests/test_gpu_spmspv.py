@@ -636,3 +636,31 @@ def test_wait_returns_the_count_without_a_copy(gpu):
     assert np.array_equal(mod.send_results_device_to_host(), want)
     mod.run()                                  # and an eager run after the replay reports again
     assert mod.plan_.wait() == int(want["index"][0])
+
+
+@pytest.mark.parametrize("sem", ["Arithmetic", "Tropical"])
+def test_tiny_run_whose_rows_are_adjacent(gpu, sem):
+    """The one-launch kernel orders the rows it reached with a counting pass over 2048 buckets of consecutive rows + a rank
+    inside each bucket.  600 K rows make a bucket 512 rows wide; three columns that cover 1300 ADJACENT rows (two of them the
+    same rows: sums / minima of two products) put ~500 keys into each of three buckets -- the case the buckets do not help,
+    which must still come out in ascending row order -- next to a column at the far end of the matrix."""
+    n, ncols = 600000, 64
+    rows = [np.arange(200000, 200700), np.arange(200300, 201300), np.arange(200300, 201300)[::3], np.array([5, 599999])]
+    indptr = np.zeros(ncols + 1, np.uint32)
+    for c, r in enumerate(rows):
+        indptr[c + 1] = indptr[c] + len(r)
+    indptr[len(rows) + 1:] = indptr[len(rows)]
+    idx = np.concatenate(rows).astype(np.uint32)
+    rng = np.random.default_rng(5)
+    data = (rng.integers(1, 9, size=len(idx)) / np.float32(8)).astype(np.float32)
+    csc = io.CSCMatrix(n, ncols, data, idx, indptr)
+    v = M.make_sparse_vec(np.arange(4, dtype=np.uint32), np.array([0.5, 0.25, 0.75, 1.0], np.float32))
+    mask = np.zeros(n, np.float32)
+    op, zero = SEMIRINGS[sem]
+    got, mod = _run(gpu, csc, sem, "NoMask", v, mask)
+    assert mod.tiny_ is not None                     # 4 entries, 2036 products: one launch
+    res = mod.send_results_device_to_host()
+    cnt = int(res["index"][0])
+    assert np.all(np.diff(res["index"][1:cnt + 1].astype(np.int64)) > 0)
+    ref = O.spmspv(to_oracle(csc), v, op, zero, mask, MASKS["NoMask"])
+    assert_parity(got, ref, op, "adjacent rows %s" % sem)
