@@ -386,6 +386,15 @@ def test_tiny_runs_are_one_launch_with_the_same_result(gpu, sem, mask_name, monk
     picks = {"one": light[:1], "ten": light[5:15], "many": np.sort(rng.choice(light, 900, replace=False)),
              "hub": np.array([order[-1]]),                         # one long column: > 2048 non-zeros -> general path
              "dups": np.array([light[3], light[3], light[7]])}     # a column named twice
+    mid, tot = [], 0                                              # 6000 .. 8000 products in few columns: the two-launch path, hinted
+    for c in order[::-1][5:]:
+        if tot + coldeg[c] <= 8000:
+            mid.append(c)
+            tot += int(coldeg[c])
+        if tot > 6000 or len(mid) == 1000:
+            break
+    picks["mid"] = np.sort(np.array(mid))
+    assert 6000 < tot <= 8000
     mask = rand01(csc.num_rows, 11)
     for name, cols in picks.items():
         vals = (rng.integers(1, 10, size=len(cols)) / 10.0).astype(np.float32)
