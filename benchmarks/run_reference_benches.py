@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Run the REFERENCE's own benchmark drivers (benchmark/bench_{bfs,pagerank,sssp}.cpp, compiled unmodified
+"""Run the REFERENCE's own benchmark drivers (benchmark/bench_{spmv,bfs,pagerank,sssp}.cpp, compiled unmodified
 against include/graphlily by `make -C oracle ref_benches`) on the HIP backend and print what they print.
 
 The binaries take the reference's positional arguments (benchmark/run_bfs.sh:3-10):
@@ -26,7 +26,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graph", default="googleplus")
     ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--apps", default="bfs,pagerank,sssp")
+    ap.add_argument("--apps", default="spmv,spmv_verify,bfs,pagerank,sssp",
+                    help="spmv = bench_spmv.cpp as it is (100 blocking runs, :96-112); spmv_verify = the same file with its own "
+                         "verify (:15-33) called on the results (tests/cpp/ref_bench_spmv_verify.cpp)")
     ap.add_argument("--npz", default=None, help="an already written stand-in (skips generation)")
     args = ap.parse_args()
     import scipy.sparse as sp
@@ -54,11 +56,13 @@ def main():
                 print("# %s not built (needs /root/reference: make -C oracle ref_benches)" % exe)
                 rc = 2
                 continue
-            if a == "pagerank":     # bench_pagerank.cpp:67-75: num_channels out_buf_len vec_buf_len bitstream dataset
+            if a == "spmv_verify":
+                cmd = [exe, path]
+            elif a in ("pagerank", "spmv"):     # bench_pagerank.cpp:67-75, bench_spmv.cpp:116-122: num_channels out_buf_len vec_buf_len bitstream dataset
                 cmd = [exe, "16", "1024000", "30720", "unused.xclbin", path]
             else:
                 cmd = [exe, "16", "1024000", "256000", "30720", "unused.xclbin", path, str(g["iters"])]
-            print("# " + " ".join(cmd[:1] + cmd[1:5] + ["..."]), flush=True)
+            print("# " + " ".join(cmd[:5] + ["..."]), flush=True)
             t0 = time.time()
             r = subprocess.run(cmd, capture_output=True, text=True)
             sys.stdout.write(r.stdout)

@@ -171,12 +171,14 @@ def test_reference_app_drivers_run_on_hip_backend(gpu, tmp_path, golden_dir):
 @pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "bench_bfs_on_hip")),
                     reason="prebuilt reference benchmark drivers did not travel")
 def test_reference_benchmark_drivers_run_on_hip_backend(gpu):
-    """benchmark/bench_{bfs,pagerank,sssp}.cpp of the reference, compiled unmodified, run end to end."""
+    """benchmark/bench_{spmv,bfs,pagerank,sssp}.cpp of the reference, compiled unmodified, run end to end; bench_spmv.cpp's
+    own verify (:15-33, eps 1e-4 absolute) is called on the backend's results by tests/cpp/ref_bench_spmv_verify.cpp."""
     r = subprocess.run(["python", os.path.join(ROOT, "benchmarks", "run_reference_benches.py"),
                         "--graph", "googleplus", "--scale", "0.25"], capture_output=True, text=True, timeout=900)
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("GTEPS") >= 5      # BFS pull + pull-push, PageRank, SSSP pull + pull-push
+    assert r.stdout.count("GTEPS") >= 6      # SpMV, BFS pull + pull-push, PageRank, SSSP pull + pull-push
+    assert "SpMV passed" in r.stdout and "Compute THROUGHPUT" in r.stdout
 
 
 @pytest.mark.gpu
