@@ -42,12 +42,38 @@ def timed(fn, runs, warm=3):
     return float(np.median(ts)), out
 
 
-def edges_traversed(bfs, raw, d, iters):
+def bfs_times(bfs, src, iters, runs, fence=None, threshold=0.001):
+    """bench_bfs.cpp:55-89 for both modes, pull_push first: 14 untimed calls (the schedule is recorded on the third call; the
+    driver then measures both read-back ways), then the median wall time of `runs` calls, each bracketed by `fence`.  ONE helper
+    for bench.py's headline `bfs` object and for every `six_graphs` line, so that the two cannot drift apart (round 4: 33 %).
+    Returns {mode: {"s", "d", "push_iterations", "readback", "slot_modes"}}."""
+    from graphlily_amd import capi
+    fence = fence or capi.sync
+    out = {}
+    for mode in ("pull_push", "pull"):
+        fn = (lambda: bfs.pull_push(src, iters, threshold)) if mode == "pull_push" else (lambda: bfs.pull(src, iters))
+        for _ in range(14):
+            d = fn()
+        ts = []
+        for _ in range(runs):
+            fence()
+            t0 = time.perf_counter()
+            d = fn()
+            fence()
+            ts.append(time.perf_counter() - t0)
+        rb = getattr(bfs, "readback_", None)
+        modes = getattr(bfs, "bfs_slot_modes_", None)
+        out[mode] = {"s": float(np.median(ts)), "d": d, "push_iterations": getattr(bfs, "push_iterations_", None),
+                     "readback": dict(rb) if rb is not None else None, "slot_modes": None if modes is None else modes.copy()}
+    return out
+
+
+def edges_traversed(bfs, raw, d, iters, modes=None):
     """beside the nominal GTEPS, the edges a run actually looked at, from how the device evaluated every slot
     (BFS.bfs_slot_modes_): scattered = the non-zeros of the frontier's columns; streamed row-wise = every non-zero of the
     matrix; bottom-up = AT MOST the non-zeros of the rows not reached before the slot (a row stops at its first hit)."""
     d = d.astype(np.int64)
-    modes = [int(v) for v in bfs.bfs_slot_modes_]
+    modes = [int(v) for v in (bfs.bfs_slot_modes_ if modes is None else modes)]
     n = d.shape[0]
     ip = raw.adj_indptr.astype(np.int64)
     row_len = np.zeros(n, np.int64)
@@ -137,14 +163,15 @@ def run_graph(name, raw, iters, dev, runs=5, spmv_steps=100, apps=("bfs", "pager
         bfs.set_up_runtime()
         bfs.load_and_format_matrix(raw, True)
         bfs.send_matrix_host_to_device()
-        t_pull, d_pull = timed(lambda: bfs.pull(src, iters), runs, warm=14)
-        e_pull = edges_traversed(bfs, raw, d_pull, iters) if getattr(bfs, "bfs_slot_modes_", None) is not None else None
-        t_pp, d_pp = timed(lambda: bfs.pull_push(src, iters, 0.001), runs, warm=14)
-        e_pp = edges_traversed(bfs, raw, d_pp, iters) if getattr(bfs, "bfs_slot_modes_", None) is not None else None
+        bt = bfs_times(bfs, src, iters, runs)
+        t_pull, d_pull, t_pp, d_pp = bt["pull"]["s"], bt["pull"]["d"], bt["pull_push"]["s"], bt["pull_push"]["d"]
+        e_pull = edges_traversed(bfs, raw, d_pull, iters, bt["pull"]["slot_modes"]) if bt["pull"]["slot_modes"] is not None else None
+        e_pp = edges_traversed(bfs, raw, d_pp, iters, bt["pull_push"]["slot_modes"]) if bt["pull_push"]["slot_modes"] is not None else None
         nnz = bfs.get_nnz()
         rec["bfs"] = {"source": src, "pull_ms": round(t_pull * 1e3, 3), "pull_gteps": round(nnz * iters / t_pull / 1e9, 1),
                       "pull_push_ms": round(t_pp * 1e3, 3), "pull_push_gteps": round(nnz * iters / t_pp / 1e9, 1),
-                      "push_iterations": bfs.push_iterations_, "reached": int((d_pull != 0).sum()),
+                      "push_iterations": bt["pull_push"]["push_iterations"], "reached": int((d_pull != 0).sum()),
+                      "readback": {k: (bt[k]["readback"] or {}).get("way") for k in ("pull_push", "pull")},
                       "ok": bool(np.array_equal(d_pull, d_pp))}
         if e_pp is not None:
             rec["bfs"].update({"pull_push_gteps_traversed": round(e_pp[0] / t_pp / 1e9, 1), "pull_gteps_traversed": round(e_pull[0] / t_pull / 1e9, 1),

@@ -423,9 +423,13 @@ class BFS(_GraphApp):
                     and os.environ.get("GRAPHLILY_BFS_U8", "1") != "0" and capi.host_unpack_threads() >= 4)
         # The packed read-back's second half runs on HOST threads: on a busy box it loses to the plain float copy (round 3:
         # 0.39 - 0.52 ms for the same call over the round's boxes; same-box, same-process spread 0.39 - 0.55).  So the driver
-        # MEASURES: both ways are timed (whole call, exponential average), the faster one is used, and every 32nd call tries
-        # the other one again.  GRAPHLILY_BFS_U8=0 / =2 pin the float / packed way.
-        rb = st.setdefault("readback", {"packed": None, "float": None, "calls": 0})
+        # MEASURES: both ways are timed (whole call), the faster one by the MEDIAN of its last seven calls is used, and every
+        # 32nd call tries the other one again.  The books are kept per schedule (pull and pull_push each have their own: round 4
+        # kept one exponential average for both, and the first calls of the second mode -- which enqueue and record its graph,
+        # 12 ms -- poisoned the average of whichever way was active: the mode measured second ran on the slower way, 33 %
+        # apart between two legs of one bench process).  GRAPHLILY_BFS_U8=0 / =2 pin the float / packed way.
+        rb = st.setdefault("readback", {}).setdefault((N, float(threshold), back, pull_only, lo, own),
+                                                      {"packed": None, "float": None, "calls": 0, "t_packed": [], "t_float": []})
         pin = os.environ.get("GRAPHLILY_BFS_U8", "1")
         if not can_pack or timed:
             as_bytes = can_pack
@@ -497,7 +501,10 @@ class BFS(_GraphApp):
             seen = rb.setdefault("n_" + way, 0)
             rb["n_" + way] = seen + 1
             if seen >= 2:
-                rb[way] = dt if rb[way] is None else 0.75 * rb[way] + 0.25 * dt
+                ts = rb["t_" + way]
+                ts.append(dt)
+                del ts[:-7]
+                rb[way] = float(np.median(ts))
             rb["calls"] += 1
             self.readback_ = {"way": way, "packed_ms": None if rb["packed"] is None else round(rb["packed"] * 1e3, 4),
                               "float_ms": None if rb["float"] is None else round(rb["float"] * 1e3, 4)}

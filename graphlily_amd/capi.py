@@ -329,7 +329,7 @@ GL_VAL_FLOAT, GL_VAL_UNSIGNED, GL_VAL_UFIXED_32_8 = 0, 1, 2
 GL_PLAN_HOST_FORMAT = 8
 GL_PLAN_DEVICE_FORMAT = 16
 GL_PLAN_REFERENCE_ORDER = 32
-PLAN_ARRAYS = {"entries": 0, "bases": 1, "units": 2, "hub_rows": 3, "spans": 4}
+PLAN_ARRAYS = {"entries": 0, "bases": 1, "units": 2, "hub_rows": 3, "spans": 4, "hot": 5, "hot_hdr": 6, "present": 7}
 GL_ERR_UNSUPPORTED = -5
 
 

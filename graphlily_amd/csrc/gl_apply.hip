@@ -54,41 +54,6 @@ __global__ __launch_bounds__(256) void ewise_add_kernel(const float *__restrict_
     }
 }
 
-// the same under a launch predicate: nothing happens unless *flag != 0 (a pull iteration of a device-resident SSSP schedule)
-__global__ __launch_bounds__(256) void ewise_add_flagged_kernel(const float *__restrict__ in, float *__restrict__ out, uint32_t len, float val,
-                                                                const uint32_t *__restrict__ flag) {
-    if (*flag == 0u) return;
-    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
-    const uint32_t n4 = len >> 2;   // (both vectors 16-byte aligned: checked by the caller)
-    const float4 *in4 = reinterpret_cast<const float4 *>(in);
-    float4 *out4 = reinterpret_cast<float4 *>(out);
-    for (uint32_t i = tid; i < n4; i += stride) {
-        float4 v = in4[i];
-        v.x += val; v.y += val; v.z += val; v.w += val;
-        out4[i] = v;
-    }
-    for (uint32_t i = (n4 << 2) + tid; i < len; i += stride) out[i] = in[i] + val;
-}
-
-// gl_sssp_begin: SSSP::pull_push's set-up (app/sssp.h:197-212) on the device -- distance = zero except 0 at the source
-// (ctl[2], written by the host), the one-entry frontier {1, (source, 0)}, the control words of the push -> pull decision
-// (Direction, gl_compact.h) and the per-slot pull flags ctl[32 + s]
-__global__ __launch_bounds__(256) void sssp_begin_kernel(uint32_t *__restrict__ ctl, uint32_t ctl_words, float *__restrict__ distance, uint32_t n,
-                                                         float zero, gl_idx_val *__restrict__ frontier) {
-    const uint32_t src = ctl[2];
-    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
-    for (uint32_t i = tid; i < n; i += stride) distance[i] = (i == src) ? 0.0f : zero;
-    // (grid-stride: a small vector with many iteration slots has more control words than the launch has threads)
-    for (uint32_t w = tid; w < ctl_words; w += stride)
-        if (w != 2u) ctl[w] = w == 0u ? 0xffffffffu : (w == 4u ? 0xffffffffu : (w == 15u ? ctl_words : 0u));
-    if (tid == 0) {
-        frontier[0].index = 1u;
-        frontier[0].val = 0.0f;
-        frontier[1].index = src;
-        frontier[1].val = 0.0f;
-    }
-}
-
 // hw/kernel_assign_vector_dense_impl.h:8-47
 template <int MASK>
 __global__ __launch_bounds__(256) void assign_dense_kernel(const float *__restrict__ mask, float *__restrict__ inout,
@@ -165,34 +130,6 @@ __global__ __launch_bounds__(256) void sparse_scatter_kernel(const gl_idx_val *_
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
         gl_idx_val e = sv[1u + i];
         if (e.index < range) dense[e.index] = e.val;
-    }
-}
-
-// ---- device-side bookkeeping of a whole BFS (gl_bfs_begin, gl_spmspv_run_gated, gl_bfs_pull_step_back): eight words,
-//      ctl[0] = first pull slot (0xffffffff while pushing), ctl[1] = push iterations done, ctl[2] = source vertex (written
-//      by the host before the schedule), ctl[4] = slot whose pull result is wanted as a list, ctl[5..6] = count / ticket
-//      of the running pull step
-__global__ __launch_bounds__(256) void bfs_begin_kernel(uint32_t *__restrict__ ctl, float *__restrict__ distance, uint32_t n,
-                                                        gl_idx_val *__restrict__ frontier, uint32_t *__restrict__ bits, uint32_t words) {
-    const uint32_t src = ctl[2];
-    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
-    for (uint32_t i = tid; i < n; i += stride) distance[i] = (i == src) ? 1.0f : 0.0f;      // app/bfs.h:168-171
-    if (bits)
-        for (uint32_t w = tid; w < words; w += stride) bits[w] = (w == (src >> 5)) ? (1u << (src & 31u)) : 0u;
-    if (tid == 0) {
-        ctl[3] = 0u;
-        ctl[4] = 0xffffffffu;   // no slot has asked for its pull result as a list yet (gl_bfs_pull_step_back)
-        ctl[5] = 0u;            // new-frontier count of the running pull step
-        ctl[6] = 0u;            // its workgroup ticket
-        ctl[7] = 0u;
-        if (frontier) {
-            frontier[0].index = 1u;          // one source vertex (app/bfs.h:162-166)
-            frontier[0].val = 0.0f;
-            frontier[1].index = src;
-            frontier[1].val = 1.0f;
-        }
-        ctl[0] = frontier ? 0xffffffffu : 0u;   // first pull slot: none yet / every slot
-        ctl[1] = 0u;
     }
 }
 

@@ -65,9 +65,11 @@ struct Context {
     // while such a graph is alive instead of hanging
     bool capturing = false;
     std::vector<int *> capture_refs;
+    uint64_t graph_launches = 0;       // gl_graph_launch calls so far (gl_spmspv_wait: is a plan's completion record still its last run's?)
 };
 
 Context &ctx();
+inline uint64_t graph_launches() { return ctx().graph_launches; }
 
 // bench.py's per-kernel HIP-event timing (gl_prof_begin / gl_prof_end)
 struct Profiler {

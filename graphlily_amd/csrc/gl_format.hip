@@ -14,6 +14,8 @@
 //                                         are tested per step, so the walk costs ~1/64 step per group)
 //   * emission                            a wave per group writes the 64 entries in the stream's final
 //                                         lane-interleaved order
+//   * the run-coded hot stream            run starts flagged by comparing neighbouring keys, ONE inclusive scan (rocPRIM)
+//                                         numbers the runs, a wave per hot group writes slots, values, run mask and base
 // Both formatters produce byte-identical arrays (tests/test_gpu_format.py compares them through gl_spmv_plan_export).
 #include <cstring>   // rocPRIM's texture iterator calls memset from host code
 
@@ -167,12 +169,13 @@ __global__ __launch_bounds__(kFmtThreads) void fmt_bounds_kernel(const K *__rest
 
 struct UnitDesc {
     uint32_t cold_begin, cold_end, hot_begin, hot_end;   // positions in the sorted arrays
-    uint32_t goff, r0, nrows_direct, hub_off;            // first group; first row; #rows | direct << 31; first hub_rows slot of the block
-    uint32_t nhub, seg, pad0, pad1;
+    uint32_t goff, r0, nrows_direct, hub_off;            // first cold group; first row; #rows | direct << 31; first hub_rows slot of the block
+    uint32_t nhub, seg, hot_e0, present_off;             // first hot element; first entry of the unit's present list
+    uint32_t nhot_groups, pad0, pad1, pad2;              // hot groups incl. the padding up to whole elements
 };
 
 struct UnitGroups {
-    uint32_t ncold_raw, ncold, nhot_raw, nhot;   // groups with entries / after padding to the stream layout's multiple
+    uint32_t ncold_raw, ncold;   // cold groups with entries / after padding to the stream layout's multiple
 };
 
 // One wave per unit: cut the unit's cold piece into groups.  A group holds <= 64 consecutive entries whose gather
@@ -221,27 +224,22 @@ __global__ __launch_bounds__(64) void fmt_group_kernel(const K *__restrict__ key
         gstart[u.goff + k] = 0u;
         gcount[u.goff + k] = 0u;
     }
-    const uint32_t nhot_raw = (u.hot_end - u.hot_begin + 63u) / 64u;
-    const uint32_t nhot = (nhot_raw + group_mult - 1u) / group_mult * group_mult;
     if (lane == 0) {
-        ug[blockIdx.x] = UnitGroups{ncold_raw, ncold, nhot_raw, nhot};
-        plan_units[2u * blockIdx.x] = make_uint4(u.goff, ncold, u.r0, u.nrows_direct);
-        plan_units[2u * blockIdx.x + 1u] = make_uint4(u.hub_off, u.nhub, nhot, u.seg);
+        ug[blockIdx.x] = UnitGroups{ncold_raw, ncold};
+        plan_units[3u * blockIdx.x] = make_uint4(u.goff, ncold, u.r0, u.nrows_direct);
+        plan_units[3u * blockIdx.x + 1u] = make_uint4(u.hub_off, u.nhub, u.nhot_groups, u.seg);
     }
 }
 
-// stream layouts as in gl_spmv.hip: 0 narrow (8 B), 1 wide (two 8-B groups lane-interleaved), 2 pair (two 4-B groups),
-// 3 quad (four 4-B groups)
+// cold stream layouts as in gl_spmv.hip: 1 wide (two 8-B groups lane-interleaved), 3 quad (four 4-B groups)
 template <int LAYOUT>
 __device__ __forceinline__ void fmt_store(void *entries, uint32_t g, uint32_t lane, uint32_t ex, uint32_t ey) {
-    if (LAYOUT == 0) static_cast<uint2 *>(entries)[(size_t)g * 64u + lane] = make_uint2(ex, ey);
-    else if (LAYOUT == 1) static_cast<uint2 *>(entries)[(size_t)(g >> 1) * 128u + 2u * lane + (g & 1u)] = make_uint2(ex, ey);
-    else if (LAYOUT == 2) static_cast<uint32_t *>(entries)[(size_t)(g >> 1) * 128u + 2u * lane + (g & 1u)] = ex;
+    if (LAYOUT == 1) static_cast<uint2 *>(entries)[(size_t)(g >> 1) * 128u + 2u * lane + (g & 1u)] = make_uint2(ex, ey);
     else static_cast<uint32_t *>(entries)[(size_t)(g >> 2) * 256u + 4u * lane + (g & 3u)] = ex;
 }
 
-// One workgroup per unit, one wave per group: entry = (gather index - base) << 14 | slot, value.  Hub rows (their list
-// is per block) spread over 16 private slots picked by the entry's position in its group.
+// One workgroup per unit, one wave per cold group: entry = (gather index - base) << 14 | slot, value.  Hub rows (their
+// list is per block) spread over 16 private slots picked by the entry's position in its group.
 template <typename K, int LAYOUT>
 __global__ __launch_bounds__(kThreads) void fmt_emit_kernel(const K *__restrict__ keys, const uint2 *__restrict__ payload,
                                                             const UnitDesc *__restrict__ units, const UnitGroups *__restrict__ ug,
@@ -260,21 +258,11 @@ __global__ __launch_bounds__(kThreads) void fmt_emit_kernel(const K *__restrict_
         if (threadIdx.x < u.nhub) hub_of[hub_rows[u.hub_off + threadIdx.x]] = (uint8_t)threadIdx.x;
         __syncthreads();
     }
-    const uint32_t total = n.ncold + n.nhot;
-    for (uint32_t k = wave; k < total; k += kWaves) {
+    for (uint32_t k = wave; k < n.ncold; k += kWaves) {
         const uint32_t g = u.goff + k;
-        uint32_t st, cnt, base = 0u;
-        const bool cold = k < n.ncold;
-        if (cold) {
-            st = gstart[g];
-            cnt = gcount[g];
-            if (cnt) base = (uint32_t)(keys[st] & cmask);
-        } else {
-            const uint32_t kh = k - n.ncold;
-            st = u.hot_begin + kh * 64u;
-            cnt = kh < n.nhot_raw ? min(64u, u.hot_end - st) : 0u;
-        }
-        uint32_t ex = kRowPad, ey = 0u;
+        const uint32_t st = gstart[g], cnt = gcount[g];
+        const uint32_t base = cnt ? (uint32_t)(keys[st] & cmask) : 0u;
+        uint32_t ex = nrows + kHubSlots * u.nhub + lane, ey = 0u;   // padding: the lane's dummy slot of the block
         if (lane < cnt) {
             const uint32_t idx = (uint32_t)(keys[st + lane] & cmask);
             const uint2 pl = payload[st + lane];
@@ -289,6 +277,94 @@ __global__ __launch_bounds__(kThreads) void fmt_emit_kernel(const K *__restrict_
         fmt_store<LAYOUT>(entries, g, lane, ex, ey);
         if (lane == 0) bases[g] = base;
     }
+}
+
+// ---- the run-coded hot stream (gl_spmv_plan.h)
+// flags[i] = 1 where sorted position i is a hot entry that starts a run: its key differs from its predecessor's (block,
+// hot bit or slot).  Dropped entries (the bit above the block field) and cold ones carry hot bit 0.
+template <typename K>
+__global__ __launch_bounds__(kFmtThreads) void fmt_run_flags_kernel(const K *__restrict__ keys, uint64_t n, uint32_t cb, uint32_t *__restrict__ flags) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kFmtThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kFmtThreads) {
+        const K k = keys[i];
+        flags[i] = (((k >> cb) & (K)1) != 0 && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+    }
+}
+// a unit that begins inside a run (column segments cut the hot entries by position) starts one of its own
+__global__ __launch_bounds__(kFmtThreads) void fmt_run_unit_starts_kernel(const UnitDesc *__restrict__ units, uint32_t nunits, uint32_t *__restrict__ flags) {
+    const uint32_t u = blockIdx.x * kFmtThreads + threadIdx.x;
+    if (u < nunits && units[u].hot_begin < units[u].hot_end) flags[units[u].hot_begin] = 1u;
+}
+
+// One workgroup per unit, one wave per hot group.  runs = inclusive scan of the flags: entry i's table slot within the unit
+// is runs[i] - runs[hot_begin].
+template <typename K, bool PATTERN>
+__global__ __launch_bounds__(kThreads) void fmt_emit_hot_kernel(const K *__restrict__ keys, const uint2 *__restrict__ payload,
+                                                                const uint32_t *__restrict__ runs, const UnitDesc *__restrict__ units,
+                                                                const uint32_t *__restrict__ hub_rows, uint32_t cb,
+                                                                unsigned char *__restrict__ hot, uint32_t *__restrict__ hot_hdr,
+                                                                uint16_t *__restrict__ present, uint4 *__restrict__ plan_units) {
+    __shared__ uint8_t hub_of[kMaxBlockRows + 1];
+    constexpr uint32_t HG = PATTERN ? kHotGroupsPattern : kHotGroupsGeneral;
+    constexpr uint32_t EB = PATTERN ? kHotElemBytesPattern : kHotElemBytesGeneral;
+    const UnitDesc u = units[blockIdx.x];
+    const uint32_t nrows = u.nrows_direct & 0xffffu;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const K cmask = ((K)1 << cb) - 1;
+    if (u.nhub) {
+        for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) hub_of[i] = 0xffu;
+        __syncthreads();
+        if (threadIdx.x < u.nhub) hub_of[hub_rows[u.hub_off + threadIdx.x]] = (uint8_t)threadIdx.x;
+        __syncthreads();
+    }
+    const uint32_t m = u.hot_end - u.hot_begin, nraw = (m + 63u) / 64u;
+    const uint32_t s0 = m ? runs[u.hot_begin] : 0u;
+    const uint32_t pad_slot = nrows + kHubSlots * u.nhub + lane;   // padding: the lane's dummy slot of the block
+    for (uint32_t hg = wave; hg < u.nhot_groups; hg += kWaves) {
+        const uint32_t st = u.hot_begin + hg * 64u, cnt = hg < nraw ? min(64u, u.hot_end - st) : 0u;
+        const size_t e = (size_t)u.hot_e0 + hg / HG;
+        const uint32_t k = hg % HG;
+        uint32_t local = 0u;
+        bool start = false;
+        if (lane >= cnt) {
+            reinterpret_cast<uint16_t *>(hot + e * EB)[lane * (PATTERN ? 8u : 4u) + k] = (uint16_t)pad_slot;   // (values stay 0)
+        } else {
+            const uint32_t i = st + lane, si = runs[i];
+            local = si - s0;
+            start = i == u.hot_begin || runs[i - 1u] != si;
+            const uint32_t slot_col = (uint32_t)(keys[i] & cmask);
+            if (start) present[u.present_off + local] = (uint16_t)slot_col;
+            const uint2 pl = payload[i];
+            uint32_t slot = pl.x;
+            if (u.nhub) {
+                const uint32_t hb = hub_of[pl.x];
+                if (hb != 0xffu) slot = nrows + kHubSlots * hb + (lane & (kHubSlots - 1u));
+            }
+            unsigned char *el = hot + e * EB;
+            if (PATTERN) {
+                reinterpret_cast<uint16_t *>(el)[lane * 8u + k] = (uint16_t)slot;
+            } else {
+                reinterpret_cast<uint16_t *>(el)[lane * 4u + k] = (uint16_t)slot;
+                reinterpret_cast<uint32_t *>(el + 512)[lane * 4u + k] = pl.y;
+            }
+        }
+        const unsigned long long mask = __ballot(start && lane >= 1u) >> 1;   // bit l - 1: entry l starts a run
+        const uint32_t base = __shfl(local, 0);
+        if (lane == 0) {
+            uint32_t *hd = hot_hdr + e * (kHotHdrWordsPerGroup * HG);
+            hd[2u * k] = (uint32_t)mask;
+            hd[2u * k + 1u] = (uint32_t)(mask >> 32);
+            hd[2u * HG + k] = base;
+        }
+    }
+    if (threadIdx.x == 0)
+        plan_units[3u * blockIdx.x + 2u] = make_uint4(u.hot_e0, u.present_off, m ? runs[u.hot_end - 1u] - s0 + 1u : 0u, 0u);
+}
+
+// the element of slack behind the stream (the kernel's clamped loads land there, never accumulated): kRowPad in every slot;
+// values start as 0 everywhere
+__global__ void fmt_fill_hot_kernel(uint32_t *hot, size_t elems, uint32_t words_per_elem, uint32_t slot_words) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < elems * words_per_elem; i += (size_t)gridDim.x * 256u)
+        hot[i] = (i % words_per_elem) < slot_words ? (kRowPad | (kRowPad << 16)) : 0u;
 }
 
 __global__ void fmt_fill_u32_kernel(uint32_t *dst, uint32_t v, size_t n) {
@@ -333,7 +409,8 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     const uint32_t nblocks = bp.nblocks, nunits = bp.nunits;
     const uint32_t rows = c->row_end - c->row_begin;
     const uint64_t nnz = c->nnz;
-    const uint64_t total_groups = e.unit_goff[nunits];
+    const uint32_t hot_groups = e.pattern ? kHotGroupsPattern : kHotGroupsGeneral;
+    const uint32_t hot_elem_bytes = e.pattern ? kHotElemBytesPattern : kHotElemBytesGeneral;
 
     DevMem d_bstart, d_colmap, d_keys, d_keys2, d_pl, d_pl2, d_off;
     int rc;
@@ -364,9 +441,15 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     hub_count.assign(nblocks, 0u);
     std::vector<UnitDesc> units(nunits);
     uint64_t hn = 0;
+    std::vector<uint64_t> mcs(nblocks), mhs(nblocks);
+    for (uint32_t b = 0; b < nblocks; b++) mcs[b] = off[2 * b + 1] - off[2 * b], mhs[b] = off[2 * b + 2] - off[2 * b + 1];
+    const UnitLayout ul = layout_units(bp, mcs, mhs, e.jump_slack, hot_groups, e.nhot_table);
+    const uint64_t total_groups = ul.cold_goff[nunits], hot_elems = ul.hot_e0[nunits];
+    if (total_groups >= 0xffffffffull || hot_elems >= 0xffffffffull || ul.present_off[nunits] >= 0xffffffffull)
+        return set_error(GL_ERR_UNSUPPORTED, "plan creation: more than 2^32 - 1 groups in a shard");
     for (uint32_t b = 0; b < nblocks; b++) {
         const uint32_t r0 = bp.bstart[b], r1 = bp.bstart[b + 1];
-        const uint64_t mc = off[2 * b + 1] - off[2 * b], mh = off[2 * b + 2] - off[2 * b + 1], m = mc + mh;
+        const uint64_t mc = mcs[b], mh = mhs[b], m = mc + mh;
         hn += mh;
         const uint64_t thr = std::max<uint64_t>(256, m / (uint64_t)e.hub_div);
         uint32_t nh = 0;
@@ -387,13 +470,17 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
             u.cold_end = (uint32_t)(off[2 * b] + mc * (sg + 1) / S);
             u.hot_begin = (uint32_t)(off[2 * b + 1] + mh * sg / S);
             u.hot_end = (uint32_t)(off[2 * b + 1] + mh * (sg + 1) / S);
-            u.goff = (uint32_t)e.unit_goff[bp.unit_of[sg][b]];
+            const size_t ui = bp.unit_of[sg][b];
+            u.goff = (uint32_t)ul.cold_goff[ui];
             u.r0 = r0;
             u.nrows_direct = (r1 - r0) | (bp.all_direct ? 0x80000000u : 0u);
             u.hub_off = (uint32_t)((size_t)b * kMaxHubRows);
             u.nhub = nh;
             u.seg = sg;
-            u.pad0 = u.pad1 = 0u;
+            u.hot_e0 = (uint32_t)ul.hot_e0[ui];
+            u.present_off = (uint32_t)ul.present_off[ui];
+            u.nhot_groups = (uint32_t)(ul.hot_e0[ui + 1] - ul.hot_e0[ui]) * hot_groups;
+            u.pad0 = u.pad1 = u.pad2 = 0u;
         }
     }
     *hot_nnz = hn;
@@ -404,13 +491,32 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     const size_t n_bases = (size_t)total_groups + 4u;
     GL_HIP(hipMalloc((void **)&p->d_entries, entry_bytes + tail_bytes));
     GL_HIP(hipMalloc((void **)&p->d_bases, n_bases * 4u));
-    GL_HIP(hipMalloc((void **)&p->d_units, (size_t)nunits * 2u * sizeof(uint4) + 16u));
+    GL_HIP(hipMalloc((void **)&p->d_units, (size_t)nunits * 3u * sizeof(uint4) + 16u));
     GL_HIP(hipMalloc((void **)&p->d_hub_rows, hub_rows.size() * 4u + 16u));
-    p->device_bytes += entry_bytes + tail_bytes + n_bases * 4u + (size_t)nunits * 2u * sizeof(uint4) + hub_rows.size() * 4u;
+    // the run-coded hot stream: one element of slack behind it (the kernel's clamped loads), like the host formatter's vectors
+    const size_t hot_bytes = (size_t)(hot_elems + 1u) * hot_elem_bytes;
+    const size_t hdr_bytes = (size_t)(hot_elems + 1u) * kHotHdrWordsPerGroup * hot_groups * 4u;
+    const size_t present_bytes = (size_t)std::max<uint64_t>(ul.present_off[nunits], 2u) * 2u;
+    GL_HIP(hipMalloc((void **)&p->d_hot, hot_bytes));
+    GL_HIP(hipMalloc((void **)&p->d_hot_hdr, hdr_bytes));
+    GL_HIP(hipMalloc((void **)&p->d_present, present_bytes));
+    p->device_bytes += entry_bytes + tail_bytes + n_bases * 4u + (size_t)nunits * 3u * sizeof(uint4) + hub_rows.size() * 4u +
+                       hot_bytes + hdr_bytes + present_bytes;
     p->b_entries = entry_bytes + tail_bytes;
     p->b_bases = n_bases * 4u;
-    p->b_units = (size_t)nunits * 2u * sizeof(uint4);
+    p->b_units = (size_t)nunits * 3u * sizeof(uint4);
     p->b_hub_rows = hub_rows.size() * 4u;
+    p->b_hot = hot_bytes;
+    p->b_hot_hdr = hdr_bytes;
+    p->b_present = present_bytes;
+    p->ngroups = total_groups;
+    p->nhot_elems = hot_elems;
+    GL_HIP(hipMemsetAsync(p->d_hot_hdr, 0, hdr_bytes, s));
+    GL_HIP(hipMemsetAsync(p->d_present, 0, present_bytes, s));
+    GL_HIP(hipMemsetAsync(p->d_hot, 0, hot_bytes, s));
+    fmt_fill_hot_kernel<<<1, 256, 0, s>>>(reinterpret_cast<uint32_t *>(p->d_hot + (size_t)hot_elems * hot_elem_bytes), 1u, hot_elem_bytes / 4u,
+                                          hot_groups * 64u * 2u / 4u);
+    GL_LAUNCH_CHECK();
     GL_HIP(hipMemsetAsync(p->d_entries, 0, entry_bytes, s));
     GL_HIP(hipMemsetAsync(p->d_bases, 0, n_bases * 4u, s));
     fmt_fill_u32_kernel<<<1, 256, 0, s>>>(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(p->d_entries) + entry_bytes), kRowPad, tail_bytes / 4u);
@@ -425,20 +531,42 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     fmt_group_kernel<K><<<nunits, 64, 0, s>>>(keys, d_units.as<UnitDesc>(), cb, e.group_mult, d_gstart.as<uint32_t>(), d_gcount.as<uint32_t>(),
                                               d_ug.as<UnitGroups>(), p->d_units);
     GL_LAUNCH_CHECK();
-    const int layout = e.pattern ? (e.wide ? 3 : 2) : (e.wide ? 1 : 0);
 #define GL_FMT_EMIT(L)                                                                                                           \
     fmt_emit_kernel<K, L><<<nunits, kThreads, 0, s>>>(keys, payload, d_units.as<UnitDesc>(), d_ug.as<UnitGroups>(),             \
                                                       d_gstart.as<uint32_t>(), d_gcount.as<uint32_t>(), p->d_hub_rows, cb,      \
                                                       (void *)p->d_entries, p->d_bases)
-    switch (layout) {
-        case 0: GL_FMT_EMIT(0); break;
-        case 1: GL_FMT_EMIT(1); break;
-        case 2: GL_FMT_EMIT(2); break;
-        default: GL_FMT_EMIT(3); break;
-    }
+    if (e.pattern) GL_FMT_EMIT(3);
+    else GL_FMT_EMIT(1);
 #undef GL_FMT_EMIT
     GL_LAUNCH_CHECK();
-    GL_HIP(hipStreamSynchronize(s));   // scratch and host vectors die here
+    // ---- the hot stream: number the runs (one scan over the sorted entries), then a wave per hot group
+    {
+        DevMem d_flags, d_runs, d_tmp;
+        if ((rc = d_flags.alloc(std::max<uint64_t>(nnz, 1u) * 4u)) != GL_OK || (rc = d_runs.alloc(std::max<uint64_t>(nnz, 1u) * 4u)) != GL_OK) return rc;
+        fmt_run_flags_kernel<K><<<std::min<unsigned>(cdiv(std::max<uint64_t>(nnz, 1u), kFmtThreads), (unsigned)ctx().num_cus * 32u), kFmtThreads, 0, s>>>(
+            keys, nnz, cb, d_flags.as<uint32_t>());
+        GL_LAUNCH_CHECK();
+        fmt_run_unit_starts_kernel<<<cdiv(nunits, kFmtThreads), kFmtThreads, 0, s>>>(d_units.as<UnitDesc>(), nunits, d_flags.as<uint32_t>());
+        GL_LAUNCH_CHECK();
+        size_t tmp_bytes = 0;
+        GL_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, d_flags.as<uint32_t>(), d_runs.as<uint32_t>(), (size_t)nnz, rocprim::plus<uint32_t>(), s));
+        if ((rc = d_tmp.alloc(tmp_bytes)) != GL_OK) return rc;
+        GL_HIP(rocprim::inclusive_scan(d_tmp.p, tmp_bytes, d_flags.as<uint32_t>(), d_runs.as<uint32_t>(), (size_t)nnz, rocprim::plus<uint32_t>(), s));
+        if (e.pattern)
+            fmt_emit_hot_kernel<K, true><<<nunits, kThreads, 0, s>>>(keys, payload, d_runs.as<uint32_t>(), d_units.as<UnitDesc>(), p->d_hub_rows, cb,
+                                                                     p->d_hot, p->d_hot_hdr, p->d_present, p->d_units);
+        else
+            fmt_emit_hot_kernel<K, false><<<nunits, kThreads, 0, s>>>(keys, payload, d_runs.as<uint32_t>(), d_units.as<UnitDesc>(), p->d_hub_rows, cb,
+                                                                      p->d_hot, p->d_hot_hdr, p->d_present, p->d_units);
+        GL_LAUNCH_CHECK();
+        GL_HIP(hipStreamSynchronize(s));   // scratch dies here
+    }
+    // the LDS table holds the longest present list
+    std::vector<uint4> pu((size_t)nunits * 3u);
+    GL_HIP(hipMemcpy(pu.data(), p->d_units, pu.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    uint32_t max_present = 0;
+    for (uint32_t u = 0; u < nunits; u++) max_present = std::max(max_present, pu[3u * u + 2u].z);
+    p->nhot_lds = (max_present + 63u) / 64u * 64u;
     return GL_OK;
 }
 

@@ -410,6 +410,7 @@ int gl_graph_launch(gl_graph graph) {
     GL_REQUIRE_INIT();
     GL_ARG(graph != nullptr);
     GL_HIP(hipGraphLaunch(graph->exec, gl::ctx().stream));
+    gl::ctx().graph_launches++;   // completion records of runs enqueued before the replay no longer describe their plans' last run
     return GL_OK;
 }
 

@@ -41,11 +41,12 @@ struct gl_spmspv_plan_s {
     uint32_t *d_cursor = nullptr;      // tiles, zero between runs
     uint32_t *d_state = nullptr;       // tiles, zero between runs
     uint32_t *d_sync = nullptr;        // gl::kSyncWords, zero between runs
-    unsigned long long *d_slices = nullptr;  // gl::kBinMaxSlices tagged slice sums of the bin kernel's rendezvous
+    unsigned long long *d_slices = nullptr;  // 2 x gl::kBinMaxSlices tagged slice sums of the bin kernel's rendezvous (by round parity)
     // a blocking caller's completion record: the fold's last workgroup stores seq << 32 | count (gl_spmspv_wait)
     unsigned long long *h_rec = nullptr;     // page-locked, device-visible
     uint32_t seq = 0;                        // of the last run that was given the record
     bool rec_pending = false;                // that run is the last one enqueued on this plan
+    uint64_t rec_epoch = 0;                  // gl::graph_launches() when it was enqueued: a replayed graph may have rerun the plan since
     uint32_t nnz_hint = ~0u;                 // entries of the next run's vector, if a hint said so (sizes the bin grid)
     // direction switch inside the operator ((||,&&) only): a frontier whose columns hold more than 1/32 of the
     // matrix is cheaper to apply row-wise with the attached boolean SpMV plan than to scatter
@@ -815,7 +816,7 @@ int gl_spmspv_plan_create(gl_spmspv_plan *plan, uint32_t num_rows, uint32_t num_
     size_t b_acc = (size_t)(nrows ? nrows : 1) * sizeof(float);
     const uint32_t ntiles = p->tiles.count;
     size_t b_tiles = (size_t)(ntiles + 1u) * sizeof(uint32_t);
-    size_t b_queue = (size_t)gl::kBinMaxSlices * sizeof(unsigned long long);
+    size_t b_queue = 2u * (size_t)gl::kBinMaxSlices * sizeof(unsigned long long);
     size_t b_bins = (p->binned && kept) ? kept * sizeof(uint2) : 16;
     if (!on_device && (e = hipMalloc((void **)&p->d_indptr, b_indptr)) != hipSuccess) return fail(e);
     if (!on_device && (e = hipMalloc((void **)&p->d_stream, b_stream ? b_stream : 16)) != hipSuccess) return fail(e);
@@ -977,6 +978,7 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
             t.host_rec = report ? p->h_rec : nullptr;
             t.seq = report ? ++p->seq : 0u;
             p->rec_pending = report;
+            p->rec_epoch = gl::graph_launches();
         }
         switch (op) {
             case GL_OP_MULADD: return gl::launch_tiny_mask<GL_OP_MULADD>(mask_type, t, d_mask, zero, d_inout, val, s);
@@ -1106,13 +1108,26 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     f.host_rec = report ? p->h_rec : nullptr;
     f.seq = report ? ++p->seq : 0u;
     p->rec_pending = report;
+    p->rec_epoch = gl::graph_launches();
     return gl::launch_fold(op + 3 * val_type, f, s);
+}
+
+// the record of the plan's last run has arrived: hand its count out ONCE (a later call, with other work enqueued since, reads the
+// head element instead), or report the run's failed rendezvous (gl_spmspv_bin.h kSyncErr)
+static int spmspv_take_record(gl_spmspv_plan p, unsigned long long v, uint32_t *nnz) {
+    p->rec_pending = false;
+    if ((uint32_t)v == 0xffffffffu)
+        return gl::set_error(GL_ERR_HIP, "gl_spmspv_run: a workgroup rendezvous timed out (another kernel kept workgroups of the run from "
+                             "being resident); the result list was emptied");
+    if (nnz) *nnz = (uint32_t)v;
+    return GL_OK;
 }
 
 int gl_spmspv_wait(gl_spmspv_plan p, uint32_t *nnz) {
     GL_TRACE();
     GL_REQUIRE_INIT();
     GL_ARG(p != nullptr);
+    if (p->rec_pending && p->rec_epoch != gl::graph_launches()) p->rec_pending = false;   // a graph replay may have rerun this plan
     if (p->rec_pending) {
         // the fold's last workgroup stores seq << 32 | count to page-locked memory once every result has been written: the host
         // sees it ~5 us before hipStreamSynchronize returns (profiles/r03_ubench_sync.txt)
@@ -1120,19 +1135,13 @@ int gl_spmspv_wait(gl_spmspv_plan p, uint32_t *nnz) {
         const unsigned long long want = (unsigned long long)p->seq;
         for (uint64_t spins = 0;; spins++) {
             const unsigned long long v = *rec;
-            if ((v >> 32) == want) {
-                if (nnz) *nnz = (uint32_t)v;
-                return GL_OK;
-            }
+            if ((v >> 32) == want) return spmspv_take_record(p, v, nnz);
             if (spins > (1ull << 16) && hipStreamQuery(gl::ctx().stream) != hipErrorNotReady) break;   // the stream is idle (or failed)
             __builtin_ia32_pause();
         }
         GL_HIP(hipStreamSynchronize(gl::ctx().stream));
         const unsigned long long v = *rec;
-        if ((v >> 32) == want) {
-            if (nnz) *nnz = (uint32_t)v;
-            return GL_OK;
-        }
+        if ((v >> 32) == want) return spmspv_take_record(p, v, nnz);
         return gl::set_error(GL_ERR_HIP, "gl_spmspv_wait: the run finished without its completion record (sequence %u, found %u)", p->seq,
                              (uint32_t)(v >> 32));
     }

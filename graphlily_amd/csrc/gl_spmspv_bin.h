@@ -46,7 +46,10 @@ constexpr uint32_t kFoldMaxRounds = kFoldMaxRows / kFoldThreads;   // 16 rounds 
 // words of gl_spmspv_plan_s::d_sync.  kSyncGen: the generation that tags the bin kernel's slice sums and the fold kernel's tile
 // states, starts at 1 and only grows (the fold's last tile advances it); kSyncFoldTicket: tiles handed out so far (64 bits,
 // only grows); kSyncFoldDone: finished workgroups << 32 | their entries (64 bits), zero between runs
-enum : uint32_t { kSyncGen = 0, kSyncFoldDone = 4 /* 64 bits */, kSyncFoldTicket = 8 /* 64 bits */, kSyncWords = 16 };
+// kSyncErr: a rendezvous poll gave up (its spin limit ran out -- the all-workgroups-resident assumption was broken by a co-resident
+// kernel): the run's list is emptied and a blocking caller gets GL_ERR_HIP from gl_spmspv_wait instead of a wrong result
+enum : uint32_t { kSyncGen = 0, kSyncFoldDone = 4 /* 64 bits */, kSyncFoldTicket = 8 /* 64 bits */, kSyncErr = 12, kSyncWords = 16 };
+constexpr uint32_t kSpinLimit = 1u << 24;
 
 // row -> tile without a division: tile = (row * magic) >> (32 + shift), checked on the host for every tile boundary at plan
 // creation (the function is monotone, so exact boundaries make it exact everywhere); magic == 0: rows per tile is 1 << shift
@@ -70,7 +73,7 @@ struct BinArgs {
     uint32_t *cursor;           // records reserved per tile (may exceed the capacity: the surplus went to acc)
     float *acc;                 // dense accumulator of the shard's rows
     uint32_t *sync;
-    unsigned long long *slices; // kBinMaxSlices words: tag << 32 | non-zeros in the columns of a slice of the vector
+    unsigned long long *slices; // 2 x kBinMaxSlices words (by round parity): tag << 32 | non-zeros in the columns of a slice of the vector
     TileMap tiles;
     uint32_t binned;            // 0: more tiles than the kernel has counters for -- every product goes to acc
     uint32_t row_begin, num_cols;
@@ -384,7 +387,10 @@ __device__ __forceinline__ uint32_t bin_window(const BinArgs &a, BinLds &L, cons
 // b + G, ... and publishes each sum as a tagged word; every workgroup polls all S words (the grid is at most one workgroup
 // per compute unit: all are resident), scans them, finds the slice its range starts in and from there stages 1024 vector
 // entries at a time (their prefix of column lengths in LDS), a lane per product, the lane's column by binary search.
-// Tags: sync[kSyncGen] + round; the last workgroup to leave advances the generation, so the words need no reset.
+// Tags: sync[kSyncGen] + round; the last workgroup to leave advances the generation, so the words need no reset.  Vectors of
+// more than 2048 x E entries take several rounds; the words are DOUBLE-BUFFERED by round parity: a workgroup that leaves round r
+// early publishes round r + 1 into the other half while slower ones still poll round r, and nobody can be two rounds ahead
+// (round r + 1's rendezvous needs everybody's r + 1 publication, which a workgroup makes after its last poll of round r).
 template <int OP>
 __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
     __shared__ BinLds L;
@@ -446,6 +452,7 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
         const uint32_t nv = (uint32_t)min((unsigned long long)vnnz - rbase, (unsigned long long)kBinMaxSlices * E);
         const uint32_t S = (nv + E - 1u) / E;
         const uint32_t tag = gen0 + rounds;
+        unsigned long long *slices = a.slices + (size_t)(rounds & 1u) * kBinMaxSlices;
         const gl_idx_val *vec = a.vec + 1u + rbase;
         // ---- 1. the non-zeros in the columns of my slices
         for (uint32_t sl = blk; sl < S; sl += G) {
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
                 unsigned long long sum = 0ull;
                 for (uint32_t k = 0; k < 16u; k++) sum += L.wave64[k];
                 const unsigned long long word = ((unsigned long long)tag << 32) | (sum > 0xfffffffeull ? 0xffffffffull : sum);
-                __hip_atomic_store(&a.slices[sl], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slices[sl], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
         }
@@ -484,8 +491,12 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
                     if (sl < S) {
                         unsigned long long w;
                         uint32_t spins = 0;
-                        while ((uint32_t)((w = __hip_atomic_load(&a.slices[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag && ++spins < (1u << 24))
+                        while ((uint32_t)((w = __hip_atomic_load(&slices[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag && ++spins < kSpinLimit)
                             __builtin_amdgcn_s_sleep(1);
+                        if ((uint32_t)(w >> 32) != tag) {   // gave up: the word belongs to another round -- no products from it, and the run is marked failed
+                            __hip_atomic_store(&a.sync[kSyncErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            w = 0ull;
+                        }
                         v = w & 0xffffffffull;
                         if (v == 0xffffffffull) {
                             over = true;
@@ -713,8 +724,12 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
         if (tid == 0) __hip_atomic_store(&a.state[t], tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (uint32_t u = lane; u < t; u += 64u) {
             uint32_t w, spins = 0;
-            while (((w = __hip_atomic_load(&a.state[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff0000u) != tag && ++spins < (1u << 24))
+            while (((w = __hip_atomic_load(&a.state[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff0000u) != tag && ++spins < kSpinLimit)
                 __builtin_amdgcn_s_sleep(1);
+            if ((w & 0xffff0000u) != tag) {   // gave up on a tile in front: the list cannot be placed -- the run is marked failed
+                __hip_atomic_store(&a.sync[kSyncErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w = 0u;
+            }
             before += w & 0xffffu;
         }
 #pragma unroll
@@ -744,7 +759,8 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
     if (t == T_ - 1u && tid == 0) {
         // the last tile has seen every other tile's state: the list's length, and fresh tags for the next
         // run (every workgroup of this launch has read the generation by now)
-        a.out[0].index = before + total;
+        // (a failed rendezvous -- kSyncErr, set by the bin launch in front or by this tile's own look-back -- leaves an EMPTY list)
+        a.out[0].index = __hip_atomic_load(&a.sync[kSyncErr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0u : before + total;
         a.out[0].val = a.head_val;
         __hip_atomic_store(&a.sync[kSyncGen], gen0 + (a.bin_vec ? spmspv_bin_rounds(a.bin_vec[0].index, a.bin_grid) : 1u), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -759,7 +775,12 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
         unsigned long long *done = reinterpret_cast<unsigned long long *>(a.sync + kSyncFoldDone);
         const unsigned long long old = __hip_atomic_fetch_add(done, (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(old >> 32) == T_ - 1u) {
-            const uint32_t all = (uint32_t)old + total;
+            uint32_t all = (uint32_t)old + total;
+            // every workgroup marked its failure before its arrival above: count 0xffffffff tells gl_spmspv_wait, the mark is cleared
+            if (__hip_atomic_load(&a.sync[kSyncErr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                all = 0xffffffffu;
+                __hip_atomic_store(&a.sync[kSyncErr], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __hip_atomic_store(a.host_rec, ((unsigned long long)a.seq << 32) | all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next run's first arrival is a launch away)
         }

@@ -19,7 +19,7 @@
 // (||,&&)-only bit layout lives in gl_spmv_bool.hip.
 // Hence the layout -- the CDNA4 counterpart of the FPGA's "dense-vector tile in URAM + output buffer
 // in URAM" partitioning (kernel_spmv_impl.h:470-495), with the roles swapped:
-//   row block   <= 15359 consecutive rows whose accumulators live in LDS for the whole sweep
+//   row block   <= 15295 consecutive rows whose accumulators live in LDS for the whole sweep
 //               (f64 for (+,x), so ds_add_f64; 32-bit ordered-int min for (min,+); plain store for (||,&&));
 //   entries     of a row block are stored COLUMN-SORTED, 8 bytes each:
 //               { (col - group_base) << 14 | row_in_block , val },  64 entries = one 512-byte group with
@@ -29,11 +29,13 @@
 //               about 256*k equally sized units exist (256 CUs); units are numbered segment-major so
 //               concurrently running workgroups sweep the same column window of x (L2 resident).
 //   hot columns the H highest-degree columns of the shard (on power-law graphs 8K columns hold a third of
-//               the non-zeros) are cached per workgroup in an LDS table; their entries form separate
-//               "hot" groups { hot_slot << 14 | row_in_block , val } that need no vector-memory gather.
-//               Cold groups are bound by the texture addresser (one gather lane per clock per CU), hot
-//               groups by HBM; a wavefront processes UC cold and UH hot groups per iteration so that
-//               both limits are worked against at the same time.
+//               the non-zeros) are cached per workgroup in an LDS table; their entries need no vector-memory
+//               gather and, sorted by column, form RUNS: the hot stream is run-coded (gl_spmv_plan.h) -- a
+//               16-bit row slot (+ the value) per entry, the column as one bit per entry and a base per
+//               group, slots numbered per unit -- 6.19 bytes per entry instead of 8 (2.19 instead of 4 in the
+//               pattern layout).  The loop is bound by the CU's vector-memory pipe (45 clocks per 512 B of
+//               stream + 4 + 2.2 clocks per line of a cold gather), so bytes per entry are what is left to
+//               save; a wavefront processes UC cold and UH hot stream elements per iteration.
 //   hub rows    a row that owns more than ~1/48 of its block's entries would make many lanes of every
 //               wavefront step hit one LDS word; its entries are spread over 16 private slots (chosen
 //               by the entry's position in its group, i.e. at format time) that are summed before the
@@ -48,12 +50,16 @@
 namespace gl {
 
 struct SpmvArgs {
-    const uint2 *entries;     // groups of 64
-    const uint32_t *bases;    // one base column per group
-    const uint4 *units;       // 2 per unit: {first group, #cold groups, first row, #rows | direct << 31}, {hub offset, #hub rows, #hot groups, segment}
+    const uint2 *entries;     // cold groups of 64
+    const uint32_t *bases;    // one base column per cold group
+    const uint4 *units;       // 3 per unit: {first cold group, #cold groups, first row, #rows | direct << 31},
+                              // {hub offset, #hub rows, #hot groups, segment}, {first hot element, present offset, #present, -}
     const uint32_t *hub_rows; // row_in_block of every hub row, per block
-    const float *hot_x;       // x[hot_cols[k]], gathered once per run by spmv_hot_gather_kernel
-    uint32_t nhot;            // cached columns (LDS table length, multiple of 64)
+    const float *hot_x;       // x[hot_cols[k]], gathered once per run by the helper kernel
+    uint32_t nhot;            // LDS table length: the longest present list, multiple of 64
+    const unsigned char *hot; // run-coded hot elements (gl_spmv_plan.h)
+    const uint32_t *hot_hdr;  // per element: HG x {mask lo, mask hi}, HG x base
+    const uint16_t *present;  // per unit: the slots of hot_x that occur in it, ascending
     const float *x;
     const float *mask;
     float *y;
@@ -115,32 +121,21 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
 
 
 // ---------------------------------------------------------------- stream layouts
-// One kernel body serves the four stream layouts; a layout says what one lane reads per load instruction
-// (8 or 16 bytes), how many consecutive 64-entry groups that read covers (stored lane-interleaved: lane L's
-// element holds entry L of each of the G groups) and whether values travel with the indices.
-//   NARROW  8 B: { index, value }                        1 group   (GRAPHLILY_DEBUG spmv_wide=0)
-//   WIDE   16 B: { A.index, A.value, B.index, B.value }  2 groups  (default general layout; scripts/ubench_mix:
-//                                                        half as many stream instructions per byte, -5 %)
-//   PAIR    8 B: { A.index, B.index }                    2 groups  (pattern plans, GRAPHLILY_DEBUG spmv_pat4=0)
-//   QUAD   16 B: { A.index .. D.index }                  4 groups  (default pattern layout)
-// index = (col - group_base) << 14 | slot.  Pattern plans (every column's stored values are equal) fold the
-// value into z[c] = colval[c] (x) x[c] once per run (spmv_prescale_kernel) and gather z instead of x.
+// One kernel body serves both layouts; a layout says what one lane reads per load instruction and how many consecutive
+// 64-entry groups that read covers (stored lane-interleaved: lane L's element holds entry L of each of the groups).
+//   COLD stream, index = (gather index - group_base) << 14 | slot:
+//     WIDE   16 B: { A.index, A.value, B.index, B.value }  2 groups  (general layout)
+//     QUAD   16 B: { A.index .. D.index }                  4 groups  (pattern layout)
+//   HOT stream, run-coded (gl_spmv_plan.h): 16-bit slots, the column from the element's header
+//     WIDE   8 B of slots + 16 B of values per lane        4 groups
+//     QUAD   16 B of slots per lane                        8 groups
+// Pattern plans (every column's stored values are equal) fold the value into z[c] = colval[c] (x) x[c] once per run and
+// gather z instead of x.  (Round 5 retired the 8-byte-per-lane NARROW / PAIR streams of rounds 1-2: A/B leftovers.)
 //   WIDE_KEEP / QUAD_KEEP: the same streams read without the non-temporal hint (plans that fit the Infinity Cache)
-enum { kLayNarrow = 0, kLayWide = 1, kLayPair = 2, kLayQuad = 3, kLayWideKeep = 4, kLayQuadKeep = 5 };
+enum { kLayWide = 1, kLayQuad = 3, kLayWideKeep = 4, kLayQuadKeep = 5 };
 
 template <int L>
 struct Lay;
-
-template <>
-struct Lay<kLayNarrow> {
-    using E = uint2;
-    static constexpr int G = 1;
-    static constexpr bool kValues = true;
-    __device__ static E load(const void *s, size_t i) { return load_stream_nt(static_cast<const uint2 *>(s) + i); }
-    __device__ static E pad() { return make_uint2(kRowPad, 0u); }
-    __device__ static uint32_t key(const E &e, int) { return e.x; }
-    __device__ static float val(const E &e, int) { return __uint_as_float(e.y); }
-};
 
 template <>
 struct Lay<kLayWide> {
@@ -148,20 +143,25 @@ struct Lay<kLayWide> {
     static constexpr int G = 2;
     static constexpr bool kValues = true;
     __device__ static E load(const void *s, size_t i) { return load_stream_nt16(static_cast<const uint4 *>(s) + i); }
-    __device__ static E pad() { return make_uint4(kRowPad, 0u, kRowPad, 0u); }
     __device__ static uint32_t key(const E &e, int k) { return k ? e.z : e.x; }
     __device__ static float val(const E &e, int k) { return __uint_as_float(k ? e.w : e.y); }
-};
-
-template <>
-struct Lay<kLayPair> {
-    using E = uint2;
-    static constexpr int G = 2;
-    static constexpr bool kValues = false;
-    __device__ static E load(const void *s, size_t i) { return load_stream_nt(static_cast<const uint2 *>(s) + i); }
-    __device__ static E pad() { return make_uint2(kRowPad, kRowPad); }
-    __device__ static uint32_t key(const E &e, int k) { return k ? e.y : e.x; }
-    __device__ static float val(const E &, int) { return 0.0f; }
+    struct H {
+        uint2 rows;
+        uint4 vals;
+    };
+    static constexpr int HG = (int)kHotGroupsGeneral;
+    __device__ static H load_hot(const unsigned char *hot, size_t e, uint32_t lane) {
+        const unsigned char *p = hot + e * kHotElemBytesGeneral;
+        H h;
+        h.rows = load_stream_nt(reinterpret_cast<const uint2 *>(p) + lane);
+        h.vals = load_stream_nt16(reinterpret_cast<const uint4 *>(p + 512) + lane);
+        return h;
+    }
+    __device__ static uint32_t hot_slot(const H &h, int k) {
+        const uint32_t w = k < 2 ? h.rows.x : h.rows.y;
+        return (k & 1) ? w >> 16 : w & 0xffffu;
+    }
+    __device__ static float hot_val(const H &h, int k) { return __uint_as_float(k == 0 ? h.vals.x : k == 1 ? h.vals.y : k == 2 ? h.vals.z : h.vals.w); }
 };
 
 template <>
@@ -170,18 +170,43 @@ struct Lay<kLayQuad> {
     static constexpr int G = 4;
     static constexpr bool kValues = false;
     __device__ static E load(const void *s, size_t i) { return load_stream_nt16(static_cast<const uint4 *>(s) + i); }
-    __device__ static E pad() { return make_uint4(kRowPad, kRowPad, kRowPad, kRowPad); }
     __device__ static uint32_t key(const E &e, int k) { return k == 0 ? e.x : k == 1 ? e.y : k == 2 ? e.z : e.w; }
     __device__ static float val(const E &, int) { return 0.0f; }
+    struct H {
+        uint4 rows;
+    };
+    static constexpr int HG = (int)kHotGroupsPattern;
+    __device__ static H load_hot(const unsigned char *hot, size_t e, uint32_t lane) {
+        H h;
+        h.rows = load_stream_nt16(reinterpret_cast<const uint4 *>(hot + e * kHotElemBytesPattern) + lane);
+        return h;
+    }
+    __device__ static uint32_t hot_slot(const H &h, int k) {
+        const uint32_t w = (k >> 1) == 0 ? h.rows.x : (k >> 1) == 1 ? h.rows.y : (k >> 1) == 2 ? h.rows.z : h.rows.w;
+        return (k & 1) ? w >> 16 : w & 0xffffu;
+    }
+    __device__ static float hot_val(const H &, int) { return 0.0f; }
 };
 
 template <>
 struct Lay<kLayWideKeep> : Lay<kLayWide> {
     __device__ static E load(const void *s, size_t i) { return load_stream_keep16(static_cast<const uint4 *>(s) + i); }
+    __device__ static H load_hot(const unsigned char *hot, size_t e, uint32_t lane) {
+        const unsigned char *p = hot + e * kHotElemBytesGeneral;
+        H h;
+        h.rows = load_stream_keep(reinterpret_cast<const uint2 *>(p) + lane);
+        h.vals = load_stream_keep16(reinterpret_cast<const uint4 *>(p + 512) + lane);
+        return h;
+    }
 };
 template <>
 struct Lay<kLayQuadKeep> : Lay<kLayQuad> {
     __device__ static E load(const void *s, size_t i) { return load_stream_keep16(static_cast<const uint4 *>(s) + i); }
+    __device__ static H load_hot(const unsigned char *hot, size_t e, uint32_t lane) {
+        H h;
+        h.rows = load_stream_keep16(reinterpret_cast<const uint4 *>(hot + e * kHotElemBytesPattern) + lane);
+        return h;
+    }
 };
 
 // One slot's work: UC cold and UH hot stream elements (either may be 0).  Every load is unconditional -- indices clamp
@@ -198,10 +223,12 @@ __device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Til
     using TL = Tile<OP>;
     using LY = Lay<L>;
     using E = typename LY::E;
-    constexpr int G = LY::G;
+    using H = typename LY::H;
+    constexpr int G = LY::G, HG = LY::HG;
     E ec[UC > 0 ? UC : 1];
     uint32_t bc[UC > 0 ? UC : 1][G];
-    E eh[UH > 0 ? UH : 1];
+    H eh[UH > 0 ? UH : 1];
+    uint32_t hm[UH > 0 ? UH : 1][2 * HG], hb[UH > 0 ? UH : 1][HG];   // run masks and bases: scalar registers
 #pragma unroll
     for (int u = 0; u < UC; u++) {
         const uint32_t ei = min(ic + u * kWaves, sg.nc_last);
@@ -210,7 +237,15 @@ __device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Til
         for (int k = 0; k < G; k++) bc[u][k] = load_const(a.bases + sg.g0 + G * ei + k);
     }
 #pragma unroll
-    for (int u = 0; u < UH; u++) eh[u] = LY::load(a.entries, (size_t)(sg.h0 + min(ih + u * kWaves, sg.nh_last)) * 64u + lane);
+    for (int u = 0; u < UH; u++) {
+        const size_t e = (size_t)sg.h0 + min(ih + u * kWaves, sg.nh_last);
+        eh[u] = LY::load_hot(a.hot, e, lane);
+        const uint32_t *hd = a.hot_hdr + e * (kHotHdrWordsPerGroup * HG);
+#pragma unroll
+        for (int k = 0; k < 2 * HG; k++) hm[u][k] = load_const(hd + k);
+#pragma unroll
+        for (int k = 0; k < HG; k++) hb[u][k] = load_const(hd + 2 * HG + k);
+    }
     // the next slot's ticket is drawn while the loads are in flight: at the end of the step it would have to wait for
     // the step's own accumulates (LDS operations complete in order)
     if (a.tickets && lane == 0) ticket = __hip_atomic_fetch_add(next_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -219,47 +254,56 @@ __device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Til
     for (int u = 0; u < UC; u++)
 #pragma unroll
         for (int k = 0; k < G; k++) xc[u][k] = xsrc[bc[u][k] + (LY::key(ec[u], k) >> kRowBits)];
+    // Padding entries name one of the block's DUMMY slots (behind its last accumulator, one per lane: the formatters write
+    // them), so an element's accumulates are straight-line code -- no per-entry compare and branch, and the table look-ups of a hot element
+    // are all in flight before the first accumulate waits for one (an LDS round trip per entry was the hot path's critical
+    // path: s_waitcnt lgkmcnt counts in order).  Only whole elements past the end of the unit's stream (clamped loads) are
+    // skipped, by a wave-uniform branch.
 #pragma unroll
     for (int u = 0; u < UH; u++) {
-        const bool in = ih + u * kWaves < sg.nh;
+        if (ih + u * kWaves < sg.nh) {
+            float hv[HG];
 #pragma unroll
-        for (int k = 0; k < G; k++) {
-            const uint32_t key = LY::key(eh[u], k), r = in ? (key & kRowPad) : kRowPad;
-            if (r != kRowPad) {
-                if (LY::kValues) TL::acc(tile, r, LY::val(eh[u], k), hot_x[key >> kRowBits]);
-                else TL::accz(tile, r, hot_x[key >> kRowBits]);
+            for (int k = 0; k < HG; k++) {
+                // the entry's table slot: the group's base + the runs that start in the lanes below (v_mbcnt on the scalar mask)
+                const uint32_t ts = __builtin_amdgcn_mbcnt_hi(hm[u][2 * k + 1], __builtin_amdgcn_mbcnt_lo(hm[u][2 * k], hb[u][k]));
+                hv[k] = hot_x[ts];
+            }
+#pragma unroll
+            for (int k = 0; k < HG; k++) {
+                if (LY::kValues) TL::acc(tile, LY::hot_slot(eh[u], k), LY::hot_val(eh[u], k), hv[k]);
+                else TL::accz(tile, LY::hot_slot(eh[u], k), hv[k]);
             }
         }
     }
 #pragma unroll
     for (int u = 0; u < UC; u++) {
-        const bool in = ic + u * kWaves < sg.nc;
+        if (ic + u * kWaves < sg.nc) {
 #pragma unroll
-        for (int k = 0; k < G; k++) {
-            const uint32_t r = in ? (LY::key(ec[u], k) & kRowPad) : kRowPad;
-            if (r != kRowPad) {
-                if (LY::kValues) TL::acc(tile, r, LY::val(ec[u], k), xc[u][k]);
-                else TL::accz(tile, r, xc[u][k]);
+            for (int k = 0; k < G; k++) {
+                if (LY::kValues) TL::acc(tile, LY::key(ec[u], k) & kRowPad, LY::val(ec[u], k), xc[u][k]);
+                else TL::accz(tile, LY::key(ec[u], k) & kRowPad, xc[u][k]);
             }
         }
     }
 }
 
-// One workgroup per unit.  UC cold and UH hot stream ELEMENTS (Lay<L>::G groups each) per wavefront iteration;
-// group counts per unit are multiples of G.
+// One workgroup per unit.  UC cold and UH hot stream ELEMENTS (Lay<L>::G / HG groups each) per wavefront iteration;
+// group counts per unit are multiples of G / HG.
 template <int OP, int MASK, int L, int UC, int UH>
 __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     using TL = Tile<OP>;
     using T = typename TL::T;
     using LY = Lay<L>;
-    constexpr int G = LY::G;
+    constexpr int G = LY::G, HG = LY::HG;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
     T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);   // nhot is a multiple of 64
 
     if (a.run_flag && *a.run_flag == 0u) return;
     const uint32_t unit = __builtin_amdgcn_readfirstlane(blockIdx.x);   // pinned to an SGPR: see clock_stamp
-    const uint4 d = load_const(a.units + 2u * unit), dh = load_const(a.units + 2u * unit + 1u);   // scalar loads
+    const uint4 d = load_const(a.units + 3u * unit), dh = load_const(a.units + 3u * unit + 1u);   // scalar loads
+    const uint4 dp = load_const(a.units + 3u * unit + 2u);
     const uint32_t g0 = d.x, ncold = d.y, nrows = d.w & 0xffffu;
     const uint32_t nhub = dh.y, nhotg = dh.z;
     const uint32_t nslots = nrows + kHubSlots * nhub;
@@ -269,14 +313,15 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
 
     __shared__ uint32_t next_iter;   // ticket: the first kWaves iterations are taken by wave number
     if (threadIdx.x == 0) next_iter = kWaves;
-    if (UH > 0) {
+    if (UH > 0) {   // the table: the values of the hot columns that occur in this unit, in the unit's slot order
+        const uint16_t *pres = a.present + dp.y;
         if (a.self_hot_cols) {   // short streams: a helper launch in front would cost more than these few scattered reads
-            for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.x[a.self_hot_cols[i]];
+            for (uint32_t i = threadIdx.x; i < dp.z; i += kThreads) hot_x[i] = a.x[a.self_hot_cols[pres[i]]];
         } else {
-            for (uint32_t i = threadIdx.x; i < a.nhot; i += kThreads) hot_x[i] = a.hot_x[i];   // coalesced, L2 hits
+            for (uint32_t i = threadIdx.x; i < dp.z; i += kThreads) hot_x[i] = a.hot_x[pres[i]];   // ascending, nearly dense: L2 hits
         }
     }
-    for (uint32_t i = threadIdx.x; i < nslots; i += kThreads) tile[i] = TL::ident();
+    for (uint32_t i = threadIdx.x; i < nslots + kPadSlots; i += kThreads) tile[i] = TL::ident();   // (+ the dummies that padding entries name)
     __syncthreads();
 
     // The stream is consumed in rounds of kWaves slots: slot w of round j takes cold elements j*kWaves*UC + w + u*kWaves
@@ -287,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     const float *xsrc = LY::kValues ? a.xg : a.z;
     StreamGeom sg;
     sg.g0 = g0;
-    sg.c0 = g0 / G, sg.nc = ncold / G, sg.h0 = (g0 + ncold) / G, sg.nh = nhotg / G;
+    sg.c0 = g0 / G, sg.nc = ncold / G, sg.h0 = dp.x, sg.nh = nhotg / HG;
     sg.nc_last = max(sg.nc, 1u) - 1u, sg.nh_last = max(sg.nh, 1u) - 1u;
     const uint32_t rc = (sg.nc + kWaves * UC - 1) / (kWaves * UC), rh = UH > 0 ? (sg.nh + kWaves * UH - 1) / (kWaves * UH) : 0u;
     const uint32_t n_both = min(rc, rh) * kWaves, n_all = max(rc, rh) * kWaves;
@@ -558,7 +603,7 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
                                                                                                 p->d_xc, p->ncompact, a.run_flag);
         GL_LAUNCH_CHECK();
     }
-    const size_t lds = (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(typename Tile<OP>::T);
+    const size_t lds = (size_t)p->nhot_lds * 4u + ((size_t)p->max_block_rows + kPadSlots) * sizeof(typename Tile<OP>::T);   // + the dummy slots
     if (lds > kLdsBudget)
         return set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_NO_MULADD "
                          "(hot-column table sized for 4-byte accumulators); (+,x) needs a plan without it");
@@ -571,70 +616,27 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     // 0.048 -> 0.046 ms; the 45 MB googleplus pattern plan lost 3 %: below 64 MB the hint stays)
     static const size_t keep_bytes = (size_t)224 << 20;
     static const size_t keep_min = (size_t)64 << 20;
-    const bool keep = OP < 3 && p->wide && p->device_bytes <= keep_bytes && p->device_bytes >= keep_min;
-    if (OP < 3 && keep && p->pattern) {
-        switch (p->mix) {
-            case 0: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayQuadKeep, 2, 0>(p, a, lds, s); break;
-            case 1: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayQuadKeep, 2, 1>(p, a, lds, s); break;
-            case 9: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayQuadKeep, 1, 2>(p, a, lds, s); break;
-            case 6: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayQuadKeep, 2, 2>(p, a, lds, s); break;
-            default: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayQuadKeep, 1, 1>(p, a, lds, s); break;
-        }
-    } else if (OP < 3 && keep) {
-        switch (p->mix) {
-            case 0: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 2, 0>(p, a, lds, s); break;
-            case 1: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 2, 1>(p, a, lds, s); break;
-            case 2: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 1, 1>(p, a, lds, s); break;
-            case 3: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 3, 1>(p, a, lds, s); break;
-            case 6: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 3, 2>(p, a, lds, s); break;
-            case 7: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 3, 3>(p, a, lds, s); break;
-            case 8: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 1, 2>(p, a, lds, s); break;
-            case 9: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 2, 3>(p, a, lds, s); break;
-            default: rc = launch_variant<OP < 3 ? OP : 0, MASK, kLayWideKeep, 2, 2>(p, a, lds, s); break;
-        }
-    } else if (p->pattern && p->wide) {
-        switch (p->mix) {   // cold quads, hot quads per iteration
-            case 0: rc = launch_variant<OP, MASK, kLayQuad, 2, 0>(p, a, lds, s); break;
-            case 1: rc = launch_variant<OP, MASK, kLayQuad, 2, 1>(p, a, lds, s); break;
-            case 9: rc = launch_variant<OP, MASK, kLayQuad, 1, 2>(p, a, lds, s); break;
-            case 6: rc = launch_variant<OP, MASK, kLayQuad, 2, 2>(p, a, lds, s); break;
-            default: rc = launch_variant<OP, MASK, kLayQuad, 1, 1>(p, a, lds, s); break;
-        }
-    } else if (p->pattern) {
-        switch (p->mix) {   // cold pairs, hot pairs per iteration
-            case 0: rc = launch_variant<OP, MASK, kLayPair, 3, 0>(p, a, lds, s); break;
-            case 2: rc = launch_variant<OP, MASK, kLayPair, 2, 2>(p, a, lds, s); break;
-            case 3: rc = launch_variant<OP, MASK, kLayPair, 3, 1>(p, a, lds, s); break;
-            case 4: rc = launch_variant<OP, MASK, kLayPair, 1, 1>(p, a, lds, s); break;
-            case 5: rc = launch_variant<OP, MASK, kLayPair, 4, 2>(p, a, lds, s); break;
-            case 6: rc = launch_variant<OP, MASK, kLayPair, 3, 2>(p, a, lds, s); break;
-            case 7: rc = launch_variant<OP, MASK, kLayPair, 4, 1>(p, a, lds, s); break;
-            case 8: rc = launch_variant<OP, MASK, kLayPair, 1, 2>(p, a, lds, s); break;
-            case 9: rc = launch_variant<OP, MASK, kLayPair, 2, 3>(p, a, lds, s); break;
-            default: rc = launch_variant<OP, MASK, kLayPair, 2, 1>(p, a, lds, s); break;
-        }
-    } else if (p->wide) {
-        switch (p->mix) {   // cold pairs, hot pairs per iteration
-            case 0: rc = launch_variant<OP, MASK, kLayWide, 2, 0>(p, a, lds, s); break;
-            case 1: rc = launch_variant<OP, MASK, kLayWide, 2, 1>(p, a, lds, s); break;
-            case 2: rc = launch_variant<OP, MASK, kLayWide, 1, 1>(p, a, lds, s); break;
-            case 3: rc = launch_variant<OP, MASK, kLayWide, 3, 1>(p, a, lds, s); break;
-            case 6: rc = launch_variant<OP, MASK, kLayWide, 3, 2>(p, a, lds, s); break;
-            case 7: rc = launch_variant<OP, MASK, kLayWide, 3, 3>(p, a, lds, s); break;
-            case 8: rc = launch_variant<OP, MASK, kLayWide, 1, 2>(p, a, lds, s); break;
-            case 9: rc = launch_variant<OP, MASK, kLayWide, 2, 3>(p, a, lds, s); break;
-            default: rc = launch_variant<OP, MASK, kLayWide, 2, 2>(p, a, lds, s); break;
-        }
-    } else
-    switch (p->mix) {
-        case 1: rc = launch_variant<OP, MASK, kLayNarrow, 3, 1>(p, a, lds, s); break;
-        case 2: rc = launch_variant<OP, MASK, kLayNarrow, 2, 1>(p, a, lds, s); break;
-        case 3: rc = launch_variant<OP, MASK, kLayNarrow, 2, 2>(p, a, lds, s); break;
-        case 4: rc = launch_variant<OP, MASK, kLayNarrow, 4, 2>(p, a, lds, s); break;
-        case 5: rc = launch_variant<OP, MASK, kLayNarrow, 3, 3>(p, a, lds, s); break;
-        case 6: rc = launch_variant<OP, MASK, kLayNarrow, 4, 1>(p, a, lds, s); break;
-        default: rc = launch_variant<OP, MASK, kLayNarrow, 4, 0>(p, a, lds, s); break;
+    const bool keep = OP < 3 && p->device_bytes <= keep_bytes && p->device_bytes >= keep_min;
+    // p->mix: cold / hot stream elements per wavefront iteration (general: 2 / 4 groups each, pattern: 4 / 8)
+#define GL_SPMV_MIXES(O, LAY)                                                                \
+    switch (p->mix) {                                                                         \
+        case 0: rc = launch_variant<O, MASK, LAY, 2, 0>(p, a, lds, s); break;                 \
+        case 1: rc = launch_variant<O, MASK, LAY, 4, 1>(p, a, lds, s); break;                 \
+        case 2: rc = launch_variant<O, MASK, LAY, 3, 1>(p, a, lds, s); break;                 \
+        case 4: rc = launch_variant<O, MASK, LAY, 1, 1>(p, a, lds, s); break;                 \
+        default: rc = launch_variant<O, MASK, LAY, 2, 1>(p, a, lds, s); break;                \
     }
+    constexpr int OPK = OP < 3 ? OP : 0;   // (the integer value types never take the keep variants: no instantiations for them)
+    if (OP < 3 && keep && p->pattern) {
+        GL_SPMV_MIXES(OPK, kLayQuadKeep)
+    } else if (OP < 3 && keep) {
+        GL_SPMV_MIXES(OPK, kLayWideKeep)
+    } else if (p->pattern) {
+        GL_SPMV_MIXES(OP, kLayQuad)
+    } else {
+        GL_SPMV_MIXES(OP, kLayWide)
+    }
+#undef GL_SPMV_MIXES
     if (rc != GL_OK) return rc;
     GL_LAUNCH_CHECK();
     if (timed) {
@@ -961,7 +963,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     if (nnz > 0 && gl::debug_knob("spmv_hot", 1) != 0) {
         // 8-byte accumulators unless the caller promised to run only the 4-byte-tile semirings
         const size_t elem = (flags & (GL_PLAN_NO_MULADD | GL_PLAN_BOOLEAN)) ? sizeof(float) : sizeof(double);
-        const size_t tile_bytes = ((size_t)tallest + gl::kHubSlots * gl::kMaxHubRows) * elem;
+        const size_t tile_bytes = ((size_t)tallest + gl::kHubSlots * gl::kMaxHubRows + gl::kPadSlots) * elem;   // (+ the dummy slots of padding entries)
         // as many columns as fit next to the tallest tile, in steps of 1024, at most 32 K
         uint32_t room = 0;
         if (tile_bytes + 4096u <= gl::kLdsBudget)
@@ -1104,33 +1106,25 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         pattern = !mismatch;
         diag_mode = pattern && exceptions > 0;
     }
-    // 16-byte stream loads: lane-interleaved pairs of 8-byte groups, or quads of 4-byte (pattern) groups
-    const bool wide = pattern ? gl::debug_knob("spmv_pat4", 1) != 0 : gl::debug_knob("spmv_wide", 1) != 0;
-    const uint32_t group_mult = pattern ? (wide ? 4u : 2u) : (wide ? 2u : 1u);   // units hold whole pairs / quads of groups
-
-    // ---- group budget per unit (upper bound), so every block can be emitted independently;
-    //      units are numbered segment-major: u = s * nblocks + b
-    std::vector<uint64_t> unit_goff((size_t)nunits + 1, 0);
-    for (uint32_t b = 0; b < nblocks; b++) {
-        const uint64_t m = (uint64_t)h_indptr[bstart[b + 1]] - h_indptr[bstart[b]];
-        const uint32_t S = seg[b];
-        for (uint32_t s = 0; s < S; s++) {
-            const uint64_t c0 = m * s / S, c1 = m * (s + 1) / S;
-            unit_goff[(size_t)unit_of[s][b] + 1] = ((c1 - c0 + 63) / 64 + jump_slack + 9u) / 4u * 4u;   // multiple of 4
-        }
-    }
-    for (size_t i = 0; i < (size_t)nunits; i++) unit_goff[i + 1] += unit_goff[i];
-    const uint64_t total_groups = unit_goff[nunits];
-    GL_ARG(total_groups < 0xffffffffull);
+    // 16-byte stream loads: lane-interleaved pairs of 8-byte groups, or quads of 4-byte (pattern) groups; the run-coded
+    // hot stream in elements of 4 (8) groups
+    const bool wide = true;
+    const uint32_t group_mult = pattern ? 4u : 2u;   // units hold whole pairs / quads of cold groups
+    const uint32_t hot_groups = pattern ? gl::kHotGroupsPattern : gl::kHotGroupsGeneral;
+    const uint32_t hot_elem_bytes = pattern ? gl::kHotElemBytesPattern : gl::kHotElemBytesGeneral;
+    const uint32_t hot_hdr_words = gl::kHotHdrWordsPerGroup * hot_groups;
 
     std::vector<uint2> entries;
     std::vector<uint32_t> bases;
     std::vector<uint4> units;
     std::vector<uint32_t> hub_rows;   // slot b*kMaxHubRows + h
     std::vector<uint32_t> hub_count(nblocks, 0);
+    std::vector<unsigned char> hot_bytes;
+    std::vector<uint32_t> hot_hdr;
+    std::vector<uint16_t> present;
     uint32_t max_rows = 0;
     int bad_col = 0;
-    uint64_t hot_nnz = 0;
+    uint64_t hot_nnz = 0, total_groups = 0;
     gl_spmv_plan p = new gl_spmv_plan_s();
 
     if (on_device) {
@@ -1140,7 +1134,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             colmap[c] = (have_hot && hot_slot[c] != 0xffffffffu) ? (0x80000000u | hot_slot[c]) : (compact ? (cmap[c] & 0x7fffffffu) : c);
         gl::EmitGeneral eg;
         eg.bp = &bp;
-        eg.unit_goff = unit_goff.data();
+        eg.jump_slack = jump_slack;
         eg.colmap = colmap.data();
         eg.gather_cols = gather_cols;
         eg.nhot_table = nhot_table;
@@ -1158,12 +1152,49 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             gl_spmv_plan_destroy(p);
             return erc;
         }
+        total_groups = p->ngroups;
     } else {
+    // ---- pass 1: cold / hot entries per block, from which every unit's place in the arrays follows (layout_units)
+    std::vector<uint64_t> mc(nblocks, 0), mh(nblocks, 0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t b = 0; b < (int64_t)nblocks; b++) {
+        uint64_t nc = 0, nh = 0;
+        bool bad = false;
+        for (uint32_t r = bstart[b]; r < bstart[b + 1]; r++)
+            for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
+                const uint32_t c = h_indices[i];
+                if (c >= num_cols) { bad = true; continue; }
+                if (diag_mode && c == r && __builtin_bit_cast(uint32_t, h_data[i]) != colbits[c]) continue;
+                if (have_hot && hot_slot[c] != 0xffffffffu) nh++; else nc++;
+            }
+        mc[b] = nc, mh[b] = nh;
+        if (bad) {
+#pragma omp atomic write
+            bad_col = 1;
+        }
+    }
+    if (bad_col) {
+        gl_spmv_plan_destroy(p);
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", num_cols);
+    }
+    const gl::UnitLayout ul = gl::layout_units(bp, mc, mh, jump_slack, hot_groups, nhot_table);
+    total_groups = ul.cold_goff[nunits];
+    const uint64_t hot_elems = ul.hot_e0[nunits];
+    GL_ARG(total_groups < 0xffffffffull && hot_elems < 0xffffffffull && ul.present_off[nunits] < 0xffffffffull);
     entries.resize(total_groups * 64);
     bases.resize(total_groups);
-    units.resize((size_t)nunits * 2);
+    units.resize((size_t)nunits * 3);
     hub_rows.assign((size_t)nblocks * gl::kMaxHubRows, 0);
-#pragma omp parallel reduction(+ : hot_nnz)
+    // hot arrays with one element of slack behind them (the kernel's clamped loads land there; never accumulated)
+    hot_bytes.assign((size_t)(hot_elems + 1) * hot_elem_bytes, 0);
+    {
+        uint16_t *rows16 = reinterpret_cast<uint16_t *>(hot_bytes.data() + (size_t)hot_elems * hot_elem_bytes);
+        for (uint32_t k = 0; k < 64u * hot_groups; k++) rows16[k] = (uint16_t)gl::kRowPad;
+    }
+    hot_hdr.assign((size_t)(hot_elems + 1) * hot_hdr_words, 0u);
+    present.assign((size_t)std::max<uint64_t>(ul.present_off[nunits], 2u), 0);
+    uint32_t max_present = 0;
+#pragma omp parallel reduction(+ : hot_nnz) reduction(max : max_present)
     {
         std::vector<gl::Rec> recs, tmp, hot;
 #pragma omp for schedule(dynamic, 1)
@@ -1171,25 +1202,18 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             const uint32_t r0 = bstart[b], r1 = bstart[b + 1];
             recs.clear();
             hot.clear();
-            bool bad = false;
             for (uint32_t r = r0; r < r1; r++)
                 for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
                     const uint32_t c = h_indices[i];
-                    if (c >= num_cols) { bad = true; continue; }
                     const uint32_t v = __builtin_bit_cast(uint32_t, h_data[i]);
                     if (diag_mode && c == r && v != colbits[c]) continue;   // the row's diagonal exception lives in diag_val
                     if (have_hot && hot_slot[c] != 0xffffffffu) hot.push_back(gl::Rec{hot_slot[c], r - r0, v});
                     else recs.push_back(gl::Rec{compact ? cmap[c] : c, r - r0, v});
                 }
-            if (bad) {
-#pragma omp atomic write
-                bad_col = 1;
-                continue;
-            }
             gl::sort_by_col(recs, tmp, gather_cols);
-            gl::sort_by_col(hot, tmp, nhot_table ? nhot_table : 1u);   // by slot: neighbours share an LDS word
+            gl::sort_by_col(hot, tmp, nhot_table ? nhot_table : 1u);   // by slot: a column's entries form a run
             hot_nnz += hot.size();
-            const uint64_t mc = recs.size(), m = mc + hot.size();
+            const uint64_t mcb = recs.size(), m = mcb + hot.size();
             // hub rows: a large share of the block's entries (=> several lanes of every step on one LDS word)
             std::vector<uint32_t> cnt(r1 - r0, 0);
             for (const gl::Rec &rc : recs) cnt[rc.row_local]++;
@@ -1207,6 +1231,9 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
                 hub_count[b] = nh;
             }
             const uint32_t nrows_b = r1 - r0;
+            // padding entries accumulate into the slots behind the block's last one (dummies nobody reads, one per lane): the
+            // kernel's accumulates need no test
+            const uint32_t pad_slot = nrows_b + gl::kHubSlots * hub_count[b];
             // the block's cold entries (column-sorted) and hot entries (slot-sorted) are each cut into S pieces
             auto slot_of = [&](const gl::Rec &rc, uint32_t fill) -> uint32_t {
                 const int hb = hub_of[rc.row_local];
@@ -1215,13 +1242,14 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             const uint32_t S = seg[b];
             for (uint32_t s = 0; s < S; s++) {
                 const size_t u = unit_of[s][b];
-                uint64_t g = unit_goff[u];     // groups [unit_goff[u], g) are complete or open
+                const uint64_t goff = ul.cold_goff[u];
+                uint64_t g = goff;             // groups [goff, g) are complete or open
                 uint32_t fill = 64, base = 0;  // fill == 64: no open group
-                for (uint64_t i = mc * s / S; i < mc * (s + 1) / S; i++) {
+                for (uint64_t i = mcb * s / S; i < mcb * (s + 1) / S; i++) {
                     const gl::Rec &rc = recs[i];
                     if (fill == 64 || rc.col - base >= (1u << gl::kColOffBits)) {
                         if (fill != 64)
-                            for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
+                            for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(pad_slot + fill, 0u);
                         base = rc.col;
                         bases[g] = base;
                         g++;
@@ -1230,39 +1258,51 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
                     entries[(g - 1) * 64 + fill] = make_uint2(((rc.col - base) << gl::kRowBits) | slot_of(rc, fill), rc.val);
                     fill++;
                 }
-                if (g > unit_goff[u])
-                    for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
-                auto pad_group = [&]() {   // an all-padding group keeps the count a multiple of group_mult
+                if (g > goff)
+                    for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(pad_slot + fill, 0u);
+                while ((g - goff) % group_mult) {   // an all-padding group keeps the count a multiple of group_mult
                     bases[g] = 0;
-                    for (uint32_t k = 0; k < 64; k++) entries[g * 64 + k] = make_uint2(gl::kRowPad, 0u);
+                    for (uint32_t k = 0; k < 64; k++) entries[g * 64 + k] = make_uint2(pad_slot + k, 0u);
                     g++;
-                };
-                while ((g - unit_goff[u]) % group_mult) pad_group();
-                const uint32_t ncold = (uint32_t)(g - unit_goff[u]);
-                const uint64_t gh0 = g, mh = hot.size();
-                fill = 64;
-                for (uint64_t i = mh * s / S; i < mh * (s + 1) / S; i++) {
-                    if (fill == 64) {
-                        bases[g] = 0;
-                        g++;
-                        fill = 0;
-                    }
-                    entries[(g - 1) * 64 + fill] = make_uint2((hot[i].col << gl::kRowBits) | slot_of(hot[i], fill), hot[i].val);
-                    fill++;
                 }
-                if (g > gh0)
-                    for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(gl::kRowPad, 0u);
-                while ((g - gh0) % group_mult) pad_group();
-                units[2 * u] = make_uint4((uint32_t)unit_goff[u], ncold, r0, (r1 - r0) | (all_direct ? 0x80000000u : 0u));
-                units[2 * u + 1] = make_uint4((uint32_t)((size_t)b * gl::kMaxHubRows), hub_count[b], (uint32_t)(g - gh0), s);
+                const uint32_t ncold = (uint32_t)(g - goff);
+                // ---- the unit's hot entries, run-coded (gl_spmv_plan.h)
+                const uint64_t h0 = hot.size() * s / S, h1 = hot.size() * (s + 1) / S, e0 = ul.hot_e0[u];
+                uint16_t *pres = present.data() + ul.present_off[u];
+                uint32_t np = 0;
+                for (size_t e = (size_t)e0; e < (size_t)ul.hot_e0[u + 1]; e++) {   // every slot of the unit's elements starts as padding
+                    uint16_t *rows16 = reinterpret_cast<uint16_t *>(hot_bytes.data() + e * hot_elem_bytes);
+                    for (uint32_t k = 0; k < 64u * hot_groups; k++) rows16[k] = (uint16_t)(pad_slot + k / hot_groups);   // (lane k / HG)
+                }
+                for (uint64_t i = h0; i < h1; i++) {
+                    const uint64_t j = i - h0, hg = j / 64;
+                    const uint32_t l = (uint32_t)(j % 64), k = (uint32_t)(hg % hot_groups);
+                    const size_t e = (size_t)(e0 + hg / hot_groups);
+                    const bool start = i == h0 || hot[i].col != hot[i - 1].col;
+                    if (start) pres[np++] = (uint16_t)hot[i].col;
+                    uint32_t *hd = hot_hdr.data() + e * hot_hdr_words;
+                    if (l == 0) hd[2 * hot_groups + k] = np - 1u;                               // the group's first table slot
+                    else if (start) hd[2 * k + ((l - 1u) >> 5)] |= 1u << ((l - 1u) & 31u);      // bit l - 1: entry l starts a run
+                    unsigned char *el = hot_bytes.data() + e * hot_elem_bytes;
+                    const uint16_t slot16 = (uint16_t)slot_of(hot[i], l);
+                    if (pattern) {
+                        reinterpret_cast<uint16_t *>(el)[l * 8u + k] = slot16;
+                    } else {
+                        reinterpret_cast<uint16_t *>(el)[l * 4u + k] = slot16;
+                        reinterpret_cast<uint32_t *>(el + 512)[l * 4u + k] = hot[i].val;
+                    }
+                }
+                max_present = std::max(max_present, np);
+                const uint32_t nhotg = (uint32_t)(ul.hot_e0[u + 1] - e0) * hot_groups;
+                units[3 * u] = make_uint4((uint32_t)goff, ncold, r0, (r1 - r0) | (all_direct ? 0x80000000u : 0u));
+                units[3 * u + 1] = make_uint4((uint32_t)((size_t)b * gl::kMaxHubRows), hub_count[b], nhotg, s);
+                units[3 * u + 2] = make_uint4((uint32_t)e0, (uint32_t)ul.present_off[u], np, 0u);
             }
         }
     }
+    p->nhot_elems = hot_elems;
+    p->nhot_lds = (max_present + 63u) / 64u * 64u;
     }   // host emission
-    if (bad_col) {
-        gl_spmv_plan_destroy(p);
-        return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", num_cols);
-    }
     for (uint32_t b = 0; b < nblocks; b++)
         max_rows = std::max(max_rows, bstart[b + 1] - bstart[b] + gl::kHubSlots * hub_count[b]);   // LDS slots
 
@@ -1285,17 +1325,12 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     }
     p->flags = flags;
     {
-        // cold : hot groups per wavefront iteration follow the share of non-zeros the hot table serves
-        // (measured on the stand-ins: orkut / products, 34-36 % hot, are best at 3 cold + 2 hot pairs;
-        // hollywood / ppa / googleplus, > 50 %, at 2 + 2; since rounds past the end of the shorter stream touch only the
-        // other one, the choice is worth 2 % at most)
+        // cold : hot stream elements per wavefront iteration follow the share of non-zeros the hot table serves: with 2 (4)
+        // groups per cold element and 4 (8) per hot one, c + 1 elements serve a hot share of 2 / (c + 2).  Rounds past the
+        // end of the shorter stream touch only the other one, so the choice is worth a few per cent at most.
         const long forced = gl::debug_knob("spmv_mix", -1);
         const double hot_frac = nnz ? (double)hot_nnz / (double)nnz : 0.0;
-        int mix = 5;                                   // wide: 2 + 2 pairs; narrow: 3 + 3 groups
-        // (re-swept with the packed gather vector: cold groups got cheaper, so a little more of them per slot)
-        if (pattern) mix = hot_frac >= 0.60 ? 9 : hot_frac < 0.45 ? 1 : 6;   // quads: 2 + 1 / 2 + 2 / 1 + 2; pairs: 2 + 1 / 3 + 2 / 2 + 3
-        else if (wide && hot_frac < 0.50) mix = 6;     // 3 + 2 pairs
-        else if (wide && hot_frac >= 0.60) mix = 9;    // 2 + 3 pairs
+        const int mix = hot_frac < 0.365 ? 1 : hot_frac < 0.45 ? 2 : hot_frac < 0.585 ? 3 : 4;   // 4 + 1, 3 + 1, 2 + 1, 1 + 1
         p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : mix);   // 0 would skip the hot groups
     }
     auto up = [&](void **d, const void *h, size_t bytes) -> int {
@@ -1306,8 +1341,8 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     };
     p->pattern = pattern;
     p->wide = wide;
-    if (wide && !pattern && !on_device) {
-        // pair P = groups 2P, 2P+1 -> lane l holds { A[l], B[l] } (two uint2 = one 16-byte load)
+    if (!pattern && !on_device) {
+        // pair P = cold groups 2P, 2P+1 -> lane l holds { A[l], B[l] } (two uint2 = one 16-byte load)
         const uint64_t npairs = total_groups / 2;
 #pragma omp parallel for schedule(static)
         for (int64_t P = 0; P < (int64_t)npairs; P++) {
@@ -1320,24 +1355,16 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         }
     }
     if (pattern && !on_device) {
-        // 4-byte entries, lane-interleaved: pair P = groups 2P (-> .x), 2P+1 (-> .y); or quad Q = groups 4Q .. 4Q+3
-        // (-> .x .y .z .w of one 16-byte element = two consecutive uint2)
-        const uint64_t npairs = total_groups / 2;
-        std::vector<uint2> packed(npairs * 64);
-        if (wide) {
+        // 4-byte entries, lane-interleaved: quad Q = cold groups 4Q .. 4Q+3 (-> .x .y .z .w of one 16-byte element = two
+        // consecutive uint2)
+        std::vector<uint2> packed(total_groups / 2 * 64);
 #pragma omp parallel for schedule(static)
-            for (int64_t Q = 0; Q < (int64_t)(total_groups / 4); Q++)
-                for (uint32_t l = 0; l < 64; l++) {
-                    const size_t g = (size_t)Q * 4;
-                    packed[(size_t)Q * 128 + 2 * l] = make_uint2(entries[g * 64 + l].x, entries[(g + 1) * 64 + l].x);
-                    packed[(size_t)Q * 128 + 2 * l + 1] = make_uint2(entries[(g + 2) * 64 + l].x, entries[(g + 3) * 64 + l].x);
-                }
-        } else {
-#pragma omp parallel for schedule(static)
-            for (int64_t P = 0; P < (int64_t)npairs; P++)
-                for (uint32_t l = 0; l < 64; l++)
-                    packed[(size_t)P * 64 + l] = make_uint2(entries[(size_t)(2 * P) * 64 + l].x, entries[(size_t)(2 * P + 1) * 64 + l].x);
-        }
+        for (int64_t Q = 0; Q < (int64_t)(total_groups / 4); Q++)
+            for (uint32_t l = 0; l < 64; l++) {
+                const size_t g = (size_t)Q * 4;
+                packed[(size_t)Q * 128 + 2 * l] = make_uint2(entries[g * 64 + l].x, entries[(g + 1) * 64 + l].x);
+                packed[(size_t)Q * 128 + 2 * l + 1] = make_uint2(entries[(g + 2) * 64 + l].x, entries[(g + 3) * 64 + l].x);
+            }
         entries.swap(packed);
     }
     // one element of slack: the kernel's loads are unconditional and clamp to a unit's last element, which for a unit
@@ -1349,7 +1376,10 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * sizeof(uint2))) != GL_OK ||
             (rc = up((void **)&p->d_bases, bases.data(), bases.size() * sizeof(uint32_t))) != GL_OK ||
             (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK ||
-            (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK) {
+            (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK ||
+            (rc = up((void **)&p->d_hot, hot_bytes.data(), hot_bytes.size())) != GL_OK ||
+            (rc = up((void **)&p->d_hot_hdr, hot_hdr.data(), hot_hdr.size() * sizeof(uint32_t))) != GL_OK ||
+            (rc = up((void **)&p->d_present, present.data(), present.size() * sizeof(uint16_t))) != GL_OK) {
             gl_spmv_plan_destroy(p);
             return rc;
         }
@@ -1357,6 +1387,9 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         p->b_bases = bases.size() * sizeof(uint32_t);
         p->b_units = units.size() * sizeof(uint4);
         p->b_hub_rows = hub_rows.size() * sizeof(uint32_t);
+        p->b_hot = hot_bytes.size();
+        p->b_hot_hdr = hot_hdr.size() * sizeof(uint32_t);
+        p->b_present = present.size() * sizeof(uint16_t);
     }
     if ((rc = up((void **)&p->d_hot_cols, hot_cols.data(), hot_cols.size() * sizeof(uint32_t))) != GL_OK ||
         (rc = up((void **)&p->d_blocks, blocks.data(), blocks.size() * sizeof(uint4))) != GL_OK ||
@@ -1467,6 +1500,9 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_bases);
     (void)hipFree(p->d_units);
     (void)hipFree(p->d_hub_rows);
+    (void)hipFree(p->d_hot);
+    (void)hipFree(p->d_hot_hdr);
+    (void)hipFree(p->d_present);
     (void)hipFree(p->d_hot_cols);
     (void)hipFree(p->d_hot_x);
     (void)hipFree(p->d_spans);
@@ -1602,6 +1638,9 @@ int gl_spmv_plan_export(gl_spmv_plan p, int array, void *h_dst, size_t capacity,
         case GL_PLAN_ARRAY_UNITS: src = p->d_units, n = p->b_units; break;
         case GL_PLAN_ARRAY_HUB_ROWS: src = p->d_hub_rows, n = p->b_hub_rows; break;
         case GL_PLAN_ARRAY_SPANS: src = p->d_spans, n = p->b_spans; break;
+        case GL_PLAN_ARRAY_HOT: src = p->d_hot, n = p->b_hot; break;
+        case GL_PLAN_ARRAY_HOT_HDR: src = p->d_hot_hdr, n = p->b_hot_hdr; break;
+        case GL_PLAN_ARRAY_PRESENT: src = p->d_present, n = p->b_present; break;
         default: return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_export: unknown array %d", array);
     }
     *bytes = n;
@@ -1654,8 +1693,8 @@ namespace gl {
 int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_y, int op, float zero, int mask_type,
                      const uint32_t *run_flag) {
     if (p->boolean || p->reference_order) return set_error(GL_ERR_UNSUPPORTED, "spmv_run_general: boolean / reference-order layout");
-    if ((p->flags & (GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD)) && (op == GL_OP_MULADD || op == gl::kOpFixMulAdd) && p->nhot &&
-        (size_t)p->nhot * 4u + (size_t)p->max_block_rows * sizeof(gl::Tile<GL_OP_MULADD>::T) > gl::kLdsBudget)
+    if ((p->flags & (GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD)) && (op == GL_OP_MULADD || op == gl::kOpFixMulAdd) && p->nhot_lds &&
+        (size_t)p->nhot_lds * 4u + ((size_t)p->max_block_rows + gl::kPadSlots) * sizeof(gl::Tile<GL_OP_MULADD>::T) > gl::kLdsBudget)
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_NO_MULADD "
                              "(hot-column table sized for 4-byte accumulators); (+,x) needs a plan without it");
     gl::SpmvArgs a;
@@ -1664,7 +1703,10 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
     a.units = p->d_units;
     a.hub_rows = p->d_hub_rows;
     a.hot_x = p->d_hot_x;
-    a.nhot = p->nhot;
+    a.nhot = p->nhot_lds;
+    a.hot = p->d_hot;
+    a.hot_hdr = p->d_hot_hdr;
+    a.present = p->d_present;
     a.x = d_x;
     a.xg = p->ncompact ? p->d_xc : d_x;
     a.mask = d_mask;

@@ -19,7 +19,10 @@ constexpr uint32_t kMaxBlockRows = kRowPad;            // 16383
 constexpr uint32_t kColOffBits = 32 - kRowBits;        // 18
 constexpr uint32_t kHubSlots = 16;                     // private accumulators per hub row
 constexpr uint32_t kMaxHubRows = 64;                   // per row block
-constexpr uint32_t kMaxPlainRows = kMaxBlockRows - kHubSlots * kMaxHubRows;
+// Padding entries accumulate into DUMMY slots behind a block's last accumulator -- one per lane (a group's padding lanes all
+// on one LDS address would serialise the atomic: EXPERIMENTS R3.12), so a block's slots + kPadSlots still fit the 14-bit field
+constexpr uint32_t kPadSlots = 64;
+constexpr uint32_t kMaxPlainRows = kMaxBlockRows - kHubSlots * kMaxHubRows - kPadSlots;
 constexpr uint32_t kBoolMaxPhases = 8;                 // wider matrices keep the general layout
 constexpr uint32_t kLdsBudget = 160u * 1024u - 512u;   // per-CU LDS minus a little slack
 constexpr uint32_t kThreads = 1024;                    // one workgroup per CU: 16 wavefronts share the tile
@@ -36,6 +39,19 @@ constexpr uint32_t kBoolTileWords = (kMaxBlockRows + 1u) / 32u;  // 512: one bit
 constexpr uint32_t kBoolHubSlots = 32;                        // private bits per hub row, one per tile word 480..511
 constexpr uint32_t kBoolHubMax = 31;                          // hub rows per block (bit 31 of word 511 is the padding slot)
 constexpr uint32_t kBoolHubBit0 = (kBoolTileWords - kBoolHubSlots) * 32u;   // 15360: plain rows use the bits below
+
+// Run-coded hot stream (round 5).  A unit's hot entries -- those whose column has a slot in the LDS table -- are sorted by
+// slot, so a column's entries form a RUN: the entry keeps a 16-bit row slot (+ its value in the general layout) and the
+// column travels as one bit per entry ("the next entry starts a new run") + one base per 64-entry group.  The slots are
+// numbered per UNIT (rank among the hot columns that occur in the unit, listed in the unit's `present` array), so that runs
+// advance the slot by exactly one and lane l of a group reads table[base + popcount(mask below l)] (v_mbcnt with a scalar mask).
+// An ELEMENT is what one wavefront step loads: HG groups, lane-interleaved -- general: 8 B of row slots + 16 B of values
+// per lane (HG = 4), pattern: 16 B of row slots per lane (HG = 8) -- with a 12-byte header per group kept apart (scalar loads):
+// 6.19 instead of 8 bytes per hot entry, 2.19 instead of 4 in the pattern layout.
+constexpr uint32_t kHotGroupsGeneral = 4, kHotGroupsPattern = 8;
+constexpr uint32_t kHotElemBytesGeneral = kHotGroupsGeneral * 64u * 6u;   // 512 B of row slots, then 1024 B of values
+constexpr uint32_t kHotElemBytesPattern = kHotGroupsPattern * 64u * 2u;   // 1024 B of row slots
+constexpr uint32_t kHotHdrWordsPerGroup = 3;                              // per element: HG x {mask lo, mask hi}, then HG bases
 
 struct Shape {
     uint32_t blocks, segments;
@@ -77,6 +93,38 @@ struct BlockPlan {
 BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin, uint32_t row_end, uint32_t max_rows,
                       uint32_t align = 1);
 
+// Where every unit's pieces start, from the cold / hot entry counts of the row blocks (shared by the host and the device
+// formatter, which must agree byte for byte): cold groups are budgeted (a group also ends where the gather index leaves the
+// 18-bit window, `jump_slack` bounds how often), hot elements and present lists are exact / capped by the table size.
+struct UnitLayout {
+    std::vector<uint64_t> cold_goff;      // nunits + 1: first cold group (multiples of 4)
+    std::vector<uint64_t> hot_e0;         // nunits + 1: first hot element
+    std::vector<uint64_t> present_off;    // nunits + 1: first entry of the unit's present list (16-bit entries, even offsets)
+};
+inline UnitLayout layout_units(const BlockPlan &bp, const std::vector<uint64_t> &mc, const std::vector<uint64_t> &mh, uint32_t jump_slack,
+                               uint32_t hot_groups, uint32_t nhot_table) {
+    UnitLayout ul;
+    ul.cold_goff.assign((size_t)bp.nunits + 1, 0);
+    ul.hot_e0.assign((size_t)bp.nunits + 1, 0);
+    ul.present_off.assign((size_t)bp.nunits + 1, 0);
+    for (uint32_t b = 0; b < bp.nblocks; b++) {
+        const uint32_t S = bp.seg[b];
+        for (uint32_t s = 0; s < S; s++) {
+            const size_t u = bp.unit_of[s][b];
+            const uint64_t c = mc[b] * (s + 1) / S - mc[b] * s / S, h = mh[b] * (s + 1) / S - mh[b] * s / S;
+            ul.cold_goff[u + 1] = ((c + 63) / 64 + jump_slack + 9u) / 4u * 4u;
+            ul.hot_e0[u + 1] = ((h + 63) / 64 + hot_groups - 1u) / hot_groups;
+            ul.present_off[u + 1] = (std::min<uint64_t>(h, nhot_table) + 1u) / 2u * 2u;
+        }
+    }
+    for (size_t u = 0; u < bp.nunits; u++) {
+        ul.cold_goff[u + 1] += ul.cold_goff[u];
+        ul.hot_e0[u + 1] += ul.hot_e0[u];
+        ul.present_off[u + 1] += ul.present_off[u];
+    }
+    return ul;
+}
+
 }  // namespace gl
 
 struct gl_spmv_plan_s {
@@ -84,9 +132,14 @@ struct gl_spmv_plan_s {
     uint64_t nnz = 0;
     uint32_t nunits = 0, nblocks = 0, segments = 1, max_block_rows = 0;
     uint64_t ngroups = 0;
-    uint2 *d_entries = nullptr;
+    uint2 *d_entries = nullptr;      // cold groups
     uint32_t *d_bases = nullptr;
-    uint4 *d_units = nullptr;
+    uint4 *d_units = nullptr;        // 3 per unit
+    unsigned char *d_hot = nullptr;  // run-coded hot elements (gl::kHotElemBytes*)
+    uint32_t *d_hot_hdr = nullptr;   // their headers
+    uint16_t *d_present = nullptr;   // per unit: the hot-table slots that occur in it, ascending
+    uint32_t nhot_lds = 0;           // longest present list, rounded up to 64: the LDS table's length
+    uint64_t nhot_elems = 0;
     uint32_t *d_hub_rows = nullptr;
     uint32_t flags = 0;        // GL_PLAN_* given at creation
     uint32_t nhot = 0;         // cached ("hot") columns, multiple of 64
@@ -130,6 +183,7 @@ struct gl_spmv_plan_s {
     float *d_csr_data = nullptr;
     uint64_t device_bytes = 0;
     size_t b_entries = 0, b_bases = 0, b_units = 0, b_hub_rows = 0, b_spans = 0;   // sizes of the formatted arrays (gl_spmv_plan_export)
+    size_t b_hot = 0, b_hot_hdr = 0, b_present = 0;
 };
 
 namespace gl {
@@ -152,7 +206,7 @@ int fmt_detect_pattern(DevCsr *c, uint32_t num_cols, std::vector<uint32_t> &colb
 
 struct EmitGeneral {   // what the host planner decided (gl_spmv_plan_create_ex)
     const BlockPlan *bp;
-    const uint64_t *unit_goff;         // nunits + 1 group offsets (budgets)
+    uint32_t jump_slack;               // layout_units' bound on early group cuts
     const uint32_t *colmap;            // per column: 0x80000000 | hot slot, or the index the cold entry gathers from
     uint32_t gather_cols, nhot_table;  // ranges of those two index spaces
     bool diag_mode;                    // diagonal entries that differ from their column's value are dropped
@@ -164,7 +218,8 @@ struct EmitGeneral {   // what the host planner decided (gl_spmv_plan_create_ex)
     const uint32_t *h_indptr;          // host indptr (global), for the per-row counts
     uint32_t num_cols;
 };
-// fills p->d_entries / d_bases / d_units / d_hub_rows (allocated here) and hub_count, hot_nnz
+// fills p->d_entries / d_bases / d_units / d_hub_rows / d_hot / d_hot_hdr / d_present (allocated here), p->ngroups,
+// p->nhot_elems, p->nhot_lds and hub_count, hot_nnz
 int fmt_emit_general(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vector<uint32_t> &hub_count, uint64_t *hot_nnz);
 // (||,&&) layout: the device twin of bool_plan_build's record loop (gl_spmv_bool.hip)
 struct EmitBool {

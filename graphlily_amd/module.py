@@ -17,6 +17,7 @@ public cl::Buffer members (`vector_buf`, `mask_buf`, ...), including being share
 (oracle/) and the product never routes through it.
 """
 import collections
+import os
 import sys
 
 import numpy as np
@@ -93,12 +94,22 @@ class BaseModule:
         capi.init(self.device_)
 
     def copy_buffer_device_to_device(self, src, dst, nbytes):
-        BaseModule.device_writes_ += 1
+        BaseModule._wrote(dst)
         capi.copy_d2d(dst, src, nbytes)
         capi.sync()
 
-    def _finish(self):
-        BaseModule.device_writes_ += 1       # every run / send_* of every module ends here
+    @staticmethod
+    def _wrote(*buffers):
+        """One more module call has written device memory; `buffers` are the ones it wrote (each remembers the call's number:
+        SpMSpVModule.get_results_nnz trusts the operator's completion record only while its run is the last writer of
+        results_buf)."""
+        BaseModule.device_writes_ += 1
+        for b in buffers:
+            if b is not None:
+                b.last_write_ = BaseModule.device_writes_
+
+    def _finish(self, *written):
+        BaseModule._wrote(*written)       # every run / send_* of every module ends here
         if self.blocking:
             capi.sync()
 
@@ -166,6 +177,9 @@ class SpMVModule(BaseModule):
         # the semiring known at upload time sizes the LDS split (accumulators vs hot-column table); a later
         # switch to (+,x) on a plan built for the 4-byte semirings re-formats the matrix (see run())
         flags = self._plan_flags(self.semiring_.op) | self.plan_flags_
+        if os.environ.get("GRAPHLILY_SPMV_ORDER") == "reference":   # the C++ module layer's switch (spmv_module.h), mirrored
+            flags |= capi.GL_PLAN_REFERENCE_ORDER
+            self.plan_flags_ |= capi.GL_PLAN_REFERENCE_ORDER
         if flags & capi.GL_PLAN_REFERENCE_ORDER:
             flags = capi.GL_PLAN_REFERENCE_ORDER
         for client in getattr(self, "pull_clients_", ()):   # the old plan is about to go away
@@ -215,7 +229,7 @@ class SpMVModule(BaseModule):
             self._make_plan()
         self.plan_.run(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
                        self.mask_type_)
-        self._finish()
+        self._finish(self.results_buf)
 
     # extensions for row-sharded (||,&&) runs: x as a bit vector (gl_spmv_plan_bits_words / gl_spmv_run_bits)
     def bits_words(self):
@@ -228,7 +242,7 @@ class SpMVModule(BaseModule):
         BFS pull iteration in one launch, frontier in and out as bit vectors.  Raises GraphLilyError
         (GL_ERR_UNSUPPORTED) for split plans."""
         self.plan_.bfs_pull_step(bits_in, bits_out, distance_buf, level)
-        self._finish()
+        self._finish(bits_out, distance_buf)
 
     def fused_bfs_ok(self):
         if self.plan_ is None or not self._plan_serves(self.semiring_.op) or self.semiring_.zero != 0.0:
@@ -239,7 +253,7 @@ class SpMVModule(BaseModule):
     def run_bits(self, bits_buf):
         mask = self.mask_buf if self.mask_type_ != kNoMask else None
         self.plan_.run_bits(bits_buf, mask, self.results_buf, self.semiring_.zero, self.mask_type_)
-        self._finish()
+        self._finish(self.results_buf)
 
     def send_vector_device_to_host(self):
         return self.vector_buf.read(np.float32, self.get_num_cols())
@@ -393,7 +407,7 @@ class SpMSpVModule(BaseModule):
         tiny = self._hint_tiny()
         self.plan_.run(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
                        self.mask_type_)
-        self._finish_run()
+        self._finish_run(self.results_buf)
         if tiny:      # this run wrote the results and the accumulator, not the vector
             self.tiny_ = (self.tiny_[0], self.tiny_[1], BaseModule.device_writes_, self.tiny_[3])
 
@@ -403,13 +417,14 @@ class SpMSpVModule(BaseModule):
         mask = self.mask_buf if self.mask_type_ != kNoMask else None
         self.plan_.run_assign(self.vector_buf, mask, self.results_buf, self.semiring_.op, self.semiring_.zero,
                               self.mask_type_, inout_buf, val)
-        self._finish_run()
+        self._finish_run(self.results_buf, inout_buf)
 
-    def _finish_run(self):
+    def _finish_run(self, *written):
         """A blocking run waits for the operator's own completion record (gl_spmspv_wait: the fold's last workgroup stores the
         result count to page-locked memory) instead of the whole stream, and remembers the count for get_results_nnz."""
-        BaseModule.device_writes_ += 1
+        BaseModule._wrote(*written)
         self.nnz_known_ = None
+        self.run_stamp_ = BaseModule.device_writes_
         if self.blocking:
             n = self.plan_.wait()
             if n is not None:
@@ -419,8 +434,11 @@ class SpMSpVModule(BaseModule):
         k = getattr(self, "nnz_known_", None)
         if k is not None and k[1] is self.results_buf and k[2] == BaseModule.device_writes_:
             return k[0]       # (no module call has written device memory since the run reported it)
-        if not self.blocking and getattr(self.plan_, "wait", None) is not None:
-            n = self.plan_.wait()       # the run's own completion record, if it kept one: no device -> host copy
+        # the run's own completion record, if it kept one (no device -> host copy) -- trusted only while that run is the last
+        # module call that wrote results_buf (SSSP's relax step, enqueued behind the run, only reads it: app/sssp.h:218-221)
+        if not self.blocking and getattr(self.plan_, "wait", None) is not None and \
+                getattr(self, "run_stamp_", None) is not None and getattr(self.results_buf, "last_write_", None) == self.run_stamp_:
+            n = self.plan_.wait()
             if n is not None:
                 return n
         return capi.sparse_nnz(self.results_buf)
@@ -454,7 +472,7 @@ class eWiseAddModule(BaseModule):
 
     def run(self, length, val):
         capi.ewise_add(self.in_buf, self.out_buf, length, val)
-        self._finish()
+        self._finish(self.out_buf)
 
     def send_out_device_to_host(self):
         return self.out_buf.read(np.float32)
@@ -487,7 +505,7 @@ class AssignVectorDenseModule(BaseModule):
         if self.mask_type_ not in (kMaskWriteToZero, kMaskWriteToOne):
             _fatal("Invalid mask type")  # assign_vector_dense_module.h:242-245
         capi.assign_dense(self.mask_buf, self.inout_buf, length, val, self.mask_type_)
-        self._finish()
+        self._finish(self.inout_buf)
 
     def send_mask_device_to_host(self):
         return self.mask_buf.read(np.float32)
@@ -542,7 +560,7 @@ class AssignVectorSparseModule(BaseModule):
             if self.generate_new_frontier_:
                 _fatal("[ERROR]: this->generate_new_frontier_ should be false")
             capi.assign_sparse(self.mask_buf, self.inout_buf, val, self._max_entries())
-        self._finish()
+        self._finish(self.inout_buf, self.new_frontier_buf)
 
     def send_mask_device_to_host(self):
         return self.mask_buf.read(IDX_VAL)

@@ -242,6 +242,9 @@ class DeviceBuffer {
         // levels only, and a download tries the packed read-back (gl_buf_d2h_levels checks every value).  Any other access
         // through ptr() forgets it.
         float levels_max = -1.0f;
+        // number of the last access through ptr() (any of them may be a write; rptr() is the read-only access that leaves it):
+        // SpMSpVModule::get_results_nnz trusts its run's completion record only while nobody has touched results_buf since
+        uint64_t touched = 0;
         ~Impl() { if (ptr) gl_buf_free(ptr); }
     };
     std::shared_ptr<Impl> impl_;
@@ -260,8 +263,21 @@ public:
             f();
         }
         impl_->levels_max = -1.0f;
+        static uint64_t clock = 0;
+        impl_->touched = ++clock;
         return impl_->ptr;
     }
+    // the pointer for a call that only READS the buffer (debts are settled, the touch stamp stays)
+    const void *rptr() const {
+        if (!impl_) return nullptr;
+        const uint64_t t = impl_->touched;
+        const float lv = impl_->levels_max;
+        const void *p = ptr();
+        impl_->touched = t;
+        impl_->levels_max = lv;
+        return p;
+    }
+    uint64_t touched() const { return impl_ ? impl_->touched : 0; }
     size_t size() const { return impl_ ? impl_->bytes : 0; }
     bool valid() const { return impl_ && impl_->ptr != nullptr; }
     void upload(const void *host, size_t bytes) const {

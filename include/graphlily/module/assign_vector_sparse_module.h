@@ -70,14 +70,14 @@ public:
     void run(vector_data_t val) {
         barrier_();
         if (generate_new_frontier_) die_("[ERROR]: this->generate_new_frontier_ should be false");
-        GRAPHLILY_CHECK(gl_assign_sparse_typed(mask_buf.ptr(), inout_buf.ptr(), VK::bits(val), capacity_()));
+        GRAPHLILY_CHECK(gl_assign_sparse_typed(mask_buf.rptr(), inout_buf.ptr(), VK::bits(val), capacity_()));
         finish_();
     }
     // SSSP mode
     void run() {
         barrier_();
         if (!generate_new_frontier_) die_("[ERROR]: this->generate_new_frontier_ should be true");
-        GRAPHLILY_CHECK(gl_assign_sparse_new_frontier_typed(mask_buf.ptr(), inout_buf.ptr(), new_frontier_buf.ptr(), capacity_(), VK::kind));
+        GRAPHLILY_CHECK(gl_assign_sparse_new_frontier_typed(mask_buf.rptr(), inout_buf.ptr(), new_frontier_buf.ptr(), capacity_(), VK::kind));
         finish_();
     }
 

@@ -195,8 +195,13 @@ private:
     uint32_t known_nnz_ = 0;
     uint64_t known_stamp_ = 0;
     // a blocking run waits for the operator's own completion record instead of the whole stream
+    // results_buf's touch stamp right after the last run(): while it stands, the run's completion record describes the buffer
+    uint64_t run_touch_ = 0;
+    const void *run_results_ = nullptr;
     void finish_run_() {
         known_stamp_ = 0;
+        run_touch_ = results_buf.touched();
+        run_results_ = results_buf.id();
         if (!blocking_) return;
         uint32_t nnz = 0xffffffffu;
         GRAPHLILY_CHECK(gl_spmspv_wait(plan_, &nnz));
@@ -243,7 +248,11 @@ public:
             return known_nnz_;
         }
         uint32_t nnz = 0xffffffffu;
-        if (!blocking_ && plan_) GRAPHLILY_CHECK(gl_spmspv_wait(plan_, &nnz));   // (the run's own record, if it kept one)
+        // the run's own record, if it kept one -- trusted while nobody has accessed results_buf for writing since that run
+        // (SSSP's relax step, enqueued behind the run, only reads it as its mask: app/sssp.h:218-221); handed out once
+        if (!blocking_ && plan_ && run_touch_ != 0 && run_results_ == results_buf.id() && results_buf.touched() == run_touch_)
+            GRAPHLILY_CHECK(gl_spmspv_wait(plan_, &nnz));
+        run_touch_ = 0;
         if (nnz == 0xffffffffu) GRAPHLILY_CHECK(gl_sparse_nnz((const gl_idx_val *)results_buf.ptr(), &nnz));
         return nnz;
     }

@@ -59,7 +59,17 @@ class SpMVModule : public BaseModule {
 
     // The semiring known at upload time picks the layout: pattern-only entries and a bit vector for (||,&&),
     // a larger hot-column table for (min,+), 8-byte accumulators for (+,x).
+    // GRAPHLILY_SPMV_ORDER=reference (float only; read when the plan is made): the DIAGNOSTIC layout that evaluates the
+    // reference's own loop -- CSR order, fp32 multiply and add rounded separately (spmv_module.h:478-510 of the reference) -- and
+    // is bit-equal to compute_reference_results for all three semirings.  The default layouts accumulate (+,x) in f64, i.e. they
+    // return the correctly rounded row sum, which differs from the reference's sequential fp32 sum by that sum's own rounding
+    // error ("float (+,x) vs the reference loop").
+    static bool reference_order_() {
+        const char *e = getenv("GRAPHLILY_SPMV_ORDER");
+        return kFloat && e && std::string(e) == "reference";
+    }
     static uint32_t flags_for_(OperationType op) {
+        if (reference_order_()) return GL_PLAN_REFERENCE_ORDER;
         if (op == kLogicalAndOr && kFloat) return GL_PLAN_BOOLEAN | GL_PLAN_NO_MULADD;   // (the bit layout serves float only)
         return (op != kMulAdd) ? GL_PLAN_NO_MULADD : 0u;
     }
@@ -215,8 +225,10 @@ public:
         }
         // the first call of an SSSP / PageRank pull iteration (SpMV, then eWiseAdd(n, val) results -> vector)?  It waits for the
         // second one (module/fusion.h 3.)
+        // (not on the reference-order layout: folding eWiseAdd's value into the SpMV starts the sequential float sum from it,
+        //  which rounds differently from sum-then-add -- that layout exists to be bit-equal to the reference)
         if (!blocking_ && kFloat && F.enabled() && mask_type_ == kNoMask && !sharded_ && get_num_rows() == get_num_cols() &&
-            !(plan_flags_ & GL_PLAN_BOOLEAN) && vector_buf.valid() && results_buf.valid() && vector_buf.id() != results_buf.id()) {
+            !(plan_flags_ & (GL_PLAN_BOOLEAN | GL_PLAN_REFERENCE_ORDER)) && vector_buf.valid() && results_buf.valid() && vector_buf.id() != results_buf.id()) {
             F.defer_copy_spmv(this, get_num_rows(), vector_buf, results_buf, VK::bits(semiring_.zero) == 0u, semiring_.op == kMulAdd,
                               [this](float extra, bool fold) { run_now_plus_(extra, fold); },
                               [this](const DeviceBuffer &x, const DeviceBuffer &y) {

@@ -217,6 +217,9 @@ int gl_spmv_plan_describe(gl_spmv_plan plan, gl_spmv_plan_desc *out);
 #define GL_PLAN_ARRAY_UNITS 2
 #define GL_PLAN_ARRAY_HUB_ROWS 3
 #define GL_PLAN_ARRAY_SPANS 4
+#define GL_PLAN_ARRAY_HOT 5     /* general / pattern layouts: the run-coded hot stream, */
+#define GL_PLAN_ARRAY_HOT_HDR 6 /* its per-group run masks and bases, */
+#define GL_PLAN_ARRAY_PRESENT 7 /* and every unit's list of the hot-table slots that occur in it */
 int gl_spmv_plan_export(gl_spmv_plan plan, int array, void *h_dst, size_t capacity, size_t *bytes);
 /* Extension for row-sharded (||,&&) runs: x as a bit vector supplied by the caller, so that ranks exchange
  * n/8 bytes per iteration instead of 4n (multi-GPU).  gl_spmv_plan_bits_words: length in 32-bit words

@@ -261,3 +261,41 @@ def test_pagerank_hollywood_two_ranks(gpu):
     calm = rel_ref_exact <= 5e-6
     assert np.all(rel_ref[calm] <= 1e-5)
     assert np.all(rel_ref <= 1e-5 + 2.0 * rel_ref_exact)
+
+
+# ------------------------------------------------------------------------------------------- the reference tests' own bar
+@pytest.mark.parametrize("name", list(datasets.PAPER_GRAPHS))
+def test_fast_layouts_meet_the_reference_tests_own_bar(gpu, name):
+    """The reference's tests and bench_spmv.cpp's `verify` accept |kernel - reference| <= 1e-4 ABSOLUTE
+    (tests/test_module_spmv_spmspv.cpp:33-40, benchmark/bench_spmv.cpp:15-33).  The fast layouts (f64 row sums) against
+    the fp32 oracle under that bar, on every one of the six stand-ins: bench_spmv's protocol (values 1/num_rows, x in
+    {0,1}) on the general and the pattern layout, and 10 PageRank iterations (damping 0.9, app/pagerank.h:80-90).  Where the
+    oracle's own sequential fp32 sum drifts by more than 1e-5 relative (hub rows) this is the bar that still holds; the
+    measured maxima are logged (gpurun_out/fullsize_margins.jsonl)."""
+    m = _graph(name)
+    mb = io.CSRMatrix(m.num_rows, m.num_cols, np.full(m.nnz, np.float32(1.0 / m.num_rows), np.float32), m.adj_indices.copy(), m.adj_indptr.copy())
+    io.util_round_csr_matrix_dim(mb, 128, 8)
+    x = np.random.default_rng(42).integers(0, 2, size=mb.num_cols).astype(np.float32)
+    ref = O.spmv(to_oracle(mb), x, O.MULADD, 0.0)
+    worst = {}
+    for layout, flags in (("general", M.capi.GL_PLAN_KEEP_VALUES), ("pattern", 0)):
+        plan = M.capi.SpMVPlan(mb.num_rows, mb.num_cols, mb.adj_indptr, mb.adj_indices, mb.adj_data, flags=flags)
+        assert plan.info()["layout"] == layout
+        dx, dy = M.capi.DeviceBuffer.from_host(x), M.capi.DeviceBuffer(4 * mb.num_rows)
+        plan.run(dx, None, dy, 0, 0.0, 0)
+        got = dy.read(np.float32, mb.num_rows)
+        worst[layout] = float(np.abs(got.astype(np.float64) - ref).max())
+        assert worst[layout] <= 1e-4, "%s %s: max |got - oracle| = %g" % (name, layout, worst[layout])
+        plan.destroy()
+    om = _oracle_prepared(m, "pagerank")
+    pref = O.pagerank(om, 0.9, 10)
+    pr = app.PageRank(16, 0, 0)
+    pr.set_up_runtime()
+    pr.load_and_format_matrix(m, 0.9, True)
+    pr.send_matrix_host_to_device()
+    got = pr.pull(0.9, 10)
+    worst["pagerank"] = float(np.abs(got.astype(np.float64) - pref).max())
+    rel = np.abs(got.astype(np.float64) - pref) / np.abs(pref)
+    _margin(config="reference tests' bar (abs 1e-4)", graph=name, n=int(mb.num_rows), max_abs_err_vs_oracle=worst,
+            pagerank_max_rel_err_vs_oracle=float(rel.max()))
+    assert worst["pagerank"] <= 1e-4

@@ -1,5 +1,6 @@
 """GPU: plan creation on the device (csrc/gl_format.hip) produces the SAME device layout as the host
-formatter -- entries, bases, unit descriptors, hub rows (and phase spans for the boolean layout) compared byte for
+formatter -- entries, bases, unit descriptors, hub rows (and phase spans for the boolean layout; the run-coded hot stream,
+its headers and the units' present lists for the other two) compared byte for
 byte through gl_spmv_plan_export -- for every layout, for row shards and split plans, with hot columns and hub rows,
 and the plans it makes compute the oracle's results.  The full-size case also reports the two creation times."""
 import json
@@ -33,7 +34,7 @@ def _assert_same_layout(a, b, what):
     for k in ("nnz", "num_units", "blocks", "segments", "max_block_rows", "groups", "hot_columns", "hot_nnz", "mix", "layout",
               "device_bytes"):
         assert ia[k] == ib[k], "%s: plan.%s host %r device %r" % (what, k, ia[k], ib[k])
-    names = ["entries", "bases", "units", "hub_rows"] + (["spans"] if ia["layout"] == "boolean" else [])
+    names = ["entries", "bases", "units", "hub_rows"] + (["spans"] if ia["layout"] == "boolean" else ["hot", "hot_hdr", "present"])
     for name in names:
         ha, hb = a.export(name), b.export(name)
         assert ha.shape == hb.shape, "%s: %s has %d words on the host, %d on the device" % (what, name, ha.size, hb.size)

@@ -584,6 +584,32 @@ def test_vector_longer_than_one_rendezvous_round(gpu):
     assert np.array_equal(M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), n, 0.0), ref)
 
 
+def test_rendezvous_rounds_with_unequal_work(gpu):
+    """4.5 M vector entries = three rendezvous rounds, and the first two hold almost no products (their columns are empty but
+    for a handful): most workgroups leave rounds 0 and 1 at once (`lo >= P`) and publish the next round's slice sums while the
+    few with work still poll the current one -- the slice words are double-buffered by round parity so that those pollers
+    still find their round's tags (with one buffer they spun out and used the next round's sums).  Repeated so
+    that the generations of several runs pass through both halves."""
+    n = 4500000
+    deg = np.zeros(n, np.uint32)
+    deg[::100003] = 3            # ~45 short columns spread over the first two rounds
+    deg[4300000:] = 1            # the last round: one entry per column
+    indptr = np.zeros(n + 1, np.uint32)
+    np.cumsum(deg, out=indptr[1:])
+    nnz = int(indptr[-1])
+    rows = ((np.arange(nnz, dtype=np.int64) * 11 + 5) % n).astype(np.uint32)
+    csc = io.CSCMatrix(n, n, np.full(nnz, 2.0, np.float32), rows, indptr)
+    vals = (np.arange(n) % 3 + 1).astype(np.float32)
+    v = M.make_sparse_vec(np.arange(n, dtype=np.uint32), vals)
+    got, mod = _run(gpu, csc, "Arithmetic", "NoMask", v, np.zeros(n, np.float32))
+    ref = np.zeros(n, np.float64)
+    np.add.at(ref, rows, 2.0 * np.repeat(vals, deg).astype(np.float64))
+    assert np.array_equal(got, ref.astype(np.float32))
+    for _ in range(3):
+        mod.run()
+        assert np.array_equal(M.convert_sparse_vec_to_dense_vec(mod.send_results_device_to_host(), n, 0.0), ref.astype(np.float32))
+
+
 def test_duplicates_beyond_32_bits_of_products(gpu):
     """A vector that names one dense column 70 000 times: 4.6e9 products, more than the kernel's 32-bit product numbers
     hold -- it must notice (the slice sums saturate) and take the column-by-column path; the bins overflow into the dense

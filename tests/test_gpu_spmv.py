@@ -108,7 +108,7 @@ def test_decompositions(gpu, blocks, segments, monkeypatch):
             _check(got, m, sem, mk, x, mask, "shape %dx%d %s %s" % (blocks, segments, sem, mk))
 
 
-@pytest.mark.parametrize("hot,mix", [("0", "-1"), ("1024", "5"), ("1", "3"), ("1", "6"), ("4096", "1")])
+@pytest.mark.parametrize("hot,mix", [("0", "-1"), ("1024", "3"), ("1", "1"), ("1", "2"), ("4096", "4")])
 def test_hot_column_cache_variants(gpu, hot, mix, monkeypatch):
     """The LDS-cached hot columns and the cold/hot interleave are pure work re-arrangements: any table
     size (0 = disabled) and any interleave must reproduce the same results, with and without segments."""
@@ -124,34 +124,37 @@ def test_hot_column_cache_variants(gpu, hot, mix, monkeypatch):
             _check(got, m, sem, "WriteToOne", x, mask, "hot %s mix %s shape %s %s" % (hot, mix, shape, sem))
 
 
-def test_pattern_pair_layout_fallback(gpu, monkeypatch):
-    """GRAPHLILY_DEBUG spmv_pat4=0 keeps two pattern groups per 8-byte load instead of four per 16-byte load."""
-    set_knob(monkeypatch, "spmv_pat4", "0")
-    m = spmv_prepare("rmat_sym_50K")
-    m.adj_data = np.full(m.nnz, np.float32(0.5), np.float32)
-    x, mask = rand01(m.num_cols, 8), rand01(m.num_rows, 9)
-    for shape in ((0, 0), (5, 2)):
-        set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
-        set_knob(monkeypatch, "spmv_segments", str(shape[1]))
-        for sem in ("Arithmetic", "Tropical"):
-            got = _run_spmv(gpu, m, sem, "WriteToOne", x, mask)
-            _check(got, m, sem, "WriteToOne", x, mask, "pattern pairs %s %s" % (shape, sem))
-
-
-def test_narrow_general_layout(gpu, monkeypatch):
-    """GRAPHLILY_DEBUG spmv_wide=0 keeps the 8-byte-per-lane stream (one group per load) -- the fallback of the default
-    lane-interleaved group pairs; same results."""
-    set_knob(monkeypatch, "spmv_wide", "0")
+@pytest.mark.parametrize("kind", ["general", "pattern"])
+@pytest.mark.parametrize("hot", ["64", "1024", "1"])
+def test_run_coded_hot_stream(gpu, kind, hot, monkeypatch):
+    """The hot stream is run-coded (csrc/gl_spmv_plan.h): 16-bit row slots, the column as one bit per entry + a base per group,
+    table slots numbered per unit.  Runs longer than a group, runs cut by a column segment's boundary, columns absent from a
+    unit and a table of one wavefront's width all give the oracle's results; general (values travel) and pattern layout."""
+    set_knob(monkeypatch, "spmv_hot", hot)
     m = spmv_prepare("rmat_sym_50K")
     rng = np.random.default_rng(31)
-    m.adj_data = rng.random(m.nnz, dtype=np.float32)
+    m.adj_data = rng.random(m.nnz, dtype=np.float32) if kind == "general" else np.full(m.nnz, np.float32(0.5), np.float32)
     x, mask = rng.random(m.num_cols, dtype=np.float32), rand01(m.num_rows, 4)
-    for shape in ((0, 0), (3, 4)):
+    for shape in ((0, 0), (3, 4), (40, 1)):
         set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
         set_knob(monkeypatch, "spmv_segments", str(shape[1]))
         for sem in ("Arithmetic", "Tropical"):
             got = _run_spmv(gpu, m, sem, "WriteToZero", x, mask)
-            _check(got, m, sem, "WriteToZero", x, mask, "narrow %s %s" % (shape, sem))
+            _check(got, m, sem, "WriteToZero", x, mask, "run-coded hot %s table %s shape %s %s" % (kind, hot, shape, sem))
+
+
+def test_run_coded_hot_stream_dense_columns(gpu, monkeypatch):
+    """dense_1K: every column is as hot as every other and every run is as long as the block is tall (runs spanning many
+    groups and elements); with hub rows off and on (a dense row is a hub row of its block)."""
+    m = spmv_prepare("dense_1K")
+    rng = np.random.default_rng(32)
+    m.adj_data = rng.random(m.nnz, dtype=np.float32)
+    x, mask = rng.random(m.num_cols, dtype=np.float32), rand01(m.num_rows, 5)
+    for hub_div in ("48", "1000000"):
+        set_knob(monkeypatch, "spmv_hub_div", hub_div)
+        for sem in ("Arithmetic", "Tropical", "Logical"):
+            got = _run_spmv(gpu, m, sem, "WriteToOne", x, mask)
+            _check(got, m, sem, "WriteToOne", x, mask, "dense columns hub_div %s %s" % (hub_div, sem))
 
 
 def test_hub_row_spreading(gpu):
