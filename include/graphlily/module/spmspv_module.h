@@ -81,6 +81,7 @@ public:
         row_end_ = row_end;
         sharded_ = true;
     }
+    gl_spmspv_plan plan_handle() const { return plan_; }   // extension: the device-resident schedules of graphlily/app/*.h
 
     void load_and_format_matrix(CSCMatrix<float> const &csc_matrix_float) { csc_matrix_float_ = csc_matrix_float; }
 

@@ -16,6 +16,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "graphlily_amd", "lib")
 DRIVER = os.path.join(ROOT, "build", "modules_driver")
 REF_APPS = os.path.join(ROOT, "oracle", "_ref", "ref_apps_on_hip")
+APPS_DRIVER = os.path.join(ROOT, "build", "apps_driver")
+
+
+def _build_apps_driver():
+    """tests/cpp/apps_driver.cpp against include/graphlily/app/{bfs,sssp,pagerank}.h -- this repo's own app drivers (the
+    reference's classes over the device-resident schedules); needs no reference tree."""
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "apps_driver.cpp"), "-o", APPS_DRIVER,
+                           "-L", LIBDIR, "-lgraphlily_hip", "-Wl,-rpath," + LIBDIR])
 
 
 def _build_driver():
@@ -63,6 +73,29 @@ def test_module_headers_compile_and_fail_loudly_without_gpu():
         assert "gl_init" in r.stdout + r.stderr       # print-and-exit convention of the reference
 
 
+def test_app_headers_compile_and_fail_loudly_without_gpu(tmp_path):
+    from graphlily_amd import capi
+    _build_apps_driver()
+    if capi.device_count() == 0:
+        r = subprocess.run([APPS_DRIVER, str(tmp_path / "none.npz"), str(tmp_path), "4"], capture_output=True, text=True)
+        assert r.returncode != 0
+        assert "gl_init" in r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/benchmark"), reason="reference tree not present")
+@pytest.mark.parametrize("define", ["", "-DGRAPHLILY_USE_REFERENCE_APPS", "-DGRAPHLILY_VAL_UFIXED"])
+def test_reference_bench_drivers_compile_against_the_app_headers(define, tmp_path):
+    """benchmark/bench_{bfs,pagerank,sssp}.cpp of the reference, unmodified, with -I<repo>/include first: "graphlily/app/*.h"
+    resolves to this repo's drivers; -DGRAPHLILY_USE_REFERENCE_APPS makes them step aside for the checkout's (#include_next)."""
+    for app in ("bfs", "pagerank", "sssp"):
+        subprocess.check_call(["g++", "-std=c++11", "-O1", "-w"] + ([define] if define else []) +
+                              ["-I", os.path.join(ROOT, "include"), "-I", "/root/reference", "/root/reference/benchmark/bench_%s.cpp" % app,
+                               "-o", str(tmp_path / ("bench_" + app)), "-L", LIBDIR, "-lgraphlily_hip", "-Wl,-rpath," + LIBDIR])
+    out = subprocess.run(["nm", "-C", str(tmp_path / "bench_bfs")], capture_output=True, text=True).stdout
+    # which BFS got compiled in: the device-resident schedule serves val_t = float only (dead code otherwise)
+    assert ("gl_bfs_bits_shard_step" in out) == (define == "")
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/graphlily/app"), reason="reference tree not present")
 def test_reference_app_drivers_compile_unmodified():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref_apps"])
@@ -76,6 +109,52 @@ def test_cpp_module_layer_parity(gpu):
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ALL CHECKS PASSED" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nnz,iters", [(30000, 400000, 8), (600000, 7000000, 9)])
+def test_cpp_app_drivers_match_the_oracle(gpu, tmp_path, n, nnz, iters):
+    """include/graphlily/app/{bfs,sssp,pagerank}.h driven from C++ (tests/cpp/apps_driver.cpp): BFS pull / pull_push on the
+    device-resident schedule (first call enqueued, then the replayed hipGraph; 600 K vertices: the packed read-back), push, the
+    same through a world-of-one gl_dist_* communicator (the sharded schedule's path), SSSP in its three modes, PageRank.  Every
+    result word for word against the oracle (BFS / SSSP) or to 1e-4 (PageRank, the reference tests' bar)."""
+    import scipy.sparse as sp
+    from graphlily_amd import datasets
+    from oracle import oracle as O
+    from helpers import to_oracle
+    _build_apps_driver()
+    m = datasets.rmat(n, nnz, seed=3)
+    A = sp.csr_matrix((m.adj_data, m.adj_indices.astype(np.int32), m.adj_indptr.astype(np.int32)), shape=(m.num_rows, m.num_cols),
+                      dtype=np.float32)
+    p = str(tmp_path / "rmat_csr_float32.npz")
+    sp.save_npz(p, A, compressed=False)
+    r = subprocess.run([APPS_DRIVER, p, str(tmp_path), str(iters), "dist"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count(" OK") == 13
+
+    def rd(name):
+        return np.fromfile(str(tmp_path / (name + ".bin")), dtype=np.float32)
+
+    ob = to_oracle(m)
+    O.util_round_csr_matrix_dim(ob, 128, 128)
+    ob.adj_data = np.ones(ob.nnz, np.float32)
+    ref = O.bfs(ob, 0, iters)
+    for name in ("bfs_pull_push", "bfs_pull", "bfs_push", "bfs_pull_push_dist"):
+        assert np.array_equal(rd(name).view(np.uint32), ref.view(np.uint32)), name
+    assert len(np.unique(ref)) > 3
+    os_ = to_oracle(m)
+    O.sssp_preprocess(os_)
+    O.util_round_csr_matrix_dim(os_, 128, 128)
+    ref = O.sssp(os_, 0, iters, zero=999999999.0)
+    for name in ("sssp_pull_push", "sssp_pull", "sssp_push"):
+        assert np.array_equal(rd(name).view(np.uint32), ref.view(np.uint32)), name
+    op = to_oracle(m)
+    O.util_round_csr_matrix_dim(op, 128, 128)
+    O.util_normalize_csr_matrix_by_outdegree(op)
+    op.adj_data = (op.adj_data * np.float32(0.9)).astype(np.float32)
+    ref = O.pagerank(op, 0.9, 10)
+    assert np.abs(rd("pagerank").astype(np.float64) - ref).max() <= 1e-4
 
 
 @pytest.mark.gpu
