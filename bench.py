@@ -122,9 +122,42 @@ def main():
 
     capi.init(local_rank)
     capi.set_stream(torch.cuda.current_stream().cuda_stream)   # library kernels on torch's stream
+    bfs_comm, preflight = None, None
     if use_dist and args.cabi_comm:
         from graphlily_amd.dist import CabiComm
         bfs_comm = CabiComm(True, force=args.force_dist)       # the BFS exchange through gl_dist_*: recordable into the hipGraph
+
+    # every exit path (an exception in a leg, SystemExit) ends the hipGraphs that recorded RCCL operations BEFORE their
+    # communicator: RCCL's communicator destroy waits for such graphs (a 15-minute hang at exit in round 4)
+    import atexit
+    closed = []
+
+    def close_comms(normal=False):
+        if closed:
+            return
+        closed.append(True)
+        if use_dist:
+            try:
+                if normal:
+                    dist.barrier()
+                if bfs_comm is not None:
+                    bfs_comm.gl.destroy()        # (capi.Dist.destroy ends the graphs that recorded its exchanges first)
+                if normal:
+                    dist.destroy_process_group()
+            except Exception as e:
+                print("bench.py: closing the communicators: %r" % (e,), file=sys.stderr)
+
+    atexit.register(close_comms)
+
+    # ------------------------------------------------------------------ first contact with the peers, before anything is timed
+    if use_dist:
+        from graphlily_amd import dist as gdist
+        preflight = gdist.preflight(comm, dev, args.gpus if world > 1 else 1, cabi=bfs_comm,
+                                    fail_cabi="dist_preflight_fail_cabi=1" in os.environ.get("GRAPHLILY_DEBUG", ""))
+        if bfs_comm is not None and preflight["exchange_path"] != "cabi":
+            # the C ABI exchange did not pass: BFS goes through torch.distributed like everything else (recorded in the line)
+            bfs_comm.gl.destroy()
+            bfs_comm = None
 
     # ------------------------------------------------------------------ workload
     t0 = time.time()
@@ -298,7 +331,7 @@ def main():
     if not args.no_bfs:
         try:
             keep = {}
-            out["bfs"] = _bench_bfs(app, capi, bfs_comm if (use_dist and args.cabi_comm) else comm, raw, g["iters"], local_rank, args.bfs_runs,
+            out["bfs"] = _bench_bfs(app, capi, bfs_comm if bfs_comm is not None else comm, raw, g["iters"], local_rank, args.bfs_runs,
                                     fence, keep)
             if args.emulate_rank and world == 1:
                 out["bfs_emulated_ranks"] = _bench_emulated(app, capi, raw, g["iters"], local_rank, args.bfs_runs, args.emulate_rank,
@@ -325,13 +358,24 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = _cpu_baseline(csr, x.cpu().numpy(), alg_bytes)
 
+    if preflight is not None:
+        # the exchange steps timed APART from compute (pre-flight: median of 10 device-synchronised exchanges of orkut's sizes),
+        # and what an app's iteration pays for them: BFS one bit all-gather (+ tallies) per slot, PageRank / SSSP pull one dense
+        # all-gather per iteration
+        path = preflight["exchange_path"]
+        ex = preflight["exchange_ms"].get(path if path in preflight["exchange_ms"] else "torch", {})
+        bits_ms = ex.get("bits_384KB_with_tallies", ex.get("bits_384KB"))
+        out["rccl_ranks"] = preflight["ranks"]
+        out["exchange_path"] = {"bfs": path, "dense": "torch", "backend": preflight["backend"], "cabi_error": preflight["cabi_error"],
+                                "verified": preflight["verified"]}
+        out["exchange_ms"] = dict(preflight["exchange_ms"])
+        out["exchange_ms"]["per_app"] = {"bfs_per_run": None if bits_ms is None else round(bits_ms * g["iters"], 4),
+                                         "pagerank_per_iteration": preflight["exchange_ms"].get("torch", {}).get("dense_12MB"),
+                                         "sssp_pull_per_iteration": preflight["exchange_ms"].get("torch", {}).get("dense_12MB"),
+                                         "note": "384 KB of bits / 12 MB of floats = orkut's vectors, whatever graph is benched"}
     if rank == 0:
         print(json.dumps(_ordered(out)), flush=True)
-    if use_dist:
-        dist.barrier()
-        if args.cabi_comm:
-            bfs_comm.gl.destroy()        # (ends the graphs that recorded its exchanges first)
-        dist.destroy_process_group()
+    close_comms(normal=True)
 
 
 def _ordered(out):

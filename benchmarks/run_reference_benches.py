@@ -51,7 +51,11 @@ def main():
             del m, A
         rc = 0
         for a in args.apps.split(","):
-            exe = os.path.join(ROOT, "oracle", "_ref", "bench_%s_on_hip" % a)
+            # <app>_refapps: the same driver compiled with -DGRAPHLILY_USE_REFERENCE_APPS (the checkout's app headers over the
+            # module layer) instead of this repo's include/graphlily/app/ drivers
+            refapps = a.endswith("_refapps")
+            a = a[:-len("_refapps")] if refapps else a
+            exe = os.path.join(ROOT, "oracle", "_ref", "bench_%s_on_hip%s" % (a, "_refapps" if refapps else ""))
             if not os.path.exists(exe):
                 print("# %s not built (needs /root/reference: make -C oracle ref_benches)" % exe)
                 rc = 2

@@ -276,3 +276,154 @@ class CabiComm(Comm):
 
     def exchange_bits(self, bits_buf, k, bounds, tally_slot_buf=None, tally_slot=None):
         self.gl.all_gather_bits_tally(bits_buf, bounds, tally_slot_buf)
+
+
+def preflight(comm, device, expect_world, cabi=None, rows=3_072_512, watchdog_s=60.0, fail_cabi=False):
+    """First contact with the peers, BEFORE anything is timed (bench.py --gpus N; round 4's verdict: the row-sharded path had
+    only ever met one RCCL rank, gloo ranks and an emulation):
+
+      * the process group holds `expect_world` ranks;
+      * a BIT all-gather of `rows` bits (orkut: 384 KB -- a BFS slot's exchange) and a DENSE all-gather of `rows` floats
+        (12 MB -- a PageRank / SSSP iteration's exchange), each on nnz-style UNEVEN bounds and on equal bounds, every word
+        verified on every rank against the pattern its owner wrote;
+      * the same two through the C ABI's communicator (`cabi`: a CabiComm, gl_dist_all_gather_bits_tally with tallies /
+        gl_dist_all_gather_f32) when one is given -- a failure there (exception or wrong words) is RECORDED and the caller
+        falls back to the torch path;
+      * how long one exchange of each kind takes (median of 10, device-synchronised) -- `exchange_ms`, timed apart from compute;
+      * a watchdog: if all of this takes longer than `watchdog_s` (a collective that never completes), the process prints one
+        JSON line saying so and exits with code 3 instead of hanging its launcher.
+
+    Returns {"ranks", "backend", "verified", "exchange_path", "cabi_error", "exchange_ms": {...}}; raises on a torch-path failure
+    (there is nothing to fall back to)."""
+    import json
+    import os
+    import threading
+    import time
+    import torch
+    W, rank = comm.world_size, comm.rank
+    out = {"ranks": W, "backend": None, "verified": False, "exchange_path": "torch", "cabi_error": None, "exchange_ms": {}}
+    if not comm.distributed:
+        out.update({"backend": "none", "verified": True, "exchange_path": "none"})
+        return out
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(watchdog_s):
+            print(json.dumps({"error": "multi-GPU pre-flight did not finish within %.0f s (a collective hung); rank %d of %d"
+                                       % (watchdog_s, rank, W), "preflight": out}), flush=True)
+            os._exit(3)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        out["backend"] = comm.dist.get_backend(comm.group)
+        if W != expect_world:
+            raise RuntimeError("the process group holds %d ranks, --gpus asked for %d" % (W, expect_world))
+        rows = max(rows // (64 * W) * (64 * W), 64 * W)
+        words = rows // 32
+        cuda = torch.device(device).type == "cuda"
+
+        def sync():
+            if cuda:
+                torch.cuda.synchronize()
+
+        def bounds_of(uneven):
+            if not uneven or W == 1:
+                return [rows // W * r for r in range(W + 1)]
+            # nnz-balanced ranges differ in length: shift the interior cuts by alternating multiples of 64 rows
+            b = [0] + [rows // W * r + (64 * (1 + r % 3) if r % 2 else -64 * (1 + r % 2)) for r in range(1, W)] + [rows]
+            return b
+
+        def owner_pattern(idx, bnds):
+            own = torch.zeros_like(idx)
+            for r in range(1, W):
+                own += (idx >= bnds[r]).to(idx.dtype)
+            return own
+
+        def check(kind, vec, bnds, unit):
+            idx = torch.arange(vec.shape[0], device=vec.device, dtype=torch.int64)
+            own = owner_pattern(idx, [b // unit for b in bnds])
+            want = (idx * 7 + own * 1000003 + 11) % 16777213       # (exact in float32 below 2^24)
+            ok = bool(torch.equal(vec.to(torch.int64), want))
+            flag = torch.tensor([0 if ok else 1], dtype=torch.int64, device=vec.device if out["backend"] != "gloo" else "cpu")
+            comm.dist.all_reduce(flag, group=comm.group)
+            if int(flag.item()):
+                raise RuntimeError("%s all-gather returned wrong words on %d rank(s)" % (kind, int(flag.item())))
+
+        def fill(vec, bnds, unit):
+            vec.zero_()
+            lo, hi = bnds[rank] // unit, bnds[rank + 1] // unit
+            idx = torch.arange(lo, hi, device=vec.device, dtype=torch.int64)
+            vec[lo:hi] = ((idx * 7 + rank * 1000003 + 11) % 16777213).to(vec.dtype)
+
+        def median_ms(fn, n=10):
+            ts = []
+            for _ in range(n):
+                sync()
+                t0 = time.perf_counter()
+                fn()
+                sync()
+                ts.append(time.perf_counter() - t0)
+            return round(float(np.median(ts)) * 1e3, 4)
+
+        bits = torch.zeros(words, dtype=torch.int32, device=device)
+        dense = torch.zeros(rows, dtype=torch.float32, device=device)
+        for uneven in (True, False):
+            bnds = bounds_of(uneven)
+            fill(bits, bnds, 32)
+            comm.all_gather_slices(bits, [b // 32 for b in bnds])
+            check("bit (torch path, %s bounds)" % ("uneven" if uneven else "equal"), bits, bnds, 32)
+            fill(dense, bnds, 1)
+            comm.all_gather_slices(dense, bnds)
+            check("dense (torch path, %s bounds)" % ("uneven" if uneven else "equal"), dense, bnds, 1)
+        bnds = bounds_of(True)
+        out["exchange_ms"]["torch"] = {"bits_384KB": median_ms(lambda: comm.all_gather_slices(bits, [b // 32 for b in bnds])),
+                                       "dense_12MB": median_ms(lambda: comm.all_gather_slices(dense, bnds))}
+        out["verified"] = True
+        if cabi is not None:
+            try:
+                if fail_cabi:
+                    raise RuntimeError("forced by the test hook (GRAPHLILY_DEBUG dist_preflight_fail_cabi=1)")
+                from . import capi
+                bbits, bdense = capi.DeviceBuffer.from_torch(bits), capi.DeviceBuffer.from_torch(dense)
+                tally = torch.zeros(W * capi.GL_BFS_TALLY_RANK_WORDS, dtype=torch.int32, device=device)
+                btally = capi.DeviceBuffer.from_torch(tally)
+                for uneven in (True, False):
+                    bnds = bounds_of(uneven)
+                    fill(bits, bnds, 32)
+                    tally.zero_()
+                    tally[rank * capi.GL_BFS_TALLY_RANK_WORDS:(rank + 1) * capi.GL_BFS_TALLY_RANK_WORDS] = rank + 1
+                    sync()
+                    cabi.gl.all_gather_bits_tally(bbits, bnds, btally)
+                    capi.sync()
+                    check("bit (C ABI path, %s bounds)" % ("uneven" if uneven else "equal"), bits, bnds, 32)
+                    want = torch.arange(1, W + 1, device=device, dtype=torch.int32).repeat_interleave(capi.GL_BFS_TALLY_RANK_WORDS)
+                    if not torch.equal(tally, want):
+                        raise RuntimeError("the tallies that ride with the bit all-gather came back wrong")
+                    fill(dense, bnds, 1)
+                    sync()
+                    cabi.gl.all_gather_f32(bdense, bnds)
+                    capi.sync()
+                    check("dense (C ABI path, %s bounds)" % ("uneven" if uneven else "equal"), dense, bnds, 1)
+                bnds = bounds_of(True)
+
+                def cabi_bits():
+                    cabi.gl.all_gather_bits_tally(bbits, bnds, btally)
+                    capi.sync()
+
+                def cabi_dense():
+                    cabi.gl.all_gather_f32(bdense, bnds)
+                    capi.sync()
+
+                out["exchange_ms"]["cabi"] = {"bits_384KB_with_tallies": median_ms(cabi_bits), "dense_12MB": median_ms(cabi_dense)}
+                out["exchange_path"] = "cabi"
+            except Exception as e:          # recorded; the caller keeps the torch path
+                out["cabi_error"] = repr(e)
+                # every rank must take the same path: one rank's failure is everybody's
+            flag = torch.tensor([0 if out["exchange_path"] == "cabi" else 1], dtype=torch.int64,
+                                device=device if out["backend"] != "gloo" else "cpu")
+            comm.dist.all_reduce(flag, group=comm.group)
+            if int(flag.item()) and out["exchange_path"] == "cabi":
+                out["exchange_path"], out["cabi_error"] = "torch", "another rank's C ABI pre-flight failed"
+        return out
+    finally:
+        done.set()

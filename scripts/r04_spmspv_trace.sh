@@ -1,7 +1,7 @@
-# round 4: per-kernel durations of blocking SpMSpV calls (rocprofv3 kernel trace of scripts/r03_spmspv_call_trace.py)
+# round 4: per-kernel durations of blocking SpMSpV calls (rocprofv3 kernel trace of scripts/spmspv_call_trace.py)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 for c in "$@"; do set -- $c
-  cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/sp_trace && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sp_trace -- python $GRAFT_REPO_ROOT/scripts/r03_spmspv_call_trace.py $1 $2 > /tmp/sp_trace.log 2>&1
+  cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/sp_trace && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sp_trace -- python $GRAFT_REPO_ROOT/scripts/spmspv_call_trace.py $1 $2 > /tmp/sp_trace.log 2>&1
   cd $GRAFT_REPO_ROOT
   echo "== $1 $2"; grep "blocking\|enqueued" /tmp/sp_trace.log
   python - <<'PY'

@@ -366,3 +366,25 @@ def test_gl_dist_slice_plan_arithmetic():
     b = partition_rows_by_nnz(m.adj_indptr, 8)
     lo, hi = capi.dist_slice_plan(1, b)
     assert lo[0] == 0 and hi[-1] == 4 * ((m.num_rows + 31) // 32) and np.all(hi[:-1] == lo[1:]) and np.all(hi >= lo)
+
+
+# ---- the multi-GPU pre-flight of bench.py --gpus N (graphlily_amd.dist.preflight), on gloo ranks
+def _body_preflight(comm):
+    from graphlily_amd.dist import preflight
+    pf = preflight(comm, "cpu", comm.world_size, rows=64 * comm.world_size * 32)
+    ok = (pf["ranks"] == comm.world_size and pf["backend"] == "gloo" and pf["verified"] is True and pf["exchange_path"] == "torch"
+          and pf["exchange_ms"]["torch"]["bits_384KB"] > 0 and pf["exchange_ms"]["torch"]["dense_12MB"] > 0)
+    # a world of the wrong size is refused before any collective
+    try:
+        preflight(comm, "cpu", comm.world_size + 1, rows=64 * comm.world_size * 32)
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "ranks" in str(e)
+    return ok
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_preflight_verifies_both_all_gathers(world):
+    """bench.py's first contact with its peers: the process group's size, a bit and a dense all-gather on uneven and on equal
+    bounds with every word verified on every rank, the exchange timed apart from compute -- here on gloo ranks."""
+    assert all(_spawn("_body_preflight", world).values())

@@ -192,6 +192,30 @@ def test_bench_one_rank_rccl(gpu):
     assert rec["n_gpus"] == 1 and rec["selfcheck_ok"] is True
     assert "error" not in rec.get("bfs", {}), rec["bfs"]
     assert rec["bfs"]["pull"]["reached"] == rec["bfs"]["pull_push"]["reached"] > 0
+    # the pre-flight ran on RCCL before anything was timed: ranks as asked, both verified all-gathers, the exchange timed apart
+    assert rec["rccl_ranks"] == 1 and rec["exchange_path"]["backend"] == "nccl" and rec["exchange_path"]["verified"] is True
+    assert rec["exchange_path"]["bfs"] == "torch" and rec["exchange_ms"]["torch"]["dense_12MB"] > 0
+    assert rec["exchange_ms"]["per_app"]["bfs_per_run"] > 0
+
+
+def test_bench_falls_back_when_the_c_abi_preflight_fails(gpu):
+    """`--cabi-comm` with a pre-flight failure of the C ABI exchange (forced: GRAPHLILY_DEBUG dist_preflight_fail_cabi=1): the
+    failure is recorded, the sharded BFS runs on the torch.distributed path, the line still comes out, and the process ends
+    without waiting for a communicator (the C ABI communicator is destroyed right away)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["GRAPHLILY_DEBUG"] = "dist_preflight_fail_cabi=1"
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--cabi-comm", "--no-six-graphs", "--no-spmspv",
+                        "--steps", "10", "--warmup", "2", "--scale", "0.1", "--bfs-runs", "1", "--no-cpu-baseline", "--no-pattern"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["exchange_path"]["bfs"] == "torch" and "forced by the test hook" in rec["exchange_path"]["cabi_error"]
+    assert rec["bfs"]["exchange"] == "Comm" and "error" not in rec["bfs"]
+    assert rec["bfs"]["pull"]["reached"] == rec["bfs"]["pull_push"]["reached"] > 0
 
 
 def test_bench_one_rank_rccl_exchange_inside_the_graph(gpu):
@@ -214,6 +238,9 @@ def test_bench_one_rank_rccl_exchange_inside_the_graph(gpu):
     assert "error" not in rec.get("bfs", {}), rec["bfs"]
     assert rec["bfs"]["exchange"] == "CabiComm" and "hipGraph" in rec["bfs"]["schedule"], rec["bfs"]
     assert rec["bfs"]["pull"]["reached"] == rec["bfs"]["pull_push"]["reached"] > 0
+    # the pre-flight verified the C ABI exchange (bits + tallies, dense) before the BFS leg took that path
+    assert rec["exchange_path"]["bfs"] == "cabi" and rec["exchange_path"]["cabi_error"] is None
+    assert rec["exchange_ms"]["cabi"]["bits_384KB_with_tallies"] > 0 and rec["exchange_ms"]["cabi"]["dense_12MB"] > 0
 
 
 def test_a_communicator_outlives_the_graphs_that_recorded_it(gpu):

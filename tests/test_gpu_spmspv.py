@@ -97,6 +97,49 @@ def test_power_law(gpu, sem, mask_name, sparsity):
     assert_parity(got, ref, op, "gplus/%s/%s" % (sem, mask_name))
 
 
+def _column_constant_csc(kind, seed=4):
+    """rmat_20K as a CSC whose columns are constant apart from the diagonal: `sssp` = unit weights + weight-0 self edges
+    (app/sssp.h:16-62), `pagerank` = 0.9 / out-degree per column (app/pagerank.h:66-67) with the diagonal entries set to other
+    values (exceptions), `unit` = all ones."""
+    m = named_matrix("rmat_20K")
+    if kind == "sssp":
+        io.sssp_add_self_edges(m)
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    c = io.csr2csc(m)
+    if kind == "pagerank":
+        deg = np.maximum(np.diff(c.adj_indptr.astype(np.int64)), 1)
+        col_of = np.repeat(np.arange(c.num_cols), np.diff(c.adj_indptr.astype(np.int64)))
+        c.adj_data = (np.float32(0.9) / deg[col_of].astype(np.float32)).astype(np.float32)
+        diag = c.adj_indices == col_of
+        c.adj_data[diag] = np.random.default_rng(seed).random(int(diag.sum()), dtype=np.float32) + 2.0   # exceptions
+    elif kind == "unit":
+        c.adj_data = np.ones(c.nnz, np.float32)
+    return c
+
+
+@pytest.mark.parametrize("kind", ["sssp", "pagerank", "unit"])
+@pytest.mark.parametrize("cnt", [300, 2500, 9000, 20000])
+def test_column_constant_matrices(gpu, kind, cnt):
+    """The matrices the apps build -- unit weights, SSSP's zero diagonal (app/sssp.h:16-62), PageRank-like 0.9 / out-degree
+    columns, here with diagonal exceptions -- through every path of the bin kernel (one window / four windows / the
+    rendezvous / the whole vector), three semirings, a mask compared with `zero`.  (Round 5 tried 4-byte bin records for such
+    matrices -- 12 bytes moved per product instead of 24 -- and reverted them: the operator is bound by its phases, not its
+    bytes; EXPERIMENTS R5.4.  The cases stay.)"""
+    c = _column_constant_csc(kind)
+    rng = np.random.default_rng(cnt)
+    cols = np.sort(rng.choice(c.num_cols, size=min(cnt, c.num_cols), replace=False)).astype(np.uint32)
+    for sem in ("Arithmetic", "Tropical", "Logical"):
+        op, zero = SEMIRINGS[sem]
+        vals = (rng.integers(1, 9, size=cols.shape[0]) / 4.0).astype(np.float32)
+        if sem == "Logical":
+            vals[::7] = 0.0                     # (entries whose products cannot change a result)
+        v = M.make_sparse_vec(cols, vals)
+        mask = np.where(rand01(c.num_rows, 5) > 0, np.float32(zero), np.float32(3)).astype(np.float32)
+        got, mod = _run(gpu, c, sem, "WriteToZero", v, mask)
+        ref = O.spmspv(to_oracle(c), v, op, zero, mask, MASKS["WriteToZero"])
+        assert_parity(got, ref, op, "column-constant %s %s %d" % (kind, sem, cnt))
+
+
 def test_saturating_min_plus(gpu):
     """(min,+) products saturate at FLOAT_INF (hw/float_pe.h:24-33, spmspv_module.h:482-491)."""
     c = _csc("dense_1K")
