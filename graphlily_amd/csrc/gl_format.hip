@@ -9,11 +9,10 @@
 //   * column-constant ("pattern") test    two passes, wave per row
 //   * the per-block column sort           ONE stable radix sort of all entries by (block, hot?, gather index)
 //                                         (rocPRIM; the host sorts each block's records on its own)
-//   * group packing                       a wave per unit walks its sorted piece: a group ends after 64 entries or
-//                                         where the column offset would overflow its 18 bits (64 candidate groups
-//                                         are tested per step, so the walk costs ~1/64 step per group)
-//   * emission                            a wave per group writes the 64 entries in the stream's final
-//                                         lane-interleaved order
+//   * the delta-coded cold stream         gaps between neighbouring sorted entries give the dummy entries each one needs
+//                                         (255 columns per dummy), ONE inclusive scan (rocPRIM) gives every entry its
+//                                         position in its unit's stream, a thread per entry writes it and its dummies in
+//                                         the stream's final lane-interleaved order
 //   * the run-coded hot stream            run starts flagged by comparing neighbouring keys, ONE inclusive scan (rocPRIM)
 //                                         numbers the runs, a wave per hot group writes slots, values, run mask and base
 // Both formatters produce byte-identical arrays (tests/test_gpu_format.py compares them through gl_spmv_plan_export).
@@ -174,83 +173,44 @@ struct UnitDesc {
     uint32_t nhot_groups, pad0, pad1, pad2;              // hot groups incl. the padding up to whole elements
 };
 
-struct UnitGroups {
-    uint32_t ncold_raw, ncold;   // cold groups with entries / after padding to the stream layout's multiple
-};
-
-// One wave per unit: cut the unit's cold piece into groups.  A group holds <= 64 consecutive entries whose gather
-// index is within 2^18 of its first entry's (the host formatter's rule, gl_spmv.hip).  64 candidate groups per step.
+// ---- the delta-coded cold stream (gl_spmv_plan.h)
+// dummies[i] = dummy entries in front of sorted position i: a cold entry whose predecessor is a cold entry of the same block
+// and more than 255 gather indices away needs one per 255 columns of the gap.  (Hot and dropped entries: 0.)
 template <typename K>
-__global__ __launch_bounds__(64) void fmt_group_kernel(const K *__restrict__ keys, const UnitDesc *__restrict__ units, uint32_t cb,
-                                                       uint32_t group_mult, uint32_t *__restrict__ gstart, uint32_t *__restrict__ gcount,
-                                                       UnitGroups *__restrict__ ug, uint4 *__restrict__ plan_units) {
-    const UnitDesc u = units[blockIdx.x];
-    const uint32_t lane = threadIdx.x;
-    const K cmask = ((K)1 << cb) - 1;
-    uint32_t cur = u.cold_begin, g = u.goff;
-    const uint32_t end = u.cold_end;
-    while (cur < end) {
-        const uint32_t p = cur + 64u * lane;
-        bool full = false;
-        if (p < end && end - p >= 64u)
-            full = (uint32_t)(keys[p + 63u] & cmask) - (uint32_t)(keys[p] & cmask) < (1u << kColOffBits);
-        const unsigned long long notfull = __ballot(!full);
-        const uint32_t f = notfull ? (uint32_t)__builtin_ctzll(notfull) : 64u;
-        if (lane < f) {
-            gstart[g + lane] = p;
-            gcount[g + lane] = 64u;
+__global__ __launch_bounds__(kFmtThreads) void fmt_gap_kernel(const K *__restrict__ keys, uint64_t n, uint32_t cb, uint32_t bb, uint32_t *__restrict__ dummies) {
+    const K cmask = ((K)1 << cb) - 1, drop = (K)1 << (bb + cb + 1u);
+    for (uint64_t i = (uint64_t)blockIdx.x * kFmtThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kFmtThreads) {
+        uint32_t d = 0u;
+        if (i > 0) {
+            const K k = keys[i], kp = keys[i - 1];
+            if ((k >> cb) == (kp >> cb) && ((k >> cb) & (K)1) == 0 && !(k & drop)) {      // same block, both cold
+                const uint32_t gap = (uint32_t)(k & cmask) - (uint32_t)(kp & cmask);
+                if (gap > kColdMaxDelta) d = (gap - 1u) / kColdMaxDelta;
+            }
         }
-        g += f;
-        if (f == 64u) {
-            cur += 64u * 64u;
-            continue;
-        }
-        const uint32_t pf = cur + 64u * f;
-        if (pf >= end) break;
-        const uint32_t j = pf + lane;
-        const bool viol = j < end && (uint32_t)(keys[j] & cmask) - (uint32_t)(keys[pf] & cmask) >= (1u << kColOffBits);
-        const unsigned long long vm = __ballot(viol);
-        const uint32_t cnt = vm ? (uint32_t)__builtin_ctzll(vm) : min(64u, end - pf);
-        if (lane == 0) {
-            gstart[g] = pf;
-            gcount[g] = cnt;
-        }
-        g++;
-        cur = pf + cnt;
-    }
-    const uint32_t ncold_raw = g - u.goff;
-    const uint32_t ncold = (ncold_raw + group_mult - 1u) / group_mult * group_mult;
-    for (uint32_t k = ncold_raw + lane; k < ncold; k += 64u) {   // all-padding groups
-        gstart[u.goff + k] = 0u;
-        gcount[u.goff + k] = 0u;
-    }
-    if (lane == 0) {
-        ug[blockIdx.x] = UnitGroups{ncold_raw, ncold};
-        plan_units[3u * blockIdx.x] = make_uint4(u.goff, ncold, u.r0, u.nrows_direct);
-        plan_units[3u * blockIdx.x + 1u] = make_uint4(u.hub_off, u.nhub, u.nhot_groups, u.seg);
+        dummies[i] = d;
     }
 }
-
-// cold stream layouts as in gl_spmv.hip: 1 wide (two 8-B groups lane-interleaved), 3 quad (four 4-B groups)
-template <int LAYOUT>
-__device__ __forceinline__ void fmt_store(void *entries, uint32_t g, uint32_t lane, uint32_t ex, uint32_t ey) {
-    if (LAYOUT == 1) static_cast<uint2 *>(entries)[(size_t)(g >> 1) * 128u + 2u * lane + (g & 1u)] = make_uint2(ex, ey);
-    else static_cast<uint32_t *>(entries)[(size_t)(g >> 2) * 256u + 4u * lane + (g & 3u)] = ex;
+// a unit that begins inside a block's cold entries (column segments) starts its own stream: no dummies in front of its first entry
+__global__ __launch_bounds__(kFmtThreads) void fmt_gap_unit_starts_kernel(const UnitDesc *__restrict__ units, uint32_t nunits, uint32_t *__restrict__ dummies) {
+    const uint32_t u = blockIdx.x * kFmtThreads + threadIdx.x;
+    if (u < nunits && units[u].cold_begin < units[u].cold_end) dummies[units[u].cold_begin] = 0u;
 }
 
-// One workgroup per unit, one wave per cold group: entry = (gather index - base) << 14 | slot, value.  Hub rows (their
-// list is per block) spread over 16 private slots picked by the entry's position in its group.
-template <typename K, int LAYOUT>
-__global__ __launch_bounds__(kThreads) void fmt_emit_kernel(const K *__restrict__ keys, const uint2 *__restrict__ payload,
-                                                            const UnitDesc *__restrict__ units, const UnitGroups *__restrict__ ug,
-                                                            const uint32_t *__restrict__ gstart, const uint32_t *__restrict__ gcount,
-                                                            const uint32_t *__restrict__ hub_rows, uint32_t cb, void *__restrict__ entries,
-                                                            uint32_t *__restrict__ bases) {
+// One workgroup per unit, a thread per cold entry: the entry and the dummies in front of it go to their positions in the unit's
+// stream (ahead[i] = inclusive scan of the dummy counts), position q = lane q % 64 of group goff + q / 64; then the padding up
+// to whole elements.  Hub rows (their list is per block) spread over 16 private slots picked by the entry's lane.
+template <typename K, bool PATTERN>
+__global__ __launch_bounds__(kThreads) void fmt_emit_cold_kernel(const K *__restrict__ keys, const uint2 *__restrict__ payload,
+                                                                 const uint32_t *__restrict__ ahead, const UnitDesc *__restrict__ units,
+                                                                 const uint32_t *__restrict__ hub_rows, uint32_t cb,
+                                                                 unsigned char *__restrict__ cold, uint32_t *__restrict__ bases,
+                                                                 uint4 *__restrict__ plan_units) {
     __shared__ uint8_t hub_of[kMaxBlockRows + 1];
+    constexpr uint32_t G = PATTERN ? kColdGroupsPattern : kColdGroupsGeneral;
+    constexpr uint32_t EB = PATTERN ? kColdElemBytesPattern : kColdElemBytesGeneral;
     const UnitDesc u = units[blockIdx.x];
-    const UnitGroups n = ug[blockIdx.x];
     const uint32_t nrows = u.nrows_direct & 0xffffu;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const K cmask = ((K)1 << cb) - 1;
     if (u.nhub) {
         for (uint32_t i = threadIdx.x; i < nrows; i += kThreads) hub_of[i] = 0xffu;
@@ -258,24 +218,52 @@ __global__ __launch_bounds__(kThreads) void fmt_emit_kernel(const K *__restrict_
         if (threadIdx.x < u.nhub) hub_of[hub_rows[u.hub_off + threadIdx.x]] = (uint8_t)threadIdx.x;
         __syncthreads();
     }
-    for (uint32_t k = wave; k < n.ncold; k += kWaves) {
-        const uint32_t g = u.goff + k;
-        const uint32_t st = gstart[g], cnt = gcount[g];
-        const uint32_t base = cnt ? (uint32_t)(keys[st] & cmask) : 0u;
-        uint32_t ex = nrows + kHubSlots * u.nhub + lane, ey = 0u;   // padding: the lane's dummy slot of the block
-        if (lane < cnt) {
-            const uint32_t idx = (uint32_t)(keys[st + lane] & cmask);
-            const uint2 pl = payload[st + lane];
-            uint32_t slot = pl.x;
-            if (u.nhub) {
-                const uint32_t hb = hub_of[pl.x];
-                if (hb != 0xffu) slot = nrows + kHubSlots * hb + (lane & (kHubSlots - 1u));
-            }
-            ex = ((idx - base) << kRowBits) | slot;
-            ey = pl.y;
+    const uint32_t pad0 = nrows + kHubSlots * u.nhub;   // the block's dummy slots: pad0 + lane
+    auto put = [&](uint32_t q, uint32_t idx, uint32_t delta, uint32_t slot, uint32_t val) {
+        const uint32_t g = u.goff + q / 64u, lane = q % 64u, k = g % G;
+        unsigned char *el = cold + (size_t)(g / G) * EB;
+        if (!lane) {
+            bases[g] = idx;       // (a group's first entry: its index is the group's base)
+            delta = 0u;
         }
-        fmt_store<LAYOUT>(entries, g, lane, ex, ey);
-        if (lane == 0) bases[g] = base;
+        if (PATTERN) {
+            reinterpret_cast<uint16_t *>(el)[lane * 8u + k] = (uint16_t)slot;
+            el[1024u + lane * 8u + k] = (unsigned char)delta;
+        } else {
+            reinterpret_cast<uint16_t *>(el)[lane * 4u + k] = (uint16_t)slot;
+            el[512u + lane * 4u + k] = (unsigned char)delta;
+            reinterpret_cast<uint32_t *>(el + 768u)[lane * 4u + k] = val;
+        }
+    };
+    const uint32_t m = u.cold_end - u.cold_begin;
+    const uint32_t a0 = m ? ahead[u.cold_begin] : 0u;
+    for (uint32_t j = threadIdx.x; j < m; j += kThreads) {
+        const uint32_t i = u.cold_begin + j;
+        const uint32_t idx = (uint32_t)(keys[i] & cmask);
+        const uint32_t before = ahead[i] - a0;                             // dummies of the unit up to and including this entry's
+        const uint32_t mine = j ? ahead[i] - ahead[i - 1u] : 0u;           // ... of which in front of this entry
+        const uint32_t prev = j ? (uint32_t)(keys[i - 1u] & cmask) : idx;
+        const uint32_t q = j + before;
+        for (uint32_t t = 1; t <= mine; t++) {
+            const uint32_t qd = q - mine + (t - 1u);
+            put(qd, prev + kColdMaxDelta * t, kColdMaxDelta, pad0 + qd % 64u, 0u);
+        }
+        const uint2 pl = payload[i];
+        uint32_t slot = pl.x;
+        if (u.nhub) {
+            const uint32_t hb = hub_of[pl.x];
+            if (hb != 0xffu) slot = nrows + kHubSlots * hb + ((q % 64u) & (kHubSlots - 1u));
+        }
+        put(q, idx, idx - (prev + kColdMaxDelta * mine), slot, pl.y);
+    }
+    const uint32_t total = m ? m + (ahead[u.cold_end - 1u] - a0) : 0u;
+    const uint32_t qend = (total + 64u * G - 1u) / (64u * G) * (64u * G);
+    const uint32_t last = m ? (uint32_t)(keys[u.cold_end - 1u] & cmask) : 0u;
+    for (uint32_t q = total + threadIdx.x; q < qend; q += kThreads)      // padding: delta 0 behind the last entry, base 0 in all-padding groups
+        put(q, (q / 64u == (total - 1u) / 64u && total) ? last : 0u, 0u, pad0 + q % 64u, 0u);
+    if (threadIdx.x == 0) {
+        plan_units[3u * blockIdx.x] = make_uint4(u.goff, qend / 64u, u.r0, u.nrows_direct);
+        plan_units[3u * blockIdx.x + 1u] = make_uint4(u.hub_off, u.nhub, u.nhot_groups, u.seg);
     }
 }
 
@@ -443,7 +431,7 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     uint64_t hn = 0;
     std::vector<uint64_t> mcs(nblocks), mhs(nblocks);
     for (uint32_t b = 0; b < nblocks; b++) mcs[b] = off[2 * b + 1] - off[2 * b], mhs[b] = off[2 * b + 2] - off[2 * b + 1];
-    const UnitLayout ul = layout_units(bp, mcs, mhs, e.jump_slack, hot_groups, e.nhot_table);
+    const UnitLayout ul = layout_units(bp, mcs, mhs, e.dummy_max, hot_groups, e.nhot_table);
     const uint64_t total_groups = ul.cold_goff[nunits], hot_elems = ul.hot_e0[nunits];
     if (total_groups >= 0xffffffffull || hot_elems >= 0xffffffffull || ul.present_off[nunits] >= 0xffffffffull)
         return set_error(GL_ERR_UNSUPPORTED, "plan creation: more than 2^32 - 1 groups in a shard");
@@ -486,9 +474,11 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     *hot_nnz = hn;
 
     // ---- outputs, sized and padded exactly like the host formatter's vectors
-    const size_t entry_bytes = e.pattern ? (size_t)total_groups * 64u * 4u : (size_t)total_groups * 64u * 8u;
-    const size_t tail_bytes = 128u * 8u;                 // 128 x (kRowPad, kRowPad): the kernels' clamped loads land here
-    const size_t n_bases = (size_t)total_groups + 4u;
+    const uint32_t cold_groups = e.pattern ? kColdGroupsPattern : kColdGroupsGeneral;
+    const size_t cold_elem_bytes = e.pattern ? kColdElemBytesPattern : kColdElemBytesGeneral;
+    const size_t entry_bytes = (size_t)(total_groups / cold_groups) * cold_elem_bytes;
+    const size_t tail_bytes = cold_elem_bytes;           // one element of slack: the kernels' clamped loads land here
+    const size_t n_bases = (size_t)total_groups + 8u;
     GL_HIP(hipMalloc((void **)&p->d_entries, entry_bytes + tail_bytes));
     GL_HIP(hipMalloc((void **)&p->d_bases, n_bases * 4u));
     GL_HIP(hipMalloc((void **)&p->d_units, (size_t)nunits * 3u * sizeof(uint4) + 16u));
@@ -517,28 +507,35 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     fmt_fill_hot_kernel<<<1, 256, 0, s>>>(reinterpret_cast<uint32_t *>(p->d_hot + (size_t)hot_elems * hot_elem_bytes), 1u, hot_elem_bytes / 4u,
                                           hot_groups * 64u * 2u / 4u);
     GL_LAUNCH_CHECK();
-    GL_HIP(hipMemsetAsync(p->d_entries, 0, entry_bytes, s));
+    GL_HIP(hipMemsetAsync(p->d_entries, 0, entry_bytes + tail_bytes, s));
     GL_HIP(hipMemsetAsync(p->d_bases, 0, n_bases * 4u, s));
-    fmt_fill_u32_kernel<<<1, 256, 0, s>>>(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(p->d_entries) + entry_bytes), kRowPad, tail_bytes / 4u);
-    GL_LAUNCH_CHECK();
     GL_HIP(hipMemcpyAsync(p->d_hub_rows, hub_rows.data(), hub_rows.size() * 4u, hipMemcpyHostToDevice, s));
 
-    DevMem d_units, d_ug, d_gstart, d_gcount;
-    if ((rc = d_units.alloc((size_t)nunits * sizeof(UnitDesc))) != GL_OK || (rc = d_ug.alloc((size_t)nunits * sizeof(UnitGroups))) != GL_OK ||
-        (rc = d_gstart.alloc((size_t)total_groups * 4u)) != GL_OK || (rc = d_gcount.alloc((size_t)total_groups * 4u)) != GL_OK)
-        return rc;
+    DevMem d_units;
+    if ((rc = d_units.alloc((size_t)nunits * sizeof(UnitDesc))) != GL_OK) return rc;
     GL_HIP(hipMemcpyAsync(d_units.p, units.data(), (size_t)nunits * sizeof(UnitDesc), hipMemcpyHostToDevice, s));
-    fmt_group_kernel<K><<<nunits, 64, 0, s>>>(keys, d_units.as<UnitDesc>(), cb, e.group_mult, d_gstart.as<uint32_t>(), d_gcount.as<uint32_t>(),
-                                              d_ug.as<UnitGroups>(), p->d_units);
-    GL_LAUNCH_CHECK();
-#define GL_FMT_EMIT(L)                                                                                                           \
-    fmt_emit_kernel<K, L><<<nunits, kThreads, 0, s>>>(keys, payload, d_units.as<UnitDesc>(), d_ug.as<UnitGroups>(),             \
-                                                      d_gstart.as<uint32_t>(), d_gcount.as<uint32_t>(), p->d_hub_rows, cb,      \
-                                                      (void *)p->d_entries, p->d_bases)
-    if (e.pattern) GL_FMT_EMIT(3);
-    else GL_FMT_EMIT(1);
-#undef GL_FMT_EMIT
-    GL_LAUNCH_CHECK();
+    // ---- the cold stream: dummies per gap, one scan, a thread per entry
+    {
+        DevMem d_gap, d_ahead, d_tmp;
+        if ((rc = d_gap.alloc(std::max<uint64_t>(nnz, 1u) * 4u)) != GL_OK || (rc = d_ahead.alloc(std::max<uint64_t>(nnz, 1u) * 4u)) != GL_OK) return rc;
+        fmt_gap_kernel<K><<<std::min<unsigned>(cdiv(std::max<uint64_t>(nnz, 1u), kFmtThreads), (unsigned)ctx().num_cus * 32u), kFmtThreads, 0, s>>>(
+            keys, nnz, cb, bb, d_gap.as<uint32_t>());
+        GL_LAUNCH_CHECK();
+        fmt_gap_unit_starts_kernel<<<cdiv(nunits, kFmtThreads), kFmtThreads, 0, s>>>(d_units.as<UnitDesc>(), nunits, d_gap.as<uint32_t>());
+        GL_LAUNCH_CHECK();
+        size_t tmp_bytes = 0;
+        GL_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, d_gap.as<uint32_t>(), d_ahead.as<uint32_t>(), (size_t)nnz, rocprim::plus<uint32_t>(), s));
+        if ((rc = d_tmp.alloc(tmp_bytes)) != GL_OK) return rc;
+        GL_HIP(rocprim::inclusive_scan(d_tmp.p, tmp_bytes, d_gap.as<uint32_t>(), d_ahead.as<uint32_t>(), (size_t)nnz, rocprim::plus<uint32_t>(), s));
+        if (e.pattern)
+            fmt_emit_cold_kernel<K, true><<<nunits, kThreads, 0, s>>>(keys, payload, d_ahead.as<uint32_t>(), d_units.as<UnitDesc>(), p->d_hub_rows, cb,
+                                                                      reinterpret_cast<unsigned char *>(p->d_entries), p->d_bases, p->d_units);
+        else
+            fmt_emit_cold_kernel<K, false><<<nunits, kThreads, 0, s>>>(keys, payload, d_ahead.as<uint32_t>(), d_units.as<UnitDesc>(), p->d_hub_rows, cb,
+                                                                       reinterpret_cast<unsigned char *>(p->d_entries), p->d_bases, p->d_units);
+        GL_LAUNCH_CHECK();
+        GL_HIP(hipStreamSynchronize(s));   // scratch dies here
+    }
     // ---- the hot stream: number the runs (one scan over the sorted entries), then a wave per hot group
     {
         DevMem d_flags, d_runs, d_tmp;

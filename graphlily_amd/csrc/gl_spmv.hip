@@ -21,10 +21,11 @@
 // in URAM" partitioning (kernel_spmv_impl.h:470-495), with the roles swapped:
 //   row block   <= 15295 consecutive rows whose accumulators live in LDS for the whole sweep
 //               (f64 for (+,x), so ds_add_f64; 32-bit ordered-int min for (min,+); plain store for (||,&&));
-//   entries     of a row block are stored COLUMN-SORTED, 8 bytes each:
-//               { (col - group_base) << 14 | row_in_block , val },  64 entries = one 512-byte group with
-//               one base column, so a wavefront step is one coalesced 512-byte read and its 64 gathers
-//               of x fall into a handful of adjacent cache lines;
+//   entries     of a row block are stored COLUMN-SORTED and DELTA-CODED (gl_spmv_plan.h): a 16-bit row slot, an
+//               8-bit delta to the previous entry's gather index and the value -- 7 bytes (3 in the pattern
+//               layout); 64 entries = one group with one base index, a lane's index = base + the prefix sum of
+//               the deltas over the lanes (DPP), so a wavefront step is a coalesced read and its 64 gathers of
+//               x fall into a handful of adjacent cache lines;
 //   segments    a row block's stream is cut into S equal pieces ("units", one workgroup each) so that
 //               about 256*k equally sized units exist (256 CUs); units are numbered segment-major so
 //               concurrently running workgroups sweep the same column window of x (L2 resident).
@@ -50,8 +51,8 @@
 namespace gl {
 
 struct SpmvArgs {
-    const uint2 *entries;     // cold groups of 64
-    const uint32_t *bases;    // one base column per cold group
+    const unsigned char *entries;   // delta-coded cold elements
+    const uint32_t *bases;    // one base gather index per cold group
     const uint4 *units;       // 3 per unit: {first cold group, #cold groups, first row, #rows | direct << 31},
                               // {hub offset, #hub rows, #hot groups, segment}, {first hot element, present offset, #present, -}
     const uint32_t *hub_rows; // row_in_block of every hub row, per block
@@ -121,30 +122,72 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
 
 
 // ---------------------------------------------------------------- stream layouts
-// One kernel body serves both layouts; a layout says what one lane reads per load instruction and how many consecutive
-// 64-entry groups that read covers (stored lane-interleaved: lane L's element holds entry L of each of the groups).
-//   COLD stream, index = (gather index - group_base) << 14 | slot:
-//     WIDE   16 B: { A.index, A.value, B.index, B.value }  2 groups  (general layout)
-//     QUAD   16 B: { A.index .. D.index }                  4 groups  (pattern layout)
-//   HOT stream, run-coded (gl_spmv_plan.h): 16-bit slots, the column from the element's header
-//     WIDE   8 B of slots + 16 B of values per lane        4 groups
-//     QUAD   16 B of slots per lane                        8 groups
+// One kernel body serves both layouts; a layout says what one lane reads per ELEMENT (the groups a wavefront step loads,
+// stored lane-interleaved: lane L holds entry L of each of the element's groups).  gl_spmv_plan.h describes both codings.
+//   COLD stream, delta-coded: 16-bit slots, 8-bit deltas, the index from the group's base + a prefix sum over the lanes
+//     WIDE   8 B of slots + 4 B of deltas + 16 B of values per lane   4 groups  (general layout, 7 B per entry)
+//     QUAD   16 B of slots + 8 B of deltas per lane                   8 groups  (pattern layout, 3 B per entry)
+//   HOT stream, run-coded: 16-bit slots, the table slot from the element's header
+//     WIDE   8 B of slots + 16 B of values per lane                   4 groups  (6.19 B per entry)
+//     QUAD   16 B of slots per lane                                   8 groups  (2.19 B per entry)
 // Pattern plans (every column's stored values are equal) fold the value into z[c] = colval[c] (x) x[c] once per run and
-// gather z instead of x.  (Round 5 retired the 8-byte-per-lane NARROW / PAIR streams of rounds 1-2: A/B leftovers.)
+// gather z instead of x.  (Round 5 retired the 8-byte-per-lane NARROW / PAIR streams of rounds 1-2, and the 32-bit
+// { delta << 14 | slot } cold keys of rounds 1-4.)
 //   WIDE_KEEP / QUAD_KEEP: the same streams read without the non-temporal hint (plans that fit the Infinity Cache)
 enum { kLayWide = 1, kLayQuad = 3, kLayWideKeep = 4, kLayQuadKeep = 5 };
+
+__device__ __forceinline__ uint32_t load_stream_nt4(const uint32_t *p) {
+#ifdef GL_STREAM_PLAIN
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+
+// inclusive prefix sum over the 64 lanes of BOTH 16-bit halves of v at once (the halves must not carry: 63 x 255 < 2^16):
+// four row_shr steps scan the 16-lane rows, row_bcast:15 / :31 carry the row totals on -- six DPP adds, no LDS
+__device__ __forceinline__ uint32_t wave_scan_pairs(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
 
 template <int L>
 struct Lay;
 
 template <>
 struct Lay<kLayWide> {
-    using E = uint4;
-    static constexpr int G = 2;
+    static constexpr int G = (int)kColdGroupsGeneral;
     static constexpr bool kValues = true;
-    __device__ static E load(const void *s, size_t i) { return load_stream_nt16(static_cast<const uint4 *>(s) + i); }
-    __device__ static uint32_t key(const E &e, int k) { return k ? e.z : e.x; }
-    __device__ static float val(const E &e, int k) { return __uint_as_float(k ? e.w : e.y); }
+    struct E {
+        uint2 slots;
+        uint32_t deltas;
+        uint4 vals;
+    };
+    template <bool KEEP>
+    __device__ static E load_cold(const unsigned char *cold, size_t e, uint32_t lane) {
+        const unsigned char *p = cold + e * kColdElemBytesGeneral;
+        E c;
+        c.slots = KEEP ? load_stream_keep(reinterpret_cast<const uint2 *>(p) + lane) : load_stream_nt(reinterpret_cast<const uint2 *>(p) + lane);
+        c.deltas = KEEP ? reinterpret_cast<const uint32_t *>(p + 512)[lane] : load_stream_nt4(reinterpret_cast<const uint32_t *>(p + 512) + lane);
+        c.vals = KEEP ? load_stream_keep16(reinterpret_cast<const uint4 *>(p + 768) + lane) : load_stream_nt16(reinterpret_cast<const uint4 *>(p + 768) + lane);
+        return c;
+    }
+    __device__ static E load(const unsigned char *cold, size_t e, uint32_t lane) { return load_cold<false>(cold, e, lane); }
+    // offs[k] = gather index of this lane's entry of group k, relative to the group's base
+    __device__ static void offsets(const E &c, uint32_t (&offs)[G]) {
+        const uint32_t a = wave_scan_pairs(c.deltas & 0x00ff00ffu), b = wave_scan_pairs((c.deltas >> 8) & 0x00ff00ffu);
+        offs[0] = a & 0xffffu, offs[2] = a >> 16, offs[1] = b & 0xffffu, offs[3] = b >> 16;
+    }
+    __device__ static uint32_t slot(const E &c, int k) {
+        const uint32_t w = k < 2 ? c.slots.x : c.slots.y;
+        return (k & 1) ? w >> 16 : w & 0xffffu;
+    }
+    __device__ static float val(const E &c, int k) { return __uint_as_float(k == 0 ? c.vals.x : k == 1 ? c.vals.y : k == 2 ? c.vals.z : c.vals.w); }
     struct H {
         uint2 rows;
         uint4 vals;
@@ -166,11 +209,31 @@ struct Lay<kLayWide> {
 
 template <>
 struct Lay<kLayQuad> {
-    using E = uint4;
-    static constexpr int G = 4;
+    static constexpr int G = (int)kColdGroupsPattern;
     static constexpr bool kValues = false;
-    __device__ static E load(const void *s, size_t i) { return load_stream_nt16(static_cast<const uint4 *>(s) + i); }
-    __device__ static uint32_t key(const E &e, int k) { return k == 0 ? e.x : k == 1 ? e.y : k == 2 ? e.z : e.w; }
+    struct E {
+        uint4 slots;
+        uint2 deltas;
+    };
+    template <bool KEEP>
+    __device__ static E load_cold(const unsigned char *cold, size_t e, uint32_t lane) {
+        const unsigned char *p = cold + e * kColdElemBytesPattern;
+        E c;
+        c.slots = KEEP ? load_stream_keep16(reinterpret_cast<const uint4 *>(p) + lane) : load_stream_nt16(reinterpret_cast<const uint4 *>(p) + lane);
+        c.deltas = KEEP ? load_stream_keep(reinterpret_cast<const uint2 *>(p + 1024) + lane) : load_stream_nt(reinterpret_cast<const uint2 *>(p + 1024) + lane);
+        return c;
+    }
+    __device__ static E load(const unsigned char *cold, size_t e, uint32_t lane) { return load_cold<false>(cold, e, lane); }
+    __device__ static void offsets(const E &c, uint32_t (&offs)[G]) {
+        const uint32_t a = wave_scan_pairs(c.deltas.x & 0x00ff00ffu), b = wave_scan_pairs((c.deltas.x >> 8) & 0x00ff00ffu);
+        const uint32_t d = wave_scan_pairs(c.deltas.y & 0x00ff00ffu), f = wave_scan_pairs((c.deltas.y >> 8) & 0x00ff00ffu);
+        offs[0] = a & 0xffffu, offs[2] = a >> 16, offs[1] = b & 0xffffu, offs[3] = b >> 16;
+        offs[4] = d & 0xffffu, offs[6] = d >> 16, offs[5] = f & 0xffffu, offs[7] = f >> 16;
+    }
+    __device__ static uint32_t slot(const E &c, int k) {
+        const uint32_t w = (k >> 1) == 0 ? c.slots.x : (k >> 1) == 1 ? c.slots.y : (k >> 1) == 2 ? c.slots.z : c.slots.w;
+        return (k & 1) ? w >> 16 : w & 0xffffu;
+    }
     __device__ static float val(const E &, int) { return 0.0f; }
     struct H {
         uint4 rows;
@@ -190,7 +253,7 @@ struct Lay<kLayQuad> {
 
 template <>
 struct Lay<kLayWideKeep> : Lay<kLayWide> {
-    __device__ static E load(const void *s, size_t i) { return load_stream_keep16(static_cast<const uint4 *>(s) + i); }
+    __device__ static E load(const unsigned char *cold, size_t e, uint32_t lane) { return load_cold<true>(cold, e, lane); }
     __device__ static H load_hot(const unsigned char *hot, size_t e, uint32_t lane) {
         const unsigned char *p = hot + e * kHotElemBytesGeneral;
         H h;
@@ -201,7 +264,7 @@ struct Lay<kLayWideKeep> : Lay<kLayWide> {
 };
 template <>
 struct Lay<kLayQuadKeep> : Lay<kLayQuad> {
-    __device__ static E load(const void *s, size_t i) { return load_stream_keep16(static_cast<const uint4 *>(s) + i); }
+    __device__ static E load(const unsigned char *cold, size_t e, uint32_t lane) { return load_cold<true>(cold, e, lane); }
     __device__ static H load_hot(const unsigned char *hot, size_t e, uint32_t lane) {
         H h;
         h.rows = load_stream_keep16(reinterpret_cast<const uint4 *>(hot + e * kHotElemBytesPattern) + lane);
@@ -232,7 +295,7 @@ __device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Til
 #pragma unroll
     for (int u = 0; u < UC; u++) {
         const uint32_t ei = min(ic + u * kWaves, sg.nc_last);
-        ec[u] = LY::load(a.entries, (size_t)(sg.c0 + ei) * 64u + lane);
+        ec[u] = LY::load(a.entries, (size_t)sg.c0 + ei, lane);
 #pragma unroll
         for (int k = 0; k < G; k++) bc[u][k] = load_const(a.bases + sg.g0 + G * ei + k);
     }
@@ -251,14 +314,17 @@ __device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Til
     if (a.tickets && lane == 0) ticket = __hip_atomic_fetch_add(next_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     float xc[UC > 0 ? UC : 1][G];
 #pragma unroll
-    for (int u = 0; u < UC; u++)
+    for (int u = 0; u < UC; u++) {
+        uint32_t offs[G];
+        LY::offsets(ec[u], offs);            // the lanes' gather indices relative to their groups' bases: prefix sums of the deltas
 #pragma unroll
-        for (int k = 0; k < G; k++) xc[u][k] = xsrc[bc[u][k] + (LY::key(ec[u], k) >> kRowBits)];
+        for (int k = 0; k < G; k++) xc[u][k] = xsrc[bc[u][k] + offs[k]];
+    }
     // Padding entries name one of the block's DUMMY slots (behind its last accumulator, one per lane: the formatters write
-    // them), so an element's accumulates are straight-line code -- no per-entry compare and branch, and the table look-ups of a hot element
-    // are all in flight before the first accumulate waits for one (an LDS round trip per entry was the hot path's critical
-    // path: s_waitcnt lgkmcnt counts in order).  Only whole elements past the end of the unit's stream (clamped loads) are
-    // skipped, by a wave-uniform branch.
+    // them), so an element's accumulates are straight-line code -- no per-entry compare and branch, and the table look-ups of a
+    // hot element are all in flight before the first accumulate waits for one (an LDS round trip per entry was the hot path's
+    // critical path: s_waitcnt lgkmcnt counts in order).  Only whole elements past the end of the unit's stream (clamped loads)
+    // are skipped, by a wave-uniform branch.
 #pragma unroll
     for (int u = 0; u < UH; u++) {
         if (ih + u * kWaves < sg.nh) {
@@ -281,8 +347,8 @@ __device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Til
         if (ic + u * kWaves < sg.nc) {
 #pragma unroll
             for (int k = 0; k < G; k++) {
-                if (LY::kValues) TL::acc(tile, LY::key(ec[u], k) & kRowPad, LY::val(ec[u], k), xc[u][k]);
-                else TL::accz(tile, LY::key(ec[u], k) & kRowPad, xc[u][k]);
+                if (LY::kValues) TL::acc(tile, LY::slot(ec[u], k), LY::val(ec[u], k), xc[u][k]);
+                else TL::accz(tile, LY::slot(ec[u], k), xc[u][k]);
             }
         }
     }
@@ -332,7 +398,7 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     const float *xsrc = LY::kValues ? a.xg : a.z;
     StreamGeom sg;
     sg.g0 = g0;
-    sg.c0 = g0 / G, sg.nc = ncold / G, sg.h0 = dp.x, sg.nh = nhotg / HG;
+    sg.c0 = g0 / G, sg.nc = ncold / G, sg.h0 = dp.x, sg.nh = nhotg / HG;   // (elements)
     sg.nc_last = max(sg.nc, 1u) - 1u, sg.nh_last = max(sg.nh, 1u) - 1u;
     const uint32_t rc = (sg.nc + kWaves * UC - 1) / (kWaves * UC), rh = UH > 0 ? (sg.nh + kWaves * UH - 1) / (kWaves * UH) : 0u;
     const uint32_t n_both = min(rc, rh) * kWaves, n_all = max(rc, rh) * kWaves;
@@ -617,13 +683,13 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
     static const size_t keep_bytes = (size_t)224 << 20;
     static const size_t keep_min = (size_t)64 << 20;
     const bool keep = OP < 3 && p->device_bytes <= keep_bytes && p->device_bytes >= keep_min;
-    // p->mix: cold / hot stream elements per wavefront iteration (general: 2 / 4 groups each, pattern: 4 / 8)
+    // p->mix: cold / hot stream elements per wavefront iteration (an element: 4 groups in the general layout, 8 in the pattern one)
 #define GL_SPMV_MIXES(O, LAY)                                                                \
     switch (p->mix) {                                                                         \
         case 0: rc = launch_variant<O, MASK, LAY, 2, 0>(p, a, lds, s); break;                 \
-        case 1: rc = launch_variant<O, MASK, LAY, 4, 1>(p, a, lds, s); break;                 \
-        case 2: rc = launch_variant<O, MASK, LAY, 3, 1>(p, a, lds, s); break;                 \
-        case 4: rc = launch_variant<O, MASK, LAY, 1, 1>(p, a, lds, s); break;                 \
+        case 1: rc = launch_variant<O, MASK, LAY, 3, 1>(p, a, lds, s); break;                 \
+        case 3: rc = launch_variant<O, MASK, LAY, 1, 1>(p, a, lds, s); break;                 \
+        case 4: rc = launch_variant<O, MASK, LAY, 1, 2>(p, a, lds, s); break;                 \
         default: rc = launch_variant<O, MASK, LAY, 2, 1>(p, a, lds, s); break;                \
     }
     constexpr int OPK = OP < 3 ? OP : 0;   // (the integer value types never take the keep variants: no instantiations for them)
@@ -940,7 +1006,6 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     // ---- row blocks and segments per block (gl_spmv_plan.h)
     const gl::Shape shape = gl::choose_shape(rows, num_cols, nnz, gl::ctx().num_cus);
     const gl::BlockPlan bp = gl::plan_blocks(shape, h_indptr, row_begin, row_end, gl::kMaxPlainRows);
-    const uint32_t jump_slack = (num_cols >> gl::kColOffBits) + 5;   // early cuts + cold/hot rounding
     uint32_t tallest = 0;
     for (uint32_t b = 0; b < bp.nblocks; b++) tallest = std::max(tallest, bp.bstart[b + 1] - bp.bstart[b]);
 
@@ -1106,15 +1171,17 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         pattern = !mismatch;
         diag_mode = pattern && exceptions > 0;
     }
-    // 16-byte stream loads: lane-interleaved pairs of 8-byte groups, or quads of 4-byte (pattern) groups; the run-coded
-    // hot stream in elements of 4 (8) groups
+    // the delta-coded cold stream and the run-coded hot stream, both in elements of 4 (pattern: 8) lane-interleaved groups
     const bool wide = true;
-    const uint32_t group_mult = pattern ? 4u : 2u;   // units hold whole pairs / quads of cold groups
+    const uint32_t cold_groups = pattern ? gl::kColdGroupsPattern : gl::kColdGroupsGeneral;   // units hold whole elements
+    const uint32_t cold_elem_bytes = pattern ? gl::kColdElemBytesPattern : gl::kColdElemBytesGeneral;
+    // dummy entries bridge gaps of more than 255 columns, 255 at a time: a unit's indices span at most the gather vector
+    const uint32_t dummy_max = gather_cols / gl::kColdMaxDelta + 1u;
     const uint32_t hot_groups = pattern ? gl::kHotGroupsPattern : gl::kHotGroupsGeneral;
     const uint32_t hot_elem_bytes = pattern ? gl::kHotElemBytesPattern : gl::kHotElemBytesGeneral;
     const uint32_t hot_hdr_words = gl::kHotHdrWordsPerGroup * hot_groups;
 
-    std::vector<uint2> entries;
+    std::vector<unsigned char> entries;   // cold elements
     std::vector<uint32_t> bases;
     std::vector<uint4> units;
     std::vector<uint32_t> hub_rows;   // slot b*kMaxHubRows + h
@@ -1134,7 +1201,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             colmap[c] = (have_hot && hot_slot[c] != 0xffffffffu) ? (0x80000000u | hot_slot[c]) : (compact ? (cmap[c] & 0x7fffffffu) : c);
         gl::EmitGeneral eg;
         eg.bp = &bp;
-        eg.jump_slack = jump_slack;
+        eg.dummy_max = dummy_max;
         eg.colmap = colmap.data();
         eg.gather_cols = gather_cols;
         eg.nhot_table = nhot_table;
@@ -1143,7 +1210,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         eg.diag_has = diag_has.data();
         eg.pattern = pattern;
         eg.wide = wide;
-        eg.group_mult = group_mult;
+        eg.group_mult = cold_groups;
         eg.hub_div = (uint32_t)std::max<long>(1, gl::debug_knob("spmv_hub_div", 48));
         eg.h_indptr = h_indptr;
         eg.num_cols = num_cols;
@@ -1177,12 +1244,13 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         gl_spmv_plan_destroy(p);
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", num_cols);
     }
-    const gl::UnitLayout ul = gl::layout_units(bp, mc, mh, jump_slack, hot_groups, nhot_table);
+    const gl::UnitLayout ul = gl::layout_units(bp, mc, mh, dummy_max, hot_groups, nhot_table);
     total_groups = ul.cold_goff[nunits];
     const uint64_t hot_elems = ul.hot_e0[nunits];
     GL_ARG(total_groups < 0xffffffffull && hot_elems < 0xffffffffull && ul.present_off[nunits] < 0xffffffffull);
-    entries.resize(total_groups * 64);
-    bases.resize(total_groups);
+    // cold elements with one element of slack behind them (clamped loads); slots of the slack are never accumulated
+    entries.assign((size_t)(total_groups / cold_groups + 1) * cold_elem_bytes, 0);
+    bases.assign(total_groups, 0u);
     units.resize((size_t)nunits * 3);
     hub_rows.assign((size_t)nblocks * gl::kMaxHubRows, 0);
     // hot arrays with one element of slack behind them (the kernel's clamped loads land there; never accumulated)
@@ -1243,28 +1311,40 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             for (uint32_t s = 0; s < S; s++) {
                 const size_t u = unit_of[s][b];
                 const uint64_t goff = ul.cold_goff[u];
-                uint64_t g = goff;             // groups [goff, g) are complete or open
-                uint32_t fill = 64, base = 0;  // fill == 64: no open group
+                // ---- the unit's cold entries, delta-coded (gl_spmv_plan.h): position q of the unit's stream = lane q % 64 of
+                //      group goff + q / 64
+                uint64_t q = 0;
+                uint32_t prev = 0;
+                auto put = [&](uint32_t idx, uint32_t slot, uint32_t val) {
+                    const uint64_t g = goff + q / 64;
+                    const uint32_t lane = (uint32_t)(q % 64), k = (uint32_t)(g % cold_groups);
+                    unsigned char *el = entries.data() + (size_t)(g / cold_groups) * cold_elem_bytes;
+                    const uint32_t delta = lane ? idx - prev : 0u;     // (a group's first entry: its index is the group's base)
+                    if (!lane) bases[g] = idx;
+                    if (pattern) {
+                        reinterpret_cast<uint16_t *>(el)[lane * 8u + k] = (uint16_t)slot;
+                        el[1024u + lane * 8u + k] = (unsigned char)delta;
+                    } else {
+                        reinterpret_cast<uint16_t *>(el)[lane * 4u + k] = (uint16_t)slot;
+                        el[512u + lane * 4u + k] = (unsigned char)delta;
+                        reinterpret_cast<uint32_t *>(el + 768u)[lane * 4u + k] = val;
+                    }
+                    prev = idx;
+                    q++;
+                };
                 for (uint64_t i = mcb * s / S; i < mcb * (s + 1) / S; i++) {
                     const gl::Rec &rc = recs[i];
-                    if (fill == 64 || rc.col - base >= (1u << gl::kColOffBits)) {
-                        if (fill != 64)
-                            for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(pad_slot + fill, 0u);
-                        base = rc.col;
-                        bases[g] = base;
-                        g++;
-                        fill = 0;
-                    }
-                    entries[(g - 1) * 64 + fill] = make_uint2(((rc.col - base) << gl::kRowBits) | slot_of(rc, fill), rc.val);
-                    fill++;
+                    if (q)   // dummy entries (a dummy slot, value 0) bridge a gap of more than 255 columns, 255 at a time
+                        while (rc.col - prev > gl::kColdMaxDelta) put(prev + gl::kColdMaxDelta, pad_slot + (uint32_t)(q % 64), 0u);
+                    put(rc.col, slot_of(rc, (uint32_t)(q % 64)), rc.val);
                 }
-                if (g > goff)
-                    for (; fill < 64; fill++) entries[(g - 1) * 64 + fill] = make_uint2(pad_slot + fill, 0u);
-                while ((g - goff) % group_mult) {   // an all-padding group keeps the count a multiple of group_mult
-                    bases[g] = 0;
-                    for (uint32_t k = 0; k < 64; k++) entries[g * 64 + k] = make_uint2(pad_slot + k, 0u);
-                    g++;
+                // padding up to whole elements: dummy slots, delta 0 (all-padding groups: base 0)
+                const uint64_t qend = (q + 64u * cold_groups - 1) / (64u * cold_groups) * (64u * cold_groups);
+                while (q < qend) {
+                    if (q % 64 == 0) prev = 0;
+                    put(prev, pad_slot + (uint32_t)(q % 64), 0u);
                 }
+                const uint64_t g = goff + q / 64;
                 const uint32_t ncold = (uint32_t)(g - goff);
                 // ---- the unit's hot entries, run-coded (gl_spmv_plan.h)
                 const uint64_t h0 = hot.size() * s / S, h1 = hot.size() * (s + 1) / S, e0 = ul.hot_e0[u];
@@ -1325,12 +1405,12 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     }
     p->flags = flags;
     {
-        // cold : hot stream elements per wavefront iteration follow the share of non-zeros the hot table serves: with 2 (4)
-        // groups per cold element and 4 (8) per hot one, c + 1 elements serve a hot share of 2 / (c + 2).  Rounds past the
-        // end of the shorter stream touch only the other one, so the choice is worth a few per cent at most.
+        // cold : hot stream elements per wavefront iteration follow the share of non-zeros the hot table serves (cold and hot
+        // elements hold the same number of groups): 3 + 1, 2 + 1, 1 + 1, 1 + 2.  Rounds past the end of the shorter stream touch
+        // only the other one, so the choice is worth a few per cent at most.
         const long forced = gl::debug_knob("spmv_mix", -1);
         const double hot_frac = nnz ? (double)hot_nnz / (double)nnz : 0.0;
-        const int mix = hot_frac < 0.365 ? 1 : hot_frac < 0.45 ? 2 : hot_frac < 0.585 ? 3 : 4;   // 4 + 1, 3 + 1, 2 + 1, 1 + 1
+        const int mix = hot_frac < 0.29 ? 1 : hot_frac < 0.42 ? 2 : hot_frac < 0.60 ? 3 : 4;
         p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : mix);   // 0 would skip the hot groups
     }
     auto up = [&](void **d, const void *h, size_t bytes) -> int {
@@ -1341,39 +1421,12 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     };
     p->pattern = pattern;
     p->wide = wide;
-    if (!pattern && !on_device) {
-        // pair P = cold groups 2P, 2P+1 -> lane l holds { A[l], B[l] } (two uint2 = one 16-byte load)
-        const uint64_t npairs = total_groups / 2;
-#pragma omp parallel for schedule(static)
-        for (int64_t P = 0; P < (int64_t)npairs; P++) {
-            uint2 tmp[128];
-            memcpy(tmp, &entries[(size_t)P * 128], sizeof(tmp));
-            for (uint32_t l = 0; l < 64; l++) {
-                entries[(size_t)P * 128 + 2 * l] = tmp[l];
-                entries[(size_t)P * 128 + 2 * l + 1] = tmp[64 + l];
-            }
-        }
-    }
-    if (pattern && !on_device) {
-        // 4-byte entries, lane-interleaved: quad Q = cold groups 4Q .. 4Q+3 (-> .x .y .z .w of one 16-byte element = two
-        // consecutive uint2)
-        std::vector<uint2> packed(total_groups / 2 * 64);
-#pragma omp parallel for schedule(static)
-        for (int64_t Q = 0; Q < (int64_t)(total_groups / 4); Q++)
-            for (uint32_t l = 0; l < 64; l++) {
-                const size_t g = (size_t)Q * 4;
-                packed[(size_t)Q * 128 + 2 * l] = make_uint2(entries[g * 64 + l].x, entries[(g + 1) * 64 + l].x);
-                packed[(size_t)Q * 128 + 2 * l + 1] = make_uint2(entries[(g + 2) * 64 + l].x, entries[(g + 3) * 64 + l].x);
-            }
-        entries.swap(packed);
-    }
     // one element of slack: the kernel's loads are unconditional and clamp to a unit's last element, which for a unit
     // without groups is the element that follows it
     int rc = GL_OK;
     if (!on_device) {   // (the device formatter wrote these four arrays in place)
-        entries.insert(entries.end(), 128, make_uint2(gl::kRowPad, gl::kRowPad));
-        bases.insert(bases.end(), 4, 0u);
-        if ((rc = up((void **)&p->d_entries, entries.data(), entries.size() * sizeof(uint2))) != GL_OK ||
+        bases.insert(bases.end(), 8, 0u);
+        if ((rc = up((void **)&p->d_entries, entries.data(), entries.size())) != GL_OK ||
             (rc = up((void **)&p->d_bases, bases.data(), bases.size() * sizeof(uint32_t))) != GL_OK ||
             (rc = up((void **)&p->d_units, units.data(), units.size() * sizeof(uint4))) != GL_OK ||
             (rc = up((void **)&p->d_hub_rows, hub_rows.data(), hub_rows.size() * sizeof(uint32_t))) != GL_OK ||
@@ -1383,7 +1436,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             gl_spmv_plan_destroy(p);
             return rc;
         }
-        p->b_entries = entries.size() * sizeof(uint2);
+        p->b_entries = entries.size();
         p->b_bases = bases.size() * sizeof(uint32_t);
         p->b_units = units.size() * sizeof(uint4);
         p->b_hub_rows = hub_rows.size() * sizeof(uint32_t);
@@ -1698,7 +1751,7 @@ int spmv_run_general(gl_spmv_plan p, const float *d_x, const float *d_mask, floa
         return gl::set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_NO_MULADD "
                              "(hot-column table sized for 4-byte accumulators); (+,x) needs a plan without it");
     gl::SpmvArgs a;
-    a.entries = p->d_entries;
+    a.entries = reinterpret_cast<const unsigned char *>(p->d_entries);
     a.bases = p->d_bases;
     a.units = p->d_units;
     a.hub_rows = p->d_hub_rows;

@@ -48,6 +48,19 @@ constexpr uint32_t kBoolHubBit0 = (kBoolTileWords - kBoolHubSlots) * 32u;   // 1
 // An ELEMENT is what one wavefront step loads: HG groups, lane-interleaved -- general: 8 B of row slots + 16 B of values
 // per lane (HG = 4), pattern: 16 B of row slots per lane (HG = 8) -- with a 12-byte header per group kept apart (scalar loads):
 // 6.19 instead of 8 bytes per hot entry, 2.19 instead of 4 in the pattern layout.
+// Delta-coded cold stream (round 5).  A unit's cold entries are sorted by gather index, and in the classes the packed vector
+// lists first consecutive entries are a few columns apart: the entry keeps a 16-bit row slot (+ its value) and an 8-BIT DELTA to
+// its predecessor; entry 0 of a 64-entry group has delta 0 and the group's base (a scalar) is its index.  Lane l's index is
+// base + the inclusive prefix sum of the deltas over the lanes -- six DPP adds per PAIR of groups (two 16-bit fields per
+// register: 63 x 255 < 2^16).  A gap of more than 255 columns is bridged by DUMMY entries (a dummy slot, value 0, delta 255):
+// rare where the vector is dense, one or two per entry only among the rarest columns (a few per cent of the entries).  An
+// element = the groups one wavefront step loads, lane-interleaved -- general: 8 B of slots + 4 B of deltas + 16 B of values per
+// lane (4 groups, 7 B per entry instead of 8), pattern: 16 B of slots + 8 B of deltas (8 groups, 3 B per entry instead of 4).
+constexpr uint32_t kColdGroupsGeneral = 4, kColdGroupsPattern = 8;
+constexpr uint32_t kColdElemBytesGeneral = kColdGroupsGeneral * 64u * 7u;   // 512 B of slots, 256 B of deltas, 1024 B of values
+constexpr uint32_t kColdElemBytesPattern = kColdGroupsPattern * 64u * 3u;   // 1024 B of slots, 512 B of deltas
+constexpr uint32_t kColdMaxDelta = 255;
+
 constexpr uint32_t kHotGroupsGeneral = 4, kHotGroupsPattern = 8;
 constexpr uint32_t kHotElemBytesGeneral = kHotGroupsGeneral * 64u * 6u;   // 512 B of row slots, then 1024 B of values
 constexpr uint32_t kHotElemBytesPattern = kHotGroupsPattern * 64u * 2u;   // 1024 B of row slots
@@ -94,14 +107,15 @@ BlockPlan plan_blocks(Shape shape, const uint32_t *h_indptr, uint32_t row_begin,
                       uint32_t align = 1);
 
 // Where every unit's pieces start, from the cold / hot entry counts of the row blocks (shared by the host and the device
-// formatter, which must agree byte for byte): cold groups are budgeted (a group also ends where the gather index leaves the
-// 18-bit window, `jump_slack` bounds how often), hot elements and present lists are exact / capped by the table size.
+// formatter, which must agree byte for byte): cold groups are budgeted (`dummy_max` bounds the dummy entries a unit can need:
+// each advances the gather index by 255, and a unit's indices span at most the gather vector), hot elements and present lists
+// are exact / capped by the table size.
 struct UnitLayout {
-    std::vector<uint64_t> cold_goff;      // nunits + 1: first cold group (multiples of 4)
+    std::vector<uint64_t> cold_goff;      // nunits + 1: first cold group (multiples of 8)
     std::vector<uint64_t> hot_e0;         // nunits + 1: first hot element
     std::vector<uint64_t> present_off;    // nunits + 1: first entry of the unit's present list (16-bit entries, even offsets)
 };
-inline UnitLayout layout_units(const BlockPlan &bp, const std::vector<uint64_t> &mc, const std::vector<uint64_t> &mh, uint32_t jump_slack,
+inline UnitLayout layout_units(const BlockPlan &bp, const std::vector<uint64_t> &mc, const std::vector<uint64_t> &mh, uint32_t dummy_max,
                                uint32_t hot_groups, uint32_t nhot_table) {
     UnitLayout ul;
     ul.cold_goff.assign((size_t)bp.nunits + 1, 0);
@@ -112,7 +126,7 @@ inline UnitLayout layout_units(const BlockPlan &bp, const std::vector<uint64_t> 
         for (uint32_t s = 0; s < S; s++) {
             const size_t u = bp.unit_of[s][b];
             const uint64_t c = mc[b] * (s + 1) / S - mc[b] * s / S, h = mh[b] * (s + 1) / S - mh[b] * s / S;
-            ul.cold_goff[u + 1] = ((c + 63) / 64 + jump_slack + 9u) / 4u * 4u;
+            ul.cold_goff[u + 1] = c ? ((c + dummy_max + 63) / 64 + 7u) / 8u * 8u : 0u;
             ul.hot_e0[u + 1] = ((h + 63) / 64 + hot_groups - 1u) / hot_groups;
             ul.present_off[u + 1] = (std::min<uint64_t>(h, nhot_table) + 1u) / 2u * 2u;
         }
@@ -132,8 +146,8 @@ struct gl_spmv_plan_s {
     uint64_t nnz = 0;
     uint32_t nunits = 0, nblocks = 0, segments = 1, max_block_rows = 0;
     uint64_t ngroups = 0;
-    uint2 *d_entries = nullptr;      // cold groups
-    uint32_t *d_bases = nullptr;
+    uint2 *d_entries = nullptr;      // delta-coded cold elements (gl::kColdElemBytes*), addressed as bytes
+    uint32_t *d_bases = nullptr;     // one base gather index per cold group
     uint4 *d_units = nullptr;        // 3 per unit
     unsigned char *d_hot = nullptr;  // run-coded hot elements (gl::kHotElemBytes*)
     uint32_t *d_hot_hdr = nullptr;   // their headers
@@ -206,7 +220,7 @@ int fmt_detect_pattern(DevCsr *c, uint32_t num_cols, std::vector<uint32_t> &colb
 
 struct EmitGeneral {   // what the host planner decided (gl_spmv_plan_create_ex)
     const BlockPlan *bp;
-    uint32_t jump_slack;               // layout_units' bound on early group cuts
+    uint32_t dummy_max;                // layout_units' bound on the dummy entries of a unit
     const uint32_t *colmap;            // per column: 0x80000000 | hot slot, or the index the cold entry gathers from
     uint32_t gather_cols, nhot_table;  // ranges of those two index spaces
     bool diag_mode;                    // diagonal entries that differ from their column's value are dropped
