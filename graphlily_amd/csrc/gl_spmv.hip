@@ -687,9 +687,7 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
 #define GL_SPMV_MIXES(O, LAY)                                                                \
     switch (p->mix) {                                                                         \
         case 0: rc = launch_variant<O, MASK, LAY, 2, 0>(p, a, lds, s); break;                 \
-        case 1: rc = launch_variant<O, MASK, LAY, 3, 1>(p, a, lds, s); break;                 \
         case 3: rc = launch_variant<O, MASK, LAY, 1, 1>(p, a, lds, s); break;                 \
-        case 4: rc = launch_variant<O, MASK, LAY, 1, 2>(p, a, lds, s); break;                 \
         default: rc = launch_variant<O, MASK, LAY, 2, 1>(p, a, lds, s); break;                \
     }
     constexpr int OPK = OP < 3 ? OP : 0;   // (the integer value types never take the keep variants: no instantiations for them)
@@ -1039,7 +1037,10 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         // prologue, an LDS look-up per entry).  From 100 M non-zeros on the size hardly matters (+-1 %); below 64 M the first
         // 1-2 K columns are all that pays (ogbl-ppa stand-in 61.8 -> 64.4 % of peak, pokec 49.8 -> 49.8); and a short stream
         // whose whole x fits a corner of the L2 (googleplus stand-in: 432 KB) runs fastest with no table (57.5 -> 65.2 %).
-        if (nnz < (64ull << 20)) H = std::min<uint32_t>(H, 2048u);
+        // Round 5: run-coded hot entries cost 6.19 (2.19) bytes and no gather, delta-coded cold ones 7 (3) + a gather -- the cap of
+        // 2048 columns below 64 M non-zeros no longer pays (profiles/r05_hot_table_sweep.txt: ogbl-ppa general 0.068 -> 0.062 ms,
+        // pattern 0.049 -> 0.044 with the 6464 columns the degree floor admits; pokec and the community stand-in flat); the short
+        // stream with a tiny x still runs fastest without a table (googleplus 0.016 against 0.017-0.018 ms).
         if (nnz <= (16ull << 20) && (uint64_t)num_cols * 4u <= (1ull << 20)) H = 0;
         const long forced = gl::debug_knob("spmv_hot", 1);
         if (forced > 1) H = std::min<uint32_t>(room, (uint32_t)forced);
@@ -1405,12 +1406,17 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     }
     p->flags = flags;
     {
-        // cold : hot stream elements per wavefront iteration follow the share of non-zeros the hot table serves (cold and hot
-        // elements hold the same number of groups): 3 + 1, 2 + 1, 1 + 1, 1 + 2.  Rounds past the end of the shorter stream touch
-        // only the other one, so the choice is worth a few per cent at most.
+        // cold + hot stream elements per wavefront iteration (cold and hot elements hold the same number of groups): 2 + 1 (mix 2)
+        // or 1 + 1 (mix 3).  Rounds past the end of the shorter stream touch only the other one.  Swept on every stand-in
+        // (profiles/r05_mix_sweep_delta_cold.txt, r05_mix_sweep_small_graphs.txt; 3 + 1 and 1 + 2 lost everywhere but one tie and
+        // are gone): general layout -- orkut (34 % hot) 0.275 ms at 2 + 1, 0.297 at 1 + 1; hollywood (61 %) 0.137 / 0.134;
+        // products (36 %) 0.179 / 0.178 -- pattern layout 1 + 1 everywhere (products 0.138 -> 0.130, pokec 0.048 -> 0.045).
         const long forced = gl::debug_knob("spmv_mix", -1);
         const double hot_frac = nnz ? (double)hot_nnz / (double)nnz : 0.0;
-        const int mix = hot_frac < 0.29 ? 1 : hot_frac < 0.42 ? 2 : hot_frac < 0.60 ? 3 : 4;
+        // (profiles/r05_mix_sweep_small_graphs.txt: three cold elements per step are too many -- ogbl-ppa general 0.068 ms at 3 + 1,
+        //  0.062 at 2 + 1, 0.064 at 1 + 1; the pattern layout, whose elements hold 8 groups, is fastest at 1 + 1 even where a
+        //  quarter of the entries are hot: pokec 0.051 / 0.048 / 0.045, ogbl-ppa 0.049 / 0.046 / 0.043)
+        const int mix = (pattern || hot_frac >= 0.42) ? 3 : 2;
         p->mix = !have_hot ? 0 : (forced > 0 ? (int)forced : mix);   // 0 would skip the hot groups
     }
     auto up = [&](void **d, const void *h, size_t bytes) -> int {

@@ -143,6 +143,42 @@ def test_run_coded_hot_stream(gpu, kind, hot, monkeypatch):
             _check(got, m, sem, "WriteToZero", x, mask, "run-coded hot %s table %s shape %s %s" % (kind, hot, shape, sem))
 
 
+@pytest.mark.parametrize("kind", ["general", "pattern"])
+def test_delta_coded_cold_stream_bridges_wide_gaps(gpu, kind, monkeypatch):
+    """The cold stream is delta-coded (csrc/gl_spmv_plan.h): a 16-bit row slot + an 8-bit delta to the previous entry's gather
+    index, the index from a prefix sum over the lanes; a gap of more than 255 columns is bridged by dummy entries.  A WIDE matrix
+    (20 K rows x 300 K columns, 4 entries per row, 64 row blocks: ~1250 entries per block spread over 300 K columns, mean gap
+    240) makes most gaps need one or more dummies; the host and the device formatter must agree on every byte of it, and both
+    layouts give the oracle's results for the three semirings."""
+    from graphlily_amd import capi
+    rng = np.random.default_rng(77)
+    rows, cols, deg = 20096, 300032, 4
+    indices = np.sort(rng.integers(0, cols, size=(rows, deg)), axis=1).astype(np.uint32).reshape(-1)
+    indptr = np.arange(0, rows * deg + 1, deg, dtype=np.uint32)
+    data = rng.random(rows * deg, dtype=np.float32) if kind == "general" else np.full(rows * deg, np.float32(0.25), np.float32)
+    m = io.CSRMatrix(rows, cols, data, indices, indptr)
+    set_knob(monkeypatch, "spmv_blocks", "64")
+    x, mask = rng.random(cols, dtype=np.float32), rand01(rows, 3)
+    plans = [capi.SpMVPlan(rows, cols, indptr, indices, data, flags=f) for f in (capi.GL_PLAN_HOST_FORMAT, capi.GL_PLAN_DEVICE_FORMAT)]
+    assert plans[0].info()["layout"] == kind and plans[0].info()["groups"] == plans[1].info()["groups"]
+    for name in ("entries", "bases", "units", "hot", "hot_hdr", "present"):
+        assert np.array_equal(plans[0].export(name), plans[1].export(name)), name
+    # the stream holds visibly more slots than entries: the dummies (and the padding of 64 units)
+    assert plans[0].info()["groups"] * 64 > 1.3 * rows * deg
+    om = to_oracle(m)
+    for sem, op, zero in (("Arithmetic", 0, 0.0), ("Tropical", 2, 255.0), ("Logical", 1, 0.0)):
+        xs = x if op != 2 else np.where(x > 0.5, x, np.float32(zero)).astype(np.float32)
+        ref = O.spmv(om, xs, op, zero, mask, MASKS["WriteToZero"])
+        for p in plans:
+            dx, dm, dy = capi.DeviceBuffer.from_host(xs), capi.DeviceBuffer.from_host(mask), capi.DeviceBuffer(4 * rows)
+            p.run(dx, dm, dy, op, zero, MASKS["WriteToZero"])
+            got = dy.read(np.float32, rows)
+            if op == 0:
+                assert np.allclose(got, ref, rtol=1e-5, atol=1e-7)
+            else:
+                assert np.array_equal(got, ref), sem
+
+
 def test_run_coded_hot_stream_dense_columns(gpu, monkeypatch):
     """dense_1K: every column is as hot as every other and every run is as long as the block is tall (runs spanning many
     groups and elements); with hub rows off and on (a dense row is a hub row of its block)."""
