@@ -316,9 +316,20 @@ __device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Til
 #pragma unroll
     for (int u = 0; u < UC; u++) {
         uint32_t offs[G];
-        LY::offsets(ec[u], offs);            // the lanes' gather indices relative to their groups' bases: prefix sums of the deltas
+#ifdef GL_ABLATE_SCAN      // scratch A/B builds (scripts/build_variant.sh WORK <name> -DGL_ABLATE_...): what does each part of the step cost?
 #pragma unroll
-        for (int k = 0; k < G; k++) xc[u][k] = xsrc[bc[u][k] + offs[k]];
+        for (int k = 0; k < G; k++) offs[k] = 0u;
+#else
+        LY::offsets(ec[u], offs);            // the lanes' gather indices relative to their groups' bases: prefix sums of the deltas
+#endif
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+#ifdef GL_ABLATE_GATHER
+            xc[u][k] = __uint_as_float(bc[u][k] + offs[k]);
+#else
+            xc[u][k] = xsrc[bc[u][k] + offs[k]];
+#endif
+        }
     }
     // Padding entries name one of the block's DUMMY slots (behind its last accumulator, one per lane: the formatters write
     // them), so an element's accumulates are straight-line code -- no per-entry compare and branch, and the table look-ups of a
@@ -337,8 +348,12 @@ __device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Til
             }
 #pragma unroll
             for (int k = 0; k < HG; k++) {
+#ifdef GL_ABLATE_ACC
+                asm volatile("" ::"v"(LY::hot_slot(eh[u], k)), "v"(LY::hot_val(eh[u], k)), "v"(hv[k]));
+#else
                 if (LY::kValues) TL::acc(tile, LY::hot_slot(eh[u], k), LY::hot_val(eh[u], k), hv[k]);
                 else TL::accz(tile, LY::hot_slot(eh[u], k), hv[k]);
+#endif
             }
         }
     }
@@ -347,8 +362,12 @@ __device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Til
         if (ic + u * kWaves < sg.nc) {
 #pragma unroll
             for (int k = 0; k < G; k++) {
+#ifdef GL_ABLATE_ACC
+                asm volatile("" ::"v"(LY::slot(ec[u], k)), "v"(LY::val(ec[u], k)), "v"(xc[u][k]));
+#else
                 if (LY::kValues) TL::acc(tile, LY::slot(ec[u], k), LY::val(ec[u], k), xc[u][k]);
                 else TL::accz(tile, LY::slot(ec[u], k), xc[u][k]);
+#endif
             }
         }
     }
