@@ -272,47 +272,54 @@ struct Lay<kLayQuadKeep> : Lay<kLayQuad> {
     }
 };
 
-// One slot's work: UC cold and UH hot stream elements (either may be 0).  Every load is unconditional -- indices clamp
-// to the stream's last element and the plan pads its arrays by one element -- because conditional loads make the
-// compiler serialise them with s_waitcnt vmcnt(0); out-of-range elements are dropped at the accumulate.
+// One slot's work: UC cold and UH hot stream elements (either may be 0), in three pieces so that the loop below can keep the
+// NEXT slot's stream loads in flight while this slot gathers and accumulates.  Every load is unconditional -- indices clamp to
+// the stream's last element and the plan pads its arrays by one element -- because conditional loads make the compiler
+// serialise them with s_waitcnt vmcnt(0); out-of-range elements are dropped at the accumulate.
 struct StreamGeom {
     uint32_t g0, c0, nc, nc_last, h0, nh, nh_last;
 };
 
-template <int OP, int L, int UC, int UH>
-__device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Tile<OP>::T *tile, const float *hot_x,
-                                                 const float *xsrc, const StreamGeom &sg, uint32_t lane, uint32_t ic, uint32_t ih,
-                                                 uint32_t *next_slot, uint32_t &ticket) {
-    using TL = Tile<OP>;
+template <int L, int UC, int UH>
+struct SlotRegs {
     using LY = Lay<L>;
-    using E = typename LY::E;
-    using H = typename LY::H;
+    typename LY::E ec[UC > 0 ? UC : 1];
+    uint32_t bc[UC > 0 ? UC : 1][LY::G];                                       // the cold groups' bases: scalar registers
+    typename LY::H eh[UH > 0 ? UH : 1];
+    uint32_t hm[UH > 0 ? UH : 1][2 * LY::HG], hb[UH > 0 ? UH : 1][LY::HG];     // run masks and bases: scalar registers
+    uint32_t ic, ih;                                                            // first cold / hot element of the slot
+};
+
+// 1. the slot's stream loads (vector: the elements; scalar: bases and headers)
+template <int L, int UC, int UH>
+__device__ __forceinline__ void slot_load(const SpmvArgs &a, const StreamGeom &sg, uint32_t lane, uint32_t ic, uint32_t ih, SlotRegs<L, UC, UH> &r) {
+    using LY = Lay<L>;
     constexpr int G = LY::G, HG = LY::HG;
-    E ec[UC > 0 ? UC : 1];
-    uint32_t bc[UC > 0 ? UC : 1][G];
-    H eh[UH > 0 ? UH : 1];
-    uint32_t hm[UH > 0 ? UH : 1][2 * HG], hb[UH > 0 ? UH : 1][HG];   // run masks and bases: scalar registers
+    r.ic = ic, r.ih = ih;
 #pragma unroll
     for (int u = 0; u < UC; u++) {
         const uint32_t ei = min(ic + u * kWaves, sg.nc_last);
-        ec[u] = LY::load(a.entries, (size_t)sg.c0 + ei, lane);
+        r.ec[u] = LY::load(a.entries, (size_t)sg.c0 + ei, lane);
 #pragma unroll
-        for (int k = 0; k < G; k++) bc[u][k] = load_const(a.bases + sg.g0 + G * ei + k);
+        for (int k = 0; k < G; k++) r.bc[u][k] = load_const(a.bases + sg.g0 + G * ei + k);
     }
 #pragma unroll
     for (int u = 0; u < UH; u++) {
         const size_t e = (size_t)sg.h0 + min(ih + u * kWaves, sg.nh_last);
-        eh[u] = LY::load_hot(a.hot, e, lane);
+        r.eh[u] = LY::load_hot(a.hot, e, lane);
         const uint32_t *hd = a.hot_hdr + e * (kHotHdrWordsPerGroup * HG);
 #pragma unroll
-        for (int k = 0; k < 2 * HG; k++) hm[u][k] = load_const(hd + k);
+        for (int k = 0; k < 2 * HG; k++) r.hm[u][k] = load_const(hd + k);
 #pragma unroll
-        for (int k = 0; k < HG; k++) hb[u][k] = load_const(hd + 2 * HG + k);
+        for (int k = 0; k < HG; k++) r.hb[u][k] = load_const(hd + 2 * HG + k);
     }
-    // the next slot's ticket is drawn while the loads are in flight: at the end of the step it would have to wait for
-    // the step's own accumulates (LDS operations complete in order)
-    if (a.tickets && lane == 0) ticket = __hip_atomic_fetch_add(next_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    float xc[UC > 0 ? UC : 1][G];
+}
+
+// 2. the cold entries' gathers: indices from the prefix sums of the deltas
+template <int L, int UC, int UH>
+__device__ __forceinline__ void slot_gather(const float *xsrc, const SlotRegs<L, UC, UH> &r, float (&xc)[UC > 0 ? UC : 1][Lay<L>::G]) {
+    using LY = Lay<L>;
+    constexpr int G = LY::G;
 #pragma unroll
     for (int u = 0; u < UC; u++) {
         uint32_t offs[G];
@@ -320,57 +327,124 @@ __device__ __forceinline__ void spmv_stream_step(const SpmvArgs &a, typename Til
 #pragma unroll
         for (int k = 0; k < G; k++) offs[k] = 0u;
 #else
-        LY::offsets(ec[u], offs);            // the lanes' gather indices relative to their groups' bases: prefix sums of the deltas
+        LY::offsets(r.ec[u], offs);          // the lanes' gather indices relative to their groups' bases: prefix sums of the deltas
 #endif
 #pragma unroll
         for (int k = 0; k < G; k++) {
 #ifdef GL_ABLATE_GATHER
-            xc[u][k] = __uint_as_float(bc[u][k] + offs[k]);
+            xc[u][k] = __uint_as_float(r.bc[u][k] + offs[k]);
 #else
-            xc[u][k] = xsrc[bc[u][k] + offs[k]];
+            xc[u][k] = xsrc[r.bc[u][k] + offs[k]];
 #endif
         }
     }
-    // Padding entries name one of the block's DUMMY slots (behind its last accumulator, one per lane: the formatters write
-    // them), so an element's accumulates are straight-line code -- no per-entry compare and branch, and the table look-ups of a
-    // hot element are all in flight before the first accumulate waits for one (an LDS round trip per entry was the hot path's
-    // critical path: s_waitcnt lgkmcnt counts in order).  Only whole elements past the end of the unit's stream (clamped loads)
-    // are skipped, by a wave-uniform branch.
+}
+
+// 3. the accumulates.  Padding entries name one of the block's DUMMY slots (behind its last accumulator, one per lane: the
+// formatters write them), so an element's accumulates are straight-line code -- no per-entry compare and branch, and the table
+// look-ups of a hot element are all in flight before the first accumulate waits for one (an LDS round trip per entry was the hot
+// path's critical path: s_waitcnt lgkmcnt counts in order).  Only whole elements past the end of the unit's stream (clamped
+// loads) are skipped, by a wave-uniform branch.
+template <int OP, int L, int UC, int UH>
+__device__ __forceinline__ void slot_accumulate(typename Tile<OP>::T *tile, const float *hot_x, const StreamGeom &sg,
+                                                const SlotRegs<L, UC, UH> &r, const float (&xc)[UC > 0 ? UC : 1][Lay<L>::G]) {
+    using TL = Tile<OP>;
+    using LY = Lay<L>;
+    constexpr int G = LY::G, HG = LY::HG;
 #pragma unroll
     for (int u = 0; u < UH; u++) {
-        if (ih + u * kWaves < sg.nh) {
+        if (r.ih + u * kWaves < sg.nh) {
             float hv[HG];
 #pragma unroll
             for (int k = 0; k < HG; k++) {
                 // the entry's table slot: the group's base + the runs that start in the lanes below (v_mbcnt on the scalar mask)
-                const uint32_t ts = __builtin_amdgcn_mbcnt_hi(hm[u][2 * k + 1], __builtin_amdgcn_mbcnt_lo(hm[u][2 * k], hb[u][k]));
+                const uint32_t ts = __builtin_amdgcn_mbcnt_hi(r.hm[u][2 * k + 1], __builtin_amdgcn_mbcnt_lo(r.hm[u][2 * k], r.hb[u][k]));
                 hv[k] = hot_x[ts];
             }
 #pragma unroll
             for (int k = 0; k < HG; k++) {
 #ifdef GL_ABLATE_ACC
-                asm volatile("" ::"v"(LY::hot_slot(eh[u], k)), "v"(LY::hot_val(eh[u], k)), "v"(hv[k]));
+                asm volatile("" ::"v"(LY::hot_slot(r.eh[u], k)), "v"(LY::hot_val(r.eh[u], k)), "v"(hv[k]));
 #else
-                if (LY::kValues) TL::acc(tile, LY::hot_slot(eh[u], k), LY::hot_val(eh[u], k), hv[k]);
-                else TL::accz(tile, LY::hot_slot(eh[u], k), hv[k]);
+                if (LY::kValues) TL::acc(tile, LY::hot_slot(r.eh[u], k), LY::hot_val(r.eh[u], k), hv[k]);
+                else TL::accz(tile, LY::hot_slot(r.eh[u], k), hv[k]);
 #endif
             }
         }
     }
 #pragma unroll
     for (int u = 0; u < UC; u++) {
-        if (ic + u * kWaves < sg.nc) {
+        if (r.ic + u * kWaves < sg.nc) {
 #pragma unroll
             for (int k = 0; k < G; k++) {
 #ifdef GL_ABLATE_ACC
-                asm volatile("" ::"v"(LY::slot(ec[u], k)), "v"(LY::val(ec[u], k)), "v"(xc[u][k]));
+                asm volatile("" ::"v"(LY::slot(r.ec[u], k)), "v"(LY::val(r.ec[u], k)), "v"(xc[u][k]));
 #else
-                if (LY::kValues) TL::acc(tile, LY::slot(ec[u], k), LY::val(ec[u], k), xc[u][k]);
-                else TL::accz(tile, LY::slot(ec[u], k), xc[u][k]);
+                if (LY::kValues) TL::acc(tile, LY::slot(r.ec[u], k), LY::val(r.ec[u], k), xc[u][k]);
+                else TL::accz(tile, LY::slot(r.ec[u], k), xc[u][k]);
 #endif
             }
         }
     }
+}
+
+// The slots [it, n) of one phase (cold + hot elements, cold only, hot only), SOFTWARE-PIPELINED: while slot i's gathers and
+// accumulates run, slot i + 1's stream loads are already in flight.  Round 5's ablation builds (profiles/r05_ablation.txt)
+// showed a step's parts ADDING up -- pattern layout on orkut 0.208 ms, without gathers 0.177, without accumulates 0.170, without
+// both 0.108 = the stream alone at 7.2 TB/s -- i.e. the 16 wavefronts of a CU did not overlap one another's phases: each
+// wavefront had its stream loads in flight for a fraction of its iteration only.  Order per slot: gathers of slot i, the ticket
+// and the (unconditional, clamped) loads of slot i + 1, then -- s_waitcnt vmcnt counts in order, the compiler leaves exactly the
+// younger loads outstanding -- the accumulates of slot i.  The last slot of a phase prefetches one clamped slot for nothing.
+// Same-box A/B (profiles/r05_ab_pipelined.txt): general layout orkut 0.278 -> 0.275 ms, products 0.185 -> 0.181, hollywood 0.136
+// -> 0.133, the shuffled community stand-in 0.303 -> 0.285 -- it is bound by its HBM traffic (PMC: 6.05 TB/s), little was left to
+// overlap.  The PATTERN layout loses (pokec 0.045 -> 0.049, ogbl-ppa 0.044 -> 0.046, the large graphs flat): two sets of its 24
+// header registers per hot element do not fit the scalar register file (v_writelane spills), and its step is bound by LDS
+// atomics + VALU + gathers rather than by stream latency -- so only the general layout is pipelined (PIPE).
+template <int OP, int L, int UC, int UH>
+__device__ __forceinline__ uint32_t spmv_phase(const SpmvArgs &a, typename Tile<OP>::T *tile, const float *hot_x, const float *xsrc,
+                                               const StreamGeom &sg, uint32_t lane, uint32_t it, uint32_t n, uint32_t *next_slot) {
+    if (it >= n) return it;
+    auto cold_of = [](uint32_t i) { return i / kWaves * (kWaves * UC) + i % kWaves; };
+    auto hot_of = [](uint32_t i) { return i / kWaves * (kWaves * UH) + i % kWaves; };
+    constexpr bool PIPE = Lay<L>::kValues;
+    if (!PIPE) {
+        // one slot at a time: its loads, the next slot's ticket (drawn while they are in flight: at the end of the step it would
+        // wait for the step's own accumulates -- LDS operations complete in order), gathers, accumulates
+        while (it < n) {
+            SlotRegs<L, UC, UH> r;
+            slot_load<L, UC, UH>(a, sg, lane, cold_of(it), hot_of(it), r);
+            uint32_t ticket = 0;
+            if (a.tickets && lane == 0) ticket = __hip_atomic_fetch_add(next_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            float xc[UC > 0 ? UC : 1][Lay<L>::G];
+            slot_gather<L, UC, UH>(xsrc, r, xc);
+            slot_accumulate<OP, L, UC, UH>(tile, hot_x, sg, r, xc);
+            it = a.tickets ? __builtin_amdgcn_readfirstlane(ticket) : it + kWaves;
+        }
+        return it;
+    }
+    SlotRegs<L, UC, UH> cur;
+    slot_load<L, UC, UH>(a, sg, lane, cold_of(it), hot_of(it), cur);
+    while (true) {
+        float xc[UC > 0 ? UC : 1][Lay<L>::G];
+        slot_gather<L, UC, UH>(xsrc, cur, xc);
+        __builtin_amdgcn_sched_barrier(0);
+        // the next slot: its ticket (wavefronts draw slots from an LDS counter: with a static split the hardware's oldest-first
+        // issue lets the low wavefronts finish ~10 % early) and its loads
+        uint32_t nxt = it + kWaves;
+        if (a.tickets) {
+            uint32_t ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(next_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nxt = __builtin_amdgcn_readfirstlane(ticket);
+        }
+        SlotRegs<L, UC, UH> nx;
+        slot_load<L, UC, UH>(a, sg, lane, cold_of(nxt), hot_of(nxt), nx);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_accumulate<OP, L, UC, UH>(tile, hot_x, sg, cur, xc);
+        it = nxt;
+        if (it >= n) break;
+        cur = nx;
+    }
+    return it;
 }
 
 // One workgroup per unit.  UC cold and UH hot stream ELEMENTS (Lay<L>::G / HG groups each) per wavefront iteration;
@@ -421,23 +495,10 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     sg.nc_last = max(sg.nc, 1u) - 1u, sg.nh_last = max(sg.nh, 1u) - 1u;
     const uint32_t rc = (sg.nc + kWaves * UC - 1) / (kWaves * UC), rh = UH > 0 ? (sg.nh + kWaves * UH - 1) / (kWaves * UH) : 0u;
     const uint32_t n_both = min(rc, rh) * kWaves, n_all = max(rc, rh) * kWaves;
-    uint32_t it = wave, ticket = 0;
-    while (it < n_both) {
-        spmv_stream_step<OP, L, UC, UH>(a, tile, hot_x, xsrc, sg, lane, it / kWaves * (kWaves * UC) + it % kWaves,
-                                        it / kWaves * (kWaves * UH) + it % kWaves, &next_iter, ticket);
-        it = a.tickets ? __builtin_amdgcn_readfirstlane(ticket) : it + kWaves;
-    }
-    if (rc > rh) {
-        while (it < n_all) {
-            spmv_stream_step<OP, L, UC, 0>(a, tile, hot_x, xsrc, sg, lane, it / kWaves * (kWaves * UC) + it % kWaves, 0u, &next_iter, ticket);
-            it = a.tickets ? __builtin_amdgcn_readfirstlane(ticket) : it + kWaves;
-        }
-    } else if (UH > 0) {
-        while (it < n_all) {
-            spmv_stream_step<OP, L, 0, UH>(a, tile, hot_x, xsrc, sg, lane, 0u, it / kWaves * (kWaves * UH) + it % kWaves, &next_iter, ticket);
-            it = a.tickets ? __builtin_amdgcn_readfirstlane(ticket) : it + kWaves;
-        }
-    }
+    uint32_t it = wave;
+    it = spmv_phase<OP, L, UC, UH>(a, tile, hot_x, xsrc, sg, lane, it, n_both, &next_iter);
+    if (rc > rh) it = spmv_phase<OP, L, UC, 0>(a, tile, hot_x, xsrc, sg, lane, it, n_all, &next_iter);
+    else if (UH > 0) it = spmv_phase<OP, L, 0, UH>(a, tile, hot_x, xsrc, sg, lane, it, n_all, &next_iter);
     spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
 }
 
