@@ -425,17 +425,15 @@ __device__ __forceinline__ uint32_t spmv_phase(const SpmvArgs &a, typename Tile<
     SlotRegs<L, UC, UH> cur;
     slot_load<L, UC, UH>(a, sg, lane, cold_of(it), hot_of(it), cur);
     while (true) {
+        // the next slot's ticket (wavefronts draw slots from an LDS counter: with a static split the hardware's oldest-first issue
+        // lets the low wavefronts finish ~10 % early), drawn first: it returns behind the previous slot's accumulates (LDS
+        // operations complete in order) while this slot's prefix scans and gathers are issued
+        uint32_t ticket = 0;
+        if (a.tickets && lane == 0) ticket = __hip_atomic_fetch_add(next_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         float xc[UC > 0 ? UC : 1][Lay<L>::G];
         slot_gather<L, UC, UH>(xsrc, cur, xc);
         __builtin_amdgcn_sched_barrier(0);
-        // the next slot: its ticket (wavefronts draw slots from an LDS counter: with a static split the hardware's oldest-first
-        // issue lets the low wavefronts finish ~10 % early) and its loads
-        uint32_t nxt = it + kWaves;
-        if (a.tickets) {
-            uint32_t ticket = 0;
-            if (lane == 0) ticket = __hip_atomic_fetch_add(next_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            nxt = __builtin_amdgcn_readfirstlane(ticket);
-        }
+        const uint32_t nxt = a.tickets ? __builtin_amdgcn_readfirstlane(ticket) : it + kWaves;
         SlotRegs<L, UC, UH> nx;
         slot_load<L, UC, UH>(a, sg, lane, cold_of(nxt), hot_of(nxt), nx);
         __builtin_amdgcn_sched_barrier(0);
