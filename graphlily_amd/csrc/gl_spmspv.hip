@@ -1031,6 +1031,7 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     a.row_begin = p->row_begin;
     a.num_cols = p->num_cols;
     a.max_col_len = p->max_col_len;
+    a.by_entries = p->max_col_len <= (uint32_t)gl::debug_knob("spmspv_by_entries_maxcol", gl::kBinByEntriesMaxCol) ? 1u : 0u;
     // at most one workgroup per compute unit (the kernel's rendezvous waits for every workgroup of the grid: all must be
     // resident), fewer when the caller has said how short the vector is
     uint32_t grid = (uint32_t)gl::ctx().num_cus;
@@ -1393,3 +1394,10 @@ int preload_spmspv() {
     return GL_OK;
 }
 }  // namespace gl
+
+#if defined(GL_STAMPS)
+// scratch builds only: the phase stamps of the last bin / fold launches (2 x 256 x 16 words)
+extern "C" int gl_debug_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gl::g_stamps), sizeof(gl::g_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -31,12 +31,31 @@
 
 namespace gl {
 
+// -DGL_STAMPS (scratch builds, scripts/spmspv_stamps.py): thread 0 of every workgroup leaves wall_clock64() (100 MHz) at the phase
+// boundaries of the bin (k = 0) and fold (k = 1) kernels; gl_debug_stamps copies them out
+#if defined(GL_STAMPS)
+__device__ unsigned long long g_stamps[2][256][16];
+#define GL_STAMP(k, p)                                                                              \
+    do {                                                                                            \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 256u) g_stamps[k][blockIdx.x][p] = wall_clock64();     \
+    } while (0)
+#else
+#define GL_STAMP(k, p) do { } while (0)
+#endif
+// the wavefront of a workgroup that polls the other workgroups' words (the publishing thread is in wavefront 0)
+#if !defined(GL_POLL_WAVE)
+#define GL_POLL_WAVE 0
+#endif
+
 constexpr uint32_t kBinThreads = 1024;
 constexpr uint32_t kBinItems = 8;                          // products per thread and batch
 constexpr uint32_t kBinBatch = kBinThreads * kBinItems;    // 8192 products are sorted by tile at a time
 constexpr uint32_t kBinMaxTiles = 2048;                    // LDS counters of the bin kernel
 constexpr uint32_t kBinSlice = 1024;                       // vector entries a workgroup stages at a time
-constexpr uint32_t kBinLocalWindows = 4;                     // vectors of up to 4 x 1024 entries need no rendezvous
+constexpr uint32_t kBinLocalWindows = 4;                   // vectors of up to 4 x 1024 entries need no rendezvous (16: R5.11, slower)
+constexpr uint32_t kBinByEntries = 128;                    // cut by entries: at most this many vector entries per workgroup ...
+constexpr uint32_t kBinByEntriesMaxCol = 12288;            // ... and no column longer than a batch and a half (else: equal PRODUCT ranges)
 constexpr uint32_t kBinMaxSlices = 2048;                   // slices of the vector per rendezvous (two per thread)
 constexpr uint32_t kFoldThreads = 1024;
 constexpr uint32_t kFoldMaxRows = 16384;                   // rows per tile: 128 KB of 8-byte accumulators
@@ -79,6 +98,7 @@ struct BinArgs {
     uint32_t row_begin, num_cols;
     uint32_t max_col_len;       // longest column of the shard
     const uint32_t *mode;       // non-null: skip when mode[0] != 0 (the run goes row-wise instead)
+    uint32_t by_entries;        // no column of the shard is longer than kBinByEntriesMaxCol: mid-size vectors are cut by ENTRIES
 };
 
 // ordered-integer trick: for IEEE floats, a >= 0 compares like int, a < 0 like reversed uint
@@ -204,6 +224,7 @@ __device__ __forceinline__ void bin_batch(const BinArgs &a, BinLds &L, const uin
         rank[k] = ok[k] ? atomicAdd(&L.cnt[t[k]], 1u) : 0u;
     }
     __syncthreads();
+    GL_STAMP(0, 7);      // histogram done
     // tiles 2 tid and 2 tid + 1: counts -> one reservation each in the tiles' bins (issued before the scan's barriers)
     uint32_t c0 = 0, c1 = 0, g0 = 0, g1 = 0, b0 = 0, b1 = 0, b2 = 0;
     const uint32_t t0 = 2u * tid;
@@ -224,6 +245,7 @@ __device__ __forceinline__ void bin_batch(const BinArgs &a, BinLds &L, const uin
             g1 = atomicAdd(&a.cursor[t0 + 1u], c1);
         }
     }
+    GL_STAMP(0, 8);      // reservations back
     if (!sorted) {
         if (c0) {
             L.dest[t0] = b0 + g0;
@@ -324,6 +346,7 @@ __device__ __forceinline__ uint32_t bin_window(const BinArgs &a, BinLds &L, cons
     L.pref[tid] = pw;
     L.val[tid] = xv;
     __syncthreads();
+    GL_STAMP(0, 4);      // window staged
     if (grid) {
         // equal ranges of products, at least 2048 (a batch that small is mostly fixed cost), whole groups of 64
         const uint32_t Q = (max((W + grid - 1u) / grid, 2048u) + 63u) & ~63u;
@@ -355,6 +378,7 @@ __device__ __forceinline__ uint32_t bin_window(const BinArgs &a, BinLds &L, cons
             L.tab[tid] = l2;
         }
         __syncthreads();
+        GL_STAMP(0, 5);  // owner table
         const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
         for (uint32_t k = 0; k < kBinItems; k++) {
@@ -375,7 +399,9 @@ __device__ __forceinline__ uint32_t bin_window(const BinArgs &a, BinLds &L, cons
             row[k] = rv[k].x - a.row_begin;
             ok[k] = ok[k] && spmspv_product<OP>(bitsf(rv[k].y), xs[k], z[k]);
         }
+        GL_STAMP(0, 6);  // stream in
         bin_batch<OP>(a, L, row, z, ok, a1 - w0 > direct_limit);
+        GL_STAMP(0, 9);  // batch stored
     }
     return W;
 }
@@ -396,6 +422,7 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
     __shared__ BinLds L;
     if (a.mode && a.mode[0]) return;
     const uint32_t tid = threadIdx.x, G = gridDim.x, blk = blockIdx.x;
+    GL_STAMP(0, 0);
     for (uint32_t i = tid; i < kBinMaxTiles; i += kBinThreads) L.cnt[i] = 0u;
     const uint32_t vnnz = a.vec[0].index;
     const uint32_t E = min(kBinSlice, max(1u, (vnnz + G - 1u) / G));
@@ -446,6 +473,15 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
         }
         return;
     }
+    // mid-size vectors over a matrix without long columns: equal slices of the VECTOR, one per workgroup -- no prefix over the whole
+    // vector, hence no rendezvous (8 us of a 22 us launch, EXPERIMENTS R5.11); the price is one workgroup's luck with its columns,
+    // at most kBinByEntriesMaxCol products more than its neighbours (a batch and a half: ~7 us), which is why long-columned
+    // matrices and longer vectors (where a slice's sum varies by more than that) keep the equal product ranges below
+    if (a.by_entries && vnnz <= kBinByEntries * G) {
+        const uint32_t Es = (vnnz + G - 1u) / G, e0 = blk * Es;
+        if (e0 < vnnz) (void)bin_window<OP>(a, L, a.vec + 1u + e0, min(Es, vnnz - e0), 0ull, 0ull, ~0ull, 0u);
+        return;
+    }
     const uint32_t gen0 = a.sync[kSyncGen];
     uint32_t rounds = 0;
     for (unsigned long long rbase = 0; rbase < vnnz; rbase += (unsigned long long)kBinMaxSlices * E, rounds++) {
@@ -474,12 +510,13 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
             }
             __syncthreads();
         }
+        GL_STAMP(0, 1);  // slice sums published
         // ---- 2. everybody's sums: total, overflow, my range's first slice.  ONE wavefront per workgroup polls the tagged
         // words (sixteen wavefronts polling 250 words each queued up at the handful of lines the words live in: 5 us from the
         // last publication to the release; one counter that every workgroup adds to and polls is slower still, same-box
         // 8 us against 4) and scans them in registers; the results reach the other wavefronts through LDS.
-        if (tid < 64u) {
-            const uint32_t lane = tid;
+        if ((tid >> 6) == GL_POLL_WAVE) {
+            const uint32_t lane = tid & 63u;
             unsigned long long P = 0ull, pre0 = 0ull, lo = 0ull, Q = 0ull;
             uint32_t s0 = 0xffffffffu;
             bool over = false;
@@ -540,6 +577,7 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
             }
         }
         __syncthreads();
+        GL_STAMP(0, 2);  // rendezvous over
         const unsigned long long P = L.r_P, lo = L.r_lo, hi = L.r_hi, pre0 = L.pre0;
         const uint32_t s0 = L.word;
         const bool over = L.r_over != 0u;
@@ -587,6 +625,7 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
         }
         __syncthreads();
     }
+    GL_STAMP(0, 10);
     // (the fold kernel that follows advances the generation: spmspv_bin_rounds)
 }
 
@@ -635,6 +674,7 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
     constexpr bool BITS = OPX >= 3;   // the integer value types compare bit patterns (zero may be a NaN as a float)
     const uint32_t T_ = a.tiles.count, R = a.tiles.rows;
     uint32_t t = blockIdx.x;
+    GL_STAMP(1, 0);
     if (a.tickets) {   // (every run takes exactly T_ tickets: the counter modulo T_ is the tile, in arrival order)
         if (tid == 0)
             s_word = (uint32_t)(__hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.sync + kSyncFoldTicket), 1ull, __ATOMIC_RELAXED,
@@ -656,6 +696,7 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
         for (uint32_t i = tid; i < rows; i += kFoldThreads) tile[i] = TL::ident();
         __syncthreads();
         if (tid == 0 && raw) a.cursor[t] = 0u;   // (behind the barrier: every wavefront has read it)
+        GL_STAMP(1, 1);  // cursor read, tile cleared
         // ---- the bin -> the tile's accumulators (4 records per thread in flight)
         const uint2 *bin = a.bins + bb;
         for (uint32_t i0 = 0; i0 < cnt; i0 += 4u * kFoldThreads) {
@@ -670,6 +711,7 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
                 if (e[u].x != 0xffffffffu) TL::accz(tile, e[u].x - row0, bitsf(e[u].y));
         }
         __syncthreads();
+        GL_STAMP(1, 2);  // bin accumulated
         // ---- per row: the value, the mask (compared with `zero`, hw/kernel_spmspv_impl.h:262-283), the keep flag; the value
         // goes back into the row's LDS slot as a float for the write pass
         for (uint32_t j = 0; j < rounds; j++) {
@@ -720,8 +762,9 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
     // ---- publish the tile's count; entries of the tiles in front = this tile's place in the list.  The first wavefront
     // polls the states in front (tiles handed out in arrival order have all started: nobody waits for a tile that has not).
     uint32_t before = 0;
-    if (tid < 64u) {
-        if (tid == 0) __hip_atomic_store(&a.state[t], tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    GL_STAMP(1, 3);      // count known
+    if (tid == 0) __hip_atomic_store(&a.state[t], tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == GL_POLL_WAVE) {
         for (uint32_t u = lane; u < t; u += 64u) {
             uint32_t w, spins = 0;
             while (((w = __hip_atomic_load(&a.state[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff0000u) != tag && ++spins < kSpinLimit)
@@ -734,10 +777,11 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
-        if (tid == 0) s_word = before;
+        if (lane == 0) s_word = before;
     }
     __syncthreads();
     before = s_word;
+    GL_STAMP(1, 4);      // counts in front seen
     // ---- the write pass
     const uint32_t row_g0 = a.row_begin + row0;
     if (total) {
@@ -765,6 +809,7 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
         __hip_atomic_store(&a.sync[kSyncGen], gen0 + (a.bin_vec ? spmspv_bin_rounds(a.bin_vec[0].index, a.bin_grid) : 1u), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
+    GL_STAMP(1, 5);      // list written
     if (!a.host_rec) return;
     // ---- a blocking caller: the last workgroup to finish stores {sequence, count} to page-locked host memory.  ONE atomic
     // per workgroup: the 64-bit word counts the finished workgroups in its high half and sums their entries in the low one, so

@@ -118,11 +118,11 @@ def _column_constant_csc(kind, seed=4):
 
 
 @pytest.mark.parametrize("kind", ["sssp", "pagerank", "unit"])
-@pytest.mark.parametrize("cnt", [300, 2500, 9000, 20000])
+@pytest.mark.parametrize("cnt", [300, 1025, 2500, 4097, 9000, 16384, 16385, 20000])
 def test_column_constant_matrices(gpu, kind, cnt):
     """The matrices the apps build -- unit weights, SSSP's zero diagonal (app/sssp.h:16-62), PageRank-like 0.9 / out-degree
-    columns, here with diagonal exceptions -- through every path of the bin kernel (one window / four windows / the
-    rendezvous / the whole vector), three semirings, a mask compared with `zero`.  (Round 5 tried 4-byte bin records for such
+    columns, here with diagonal exceptions -- through every path of the bin kernel (one window / 2, 4, 8, 16 entries per thread
+    without a rendezvous, up to 16 windows / the rendezvous / the whole vector), three semirings, a mask compared with `zero`.  (Round 5 tried 4-byte bin records for such
     matrices -- 12 bytes moved per product instead of 24 -- and reverted them: the operator is bound by its phases, not its
     bytes; EXPERIMENTS R5.4.  The cases stay.)"""
     c = _column_constant_csc(kind)
@@ -138,6 +138,37 @@ def test_column_constant_matrices(gpu, kind, cnt):
         got, mod = _run(gpu, c, sem, "WriteToZero", v, mask)
         ref = O.spmspv(to_oracle(c), v, op, zero, mask, MASKS["WriteToZero"])
         assert_parity(got, ref, op, "column-constant %s %s %d" % (kind, sem, cnt))
+
+
+@pytest.mark.parametrize("cnt", [4097, 9000, 20000])
+def test_cut_by_entries_and_cut_by_products_agree(gpu, cnt, monkeypatch):
+    """A mid-size vector over a matrix without long columns is cut into equal slices of ENTRIES (no rendezvous); with long
+    columns, or forced by the knob, into equal ranges of PRODUCTS behind the rendezvous.  Both against the oracle, and
+    bit-identical lists for the order-free semirings."""
+    c = _column_constant_csc("sssp")
+    assert int(np.diff(c.adj_indptr.astype(np.int64)).max()) <= 12288      # (else the default would not take the first path)
+    rng = np.random.default_rng(cnt + 1)
+    cols = np.sort(rng.choice(c.num_cols, size=cnt, replace=False)).astype(np.uint32)
+    vals = (rng.integers(1, 9, size=cnt) / 4.0).astype(np.float32)
+    v = M.make_sparse_vec(cols, vals)
+    mask = np.zeros(c.num_rows, np.float32)
+    for sem in ("Arithmetic", "Tropical", "Logical"):
+        op, zero = SEMIRINGS[sem]
+        ref = O.spmspv(to_oracle(c), v, op, zero, mask, MASKS["NoMask"])
+        lists = []
+        for knob in (None, "spmspv_by_entries_maxcol=0"):
+            if knob:
+                monkeypatch.setenv("GRAPHLILY_DEBUG", knob)
+            else:
+                monkeypatch.delenv("GRAPHLILY_DEBUG", raising=False)
+            got, mod = _run(gpu, c, sem, "NoMask", v, mask)
+            assert_parity(got, ref, op, "%s %d %s" % (sem, cnt, knob))
+            lists.append(got.copy())
+        monkeypatch.delenv("GRAPHLILY_DEBUG", raising=False)
+        if sem != "Arithmetic":                      # (dense forms of the two lists)
+            assert np.array_equal(lists[0], lists[1])
+        else:
+            assert np.array_equal(lists[0] != 0, lists[1] != 0)
 
 
 def test_saturating_min_plus(gpu):
@@ -697,7 +728,7 @@ def test_wait_returns_the_count_without_a_copy(gpu):
     mod.load_and_format_matrix(csc)
     mod.send_matrix_host_to_device()
     mod.blocking = False
-    for cnt in (5, 700, 2500, 9000):     # one workgroup / one window / three windows (no rendezvous) / the rendezvous
+    for cnt in (5, 700, 2500, 9000):     # one workgroup / one window / three, nine windows (no rendezvous)
         cols = np.sort(rng.choice(30000, size=cnt, replace=False)).astype(np.uint32)
         mod.send_vector_host_to_device(M.make_sparse_vec(cols, np.ones(cnt, np.float32)))
         for _ in range(3):
