@@ -209,7 +209,7 @@ __host__ __device__ inline uint32_t bin_direct_limit(uint32_t tiles) { return mi
 // its tile's reservation + its rank in the tile -- two barriers instead of five, no scan.
 template <int OP>
 __device__ __forceinline__ void bin_batch(const BinArgs &a, BinLds &L, const uint32_t (&row)[kBinItems], const float (&z)[kBinItems],
-                                          const bool (&ok)[kBinItems], bool sorted) {
+                                          const bool (&ok)[kBinItems], bool sorted, uint32_t stamp_base = 0u) {
     const uint32_t tid = threadIdx.x;
     if (!a.binned) {
 #pragma unroll
@@ -224,7 +224,7 @@ __device__ __forceinline__ void bin_batch(const BinArgs &a, BinLds &L, const uin
         rank[k] = ok[k] ? atomicAdd(&L.cnt[t[k]], 1u) : 0u;
     }
     __syncthreads();
-    GL_STAMP(0, 7);      // histogram done
+    GL_STAMP(0, 7u + stamp_base);      // histogram done
     // tiles 2 tid and 2 tid + 1: counts -> one reservation each in the tiles' bins (issued before the scan's barriers)
     uint32_t c0 = 0, c1 = 0, g0 = 0, g1 = 0, b0 = 0, b1 = 0, b2 = 0;
     const uint32_t t0 = 2u * tid;
@@ -245,7 +245,7 @@ __device__ __forceinline__ void bin_batch(const BinArgs &a, BinLds &L, const uin
             g1 = atomicAdd(&a.cursor[t0 + 1u], c1);
         }
     }
-    GL_STAMP(0, 8);      // reservations back
+    GL_STAMP(0, 8u + stamp_base);      // reservations back
     if (!sorted) {
         if (c0) {
             L.dest[t0] = b0 + g0;
@@ -378,7 +378,8 @@ __device__ __forceinline__ uint32_t bin_window(const BinArgs &a, BinLds &L, cons
             L.tab[tid] = l2;
         }
         __syncthreads();
-        GL_STAMP(0, 5);  // owner table
+        const uint32_t sb = w0 == a0 ? 0u : 6u;   // (stamps: the first batch in 5 .. 9, the last one in 11 .. 15)
+        GL_STAMP(0, 5u + sb);  // owner table
         const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
         for (uint32_t k = 0; k < kBinItems; k++) {
@@ -399,9 +400,9 @@ __device__ __forceinline__ uint32_t bin_window(const BinArgs &a, BinLds &L, cons
             row[k] = rv[k].x - a.row_begin;
             ok[k] = ok[k] && spmspv_product<OP>(bitsf(rv[k].y), xs[k], z[k]);
         }
-        GL_STAMP(0, 6);  // stream in
-        bin_batch<OP>(a, L, row, z, ok, a1 - w0 > direct_limit);
-        GL_STAMP(0, 9);  // batch stored
+        GL_STAMP(0, 6u + sb);  // stream in
+        bin_batch<OP>(a, L, row, z, ok, a1 - w0 > direct_limit, sb);
+        GL_STAMP(0, 9u + sb);  // batch stored
     }
     return W;
 }

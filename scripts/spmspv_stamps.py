@@ -23,7 +23,8 @@ mask = torch.zeros(n, device=dev)
 res = torch.zeros(n + 1, dtype=torch.int64, device=dev)
 bm, br = capi.DeviceBuffer.from_torch(mask), capi.DeviceBuffer.from_torch(res)
 L = ctypes.CDLL(capi.LIB_PATH)
-BIN = ["start", "sums out", "rendezvous", "-", "staged", "owner tab", "stream in", "histogram", "reserved", "stored", "end"]
+BIN = ["start", "sums out", "rendezvous", "-", "staged", "owner tab", "stream in", "histogram", "reserved", "stored", "end",
+       "L owner tab", "L stream in", "L histogram", "L reserved", "L stored"]    # (L: the range's last batch when it has several)
 FOLD = ["start", "cleared", "accumulated", "count", "fronts seen", "written"]
 for sp in args.sparsity:
     cnt = max(1, int(n * (1 - sp)))
