@@ -245,9 +245,19 @@ class DeviceBuffer {
         // number of the last access through ptr() (any of them may be a write; rptr() is the read-only access that leaves it):
         // SpMSpVModule::get_results_nnz trusts its run's completion record only while nobody has touched results_buf since
         uint64_t touched = 0;
+        // Runs once before the next access that may WRITE the buffer (ptr(), not rptr() / download()): a buffer that owes "a copy of
+        // this one, taken when somebody reads it" (module/fusion.h: results after a results -> vector swap) takes its copy now.
+        std::function<void()> before_write;
         ~Impl() { if (ptr) gl_buf_free(ptr); }
     };
     std::shared_ptr<Impl> impl_;
+    void settle_() const {
+        if (impl_->on_access) {
+            std::function<void()> f;
+            f.swap(impl_->on_access);     // cleared first: the settling code uses the buffer itself
+            f();
+        }
+    }
 
 public:
     DeviceBuffer() = default;
@@ -257,9 +267,10 @@ public:
     }
     void *ptr() const {
         if (!impl_) return nullptr;
-        if (impl_->on_access) {
+        settle_();
+        if (impl_->before_write) {
             std::function<void()> f;
-            f.swap(impl_->on_access);     // cleared first: the settling code uses the buffer itself
+            f.swap(impl_->before_write);  // (once: whoever derived something from the old contents has it now)
             f();
         }
         impl_->levels_max = -1.0f;
@@ -267,15 +278,12 @@ public:
         impl_->touched = ++clock;
         return impl_->ptr;
     }
-    // the pointer for a call that only READS the buffer (debts are settled, the touch stamp stays)
+    // the pointer for a call that only READS the buffer: its own debt is settled; the touch stamp, the levels hint and the
+    // before-write hook stay
     const void *rptr() const {
         if (!impl_) return nullptr;
-        const uint64_t t = impl_->touched;
-        const float lv = impl_->levels_max;
-        const void *p = ptr();
-        impl_->touched = t;
-        impl_->levels_max = lv;
-        return p;
+        settle_();
+        return impl_->ptr;
     }
     uint64_t touched() const { return impl_ ? impl_->touched : 0; }
     size_t size() const { return impl_ ? impl_->bytes : 0; }
@@ -286,11 +294,10 @@ public:
     }
     void download(void *host, size_t bytes) const {
         assert(bytes <= size());
-        const float levels = impl_ ? impl_->levels_max : -1.0f;     // (ptr() below forgets the hint: a download does not write)
-        void *p = ptr();
+        const float levels = impl_ ? impl_->levels_max : -1.0f;
+        const void *p = rptr();                                      // (a download does not write)
         if (levels >= 0.0f && bytes == size() && (bytes & 3u) == 0) {
             GRAPHLILY_CHECK(gl_buf_d2h_levels(static_cast<float *>(host), static_cast<const float *>(p), bytes / 4u, levels, nullptr));
-            impl_->levels_max = levels;
         } else {
             GRAPHLILY_CHECK(gl_buf_d2h(host, p, bytes));
         }
@@ -302,6 +309,8 @@ public:
     bool owed() const { return impl_ && (bool)impl_->on_access; }
     void owe(std::function<void()> f) const { if (impl_) impl_->on_access = std::move(f); }
     void settle_quietly() const { if (impl_) impl_->on_access = nullptr; }
+    void on_write(std::function<void()> f) const { if (impl_) impl_->before_write = std::move(f); }
+    void clear_on_write() const { if (impl_) impl_->before_write = nullptr; }
     // exchange the device blocks of two buffers of equal size: every handle of `this` then names what `o`'s handles named and
     // vice versa (module/fusion.h: results -> vector "copies" of the pull loops become a swap)
     void swap_storage(const DeviceBuffer &o) const {

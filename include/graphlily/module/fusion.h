@@ -59,9 +59,12 @@ struct PullFusion {
 
     void forget(const void *module) {
         flush();
-        if (copy_module == module) {                // its plan is about to change or go: what a swap left owed is written now
-            if (last_copy_res.owed()) (void)last_copy_res.ptr();
+        if (last_copy_module == module) {           // its plan is about to change or go: what ITS swap left owed is written now
+            if (last_copy_res.owed()) (void)last_copy_res.ptr();   // (the debt re-runs this module's SpMV: it cannot outlive it)
             last_copy_res = DeviceBuffer();
+            last_copy_module = nullptr;
+        }
+        if (copy_module == module) {
             rerun_spmv = nullptr;
             copy_module = nullptr;
         }
@@ -192,7 +195,8 @@ struct PullFusion {
     bool copy_zero_is_0 = false, copy_muladd = false;
     std::function<void(float, bool)> run_copy_spmv;   // (extra term, fold it into the epilogue?) -> the SpMV on the bound buffers
     std::function<void(const DeviceBuffer &, const DeviceBuffer &)> rerun_spmv;   // (x, y): the plain SpMV on explicit buffers
-    DeviceBuffer last_copy_res;                     // the results buffer the last swap left owed
+    DeviceBuffer last_copy_res;                     // the results buffer the last swap left owed ...
+    const void *last_copy_module = nullptr;         // ... and the module whose SpMV that debt would re-run
     const void *copy_module = nullptr;
 
     // SpMVModule::run on a non-blocking module, no mask, whole square matrix, general / pattern layout: do not launch yet
@@ -219,8 +223,9 @@ struct PullFusion {
         stage = 0;
         copy_kind = false;
         res.settle_quietly();
-        (void)vec.ptr();                            // (whatever the vector itself still owed)
+        (void)vec.rptr();                           // (whatever the vector itself still owed)
         if (last_copy_res.valid() && last_copy_res.id() != res.id() && last_copy_res.owed()) (void)last_copy_res.ptr();
+        vec.clear_on_write();                       // (the previous swap's hook: `results` is about to be overwritten, or was just settled)
         std::function<void(float, bool)> r;
         r.swap(run_copy_spmv);
         r(val, fold);                               // results' block = A x (+ val)
@@ -230,7 +235,11 @@ struct PullFusion {
         if (!fold) {
             rr.owe([v, rr] {                        // results = vector (what the copy would have left in both)
                 GRAPHLILY_CHECK(gl_buf_d2d(rr.raw(), v.raw(), rr.size()));
+                v.clear_on_write();
             });
+            // ... taken when somebody reads `results` -- or just before anybody gets to WRITE `vector` (an upload, another module's
+            // output bound to it): the copy must be of A x, not of what comes next.  The loop's own SpMV reads through rptr().
+            v.on_write([rr] { if (rr.owed()) (void)rr.ptr(); });
         } else {
             rr.owe([rr, again] {                    // results = A x_old, and x_old is what results' block holds
                 DeviceBuffer tmp(rr.size());
@@ -239,6 +248,7 @@ struct PullFusion {
             });
         }
         last_copy_res = rr;
+        last_copy_module = copy_module;
         vec = res = DeviceBuffer();
         return true;
     }

@@ -79,10 +79,10 @@ class SpMVModule : public BaseModule {
     }
     void make_plan_() {
         const CSRMatrix<float> &m = csr_matrix_float_;
+        detail::fusion().forget(this);      // (first: a debt that re-runs this module's SpMV needs the plan it ran on)
         gl_spmv_plan_destroy(plan_);
         plan_ = nullptr;
         plan_flags_ = flags_for_(semiring_.op);
-        detail::fusion().forget(this);
         const float *values = m.adj_data.data();
         std::vector<vector_data_t> words;   // the integer value types: the matrix as value words (same size, passed as bits)
         if (!kFloat) {
@@ -103,7 +103,7 @@ class SpMVModule : public BaseModule {
     }
     bool fusable_plan_ = false;
     void run_now_() {
-        GRAPHLILY_CHECK(gl_spmv_run_typed(plan_, vector_buf.ptr(), mask_type_ == kNoMask ? nullptr : mask_buf.ptr(), results_buf.ptr(),
+        GRAPHLILY_CHECK(gl_spmv_run_typed(plan_, vector_buf.rptr(), mask_type_ == kNoMask ? nullptr : mask_buf.rptr(), results_buf.ptr(),
                                           (int)semiring_.op, VK::bits(semiring_.zero), (int)mask_type_, VK::kind));
     }
 
@@ -248,7 +248,7 @@ public:
         }
         uint32_t zb;
         memcpy(&zb, &extra, 4);
-        GRAPHLILY_CHECK(gl_spmv_run_typed(plan_, vector_buf.ptr(), nullptr, results_buf.ptr(), (int)semiring_.op, zb, (int)kNoMask, VK::kind));
+        GRAPHLILY_CHECK(gl_spmv_run_typed(plan_, vector_buf.rptr(), nullptr, results_buf.ptr(), (int)semiring_.op, zb, (int)kNoMask, VK::kind));
     }
 
     // (a download of a buffer that a deferred / fused call still owes settles the debt first: DeviceBuffer::ptr)

@@ -344,6 +344,39 @@ int main() {
             p.eWise->run(n / 2, val);
             seen[fused].push_back(p.SpMV->send_results_device_to_host());
             seen[fused].push_back(p.SpMV->send_vector_device_to_host());
+            // the vector overwritten IN PLACE while the swap's results are still owed ("a copy of the vector, taken when somebody
+            // reads it"): the results must be what the SpMV left, not what was uploaded since
+            p.SpMV->run();
+            p.eWise->run(n, val);
+            aligned_dense_vec_t x2(n, 0.25f);
+            p.SpMV->vector_buf.upload(x2.data(), (size_t)n * sizeof(val_t));
+            seen[fused].push_back(p.SpMV->send_results_device_to_host());
+            seen[fused].push_back(p.SpMV->send_vector_device_to_host());
+            // a module destroyed while its swap's results are still owed, with ANOTHER module's SpMV deferred in between: the
+            // buffer (kept alive by this handle) must hold the results, and settling it must not need the dead module
+            {
+                Pull *a = new Pull(sssp ? TropicalSemiring : ArithmeticSemiring);
+                a->set_up_runtime("unused.xclbin");
+                a->SpMV->load_and_format_matrix(g, true);
+                a->SpMV->send_matrix_host_to_device();
+                a->SpMV->send_vector_host_to_device(x);
+                a->eWise->bind_in_buf(a->SpMV->results_buf);
+                a->eWise->bind_out_buf(a->SpMV->vector_buf);
+                a->SpMV->run();
+                a->eWise->run(n, val);
+                auto keep = a->SpMV->results_buf;
+                Pull b(sssp ? TropicalSemiring : ArithmeticSemiring);
+                b.set_up_runtime("unused.xclbin");
+                b.SpMV->load_and_format_matrix(g, true);
+                b.SpMV->send_matrix_host_to_device();
+                b.SpMV->send_vector_host_to_device(x2);
+                b.SpMV->run();                                   // (deferred when the fusion is on)
+                delete a;
+                aligned_dense_vec_t got(n);
+                keep.download(got.data(), (size_t)n * sizeof(val_t));
+                seen[fused].push_back(got);
+                seen[fused].push_back(b.SpMV->send_results_device_to_host());
+            }
         }
         unsetenv("GRAPHLILY_MODULE_FUSION");
         for (size_t k = 0; k < seen[0].size(); k++) {
