@@ -9,12 +9,13 @@
 //   * a random 4-byte gather of x costs a whole cache line (~100 G/s from a 10 MB vector), but a gather whose
 //     64 lanes read NEIGHBOURING columns costs ~20 clocks, from L1 and L2 alike -- and that cost ADDS to the
 //     stream's: only fewer bytes per entry or fewer gather instructions (x values served from LDS) make
-//     the loop faster; unrolling, software pipelining and LDS window staging were measured and do not;
+//     the loop faster; unrolling and LDS window staging were measured and do not (issuing the next slot's stream loads
+//     under the current slot's accumulates does, a little, since the accumulates became straight-line code: spmv_phase);
 //   * in the real stream a gather costs ~4 + 2.2 clocks per distinct 128-byte line it touches, and a row block's
 //     sweep touches every line of x that holds one of its columns -- so the cold entries index a PACKED copy of x
 //     (never-gathered columns dropped, rare ones clustered by degree class), refilled per run by a helper kernel;
 //   * LDS atomics on 4/8-byte integers and on f64 run at full rate, ds_add_f32 at a third of it.
-// This file holds the GENERAL layout (8-byte entries) and the PATTERN layout (4-byte entries for
+// This file holds the GENERAL layout (7-byte cold / 6.19-byte hot entries) and the PATTERN layout (3 / 2.19-byte entries for
 // column-constant matrices), both served by spmv_rbcs_kernel<OP, MASK, stream layout, UC, UH>; the
 // (||,&&)-only bit layout lives in gl_spmv_bool.hip.
 // Hence the layout -- the CDNA4 counterpart of the FPGA's "dense-vector tile in URAM + output buffer
