@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <cassert>
+#include <cmath>        // (the reference's global.h brings <cmath> and <fstream> in through ap_fixed.h / xcl2.hpp: its drivers call floor(),
+#include <fstream>      //  abs(float) and use std::ofstream without including either -- bench_spmspv.cpp:157,308, bench_spmv.cpp)
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
