@@ -51,6 +51,10 @@
 
 namespace gl {
 
+#if defined(GL_UNIT_CLOCKS)
+__device__ unsigned long long g_unit_clocks[2 * 4096];   // {start, end} of every unit of the last spmv_rbcs_kernel launch (100 MHz)
+#endif
+
 struct SpmvArgs {
     const unsigned char *entries;   // delta-coded cold elements
     const uint32_t *bases;    // one base gather index per cold group
@@ -459,6 +463,9 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);   // nhot is a multiple of 64
 
     if (a.run_flag && *a.run_flag == 0u) return;
+#if defined(GL_UNIT_CLOCKS)
+    const unsigned long long unit_t0 = wall_clock64();
+#endif
     const uint32_t unit = __builtin_amdgcn_readfirstlane(blockIdx.x);   // pinned to an SGPR: see clock_stamp
     const uint4 d = load_const(a.units + 3u * unit), dh = load_const(a.units + 3u * unit + 1u);   // scalar loads
     const uint4 dp = load_const(a.units + 3u * unit + 2u);
@@ -499,6 +506,15 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     if (rc > rh) it = spmv_phase<OP, L, UC, 0>(a, tile, hot_x, xsrc, sg, lane, it, n_all, &next_iter);
     else if (UH > 0) it = spmv_phase<OP, L, 0, UH>(a, tile, hot_x, xsrc, sg, lane, it, n_all, &next_iter);
     spmv_unit_epilogue<OP, MASK>(a, tile, d, dh);
+#if defined(GL_UNIT_CLOCKS)
+    // scratch builds (scripts/unit_clocks.py): what every unit of the last launch took, start of the workgroup to its last store
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && unit < 4096u) {
+        g_unit_clocks[2u * unit] = unit_t0;
+        g_unit_clocks[2u * unit + 1u] = wall_clock64();
+    }
+#endif
 }
 
 // z[j] = colval (x) x of gathered column j (all columns, or the packed ones), four per thread, and the hot table from
@@ -1888,3 +1904,10 @@ int preload_spmv() {
     return GL_OK;
 }
 }  // namespace gl
+
+#if defined(GL_UNIT_CLOCKS)
+// scratch builds only: {start, end} wall_clock64() stamps of the units of the last main SpMV launch (2 x 4096 words)
+extern "C" int gl_debug_unit_clocks(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gl::g_unit_clocks), sizeof(gl::g_unit_clocks)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -1,32 +1,71 @@
-"""scratch: summarise a GRAPHLILY_SPMV_CLOCKS dump (wall_clock64 ticks at 100 MHz).
-Columns: unit, 5 stamps (entry, prologue done, wave 0's loop done, all waves done, end),
-hardware id (HW_ID | XCC_ID << 32), #cold groups, #hot groups, #rows, #hub rows."""
-import sys
-import numpy as np
-a = np.loadtxt(sys.argv[1], dtype=np.int64)
-st = a[:, 1:6].astype(np.float64) / 100.0   # us
-cold, hot, rows, hubs = (a[:, k].astype(float) for k in (7, 8, 9, 10))
-hw = a[:, 6]
-xcc, cu, sh, se = (hw >> 32) & 0xf, (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 7
-t_first = st[:, 0].min()
-print("units %d  kernel span %.1f us  first entry spread %.1f us  last unit entry at %.1f us" %
-      (len(a), st[:, 4].max() - t_first, np.sort(st[:, 0])[min(255, len(a) - 1)] - t_first, st[:, 0].max() - t_first))
-names = ["prologue", "loop (wave 0)", "wait for all waves", "epilogue"]
-for k, nm in enumerate(names):
-    d = st[:, k + 1] - st[:, k]
-    print("  %-26s mean %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % (nm, d.mean(), np.median(d), np.percentile(d, 90), d.max()))
-dur = st[:, 4] - st[:, 0]
-print("  %-26s mean %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us" % ("whole unit", dur.mean(), np.median(dur), np.percentile(dur, 90), dur.max()))
-A = np.stack([cold, hot, np.ones_like(cold)], axis=1)
-coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
-print("fit unit = %.4f us * cold_groups + %.4f us * hot_groups + %.1f us ; residual rms %.2f us" %
-      (coef[0], coef[1], coef[2], float(np.sqrt(np.mean((dur - A @ coef) ** 2)))))
-print("ideal at 45 clk / 512 B stream: %.1f us per unit (mean groups %.0f)" % ((cold + hot).mean() * 45 / 2400.0, (cold + hot).mean()))
-loop = st[:, 3] - st[:, 1]   # prologue done -> all waves done
-per = loop / np.maximum(cold + hot, 1) * 2400.0   # clocks per group at 2.4 GHz
-print("loop clocks per group: mean %.1f  min %.1f  max %.1f" % (per.mean(), per.min(), per.max()))
-for nm, key in (("xcc", xcc), ("se", se), ("cu", cu)):
-    vals = sorted(set(key.tolist()))
-    print("  by %s: " % nm + "  ".join("%d: %.1f (n=%d)" % (v, per[key == v].mean(), (key == v).sum()) for v in vals))
-print("corr(clocks per group, cold share) %.2f   corr(.., rows) %.2f   corr(.., unit index) %.2f" %
-      (np.corrcoef(per, cold / np.maximum(cold + hot, 1))[0, 1], np.corrcoef(per, rows)[0, 1], np.corrcoef(per, a[:, 0])[0, 1]))
+"""Scratch: what every unit (row block) of the main SpMV launch takes, run after run -- how much of the launch's tail
+(max / mean of the units' durations) repeats, i.e. what re-cutting the row blocks from MEASURED per-unit times could take back.
+Needs a -DGL_UNIT_CLOCKS build:  bash scripts/build_variant.sh WORK clocks -DGL_UNIT_CLOCKS
+    GRAPHLILY_HIP_LIB=scripts/_variants/clocks.so python scripts/unit_clocks.py orkut [flags]      (flags 4 = general, 0 = pattern)"""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphlily_amd import capi, datasets, io  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "orkut"
+flags = int(sys.argv[2]) if len(sys.argv) > 2 else capi.GL_PLAN_KEEP_VALUES
+dev = torch.device("cuda:0")
+capi.init(0)
+m = datasets.paper_graph(name, 1.0, device=dev)
+m.adj_data = np.full(m.nnz, np.float32(1.0 / m.num_rows), np.float32)
+io.util_round_csr_matrix_dim(m, 128, 8)
+plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data, flags=flags)
+info = plan.info()
+U = info["num_units"]
+x = torch.randint(0, 2, (m.num_cols,), device=dev).float()
+y = torch.zeros(m.num_rows, device=dev)
+bx, by = capi.DeviceBuffer.from_torch(x), capi.DeviceBuffer.from_torch(y)
+L = ctypes.CDLL(capi.LIB_PATH)
+buf = np.zeros(2 * 4096, np.uint64)
+for _ in range(30):
+    plan.run(bx, None, by, 0, 0.0, 0)
+capi.sync()
+runs = []
+for _ in range(24):
+    for _ in range(3):
+        plan.run(bx, None, by, 0, 0.0, 0)
+    capi.sync()
+    assert L.gl_debug_unit_clocks(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    c = buf.astype(np.int64).reshape(-1, 2)[:U]
+    runs.append(np.stack([(c[:, 0] - c[:, 0].min()) / 100.0, (c[:, 1] - c[:, 0]) / 100.0], axis=1))
+r = np.stack(runs)                      # runs x units x {start, duration} in us
+dur = r[:, :, 1]
+span = (r[:, :, 0] + r[:, :, 1]).max(axis=1)
+print("%s %s layout, %d units: launch span %.1f us (median of %d runs), unit duration mean %.1f, per-run max / mean %.4f"
+      % (name, info["layout"], U, np.median(span), len(runs), dur.mean(), float(np.median(dur.max(axis=1) / dur.mean(axis=1)))))
+med = np.median(dur, axis=0)            # what repeats: a unit's median over the runs
+noise = dur - med[None, :]
+print("  units' MEDIAN durations: max / mean %.4f (the part of the tail that repeats), std %.2f us; run-to-run std of a unit around "
+      "its median %.2f us" % (med.max() / med.mean(), med.std(), noise.std()))
+# what a perfect re-cut of the repeatable part would leave: every unit at the mean of the medians + its run-to-run noise
+ideal = (med.mean() + noise).max(axis=1)
+print("  launch ends (units only) at %.1f us now; with the repeatable part cut away and the same noise: %.1f us (%.1f %% less)"
+      % (np.median(dur.max(axis=1)), np.median(ideal), 100.0 * (1.0 - np.median(ideal) / np.median(dur.max(axis=1)))))
+half = len(runs) // 2
+a, b = np.median(dur[:half], axis=0), np.median(dur[half:], axis=0)
+print("  correlation of the units' medians between the first and the second half of the runs: %.2f" % float(np.corrcoef(a, b)[0, 1]))
+order = np.argsort(-med)[:6]
+print("  slowest units (median us):", ", ".join("%d: %.1f" % (int(u), med[u]) for u in order), " fastest:", ", ".join("%d: %.1f" % (int(u), med[u]) for u in np.argsort(med)[:4]))
+
+# who are the slow units?  the longest rows of the matrix and the units that hold them
+try:
+    uw = plan.export("units").reshape(-1, 12)[:U]            # 3 x uint4 per unit: {g0, ncold, first row, rows | flags}, {hub off, hubs, hot groups, seg}, ...
+    first, nrows, nhub = uw[:, 2].astype(np.int64), (uw[:, 3] & 0xffff).astype(np.int64), uw[:, 5].astype(np.int64)
+    deg = np.diff(m.adj_indptr.astype(np.int64))
+    ent = np.array([int(m.adj_indptr[min(f + r, m.num_rows)]) - int(m.adj_indptr[f]) for f, r in zip(first, nrows)])
+    top = np.argsort(-deg)[:5]
+    for rr in top:
+        u = int(np.searchsorted(first, rr, side="right") - 1)
+        print("  row %d: %d entries = %.1f %% of unit %d's %d (unit median %.1f us = %+.1f %% of the mean, %d hub rows)"
+              % (rr, deg[rr], 100.0 * deg[rr] / max(ent[u], 1), u, ent[u], med[u], 100.0 * (med[u] / med.mean() - 1.0), nhub[u]))
+    for u in order[:3]:
+        rows = np.arange(first[u], min(first[u] + nrows[u], m.num_rows))
+        big = rows[np.argmax(deg[rows])]
+        print("  slow unit %d: %d rows, %d entries, longest row %d entries (%.1f %%), %d hub rows" % (u, nrows[u], ent[u], deg[big], 100.0 * deg[big] / max(ent[u], 1), nhub[u]))
+except Exception as e:     # (the export's layout is an implementation detail: this part may rot)
+    print("  (units export not understood: %r)" % (e,))
