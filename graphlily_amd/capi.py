@@ -41,7 +41,7 @@ EXPORTS = [
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_unpack_bits", "gl_bfs_bits_begin_from", "gl_spmv_run_bits", "gl_bfs_pull_step",
     "gl_prof_begin", "gl_prof_end", "gl_span_begin", "gl_span_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run", "gl_spmspv_run_assign",
-    "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_plan_hint_work", "gl_spmspv_last_direction", "gl_spmspv_wait",
+    "gl_spmspv_plan_attach_pull", "gl_spmspv_plan_hint", "gl_spmspv_plan_hint_work", "gl_spmspv_last_direction", "gl_spmspv_wait", "gl_spmspv_failed_runs",
     "gl_sparse_nnz", "gl_ewise_add", "gl_assign_dense", "gl_assign_sparse",
     "gl_assign_sparse_new_frontier", "gl_sparse_to_dense",
     "gl_csr2csc", "gl_csr_normalize_by_outdegree", "gl_npz_csr_open", "gl_npz_csr_read", "gl_npz_csr_close",
@@ -112,7 +112,7 @@ def lib():
         "gl_spmspv_plan_destroy": [vp], "gl_spmspv_plan_info": [vp, P(u64), P(u64)],
         "gl_spmspv_run": [vp, vp, vp, vp, i32, f32, i32],
         "gl_spmspv_run_assign": [vp, vp, vp, vp, i32, f32, i32, vp, f32],
-        "gl_spmspv_plan_attach_pull": [vp, vp], "gl_spmspv_plan_hint": [vp, u32], "gl_spmspv_plan_hint_work": [vp, u32, u64, u32], "gl_spmspv_last_direction": [vp, P(i32)], "gl_spmspv_wait": [vp, P(u32)],
+        "gl_spmspv_plan_attach_pull": [vp, vp], "gl_spmspv_plan_hint": [vp, u32], "gl_spmspv_plan_hint_work": [vp, u32, u64, u32], "gl_spmspv_last_direction": [vp, P(i32)], "gl_spmspv_wait": [vp, P(u32)], "gl_spmspv_failed_runs": [vp, P(u32)],
         "gl_sparse_nnz": [vp, P(u32)],
         "gl_ewise_add": [vp, vp, u32, f32], "gl_assign_dense": [vp, vp, u32, f32, i32],
         "gl_assign_sparse": [vp, vp, f32, u32], "gl_assign_sparse_new_frontier": [vp, vp, vp, u32],
@@ -456,6 +456,13 @@ class SpMSpVPlan:
         n = ctypes.c_uint32(0)
         check(lib().gl_spmspv_wait(ctypes.c_void_p(self.handle), ctypes.byref(n)))
         return None if n.value == 0xffffffff else n.value
+
+    def failed_runs(self):
+        """gl_spmspv_failed_runs: runs on this plan whose workgroup rendezvous timed out so far (sticky; what a caller of
+        recorded graphs checks after a replay)."""
+        n = ctypes.c_uint32(0)
+        check(lib().gl_spmspv_failed_runs(ctypes.c_void_p(self.handle), ctypes.byref(n)))
+        return n.value
 
     def run_typed(self, vector, mask, result, op, zero_bits, mask_type, val_type):
         check(lib().gl_spmspv_run_typed(ctypes.c_void_p(self.handle), _p(vector), _p(mask), _p(result), int(op), int(zero_bits),

@@ -670,6 +670,9 @@ static int launch_tiny_mask(int mask_type, const TinyArgs &a, const float *mask,
     }
 }
 
+// see gl_spmspv_run's test hook: what a rendezvous poll that gives up stores (gl_spmspv_bin.h kSyncErr)
+__global__ void spmspv_inject_timeout_kernel(uint32_t *sync) { sync[kSyncErr] = sync[kSyncGen]; }
+
 template <int OPX>
 static int launch_fold_op(const FoldArgs &f, hipStream_t s) {
     using T = typename Tile<OPX>::T;
@@ -1110,6 +1113,12 @@ static int spmspv_run_impl(gl_spmspv_plan p, const gl_idx_val *d_vector, const f
     f.seq = report ? ++p->seq : 0u;
     p->rec_pending = report;
     p->rec_epoch = gl::graph_launches();
+    // test hook (GRAPHLILY_DEBUG spmspv_inject_timeout=1): mark this run as one whose rendezvous timed out, the way a poll that gave
+    // up does, so that tests can drive the failure path -- reporting runs AND runs recorded into a graph -- without a real timeout
+    if (gl::debug_knob("spmspv_inject_timeout", 0) != 0) {
+        gl::spmspv_inject_timeout_kernel<<<1, 1, 0, s>>>(p->d_sync);
+        GL_LAUNCH_CHECK();
+    }
     return gl::launch_fold(op + 3 * val_type, f, s);
 }
 
@@ -1148,6 +1157,14 @@ int gl_spmspv_wait(gl_spmspv_plan p, uint32_t *nnz) {
     }
     GL_HIP(hipStreamSynchronize(gl::ctx().stream));
     if (nnz) *nnz = 0xffffffffu;   // no record: read the head element (gl_sparse_nnz)
+    return GL_OK;
+}
+
+int gl_spmspv_failed_runs(gl_spmspv_plan p, uint32_t *count) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr && count != nullptr);
+    hipStream_t s = gl::ctx().stream;
+    GL_HIP(gl::d2h_word_sync(count, p->d_sync + gl::kSyncFailedRuns, s));
     return GL_OK;
 }
 

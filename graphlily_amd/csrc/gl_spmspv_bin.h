@@ -66,8 +66,12 @@ constexpr uint32_t kFoldMaxRounds = kFoldMaxRows / kFoldThreads;   // 16 rounds 
 // states, starts at 1 and only grows (the fold's last tile advances it); kSyncFoldTicket: tiles handed out so far (64 bits,
 // only grows); kSyncFoldDone: finished workgroups << 32 | their entries (64 bits), zero between runs
 // kSyncErr: a rendezvous poll gave up (its spin limit ran out -- the all-workgroups-resident assumption was broken by a co-resident
-// kernel): the run's list is emptied and a blocking caller gets GL_ERR_HIP from gl_spmspv_wait instead of a wrong result
-enum : uint32_t { kSyncGen = 0, kSyncFoldDone = 4 /* 64 bits */, kSyncFoldTicket = 8 /* 64 bits */, kSyncErr = 12, kSyncWords = 16 };
+// kernel): the run's list is emptied and a blocking caller gets GL_ERR_HIP from gl_spmspv_wait instead of a wrong result.  The
+// word holds the GENERATION of the failed run (generations start at 1 and only grow), so it needs no clearing: a run is failed iff
+// the word equals its own generation, and a stale mark cannot empty the lists of later runs or graph replays (round 5 cleared a
+// boolean only on runs that report to the host: one timeout inside a recorded BFS slot would have emptied every later replay).
+// kSyncFailedRuns: failed runs so far, never cleared -- what gl_spmspv_failed_runs reads after non-reporting runs (graph replays).
+enum : uint32_t { kSyncGen = 0, kSyncFoldDone = 4 /* 64 bits */, kSyncFoldTicket = 8 /* 64 bits */, kSyncErr = 12, kSyncFailedRuns = 13, kSyncWords = 16 };
 constexpr uint32_t kSpinLimit = 1u << 24;
 
 // row -> tile without a division: tile = (row * magic) >> (32 + shift), checked on the host for every tile boundary at plan
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(kBinThreads) void spmspv_bin_kernel(BinArgs a) {
                         while ((uint32_t)((w = __hip_atomic_load(&slices[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag && ++spins < kSpinLimit)
                             __builtin_amdgcn_s_sleep(1);
                         if ((uint32_t)(w >> 32) != tag) {   // gave up: the word belongs to another round -- no products from it, and the run is marked failed
-                            __hip_atomic_store(&a.sync[kSyncErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&a.sync[kSyncErr], gen0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             w = 0ull;
                         }
                         v = w & 0xffffffffull;
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
             while (((w = __hip_atomic_load(&a.state[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffff0000u) != tag && ++spins < kSpinLimit)
                 __builtin_amdgcn_s_sleep(1);
             if ((w & 0xffff0000u) != tag) {   // gave up on a tile in front: the list cannot be placed -- the run is marked failed
-                __hip_atomic_store(&a.sync[kSyncErr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.sync[kSyncErr], gen0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 w = 0u;
             }
             before += w & 0xffffu;
@@ -805,8 +809,10 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
         // the last tile has seen every other tile's state: the list's length, and fresh tags for the next
         // run (every workgroup of this launch has read the generation by now)
         // (a failed rendezvous -- kSyncErr, set by the bin launch in front or by this tile's own look-back -- leaves an EMPTY list)
-        a.out[0].index = __hip_atomic_load(&a.sync[kSyncErr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0u : before + total;
+        const bool failed = __hip_atomic_load(&a.sync[kSyncErr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0;
+        a.out[0].index = failed ? 0u : before + total;
         a.out[0].val = a.head_val;
+        if (failed) __hip_atomic_fetch_add(&a.sync[kSyncFailedRuns], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&a.sync[kSyncGen], gen0 + (a.bin_vec ? spmspv_bin_rounds(a.bin_vec[0].index, a.bin_grid) : 1u), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -822,11 +828,8 @@ __global__ __launch_bounds__(kFoldThreads) void spmspv_fold_kernel(FoldArgs a) {
         const unsigned long long old = __hip_atomic_fetch_add(done, (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(old >> 32) == T_ - 1u) {
             uint32_t all = (uint32_t)old + total;
-            // every workgroup marked its failure before its arrival above: count 0xffffffff tells gl_spmspv_wait, the mark is cleared
-            if (__hip_atomic_load(&a.sync[kSyncErr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                all = 0xffffffffu;
-                __hip_atomic_store(&a.sync[kSyncErr], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            // every workgroup marked its failure (the run's generation) before its arrival above: count 0xffffffff tells gl_spmspv_wait
+            if (__hip_atomic_load(&a.sync[kSyncErr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) all = 0xffffffffu;
             __hip_atomic_store(a.host_rec, ((unsigned long long)a.seq << 32) | all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next run's first arrival is a launch away)
         }

@@ -380,50 +380,89 @@ def preflight(comm, device, expect_world, cabi=None, rows=3_072_512, watchdog_s=
                                        "dense_12MB": median_ms(lambda: comm.all_gather_slices(dense, bnds))}
         out["verified"] = True
         if cabi is not None:
-            try:
+            # Every rank walks the SAME sequence of collectives whatever it finds locally (a rank that left the
+            # sequence on a rank-local verdict -- wrong words, wrong tallies -- met the others' next collective with its final
+            # flag all-reduce, and the job ended in the watchdog).  A step = one local action (may be a C ABI collective) + one
+            # local verdict; the verdicts are all-reduced after EACH step, so that all ranks skip the remaining steps together.
+            # (A rank whose C ABI call throws BEFORE it has joined that call's collective still strands its peers inside it:
+            # that case is the watchdog's.)
+            cabi_err = None
+
+            def words_ok(vec, bnds, unit):      # local compare only -- no collective inside a step's verdict
+                idx = torch.arange(vec.shape[0], device=vec.device, dtype=torch.int64)
+                own = owner_pattern(idx, [b // unit for b in bnds])
+                return bool(torch.equal(vec.to(torch.int64), (idx * 7 + own * 1000003 + 11) % 16777213))
+
+            def step(name, fn):
+                nonlocal cabi_err
+                ok, why = True, ""
+                if cabi_err is None:            # (the same on every rank: set from all-reduced verdicts only)
+                    try:
+                        ok = bool(fn())
+                    except Exception as e:
+                        ok, why = False, ": " + repr(e)
+                    flag = torch.tensor([0 if ok else 1], dtype=torch.int64, device=device if out["backend"] != "gloo" else "cpu")
+                    comm.dist.all_reduce(flag, group=comm.group)
+                    if int(flag.item()):
+                        cabi_err = "%s failed on %d rank(s)%s" % (name, int(flag.item()), why if not ok else "")
+
+            state = {}
+
+            def s_setup():
                 if fail_cabi:
                     raise RuntimeError("forced by the test hook (GRAPHLILY_DEBUG dist_preflight_fail_cabi=1)")
-                from . import capi
-                bbits, bdense = capi.DeviceBuffer.from_torch(bits), capi.DeviceBuffer.from_torch(dense)
-                tally = torch.zeros(W * capi.GL_BFS_TALLY_RANK_WORDS, dtype=torch.int32, device=device)
-                btally = capi.DeviceBuffer.from_torch(tally)
-                for uneven in (True, False):
-                    bnds = bounds_of(uneven)
+                from . import capi as capi_lib
+                capi = getattr(cabi, "capi_module", None) or capi_lib     # (tests drive this section on gloo ranks with a stand-in)
+                state["capi"] = capi
+                state["bbits"], state["bdense"] = capi.DeviceBuffer.from_torch(bits), capi.DeviceBuffer.from_torch(dense)
+                state["tally"] = torch.zeros(W * capi.GL_BFS_TALLY_RANK_WORDS, dtype=torch.int32, device=device)
+                state["btally"] = capi.DeviceBuffer.from_torch(state["tally"])
+                return True
+
+            step("C ABI pre-flight setup", s_setup)
+            for uneven in (True, False):
+                bnds = bounds_of(uneven)
+                tag = "uneven" if uneven else "equal"
+
+                def s_bits(bnds=bnds):
+                    capi, tally = state["capi"], state["tally"]
                     fill(bits, bnds, 32)
                     tally.zero_()
                     tally[rank * capi.GL_BFS_TALLY_RANK_WORDS:(rank + 1) * capi.GL_BFS_TALLY_RANK_WORDS] = rank + 1
                     sync()
-                    cabi.gl.all_gather_bits_tally(bbits, bnds, btally)
+                    cabi.gl.all_gather_bits_tally(state["bbits"], bnds, state["btally"])
                     capi.sync()
-                    check("bit (C ABI path, %s bounds)" % ("uneven" if uneven else "equal"), bits, bnds, 32)
                     want = torch.arange(1, W + 1, device=device, dtype=torch.int32).repeat_interleave(capi.GL_BFS_TALLY_RANK_WORDS)
-                    if not torch.equal(tally, want):
-                        raise RuntimeError("the tallies that ride with the bit all-gather came back wrong")
+                    return words_ok(bits, bnds, 32) and bool(torch.equal(tally, want))
+
+                def s_dense(bnds=bnds):
                     fill(dense, bnds, 1)
                     sync()
-                    cabi.gl.all_gather_f32(bdense, bnds)
-                    capi.sync()
-                    check("dense (C ABI path, %s bounds)" % ("uneven" if uneven else "equal"), dense, bnds, 1)
-                bnds = bounds_of(True)
+                    cabi.gl.all_gather_f32(state["bdense"], bnds)
+                    state["capi"].sync()
+                    return words_ok(dense, bnds, 1)
 
+                step("bit all-gather with tallies (C ABI path, %s bounds)" % tag, s_bits)
+                step("dense all-gather (C ABI path, %s bounds)" % tag, s_dense)
+            bnds = bounds_of(True)
+
+            def s_time():
                 def cabi_bits():
-                    cabi.gl.all_gather_bits_tally(bbits, bnds, btally)
-                    capi.sync()
+                    cabi.gl.all_gather_bits_tally(state["bbits"], bnds, state["btally"])
+                    state["capi"].sync()
 
                 def cabi_dense():
-                    cabi.gl.all_gather_f32(bdense, bnds)
-                    capi.sync()
+                    cabi.gl.all_gather_f32(state["bdense"], bnds)
+                    state["capi"].sync()
 
                 out["exchange_ms"]["cabi"] = {"bits_384KB_with_tallies": median_ms(cabi_bits), "dense_12MB": median_ms(cabi_dense)}
+                return True
+
+            step("C ABI exchange timing", s_time)
+            if cabi_err is None:
                 out["exchange_path"] = "cabi"
-            except Exception as e:          # recorded; the caller keeps the torch path
-                out["cabi_error"] = repr(e)
-                # every rank must take the same path: one rank's failure is everybody's
-            flag = torch.tensor([0 if out["exchange_path"] == "cabi" else 1], dtype=torch.int64,
-                                device=device if out["backend"] != "gloo" else "cpu")
-            comm.dist.all_reduce(flag, group=comm.group)
-            if int(flag.item()) and out["exchange_path"] == "cabi":
-                out["exchange_path"], out["cabi_error"] = "torch", "another rank's C ABI pre-flight failed"
+            else:                               # recorded; the caller keeps the torch path -- on every rank alike
+                out["cabi_error"] = cabi_err
         return out
     finally:
         done.set()

@@ -64,17 +64,22 @@ private:
         uint32_t slots = 0, words = 0, nvec = 0, nvec_all = 0, ctl_words = 0;
         DeviceBuffer both;      // n distances, then the control words: one read-back fetches both
         DeviceBuffer vecs;      // nvec bit vectors of `words` words, then the ranks' tallies
-        DeviceBuffer packed;    // the levels as nibbles / bytes + the control words (gl_levels_pack)
-        void *h_packed = nullptr;
-        size_t h_packed_bytes = 0;
+        // the levels as nibbles ([0]: up to 14 iterations) / bytes ([1]) + the control words (gl_levels_pack): one pair of buffers
+        // per WIDTH, so that calls alternating between N <= 14 and N >= 15 keep their recorded graphs (one pair,
+        // re-allocated on every change of width, destroyed every graph each time)
+        DeviceBuffer packed[2];
+        void *h_packed[2] = {nullptr, nullptr};
+        size_t h_packed_bytes[2] = {0, 0};
         std::map<std::tuple<uint32_t, uint32_t, int, int>, gl_graph> graphs;   // (slots, threshold bits, pull only, packed)
         ~Schedule() { clear(); }
         void clear() {
             for (auto &g : graphs) gl_graph_destroy(g.second);
             graphs.clear();
-            if (h_packed) gl_host_free(h_packed);
-            h_packed = nullptr;
-            h_packed_bytes = 0;
+            for (int w = 0; w < 2; w++) {
+                if (h_packed[w]) gl_host_free(h_packed[w]);
+                h_packed[w] = nullptr;
+                h_packed_bytes[w] = 0;
+            }
             slots = 0;
         }
     } sched_;
@@ -121,13 +126,13 @@ private:
     aligned_dense_vec_t run_schedule_(uint32_t source, uint32_t N, float threshold, bool pull_only) {
         Schedule &s = sched_;
         const uint32_t n = matrix_num_rows_;
-        if (s.slots < N) {
+        if (!s.both.valid() || s.slots < N) {   // (N == 0 as the first call: the buffers exist all the same -- ADVICE r05)
             s.clear();
-            s.slots = N;
+            s.slots = std::max<uint32_t>(N, 1u);
             s.words = ((uint32_t)SpMV_->bits_words() + 3u) & ~3u;
-            s.nvec = N + 2;
-            s.ctl_words = (18u + 2u * N + 15u) & ~15u;
-            const size_t tally_words = GL_BFS_TALLY_WORDS(N, shards_.world);
+            s.nvec = s.slots + 2;
+            s.ctl_words = (18u + 2u * s.slots + 15u) & ~15u;
+            const size_t tally_words = GL_BFS_TALLY_WORDS(s.slots, shards_.world);
             s.nvec_all = s.nvec + (uint32_t)((tally_words + s.words - 1) / s.words);
             s.both = DeviceBuffer(sizeof(float) * ((size_t)n + s.ctl_words));
             s.vecs = DeviceBuffer(sizeof(uint32_t) * (size_t)s.nvec_all * s.words);
@@ -140,23 +145,22 @@ private:
         const bool packed = N + 1 <= 255 && n % 8 == 0 && n >= (1u << 19) && !(pin && atoi(pin) == 0) && gl_host_unpack_threads() >= 4;
         uint32_t *ctl = (uint32_t *)s.both.raw() + n;
         size_t packed_words = 0;
+        const int pw = bits == 4 ? 0 : 1;
         if (packed) {
             packed_words = ((size_t)n * bits / 8 + 15) / 16 * 4;     // levels, padded to 16 bytes; the control words follow
             const size_t bytes = 4 * (packed_words + s.ctl_words);
-            if (s.h_packed_bytes != bytes) {
-                if (s.h_packed) gl_host_free(s.h_packed);
-                GRAPHLILY_CHECK(gl_host_alloc(&s.h_packed, bytes));
-                s.h_packed_bytes = bytes;
-                s.packed = DeviceBuffer(bytes);
-                for (auto &g : s.graphs) gl_graph_destroy(g.second);   // (they recorded the old buffers)
-                s.graphs.clear();
+            if (s.h_packed_bytes[pw] != bytes) {   // (first use of this width since the schedule's buffers were made: no graph holds it yet)
+                if (s.h_packed[pw]) gl_host_free(s.h_packed[pw]);
+                GRAPHLILY_CHECK(gl_host_alloc(&s.h_packed[pw], bytes));
+                s.h_packed_bytes[pw] = bytes;
+                s.packed[pw] = DeviceBuffer(bytes);
             }
         }
         auto everything = [&] {
             enqueue_schedule_(N, threshold, pull_only);
             if (packed) {
-                GRAPHLILY_CHECK(gl_levels_pack((const float *)s.both.raw(), n, bits, ctl, s.ctl_words, s.packed.raw()));
-                GRAPHLILY_CHECK(gl_buf_d2h_async(s.h_packed, s.packed.raw(), s.h_packed_bytes));
+                GRAPHLILY_CHECK(gl_levels_pack((const float *)s.both.raw(), n, bits, ctl, s.ctl_words, s.packed[pw].raw()));
+                GRAPHLILY_CHECK(gl_buf_d2h_async(s.h_packed[pw], s.packed[pw].raw(), s.h_packed_bytes[pw]));
             }
         };
         GRAPHLILY_CHECK(gl_buf_fill_u32(ctl + 2, source, 1));          // ctl[2] = source: the recorded sequence serves any source
@@ -175,8 +179,8 @@ private:
                 if (gl_graph_begin_capture() == GL_OK) {
                     enqueue_schedule_(N, threshold, pull_only);
                     if (packed) {
-                        gl_levels_pack((const float *)s.both.raw(), n, bits, ctl, s.ctl_words, s.packed.raw());
-                        gl_buf_d2h_async(s.h_packed, s.packed.raw(), s.h_packed_bytes);
+                        gl_levels_pack((const float *)s.both.raw(), n, bits, ctl, s.ctl_words, s.packed[pw].raw());
+                        gl_buf_d2h_async(s.h_packed[pw], s.packed[pw].raw(), s.h_packed_bytes[pw]);
                     }
                     if (gl_graph_end_capture(&rec) != GL_OK) rec = nullptr;
                 }
@@ -190,8 +194,8 @@ private:
         }
         std::vector<uint32_t> c(s.ctl_words);
         if (packed) {
-            GRAPHLILY_CHECK(gl_sync_levels_unpack((float *)result.data(), s.h_packed, n, bits));
-            memcpy(c.data(), (const uint32_t *)s.h_packed + packed_words, 4u * s.ctl_words);
+            GRAPHLILY_CHECK(gl_sync_levels_unpack((float *)result.data(), s.h_packed[pw], n, bits));
+            memcpy(c.data(), (const uint32_t *)s.h_packed[pw] + packed_words, 4u * s.ctl_words);
         } else {
             GRAPHLILY_CHECK(gl_buf_d2h(result.data(), s.both.raw(), sizeof(float) * (size_t)n));
             GRAPHLILY_CHECK(gl_buf_d2h(c.data(), ctl, 4u * s.ctl_words));
@@ -302,7 +306,7 @@ public:
     }
 
     aligned_dense_vec_t pull(uint32_t source, uint32_t num_iterations) {
-        if (schedule_ok_()) return run_schedule_(source, num_iterations, -1.0f, true);
+        if (num_iterations > 0 && schedule_ok_()) return run_schedule_(source, num_iterations, -1.0f, true);   // (0 iterations: the host loop returns the start vector)
         aligned_dense_vec_t input = dense_(source, semiring_.zero, 1), distance = dense_(source, 0, 1);
         SpMV_->send_vector_host_to_device(input);
         SpMV_->send_mask_host_to_device(distance);
@@ -318,7 +322,7 @@ public:
     }
 
     aligned_dense_vec_t pull_push(uint32_t source, uint32_t num_iterations, float threshold = 0.05) {
-        if (schedule_ok_()) {
+        if (num_iterations > 0 && schedule_ok_()) {
             aligned_dense_vec_t r = run_schedule_(source, num_iterations, threshold, false);
             std::cout << "SpMSpV runs for " << push_iterations_ << " iterations" << std::endl;
             return r;

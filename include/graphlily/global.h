@@ -328,4 +328,6 @@ public:
 
 }  // namespace graphlily
 
+#include "graphlily/cl_buffers.h"   // cl::Buffer & co. as the reference's callers spell the module API's buffer handles
+
 #endif  // GRAPHLILY_GLOBAL_H_

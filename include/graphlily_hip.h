@@ -296,6 +296,11 @@ int gl_spmspv_run(gl_spmspv_plan plan, const gl_idx_val *d_vector, const float *
  * (read the head element with gl_sparse_nnz).  Work enqueued on OTHER streams
  * is not waited for. */
 int gl_spmspv_wait(gl_spmspv_plan plan, uint32_t *nnz);
+/* Extension: how many runs on this plan had a workgroup rendezvous time out so far (their result lists were emptied; a blocking
+ * caller got GL_ERR_HIP from gl_spmspv_wait).  For callers whose runs keep no completion record -- runs recorded into a hipGraph
+ * and replayed -- this is where such a failure surfaces: read it after the replay (waits for the stream, one 4-byte copy).  The
+ * reference has no counterpart (its kernel cannot time out: module/spmspv_module.h:436-441 blocks in finish()). */
+int gl_spmspv_failed_runs(gl_spmspv_plan plan, uint32_t *count);
 /* Extension: gl_spmspv_run followed by gl_assign_sparse(d_result, d_inout, val) -- the push iteration of BFS
  * (app/bfs.h:146-148: SpMSpV, then AssignVectorSparse::run(val) with the result as its mask) -- with the assign
  * done by the pass that writes the result list (one launch and one read of the list less).  d_inout may be the

@@ -1,0 +1,36 @@
+#!/bin/bash
+# round 6: the round's gpurun batches, one case per experiment (EXPERIMENTS.md R6.x).  Outputs land in gpurun_out/r06_<case>.txt;
+# the ones that are cited get copied to profiles/.
+# usage (through gpurun): bash scripts/r06_batch.sh <case> [args]
+cd /root/repo; mkdir -p gpurun_out
+CASE=${1:-help}; shift || true
+probe() {   # probe <graph> <flags> <GRAPHLILY_DEBUG value> [lib]: one line "graph flags knobs: <op 0 mask 0 line> | plan info"
+  local g=$1 f=$2 k=$3 lib=${4:-}
+  echo -n "$g flags=$f [$k] ${lib:+lib=$lib }: "
+  env GRAPHLILY_DEBUG="$k" GRAPHLILY_HIP_LIB=${lib:+scripts/_variants/$lib.so} timeout 600 python scripts/probe_spmv.py --graph $g --flags $f --no-copy --iters 100 2>&1 \
+    | grep -E "^op 0 mask 0|^plan create" | sed -e 's/^plan create [0-9.]*s //' | tr '\n' ' '; echo
+}
+case $CASE in
+two_wg)   # R6.1: two 1024-thread workgroups per CU on half-height tiles (LDS <= 80 KB each), by planner knobs alone
+  for rep in 1 2; do for g in ${GRAPHS:-orkut ogbn_products pokec}; do for f in 0 4; do
+    probe $g $f ""
+    probe $g $f "spmv_blocks=512"
+    probe $g $f "spmv_blocks=512,spmv_hot=5120"
+    probe $g $f "spmv_blocks=512,spmv_hot=3072"
+    probe $g $f "spmv_blocks=768,spmv_hot=5120"
+  done; done; done 2>&1 | tee gpurun_out/r06_two_wg.txt
+  ;;
+pmc_pattern)   # R6.2: where the pattern kernel's wave cycles go (SQ / TA / TCP / LDS counters, separate passes)
+  bash scripts/pmc_probe.sh ${1:-orkut} 2>&1 | tee gpurun_out/r06_pmc_pattern_${1:-orkut}.txt
+  ;;
+lds_atomic)    # R6.3: what an LDS atomic / read instruction costs by op, active lanes and address pattern (scripts/ubench_lds_atomic.hip)
+  timeout 300 build/ubench_lds_atomic 2>&1 | tee gpurun_out/r06_ubench_lds_atomic.txt
+  ;;
+ref_tests)     # the reference's own acceptance suites, unmodified, float + ufixed
+  timeout 1500 python benchmarks/run_reference_benches.py --apps tests --write-reference-dataset-dir 2>&1 | tee gpurun_out/r06_reference_test_suites.txt
+  ;;
+pytest)        # pytest -m gpu on the files / -k expression given
+  timeout 3000 python -m pytest -m gpu -x -q "$@" 2>&1 | tail -15 | tee gpurun_out/r06_pytest_last.txt
+  ;;
+*) echo "cases: two_wg pmc_pattern lds_atomic ref_tests pytest"; exit 1;;
+esac

@@ -51,6 +51,16 @@ int main(int argc, char **argv) {
         bfs.load_and_format_matrix(npz, true);
         bfs.send_matrix_host_to_device();
         auto ref = bfs.compute_reference_results(0, iters);
+        {   // zero iterations as the FIRST call (the schedule's buffers did not exist yet: a null control block went
+            // to the library) -- the reference returns the start vector (bfs.h:106-127)
+            auto p0 = bfs.pull(0, 0);
+            bad += same(bfs.compute_reference_results(0, 0), p0, "BFS::pull with 0 iterations as the first call", 0.f);
+            // ... and calls that alternate between the nibble (<= 14 iterations) and the byte read-back keep their own buffers
+            for (int rep = 0; rep < 2; rep++) {
+                bad += same(bfs.compute_reference_results(0, 3), bfs.pull(0, 3), "BFS::pull, 3 iterations (nibbles)", 0.f);
+                bad += same(bfs.compute_reference_results(0, 16), bfs.pull(0, 16), "BFS::pull, 16 iterations (bytes)", 0.f);
+            }
+        }
         for (int rep = 0; rep < 3; rep++) {   // first call enqueues and records, the others replay the hipGraph
             auto pp = bfs.pull_push(0, iters, 0.001f);
             auto pl = bfs.pull(0, iters);

@@ -108,6 +108,25 @@ def test_reference_bench_spmspv_compiles_unmodified_and_its_build_mode_runs(tmp_
     assert r.returncode == 0 and "nothing to synthesise" in r.stdout and "Kernel Build Complete" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests"), reason="reference tree not present")
+@pytest.mark.parametrize("define", ["", "-DGRAPHLILY_VAL_UFIXED"])
+@pytest.mark.parametrize("suite", ["test_module_apply", "test_module_spmv_spmspv", "test_app"])
+def test_reference_test_suites_compile_unmodified(suite, define, tmp_path):
+    """The reference's own acceptance suites (tests/test_module_*.cpp and tests/test_app.cpp are callers of the
+    boundary) compile UNMODIFIED against include/: <ap_fixed.h> = include/ap_fixed.h (the one type the reference takes from it),
+    <gtest/gtest.h> = tests/cpp/gtest/gtest.h (test infrastructure), the cl::Buffer / cl::CommandQueue that
+    test_module_apply.cpp:236-256 makes itself = include/graphlily/cl_buffers.h.  With no GPU every TEST stops at
+    set_up_runtime's print-and-exit (xcl2.hpp:40-46) -- never a CPU path."""
+    exe = str(tmp_path / suite)
+    cmd = ["g++", "-std=c++11", "-O2", "-w"] + ([define] if define else []) + ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"),
+          "/root/reference/tests/%s.cpp" % suite, "-o", exe, "-L", LIBDIR, "-lgraphlily_hip", "-Wl,-rpath," + LIBDIR]
+    subprocess.check_call(cmd)
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "--gtest_filter=-Synthesize.*:Clean*"], capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode != 0 and "Error calling" in r.stdout and "[       OK ]" not in r.stdout
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/graphlily/app"), reason="reference tree not present")
 def test_reference_app_drivers_compile_unmodified():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref_apps"])
@@ -270,6 +289,23 @@ def test_reference_benchmark_drivers_run_on_hip_backend(gpu):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("GTEPS") >= 6      # SpMV, BFS pull + pull-push, PageRank, SSSP pull + pull-push
     assert "SpMV passed" in r.stdout and "Compute THROUGHPUT" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_test_app")),
+                    reason="prebuilt reference test suites did not travel")
+def test_reference_test_suites_pass_on_hip_backend(gpu):
+    """tests/test_module_apply.cpp:54-261, tests/test_module_spmv_spmspv.cpp:137-314 and tests/test_app.cpp:51-135 -- the files
+    that DEFINE the acceptance bar (eps 1e-4, the semiring x mask matrix, the three apps on uniform_10K_10) -- byte-identical to
+    the checkout, on the HIP backend, for val_t = float and for the reference's shipped ap_ufixed<32, 8>: every TEST passes
+    (Synthesize is a no-op print, Clean removes ./proj in a scratch directory)."""
+    r = subprocess.run(["python", os.path.join(ROOT, "benchmarks", "run_reference_benches.py"), "--apps", "tests",
+                        "--write-reference-dataset-dir"], capture_output=True, text=True, timeout=1800)
+    sys.stdout.write(r.stdout[-6000:] + r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "# 6 of 6 suite binaries passed" in r.stdout and "[  FAILED  ]" not in r.stdout
+    # every TEST of every suite ran: 7 + 4 + 5 per value type (incl. Synthesize and Clean)
+    assert r.stdout.count("[       OK ]") == 2 * (7 + 4 + 5)
 
 
 @pytest.mark.gpu

@@ -383,6 +383,63 @@ def _body_preflight(comm):
     return ok
 
 
+class _FakeCabi:
+    """Stands in for dist.CabiComm in preflight()'s C ABI section on gloo ranks: the two exchanges run over the torch path, and
+    rank `bad_rank` (if any) finds wrong words in its copy of the first dense all-gather -- a RANK-LOCAL verdict."""
+
+    class _Mod:
+        GL_BFS_TALLY_RANK_WORDS = 64
+
+        class DeviceBuffer:
+            @staticmethod
+            def from_torch(t):
+                return t
+
+        @staticmethod
+        def sync():
+            pass
+
+    def __init__(self, comm, bad_rank):
+        self.capi_module, self.comm, self.bad_rank, self.dense_calls = self._Mod, comm, bad_rank, 0
+        self.gl = self
+
+    def all_gather_bits_tally(self, bits, bnds, tally):
+        import torch
+        self.comm.all_gather_slices(bits, [b // 32 for b in bnds])
+        W, n = self.comm.world_size, self._Mod.GL_BFS_TALLY_RANK_WORDS
+        parts = [torch.zeros(n, dtype=tally.dtype) for _ in range(W)]
+        self.comm.dist.all_gather(parts, tally[self.comm.rank * n:(self.comm.rank + 1) * n].clone(), group=self.comm.group)
+        tally.copy_(torch.cat(parts))
+
+    def all_gather_f32(self, dense, bnds):
+        self.comm.all_gather_slices(dense, bnds)
+        self.dense_calls += 1
+        if self.comm.rank == self.bad_rank and self.dense_calls == 1:
+            dense[0] += 1.0
+
+
+def _body_preflight_cabi_lockstep(comm):
+    from graphlily_amd.dist import preflight
+    rows = 64 * comm.world_size * 32
+    good = preflight(comm, "cpu", comm.world_size, cabi=_FakeCabi(comm, None), rows=rows, watchdog_s=60.0)
+    ok = good["exchange_path"] == "cabi" and good["cabi_error"] is None and good["exchange_ms"]["cabi"]["dense_12MB"] > 0
+    # ONE rank finds wrong words: every rank must leave the section at the same step and fall back together (ADVICE r05: the
+    # failing rank used to jump to the final flag all-reduce while its peers sat in the next exchange -- a 60 s watchdog exit)
+    bad = preflight(comm, "cpu", comm.world_size, cabi=_FakeCabi(comm, comm.world_size - 1), rows=rows, watchdog_s=60.0)
+    ok = ok and bad["exchange_path"] == "torch" and bad["verified"] is True
+    ok = ok and "dense all-gather (C ABI path, uneven bounds) failed on 1 rank(s)" in (bad["cabi_error"] or "")
+    ok = ok and "cabi" not in bad["exchange_ms"]
+    # ... and a rank whose section raises (the test hook) takes everybody with it just the same
+    forced = preflight(comm, "cpu", comm.world_size, cabi=_FakeCabi(comm, None), rows=rows, fail_cabi=comm.rank == 0)
+    ok = ok and forced["exchange_path"] == "torch" and "setup failed on 1 rank(s)" in (forced["cabi_error"] or "")
+    return ok
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_preflight_cabi_section_keeps_ranks_in_lockstep(world):
+    assert all(_spawn("_body_preflight_cabi_lockstep", world).values())
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_preflight_verifies_both_all_gathers(world):
     """bench.py's first contact with its peers: the process group's size, a bit and a dense all-gather on uneven and on equal

@@ -747,6 +747,60 @@ def test_wait_returns_the_count_without_a_copy(gpu):
     assert mod.plan_.wait() == int(want["index"][0])
 
 
+def test_a_timed_out_run_fails_alone(gpu, monkeypatch):
+    """A workgroup rendezvous that times out marks ITS run failed (gl_spmspv_bin.h kSyncErr holds the run's generation): the
+    list is emptied, a blocking caller gets GL_ERR_HIP -- and nothing else happens.  Round 5 kept a boolean that only a
+    host-reporting run cleared, so one timeout inside a recorded (non-reporting) run emptied every later run and replay on the
+    plan.  The timeout is injected (GRAPHLILY_DEBUG spmspv_inject_timeout, read when the run is enqueued)."""
+    from graphlily_amd import capi
+    csc = _random_csc(30000, 8, 22)
+    rng = np.random.default_rng(3)
+    mod = M.SpMSpVModule(512)
+    mod.set_semiring(M.ArithmeticSemiring)
+    mod.set_mask_type(M.kNoMask)
+    mod.set_up_runtime()
+    mod.load_and_format_matrix(csc)
+    mod.send_matrix_host_to_device()
+    mod.blocking = False
+    cols = np.sort(rng.choice(30000, size=2500, replace=False)).astype(np.uint32)
+    v = M.make_sparse_vec(cols, np.ones(2500, np.float32))
+    mod.send_vector_host_to_device(v)
+    mod.run()
+    n_good = mod.plan_.wait()
+    want = mod.send_results_device_to_host().copy()
+    assert n_good is not None and n_good > 0 and mod.plan_.failed_runs() == 0
+    ref = O.spmspv(to_oracle(csc), v, O.MULADD, 0.0, np.zeros(30000, np.float32), O.NOMASK)
+    assert np.allclose(M.convert_sparse_vec_to_dense_vec(want, 30000, 0.0), ref, rtol=1e-5, atol=1e-6)
+    # 1. a reporting run that times out: GL_ERR_HIP from the wait, an empty list, one failed run on the books
+    set_knob(monkeypatch, "spmspv_inject_timeout", 1)
+    mod.run()
+    with pytest.raises(capi.GraphLilyError) as ei:
+        mod.plan_.wait()
+    assert ei.value.code == capi.GL_ERR_HIP
+    assert int(mod.send_results_device_to_host()["index"][0]) == 0 and mod.plan_.failed_runs() == 1
+    # 2. a recorded run that times out on every replay: no record, empty lists, the counter says so
+    with capi.Graph.capture() as g:
+        mod.run()
+    set_knob(monkeypatch, "spmspv_inject_timeout", None)
+    for k in range(3):
+        g.launch()
+        assert mod.plan_.wait() is None
+        assert int(mod.send_results_device_to_host()["index"][0]) == 0
+        assert mod.plan_.failed_runs() == 2 + k
+    # 3. ... and the runs after it are healthy again, eager and recorded alike (the stale mark belongs to another generation)
+    mod.run()
+    assert mod.plan_.wait() == n_good
+    assert np.array_equal(mod.send_results_device_to_host(), want)
+    with capi.Graph.capture() as g2:
+        mod.run()
+    g.launch()                                  # the failing graph in between
+    g2.launch()
+    assert mod.plan_.wait() is None
+    assert np.array_equal(mod.send_results_device_to_host(), want) and mod.plan_.failed_runs() == 5
+    g.destroy()
+    g2.destroy()
+
+
 @pytest.mark.parametrize("sem", ["Arithmetic", "Tropical"])
 def test_tiny_run_whose_rows_are_adjacent(gpu, sem):
     """The one-launch kernel orders the rows it reached with a counting pass over 2048 buckets of consecutive rows + a rank
