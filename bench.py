@@ -390,12 +390,36 @@ def _ordered(out):
     o.update({k: v for k, v in out.items() if k not in first and k not in last})
     o.update({k: out[k] for k in last if k in out})
     bfs = out.get("bfs", {})
-    o["headline"] = {"spmv_gbps": out.get("value"), "spmv_ms_per_step": out.get("ms_per_step"),
-                     "roofline_frac": out.get("roofline", {}).get("frac"), "roofline_kernel_ms": out.get("roofline", {}).get("kernel_ms"),
-                     "bfs_pull_push_ms": bfs.get("pull_push", {}).get("ms"), "bfs_pull_push_gteps": bfs.get("pull_push", {}).get("gteps"),
-                     "bfs_pull_push_gteps_traversed": bfs.get("pull_push", {}).get("gteps_traversed"),
-                     "bfs_pull_ms": bfs.get("pull", {}).get("ms"), "bfs_pull_gteps": bfs.get("pull", {}).get("gteps"),
-                     "cpu_baseline_gbps": out.get("cpu_baseline", {}).get("value"), "n_gpus": out.get("n_gpus")}
+    cb = out.get("cpu_baseline", {})
+    hl = {"spmv_gbps": out.get("value"), "spmv_ms_per_step": out.get("ms_per_step"),
+          "roofline_frac": out.get("roofline", {}).get("frac"), "roofline_kernel_ms": out.get("roofline", {}).get("kernel_ms"),
+          "bfs_pull_push_ms": bfs.get("pull_push", {}).get("ms"), "bfs_pull_push_gteps": bfs.get("pull_push", {}).get("gteps"),
+          "bfs_pull_push_gteps_traversed": bfs.get("pull_push", {}).get("gteps_traversed"),
+          "bfs_pull_ms": bfs.get("pull", {}).get("ms"), "bfs_pull_gteps": bfs.get("pull", {}).get("gteps"),
+          "cpu_baseline_gbps": cb.get("value"), "cpu_baseline_omp_gbps": cb.get("omp_gbps"), "cpu_baseline_omp_cores": cb.get("omp_cores"),
+          "n_gpus": out.get("n_gpus")}
+    # (round 5's verdict: the driver keeps the parsed contract keys and the last 2000 characters -- everything a reader needs beyond
+    #  the contract has to sit HERE, compactly: the pattern layout's kernel, the SpMSpV legs' best / worst fraction of the HBM peak,
+    #  and per stand-in [general-layout SpMV fraction of peak wall, kernel, pattern-layout ms, PageRank ms / iteration, BFS pull-push ms])
+    pp = out.get("pattern_plan", {})
+    if "kernel_ms" in pp:
+        hl["pattern_kernel_ms"], hl["pattern_ms_per_step"], hl["pattern_traffic_frac"] = pp.get("kernel_ms"), pp.get("ms_per_step"), pp.get("frac_hbm_peak")
+    fr = [c.get("frac_hbm_peak") for c in out.get("spmspv", {}).get("cases", []) if c.get("frac_hbm_peak") is not None]
+    if fr:
+        hl["spmspv_frac_best"], hl["spmspv_frac_worst"] = max(fr), min(fr)
+    six = out.get("six_graphs", {})
+    short = {"ogbn_products": "products", "googleplus": "gplus", "ogbl_ppa": "ppa", "orkut_community": "community", "orkut_community_shuffled": "shuffled"}
+    rows = {}
+    for name, rec in six.items():
+        if not isinstance(rec, dict) or "spmv" not in rec:
+            continue
+        rows[short.get(name, name)] = [rec["spmv"].get("frac_hbm_peak"), rec["spmv"].get("kernel_frac_hbm_peak"),
+                                       rec.get("spmv_pattern", {}).get("ms"), rec.get("pagerank", {}).get("ms_per_iter"),
+                                       rec.get("bfs", {}).get("pull_push_ms")]
+    if rows:
+        hl["six"] = rows
+        hl["six_cols"] = "frac wall, frac kernel, pattern ms, pagerank ms/it, bfs pp ms"
+    o["headline"] = hl
     return o
 
 
@@ -768,8 +792,9 @@ def _cpu_baseline(csr, x, alg_bytes):
             "sample": "%d whole-matrix (+,x) SpMV passes of the timed workload in %.1f s, oracle C port, 1 thread"
                       % (res["single"][1], res["single"][2]),
             "gteps": round(res["single"][0] * 1e9 / alg_bytes * csr.nnz / 1e9, 4),
-            "omp": {"value": round(res["omp"][0], 3), "unit": "GB/s", "cores": cores,
-                    "sample": "%d passes in %.1f s, same loop row-parallel with OpenMP" % (res["omp"][1], res["omp"][2])}}
+            # (flat keys: the driver's parser keeps an object's scalars and drops nested objects)
+            "omp_gbps": round(res["omp"][0], 3), "omp_cores": cores,
+            "omp_sample": "%d passes in %.1f s, same loop row-parallel with OpenMP" % (res["omp"][1], res["omp"][2])}
 
 
 if __name__ == "__main__":

@@ -13,8 +13,10 @@
 //                                         (255 columns per dummy), ONE inclusive scan (rocPRIM) gives every entry its
 //                                         position in its unit's stream, a thread per entry writes it and its dummies in
 //                                         the stream's final lane-interleaved order
-//   * the run-coded hot stream            run starts flagged by comparing neighbouring keys, ONE inclusive scan (rocPRIM)
-//                                         numbers the runs, a wave per hot group writes slots, values, run mask and base
+//   * the run-coded hot stream            (general layout) run starts flagged by comparing neighbouring keys, ONE inclusive scan
+//                                         (rocPRIM) numbers the runs, a wave per hot group writes slots, values, run mask and base
+//   * the row-packed hot stream           (pattern layout, round 6) hot entries stay OUT of the sort: a wave per row counts the row's
+//                                         hot entries, ONE scan gives every row its first record, a wave per row writes its records
 // Both formatters produce byte-identical arrays (tests/test_gpu_format.py compares them through gl_spmv_plan_export).
 #include <cstring>   // rocPRIM's texture iterator calls memset from host code
 
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(kFmtThreads) void fmt_keys_kernel(const uint32_t *_
                                                                const uint32_t *__restrict__ data, uint32_t row_begin, uint32_t rows, uint64_t nz0,
                                                                uint32_t num_cols, const uint32_t *__restrict__ bstart, uint32_t nblocks,
                                                                const uint32_t *__restrict__ colmap, const uint32_t *__restrict__ colbits,
-                                                               uint32_t cb, uint32_t bb, K *__restrict__ keys, uint2 *__restrict__ payload) {
+                                                               uint32_t cb, uint32_t bb, K *__restrict__ keys, uint2 *__restrict__ payload,
+                                                               bool drop_hot) {
     const uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * (kFmtThreads / 64u);
     const K drop = (K)1 << (bb + cb + 1u);
     for (uint32_t row = blockIdx.x * (kFmtThreads / 64u) + (threadIdx.x >> 6); row < rows; row += nwaves) {
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(kFmtThreads) void fmt_keys_kernel(const uint32_t *_
             } else {
                 const uint32_t cm = colmap[c];
                 key = ((K)b << (cb + 1u)) | ((K)(cm >> 31) << cb) | (K)(cm & 0x7fffffffu);
+                if (drop_hot && (cm >> 31)) key = drop;   // row-packed hot stream: written from the rows themselves (fmt_emit_hot_rows_kernel)
             }
             keys[i] = key;
             payload[i] = make_uint2(r - r0, v);
@@ -348,6 +352,110 @@ __global__ __launch_bounds__(kThreads) void fmt_emit_hot_kernel(const K *__restr
         plan_units[3u * blockIdx.x + 2u] = make_uint4(u.hot_e0, u.present_off, m ? runs[u.hot_end - 1u] - s0 + 1u : 0u, 0u);
 }
 
+// ---- the ROW-PACKED hot stream of pattern plans (gl_spmv_plan.h)
+// counts[row] = hot entries of the row << 32 | its records (groups of <= 7 hot entries); a wave per row
+__global__ __launch_bounds__(kFmtThreads) void fmt_hot_row_counts_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                                         const uint32_t *__restrict__ data, uint32_t row_begin, uint32_t rows,
+                                                                         uint64_t nz0, uint32_t num_cols, const uint32_t *__restrict__ colmap,
+                                                                         const uint32_t *__restrict__ colbits, unsigned long long *__restrict__ counts) {
+    const uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * (kFmtThreads / 64u);
+    for (uint32_t row = blockIdx.x * (kFmtThreads / 64u) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+        const uint32_t r = row_begin + row;
+        const uint64_t s = indptr[row] - nz0, e = indptr[row + 1] - nz0;
+        uint32_t h = 0;
+        for (uint64_t i = s + lane; i < e; i += 64u) {
+            const uint32_t c = indices[i];
+            if (c >= num_cols || (colbits && c == r && data[i] != colbits[c])) continue;
+            h += colmap[c] >> 31;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d);
+        if (lane == 0) counts[row] = ((unsigned long long)h << 32) | (unsigned long long)((h + kHotRecEntries - 1u) / kHotRecEntries);
+    }
+}
+// out[b] = the scanned counts in front of block b's first row (incl[] = INCLUSIVE scan of counts[]; b = nblocks: everything)
+__global__ __launch_bounds__(kFmtThreads) void fmt_hot_block_starts_kernel(const unsigned long long *__restrict__ incl, const uint32_t *__restrict__ bstart,
+                                                                           uint32_t nblocks, uint32_t row_begin, unsigned long long *__restrict__ out) {
+    const uint32_t b = blockIdx.x * kFmtThreads + threadIdx.x;
+    if (b > nblocks) return;
+    const uint32_t row = bstart[b] - row_begin;
+    out[b] = row ? incl[row - 1u] : 0ull;
+}
+// every field of the unit's elements starts as padding -- the table's identity slot, the lane's dummy row slot -- and the unit's
+// third descriptor; one workgroup per unit
+__global__ __launch_bounds__(kThreads) void fmt_fill_hot_rows_kernel(const UnitDesc *__restrict__ units, unsigned char *__restrict__ hot, uint32_t nhot_table,
+                                                                     uint4 *__restrict__ plan_units) {
+    const UnitDesc u = units[blockIdx.x];
+    const uint32_t nrows = u.nrows_direct & 0xffffu, pad0 = nrows + kHubSlots * u.nhub;
+    const uint32_t ident = nhot_table | (nhot_table << 16);
+    for (uint32_t i = threadIdx.x; i < u.nhot_groups * 64u; i += kThreads) {     // (nhot_groups: the unit's hot ELEMENTS here)
+        uint4 rec = make_uint4(ident, ident, ident, (nhot_table & 0xffffu) | ((pad0 + (i & 63u)) << 16));
+        reinterpret_cast<uint4 *>(hot + (size_t)u.hot_e0 * kHotElemBytesRows)[i] = rec;
+    }
+    if (threadIdx.x == 0) plan_units[3u * blockIdx.x + 2u] = make_uint4(u.hot_e0, 0u, nhot_table, 0u);
+}
+// a wave per row: the row's hot entries, in CSR order, go to fields 0..6 of its records; record j of a block sits in the unit
+// whose cut [M s / S, M (s + 1) / S) holds j, at lane (j - cut) / chunk of element (j - cut) % chunk (chunk = the unit's elements)
+__global__ __launch_bounds__(kFmtThreads) void fmt_emit_hot_rows_kernel(const uint32_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                                        const uint32_t *__restrict__ data, uint32_t row_begin, uint32_t rows,
+                                                                        uint64_t nz0, uint32_t num_cols, const uint32_t *__restrict__ colmap,
+                                                                        const uint32_t *__restrict__ colbits, const uint32_t *__restrict__ bstart,
+                                                                        uint32_t nblocks, const unsigned long long *__restrict__ incl,
+                                                                        const unsigned long long *__restrict__ block_start,
+                                                                        const uint32_t *__restrict__ seg, const uint32_t *__restrict__ unit_of,
+                                                                        const UnitDesc *__restrict__ units, const uint32_t *__restrict__ hub_rows,
+                                                                        unsigned char *__restrict__ hot) {
+    const uint32_t lane = threadIdx.x & 63u, nwaves = gridDim.x * (kFmtThreads / 64u);
+    for (uint32_t row = blockIdx.x * (kFmtThreads / 64u) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+        const uint32_t r = row_begin + row;
+        const uint64_t s = indptr[row] - nz0, e = indptr[row + 1] - nz0;
+        const unsigned long long before = row ? incl[row - 1u] : 0ull, mine = incl[row] - before;
+        if ((uint32_t)(mine >> 32) == 0u) continue;    // no hot entry in this row
+        uint32_t lo = 0, hi = nblocks - 1u;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (bstart[mid] <= r) lo = mid; else hi = mid - 1u;
+        }
+        const uint32_t b = lo, row_local = r - bstart[b];
+        const uint64_t M = (uint32_t)block_start[b + 1u] - (uint32_t)block_start[b];        // records of the block (low halves)
+        const uint64_t rec0 = (uint32_t)before - (uint32_t)block_start[b];                   // the row's first record within the block
+        const uint32_t S = seg[b];
+        const UnitDesc u0 = units[unit_of[b]];
+        const uint32_t nrows = u0.nrows_direct & 0xffffu;
+        int hub = -1;
+        for (uint32_t k = 0; k < u0.nhub; k++)
+            if (hub_rows[u0.hub_off + k] == row_local) hub = (int)k;
+        uint32_t running = 0;
+        for (uint64_t i0 = s; i0 < e; i0 += 64u) {
+            const uint64_t i = i0 + lane;
+            uint32_t cm = 0;
+            bool is_hot = false;
+            if (i < e) {
+                const uint32_t c = indices[i];
+                if (c < num_cols && !(colbits && c == r && data[i] != colbits[c])) {
+                    cm = colmap[c];
+                    is_hot = (cm >> 31) != 0u;
+                }
+            }
+            const unsigned long long bal = __ballot(is_hot);
+            const uint32_t rank = running + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            running += (uint32_t)__popcll(bal);
+            if (!is_hot) continue;
+            const uint64_t j = rec0 + rank / kHotRecEntries;
+            const uint32_t f = rank % kHotRecEntries;
+            uint64_t guess = S == 1u ? 0u : (j * S + S - 1u) / M;
+            uint32_t sg = (uint32_t)(guess < S ? guess : S - 1u);
+            while (M * sg / S > j) sg--;
+            while (M * (sg + 1u) / S <= j) sg++;
+            const UnitDesc u = units[unit_of[(size_t)sg * nblocks + b]];
+            const uint32_t jj = (uint32_t)(j - M * sg / S), chunk = u.nhot_groups, l = jj / chunk, el = jj % chunk;
+            uint16_t *rec = reinterpret_cast<uint16_t *>(hot + (size_t)(u.hot_e0 + el) * kHotElemBytesRows) + l * 8u;
+            rec[f] = (uint16_t)(cm & 0x7fffffffu);
+            if (f == 0u) rec[7] = (uint16_t)(hub < 0 ? row_local : nrows + kHubSlots * (uint32_t)hub + (l & (kHubSlots - 1u)));
+        }
+    }
+}
+
 // the element of slack behind the stream (the kernel's clamped loads land there, never accumulated): kRowPad in every slot;
 // values start as 0 everywhere
 __global__ void fmt_fill_hot_kernel(uint32_t *hot, size_t elems, uint32_t words_per_elem, uint32_t slot_words) {
@@ -397,8 +505,9 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     const uint32_t nblocks = bp.nblocks, nunits = bp.nunits;
     const uint32_t rows = c->row_end - c->row_begin;
     const uint64_t nnz = c->nnz;
-    const uint32_t hot_groups = e.pattern ? kHotGroupsPattern : kHotGroupsGeneral;
-    const uint32_t hot_elem_bytes = e.pattern ? kHotElemBytesPattern : kHotElemBytesGeneral;
+    const bool hot_rows = e.pattern;     // pattern plans: the row-packed hot stream (hot entries stay out of the sort)
+    const uint32_t hot_groups = hot_rows ? 1u : kHotGroupsGeneral;
+    const uint32_t hot_elem_bytes = hot_rows ? kHotElemBytesRows : kHotElemBytesGeneral;
 
     DevMem d_bstart, d_colmap, d_keys, d_keys2, d_pl, d_pl2, d_off;
     int rc;
@@ -411,7 +520,7 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     GL_HIP(hipMemcpyAsync(d_colmap.p, e.colmap, (size_t)e.num_cols * 4u, hipMemcpyHostToDevice, s));
     fmt_keys_kernel<K><<<wave_grid(rows), kFmtThreads, 0, s>>>(c->d_indptr, c->d_indices, c->d_data, c->row_begin, rows, c->nz0, e.num_cols,
                                                                d_bstart.as<uint32_t>(), nblocks, d_colmap.as<uint32_t>(),
-                                                               e.diag_mode ? c->d_colbits : nullptr, cb, bb, d_keys.as<K>(), d_pl.as<uint2>());
+                                                               e.diag_mode ? c->d_colbits : nullptr, cb, bb, d_keys.as<K>(), d_pl.as<uint2>(), hot_rows);
     GL_LAUNCH_CHECK();
     if ((rc = sort_pairs<K>(d_keys.as<K>(), d_keys2.as<K>(), d_pl.as<uint2>(), d_pl2.as<uint2>(), nnz, bb + cb + 2u, s)) != GL_OK) return rc;
     (void)hipFree(d_keys.p); d_keys.p = nullptr;
@@ -429,9 +538,37 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     hub_count.assign(nblocks, 0u);
     std::vector<UnitDesc> units(nunits);
     uint64_t hn = 0;
-    std::vector<uint64_t> mcs(nblocks), mhs(nblocks);
+    std::vector<uint64_t> mcs(nblocks), mhs(nblocks), mrec(nblocks, 0);
     for (uint32_t b = 0; b < nblocks; b++) mcs[b] = off[2 * b + 1] - off[2 * b], mhs[b] = off[2 * b + 2] - off[2 * b + 1];
-    const UnitLayout ul = layout_units(bp, mcs, mhs, e.dummy_max, hot_groups, e.nhot_table);
+    // ---- row-packed hot stream: hot entries and records per row (a wave per row), ONE scan, the blocks' shares read back
+    DevMem d_rowcnt, d_rowincl, d_blockstart;
+    if (hot_rows) {
+        DevMem d_tmp;
+        if ((rc = d_rowcnt.alloc((size_t)std::max(rows, 1u) * 8u)) != GL_OK || (rc = d_rowincl.alloc((size_t)std::max(rows, 1u) * 8u)) != GL_OK ||
+            (rc = d_blockstart.alloc((size_t)(nblocks + 1u) * 8u)) != GL_OK)
+            return rc;
+        fmt_hot_row_counts_kernel<<<wave_grid(rows), kFmtThreads, 0, s>>>(c->d_indptr, c->d_indices, c->d_data, c->row_begin, rows, c->nz0, e.num_cols,
+                                                                           d_colmap.as<uint32_t>(), e.diag_mode ? c->d_colbits : nullptr,
+                                                                           d_rowcnt.as<unsigned long long>());
+        GL_LAUNCH_CHECK();
+        size_t tmp_bytes = 0;
+        GL_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, d_rowcnt.as<unsigned long long>(), d_rowincl.as<unsigned long long>(), (size_t)rows,
+                                       rocprim::plus<unsigned long long>(), s));
+        if ((rc = d_tmp.alloc(tmp_bytes)) != GL_OK) return rc;
+        GL_HIP(rocprim::inclusive_scan(d_tmp.p, tmp_bytes, d_rowcnt.as<unsigned long long>(), d_rowincl.as<unsigned long long>(), (size_t)rows,
+                                       rocprim::plus<unsigned long long>(), s));
+        fmt_hot_block_starts_kernel<<<cdiv(nblocks + 1u, kFmtThreads), kFmtThreads, 0, s>>>(d_rowincl.as<unsigned long long>(), d_bstart.as<uint32_t>(), nblocks,
+                                                                                            c->row_begin, d_blockstart.as<unsigned long long>());
+        GL_LAUNCH_CHECK();
+        std::vector<unsigned long long> bs(nblocks + 1u);
+        GL_HIP(hipMemcpyAsync(bs.data(), d_blockstart.p, bs.size() * 8u, hipMemcpyDeviceToHost, s));
+        GL_HIP(hipStreamSynchronize(s));   // (d_tmp dies here)
+        for (uint32_t b = 0; b < nblocks; b++) {
+            mhs[b] = (bs[b + 1] >> 32) - (bs[b] >> 32);
+            mrec[b] = (uint64_t)((uint32_t)bs[b + 1] - (uint32_t)bs[b]);
+        }
+    }
+    const UnitLayout ul = layout_units(bp, mcs, mhs, e.dummy_max, hot_groups, e.nhot_table, hot_rows ? &mrec : nullptr);
     const uint64_t total_groups = ul.cold_goff[nunits], hot_elems = ul.hot_e0[nunits];
     if (total_groups >= 0xffffffffull || hot_elems >= 0xffffffffull || ul.present_off[nunits] >= 0xffffffffull)
         return set_error(GL_ERR_UNSUPPORTED, "plan creation: more than 2^32 - 1 groups in a shard");
@@ -456,8 +593,8 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
             UnitDesc &u = units[bp.unit_of[sg][b]];
             u.cold_begin = (uint32_t)(off[2 * b] + mc * sg / S);
             u.cold_end = (uint32_t)(off[2 * b] + mc * (sg + 1) / S);
-            u.hot_begin = (uint32_t)(off[2 * b + 1] + mh * sg / S);
-            u.hot_end = (uint32_t)(off[2 * b + 1] + mh * (sg + 1) / S);
+            u.hot_begin = hot_rows ? 0u : (uint32_t)(off[2 * b + 1] + mh * sg / S);     // (row-packed: no hot entries in the sorted arrays)
+            u.hot_end = hot_rows ? 0u : (uint32_t)(off[2 * b + 1] + mh * (sg + 1) / S);
             const size_t ui = bp.unit_of[sg][b];
             u.goff = (uint32_t)ul.cold_goff[ui];
             u.r0 = r0;
@@ -485,7 +622,7 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     GL_HIP(hipMalloc((void **)&p->d_hub_rows, hub_rows.size() * 4u + 16u));
     // the run-coded hot stream: one element of slack behind it (the kernel's clamped loads), like the host formatter's vectors
     const size_t hot_bytes = (size_t)(hot_elems + 1u) * hot_elem_bytes;
-    const size_t hdr_bytes = (size_t)(hot_elems + 1u) * kHotHdrWordsPerGroup * hot_groups * 4u;
+    const size_t hdr_bytes = hot_rows ? (size_t)32 : (size_t)(hot_elems + 1u) * kHotHdrWordsPerGroup * hot_groups * 4u;   // (rows: no headers)
     const size_t present_bytes = (size_t)std::max<uint64_t>(ul.present_off[nunits], 2u) * 2u;
     GL_HIP(hipMalloc((void **)&p->d_hot, hot_bytes));
     GL_HIP(hipMalloc((void **)&p->d_hot_hdr, hdr_bytes));
@@ -505,7 +642,7 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
     GL_HIP(hipMemsetAsync(p->d_present, 0, present_bytes, s));
     GL_HIP(hipMemsetAsync(p->d_hot, 0, hot_bytes, s));
     fmt_fill_hot_kernel<<<1, 256, 0, s>>>(reinterpret_cast<uint32_t *>(p->d_hot + (size_t)hot_elems * hot_elem_bytes), 1u, hot_elem_bytes / 4u,
-                                          hot_groups * 64u * 2u / 4u);
+                                          hot_rows ? hot_elem_bytes / 4u : hot_groups * 64u * 2u / 4u);
     GL_LAUNCH_CHECK();
     GL_HIP(hipMemsetAsync(p->d_entries, 0, entry_bytes + tail_bytes, s));
     GL_HIP(hipMemsetAsync(p->d_bases, 0, n_bases * 4u, s));
@@ -536,6 +673,29 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
         GL_LAUNCH_CHECK();
         GL_HIP(hipStreamSynchronize(s));   // scratch dies here
     }
+    if (hot_rows) {
+        // ---- the row-packed hot stream: padding everywhere, then a wave per row writes its records
+        DevMem d_seg, d_unit_of;
+        std::vector<uint32_t> unit_of_flat((size_t)bp.Smax * nblocks, 0xffffffffu);
+        for (uint32_t sgm = 0; sgm < bp.Smax; sgm++)
+            for (uint32_t b = 0; b < nblocks; b++) unit_of_flat[(size_t)sgm * nblocks + b] = bp.unit_of[sgm][b];
+        if ((rc = d_seg.alloc((size_t)nblocks * 4u)) != GL_OK || (rc = d_unit_of.alloc(unit_of_flat.size() * 4u)) != GL_OK) return rc;
+        GL_HIP(hipMemcpyAsync(d_seg.p, bp.seg.data(), (size_t)nblocks * 4u, hipMemcpyHostToDevice, s));
+        GL_HIP(hipMemcpyAsync(d_unit_of.p, unit_of_flat.data(), unit_of_flat.size() * 4u, hipMemcpyHostToDevice, s));
+        fmt_fill_hot_rows_kernel<<<nunits, kThreads, 0, s>>>(d_units.as<UnitDesc>(), p->d_hot, e.nhot_table, p->d_units);
+        GL_LAUNCH_CHECK();
+        if (e.nhot_table) {
+            fmt_emit_hot_rows_kernel<<<wave_grid(rows), kFmtThreads, 0, s>>>(c->d_indptr, c->d_indices, c->d_data, c->row_begin, rows, c->nz0, e.num_cols,
+                                                                              d_colmap.as<uint32_t>(), e.diag_mode ? c->d_colbits : nullptr,
+                                                                              d_bstart.as<uint32_t>(), nblocks, d_rowincl.as<unsigned long long>(),
+                                                                              d_blockstart.as<unsigned long long>(), d_seg.as<uint32_t>(),
+                                                                              d_unit_of.as<uint32_t>(), d_units.as<UnitDesc>(), p->d_hub_rows, p->d_hot);
+            GL_LAUNCH_CHECK();
+        }
+        GL_HIP(hipStreamSynchronize(s));   // scratch dies here
+        p->nhot_lds = e.nhot_table ? e.nhot_table + 64u : 0u;   // the whole table + the identity slots
+        return GL_OK;
+    }
     // ---- the hot stream: number the runs (one scan over the sorted entries), then a wave per hot group
     {
         DevMem d_flags, d_runs, d_tmp;
@@ -549,12 +709,8 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
         GL_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, d_flags.as<uint32_t>(), d_runs.as<uint32_t>(), (size_t)nnz, rocprim::plus<uint32_t>(), s));
         if ((rc = d_tmp.alloc(tmp_bytes)) != GL_OK) return rc;
         GL_HIP(rocprim::inclusive_scan(d_tmp.p, tmp_bytes, d_flags.as<uint32_t>(), d_runs.as<uint32_t>(), (size_t)nnz, rocprim::plus<uint32_t>(), s));
-        if (e.pattern)
-            fmt_emit_hot_kernel<K, true><<<nunits, kThreads, 0, s>>>(keys, payload, d_runs.as<uint32_t>(), d_units.as<UnitDesc>(), p->d_hub_rows, cb,
-                                                                     p->d_hot, p->d_hot_hdr, p->d_present, p->d_units);
-        else
-            fmt_emit_hot_kernel<K, false><<<nunits, kThreads, 0, s>>>(keys, payload, d_runs.as<uint32_t>(), d_units.as<UnitDesc>(), p->d_hub_rows, cb,
-                                                                      p->d_hot, p->d_hot_hdr, p->d_present, p->d_units);
+        fmt_emit_hot_kernel<K, false><<<nunits, kThreads, 0, s>>>(keys, payload, d_runs.as<uint32_t>(), d_units.as<UnitDesc>(), p->d_hub_rows, cb,
+                                                                  p->d_hot, p->d_hot_hdr, p->d_present, p->d_units);
         GL_LAUNCH_CHECK();
         GL_HIP(hipStreamSynchronize(s));   // scratch dies here
     }

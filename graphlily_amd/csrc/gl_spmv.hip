@@ -168,6 +168,7 @@ template <>
 struct Lay<kLayWide> {
     static constexpr int G = (int)kColdGroupsGeneral;
     static constexpr bool kValues = true;
+    static constexpr bool kHotRows = false;   // run-coded hot stream
     struct E {
         uint2 slots;
         uint32_t deltas;
@@ -240,16 +241,19 @@ struct Lay<kLayQuad> {
         return (k & 1) ? w >> 16 : w & 0xffffu;
     }
     __device__ static float val(const E &, int) { return 0.0f; }
+    // ROW-PACKED hot stream (gl_spmv_plan.h): a lane's 16 bytes are one record -- fields 0..6 the table slots of seven entries
+    // of one row, field 7 the row's slot
+    static constexpr bool kHotRows = true;
     struct H {
         uint4 rows;
     };
-    static constexpr int HG = (int)kHotGroupsPattern;
+    static constexpr int HG = 1;   // (an element is 64 records; no groups, no headers)
     __device__ static H load_hot(const unsigned char *hot, size_t e, uint32_t lane) {
         H h;
-        h.rows = load_stream_nt16(reinterpret_cast<const uint4 *>(hot + e * kHotElemBytesPattern) + lane);
+        h.rows = load_stream_nt16(reinterpret_cast<const uint4 *>(hot + e * kHotElemBytesRows) + lane);
         return h;
     }
-    __device__ static uint32_t hot_slot(const H &h, int k) {
+    __device__ static uint32_t hot_slot(const H &h, int k) {   // field k of the record
         const uint32_t w = (k >> 1) == 0 ? h.rows.x : (k >> 1) == 1 ? h.rows.y : (k >> 1) == 2 ? h.rows.z : h.rows.w;
         return (k & 1) ? w >> 16 : w & 0xffffu;
     }
@@ -272,7 +276,7 @@ struct Lay<kLayQuadKeep> : Lay<kLayQuad> {
     __device__ static E load(const unsigned char *cold, size_t e, uint32_t lane) { return load_cold<true>(cold, e, lane); }
     __device__ static H load_hot(const unsigned char *hot, size_t e, uint32_t lane) {
         H h;
-        h.rows = load_stream_keep16(reinterpret_cast<const uint4 *>(hot + e * kHotElemBytesPattern) + lane);
+        h.rows = load_stream_keep16(reinterpret_cast<const uint4 *>(hot + e * kHotElemBytesRows) + lane);
         return h;
     }
 };
@@ -312,11 +316,13 @@ __device__ __forceinline__ void slot_load(const SpmvArgs &a, const StreamGeom &s
     for (int u = 0; u < UH; u++) {
         const size_t e = (size_t)sg.h0 + min(ih + u * kWaves, sg.nh_last);
         r.eh[u] = LY::load_hot(a.hot, e, lane);
-        const uint32_t *hd = a.hot_hdr + e * (kHotHdrWordsPerGroup * HG);
+        if constexpr (!LY::kHotRows) {
+            const uint32_t *hd = a.hot_hdr + e * (kHotHdrWordsPerGroup * HG);
 #pragma unroll
-        for (int k = 0; k < 2 * HG; k++) r.hm[u][k] = load_const(hd + k);
+            for (int k = 0; k < 2 * HG; k++) r.hm[u][k] = load_const(hd + k);
 #pragma unroll
-        for (int k = 0; k < HG; k++) r.hb[u][k] = load_const(hd + 2 * HG + k);
+            for (int k = 0; k < HG; k++) r.hb[u][k] = load_const(hd + 2 * HG + k);
+        }
     }
 }
 
@@ -358,7 +364,24 @@ __device__ __forceinline__ void slot_accumulate(typename Tile<OP>::T *tile, cons
     constexpr int G = LY::G, HG = LY::HG;
 #pragma unroll
     for (int u = 0; u < UH; u++) {
-        if (r.ih + u * kWaves < sg.nh) {
+        if constexpr (LY::kHotRows) {
+            // one record per lane: seven look-ups (random 4-byte LDS reads, all in flight together), combined in registers, ONE
+            // accumulate for the record's row -- 1/7 of the LDS atomics of an entry-per-lane stream (f64 atomic on random rows:
+            // 24.6 LDS clocks per wavefront instruction, random read: 7.1)
+            if (r.ih + u * kWaves < sg.nh) {
+                float hv[kHotRecEntries];
+#pragma unroll
+                for (int k = 0; k < (int)kHotRecEntries; k++) hv[k] = hot_x[LY::hot_slot(r.eh[u], k)];
+#ifdef GL_ABLATE_ACC
+                asm volatile("" ::"v"(hv[0]), "v"(hv[1]), "v"(hv[2]), "v"(hv[3]), "v"(hv[4]), "v"(hv[5]), "v"(hv[6]), "v"(LY::hot_slot(r.eh[u], 7)));
+#else
+                typename TL::T acc = TL::lift(hv[0]);
+#pragma unroll
+                for (int k = 1; k < (int)kHotRecEntries; k++) acc = TL::comb(acc, TL::lift(hv[k]));
+                TL::accl(tile, LY::hot_slot(r.eh[u], (int)kHotRecEntries), acc);
+#endif
+            }
+        } else if (r.ih + u * kWaves < sg.nh) {
             float hv[HG];
 #pragma unroll
             for (int k = 0; k < HG; k++) {
@@ -478,7 +501,12 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
 
     __shared__ uint32_t next_iter;   // ticket: the first kWaves iterations are taken by wave number
     if (threadIdx.x == 0) next_iter = kWaves;
-    if (UH > 0) {   // the table: the values of the hot columns that occur in this unit, in the unit's slot order
+    if (UH > 0 && LY::kHotRows) {
+        // row-packed hot stream: the plan's whole table under its global slot numbers (one coalesced copy), and behind it the
+        // slot that padding fields name: the semiring's identity
+        for (uint32_t i = threadIdx.x; i < dp.z; i += kThreads) hot_x[i] = a.hot_x[i];
+        if (threadIdx.x < 64u) hot_x[dp.z + threadIdx.x] = TL::zident();
+    } else if (UH > 0) {   // the table: the values of the hot columns that occur in this unit, in the unit's slot order
         const uint16_t *pres = a.present + dp.y;
         if (a.self_hot_cols) {   // short streams: a helper launch in front would cost more than these few scattered reads
             for (uint32_t i = threadIdx.x; i < dp.z; i += kThreads) hot_x[i] = a.x[a.self_hot_cols[pres[i]]];
@@ -1125,7 +1153,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         // as many columns as fit next to the tallest tile, in steps of 1024, at most 32 K
         uint32_t room = 0;
         if (tile_bytes + 4096u <= gl::kLdsBudget)
-            room = std::min<uint32_t>(1u << 15, (uint32_t)((gl::kLdsBudget - tile_bytes) / 4u / 1024u * 1024u));
+            room = std::min<uint32_t>(1u << 15, (uint32_t)((gl::kLdsBudget - tile_bytes - 256u) / 4u / 1024u * 1024u));   // (- the 64 identity slots)
         uint32_t H = room;
         // Round 4, same-box sweeps of the table size (profiles/r04_small_graph_ab.txt): with the packed gather vector ordered by
         // degree class the popular columns are cheap to gather anyway, and the table has a price per workgroup (its copy in the
@@ -1273,9 +1301,12 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     const uint32_t cold_elem_bytes = pattern ? gl::kColdElemBytesPattern : gl::kColdElemBytesGeneral;
     // dummy entries bridge gaps of more than 255 columns, 255 at a time: a unit's indices span at most the gather vector
     const uint32_t dummy_max = gather_cols / gl::kColdMaxDelta + 1u;
-    const uint32_t hot_groups = pattern ? gl::kHotGroupsPattern : gl::kHotGroupsGeneral;
-    const uint32_t hot_elem_bytes = pattern ? gl::kHotElemBytesPattern : gl::kHotElemBytesGeneral;
-    const uint32_t hot_hdr_words = gl::kHotHdrWordsPerGroup * hot_groups;
+    // pattern plans carry the ROW-PACKED hot stream (gl_spmv_plan.h): an element = 64 records of 7 table slots + a row slot, no
+    // headers, no present lists; general plans the run-coded one
+    const bool hot_rows = pattern;
+    const uint32_t hot_groups = hot_rows ? 1u : gl::kHotGroupsGeneral;
+    const uint32_t hot_elem_bytes = hot_rows ? gl::kHotElemBytesRows : gl::kHotElemBytesGeneral;
+    const uint32_t hot_hdr_words = hot_rows ? 0u : gl::kHotHdrWordsPerGroup * hot_groups;
 
     std::vector<unsigned char> entries;   // cold elements
     std::vector<uint32_t> bases;
@@ -1318,19 +1349,23 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         total_groups = p->ngroups;
     } else {
     // ---- pass 1: cold / hot entries per block, from which every unit's place in the arrays follows (layout_units)
-    std::vector<uint64_t> mc(nblocks, 0), mh(nblocks, 0);
+    std::vector<uint64_t> mc(nblocks, 0), mh(nblocks, 0), mrec(nblocks, 0);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t b = 0; b < (int64_t)nblocks; b++) {
-        uint64_t nc = 0, nh = 0;
+        uint64_t nc = 0, nh = 0, nrec = 0;
         bool bad = false;
-        for (uint32_t r = bstart[b]; r < bstart[b + 1]; r++)
+        for (uint32_t r = bstart[b]; r < bstart[b + 1]; r++) {
+            uint64_t hr = 0;
             for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
                 const uint32_t c = h_indices[i];
                 if (c >= num_cols) { bad = true; continue; }
                 if (diag_mode && c == r && __builtin_bit_cast(uint32_t, h_data[i]) != colbits[c]) continue;
-                if (have_hot && hot_slot[c] != 0xffffffffu) nh++; else nc++;
+                if (have_hot && hot_slot[c] != 0xffffffffu) hr++; else nc++;
             }
-        mc[b] = nc, mh[b] = nh;
+            nh += hr;
+            nrec += (hr + gl::kHotRecEntries - 1u) / gl::kHotRecEntries;   // row-packed hot stream: records of <= 7 entries of one row
+        }
+        mc[b] = nc, mh[b] = nh, mrec[b] = nrec;
         if (bad) {
 #pragma omp atomic write
             bad_col = 1;
@@ -1340,7 +1375,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         gl_spmv_plan_destroy(p);
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_spmv_plan_create: column index out of range (num_cols %u)", num_cols);
     }
-    const gl::UnitLayout ul = gl::layout_units(bp, mc, mh, dummy_max, hot_groups, nhot_table);
+    const gl::UnitLayout ul = gl::layout_units(bp, mc, mh, dummy_max, hot_groups, nhot_table, hot_rows ? &mrec : nullptr);
     total_groups = ul.cold_goff[nunits];
     const uint64_t hot_elems = ul.hot_e0[nunits];
     GL_ARG(total_groups < 0xffffffffull && hot_elems < 0xffffffffull && ul.present_off[nunits] < 0xffffffffull);
@@ -1353,14 +1388,15 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     hot_bytes.assign((size_t)(hot_elems + 1) * hot_elem_bytes, 0);
     {
         uint16_t *rows16 = reinterpret_cast<uint16_t *>(hot_bytes.data() + (size_t)hot_elems * hot_elem_bytes);
-        for (uint32_t k = 0; k < 64u * hot_groups; k++) rows16[k] = (uint16_t)gl::kRowPad;
+        for (uint32_t k = 0; k < (hot_rows ? hot_elem_bytes / 2u : 64u * hot_groups); k++) rows16[k] = (uint16_t)gl::kRowPad;
     }
-    hot_hdr.assign((size_t)(hot_elems + 1) * hot_hdr_words, 0u);
+    hot_hdr.assign(hot_rows ? (size_t)8 : (size_t)(hot_elems + 1) * hot_hdr_words, 0u);
     present.assign((size_t)std::max<uint64_t>(ul.present_off[nunits], 2u), 0);
     uint32_t max_present = 0;
 #pragma omp parallel reduction(+ : hot_nnz) reduction(max : max_present)
     {
         std::vector<gl::Rec> recs, tmp, hot;
+        std::vector<uint64_t> rec_of_hot;      // row-packed hot stream: the block's record each hot entry belongs to
 #pragma omp for schedule(dynamic, 1)
         for (int64_t b = 0; b < (int64_t)nblocks; b++) {
             const uint32_t r0 = bstart[b], r1 = bstart[b + 1];
@@ -1375,7 +1411,8 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
                     else recs.push_back(gl::Rec{compact ? cmap[c] : c, r - r0, v});
                 }
             gl::sort_by_col(recs, tmp, gather_cols);
-            gl::sort_by_col(hot, tmp, nhot_table ? nhot_table : 1u);   // by slot: a column's entries form a run
+            if (!hot_rows) gl::sort_by_col(hot, tmp, nhot_table ? nhot_table : 1u);   // by slot: a column's entries form a run
+            // (row-packed stream: `hot` stays as it was collected -- rows ascending, a row's entries in CSR order)
             hot_nnz += hot.size();
             const uint64_t mcb = recs.size(), m = mcb + hot.size();
             // hub rows: a large share of the block's entries (=> several lanes of every step on one LDS word)
@@ -1442,6 +1479,47 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
                 }
                 const uint64_t g = goff + q / 64;
                 const uint32_t ncold = (uint32_t)(g - goff);
+                if (hot_rows) {
+                    // ---- the unit's hot entries, ROW-PACKED (gl_spmv_plan.h): the block's records -- <= 7 entries of one row
+                    //      each, rows ascending -- are cut into the block's units by position; a unit's records are dealt to the
+                    //      lanes in 64 contiguous chunks: element e, lane l = record l * chunk + e
+                    const uint64_t M = mrec[b], j0 = M * s / S, j1 = M * (s + 1) / S, e0 = ul.hot_e0[u];
+                    const uint32_t nel = (uint32_t)(ul.hot_e0[u + 1] - e0), count = (uint32_t)(j1 - j0), chunk = nel;
+                    for (uint32_t e = 0; e < nel; e++) {      // every field starts as padding: the identity slot, the lane's dummy row
+                        uint16_t *el = reinterpret_cast<uint16_t *>(hot_bytes.data() + (size_t)(e0 + e) * hot_elem_bytes);
+                        for (uint32_t l = 0; l < 64u; l++) {
+                            for (uint32_t k = 0; k < gl::kHotRecEntries; k++) el[l * 8u + k] = (uint16_t)nhot_table;
+                            el[l * 8u + 7u] = (uint16_t)(pad_slot + l);
+                        }
+                    }
+                    // record j of the block = the (j - rec_first[row])-th group of 7 of its row's hot entries: walk the block's
+                    // hot list once, keeping the record counter
+                    if (s == 0) {
+                        rec_of_hot.clear();
+                        uint64_t j = 0;
+                        for (size_t i = 0; i < hot.size();) {
+                            size_t i1 = i;
+                            while (i1 < hot.size() && hot[i1].row_local == hot[i].row_local) i1++;
+                            for (size_t q = i; q < i1; q++) rec_of_hot.push_back(j + (q - i) / gl::kHotRecEntries);
+                            j += (i1 - i + gl::kHotRecEntries - 1u) / gl::kHotRecEntries;
+                            i = i1;
+                        }
+                    }
+                    for (size_t i = 0, f = 0; i < hot.size(); i++) {
+                        const uint64_t j = rec_of_hot[i];
+                        f = (i > 0 && rec_of_hot[i - 1] == j) ? f + 1 : 0;   // field = position inside the record
+                        if (j < j0 || j >= j1) continue;
+                        const uint32_t jj = (uint32_t)(j - j0), l = jj / chunk, e = jj % chunk;
+                        uint16_t *rec = reinterpret_cast<uint16_t *>(hot_bytes.data() + (size_t)(e0 + e) * hot_elem_bytes) + l * 8u;
+                        rec[f] = (uint16_t)hot[i].col;                       // the plan's (global) hot slot
+                        if (f == 0) rec[7] = (uint16_t)slot_of(hot[i], l);   // hub rows: private slot by lane
+                    }
+                    (void)count;
+                    units[3 * u] = make_uint4((uint32_t)goff, ncold, r0, (r1 - r0) | (all_direct ? 0x80000000u : 0u));
+                    units[3 * u + 1] = make_uint4((uint32_t)((size_t)b * gl::kMaxHubRows), hub_count[b], nel, s);
+                    units[3 * u + 2] = make_uint4((uint32_t)e0, 0u, nhot_table, 0u);
+                    continue;
+                }
                 // ---- the unit's hot entries, run-coded (gl_spmv_plan.h)
                 const uint64_t h0 = hot.size() * s / S, h1 = hot.size() * (s + 1) / S, e0 = ul.hot_e0[u];
                 uint16_t *pres = present.data() + ul.present_off[u];
@@ -1477,7 +1555,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         }
     }
     p->nhot_elems = hot_elems;
-    p->nhot_lds = (max_present + 63u) / 64u * 64u;
+    p->nhot_lds = hot_rows ? (have_hot ? nhot_table + 64u : 0u) : (max_present + 63u) / 64u * 64u;   // (rows: the whole table + the identity slots)
     }   // host emission
     for (uint32_t b = 0; b < nblocks; b++)
         max_rows = std::max(max_rows, bstart[b + 1] - bstart[b] + gl::kHubSlots * hub_count[b]);   // LDS slots

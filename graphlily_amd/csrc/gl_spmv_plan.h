@@ -61,6 +61,20 @@ constexpr uint32_t kColdElemBytesGeneral = kColdGroupsGeneral * 64u * 7u;   // 5
 constexpr uint32_t kColdElemBytesPattern = kColdGroupsPattern * 64u * 3u;   // 1024 B of slots, 512 B of deltas
 constexpr uint32_t kColdMaxDelta = 255;
 
+// Row-packed hot stream (round 6, PATTERN layout only).  rocprofv3's counters put the pattern kernel's LDS at 75 % busy: an f64
+// atomic of 64 lanes on random rows costs 24.6 LDS clocks (8 conflict-free: 16 lanes per pass over 16 double-width banks, 2 clocks
+// per access), a random 4-byte read 7.1 (scripts/ubench_lds_atomic.hip, profiles/r06_ubench_lds_atomic.txt) -- and a hot entry,
+// whose x comes from the LDS table, needs no column locality at all.  So the pattern layout's hot entries are stored ROW-major:
+// a RECORD = 7 table slots of ONE row + the row's slot, 8 x 16 bits = 16 bytes, one record per lane and element; a lane looks its
+// seven values up, combines them in registers and issues ONE accumulate for the row -- 1/7 of the atomics, no run masks, no
+// headers, no per-unit slot numbering (table slots are the plan's global hot slots; the table's slot nhot holds the semiring's
+// identity: padding fields of a row's last record name it).  A unit's records are listed by (row, CSR order) and dealt to the lanes
+// in 64 contiguous CHUNKS -- element e, lane l = record l * chunk + e -- so that the lanes of one step hold rows that lie far apart
+// (a row with more records than a chunk is a hub row, spread over its private slots by lane).  2.29 B per entry + the padding
+// (~3 fields per row and block) instead of 2.19.  The general layout keeps the run-coded stream: it is bound by its HBM traffic.
+constexpr uint32_t kHotRecEntries = 7;                     // table slots per record
+constexpr uint32_t kHotElemBytesRows = 64u * 16u;          // one 16-byte record per lane
+
 constexpr uint32_t kHotGroupsGeneral = 4, kHotGroupsPattern = 8;
 constexpr uint32_t kHotElemBytesGeneral = kHotGroupsGeneral * 64u * 6u;   // 512 B of row slots, then 1024 B of values
 constexpr uint32_t kHotElemBytesPattern = kHotGroupsPattern * 64u * 2u;   // 1024 B of row slots
@@ -115,8 +129,10 @@ struct UnitLayout {
     std::vector<uint64_t> hot_e0;         // nunits + 1: first hot element
     std::vector<uint64_t> present_off;    // nunits + 1: first entry of the unit's present list (16-bit entries, even offsets)
 };
+// (mrec != nullptr: the row-packed hot stream -- mrec[b] = records of block b, cut into the block's units by position; an element
+//  holds 64 records, no present lists)
 inline UnitLayout layout_units(const BlockPlan &bp, const std::vector<uint64_t> &mc, const std::vector<uint64_t> &mh, uint32_t dummy_max,
-                               uint32_t hot_groups, uint32_t nhot_table) {
+                               uint32_t hot_groups, uint32_t nhot_table, const std::vector<uint64_t> *mrec = nullptr) {
     UnitLayout ul;
     ul.cold_goff.assign((size_t)bp.nunits + 1, 0);
     ul.hot_e0.assign((size_t)bp.nunits + 1, 0);
@@ -127,8 +143,14 @@ inline UnitLayout layout_units(const BlockPlan &bp, const std::vector<uint64_t> 
             const size_t u = bp.unit_of[s][b];
             const uint64_t c = mc[b] * (s + 1) / S - mc[b] * s / S, h = mh[b] * (s + 1) / S - mh[b] * s / S;
             ul.cold_goff[u + 1] = c ? ((c + dummy_max + 63) / 64 + 7u) / 8u * 8u : 0u;
-            ul.hot_e0[u + 1] = ((h + 63) / 64 + hot_groups - 1u) / hot_groups;
-            ul.present_off[u + 1] = (std::min<uint64_t>(h, nhot_table) + 1u) / 2u * 2u;
+            if (mrec) {
+                const uint64_t rc = (*mrec)[b] * (s + 1) / S - (*mrec)[b] * s / S;
+                ul.hot_e0[u + 1] = (rc + 63) / 64;
+                ul.present_off[u + 1] = 0;
+            } else {
+                ul.hot_e0[u + 1] = ((h + 63) / 64 + hot_groups - 1u) / hot_groups;
+                ul.present_off[u + 1] = (std::min<uint64_t>(h, nhot_table) + 1u) / 2u * 2u;
+            }
         }
     }
     for (size_t u = 0; u < bp.nunits; u++) {
@@ -226,7 +248,7 @@ struct EmitGeneral {   // what the host planner decided (gl_spmv_plan_create_ex)
     bool diag_mode;                    // diagonal entries that differ from their column's value are dropped
     const uint32_t *colbits;           // host copy of the column values (diag_mode)
     const uint32_t *diag_has;          // host bitmap of the rows whose diagonal entry is an exception (diag_mode)
-    bool pattern, wide;
+    bool pattern, wide;                // (pattern plans carry the ROW-PACKED hot stream)
     uint32_t group_mult;
     uint32_t hub_div;
     const uint32_t *h_indptr;          // host indptr (global), for the per-row counts

@@ -26,6 +26,9 @@ struct Tile<GL_OP_MULADD> {
         __hip_atomic_fetch_add(&t[r], (T)z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __device__ static T comb(T x, T y) { return x + y; }
+    // a partial result formed in registers (the row-packed hot stream: comb() of a record's lifted table values) into row r
+    __device__ static void accl(T *t, uint32_t r, T v) { __hip_atomic_fetch_add(&t[r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ static float zident() { return 0.0f; }   // the z whose lift() is comb()'s identity (padding table slot)
     __device__ static float get(const T *t, uint32_t r) { return (float)t[r]; }
     __device__ static float init(float zero) { return zero; }
     __device__ static float finish(float zero, float s) { return zero + s; }
@@ -43,6 +46,10 @@ struct Tile<GL_OP_ANDOR> {
         if (z != 0.0f) t[r] = 1.0f;
     }
     __device__ static T comb(T x, T y) { return (x != 0.0f || y != 0.0f) ? 1.0f : 0.0f; }
+    __device__ static void accl(T *t, uint32_t r, T v) {
+        if (v != 0.0f) t[r] = 1.0f;
+    }
+    __device__ static float zident() { return 0.0f; }
     __device__ static float get(const T *t, uint32_t r) { return t[r]; }
     __device__ static float init(float zero) { return zero != 0.0f ? 1.0f : 0.0f; }
     __device__ static float finish(float zero, float s) { return (zero != 0.0f || s != 0.0f) ? 1.0f : 0.0f; }
@@ -64,6 +71,8 @@ struct Tile<GL_OP_ADDMIN> {
     __device__ static T lift(float z) { return z; }
     __device__ static void accz(T *t, uint32_t r, float z) { atomic_min_f32_as_int(&t[r], z); }
     __device__ static T comb(T x, T y) { return (y < x) ? y : x; }
+    __device__ static void accl(T *t, uint32_t r, T v) { atomic_min_f32_as_int(&t[r], v); }
+    __device__ static float zident() { return __builtin_inff(); }
     __device__ static float get(const T *t, uint32_t r) { return t[r]; }
     __device__ static float init(float zero) { return zero; }
     __device__ static float finish(float zero, float s) { return (s < zero) ? s : zero; }
@@ -82,6 +91,8 @@ struct Tile<kOpU32MulAdd> {
         __hip_atomic_fetch_add(&t[r], fbits(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __device__ static T comb(T x, T y) { return x + y; }
+    __device__ static void accl(T *t, uint32_t r, T v) { __hip_atomic_fetch_add(&t[r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ static float zident() { return bitsf(0u); }
     __device__ static float get(const T *t, uint32_t r) { return bitsf(t[r]); }
     __device__ static float init(float zero) { return zero; }
     __device__ static float finish(float zero, float s) { return bitsf(fbits(zero) + fbits(s)); }
@@ -102,6 +113,8 @@ struct Tile<kOpFixMulAdd> {
         __hip_atomic_fetch_add(&t[r], (T)fbits(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __device__ static T comb(T x, T y) { return x + y; }
+    __device__ static void accl(T *t, uint32_t r, T v) { __hip_atomic_fetch_add(&t[r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ static float zident() { return bitsf(0u); }
     __device__ static float get(const T *t, uint32_t r) { return bitsf(t[r] > 0xffffffffull ? 0xffffffffu : (uint32_t)t[r]); }
     __device__ static float init(float zero) { return zero; }
     __device__ static float finish(float zero, float s) { return bitsf(sat_add_u32(fbits(zero), fbits(s))); }
@@ -119,6 +132,10 @@ struct TileBitsAndOr {
         if (fbits(z) != 0u) t[r] = ONE;
     }
     __device__ static T comb(T x, T y) { return (x | y) ? ONE : 0u; }
+    __device__ static void accl(T *t, uint32_t r, T v) {
+        if (v) t[r] = ONE;
+    }
+    __device__ static float zident() { return bitsf(0u); }
     __device__ static float get(const T *t, uint32_t r) { return bitsf(t[r]); }
     __device__ static float init(float zero) { return bitsf(fbits(zero) != 0u ? ONE : 0u); }
     __device__ static float finish(float zero, float s) { return bitsf((fbits(zero) | fbits(s)) ? ONE : 0u); }
@@ -140,6 +157,8 @@ struct TileBitsAddMin {
         __hip_atomic_fetch_min(&t[r], fbits(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __device__ static T comb(T x, T y) { return min(x, y); }
+    __device__ static void accl(T *t, uint32_t r, T v) { __hip_atomic_fetch_min(&t[r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ static float zident() { return bitsf(0xffffffffu); }
     __device__ static float get(const T *t, uint32_t r) { return bitsf(t[r]); }
     __device__ static float init(float zero) { return zero; }
     __device__ static float finish(float zero, float s) { return bitsf(min(fbits(zero), fbits(s))); }

@@ -32,5 +32,8 @@ ref_tests)     # the reference's own acceptance suites, unmodified, float + ufix
 pytest)        # pytest -m gpu on the files / -k expression given
   timeout 3000 python -m pytest -m gpu -x -q "$@" 2>&1 | tail -15 | tee gpurun_out/r06_pytest_last.txt
   ;;
-*) echo "cases: two_wg pmc_pattern lds_atomic ref_tests pytest"; exit 1;;
+ab)            # same-box A/B: GRAPHS / FLAGS as in scripts/ab_variants.sh; arguments = variants (scripts/_variants/<name>.so, or cur[=KNOBS])
+  bash scripts/ab_variants.sh "$@" 2>&1 | tee gpurun_out/r06_ab_${AB_NAME:-last}.txt
+  ;;
+*) echo "cases: two_wg pmc_pattern lds_atomic ref_tests pytest ab"; exit 1;;
 esac
