@@ -63,6 +63,7 @@ struct SpmvArgs {
     const uint32_t *hub_rows; // row_in_block of every hub row, per block
     const float *hot_x;       // x[hot_cols[k]], gathered once per run by the helper kernel
     uint32_t nhot;            // LDS table length: the longest present list, multiple of 64
+    uint32_t tile_bytes;      // LDS bytes of the accumulator tile in front of the table (multiple of 16)
     const unsigned char *hot; // run-coded hot elements (gl_spmv_plan.h)
     const uint32_t *hot_hdr;  // per element: HG x {mask lo, mask hi}, HG x base
     const uint16_t *present;  // per unit: the slots of hot_x that occur in it, ascending
@@ -161,6 +162,23 @@ __device__ __forceinline__ uint32_t wave_scan_pairs(uint32_t v) {
     return v;
 }
 
+// SDWA forms the compiler does not pick on its own (it extracts the 16-bit half with v_and / v_bfe and then shifts or adds with a
+// VOP3 instruction: two instructions where one does): half H (0 low, 1 high) of w, shifted left / added to a scalar
+template <int H>
+__device__ __forceinline__ uint32_t half_shl(uint32_t w, uint32_t sh) {
+    uint32_t r;
+    if (H == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(sh), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(sh), "v"(w));
+    return r;
+}
+template <int H>
+__device__ __forceinline__ uint32_t half_add(uint32_t w, uint32_t scalar) {
+    uint32_t r;
+    if (H == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(r) : "v"(w), "s"(scalar));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(r) : "v"(w), "s"(scalar));
+    return r;
+}
+
 template <int L>
 struct Lay;
 
@@ -184,11 +202,17 @@ struct Lay<kLayWide> {
         return c;
     }
     __device__ static E load(const unsigned char *cold, size_t e, uint32_t lane) { return load_cold<false>(cold, e, lane); }
-    // offs[k] = gather index of this lane's entry of group k, relative to the group's base
-    __device__ static void offsets(const E &c, uint32_t (&offs)[G]) {
-        const uint32_t a = wave_scan_pairs(c.deltas & 0x00ff00ffu), b = wave_scan_pairs((c.deltas >> 8) & 0x00ff00ffu);
-        offs[0] = a & 0xffffu, offs[2] = a >> 16, offs[1] = b & 0xffffu, offs[3] = b >> 16;
+    // offs[k] = BYTE offset (4 x gather index) of this lane's entry of group k, relative to the group's base: the deltas are scaled
+    // by the masks that unpack them (63 x 255 x 4 < 2^16: still no carry between the halves), so that the gather needs no shift --
+    // a 32-bit offset next to the vector's scalar base address
+    // (pk[j]: two groups' prefix sums in one register -- group k sits in pk[k & 1], half k >> 1)
+    __device__ static void offsets(const E &c, uint32_t (&pk)[G / 2]) {
+        pk[0] = wave_scan_pairs((c.deltas << 2) & 0x03fc03fcu), pk[1] = wave_scan_pairs((c.deltas >> 6) & 0x03fc03fcu);
     }
+    __device__ static uint32_t gather_off(const uint32_t (&pk)[G / 2], int k, uint32_t base4) {   // base4 + the lane's offset of group k
+        return (k >> 1) ? half_add<1>(pk[k & 1], base4) : half_add<0>(pk[k & 1], base4);
+    }
+    __device__ static uint32_t slot_w(const E &c, int k) { return k < 2 ? c.slots.x : c.slots.y; }   // group k's slot: half k & 1 of this word
     __device__ static uint32_t slot(const E &c, int k) {
         const uint32_t w = k < 2 ? c.slots.x : c.slots.y;
         return (k & 1) ? w >> 16 : w & 0xffffu;
@@ -206,6 +230,7 @@ struct Lay<kLayWide> {
         h.vals = load_stream_nt16(reinterpret_cast<const uint4 *>(p + 512) + lane);
         return h;
     }
+    __device__ static uint32_t hot_slot_w(const H &h, int k) { return k < 2 ? h.rows.x : h.rows.y; }
     __device__ static uint32_t hot_slot(const H &h, int k) {
         const uint32_t w = k < 2 ? h.rows.x : h.rows.y;
         return (k & 1) ? w >> 16 : w & 0xffffu;
@@ -230,12 +255,16 @@ struct Lay<kLayQuad> {
         return c;
     }
     __device__ static E load(const unsigned char *cold, size_t e, uint32_t lane) { return load_cold<false>(cold, e, lane); }
-    __device__ static void offsets(const E &c, uint32_t (&offs)[G]) {
-        const uint32_t a = wave_scan_pairs(c.deltas.x & 0x00ff00ffu), b = wave_scan_pairs((c.deltas.x >> 8) & 0x00ff00ffu);
-        const uint32_t d = wave_scan_pairs(c.deltas.y & 0x00ff00ffu), f = wave_scan_pairs((c.deltas.y >> 8) & 0x00ff00ffu);
-        offs[0] = a & 0xffffu, offs[2] = a >> 16, offs[1] = b & 0xffffu, offs[3] = b >> 16;
-        offs[4] = d & 0xffffu, offs[6] = d >> 16, offs[5] = f & 0xffffu, offs[7] = f >> 16;
+    // (byte offsets: see Lay<kLayWide>; group k sits in pk[2 (k >> 2) + (k & 1)], half (k >> 1) & 1)
+    __device__ static void offsets(const E &c, uint32_t (&pk)[G / 2]) {
+        pk[0] = wave_scan_pairs((c.deltas.x << 2) & 0x03fc03fcu), pk[1] = wave_scan_pairs((c.deltas.x >> 6) & 0x03fc03fcu);
+        pk[2] = wave_scan_pairs((c.deltas.y << 2) & 0x03fc03fcu), pk[3] = wave_scan_pairs((c.deltas.y >> 6) & 0x03fc03fcu);
     }
+    __device__ static uint32_t gather_off(const uint32_t (&pk)[G / 2], int k, uint32_t base4) {
+        const uint32_t w = pk[2 * (k >> 2) + (k & 1)];
+        return ((k >> 1) & 1) ? half_add<1>(w, base4) : half_add<0>(w, base4);
+    }
+    __device__ static uint32_t slot_w(const E &c, int k) { return (k >> 1) == 0 ? c.slots.x : (k >> 1) == 1 ? c.slots.y : (k >> 1) == 2 ? c.slots.z : c.slots.w; }
     __device__ static uint32_t slot(const E &c, int k) {
         const uint32_t w = (k >> 1) == 0 ? c.slots.x : (k >> 1) == 1 ? c.slots.y : (k >> 1) == 2 ? c.slots.z : c.slots.w;
         return (k & 1) ? w >> 16 : w & 0xffffu;
@@ -253,6 +282,7 @@ struct Lay<kLayQuad> {
         h.rows = load_stream_nt16(reinterpret_cast<const uint4 *>(hot + e * kHotElemBytesRows) + lane);
         return h;
     }
+    __device__ static uint32_t hot_slot_w(const H &h, int k) { return (k >> 1) == 0 ? h.rows.x : (k >> 1) == 1 ? h.rows.y : (k >> 1) == 2 ? h.rows.z : h.rows.w; }
     __device__ static uint32_t hot_slot(const H &h, int k) {   // field k of the record
         const uint32_t w = (k >> 1) == 0 ? h.rows.x : (k >> 1) == 1 ? h.rows.y : (k >> 1) == 2 ? h.rows.z : h.rows.w;
         return (k & 1) ? w >> 16 : w & 0xffffu;
@@ -285,6 +315,17 @@ struct Lay<kLayQuadKeep> : Lay<kLayQuad> {
 // NEXT slot's stream loads in flight while this slot gathers and accumulates.  Every load is unconditional -- indices clamp to
 // the stream's last element and the plan pads its arrays by one element -- because conditional loads make the compiler
 // serialise them with s_waitcnt vmcnt(0); out-of-range elements are dropped at the accumulate.
+// accumulator `byte_off` bytes into the tile (byte_off = slot x sizeof(T), formed by ONE SDWA shift of the entry's 16-bit slot)
+template <int OP>
+constexpr uint32_t kTileShift = sizeof(typename Tile<OP>::T) == 8 ? 3u : 2u;
+// (the tile starts at LDS address 0 -- the kernel has no static LDS and checks it once -- so the byte offset IS the LDS address:
+//  formed from an integer the accumulate needs no base-address add either)
+template <int OP>
+__device__ __forceinline__ typename Tile<OP>::T *slot_ptr(typename Tile<OP>::T *, uint32_t byte_off) {
+    typedef __attribute__((address_space(3))) typename Tile<OP>::T LdsT;
+    return (typename Tile<OP>::T *)(LdsT *)(uintptr_t)byte_off;
+}
+
 struct StreamGeom {
     uint32_t g0, c0, nc, nc_last, h0, nh, nh_last;
 };
@@ -310,7 +351,8 @@ __device__ __forceinline__ void slot_load(const SpmvArgs &a, const StreamGeom &s
         const uint32_t ei = min(ic + u * kWaves, sg.nc_last);
         r.ec[u] = LY::load(a.entries, (size_t)sg.c0 + ei, lane);
 #pragma unroll
-        for (int k = 0; k < G; k++) r.bc[u][k] = load_const(a.bases + sg.g0 + G * ei + k);
+        for (int k = 0; k < G; k++)   // (byte offsets: gather indices < 2^30; shifted on the scalar unit)
+            r.bc[u][k] = __builtin_amdgcn_readfirstlane(load_const(a.bases + sg.g0 + G * ei + k) << 2);
     }
 #pragma unroll
     for (int u = 0; u < UH; u++) {
@@ -333,19 +375,21 @@ __device__ __forceinline__ void slot_gather(const float *xsrc, const SlotRegs<L,
     constexpr int G = LY::G;
 #pragma unroll
     for (int u = 0; u < UC; u++) {
-        uint32_t offs[G];
+        uint32_t pk[G / 2];
 #ifdef GL_ABLATE_SCAN      // scratch A/B builds (scripts/build_variant.sh WORK <name> -DGL_ABLATE_...): what does each part of the step cost?
 #pragma unroll
-        for (int k = 0; k < G; k++) offs[k] = 0u;
+        for (int k = 0; k < G / 2; k++) pk[k] = 0u;
 #else
-        LY::offsets(r.ec[u], offs);          // the lanes' gather indices relative to their groups' bases: prefix sums of the deltas
+        LY::offsets(r.ec[u], pk);            // the lanes' byte offsets relative to their groups' bases: prefix sums of the (scaled) deltas
 #endif
 #pragma unroll
         for (int k = 0; k < G; k++) {
+            const uint32_t off = LY::gather_off(pk, k, r.bc[u][k]);   // one SDWA add: the group's half of the packed sums + its scalar base
 #ifdef GL_ABLATE_GATHER
-            xc[u][k] = __uint_as_float(r.bc[u][k] + offs[k]);
+            xc[u][k] = __uint_as_float(off);
 #else
-            xc[u][k] = xsrc[r.bc[u][k] + offs[k]];
+            // (scalar base address + 32-bit byte offset: the load's saddr form, no 64-bit address arithmetic per lane)
+            xc[u][k] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xsrc) + off);
 #endif
         }
     }
@@ -378,7 +422,7 @@ __device__ __forceinline__ void slot_accumulate(typename Tile<OP>::T *tile, cons
                 typename TL::T acc = TL::lift(hv[0]);
 #pragma unroll
                 for (int k = 1; k < (int)kHotRecEntries; k++) acc = TL::comb(acc, TL::lift(hv[k]));
-                TL::accl(tile, LY::hot_slot(r.eh[u], (int)kHotRecEntries), acc);
+                TL::accl(slot_ptr<OP>(tile, half_shl<1>(r.eh[u].rows.w, kTileShift<OP>)), 0u, acc);   // (field 7: the row's slot)
 #endif
             }
         } else if (r.ih + u * kWaves < sg.nh) {
@@ -394,8 +438,10 @@ __device__ __forceinline__ void slot_accumulate(typename Tile<OP>::T *tile, cons
 #ifdef GL_ABLATE_ACC
                 asm volatile("" ::"v"(LY::hot_slot(r.eh[u], k)), "v"(LY::hot_val(r.eh[u], k)), "v"(hv[k]));
 #else
-                if (LY::kValues) TL::acc(tile, LY::hot_slot(r.eh[u], k), LY::hot_val(r.eh[u], k), hv[k]);
-                else TL::accz(tile, LY::hot_slot(r.eh[u], k), hv[k]);
+                typename TL::T *at = slot_ptr<OP>(tile, (k & 1) ? half_shl<1>(LY::hot_slot_w(r.eh[u], k), kTileShift<OP>)
+                                                                : half_shl<0>(LY::hot_slot_w(r.eh[u], k), kTileShift<OP>));
+                if (LY::kValues) TL::acc(at, 0u, LY::hot_val(r.eh[u], k), hv[k]);
+                else TL::accz(at, 0u, hv[k]);
 #endif
             }
         }
@@ -408,8 +454,11 @@ __device__ __forceinline__ void slot_accumulate(typename Tile<OP>::T *tile, cons
 #ifdef GL_ABLATE_ACC
                 asm volatile("" ::"v"(LY::slot(r.ec[u], k)), "v"(LY::val(r.ec[u], k)), "v"(xc[u][k]));
 #else
-                if (LY::kValues) TL::acc(tile, LY::slot(r.ec[u], k), LY::val(r.ec[u], k), xc[u][k]);
-                else TL::accz(tile, LY::slot(r.ec[u], k), xc[u][k]);
+                // the accumulator's address: the tile starts at LDS address 0, so it is the 16-bit slot shifted -- one SDWA shift
+                typename TL::T *at = slot_ptr<OP>(tile, (k & 1) ? half_shl<1>(LY::slot_w(r.ec[u], k), kTileShift<OP>)
+                                                                : half_shl<0>(LY::slot_w(r.ec[u], k), kTileShift<OP>));
+                if (LY::kValues) TL::acc(at, 0u, LY::val(r.ec[u], k), xc[u][k]);
+                else TL::accz(at, 0u, xc[u][k]);
 #endif
             }
         }
@@ -434,7 +483,7 @@ __device__ __forceinline__ uint32_t spmv_phase(const SpmvArgs &a, typename Tile<
     if (it >= n) return it;
     auto cold_of = [](uint32_t i) { return i / kWaves * (kWaves * UC) + i % kWaves; };
     auto hot_of = [](uint32_t i) { return i / kWaves * (kWaves * UH) + i % kWaves; };
-    constexpr bool PIPE = Lay<L>::kValues;
+    constexpr bool PIPE = Lay<L>::kValues;   // (round 6, with the header-free row-packed hot stream: still +-1 %, pokec -9 %: profiles/r06_ab_patpipe.txt)
     if (!PIPE) {
         // one slot at a time: its loads, the next slot's ticket (drawn while they are in flight: at the end of the step it would
         // wait for the step's own accumulates -- LDS operations complete in order), gathers, accumulates
@@ -482,8 +531,11 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     using LY = Lay<L>;
     constexpr int G = LY::G, HG = LY::HG;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw, 16));
-    T *tile = reinterpret_cast<T *>(lds_raw + (size_t)a.nhot * 4u);   // nhot is a multiple of 64
+    // the tile first: its base is a compile-time constant, so an accumulate's address is one shift of the 16-bit slot (+ the
+    // instruction's immediate offset); the hot table behind it (a.tile_bytes: multiple of 16)
+    T *tile = reinterpret_cast<T *>(__builtin_assume_aligned(lds_raw, 16));
+    if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)lds_raw) != 0u) __builtin_trap();   // (see slot_ptr)
+    float *hot_x = reinterpret_cast<float *>(__builtin_assume_aligned(lds_raw + a.tile_bytes, 16));
 
     if (a.run_flag && *a.run_flag == 0u) return;
 #if defined(GL_UNIT_CLOCKS)
@@ -499,7 +551,9 @@ __global__ __launch_bounds__(kThreads) void spmv_rbcs_kernel(SpmvArgs a) {
     // wave id as a scalar so that group indices, and with them the base-column loads, stay in SGPRs
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    __shared__ uint32_t next_iter;   // ticket: the first kWaves iterations are taken by wave number
+    // ticket: the first kWaves iterations are taken by wave number.  The word lives BEHIND the table (no static LDS: the tile then
+    // starts at LDS address 0 and an accumulate's address is the 16-bit slot shifted, one SDWA instruction)
+    uint32_t &next_iter = *reinterpret_cast<uint32_t *>(lds_raw + a.tile_bytes + (size_t)a.nhot * 4u);
     if (threadIdx.x == 0) next_iter = kWaves;
     if (UH > 0 && LY::kHotRows) {
         // row-packed hot stream: the plan's whole table under its global slot numbers (one coalesced copy), and behind it the
@@ -761,7 +815,8 @@ static int launch_variant(gl_spmv_plan p, const SpmvArgs &a, size_t lds, hipStre
 
 
 template <int OP, int MASK>
-static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
+static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a_in, hipStream_t s) {
+    SpmvArgs a = a_in;
     const uint32_t rows = p->row_end - p->row_begin;
     if (rows == 0) return GL_OK;
     if (p->nunits == 0) {   // no stored entries in this shard: y = mask(zero)
@@ -792,7 +847,9 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a, hipStream_t s) {
                                                                                                 p->d_xc, p->ncompact, a.run_flag);
         GL_LAUNCH_CHECK();
     }
-    const size_t lds = (size_t)p->nhot_lds * 4u + ((size_t)p->max_block_rows + kPadSlots) * sizeof(typename Tile<OP>::T);   // + the dummy slots
+    const size_t tile_bytes = (((size_t)p->max_block_rows + kPadSlots) * sizeof(typename Tile<OP>::T) + 15u) & ~(size_t)15u;   // + the dummy slots
+    const size_t lds = (size_t)p->nhot_lds * 4u + tile_bytes + 16u;   // (+ the ticket word behind the table)
+    a.tile_bytes = (uint32_t)tile_bytes;
     if (lds > kLdsBudget)
         return set_error(GL_ERR_UNSUPPORTED, "gl_spmv_run: this plan was created with GL_PLAN_NO_MULADD "
                          "(hot-column table sized for 4-byte accumulators); (+,x) needs a plan without it");
@@ -1055,7 +1112,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     GL_REQUIRE_INIT();
     GL_ARG(plan != nullptr && h_indptr != nullptr);
     GL_ARG(row_begin <= row_end && row_end <= num_rows);
-    GL_ARG(num_cols < 0x80000000u);
+    GL_ARG(num_cols < 0x40000000u);   // (the kernels address the gathered vector by 32-bit BYTE offsets)
     const uint64_t nz0 = h_indptr[row_begin], nz1 = h_indptr[row_end];
     GL_ARG(nz1 >= nz0);
     const uint64_t nnz = nz1 - nz0;
@@ -1153,7 +1210,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         // as many columns as fit next to the tallest tile, in steps of 1024, at most 32 K
         uint32_t room = 0;
         if (tile_bytes + 4096u <= gl::kLdsBudget)
-            room = std::min<uint32_t>(1u << 15, (uint32_t)((gl::kLdsBudget - tile_bytes - 256u) / 4u / 1024u * 1024u));   // (- the 64 identity slots)
+            room = std::min<uint32_t>(1u << 15, (uint32_t)((gl::kLdsBudget - tile_bytes - 320u) / 4u / 1024u * 1024u));   // (- the 64 identity slots, the ticket word, rounding)
         uint32_t H = room;
         // Round 4, same-box sweeps of the table size (profiles/r04_small_graph_ab.txt): with the packed gather vector ordered by
         // degree class the popular columns are cheap to gather anyway, and the table has a price per workgroup (its copy in the
