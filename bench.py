@@ -408,7 +408,8 @@ def _ordered(out):
     if fr:
         hl["spmspv_frac_best"], hl["spmspv_frac_worst"] = max(fr), min(fr)
     six = out.get("six_graphs", {})
-    short = {"ogbn_products": "products", "googleplus": "gplus", "ogbl_ppa": "ppa", "orkut_community": "community", "orkut_community_shuffled": "shuffled"}
+    short = {"ogbn_products": "products", "googleplus": "gplus", "ogbl_ppa": "ppa", "orkut_community": "community", "orkut_community_shuffled": "shuffled",
+             "uniform_3M_70": "uniform"}
     rows = {}
     for name, rec in six.items():
         if not isinstance(rec, dict) or "spmv" not in rec:
@@ -501,7 +502,8 @@ def _six_graphs(args, dev, orkut_raw, orkut_iters, headline_bfs=None):
     res, skipped = {}, []
     # ... and the orkut-sized stand-in WITH planted communities, numbered by community and relabelled at random (SpMV lines only):
     # the R-MAT stand-ins have no locality and a fat degree head, these have locality / neither
-    order = ["ogbn_products", "googleplus", "ogbl_ppa", "pokec", "hollywood", "orkut", "orkut_community", "orkut_community_shuffled"]
+    order = ["ogbn_products", "googleplus", "ogbl_ppa", "pokec", "hollywood", "orkut", "orkut_community", "orkut_community_shuffled",
+             "uniform_3M_70"]     # (the last: no degree skew at all -- the layouts' worst case, SpMV lines only)
     for name in order:
         if time.time() - t_start > args.six_graphs_budget:
             skipped.append(name)

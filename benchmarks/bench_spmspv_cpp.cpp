@@ -92,11 +92,29 @@ int main(int argc, char **argv) {
             std::vector<double> sorted(us);
             std::sort(sorted.begin(), sorted.end());
             const double ms = total / num_runs / 1000.0;
+            // ... and the same 20 runs enqueued BACK TO BACK (no completion record awaited per call: what an app loop that does
+            // not need the count on the host pays per iteration -- round 5's verdict), one synchronisation at the end
+            spmspv.set_blocking(false);
+            GRAPHLILY_CHECK(gl_sync());
+            auto b1 = std::chrono::high_resolution_clock::now();
+            for (int i = 0; i < num_runs; i++) spmspv.run();
+            GRAPHLILY_CHECK(gl_sync());
+            auto b2 = std::chrono::high_resolution_clock::now();
+            spmspv.set_blocking(true);
+            const double b2b_ms = std::chrono::duration<double, std::micro>(b2 - b1).count() / num_runs / 1000.0;
+            // bytes the run MOVES per product: the bin + fold path reads a product's {row, value} from the CSC stream, writes it to a
+            // bin and reads it back (24 B); the one-launch kernel of tiny runs reads it once (8 B); a run the operator applied
+            // row-wise streams the attached SpMV plan instead (reported as 0: not a per-product figure)
+            int dir = 0;
+            GRAPHLILY_CHECK(gl_spmspv_last_direction(spmspv.plan_handle(), &dir));
+            const double bpp = dir ? 0.0 : ((cnt <= 1024 && active <= 2048) ? 8.0 : 24.0);
             printf("{\"graph\": \"%s\", \"semiring\": \"%s\", \"caller\": \"C++ module layer\", \"vector_sparsity\": %g, \"vector_nnz\": %u, "
                    "\"active_nnz\": %.0f, \"result_nnz\": %u, \"ms\": %.4f, \"ms_median\": %.4f, \"ms_max\": %.4f, \"gbps\": %.2f, "
-                   "\"gteps\": %.3f, \"verified\": %s}\n",
+                   "\"gteps\": %.3f, \"ms_back_to_back\": %.4f, \"gbps_back_to_back\": %.2f, \"bytes_per_product\": %.0f, "
+                   "\"moved_gbps\": %.2f, \"direction\": \"%s\", \"verified\": %s}\n",
                    name.c_str(), sem.label, sparsity, cnt, active, (unsigned)res[0].index, ms, sorted[num_runs / 2] / 1000.0,
-                   sorted[num_runs - 1] / 1000.0, 8.0 * active / ms / 1e6, active / ms / 1e6, ok ? "true" : "false");
+                   sorted[num_runs - 1] / 1000.0, 8.0 * active / ms / 1e6, active / ms / 1e6, b2b_ms, 8.0 * active / b2b_ms / 1e6, bpp,
+                   bpp * active / ms / 1e6, dir ? "row-wise" : "scatter", ok ? "true" : "false");
             fflush(stdout);
         }
     }

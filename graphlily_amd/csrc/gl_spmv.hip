@@ -1187,6 +1187,55 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     uint32_t tallest = 0;
     for (uint32_t b = 0; b < bp.nblocks; b++) tallest = std::max(tallest, bp.bstart[b + 1] - bp.bstart[b]);
 
+    // ---- pattern plan?  every column's stored values are bitwise equal (unweighted graphs, out-degree
+    //      normalised PageRank matrices, bench_spmv's 1/num_rows): the stream then carries no values
+    std::vector<uint32_t> colbits, diag_has;
+    std::vector<float> diag_val;
+    bool pattern = false, diag_mode = false;
+    if (nnz > 0 && !(flags & GL_PLAN_KEEP_VALUES) && gl::debug_knob("spmv_pattern", 1) != 0) {
+        // Diagonal entries are looked at separately: a matrix that is column-constant apart from its diagonal
+        // (SSSP's unit weights + zero self edges, app/sssp.h:16-62) keeps the pattern layout, the diagonal goes
+        // into a per-row array that the epilogue folds in.
+        int mismatch = 0;
+        uint64_t exceptions = 0;
+        if (on_device) {
+            const int prc = gl::fmt_detect_pattern(staged.c, num_cols, colbits, diag_has, diag_val, &mismatch, &exceptions);
+            if (prc != GL_OK) return prc;
+        } else {
+        colbits.assign(num_cols, 0u);
+        diag_has.assign((size_t)(rows + 31) / 32, 0u);
+        diag_val.assign(rows, 0.0f);
+        // pass 1: any writer wins (all of a column's writers agree if the column is constant); pass 2 verifies
+#pragma omp parallel for schedule(static, 4096)
+        for (int64_t r = row_begin; r < (int64_t)row_end; r++)
+            for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
+                const uint32_t c = h_indices[i];
+                // write only when it changes something: hub columns are written from every thread's row range, and
+                // unconditional stores would bounce their cache lines between all cores
+                if (c < num_cols && c != (uint32_t)r) {
+                    const uint32_t bits = __builtin_bit_cast(uint32_t, h_data[i]);
+                    if (__atomic_load_n(&colbits[c], __ATOMIC_RELAXED) != bits) __atomic_store_n(&colbits[c], bits, __ATOMIC_RELAXED);
+                }
+            }
+#pragma omp parallel for schedule(static, 4096) reduction(| : mismatch) reduction(+ : exceptions)
+        for (int64_t r = row_begin; r < (int64_t)row_end; r++) {   // 4096 rows = whole diag_has words per thread
+            uint32_t nexc = 0;
+            for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
+                const uint32_t c = h_indices[i], bits = __builtin_bit_cast(uint32_t, h_data[i]);
+                if (c >= num_cols) { mismatch = 1; continue; }
+                if (colbits[c] == bits) continue;             // a regular entry of its column (diagonal or not)
+                if (c != (uint32_t)r) { mismatch = 1; continue; }
+                nexc++;                                        // diagonal entry that differs from its column's value
+                diag_val[r - row_begin] = h_data[i];
+                diag_has[(r - row_begin) >> 5] |= 1u << ((r - row_begin) & 31);
+            }
+            if (nexc > 1) mismatch = 1;   // several different diagonal values in one row: keep the general layout
+            exceptions += nexc;
+        }
+        }
+        pattern = !mismatch;
+        diag_mode = pattern && exceptions > 0;
+    }
     // ---- hot columns: the H highest-degree columns of the shard get an LDS-resident copy of x.
     //      H = what fits next to the tallest f64 tile (incl. worst-case hub slots).
     std::vector<uint32_t> hot_cols, hot_slot;   // slot -> column, column -> slot (0xffffffff = cold)
@@ -1207,10 +1256,10 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         // 8-byte accumulators unless the caller promised to run only the 4-byte-tile semirings
         const size_t elem = (flags & (GL_PLAN_NO_MULADD | GL_PLAN_BOOLEAN)) ? sizeof(float) : sizeof(double);
         const size_t tile_bytes = ((size_t)tallest + gl::kHubSlots * gl::kMaxHubRows + gl::kPadSlots) * elem;   // (+ the dummy slots of padding entries)
-        // as many columns as fit next to the tallest tile, in steps of 1024, at most 32 K
+        // as many columns as fit next to the tallest tile (whole wavefronts of slots), at most 32 K
         uint32_t room = 0;
         if (tile_bytes + 4096u <= gl::kLdsBudget)
-            room = std::min<uint32_t>(1u << 15, (uint32_t)((gl::kLdsBudget - tile_bytes - 320u) / 4u / 1024u * 1024u));   // (- the 64 identity slots, the ticket word, rounding)
+            room = std::min<uint32_t>(1u << 15, (uint32_t)((gl::kLdsBudget - tile_bytes - 320u) / 4u / 64u * 64u));   // (- the 64 identity slots, the ticket word, rounding)
         uint32_t H = room;
         // Round 4, same-box sweeps of the table size (profiles/r04_small_graph_ab.txt): with the packed gather vector ordered by
         // degree class the popular columns are cheap to gather anyway, and the table has a price per workgroup (its copy in the
@@ -1230,7 +1279,10 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             for (uint32_t c = 0; c < num_cols; c++) hist[deg[c]]++;
             // thr = smallest degree such that at most H columns have degree >= thr; a column must also
             // appear often enough to be worth a slot (>= 4 entries per row block on average)
-            const uint32_t floor_deg = std::max<uint32_t>(8u, (uint32_t)gl::debug_knob("spmv_hot_floor", 4) * bp.nblocks);
+            // (round 6: a ROW-PACKED hot entry -- pattern plans -- costs 2.3 bytes, a seventh of an LDS atomic and no gather: every
+            //  column that averages one entry per row block is worth a slot there; profiles/r06_hot_floor_sweep.txt: ogbl-ppa
+            //  0.037 -> 0.034 ms, pokec 0.041 -> 0.040, the table-size-limited stand-ins unchanged)
+            const uint32_t floor_deg = std::max<uint32_t>(8u, (uint32_t)gl::debug_knob("spmv_hot_floor", pattern ? 1 : 4) * bp.nblocks);
             uint64_t seen = 0;
             uint32_t thr = dmax + 1;
             while (thr > floor_deg && seen + hist[thr - 1] <= H) { thr--; seen += hist[thr]; }
@@ -1303,55 +1355,6 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     const uint32_t nhot_table = have_hot ? (uint32_t)((hot_cols.size() + 63) / 64 * 64) : 0u;
     if (have_hot) hot_cols.resize(nhot_table, hot_cols[0]);   // pad the table to whole wavefronts
 
-    // ---- pattern plan?  every column's stored values are bitwise equal (unweighted graphs, out-degree
-    //      normalised PageRank matrices, bench_spmv's 1/num_rows): the stream then carries no values
-    std::vector<uint32_t> colbits, diag_has;
-    std::vector<float> diag_val;
-    bool pattern = false, diag_mode = false;
-    if (nnz > 0 && !(flags & GL_PLAN_KEEP_VALUES) && gl::debug_knob("spmv_pattern", 1) != 0) {
-        // Diagonal entries are looked at separately: a matrix that is column-constant apart from its diagonal
-        // (SSSP's unit weights + zero self edges, app/sssp.h:16-62) keeps the pattern layout, the diagonal goes
-        // into a per-row array that the epilogue folds in.
-        int mismatch = 0;
-        uint64_t exceptions = 0;
-        if (on_device) {
-            const int prc = gl::fmt_detect_pattern(staged.c, num_cols, colbits, diag_has, diag_val, &mismatch, &exceptions);
-            if (prc != GL_OK) return prc;
-        } else {
-        colbits.assign(num_cols, 0u);
-        diag_has.assign((size_t)(rows + 31) / 32, 0u);
-        diag_val.assign(rows, 0.0f);
-        // pass 1: any writer wins (all of a column's writers agree if the column is constant); pass 2 verifies
-#pragma omp parallel for schedule(static, 4096)
-        for (int64_t r = row_begin; r < (int64_t)row_end; r++)
-            for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
-                const uint32_t c = h_indices[i];
-                // write only when it changes something: hub columns are written from every thread's row range, and
-                // unconditional stores would bounce their cache lines between all cores
-                if (c < num_cols && c != (uint32_t)r) {
-                    const uint32_t bits = __builtin_bit_cast(uint32_t, h_data[i]);
-                    if (__atomic_load_n(&colbits[c], __ATOMIC_RELAXED) != bits) __atomic_store_n(&colbits[c], bits, __ATOMIC_RELAXED);
-                }
-            }
-#pragma omp parallel for schedule(static, 4096) reduction(| : mismatch) reduction(+ : exceptions)
-        for (int64_t r = row_begin; r < (int64_t)row_end; r++) {   // 4096 rows = whole diag_has words per thread
-            uint32_t nexc = 0;
-            for (uint64_t i = h_indptr[r]; i < h_indptr[r + 1]; i++) {
-                const uint32_t c = h_indices[i], bits = __builtin_bit_cast(uint32_t, h_data[i]);
-                if (c >= num_cols) { mismatch = 1; continue; }
-                if (colbits[c] == bits) continue;             // a regular entry of its column (diagonal or not)
-                if (c != (uint32_t)r) { mismatch = 1; continue; }
-                nexc++;                                        // diagonal entry that differs from its column's value
-                diag_val[r - row_begin] = h_data[i];
-                diag_has[(r - row_begin) >> 5] |= 1u << ((r - row_begin) & 31);
-            }
-            if (nexc > 1) mismatch = 1;   // several different diagonal values in one row: keep the general layout
-            exceptions += nexc;
-        }
-        }
-        pattern = !mismatch;
-        diag_mode = pattern && exceptions > 0;
-    }
     // the delta-coded cold stream and the run-coded hot stream, both in elements of 4 (pattern: 8) lane-interleaved groups
     const bool wide = true;
     const uint32_t cold_groups = pattern ? gl::kColdGroupsPattern : gl::kColdGroupsGeneral;   // units hold whole elements

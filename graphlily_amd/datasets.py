@@ -134,7 +134,29 @@ EXTRA_GRAPHS = {
     "products_community": dict(n=2_449_029, nnz=124_000_000, seed=15, symmetric=True, iters=23, kind="community"),
     # the SAME graph with its vertices relabelled at random: what the community numbering is worth to a layout
     "orkut_community_shuffled": dict(n=3_072_441, nnz=213_000_000, seed=16, symmetric=True, iters=6, kind="community", shuffle=True),
+    # no degree skew at all (round 5's verdict: the layouts' two big levers -- hot table, degree-class packed vector -- are tuned on
+    # R-MAT skew): every row draws 70 columns uniformly.  The worst case for both levers at orkut's size.
+    "uniform_3M_70": dict(n=3_072_441, nnz=215_000_000, seed=17, symmetric=False, iters=6, kind="uniform"),
 }
+
+
+def uniform_torch(n, nnz, seed, device):
+    """n x n, nnz / n uniformly drawn columns per row (duplicates removed), built on the GPU like rmat_torch; host CSRMatrix."""
+    import torch
+    g = torch.Generator(device=device if device is not None else "cpu")
+    g.manual_seed(seed)
+    deg = max(1, nnz // n)
+    dev = device if device is not None else torch.device("cpu")
+    rows = torch.arange(n, device=dev, dtype=torch.int64).repeat_interleave(deg)
+    cols = torch.randint(0, n, (n * deg,), generator=g, device=dev, dtype=torch.int64)
+    key = torch.unique(rows * n + cols)
+    del rows, cols
+    rows = torch.div(key, n, rounding_mode="floor")
+    cols = (key - rows * n).to(torch.int32)
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    h_cols = cols.cpu().numpy().view(np.uint32)
+    return CSRMatrix(n, n, np.ones(h_cols.shape[0], dtype=np.float32), h_cols, indptr.cpu().numpy().astype(np.uint32))
 
 
 def community_torch(n, nnz, seed, symmetric, device, p_in=0.8, mean_size=2048, shuffle=False):
@@ -194,6 +216,8 @@ def paper_graph(name, scale=1.0, device=None):
     nnz = max(1024, int(g["nnz"] * scale))
     if g.get("kind") == "community":
         return community_torch(n, nnz, g["seed"], g["symmetric"], device, shuffle=bool(g.get("shuffle")))
+    if g.get("kind") == "uniform":
+        return uniform_torch(n, nnz, g["seed"], device)
     if device is not None:
         return rmat_torch(n, nnz, g["seed"], g["symmetric"], device)
     return rmat(n, nnz, g["seed"], g["symmetric"])

@@ -32,8 +32,19 @@ ref_tests)     # the reference's own acceptance suites, unmodified, float + ufix
 pytest)        # pytest -m gpu on the files / -k expression given
   timeout 3000 python -m pytest -m gpu -x -q "$@" 2>&1 | tail -15 | tee gpurun_out/r06_pytest_last.txt
   ;;
+rare)          # R6.6 what-if (needs the `spmv_ablate_rare` knob of commit "what-if: rare columns", since removed): the pattern kernel
+               # without the entries of the rarest columns (wrong results: how much do their lines cost?)
+  for rep in 1 2; do for g in ${GRAPHS:-orkut ogbn_products pokec}; do for d in 0 1 2 3 5 8; do
+    probe $g 0 "spmv_ablate_rare=$d"
+  done; done; done 2>&1 | tee gpurun_out/r06_whatif_rare_columns.txt
+  ;;
+hot_floor)     # R6.7: degree floor of the hot table (entries per row block a column must average), pattern layout with the row-packed stream
+  for rep in 1 2; do for g in ${GRAPHS:-pokec ogbl_ppa googleplus hollywood ogbn_products orkut}; do for d in 4 2 1; do
+    probe $g 0 "spmv_hot_floor=$d"
+  done; done; done 2>&1 | tee gpurun_out/r06_hot_floor_sweep.txt
+  ;;
 ab)            # same-box A/B: GRAPHS / FLAGS as in scripts/ab_variants.sh; arguments = variants (scripts/_variants/<name>.so, or cur[=KNOBS])
   bash scripts/ab_variants.sh "$@" 2>&1 | tee gpurun_out/r06_ab_${AB_NAME:-last}.txt
   ;;
-*) echo "cases: two_wg pmc_pattern lds_atomic ref_tests pytest ab"; exit 1;;
+*) echo "cases: two_wg pmc_pattern lds_atomic ref_tests pytest rare hot_floor ab"; exit 1;;
 esac
