@@ -179,12 +179,61 @@ def test_delta_coded_cold_stream_bridges_wide_gaps(gpu, kind, monkeypatch):
                 assert np.array_equal(got, ref), sem
 
 
-def test_run_coded_hot_stream_dense_columns(gpu, monkeypatch):
+@pytest.mark.parametrize("shape", [(0, 0), (5, 3)])
+def test_row_packed_hot_stream_record_boundaries(gpu, monkeypatch, shape):
+    """Pattern layout, round 6: a row's hot entries travel as records of 7 table slots + the row slot (csrc/gl_spmv_plan.h).  Rows
+    with 0 ... 16 hot entries (0, 1, 7, 8, 14, 15 among them: empty, padded, exactly full, one over) next to three cold ones each;
+    unsplit and split into column segments (records cut by position); the host and the device formatter agree on every byte, and
+    every semiring -- (min,+) with both zeros: the padding fields name the table's identity slot, +inf there -- gives the oracle's
+    results."""
+    from graphlily_amd import capi
+    rng = np.random.default_rng(61)
+    n, hotc = 4096, 64
+    rows, cols = [], []
+    for r in range(n):
+        k = r % 17
+        hot = (np.arange(k) * 5 + r) % hotc                      # k distinct hot columns (5 is coprime to 64)
+        cold = hotc + rng.choice(n - hotc, size=3, replace=False)
+        c = np.unique(np.concatenate([hot, cold]))
+        rows.append(np.full(c.shape[0], r))
+        cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    indptr = np.zeros(n + 1, np.uint32)
+    np.cumsum(np.bincount(rows, minlength=n), out=indptr[1:])
+    data = np.full(rows.shape[0], np.float32(0.5), np.float32)
+    m = io.CSRMatrix(n, n, data, cols.astype(np.uint32), indptr)
+    set_knob(monkeypatch, "spmv_hot", hotc)
+    set_knob(monkeypatch, "spmv_blocks", str(shape[0]))
+    set_knob(monkeypatch, "spmv_segments", str(shape[1]))
+    plans = [capi.SpMVPlan(n, n, indptr, m.adj_indices, data, flags=f) for f in (capi.GL_PLAN_HOST_FORMAT, capi.GL_PLAN_DEVICE_FORMAT)]
+    assert plans[0].info()["layout"] == "pattern" and plans[0].info()["hot_columns"] == hotc
+    assert plans[0].info()["hot_nnz"] == int(sum(r % 17 for r in range(n)))
+    for name in ("entries", "bases", "units", "hub_rows", "hot", "hot_hdr", "present"):
+        assert np.array_equal(plans[0].export(name), plans[1].export(name)), name
+    x, mask = rng.random(n, dtype=np.float32), rand01(n, 9)
+    om = to_oracle(m)
+    for sem, op, zero in (("Arithmetic", 0, 0.0), ("Tropical", 2, 255.0), ("TropicalFloatInf", 2, 999999999.0), ("Logical", 1, 0.0)):
+        xs = x if op != 2 else np.where(x > 0.5, x, np.float32(zero)).astype(np.float32)
+        ref = O.spmv(om, xs, op, zero, mask, MASKS["WriteToOne"])
+        for p in plans:
+            dx, dm, dy = capi.DeviceBuffer.from_host(xs), capi.DeviceBuffer.from_host(mask), capi.DeviceBuffer(4 * n)
+            p.run(dx, dm, dy, op, zero, MASKS["WriteToOne"])
+            got = dy.read(np.float32, n)
+            if op == 0:
+                assert np.allclose(got, ref, rtol=1e-5, atol=1e-7), sem
+            else:
+                assert np.array_equal(got, ref), sem
+
+
+@pytest.mark.parametrize("kind", ["general", "pattern"])
+def test_run_coded_hot_stream_dense_columns(gpu, monkeypatch, kind):
     """dense_1K: every column is as hot as every other and every run is as long as the block is tall (runs spanning many
-    groups and elements); with hub rows off and on (a dense row is a hub row of its block)."""
+    groups and elements); with hub rows off and on (a dense row is a hub row of its block).  Pattern layout (round 6: the
+    ROW-PACKED hot stream): every row holds 1024 hot entries = 147 records, far more than a lane's chunk -- the same row sits in
+    several lanes of a step (hub rows on: spread over the private slots by lane; off: same-address accumulates)."""
     m = spmv_prepare("dense_1K")
     rng = np.random.default_rng(32)
-    m.adj_data = rng.random(m.nnz, dtype=np.float32)
+    m.adj_data = rng.random(m.nnz, dtype=np.float32) if kind == "general" else np.full(m.nnz, np.float32(0.375), np.float32)
     x, mask = rng.random(m.num_cols, dtype=np.float32), rand01(m.num_rows, 5)
     for hub_div in ("48", "1000000"):
         set_knob(monkeypatch, "spmv_hub_div", hub_div)
@@ -193,8 +242,10 @@ def test_run_coded_hot_stream_dense_columns(gpu, monkeypatch):
             _check(got, m, sem, "WriteToOne", x, mask, "dense columns hub_div %s %s" % (hub_div, sem))
 
 
-def test_hub_row_spreading(gpu):
-    """A few rows holding most of a block's entries go through the 16 private LDS slots."""
+@pytest.mark.parametrize("kind", ["general", "pattern"])
+def test_hub_row_spreading(gpu, kind):
+    """A few rows holding most of a block's entries go through the 16 private LDS slots (pattern layout: their hot entries as
+    records of the row-packed stream, private slot by lane)."""
     rng = np.random.default_rng(5)
     n = 4096
     dense_rows = [7, 1000, 4095]
@@ -206,11 +257,12 @@ def test_hub_row_spreading(gpu):
     rows, cols = np.concatenate(rows), np.concatenate(cols)
     indptr = np.zeros(n + 1, np.uint32)
     np.cumsum(np.bincount(rows, minlength=n), out=indptr[1:])
-    m = io.CSRMatrix(n, n, rng.random(rows.shape[0], dtype=np.float32), cols.astype(np.uint32), indptr)
+    data = rng.random(rows.shape[0], dtype=np.float32) if kind == "general" else np.full(rows.shape[0], np.float32(0.25), np.float32)
+    m = io.CSRMatrix(n, n, data, cols.astype(np.uint32), indptr)
     x, mask = rng.random(n, dtype=np.float32), rand01(n, 1)
     for sem in ("Arithmetic", "Logical", "Tropical"):
         got = _run_spmv(gpu, m, sem, "NoMask", x, mask)
-        _check(got, m, sem, "NoMask", x, None, "hub rows " + sem)
+        _check(got, m, sem, "NoMask", x, None, "hub rows %s %s" % (kind, sem))
 
 
 def test_wide_column_jumps(gpu):
