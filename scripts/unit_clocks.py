@@ -69,3 +69,17 @@ try:
         print("  slow unit %d: %d rows, %d entries, longest row %d entries (%.1f %%), %d hub rows" % (u, nrows[u], ent[u], deg[big], 100.0 * deg[big] / max(ent[u], 1), nhub[u]))
 except Exception as e:     # (the export's layout is an implementation detail: this part may rot)
     print("  (units export not understood: %r)" % (e,))
+
+# round 6: what a unit's duration follows -- its cold groups and its hot elements (a least-squares fit over the units): is a cut by
+# COST (cold and hot entries priced differently) worth more than the cut by entries?
+try:
+    ncold, nhot = uw[:, 1].astype(np.float64), uw[:, 6].astype(np.float64)
+    A = np.stack([ncold, nhot, np.ones_like(ncold)], axis=1)
+    coef, *_ = np.linalg.lstsq(A, med, rcond=None)
+    fit = A @ coef
+    print("  fit: unit us = %.5f x cold groups + %.5f x hot %s + %.2f; residual std %.2f us; cold groups per unit min / mean / max %d / %d / %d, "
+          "hot %d / %d / %d" % (coef[0], coef[1], "elements" if info["layout"] == "pattern" else "groups", coef[2], float((med - fit).std()),
+                                ncold.min(), ncold.mean(), ncold.max(), nhot.min(), nhot.mean(), nhot.max()))
+    print("  the fit's own max / mean over the units: %.4f (what a cut by this cost model could remove of the tail)" % float(fit.max() / fit.mean()))
+except Exception as e:
+    print("  (fit failed: %r)" % (e,))
