@@ -289,15 +289,15 @@ __global__ __launch_bounds__(kFmtThreads) void fmt_run_unit_starts_kernel(const 
 
 // One workgroup per unit, one wave per hot group.  runs = inclusive scan of the flags: entry i's table slot within the unit
 // is runs[i] - runs[hot_begin].
-template <typename K, bool PATTERN>
+template <typename K>
 __global__ __launch_bounds__(kThreads) void fmt_emit_hot_kernel(const K *__restrict__ keys, const uint2 *__restrict__ payload,
                                                                 const uint32_t *__restrict__ runs, const UnitDesc *__restrict__ units,
                                                                 const uint32_t *__restrict__ hub_rows, uint32_t cb,
                                                                 unsigned char *__restrict__ hot, uint32_t *__restrict__ hot_hdr,
                                                                 uint16_t *__restrict__ present, uint4 *__restrict__ plan_units) {
     __shared__ uint8_t hub_of[kMaxBlockRows + 1];
-    constexpr uint32_t HG = PATTERN ? kHotGroupsPattern : kHotGroupsGeneral;
-    constexpr uint32_t EB = PATTERN ? kHotElemBytesPattern : kHotElemBytesGeneral;
+    constexpr uint32_t HG = kHotGroupsGeneral;       // (general layout only: pattern plans carry the row-packed stream, below)
+    constexpr uint32_t EB = kHotElemBytesGeneral;
     const UnitDesc u = units[blockIdx.x];
     const uint32_t nrows = u.nrows_direct & 0xffffu;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kThreads) void fmt_emit_hot_kernel(const K *__restr
         uint32_t local = 0u;
         bool start = false;
         if (lane >= cnt) {
-            reinterpret_cast<uint16_t *>(hot + e * EB)[lane * (PATTERN ? 8u : 4u) + k] = (uint16_t)pad_slot;   // (values stay 0)
+            reinterpret_cast<uint16_t *>(hot + e * EB)[lane * 4u + k] = (uint16_t)pad_slot;   // (values stay 0)
         } else {
             const uint32_t i = st + lane, si = runs[i];
             local = si - s0;
@@ -332,12 +332,8 @@ __global__ __launch_bounds__(kThreads) void fmt_emit_hot_kernel(const K *__restr
                 if (hb != 0xffu) slot = nrows + kHubSlots * hb + (lane & (kHubSlots - 1u));
             }
             unsigned char *el = hot + e * EB;
-            if (PATTERN) {
-                reinterpret_cast<uint16_t *>(el)[lane * 8u + k] = (uint16_t)slot;
-            } else {
-                reinterpret_cast<uint16_t *>(el)[lane * 4u + k] = (uint16_t)slot;
-                reinterpret_cast<uint32_t *>(el + 512)[lane * 4u + k] = pl.y;
-            }
+            reinterpret_cast<uint16_t *>(el)[lane * 4u + k] = (uint16_t)slot;
+            reinterpret_cast<uint32_t *>(el + 512)[lane * 4u + k] = pl.y;
         }
         const unsigned long long mask = __ballot(start && lane >= 1u) >> 1;   // bit l - 1: entry l starts a run
         const uint32_t base = __shfl(local, 0);
@@ -709,8 +705,8 @@ int emit_general_typed(DevCsr *c, const EmitGeneral &e, gl_spmv_plan p, std::vec
         GL_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, d_flags.as<uint32_t>(), d_runs.as<uint32_t>(), (size_t)nnz, rocprim::plus<uint32_t>(), s));
         if ((rc = d_tmp.alloc(tmp_bytes)) != GL_OK) return rc;
         GL_HIP(rocprim::inclusive_scan(d_tmp.p, tmp_bytes, d_flags.as<uint32_t>(), d_runs.as<uint32_t>(), (size_t)nnz, rocprim::plus<uint32_t>(), s));
-        fmt_emit_hot_kernel<K, false><<<nunits, kThreads, 0, s>>>(keys, payload, d_runs.as<uint32_t>(), d_units.as<UnitDesc>(), p->d_hub_rows, cb,
-                                                                  p->d_hot, p->d_hot_hdr, p->d_present, p->d_units);
+        fmt_emit_hot_kernel<K><<<nunits, kThreads, 0, s>>>(keys, payload, d_runs.as<uint32_t>(), d_units.as<UnitDesc>(), p->d_hub_rows, cb,
+                                                           p->d_hot, p->d_hot_hdr, p->d_present, p->d_units);
         GL_LAUNCH_CHECK();
         GL_HIP(hipStreamSynchronize(s));   // scratch dies here
     }

@@ -15,8 +15,8 @@
 //     sweep touches every line of x that holds one of its columns -- so the cold entries index a PACKED copy of x
 //     (never-gathered columns dropped, rare ones clustered by degree class), refilled per run by a helper kernel;
 //   * LDS atomics on 4/8-byte integers and on f64 run at full rate, ds_add_f32 at a third of it.
-// This file holds the GENERAL layout (7-byte cold / 6.19-byte hot entries) and the PATTERN layout (3 / 2.19-byte entries for
-// column-constant matrices), both served by spmv_rbcs_kernel<OP, MASK, stream layout, UC, UH>; the
+// This file holds the GENERAL layout (7-byte cold / 6.19-byte hot entries) and the PATTERN layout (3-byte cold entries, row-packed
+// hot records of 7 entries in 16 bytes, for column-constant matrices), both served by spmv_rbcs_kernel<OP, MASK, stream layout, UC, UH>; the
 // (||,&&)-only bit layout lives in gl_spmv_bool.hip.
 // Hence the layout -- the CDNA4 counterpart of the FPGA's "dense-vector tile in URAM + output buffer
 // in URAM" partitioning (kernel_spmv_impl.h:470-495), with the roles swapped:
@@ -34,8 +34,8 @@
 //               the non-zeros) are cached per workgroup in an LDS table; their entries need no vector-memory
 //               gather and, sorted by column, form RUNS: the hot stream is run-coded (gl_spmv_plan.h) -- a
 //               16-bit row slot (+ the value) per entry, the column as one bit per entry and a base per
-//               group, slots numbered per unit -- 6.19 bytes per entry instead of 8 (2.19 instead of 4 in the
-//               pattern layout).  The loop is bound by the CU's vector-memory pipe (45 clocks per 512 B of
+//               group, slots numbered per unit -- 6.19 bytes per entry instead of 8 (general layout; the pattern
+//               layout's hot entries are ROW-PACKED since round 6: gl_spmv_plan.h).  The loop is bound by the CU's vector-memory pipe (45 clocks per 512 B of
 //               stream + 4 + 2.2 clocks per line of a cold gather), so bytes per entry are what is left to
 //               save; a wavefront processes UC cold and UH hot stream elements per iteration.
 //   hub rows    a row that owns more than ~1/48 of its block's entries would make many lanes of every
@@ -135,7 +135,7 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
 //     QUAD   16 B of slots + 8 B of deltas per lane                   8 groups  (pattern layout, 3 B per entry)
 //   HOT stream, run-coded: 16-bit slots, the table slot from the element's header
 //     WIDE   8 B of slots + 16 B of values per lane                   4 groups  (6.19 B per entry)
-//     QUAD   16 B of slots per lane                                   8 groups  (2.19 B per entry)
+//     QUAD   ROW-PACKED instead (round 6): 16 B per lane = one record, 7 table slots of one row + the row slot  (2.29 B per entry)
 // Pattern plans (every column's stored values are equal) fold the value into z[c] = colval[c] (x) x[c] once per run and
 // gather z instead of x.  (Round 5 retired the 8-byte-per-lane NARROW / PAIR streams of rounds 1-2, and the 32-bit
 // { delta << 14 | slot } cold keys of rounds 1-4.)

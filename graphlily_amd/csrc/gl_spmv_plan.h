@@ -45,9 +45,10 @@ constexpr uint32_t kBoolHubBit0 = (kBoolTileWords - kBoolHubSlots) * 32u;   // 1
 // column travels as one bit per entry ("the next entry starts a new run") + one base per 64-entry group.  The slots are
 // numbered per UNIT (rank among the hot columns that occur in the unit, listed in the unit's `present` array), so that runs
 // advance the slot by exactly one and lane l of a group reads table[base + popcount(mask below l)] (v_mbcnt with a scalar mask).
-// An ELEMENT is what one wavefront step loads: HG groups, lane-interleaved -- general: 8 B of row slots + 16 B of values
-// per lane (HG = 4), pattern: 16 B of row slots per lane (HG = 8) -- with a 12-byte header per group kept apart (scalar loads):
-// 6.19 instead of 8 bytes per hot entry, 2.19 instead of 4 in the pattern layout.
+// An ELEMENT is what one wavefront step loads: HG = 4 groups, lane-interleaved -- 8 B of row slots + 16 B of values per lane --
+// with a 12-byte header per group kept apart (scalar loads): 6.19 instead of 8 bytes per hot entry.  GENERAL layout only since
+// round 6 (the pattern layout, which this coding took from 4 to 2.19 bytes per hot entry in round 5, carries the row-packed
+// stream below: it was bound by LDS atomics, not bytes).
 // Delta-coded cold stream (round 5).  A unit's cold entries are sorted by gather index, and in the classes the packed vector
 // lists first consecutive entries are a few columns apart: the entry keeps a 16-bit row slot (+ its value) and an 8-BIT DELTA to
 // its predecessor; entry 0 of a 64-entry group has delta 0 and the group's base (a scalar) is its index.  Lane l's index is
@@ -75,9 +76,8 @@ constexpr uint32_t kColdMaxDelta = 255;
 constexpr uint32_t kHotRecEntries = 7;                     // table slots per record
 constexpr uint32_t kHotElemBytesRows = 64u * 16u;          // one 16-byte record per lane
 
-constexpr uint32_t kHotGroupsGeneral = 4, kHotGroupsPattern = 8;
+constexpr uint32_t kHotGroupsGeneral = 4;
 constexpr uint32_t kHotElemBytesGeneral = kHotGroupsGeneral * 64u * 6u;   // 512 B of row slots, then 1024 B of values
-constexpr uint32_t kHotElemBytesPattern = kHotGroupsPattern * 64u * 2u;   // 1024 B of row slots
 constexpr uint32_t kHotHdrWordsPerGroup = 3;                              // per element: HG x {mask lo, mask hi}, then HG bases
 
 struct Shape {

@@ -106,6 +106,10 @@ private:
     typedef graphlily::value_kind<graphlily::val_t> VK;
 
     // an n-element vector that holds `fill` everywhere and `at_source` at the source, made on the device
+    // (a fresh DeviceBuffer per call is a block of the library's device POOL -- gl_buf_alloc hands back the block the previous call
+    //  released, GRAPHLILY_POOL_TRACE shows it -- not a hipMalloc / hipFree pair: ADVICE r05 read it as one.  The fusion swap
+    //  exchanges storage between the modules' vector and results buffers, so a buffer kept here would have to be re-bound per call
+    //  anyway.)
     DeviceBuffer device_dense_(uint32_t source, graphlily::val_t fill, graphlily::val_t at_source) {
         DeviceBuffer b(sizeof(graphlily::val_t) * (size_t)matrix_num_rows_);
         GRAPHLILY_CHECK(gl_buf_fill_u32((uint32_t *)b.ptr(), VK::bits(fill), matrix_num_rows_));
