@@ -43,8 +43,17 @@ hot_floor)     # R6.7: degree floor of the hot table (entries per row block a co
     probe $g 0 "spmv_hot_floor=$d"
   done; done; done 2>&1 | tee gpurun_out/r06_hot_floor_sweep.txt
   ;;
+spmspv_priv)   # R6.10: private per-workgroup regions behind the bins (no global reservations for large runs): parity with the path
+               # forced on small matrices, then blocking / back-to-back call times against the round's first build and with the knob off
+  GRAPHLILY_DEBUG="spmspv_priv_min=1,spmspv_priv_min_nnz=0" timeout 1500 python -m pytest tests/test_gpu_spmspv.py tests/test_gpu_apps.py -m gpu -x -q 2>&1 | tail -3
+  timeout 1500 python -m pytest tests/test_gpu_spmspv.py -m gpu -x -q 2>&1 | tail -2
+  for rep in 1 2; do for g in ${GRAPHS:-orkut hollywood ogbn_products}; do for sp in 0.9 0.95 0.99; do
+    for v in "r6base:" "cur:spmspv_priv=0" "cur:"; do lib=${v%%:*}; k=${v#*:}; [ "$lib" = cur ] && lib="" || lib=scripts/_variants/$lib.so
+      echo -n "$g $sp [$v] "; GRAPHLILY_HIP_LIB=$lib GRAPHLILY_DEBUG="$k" timeout 600 python scripts/spmspv_call_trace.py $g $sp 2>&1 | grep "blocking run\|back to back" | tr '\n' ' '; echo
+    done; done; done; done 2>&1 | tee gpurun_out/r06_ab_spmspv_private_regions.txt
+  ;;
 ab)            # same-box A/B: GRAPHS / FLAGS as in scripts/ab_variants.sh; arguments = variants (scripts/_variants/<name>.so, or cur[=KNOBS])
   bash scripts/ab_variants.sh "$@" 2>&1 | tee gpurun_out/r06_ab_${AB_NAME:-last}.txt
   ;;
-*) echo "cases: two_wg pmc_pattern lds_atomic ref_tests pytest rare hot_floor ab"; exit 1;;
+*) echo "cases: two_wg pmc_pattern lds_atomic ref_tests pytest rare hot_floor spmspv_priv ab"; exit 1;;
 esac
