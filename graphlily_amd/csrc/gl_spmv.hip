@@ -1160,7 +1160,8 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
         p->row_end = row_end;
         p->nnz = nnz;
         p->flags = flags;
-        const int rc = gl::bool_plan_build(p, h_indptr, h_indices, h_data);
+        int rc = gl::bool_plan_build(p, h_indptr, h_indices, h_data);
+        if (rc == GL_OK) rc = gl::bool_plan_compress(p);
         if (rc != GL_OK) {
             gl_spmv_plan_destroy(p);
             return rc;

@@ -12,6 +12,14 @@
 //   tile      one bit per row of the block (ds_or_b32).
 // What is left is the 4-byte stream at HBM speed.  Units, segment-major numbering, direct epilogue for
 // unsplit blocks and the init kernel + plain stores (1.0f, idempotent) for split ones are as in gl_spmv.hip.
+//
+// Round 6: the stream is DELTA-CODED to 3 bytes per entry when every group allows it (bool_plan_compress, a pass over the
+// formatted groups on the device, whichever formatter wrote them): a group's 256 entries are sorted by column, so an entry keeps
+// its 16-bit row slot and the 8-bit distance to its predecessor's bit index -- lane l holds entries 4 l .. 4 l + 3: 8 bytes of
+// slots + 4 bytes of deltas, two coalesced loads per group, 768 bytes instead of 1024 -- and the kernel rebuilds the indices with
+// one v_sad_u8 (a lane's four deltas), ONE 32-bit prefix scan over the lanes (six DPP adds per 256 entries) and three adds.
+// Padding entries repeat their predecessor's index with the ghost row slot.  A plan with a gap of more than 255 columns inside
+// some group keeps the 4-byte form (none of the stand-ins has one: a block's columns are a few apart).
 #include "gl_spmv_plan.h"
 #include "gl_bfs_shard.h"
 
@@ -118,19 +126,44 @@ constexpr int kBoolLane = kBoolGroup / 64;   // entries per lane and load
 struct BoolElem {   // one lane's share of a group
     uint32_t v[kBoolLane];
 };
-template <int KEEP>   // KEEP: no non-temporal hint -- plans that fit the Infinity Cache stay there between runs (gl_common.h)
+constexpr uint32_t kBoolGroupBytesC = kBoolGroup * 3u;   // compressed group: 2 B of row slot + 1 B of delta per entry
+// KEEP bit 0: no non-temporal hint -- plans that fit the Infinity Cache stay there between runs (gl_common.h);
+// KEEP bit 1: the delta-coded 3-byte stream (v[0], v[1]: four 16-bit row slots, v[2]: four 8-bit deltas, v[3] unused);
+// KEEP bit 2 (with bit 1): some delta of the plan needs 10 bits, and bits 8..9 sit on top of the 14-bit row slots
+template <int KEEP>
 __device__ __forceinline__ BoolElem bool_load(const void *entries, size_t group, uint32_t lane) {
     BoolElem e;
+    if ((KEEP & 2) && kBoolLane == 4) {
+        const unsigned char *g = static_cast<const unsigned char *>(entries) + group * kBoolGroupBytesC;
+        const uint2 *q = reinterpret_cast<const uint2 *>(g) + lane;
+        const uint32_t *d = reinterpret_cast<const uint32_t *>(g + kBoolGroup * 2u) + lane;
+        const uint2 t = (KEEP & 1) ? load_stream_keep(q) : load_stream_nt(q);
+        e.v[0] = t.x, e.v[1] = t.y;
+        e.v[2] = (KEEP & 1) ? *d : __builtin_nontemporal_load(d);
+        e.v[kBoolLane - 1] = 0u;
+        return e;
+    }
     if (kBoolLane == 4) {
         const uint4 *q = static_cast<const uint4 *>(entries) + group * 64u + lane;
-        const uint4 t = KEEP ? load_stream_keep16(q) : load_stream_nt16(q);
+        const uint4 t = (KEEP & 1) ? load_stream_keep16(q) : load_stream_nt16(q);
         e.v[0] = t.x, e.v[1] = t.y, e.v[kBoolLane - 2] = t.z, e.v[kBoolLane - 1] = t.w;
     } else {
         const uint2 *q = static_cast<const uint2 *>(entries) + group * 64u + lane;
-        const uint2 t = KEEP ? load_stream_keep(q) : load_stream_nt(q);
+        const uint2 t = (KEEP & 1) ? load_stream_keep(q) : load_stream_nt(q);
         e.v[0] = t.x, e.v[1] = t.y;
     }
     return e;
+}
+
+// inclusive prefix sum of v over the 64 lanes: four row_shr steps scan the 16-lane rows, row_bcast:15 / :31 carry the row totals on
+__device__ __forceinline__ uint32_t bool_wave_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+    return v;
 }
 
 // the kernel's body for workgroup `unit` (also run by the one-launch shard step of the BFS schedule, below)
@@ -226,6 +259,43 @@ __device__ __forceinline__ void spmv_bool_body(const BoolArgs &a, uint32_t *lds_
                 // of its operand, so the entry itself is the bit selector); b = first x word of the group
                 constexpr int NE = kBoolLane * kBoolStep;
                 uint32_t v[NE], w[NE];
+                if constexpr ((KEEP & 2) != 0 && kBoolLane == 4) {
+                    // delta-coded group: v[k] becomes the entry's bit index relative to the group's first x word -- the lane's
+                    // four deltas summed (v_sad_u8), ONE prefix scan over the lanes, three running adds -- and rr[k] its row slot
+                    uint32_t rr[NE];
+#pragma unroll
+                    for (int g = 0; g < kBoolStep; g++) {
+                        const BoolElem &el = e[u + g];
+                        const uint32_t dl = el.v[2];
+                        if constexpr ((KEEP & 4) != 0) {
+                            // 10-bit deltas: bits 8..9 ride in the two spare bits of the 16-bit row slots -- the slots' high bytes
+                            // gathered into one word (v_perm), their top two bits each
+                            const uint32_t hh = (__builtin_amdgcn_perm(el.v[1], el.v[0], 0x07050301u) >> 6) & 0x03030303u;
+                            const uint32_t sum = __builtin_amdgcn_sad_u8(dl, 0u, __builtin_amdgcn_sad_u8(hh, 0u, 0u) << 8);
+                            const uint32_t before = bool_wave_scan(sum) - sum;
+                            v[4 * g] = before + (dl & 255u) + ((hh & 3u) << 8);
+                            v[4 * g + 1] = v[4 * g] + ((dl >> 8) & 255u) + (((hh >> 8) & 3u) << 8);
+                            v[4 * g + 2] = v[4 * g + 1] + ((dl >> 16) & 255u) + (((hh >> 16) & 3u) << 8);
+                            v[4 * g + 3] = v[4 * g + 2] + (dl >> 24) + ((hh >> 24) << 8);
+                            rr[4 * g] = el.v[0] & kRowPad, rr[4 * g + 1] = (el.v[0] >> 16) & kRowPad;
+                            rr[4 * g + 2] = el.v[1] & kRowPad, rr[4 * g + 3] = (el.v[1] >> 16) & kRowPad;
+                        } else {
+                            const uint32_t sum = __builtin_amdgcn_sad_u8(dl, 0u, 0u);
+                            const uint32_t before = bool_wave_scan(sum) - sum;
+                            v[4 * g] = before + (dl & 255u);
+                            v[4 * g + 1] = v[4 * g] + ((dl >> 8) & 255u);
+                            v[4 * g + 2] = v[4 * g + 1] + ((dl >> 16) & 255u);
+                            v[4 * g + 3] = v[4 * g + 2] + (dl >> 24);
+                            rr[4 * g] = el.v[0] & 0xffffu, rr[4 * g + 1] = el.v[0] >> 16;
+                            rr[4 * g + 2] = el.v[1] & 0xffffu, rr[4 * g + 3] = el.v[1] >> 16;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NE; k++) w[k] = xw[b[u + k / kBoolLane] + (v[k] >> 5)];
+#pragma unroll
+                    for (int k = 0; k < NE; k++)
+                        if (__builtin_amdgcn_ubfe(w[k], v[k], 1u)) atomicOr(&tile[rr[k] >> 5], 1u << (rr[k] & 31u));
+                } else {
 #pragma unroll
                 for (int k = 0; k < NE; k++) v[k] = e[u + k / kBoolLane].v[k % kBoolLane];
 #pragma unroll
@@ -236,6 +306,7 @@ __device__ __forceinline__ void spmv_bool_body(const BoolArgs &a, uint32_t *lds_
                         const uint32_t r = (v[k] >> 5) & kRowPad;
                         atomicOr(&tile[r >> 5], 1u << (r & 31u));
                     }
+                }
                 const uint32_t t = __builtin_amdgcn_readfirstlane(drawn);
                 if (a.tickets && lane == 0) drawn = __hip_atomic_fetch_add(&next_group[sp], (uint32_t)kBoolStep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
@@ -553,8 +624,10 @@ static int launch_bool_variant(gl_spmv_plan p, const BoolArgs &a, hipStream_t s)
     // (the CSR copy for the bottom-up BFS step is not streamed by this kernel)
     const size_t rows_bytes = p->d_csr_indptr ? ((size_t)(p->row_end - p->row_begin) + 1u) * 4u + (size_t)p->nnz * 4u : 0u;
     const size_t streamed = p->device_bytes - std::min<size_t>(rows_bytes, p->device_bytes);
-    if (streamed <= keep_bytes && streamed >= keep_min) return launch_bool_keep<MASK, FUSED, 1>(p, a, s);
-    return launch_bool_keep<MASK, FUSED, 0>(p, a, s);
+    const bool keep = streamed <= keep_bytes && streamed >= keep_min;
+    if (p->bool_compressed == 2) return keep ? launch_bool_keep<MASK, FUSED, 7>(p, a, s) : launch_bool_keep<MASK, FUSED, 6>(p, a, s);
+    if (p->bool_compressed) return keep ? launch_bool_keep<MASK, FUSED, 3>(p, a, s) : launch_bool_keep<MASK, FUSED, 2>(p, a, s);
+    return keep ? launch_bool_keep<MASK, FUSED, 1>(p, a, s) : launch_bool_keep<MASK, FUSED, 0>(p, a, s);
 }
 
 template <int MASK>
@@ -657,6 +730,14 @@ int bool_plan_bfs_shard_step(gl_spmv_plan p, BfsPushArgs pa, BfsShardArgs sa, hi
     const size_t rows_bytes = p->d_csr_indptr ? ((size_t)(p->row_end - p->row_begin) + 1u) * 4u + (size_t)p->nnz * 4u : 0u;
     const size_t streamed = p->device_bytes - std::min<size_t>(rows_bytes, p->device_bytes);
     const bool keep = streamed <= keep_bytes && streamed >= keep_min;
+    if (p->bool_compressed == 2) {
+        if (p->segments > 1) return keep ? launch_shard_step<2, 7>(grid, a, pa, sa, s) : launch_shard_step<2, 6>(grid, a, pa, sa, s);
+        return keep ? launch_shard_step<1, 7>(grid, a, pa, sa, s) : launch_shard_step<1, 6>(grid, a, pa, sa, s);
+    }
+    if (p->bool_compressed) {
+        if (p->segments > 1) return keep ? launch_shard_step<2, 3>(grid, a, pa, sa, s) : launch_shard_step<2, 2>(grid, a, pa, sa, s);
+        return keep ? launch_shard_step<1, 3>(grid, a, pa, sa, s) : launch_shard_step<1, 2>(grid, a, pa, sa, s);
+    }
     if (p->segments > 1) return keep ? launch_shard_step<2, 1>(grid, a, pa, sa, s) : launch_shard_step<2, 0>(grid, a, pa, sa, s);
     return keep ? launch_shard_step<1, 1>(grid, a, pa, sa, s) : launch_shard_step<1, 0>(grid, a, pa, sa, s);
 }
@@ -759,6 +840,107 @@ int bool_plan_run_bits(gl_spmv_plan p, float *d_y, const uint32_t *run_flag, hip
 // ------------------------------------------------------------------------------------- planner
 // Units of 256*k; tall blocks (the tile is only bits) cut into column segments, because a unit copies every
 // x phase it touches into LDS: B blocks x S segments costs about B * (nphases + S - 1) phase copies.
+// ---- the delta-coded stream (see the top of the file): one wavefront per group converts it; bad[0] counts the groups that cannot
+// be coded (an entry more than 1023 bit positions behind its predecessor, or out of order), bad[1] those with a delta above 255:
+// bits 8..9 of every delta go into the two spare bits of its 16-bit row slot, and the kernels of a plan with bad[1] != 0 look there
+__global__ __launch_bounds__(256) void bool_compress_kernel(const uint4 *__restrict__ raw, uint32_t ngroups, unsigned char *__restrict__ out,
+                                                            uint32_t *__restrict__ bad) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6); g < ngroups; g += gridDim.x * 4u) {
+        const uint4 t = raw[(size_t)g * 64u + lane];
+        const uint32_t v[4] = {t.x, t.y, t.z, t.w};
+        uint32_t idx[4], row[4];
+        bool pad[4];
+        // a padding entry (ghost row slot) repeats its predecessor's index: the running maximum of the real entries' indices
+        uint32_t run = 0u;
+        bool sorted = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            row[k] = (v[k] >> 5) & kRowPad;
+            pad[k] = row[k] == kRowPad;
+            idx[k] = ((v[k] >> 19) << 5) | (v[k] & 31u);
+            if (!pad[k]) {
+                sorted = sorted && idx[k] >= run;
+                run = max(run, idx[k]);
+            }
+        }
+        // the lanes in front: inclusive max-scan of the lanes' maxima, shifted by one lane
+        uint32_t incl = run;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl = max(incl, up);
+        }
+        uint32_t before = __shfl_up(incl, 1);
+        if (lane == 0) before = 0u;
+        uint32_t prev = before, deltas = 0u;
+        bool ok = sorted, narrow = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t eff = pad[k] ? prev : idx[k];
+            const uint32_t dk = eff - prev;
+            ok = ok && eff >= prev && dk <= 1023u;
+            narrow = narrow && dk <= 255u;
+            deltas |= (dk & 255u) << (8 * k);
+            row[k] |= ((dk >> 8) & 3u) << kRowBits;
+            prev = eff;
+        }
+        if (__ballot(!ok) != 0ull) {
+            if (lane == 0) atomicAdd(bad, 1u);
+            continue;
+        }
+        if (__ballot(!narrow) != 0ull && lane == 0) atomicAdd(bad + 1, 1u);
+        unsigned char *o = out + (size_t)g * kBoolGroupBytesC;
+        reinterpret_cast<uint2 *>(o)[lane] = make_uint2(row[0] | (row[1] << 16), row[2] | (row[3] << 16));
+        reinterpret_cast<uint32_t *>(o + kBoolGroup * 2u)[lane] = deltas;
+    }
+}
+
+// after either formatter: re-code the plan's groups to 3 bytes per entry if every one of them allows it (else the plan stays as it is)
+int bool_plan_compress(gl_spmv_plan p) {
+    if (!p->boolean || kBoolLane != 4 || p->ngroups == 0 || debug_knob("bool_compress", 1) == 0) return GL_OK;
+    hipStream_t s = ctx().stream;
+    const size_t bytes = (size_t)p->ngroups * kBoolGroupBytesC;
+    unsigned char *d_new = nullptr;
+    uint32_t *d_bad = nullptr;
+    GL_HIP(hipMalloc((void **)&d_new, bytes));
+    if (hipMalloc((void **)&d_bad, 16) != hipSuccess) {
+        (void)hipFree(d_new);
+        return set_error(GL_ERR_HIP, "bool_plan_compress: out of device memory");
+    }
+    hipError_t e = hipMemsetAsync(d_bad, 0, 16, s);
+    if (e == hipSuccess) {
+        bool_compress_kernel<<<std::min<uint32_t>((uint32_t)cdiv((uint32_t)p->ngroups, 4u), (uint32_t)ctx().num_cus * 16u), 256, 0, s>>>(
+            reinterpret_cast<const uint4 *>(p->d_entries), (uint32_t)p->ngroups, d_new, d_bad);
+        e = hipGetLastError();
+    }
+    uint32_t bad = 1u, wide = 0u;
+    if (e == hipSuccess) e = d2h_word_sync(&bad, d_bad, s);
+    if (e == hipSuccess) e = d2h_word_sync(&wide, d_bad + 1, s);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) {
+        (void)hipFree(d_new);
+        return set_error(GL_ERR_HIP, "bool_plan_compress: %s", hipGetErrorString(e));
+    }
+    const long knob = debug_knob("bool_compress", 1);
+    if (knob == 2)
+        fprintf(stderr, "bool_plan_compress: of %llu groups %u cannot be delta-coded, %u need 10-bit deltas\n", (unsigned long long)p->ngroups, bad, wide);
+    // some group has a gap of more than 1023 columns: the 4-byte stream stays.  So it does when the 10-bit decoder would be needed
+    // on a stream that the Infinity Cache holds anyway (pokec, 128 MB: 0.033 ms as it is, 0.036 coded -- nothing to save but VALU
+    // work added; the 8-bit decoder is even there, googleplus, and ahead from ogbl_ppa's 160 MB on)
+    if (bad || (wide && knob != 3 && p->b_entries <= ((size_t)224 << 20))) {
+        (void)hipFree(d_new);
+        return GL_OK;
+    }
+    (void)hipFree(p->d_entries);
+    p->d_entries = reinterpret_cast<uint2 *>(d_new);
+    p->device_bytes -= p->b_entries;
+    p->b_entries = bytes;
+    p->device_bytes += bytes;
+    p->bool_compressed = (wide || knob == 3) ? 2 : 1;   // (knob 3: the 10-bit decoder on a plan that does not need it -- what it costs)
+    return GL_OK;
+}
+
 static Shape choose_shape_bool(uint64_t rows, uint64_t cols, uint64_t nnz, int num_cus) {
     Shape best{1, 1};
     if (rows == 0 || nnz == 0) return best;

@@ -204,6 +204,7 @@ struct gl_spmv_plan_s {
     uint32_t max_plain_rows = 0;     // tallest block without hub slots
     // (||,&&)-only layout (GL_PLAN_BOOLEAN): 4-byte pattern entries, x packed to bits once per run
     bool boolean = false;
+    int bool_compressed = 0;       // the groups are delta-coded, 3 bytes per entry (bool_plan_compress): 1 = 8-bit deltas, 2 = 10-bit
     uint32_t nphases = 0;
     uint4 *d_spans = nullptr;      // {first word of the phase in xbits, first group, end group, lo4 | hi4 << 16}
     uint32_t *d_xbits = nullptr;   // nphases * kBoolPhaseWords words
@@ -275,6 +276,7 @@ int fmt_normalize_by_outdegree(uint32_t num_rows, uint32_t num_cols, const uint3
 
 // gl_spmv_bool.hip
 int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_indices, const float *h_data);
+int bool_plan_compress(gl_spmv_plan p);   // after the build: 4-byte entries -> 3 (16-bit row slot + 8-bit column delta) where every group allows it
 int bool_plan_run(gl_spmv_plan p, const float *d_x, const uint32_t *bits, const float *d_mask, float *d_y, float zero,
                   int mask_type, hipStream_t s);
 int pack_bits(const float *d_x, uint32_t n, uint32_t *d_bits, hipStream_t s);

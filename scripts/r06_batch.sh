@@ -52,8 +52,36 @@ spmspv_priv)   # R6.10: private per-workgroup regions behind the bins (no global
       echo -n "$g $sp [$v] "; GRAPHLILY_HIP_LIB=$lib GRAPHLILY_DEBUG="$k" timeout 600 python scripts/spmspv_call_trace.py $g $sp 2>&1 | grep "blocking run\|back to back" | tr '\n' ' '; echo
     done; done; done; done 2>&1 | tee gpurun_out/r06_ab_spmspv_private_regions.txt
   ;;
+bool3)         # R6.11: the boolean layout's stream delta-coded to 3 bytes per entry (knob bool_compress: 0 off, 1 on, 2 on + report)
+  timeout 2400 python -m pytest -m gpu -x -q tests/test_gpu_format.py tests/test_gpu_bfs_sharded.py tests/test_gpu_apps.py tests/test_gpu_configs.py tests/test_gpu_spmv.py -k "bool or bfs or Logical or format or config" 2>&1 | tail -5
+  for g in ${GRAPHS:-orkut ogbn_products pokec hollywood ogbl_ppa googleplus}; do
+    GRAPHLILY_DEBUG="bool_compress=2" timeout 600 python scripts/probe_spmv.py --graph $g --flags 2 --ops 1 --no-copy --iters 5 2>&1 | grep "bool_plan_compress" | sed "s/^/$g: /"
+  done
+  for rep in 1 2; do for g in ${GRAPHS:-orkut ogbn_products pokec hollywood ogbl_ppa googleplus}; do for k in 0 1; do for d in 0.5 0.02; do
+    echo -n "$g bool_compress=$k density $d: "
+    GRAPHLILY_DEBUG="bool_compress=$k" timeout 600 python scripts/probe_spmv.py --graph $g --flags 2 --ops 1 --no-copy --iters 100 --density $d 2>&1 | grep -E "^op 1 mask" | tr '\n' ' '; echo
+  done; done; done; done
+  for rep in 1 2; do for k in 0 1; do
+    GRAPHLILY_DEBUG="bool_compress=$k" timeout 900 python benchmarks/bench_graphs.py --graphs ${BGRAPHS:-orkut,pokec} 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l)
+    print('bool_compress=$k', r['graph'], {k: v for k, v in r.items() if 'bfs' in k})"
+  done; done
+  ;;
+bool3b)        # R6.11: ring depth / 10-bit decoder on the delta-coded stream: variants = lib[:knobs] (cur = in-tree build)
+  timeout 1200 python -m pytest -m gpu -x -q tests/test_gpu_format.py -k "boolean" 2>&1 | tail -3
+  for g in ${GRAPHS:-orkut ogbn_products pokec hollywood}; do
+    GRAPHLILY_DEBUG="bool_compress=2" timeout 600 python scripts/probe_spmv.py --graph $g --flags 2 --ops 1 --no-copy --iters 5 2>&1 | grep "bool_plan_compress" | sed "s/^/$g: /"
+  done
+  for rep in 1 2; do for g in ${GRAPHS:-orkut ogbn_products pokec hollywood}; do for v in "$@"; do for d in 0.5 0.02; do
+    lib=${v%%:*}; k=""; [ "$v" != "$lib" ] && k=${v#*:}; [ "$lib" = cur ] && lib="" || lib=scripts/_variants/$lib.so
+    echo -n "$g [$v] density $d: "
+    GRAPHLILY_HIP_LIB=$lib GRAPHLILY_DEBUG="$k" timeout 600 python scripts/probe_spmv.py --graph $g --flags 2 --ops 1 --no-copy --iters 100 --density $d 2>&1 | grep -E "^op 1 mask" | sed -e 's/GTEPS.*//' | tr '\n' ' '; echo
+  done; done; done; done
+  ;;
 ab)            # same-box A/B: GRAPHS / FLAGS as in scripts/ab_variants.sh; arguments = variants (scripts/_variants/<name>.so, or cur[=KNOBS])
   bash scripts/ab_variants.sh "$@" 2>&1 | tee gpurun_out/r06_ab_${AB_NAME:-last}.txt
   ;;
-*) echo "cases: two_wg pmc_pattern lds_atomic ref_tests pytest rare hot_floor spmspv_priv ab"; exit 1;;
+*) echo "cases: two_wg pmc_pattern lds_atomic ref_tests pytest rare hot_floor spmspv_priv bool3 bool3b ab"; exit 1;;
 esac

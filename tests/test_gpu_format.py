@@ -237,3 +237,81 @@ def test_plan_creation_refuses_a_malformed_matrix(gpu, where, monkeypatch):
     plan = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, m.adj_data)
     assert plan.info()["nnz"] == m.nnz
     assert capi.SpMSpVPlan(c.num_rows, c.num_cols, c.adj_indptr, c.adj_indices, c.adj_data).info()["nnz"] == m.nnz
+
+
+def _bool_plan(m, data, knob, monkeypatch):
+    set_knob(monkeypatch, "bool_compress", knob)
+    return capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, data, 0, m.num_rows, flags=capi.GL_PLAN_BOOLEAN)
+
+
+@pytest.mark.parametrize("name", ["rmat_sym_50K", "gplus_small", "dense_1K", "uniform_10K_10"])
+@pytest.mark.parametrize("where", [HOST, DEV])
+def test_boolean_stream_delta_coding_decodes_to_the_4_byte_entries(gpu, name, where, monkeypatch):
+    """csrc/gl_spmv_bool.hip bool_plan_compress: the 3-byte stream (16-bit row slots + 8-bit column deltas, 768 bytes per group of
+    256) names exactly the entries of the 4-byte stream it was made from -- padding entries keep the ghost row slot and repeat
+    their predecessor's column -- and both plans compute the oracle's result."""
+    m = named_matrix(name)
+    io.util_round_csr_matrix_dim(m, 128, 128)
+    rng = np.random.default_rng(11)
+    data = (rng.random(m.nnz) < 0.9).astype(np.float32)
+    set_knob(monkeypatch, "bool_compress", 0)
+    raw = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, data, 0, m.num_rows, flags=capi.GL_PLAN_BOOLEAN | where)
+    set_knob(monkeypatch, "bool_compress", 1)
+    cod = capi.SpMVPlan(m.num_rows, m.num_cols, m.adj_indptr, m.adj_indices, data, 0, m.num_rows, flags=capi.GL_PLAN_BOOLEAN | where)
+    groups = raw.info()["groups"]
+    assert cod.info()["groups"] == groups
+    er, ec = raw.export("entries"), cod.export("entries")
+    assert er.nbytes == groups * 1024
+    for nm in ("bases", "units", "hub_rows", "spans"):
+        assert np.array_equal(raw.export(nm), cod.export(nm)), nm
+    om = to_oracle(m)
+    om.adj_data = data
+    x = (rng.random(m.num_cols) < 0.05).astype(np.float32)
+    dx = capi.DeviceBuffer.from_host(x)
+    want = O.spmv(om, x, 1, 0.0)
+    for p in (raw, cod):
+        dy = capi.DeviceBuffer(4 * m.num_rows)
+        p.run(dx, None, dy, 1, 0.0, 0)
+        assert np.array_equal(dy.read(np.float32, m.num_rows), want)
+    if ec.nbytes == er.nbytes:       # a gap of more than 255 columns somewhere: the plan keeps the 4-byte stream
+        assert np.array_equal(er, ec)
+        return
+    assert ec.nbytes == groups * 768 and cod.info()["device_bytes"] == raw.info()["device_bytes"] - groups * 256
+    g = ec.view(np.uint8).reshape(groups, 768)
+    slots = g[:, :512].copy().view(np.uint16).reshape(groups, 256).astype(np.uint32)       # lane l: entries 4 l .. 4 l + 3
+    delta = g[:, 512:].astype(np.uint32) | ((slots >> 14) << 8)     # lane l's word: its four deltas; bits 8..9 ride on the row slots
+    slots &= 0x3fff
+    idx = np.cumsum(delta, axis=1)
+    r = er.reshape(groups, 256)
+    r_row, r_idx = (r >> 5) & 0x3fff, ((r >> 19) << 5) | (r & 31)
+    assert np.array_equal(slots, r_row)
+    real = r_row != 0x3fff
+    assert np.array_equal(idx[real], r_idx[real])
+    # padding: the predecessor's column again
+    prev = np.concatenate([np.zeros((groups, 1), np.uint32), idx[:, :-1].astype(np.uint32)], axis=1)
+    assert np.array_equal(idx[~real], prev[~real])
+
+
+def test_boolean_stream_with_wide_column_gaps_keeps_4_byte_entries(gpu, monkeypatch):
+    """A matrix with neighbouring entries more than 1023 columns apart cannot be delta-coded: the plan stays on the 4-byte
+    stream (one plan, one format) and computes the oracle's result.  With gaps of 256..1023 columns the 10-bit decoder is needed
+    (bits 8..9 of a delta on top of its row slot): a stream this small stays as it is (the Infinity Cache holds it; the planner's
+    rule, csrc/gl_spmv_bool.hip bool_plan_compress) unless the knob forces the coding, and gaps below 256 are coded with 8 bits."""
+    rng = np.random.default_rng(5)
+    rows, per = 512, 4
+    # row r holds columns stride * (4 r .. 4 r + 3): whatever rows a block takes, its column-sorted entries are `stride` apart
+    for stride, knob, coded, hi_bits in ((1100, 1, False, False), (300, 1, False, False), (300, 3, True, True), (200, 1, True, False)):
+        cols = stride * rows * per
+        c = (np.arange(rows * per, dtype=np.uint32) * stride).astype(np.uint32)
+        m = io.CSRMatrix(rows, cols, np.ones(rows * per, np.float32), c, np.arange(0, rows * per + 1, per, dtype=np.uint32))
+        p = _bool_plan(m, m.adj_data, knob, monkeypatch)
+        groups = p.info()["groups"]
+        ent = p.export("entries")
+        assert ent.nbytes == groups * (768 if coded else 1024), (stride, knob)
+        if coded:
+            hi = ent.view(np.uint8).reshape(groups, 768)[:, :512].copy().view(np.uint16) >> 14
+            assert bool(hi.any()) == hi_bits, (stride, knob)
+        x = (rng.random(cols) < 0.3).astype(np.float32)
+        dx, dy = capi.DeviceBuffer.from_host(x), capi.DeviceBuffer(4 * rows)
+        p.run(dx, None, dy, 1, 0.0, 0)
+        assert np.array_equal(dy.read(np.float32, rows), O.spmv(to_oracle(m), x, 1, 0.0)), (stride, knob)
