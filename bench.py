@@ -31,6 +31,8 @@ import time
 
 import numpy as np
 
+_FULL_AFFINITY = os.sched_getaffinity(0)   # before the library narrows it to the GPU's NUMA node (see _cpu_baseline)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -779,6 +781,17 @@ def _cpu_baseline(csr, x, alg_bytes):
     from oracle import oracle as O
     om = O.CSR(csr.num_rows, csr.num_cols, csr.adj_data, csr.adj_indices, csr.adj_indptr)
     res = {}
+    # gl_init has bound this thread to the CPUs of the GPU's NUMA node (include/graphlily_hip.h gl_host_bind_near_device): the CPU
+    # baseline gets the whole machine back -- the affinity mask the process started with -- for its threads
+    near = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, _FULL_AFFINITY)
+    try:
+        return _cpu_baseline_timed(O, om, x, alg_bytes, csr, res)
+    finally:
+        os.sched_setaffinity(0, near)
+
+
+def _cpu_baseline_timed(O, om, x, alg_bytes, csr, res):
     for name, omp in (("single", False), ("omp", True)):
         O.spmv(om, x, O.MULADD, 0.0, omp=omp)   # warm-up
         n, t0 = 0, time.perf_counter()
@@ -789,7 +802,7 @@ def _cpu_baseline(csr, x, alg_bytes):
             if el > 10.0 or n >= 50:
                 break
         res[name] = (alg_bytes * n / el / 1e9, n, el)
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0))
     return {"value": round(res["single"][0], 3), "unit": "GB/s", "cores": 1, "kind": "port",
             "sample": "%d whole-matrix (+,x) SpMV passes of the timed workload in %.1f s, oracle C port, 1 thread"
                       % (res["single"][1], res["single"][2]),

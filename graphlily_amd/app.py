@@ -442,14 +442,24 @@ class BFS(_GraphApp):
             as_bytes = better if rb["calls"] % 32 != 31 else not better
         t_call = time.perf_counter()
         in_graph = as_bytes and not timed and (sliced or not sharded)
+        # Round 6: the pack kernel stores into the page-locked block itself, chunk by chunk with a flag behind each, and the host
+        # threads expand a chunk as soon as it has landed -- the expansion overlaps the PCIe transfer (GRAPHLILY_BFS_STREAM=0: the
+        # round-5 way, pack -> copy -> wait -> expand)
+        streamed = as_bytes and os.environ.get("GRAPHLILY_BFS_STREAM", "1") != "0"
         if as_bytes:
             pw = capi.levels_packed_words(own, pbits)
-            if st.get("lev8_key") != (own, pbits):
-                st["lev8"], st["lev8_key"] = capi.DeviceBuffer(4 * (pw + cw)), (own, pbits)
-                st["h8"] = capi.pinned_empty(4 * (pw + cw), np.uint8)
+            if st.get("lev8_key") != (own, pbits, streamed):
+                st["lev8_key"] = (own, pbits, streamed)
+                st["lev8"] = None if streamed else capi.DeviceBuffer(4 * (pw + cw))
+                st["h8"] = capi.pinned_empty(capi.levels_stream_bytes(own, pbits, cw) if streamed else 4 * (pw + cw), np.uint8)
                 st["graphs"] = {k: v for k, v in st["graphs"].items() if not k[5]}   # (graphs that recorded the old buffers)
+            if streamed:
+                capi.levels_stream_arm(st["h8"], own, pbits, cw)      # (before anything of this run is launched)
 
         def packed_read_back():
+            if streamed:
+                capi.levels_pack_stream(B.view(distance, lo, own, 4), own, pbits, ctl, cw, st["h8"])
+                return
             capi.levels_pack(B.view(distance, lo, own, 4), own, pbits, ctl, cw, st["lev8"])   # (levels, then the control words)
             st["lev8"].read_async(st["h8"])
 
@@ -483,8 +493,11 @@ class BFS(_GraphApp):
             if not (g and in_graph):
                 packed_read_back()
             res = capi.pinned_recycled(own, np.float32)       # (recycled: already paged in)
-            capi.sync_levels_unpack(res, st["h8"], own, pbits)   # (the host threads start now and spin until the stream is done)
-            c = st["h8"][4 * pw:].view(np.uint32).copy()
+            if streamed:
+                c = capi.sync_levels_unpack_stream(res, st["h8"], own, pbits, cw)   # (the host threads start now: chunk by chunk)
+            else:
+                capi.sync_levels_unpack(res, st["h8"], own, pbits)   # (the host threads start now and spin until the stream is done)
+                c = st["h8"][4 * pw:].view(np.uint32).copy()
         else:
             # the distances (this rank's slice of them) + the control words: two copies behind the schedule, one wait
             out = capi.pinned_recycled(own + cw, np.float32)

@@ -29,10 +29,11 @@ IDX_VAL = np.dtype([("index", np.uint32), ("val", np.float32)])
 
 # every symbol include/graphlily_hip.h declares (tests check the .so exports them all)
 EXPORTS = [
-    "gl_init", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
+    "gl_init", "gl_host_bind_near_device", "gl_device_count", "gl_set_stream", "gl_reset_stream", "gl_sync", "gl_last_error", "gl_version",
     "gl_graph_begin_capture", "gl_graph_end_capture", "gl_graph_launch", "gl_graph_destroy",
     "gl_bfs_bits_begin", "gl_bfs_bits_push_step", "gl_bfs_bits_pull_step",     "gl_bfs_bits_shard_step", "gl_bfs_bits_shard_finish", "gl_dist_all_gather_bits_tally",
     "gl_buf_d2h_async", "gl_levels_pack", "gl_host_levels_unpack", "gl_host_unpack_threads", "gl_buf_d2h_levels", "gl_sync_levels_unpack",
+    "gl_levels_stream_bytes", "gl_levels_stream_arm", "gl_levels_pack_stream", "gl_sync_levels_unpack_stream",
             "gl_dist_unique_id", "gl_dist_init", "gl_dist_destroy", "gl_dist_rank", "gl_dist_all_gather_f32",     "gl_dist_all_gather_sparse", "gl_dist_slice_plan",
     "gl_spmv_run_typed", "gl_spmspv_run_typed", "gl_ewise_add_typed", "gl_assign_dense_typed", "gl_assign_sparse_typed",
     "gl_assign_sparse_new_frontier_typed", "gl_sparse_to_dense_typed",
@@ -80,6 +81,8 @@ def lib():
         "gl_bfs_bits_begin": [vp, u32, vp, u32, vp, u32, u32, u32],
         "gl_buf_d2h_async": [vp, vp, ctypes.c_size_t],
         "gl_levels_pack": [vp, u32, i32, vp, u32, vp], "gl_host_levels_unpack": [vp, vp, ctypes.c_size_t, i32], "gl_host_unpack_threads": [], "gl_buf_d2h_levels": [vp, vp, ctypes.c_size_t, f32, P(i32)], "gl_sync_levels_unpack": [vp, vp, ctypes.c_size_t, i32],
+        "gl_levels_stream_bytes": [u32, i32, u32, P(ctypes.c_size_t)], "gl_levels_stream_arm": [vp, u32, i32, u32],
+        "gl_levels_pack_stream": [vp, u32, i32, vp, u32, vp], "gl_sync_levels_unpack_stream": [vp, vp, ctypes.c_size_t, i32, vp, u32],
         "gl_bfs_bits_push_step": [vp, vp, vp, vp, vp, u32, vp, f32, vp, u32, f32, i32],
         "gl_bfs_bits_pull_step": [vp, vp, vp, vp, vp, f32, vp, u32, f32, i32, f32],
         "gl_bfs_bits_shard_step": [vp, vp, vp, vp, u32, vp, f32, vp, vp, vp, u32, i32, i32, vp, u64, f32, i32, f32],
@@ -92,7 +95,7 @@ def lib():
         "gl_ewise_add_typed": [vp, vp, u32, u32, i32], "gl_assign_dense_typed": [vp, vp, u32, u32, i32, i32],
         "gl_assign_sparse_typed": [vp, vp, u32, u32], "gl_assign_sparse_new_frontier_typed": [vp, vp, vp, u32, i32],
         "gl_sparse_to_dense_typed": [vp, vp, u32, u32, u32],
-        "gl_init": [i32], "gl_device_count": [P(i32)], "gl_set_stream": [vp], "gl_reset_stream": [], "gl_sync": [],
+        "gl_init": [i32], "gl_host_bind_near_device": [P(i32), P(i32)], "gl_device_count": [P(i32)], "gl_set_stream": [vp], "gl_reset_stream": [], "gl_sync": [],
         "gl_buf_alloc": [P(vp), ctypes.c_size_t], "gl_buf_free": [vp],
         "gl_host_alloc": [P(vp), ctypes.c_size_t], "gl_host_free": [vp],
         "gl_host_pool_alloc": [P(vp), ctypes.c_size_t], "gl_host_pool_free": [vp], "gl_pool_trim": [], "gl_pool_stats": [P(u64), P(u64), P(u32)],
@@ -147,6 +150,14 @@ def _np_ptr(a):
 
 def init(device=0):
     check(lib().gl_init(int(device)))
+
+
+def host_bind_near_device():
+    """gl_host_bind_near_device: the calling thread onto the CPUs of the device's NUMA node -> (node, cpus), (-1, 0) if nothing applied.
+    gl_init does this itself unless GRAPHLILY_BIND_NUMA=0."""
+    node, cpus = ctypes.c_int(-1), ctypes.c_int(0)
+    check(lib().gl_host_bind_near_device(ctypes.byref(node), ctypes.byref(cpus)))
+    return node.value, cpus.value
 
 
 def pool_stats():
@@ -667,6 +678,31 @@ def sync_levels_unpack(dst, src, n, bits):
     """gl_sync_levels_unpack: wait for the library's stream, then host_levels_unpack -- the threads start before the wait."""
     assert dst.dtype == np.float32 and src.dtype == np.uint8 and dst.shape[0] >= n and src.shape[0] * (8 // bits) >= n
     check(lib().gl_sync_levels_unpack(_np_ptr(dst), _np_ptr(src), int(n), int(bits)))
+
+
+def levels_stream_bytes(n, bits, tail_words):
+    """gl_levels_stream_bytes: size of the page-locked block of a streamed read-back (packed levels, tail words, chunk flags)"""
+    b = ctypes.c_size_t(0)
+    check(lib().gl_levels_stream_bytes(int(n), int(bits), int(tail_words), ctypes.byref(b)))
+    return int(b.value)
+
+
+def levels_stream_arm(block, n, bits, tail_words):
+    """gl_levels_stream_arm: clear the block's chunk flags -- on the host, before the pack (or the graph holding it) is launched"""
+    check(lib().gl_levels_stream_arm(_np_ptr(block), int(n), int(bits), int(tail_words)))
+
+
+def levels_pack_stream(levels, n, bits, tail, tail_words, block):
+    """gl_levels_pack_stream: levels_pack whose kernel stores into the page-locked host `block` (pinned_empty) chunk by chunk"""
+    check(lib().gl_levels_pack_stream(_p(levels), int(n), int(bits), _p(tail), int(tail_words), _np_ptr(block)))
+
+
+def sync_levels_unpack_stream(dst, block, n, bits, tail_words):
+    """gl_sync_levels_unpack_stream: the floats of a streamed read-back (chunks expanded as they land) -> the tail words"""
+    assert dst.dtype == np.float32 and dst.shape[0] >= n and block.dtype == np.uint8
+    tail = np.empty(tail_words, np.uint32)
+    check(lib().gl_sync_levels_unpack_stream(_np_ptr(dst), _np_ptr(block), int(n), int(bits), _np_ptr(tail), int(tail_words)))
+    return tail
 
 
 def d2h_levels(dst, buf, n, max_level):

@@ -8,6 +8,8 @@
 #include <unistd.h>
 #include <emmintrin.h>
 #include <sys/mman.h>
+#include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -200,6 +202,39 @@ __global__ __launch_bounds__(256) void levels_pack_kernel(const float4 *__restri
         for (uint32_t i = threadIdx.x; i < tail_words; i += 256u) dst[tail_at + i] = tail[i];
 }
 
+// gl_levels_pack_stream: the same words stored straight into page-locked HOST memory, a chunk of kLevelsChunkWords per workgroup,
+// each chunk's flag raised behind its words (system-scope release: the flag does not overtake the data on its way to the host) --
+// the host expands chunk k while chunk k + 1 is still crossing PCIe.  The last workgroup delivers the tail words the same way.
+constexpr uint32_t kLevelsChunkWords = GL_LEVELS_CHUNK_WORDS;
+template <int BITS>
+__global__ __launch_bounds__(256) void levels_pack_stream_kernel(const float4 *__restrict__ src, uint32_t *__restrict__ dst, uint32_t nwords,
+                                                                 const uint32_t *__restrict__ tail, uint32_t tail_words, uint32_t tail_at,
+                                                                 uint32_t *__restrict__ flags, uint32_t nchunks) {
+    constexpr uint32_t M = (1u << BITS) - 1u;
+    const uint32_t c = blockIdx.x;
+    auto word = [&](uint32_t i) -> uint32_t {
+        if (BITS == 8) {
+            const float4 v = src[i];
+            return ((uint32_t)v.x & M) | (((uint32_t)v.y & M) << 8) | (((uint32_t)v.z & M) << 16) | (((uint32_t)v.w & M) << 24);
+        }
+        const float4 v = src[2u * i], w = src[2u * i + 1u];
+        return ((uint32_t)v.x & M) | (((uint32_t)v.y & M) << 4) | (((uint32_t)v.z & M) << 8) | (((uint32_t)v.w & M) << 12) |
+               (((uint32_t)w.x & M) << 16) | (((uint32_t)w.y & M) << 20) | (((uint32_t)w.z & M) << 24) | (((uint32_t)w.w & M) << 28);
+    };
+    if (c + 1u < nchunks) {
+        // 16 bytes per lane and store (1 KB per wavefront instruction: whole PCIe write bursts), the odd words of the last chunk singly
+        const uint32_t begin = c * kLevelsChunkWords, end = min(nwords, begin + kLevelsChunkWords), end4 = begin + ((end - begin) & ~3u);
+        for (uint32_t i = begin + 4u * threadIdx.x; i < end4; i += 1024u)
+            *reinterpret_cast<uint4 *>(dst + i) = make_uint4(word(i), word(i + 1u), word(i + 2u), word(i + 3u));
+        for (uint32_t i = end4 + threadIdx.x; i < end; i += 256u) dst[i] = word(i);
+    } else {
+        for (uint32_t i = threadIdx.x; i < tail_words; i += 256u) dst[tail_at + i] = tail[i];
+    }
+    __threadfence_system();   // every thread's stores have left for the host ...
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flags + (size_t)c * GL_LEVELS_FLAG_STRIDE_WORDS, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the flag
+}
+
 // gl_buf_d2h_levels: the same packing for a buffer that is only EXPECTED to hold small integers -- every value is checked
 // (a non-negative integer no larger than the field allows), a violation raises flag[0] and the caller falls back to the floats
 template <int BITS>
@@ -270,6 +305,92 @@ int gl_device_count(int *count) {
     return GL_OK;
 }
 
+// ---- host threads next to the device.  A blocking call of this library ends on the host -- the wait for the stream, the
+// expansion of a packed BFS result on a few threads, copies out of page-locked memory -- and on a two-socket host that half costs
+// 40-100 us more from the far socket than from the GPU's own (orkut's BFS, same box, process by process: 0.41-0.49 ms unbound, 0.36-
+// 0.39 bound; profiles/r06_bfs_numa_and_streamed_readback.txt).  gl_init therefore restricts the CALLING thread (and, through
+// inheritance, the threads it creates later: the OpenMP team of the expansion) to the CPUs of the device's NUMA node, within the
+// affinity mask the process had at the first call; GRAPHLILY_BIND_NUMA=0 leaves the affinity alone.
+namespace gl {
+struct NearCpus {
+    bool have_original = false, bound = false;
+    cpu_set_t original, near;
+    int node = -1, count = 0;
+    unsigned generation = 0;
+};
+static NearCpus &near_cpus() {
+    static NearCpus n;
+    return n;
+}
+// team threads that existed before the binding follow it at their next use
+static void bind_this_thread_once() {
+    NearCpus &n = near_cpus();
+    static thread_local unsigned seen = 0;
+    if (!n.bound || seen == n.generation) return;
+    seen = n.generation;
+    (void)sched_setaffinity(0, sizeof(n.near), &n.near);
+}
+}  // namespace gl
+
+int gl_host_bind_near_device(int *numa_node, int *cpus) {
+    GL_REQUIRE_INIT();
+    if (numa_node) *numa_node = -1;
+    if (cpus) *cpus = 0;
+    gl::NearCpus &n = gl::near_cpus();
+    if (!n.have_original) {
+        CPU_ZERO(&n.original);
+        if (sched_getaffinity(0, sizeof(n.original), &n.original) != 0) return GL_OK;
+        n.have_original = true;
+    }
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof(id) - 1, gl::ctx().device) != hipSuccess) {
+        (void)hipGetLastError();
+        return GL_OK;
+    }
+    for (char *q = id; *q; q++) *q = (char)tolower((unsigned char)*q);
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", id);
+    int node = -1;
+    if (FILE *f = fopen(path, "r")) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    if (node < 0) return GL_OK;   // (one node, or the platform does not say)
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    char list[4096] = {0};
+    if (FILE *f = fopen(path, "r")) {
+        if (!fgets(list, sizeof(list), f)) list[0] = 0;
+        fclose(f);
+    }
+    cpu_set_t want;
+    CPU_ZERO(&want);
+    for (const char *q = list; *q;) {   // "0-63,128-191"
+        char *end = nullptr;
+        const long a = strtol(q, &end, 10);
+        if (end == q) break;
+        long b = a;
+        if (*end == '-') {
+            q = end + 1;
+            b = strtol(q, &end, 10);
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0 && CPU_ISSET((int)c, &n.original)) CPU_SET((int)c, &want);
+        q = (*end == ',') ? end + 1 : end;
+        if (*end != ',' ) break;
+    }
+    const int count = CPU_COUNT(&want);
+    if (count == 0 || count == CPU_COUNT(&n.original)) return GL_OK;   // nothing of the node is allowed, or nothing else is
+    if (sched_setaffinity(0, sizeof(want), &want) != 0) return GL_OK;
+    n.near = want;
+    n.node = node;
+    n.count = count;
+    n.bound = true;
+    n.generation++;
+    if (numa_node) *numa_node = node;
+    if (cpus) *cpus = count;
+    return GL_OK;
+}
+
 int gl_init(int device) {
     gl::Context &c = gl::ctx();
     int n = 0;
@@ -298,6 +419,7 @@ int gl_init(int device) {
         c.initialized = false;
         return rc;
     }
+    if (!(getenv("GRAPHLILY_BIND_NUMA") && atoi(getenv("GRAPHLILY_BIND_NUMA")) == 0)) (void)gl_host_bind_near_device(nullptr, nullptr);
     return GL_OK;
 }
 
@@ -899,6 +1021,7 @@ static int levels_unpack_impl(float *h_dst, const void *h_src, size_t n, int bit
 #pragma omp parallel num_threads(nt)
     {
         const size_t T = (size_t)omp_get_num_threads(), t = (size_t)omp_get_thread_num();
+        gl::bind_this_thread_once();
         if (wait_stream) {
             if (t == 0) {
                 waited = hipStreamSynchronize(gl::ctx().stream);
@@ -945,6 +1068,142 @@ int gl_sync_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits) {
     GL_REQUIRE_INIT();
     GL_ARG(((h_dst != nullptr && h_src != nullptr) || n == 0) && (bits == 4 || bits == 8) && (bits == 8 || (n & 1u) == 0));
     return levels_unpack_impl(h_dst, h_src, n, bits, true);
+}
+
+// ---- the streamed form: pack kernel -> page-locked host block in flagged chunks -> the team expands chunks as they land
+// block layout (32-bit words): [0, nwords) packed levels | tail_at = nwords rounded up to 4: tail_words raw words | flags_at =
+// the next multiple of 16 words: one flag per chunk + one for the tail, GL_LEVELS_FLAG_STRIDE_WORDS apart (a cache line each)
+struct LevelsStream {
+    uint32_t nwords, tail_at, flags_at, nchunks;   // nchunks counts the tail's
+    size_t bytes;
+};
+static LevelsStream levels_stream_layout(uint32_t n, int bits, uint32_t tail_words) {
+    LevelsStream L;
+    L.nwords = n / (32u / (uint32_t)bits);
+    L.tail_at = (L.nwords + 3u) & ~3u;
+    L.flags_at = (L.tail_at + tail_words + 15u) & ~15u;
+    L.nchunks = (L.nwords + gl::kLevelsChunkWords - 1u) / gl::kLevelsChunkWords + 1u;
+    L.bytes = 4u * ((size_t)L.flags_at + (size_t)L.nchunks * GL_LEVELS_FLAG_STRIDE_WORDS);
+    return L;
+}
+
+int gl_levels_stream_bytes(uint32_t n, int bits, uint32_t tail_words, size_t *bytes) {
+    GL_ARG(bytes != nullptr && (bits == 4 || bits == 8) && (n & 7u) == 0);
+    *bytes = levels_stream_layout(n, bits, tail_words).bytes;
+    return GL_OK;
+}
+
+int gl_levels_stream_arm(void *h_block, uint32_t n, int bits, uint32_t tail_words) {
+    GL_ARG(h_block != nullptr && (bits == 4 || bits == 8) && (n & 7u) == 0);
+    const LevelsStream L = levels_stream_layout(n, bits, tail_words);
+    uint32_t *flags = static_cast<uint32_t *>(h_block) + L.flags_at;
+    for (uint32_t c = 0; c < L.nchunks; c++) __atomic_store_n(flags + (size_t)c * GL_LEVELS_FLAG_STRIDE_WORDS, 0u, __ATOMIC_RELAXED);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);   // (the launch that follows is what orders these against the kernel's stores)
+    return GL_OK;
+}
+
+int gl_levels_pack_stream(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *h_block) {
+    GL_REQUIRE_INIT();
+    GL_ARG(d_levels != nullptr && h_block != nullptr && (bits == 4 || bits == 8) && (n & 7u) == 0);
+    GL_ARG((((uintptr_t)d_levels | (uintptr_t)h_block) & 15u) == 0 && (tail_words == 0 || d_tail != nullptr));
+    hipPointerAttribute_t at;
+    void *dev_view = nullptr;
+    if (hipPointerGetAttributes(&at, h_block) != hipSuccess || at.type != hipMemoryTypeHost ||
+        hipHostGetDevicePointer(&dev_view, h_block, 0) != hipSuccess || dev_view == nullptr) {
+        (void)hipGetLastError();
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_levels_pack_stream: the block must be page-locked host memory (gl_host_alloc)");
+    }
+    const LevelsStream L = levels_stream_layout(n, bits, tail_words);
+    uint32_t *dst = static_cast<uint32_t *>(dev_view);
+    if (bits == 8)
+        gl::levels_pack_stream_kernel<8><<<L.nchunks, 256, 0, gl::ctx().stream>>>(reinterpret_cast<const float4 *>(d_levels), dst, L.nwords, d_tail,
+                                                                                  tail_words, L.tail_at, dst + L.flags_at, L.nchunks);
+    else
+        gl::levels_pack_stream_kernel<4><<<L.nchunks, 256, 0, gl::ctx().stream>>>(reinterpret_cast<const float4 *>(d_levels), dst, L.nwords, d_tail,
+                                                                                  tail_words, L.tail_at, dst + L.flags_at, L.nchunks);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// 32-level blocks [b0, b1) of the packed source -> floats (the SSE2 loops of levels_unpack_impl)
+static inline void levels_expand_blocks(float *h_dst, const uint8_t *src, size_t b0, size_t b1, int bits) {
+    if (bits == 8) {
+        for (size_t b = b0; b < b1; b++) {
+            expand16_stream(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b)), h_dst + 32u * b);
+            expand16_stream(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b + 16u)), h_dst + 32u * b + 16u);
+        }
+    } else {
+        const __m128i m = _mm_set1_epi8(0x0f);
+        for (size_t b = b0; b < b1; b++) {
+            const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 16u * b));
+            const __m128i lo = _mm_and_si128(v, m), hi = _mm_and_si128(_mm_srli_epi16(v, 4), m);
+            expand16_stream(_mm_unpacklo_epi8(lo, hi), h_dst + 32u * b);
+            expand16_stream(_mm_unpackhi_epi8(lo, hi), h_dst + 32u * b + 16u);
+        }
+    }
+}
+
+int gl_sync_levels_unpack_stream(float *h_dst, const void *h_block, size_t n, int bits, uint32_t *h_tail, uint32_t tail_words) {
+    GL_REQUIRE_INIT();
+    GL_ARG(((h_dst != nullptr && h_block != nullptr) || n == 0) && (bits == 4 || bits == 8) && (n & 7u) == 0 && n <= 0xffffffffull);
+    GL_ARG(tail_words == 0 || h_tail != nullptr);
+    const LevelsStream L = levels_stream_layout((uint32_t)n, bits, tail_words);
+    const uint32_t *words = static_cast<const uint32_t *>(h_block);
+    const uint8_t *src = static_cast<const uint8_t *>(h_block);
+    const uint32_t *flags = words + L.flags_at;
+    const int nt = host_expand_threads(n);
+    (void)nt;
+    const bool aligned = ((uintptr_t)h_dst & 15u) == 0;
+    const uint32_t levels_per_word = 32u / (uint32_t)bits;
+    int drained = 0, missing = 0;
+    hipError_t waited = hipSuccess;
+    // thread 0 waits for the stream (and so learns of a failed launch: the flags of a schedule that died never come); the others
+    // take the chunks round-robin, each as soon as its flag is up.  With one thread: wait, then expand everything.
+#pragma omp parallel num_threads(nt)
+    {
+        const uint32_t T = (uint32_t)omp_get_num_threads(), t = (uint32_t)omp_get_thread_num();
+        gl::bind_this_thread_once();
+        if (t == 0) {
+            waited = hipStreamSynchronize(gl::ctx().stream);
+            __atomic_store_n(&drained, 1, __ATOMIC_RELEASE);
+        }
+        const uint32_t W = T > 1u ? T - 1u : 1u, w = T > 1u ? t - 1u : 0u;
+        if (T == 1u || t > 0u) {
+            for (uint32_t c = w; c + 1u < L.nchunks; c += W) {
+                const uint32_t *f = flags + (size_t)c * GL_LEVELS_FLAG_STRIDE_WORDS;
+                bool up = false;
+                for (uint32_t spins = 0;; spins++) {
+                    if (__atomic_load_n(f, __ATOMIC_ACQUIRE) != 0u) { up = true; break; }
+                    if (__atomic_load_n(&drained, __ATOMIC_ACQUIRE)) {   // the stream is done: whatever it wrote is visible now
+                        up = __atomic_load_n(f, __ATOMIC_ACQUIRE) != 0u;
+                        break;
+                    }
+                    if (spins < (1u << 16)) _mm_pause();
+                    else usleep(50);
+                }
+                if (!up) {
+                    __atomic_store_n(&missing, 1, __ATOMIC_RELAXED);
+                    break;
+                }
+                const size_t w0 = (size_t)c * gl::kLevelsChunkWords, w1 = std::min<size_t>(L.nwords, w0 + gl::kLevelsChunkWords);
+                const size_t l0 = w0 * levels_per_word, l1 = w1 * levels_per_word;     // (a chunk holds whole 32-level blocks)
+                if (aligned) {
+                    levels_expand_blocks(h_dst, src, l0 / 32u, l1 / 32u, bits);
+                    for (size_t i = l1 / 32u * 32u; i < l1; i++)
+                        h_dst[i] = bits == 8 ? (float)src[i] : (float)((src[i / 2u] >> (4u * (i & 1u))) & 15u);
+                } else {
+                    for (size_t i = l0; i < l1; i++) h_dst[i] = bits == 8 ? (float)src[i] : (float)((src[i / 2u] >> (4u * (i & 1u))) & 15u);
+                }
+            }
+            _mm_sfence();
+        }
+    }
+    if (waited != hipSuccess) return gl::set_error(GL_ERR_HIP, "gl_sync_levels_unpack_stream: %s", hipGetErrorString(waited));
+    if (missing || __atomic_load_n(flags + (size_t)(L.nchunks - 1u) * GL_LEVELS_FLAG_STRIDE_WORDS, __ATOMIC_ACQUIRE) == 0u)
+        return gl::set_error(GL_ERR_INVALID_ARG, "gl_sync_levels_unpack_stream: the stream ended without delivering every chunk "
+                                                 "(was gl_levels_pack_stream enqueued for this block?)");
+    if (tail_words) memcpy(h_tail, words + L.tail_at, 4u * (size_t)tail_words);
+    return GL_OK;
 }
 
 int gl_buf_d2h_levels(float *h_dst, const float *d_src, size_t n, float max_level, int *packed) {

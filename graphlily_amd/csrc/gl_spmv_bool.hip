@@ -16,10 +16,11 @@
 // Round 6: the stream is DELTA-CODED to 3 bytes per entry when every group allows it (bool_plan_compress, a pass over the
 // formatted groups on the device, whichever formatter wrote them): a group's 256 entries are sorted by column, so an entry keeps
 // its 16-bit row slot and the 8-bit distance to its predecessor's bit index -- lane l holds entries 4 l .. 4 l + 3: 8 bytes of
-// slots + 4 bytes of deltas, two coalesced loads per group, 768 bytes instead of 1024 -- and the kernel rebuilds the indices with
-// one v_sad_u8 (a lane's four deltas), ONE 32-bit prefix scan over the lanes (six DPP adds per 256 entries) and three adds.
-// Padding entries repeat their predecessor's index with the ghost row slot.  A plan with a gap of more than 255 columns inside
-// some group keeps the 4-byte form (none of the stand-ins has one: a block's columns are a few apart).
+// slots + 4 bytes of deltas, one global_load_dwordx3 per lane and group, 768 bytes instead of 1024 -- and the kernel rebuilds the
+// indices with one v_sad_u8 (a lane's four deltas), ONE 32-bit prefix scan over the lanes (six DPP adds per 256 entries) and three
+// adds.  Padding entries repeat their predecessor's index with the ghost row slot.  Deltas of 256..1023 put bits 8..9 into the
+// two spare bits of the row slot (a second decoder, three more instructions per entry: pokec's rare columns); a plan with a gap
+// of more than 1023 columns inside some group keeps the 4-byte form.
 #include "gl_spmv_plan.h"
 #include "gl_bfs_shard.h"
 
@@ -128,18 +129,19 @@ struct BoolElem {   // one lane's share of a group
 };
 constexpr uint32_t kBoolGroupBytesC = kBoolGroup * 3u;   // compressed group: 2 B of row slot + 1 B of delta per entry
 // KEEP bit 0: no non-temporal hint -- plans that fit the Infinity Cache stay there between runs (gl_common.h);
-// KEEP bit 1: the delta-coded 3-byte stream (v[0], v[1]: four 16-bit row slots, v[2]: four 8-bit deltas, v[3] unused);
+// KEEP bit 1: the delta-coded 3-byte stream (v[0], v[1]: four 16-bit row slots, v[2]: four 8-bit deltas, v[3] unused; 12 bytes per lane);
 // KEEP bit 2 (with bit 1): some delta of the plan needs 10 bits, and bits 8..9 sit on top of the 14-bit row slots
 template <int KEEP>
 __device__ __forceinline__ BoolElem bool_load(const void *entries, size_t group, uint32_t lane) {
     BoolElem e;
     if ((KEEP & 2) && kBoolLane == 4) {
-        const unsigned char *g = static_cast<const unsigned char *>(entries) + group * kBoolGroupBytesC;
-        const uint2 *q = reinterpret_cast<const uint2 *>(g) + lane;
-        const uint32_t *d = reinterpret_cast<const uint32_t *>(g + kBoolGroup * 2u) + lane;
-        const uint2 t = (KEEP & 1) ? load_stream_keep(q) : load_stream_nt(q);
-        e.v[0] = t.x, e.v[1] = t.y;
-        e.v[2] = (KEEP & 1) ? *d : __builtin_nontemporal_load(d);
+        // a lane's 12 bytes are contiguous: ONE global_load_dwordx3 per lane and group (4-byte aligned)
+        typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+        typedef u32x3_t __attribute__((aligned(4))) u32x3_packed_t;
+        const u32x3_packed_t *q =
+            reinterpret_cast<const u32x3_packed_t *>(static_cast<const unsigned char *>(entries) + group * kBoolGroupBytesC + lane * 12u);
+        const u32x3_t t = (KEEP & 1) ? *q : __builtin_nontemporal_load(q);
+        e.v[0] = t.x, e.v[1] = t.y, e.v[2] = t.z;
         e.v[kBoolLane - 1] = 0u;
         return e;
     }
@@ -890,9 +892,8 @@ __global__ __launch_bounds__(256) void bool_compress_kernel(const uint4 *__restr
             continue;
         }
         if (__ballot(!narrow) != 0ull && lane == 0) atomicAdd(bad + 1, 1u);
-        unsigned char *o = out + (size_t)g * kBoolGroupBytesC;
-        reinterpret_cast<uint2 *>(o)[lane] = make_uint2(row[0] | (row[1] << 16), row[2] | (row[3] << 16));
-        reinterpret_cast<uint32_t *>(o + kBoolGroup * 2u)[lane] = deltas;
+        uint32_t *o = reinterpret_cast<uint32_t *>(out + (size_t)g * kBoolGroupBytesC) + 3u * lane;
+        o[0] = row[0] | (row[1] << 16), o[1] = row[2] | (row[3] << 16), o[2] = deltas;
     }
 }
 

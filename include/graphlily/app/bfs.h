@@ -146,22 +146,29 @@ private:
         uint32_t *ctl = (uint32_t *)s.both.raw() + n;
         size_t packed_words = 0;
         const int pw = bits == 4 ? 0 : 1;
+        // Round 6: the pack kernel stores into the page-locked block itself, a flag behind every chunk, and the host threads expand
+        // chunk k while chunk k + 1 crosses PCIe (gl_levels_pack_stream; GRAPHLILY_BFS_STREAM=0: pack -> copy -> wait -> expand)
+        static const bool streamed = !(getenv("GRAPHLILY_BFS_STREAM") && atoi(getenv("GRAPHLILY_BFS_STREAM")) == 0);
         if (packed) {
             packed_words = ((size_t)n * bits / 8 + 15) / 16 * 4;     // levels, padded to 16 bytes; the control words follow
-            const size_t bytes = 4 * (packed_words + s.ctl_words);
+            size_t bytes = 4 * (packed_words + s.ctl_words);
+            if (streamed) GRAPHLILY_CHECK(gl_levels_stream_bytes(n, bits, s.ctl_words, &bytes));
             if (s.h_packed_bytes[pw] != bytes) {   // (first use of this width since the schedule's buffers were made: no graph holds it yet)
                 if (s.h_packed[pw]) gl_host_free(s.h_packed[pw]);
                 GRAPHLILY_CHECK(gl_host_alloc(&s.h_packed[pw], bytes));
                 s.h_packed_bytes[pw] = bytes;
-                s.packed[pw] = DeviceBuffer(bytes);
+                if (!streamed) s.packed[pw] = DeviceBuffer(bytes);
             }
+            if (streamed) GRAPHLILY_CHECK(gl_levels_stream_arm(s.h_packed[pw], n, bits, s.ctl_words));   // (before this run's launches)
         }
+        auto read_back = [&]() -> int {
+            if (streamed) return gl_levels_pack_stream((const float *)s.both.raw(), n, bits, ctl, s.ctl_words, s.h_packed[pw]);
+            const int rc = gl_levels_pack((const float *)s.both.raw(), n, bits, ctl, s.ctl_words, s.packed[pw].raw());
+            return rc != GL_OK ? rc : gl_buf_d2h_async(s.h_packed[pw], s.packed[pw].raw(), s.h_packed_bytes[pw]);
+        };
         auto everything = [&] {
             enqueue_schedule_(N, threshold, pull_only);
-            if (packed) {
-                GRAPHLILY_CHECK(gl_levels_pack((const float *)s.both.raw(), n, bits, ctl, s.ctl_words, s.packed[pw].raw()));
-                GRAPHLILY_CHECK(gl_buf_d2h_async(s.h_packed[pw], s.packed[pw].raw(), s.h_packed_bytes[pw]));
-            }
+            if (packed) GRAPHLILY_CHECK(read_back());
         };
         GRAPHLILY_CHECK(gl_buf_fill_u32(ctl + 2, source, 1));          // ctl[2] = source: the recorded sequence serves any source
         uint32_t tbits;
@@ -178,10 +185,7 @@ private:
                 gl_graph rec = nullptr;
                 if (gl_graph_begin_capture() == GL_OK) {
                     enqueue_schedule_(N, threshold, pull_only);
-                    if (packed) {
-                        gl_levels_pack((const float *)s.both.raw(), n, bits, ctl, s.ctl_words, s.packed[pw].raw());
-                        gl_buf_d2h_async(s.h_packed[pw], s.packed[pw].raw(), s.h_packed_bytes[pw]);
-                    }
+                    if (packed) (void)read_back();
                     if (gl_graph_end_capture(&rec) != GL_OK) rec = nullptr;
                 }
                 s.graphs[key] = rec;      // (nullptr: capture is not possible here -- keep enqueueing)
@@ -194,8 +198,12 @@ private:
         }
         std::vector<uint32_t> c(s.ctl_words);
         if (packed) {
-            GRAPHLILY_CHECK(gl_sync_levels_unpack((float *)result.data(), s.h_packed[pw], n, bits));
-            memcpy(c.data(), (const uint32_t *)s.h_packed[pw] + packed_words, 4u * s.ctl_words);
+            if (streamed) {
+                GRAPHLILY_CHECK(gl_sync_levels_unpack_stream((float *)result.data(), s.h_packed[pw], n, bits, c.data(), s.ctl_words));
+            } else {
+                GRAPHLILY_CHECK(gl_sync_levels_unpack((float *)result.data(), s.h_packed[pw], n, bits));
+                memcpy(c.data(), (const uint32_t *)s.h_packed[pw] + packed_words, 4u * s.ctl_words);
+            }
         } else {
             GRAPHLILY_CHECK(gl_buf_d2h(result.data(), s.both.raw(), sizeof(float) * (size_t)n));
             GRAPHLILY_CHECK(gl_buf_d2h(c.data(), ctl, 4u * s.ctl_words));

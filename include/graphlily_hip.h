@@ -57,7 +57,13 @@ typedef struct gl_spmspv_plan_s *gl_spmspv_plan; /* formatted matrix for SpMSpV 
  * Replaces BaseModule::set_up_runtime / ModuleCollection::set_up_runtime
  * (module/base_module.h:106-133, app/module_collection.h:69-114): device
  * discovery, context, command queue.  No bitstream to load. */
-int gl_init(int device);                /* hipSetDevice + library stream        */
+int gl_init(int device);                /* hipSetDevice + library stream (+ gl_host_bind_near_device unless GRAPHLILY_BIND_NUMA=0) */
+/* Restrict the CALLING thread -- and the threads it creates from now on, the library's own host team included -- to the CPUs of
+ * the device's NUMA node (sysfs: the PCI device's numa_node, the node's cpulist), within the affinity mask the process had at
+ * the library's first call.  The host half of a blocking call (the wait, the expansion of a packed result, copies out of
+ * page-locked memory) costs 40-100 us more from the far socket of a two-socket host.  *numa_node / *cpus (may be NULL): what was
+ * applied, -1 / 0 when nothing was (one node, sysfs silent, or no CPU of the node allowed).  Never an error. */
+int gl_host_bind_near_device(int *numa_node, int *cpus);
 int gl_device_count(int *count);
 int gl_set_stream(void *hip_stream);    /* adopt a caller-owned hipStream_t; NULL is HIP's default (null) stream */
 int gl_reset_stream(void);              /* go back to the library-owned stream  */
@@ -99,6 +105,19 @@ int gl_levels_pack(const float *d_levels, uint32_t n, int bits, const uint32_t *
 int gl_host_unpack_threads(void);   /* how many threads gl_sync_levels_unpack uses for a large vector (packing pays from 4 on) */
 int gl_sync_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits);
 int gl_host_levels_unpack(float *h_dst, const void *h_src, size_t n, int bits);   /* the expansion alone (needs no GPU) */
+/* The same read-back STREAMED (round 6): gl_levels_pack_stream's kernel stores the packed words straight into a page-locked host
+ * block (gl_host_alloc of gl_levels_stream_bytes) in chunks of GL_LEVELS_CHUNK_WORDS, raising a flag word behind each chunk
+ * (system-scope release) and behind the tail words; gl_sync_levels_unpack_stream starts the team, whose master waits for the
+ * library's stream while the others expand chunk after chunk as the flags come up -- the expansion overlaps the PCIe transfer
+ * instead of following it -- and copies the tail words out.  gl_levels_stream_arm clears the flags: call it on the host BEFORE
+ * the pack (or the graph that holds it) is launched, once per run; the block belongs to one run at a time.  Block layout, in
+ * 32-bit words: packed levels | tail at the next multiple of 4 | flags at the next multiple of 16, one cache line each. */
+#define GL_LEVELS_CHUNK_WORDS 2048u
+#define GL_LEVELS_FLAG_STRIDE_WORDS 16u
+int gl_levels_stream_bytes(uint32_t n, int bits, uint32_t tail_words, size_t *bytes);
+int gl_levels_stream_arm(void *h_block, uint32_t n, int bits, uint32_t tail_words);
+int gl_levels_pack_stream(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *h_block);
+int gl_sync_levels_unpack_stream(float *h_dst, const void *h_block, size_t n, int bits, uint32_t *h_tail, uint32_t tail_words);
 /* Blocking read-back of n floats that are EXPECTED to be BFS levels no larger than max_level (a caller that has seen only
  * level-writing kernels touch the buffer): packed on the device with every value checked, copied as nibbles / bytes, expanded
  * on host threads; if any value is not a small non-negative integer the floats themselves are copied -- the result is always

@@ -169,6 +169,18 @@ def test_host_helpers_need_no_gpu():
     capi.check(L.gl_host_pool_free(p))
 
 
+def test_levels_stream_block_layout():
+    """gl_levels_stream_bytes (needs no GPU): packed words, the tail on the next 16-byte boundary, one 64-byte flag line per chunk of
+    GL_LEVELS_CHUNK_WORDS words plus one for the tail."""
+    for n, bits, tw in ((8, 4, 0), (8, 8, 48), (2048 * 8, 4, 48), (2048 * 8 + 8, 4, 48), (3072448, 4, 64), (3072448, 8, 64)):
+        words = n // (32 // bits)
+        tail_at = (words + 3) & ~3
+        flags_at = (tail_at + tw + 15) & ~15
+        chunks = -(-words // 2048) + 1
+        assert capi.levels_stream_bytes(n, bits, tw) == 4 * (flags_at + 16 * chunks), (n, bits, tw)
+        assert tail_at == capi.levels_packed_words(n, bits)
+
+
 def test_host_levels_unpack():
     """gl_host_levels_unpack (the host half of the BFS packed read-back): every byte / nibble value, sizes on both sides of
     the thread-count steps, nothing written past n."""

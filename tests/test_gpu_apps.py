@@ -408,4 +408,13 @@ def test_bfs_byte_read_back_equals_the_float_one(gpu, monkeypatch):
     ref2 = O.bfs(to_oracle(lm), 0, 300)
     assert ref2.max() > 255
     assert np.array_equal(b2.pull(0, 300), ref2)
-    assert np.array_equal(b2.pull(0, 200), O.bfs(to_oracle(lm), 0, 200))      # (and with bytes again)
+    ref200 = O.bfs(to_oracle(lm), 0, 200)
+    assert np.array_equal(b2.pull(0, 200), ref200)      # (and with bytes again)
+    # the packed levels streamed into the host block chunk by chunk (the default) and the round-5 way: pack, copy, wait, expand
+    ref9 = O.bfs(to_oracle(lm), 0, 9)
+    for stream in ("0", "1", "0", "1"):
+        monkeypatch.setenv("GRAPHLILY_BFS_STREAM", stream)
+        for _ in range(4):               # eager, capture, replays
+            assert np.array_equal(b2.pull(0, 200), ref200)
+            assert np.array_equal(b2.pull_push(0, 9, 0.01), ref9)      # (nibbles)
+        assert b2.readback_["way"] == "packed"

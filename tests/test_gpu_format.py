@@ -277,9 +277,9 @@ def test_boolean_stream_delta_coding_decodes_to_the_4_byte_entries(gpu, name, wh
         assert np.array_equal(er, ec)
         return
     assert ec.nbytes == groups * 768 and cod.info()["device_bytes"] == raw.info()["device_bytes"] - groups * 256
-    g = ec.view(np.uint8).reshape(groups, 768)
-    slots = g[:, :512].copy().view(np.uint16).reshape(groups, 256).astype(np.uint32)       # lane l: entries 4 l .. 4 l + 3
-    delta = g[:, 512:].astype(np.uint32) | ((slots >> 14) << 8)     # lane l's word: its four deltas; bits 8..9 ride on the row slots
+    g = ec.view(np.uint8).reshape(groups, 64, 12)                   # lane l: 8 bytes of row slots, 4 of deltas: entries 4 l .. 4 l + 3
+    slots = g[:, :, :8].copy().view(np.uint16).reshape(groups, 256).astype(np.uint32)
+    delta = g[:, :, 8:].reshape(groups, 256).astype(np.uint32) | ((slots >> 14) << 8)      # bits 8..9 of a delta ride on its row slot
     slots &= 0x3fff
     idx = np.cumsum(delta, axis=1)
     r = er.reshape(groups, 256)
@@ -309,7 +309,7 @@ def test_boolean_stream_with_wide_column_gaps_keeps_4_byte_entries(gpu, monkeypa
         ent = p.export("entries")
         assert ent.nbytes == groups * (768 if coded else 1024), (stride, knob)
         if coded:
-            hi = ent.view(np.uint8).reshape(groups, 768)[:, :512].copy().view(np.uint16) >> 14
+            hi = ent.view(np.uint8).reshape(groups, 64, 12)[:, :, :8].copy().view(np.uint16) >> 14
             assert bool(hi.any()) == hi_bits, (stride, knob)
         x = (rng.random(cols) < 0.3).astype(np.float32)
         dx, dy = capi.DeviceBuffer.from_host(x), capi.DeviceBuffer(4 * rows)

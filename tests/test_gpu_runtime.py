@@ -137,3 +137,91 @@ def test_d2h_levels_is_exact_whatever_the_buffer_holds(gpu):
     small = capi.DeviceBuffer.from_host(np.arange(1000, dtype=np.float32) % 7)
     out = np.zeros(1000, np.float32)
     assert capi.d2h_levels(out, small, 1000, 15.0) is False and np.array_equal(out, np.arange(1000, dtype=np.float32) % 7)
+
+
+def test_streamed_level_read_back(gpu):
+    """gl_levels_pack_stream / gl_sync_levels_unpack_stream (include/graphlily_hip.h): the pack kernel stores nibbles / bytes
+    straight into a page-locked host block, a flag behind every chunk of 2048 words, and the host threads expand the chunks as
+    they land -- the floats and the tail words that come back are the buffer's, for sizes below, at and across chunk boundaries,
+    run after run on one block (re-armed each time); a block whose pack was never enqueued is reported, not waited for."""
+    rng = np.random.default_rng(21)
+    tw = 48
+    tail_h = rng.integers(0, 1 << 32, size=tw, dtype=np.uint64).astype(np.uint32)
+    tail = capi.DeviceBuffer.from_host(tail_h)
+    for bits in (4, 8):
+        per_word = 32 // bits
+        for n in (8, 2048 * per_word - 8, 2048 * per_word, 2048 * per_word + 8, 600064, 3 * (1 << 20) + 24):
+            block = capi.pinned_empty(capi.levels_stream_bytes(n, bits, tw), np.uint8)
+            for rep in range(3):
+                lev = rng.integers(0, 1 << bits, size=n).astype(np.float32)
+                buf = capi.DeviceBuffer.from_host(lev)
+                out = capi.pinned_empty(n + 4, np.float32)
+                out[:] = -3.0
+                capi.levels_stream_arm(block, n, bits, tw)
+                capi.levels_pack_stream(buf, n, bits, tail, tw, block)
+                got_tail = capi.sync_levels_unpack_stream(out, block, n, bits, tw)
+                assert np.array_equal(out[:n], lev), (bits, n, rep)
+                assert np.all(out[n:] == -3.0) and np.array_equal(got_tail, tail_h), (bits, n, rep)
+    # an unaligned destination takes the plain loop
+    n = 600064
+    lev = rng.integers(0, 16, size=n).astype(np.float32)
+    block = capi.pinned_empty(capi.levels_stream_bytes(n, 4, tw), np.uint8)
+    out = np.zeros(n + 1, np.float32)[1:]
+    capi.levels_stream_arm(block, n, 4, tw)
+    capi.levels_pack_stream(capi.DeviceBuffer.from_host(lev), n, 4, tail, tw, block)
+    capi.sync_levels_unpack_stream(out, block, n, 4, tw)
+    assert np.array_equal(out, lev)
+    # armed, nothing enqueued: the stream drains, the flags stay down
+    capi.levels_stream_arm(block, n, 4, tw)
+    with pytest.raises(capi.GraphLilyError, match="without delivering"):
+        capi.sync_levels_unpack_stream(out, block, n, 4, tw)
+    # pageable memory is refused by the pack
+    with pytest.raises(capi.GraphLilyError, match="page-locked"):
+        capi.levels_pack_stream(capi.DeviceBuffer.from_host(lev), n, 4, tail, tw, np.zeros(capi.levels_stream_bytes(n, 4, tw), np.uint8))
+
+
+def test_gl_init_binds_the_calling_thread_to_the_devices_numa_node(gpu):
+    """gl_host_bind_near_device (called by gl_init): the calling thread's affinity becomes the CPUs of the GPU's NUMA node that the
+    process was allowed before -- or stays as it was when the platform names no node or the mask already lies inside it;
+    GRAPHLILY_BIND_NUMA=0 leaves it alone either way.  (Fresh processes: this one is bound already.)"""
+    import os
+    import subprocess
+    import sys
+    prog = r'''
+import os, sys
+sys.path.insert(0, %r)
+before = os.sched_getaffinity(0)
+from graphlily_amd import capi
+capi.init(0)
+after = os.sched_getaffinity(0)
+node, cpus = capi.host_bind_near_device()       # (again: same answer, or "nothing to do" once the mask lies inside the node)
+again = os.sched_getaffinity(0)
+want = None
+import torch
+pr = torch.cuda.get_device_properties(0)
+try:
+    d = "/sys/bus/pci/devices/%%04x:%%02x:%%02x.0" %% (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    nd = int(open(d + "/numa_node").read())
+    if nd >= 0:
+        want = set()
+        for part in open("/sys/devices/system/node/node%%d/cpulist" %% nd).read().strip().split(","):
+            a, _, b = part.partition("-")
+            want.update(range(int(a), int(b or a) + 1))
+        want &= before
+except OSError:
+    pass
+print(len(before), len(after), len(again), -1 if want is None else len(want), int(want is not None and after == want), node, cpus)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for knob in ("1", "0"):
+        env = dict(os.environ, GRAPHLILY_BIND_NUMA=knob)
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[knob] = [int(v) for v in r.stdout.strip().splitlines()[-1].split()]
+    before, after, again, want, equal, node, cpus = outs["1"]
+    if want > 0 and want < before:
+        assert equal == 1 and after == want and again == want, outs
+    else:
+        assert after == before, outs
+    b0, a0 = outs["0"][0], outs["0"][1]
+    assert a0 == b0, outs        # the knob: gl_init does not touch the affinity
