@@ -202,38 +202,10 @@ __global__ __launch_bounds__(256) void levels_pack_kernel(const float4 *__restri
         for (uint32_t i = threadIdx.x; i < tail_words; i += 256u) dst[tail_at + i] = tail[i];
 }
 
-// gl_levels_pack_stream: the same words stored straight into page-locked HOST memory, a chunk of kLevelsChunkWords per workgroup,
-// each chunk's flag raised behind its words (system-scope release: the flag does not overtake the data on its way to the host) --
-// the host expands chunk k while chunk k + 1 is still crossing PCIe.  The last workgroup delivers the tail words the same way.
 constexpr uint32_t kLevelsChunkWords = GL_LEVELS_CHUNK_WORDS;
-template <int BITS>
-__global__ __launch_bounds__(256) void levels_pack_stream_kernel(const float4 *__restrict__ src, uint32_t *__restrict__ dst, uint32_t nwords,
-                                                                 const uint32_t *__restrict__ tail, uint32_t tail_words, uint32_t tail_at,
-                                                                 uint32_t *__restrict__ flags, uint32_t nchunks) {
-    constexpr uint32_t M = (1u << BITS) - 1u;
-    const uint32_t c = blockIdx.x;
-    auto word = [&](uint32_t i) -> uint32_t {
-        if (BITS == 8) {
-            const float4 v = src[i];
-            return ((uint32_t)v.x & M) | (((uint32_t)v.y & M) << 8) | (((uint32_t)v.z & M) << 16) | (((uint32_t)v.w & M) << 24);
-        }
-        const float4 v = src[2u * i], w = src[2u * i + 1u];
-        return ((uint32_t)v.x & M) | (((uint32_t)v.y & M) << 4) | (((uint32_t)v.z & M) << 8) | (((uint32_t)v.w & M) << 12) |
-               (((uint32_t)w.x & M) << 16) | (((uint32_t)w.y & M) << 20) | (((uint32_t)w.z & M) << 24) | (((uint32_t)w.w & M) << 28);
-    };
-    if (c + 1u < nchunks) {
-        // 16 bytes per lane and store (1 KB per wavefront instruction: whole PCIe write bursts), the odd words of the last chunk singly
-        const uint32_t begin = c * kLevelsChunkWords, end = min(nwords, begin + kLevelsChunkWords), end4 = begin + ((end - begin) & ~3u);
-        for (uint32_t i = begin + 4u * threadIdx.x; i < end4; i += 1024u)
-            *reinterpret_cast<uint4 *>(dst + i) = make_uint4(word(i), word(i + 1u), word(i + 2u), word(i + 3u));
-        for (uint32_t i = end4 + threadIdx.x; i < end; i += 256u) dst[i] = word(i);
-    } else {
-        for (uint32_t i = threadIdx.x; i < tail_words; i += 256u) dst[tail_at + i] = tail[i];
-    }
-    __threadfence_system();   // every thread's stores have left for the host ...
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flags + (size_t)c * GL_LEVELS_FLAG_STRIDE_WORDS, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the flag
-}
+// (gl_levels_pack_stream's kernel lives in gl_spmv_bool.hip, next to the BFS schedule's kernels it follows -- see there)
+int launch_levels_pack_stream(const float *d_levels, int bits, uint32_t *dst, uint32_t nwords, const uint32_t *d_tail, uint32_t tail_words,
+                              uint32_t tail_at, uint32_t *flags, uint32_t nchunks, hipStream_t s);
 
 // gl_buf_d2h_levels: the same packing for a buffer that is only EXPECTED to hold small integers -- every value is checked
 // (a non-negative integer no larger than the field allows), a violation raises flag[0] and the caller falls back to the floats
@@ -996,14 +968,53 @@ static int host_expand_threads(size_t n) {
 
 int gl_host_unpack_threads(void) { return host_expand_threads(1u << 20); }
 
-// 16 level bytes -> 16 floats, written past the caches (the caller reads them later, if at all: no read-for-ownership)
-static inline void expand16_stream(const __m128i v, float *dst) {
+// 16 level bytes -> 16 floats.  How they are stored (GRAPHLILY_HOST_STORES=cached|stream):
+//   cached  ordinary stores (the default since round 6): at cache speed when the destination's lines are still in the cores' caches,
+//           which a result array that is recycled call after call is -- 12 MB over 16 threads are 0.8 MB each, an L2's worth; a
+//           line that is not cached costs a read-for-ownership first;
+//   stream  non-temporal stores past the caches: no read, but ~10 GB/s per core whatever the caches hold.
+// EPYC 9575F, orkut's 3 M nibbles into two alternating page-locked arrays, 16 threads: 61 us streamed, 24 us cached (8 threads
+// 65 / 32, 32 threads 38 / 16; profiles/r06_host_unpack_stores.txt).  AMD's CLZERO (claim a line without reading it, then fill
+// it) was tried for the uncached case and is two orders of magnitude slower on page-locked memory: not kept.
+extern "C++" {
+enum { kStoreStream = 0, kStoreCached = 1 };
+template <int MODE>
+static inline void expand16(const __m128i v, float *dst) {
     const __m128i z = _mm_setzero_si128();
     const __m128i lo = _mm_unpacklo_epi8(v, z), hi = _mm_unpackhi_epi8(v, z);
-    _mm_stream_ps(dst, _mm_cvtepi32_ps(_mm_unpacklo_epi16(lo, z)));
-    _mm_stream_ps(dst + 4, _mm_cvtepi32_ps(_mm_unpackhi_epi16(lo, z)));
-    _mm_stream_ps(dst + 8, _mm_cvtepi32_ps(_mm_unpacklo_epi16(hi, z)));
-    _mm_stream_ps(dst + 12, _mm_cvtepi32_ps(_mm_unpackhi_epi16(hi, z)));
+    const __m128 a = _mm_cvtepi32_ps(_mm_unpacklo_epi16(lo, z)), b = _mm_cvtepi32_ps(_mm_unpackhi_epi16(lo, z));
+    const __m128 c = _mm_cvtepi32_ps(_mm_unpacklo_epi16(hi, z)), d = _mm_cvtepi32_ps(_mm_unpackhi_epi16(hi, z));
+    if (MODE == kStoreStream) {
+        _mm_stream_ps(dst, a), _mm_stream_ps(dst + 4, b), _mm_stream_ps(dst + 8, c), _mm_stream_ps(dst + 12, d);
+    } else {
+        _mm_store_ps(dst, a), _mm_store_ps(dst + 4, b), _mm_store_ps(dst + 8, c), _mm_store_ps(dst + 12, d);
+    }
+}
+
+// 32-level blocks [b0, b1) of the packed source -> floats (destination 16-byte aligned)
+template <int MODE>
+static inline void levels_expand_blocks_mode(float *h_dst, const uint8_t *src, size_t b0, size_t b1, int bits) {
+    if (bits == 8) {
+        for (size_t b = b0; b < b1; b++) {
+            expand16<MODE>(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b)), h_dst + 32u * b);
+            expand16<MODE>(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b + 16u)), h_dst + 32u * b + 16u);
+        }
+    } else {
+        const __m128i m = _mm_set1_epi8(0x0f);
+        for (size_t b = b0; b < b1; b++) {
+            const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 16u * b));
+            const __m128i lo = _mm_and_si128(v, m), hi = _mm_and_si128(_mm_srli_epi16(v, 4), m);
+            expand16<MODE>(_mm_unpacklo_epi8(lo, hi), h_dst + 32u * b);          // levels 0 ... 15 of the block, in order
+            expand16<MODE>(_mm_unpackhi_epi8(lo, hi), h_dst + 32u * b + 16u);
+        }
+    }
+}
+}  // extern "C++"
+
+static inline void levels_expand_blocks(float *h_dst, const uint8_t *src, size_t b0, size_t b1, int bits) {
+    static const bool stream = getenv("GRAPHLILY_HOST_STORES") && !strcmp(getenv("GRAPHLILY_HOST_STORES"), "stream");
+    if (stream) levels_expand_blocks_mode<kStoreStream>(h_dst, src, b0, b1, bits);
+    else levels_expand_blocks_mode<kStoreCached>(h_dst, src, b0, b1, bits);
 }
 
 // wait_stream: the team is started FIRST and its master waits for the library's stream while the other threads spin on a
@@ -1035,22 +1046,7 @@ static int levels_unpack_impl(float *h_dst, const void *h_src, size_t n, int bit
             }
         }
         const size_t b0 = nblk * t / T, b1 = nblk * (t + 1) / T;
-        if (waited != hipSuccess) {
-            // (nothing to unpack: the error is reported below)
-        } else if (bits == 8) {
-            for (size_t b = b0; b < b1; b++) {
-                expand16_stream(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b)), h_dst + 32u * b);
-                expand16_stream(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b + 16u)), h_dst + 32u * b + 16u);
-            }
-        } else {
-            const __m128i m = _mm_set1_epi8(0x0f);
-            for (size_t b = b0; b < b1; b++) {
-                const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 16u * b));
-                const __m128i lo = _mm_and_si128(v, m), hi = _mm_and_si128(_mm_srli_epi16(v, 4), m);
-                expand16_stream(_mm_unpacklo_epi8(lo, hi), h_dst + 32u * b);          // levels 0 ... 15 of the block, in order
-                expand16_stream(_mm_unpackhi_epi8(lo, hi), h_dst + 32u * b + 16u);
-            }
-        }
+        if (waited == hipSuccess) levels_expand_blocks(h_dst, src, b0, b1, bits);
         _mm_sfence();
     }
     if (waited != hipSuccess) return gl::set_error(GL_ERR_HIP, "gl_sync_levels_unpack: %s", hipGetErrorString(waited));
@@ -1115,32 +1111,11 @@ int gl_levels_pack_stream(const float *d_levels, uint32_t n, int bits, const uin
     }
     const LevelsStream L = levels_stream_layout(n, bits, tail_words);
     uint32_t *dst = static_cast<uint32_t *>(dev_view);
-    if (bits == 8)
-        gl::levels_pack_stream_kernel<8><<<L.nchunks, 256, 0, gl::ctx().stream>>>(reinterpret_cast<const float4 *>(d_levels), dst, L.nwords, d_tail,
-                                                                                  tail_words, L.tail_at, dst + L.flags_at, L.nchunks);
-    else
-        gl::levels_pack_stream_kernel<4><<<L.nchunks, 256, 0, gl::ctx().stream>>>(reinterpret_cast<const float4 *>(d_levels), dst, L.nwords, d_tail,
-                                                                                  tail_words, L.tail_at, dst + L.flags_at, L.nchunks);
+    const int rc = gl::launch_levels_pack_stream(d_levels, bits, dst, L.nwords, d_tail, tail_words, L.tail_at, dst + L.flags_at, L.nchunks,
+                                                 gl::ctx().stream);
+    if (rc != GL_OK) return rc;
     GL_LAUNCH_CHECK();
     return GL_OK;
-}
-
-// 32-level blocks [b0, b1) of the packed source -> floats (the SSE2 loops of levels_unpack_impl)
-static inline void levels_expand_blocks(float *h_dst, const uint8_t *src, size_t b0, size_t b1, int bits) {
-    if (bits == 8) {
-        for (size_t b = b0; b < b1; b++) {
-            expand16_stream(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b)), h_dst + 32u * b);
-            expand16_stream(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 32u * b + 16u)), h_dst + 32u * b + 16u);
-        }
-    } else {
-        const __m128i m = _mm_set1_epi8(0x0f);
-        for (size_t b = b0; b < b1; b++) {
-            const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 16u * b));
-            const __m128i lo = _mm_and_si128(v, m), hi = _mm_and_si128(_mm_srli_epi16(v, 4), m);
-            expand16_stream(_mm_unpacklo_epi8(lo, hi), h_dst + 32u * b);
-            expand16_stream(_mm_unpackhi_epi8(lo, hi), h_dst + 32u * b + 16u);
-        }
-    }
 }
 
 int gl_sync_levels_unpack_stream(float *h_dst, const void *h_block, size_t n, int bits, uint32_t *h_tail, uint32_t tail_words) {
@@ -1157,6 +1132,9 @@ int gl_sync_levels_unpack_stream(float *h_dst, const void *h_block, size_t n, in
     const uint32_t levels_per_word = 32u / (uint32_t)bits;
     int drained = 0, missing = 0;
     hipError_t waited = hipSuccess;
+    const bool stamps = gl::debug_knob("levels_stream_stamps", 0) != 0;   // scratch: when the chunks were done / the stream had drained
+    const auto t_in = std::chrono::steady_clock::now();
+    double t_sync = 0.0, t_last = 0.0, t_first = 0.0;
     // thread 0 waits for the stream (and so learns of a failed launch: the flags of a schedule that died never come); the others
     // take the chunks round-robin, each as soon as its flag is up.  With one thread: wait, then expand everything.
 #pragma omp parallel num_threads(nt)
@@ -1166,6 +1144,7 @@ int gl_sync_levels_unpack_stream(float *h_dst, const void *h_block, size_t n, in
         if (t == 0) {
             waited = hipStreamSynchronize(gl::ctx().stream);
             __atomic_store_n(&drained, 1, __ATOMIC_RELEASE);
+            if (stamps) t_sync = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count();
         }
         const uint32_t W = T > 1u ? T - 1u : 1u, w = T > 1u ? t - 1u : 0u;
         if (T == 1u || t > 0u) {
@@ -1185,6 +1164,7 @@ int gl_sync_levels_unpack_stream(float *h_dst, const void *h_block, size_t n, in
                     __atomic_store_n(&missing, 1, __ATOMIC_RELAXED);
                     break;
                 }
+                if (stamps && c == 0) t_first = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count();
                 const size_t w0 = (size_t)c * gl::kLevelsChunkWords, w1 = std::min<size_t>(L.nwords, w0 + gl::kLevelsChunkWords);
                 const size_t l0 = w0 * levels_per_word, l1 = w1 * levels_per_word;     // (a chunk holds whole 32-level blocks)
                 if (aligned) {
@@ -1196,8 +1176,12 @@ int gl_sync_levels_unpack_stream(float *h_dst, const void *h_block, size_t n, in
                 }
             }
             _mm_sfence();
+            if (stamps && (L.nchunks - 2u) % W == w) t_last = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count();
         }
     }
+    if (stamps)
+        fprintf(stderr, "levels stream: first chunk up at %.1f us, last chunk expanded at %.1f us, stream drained at %.1f us (from the call)\n", t_first,
+                t_last, t_sync);
     if (waited != hipSuccess) return gl::set_error(GL_ERR_HIP, "gl_sync_levels_unpack_stream: %s", hipGetErrorString(waited));
     if (missing || __atomic_load_n(flags + (size_t)(L.nchunks - 1u) * GL_LEVELS_FLAG_STRIDE_WORDS, __ATOMIC_ACQUIRE) == 0u)
         return gl::set_error(GL_ERR_INVALID_ARG, "gl_sync_levels_unpack_stream: the stream ended without delivering every chunk "
