@@ -86,6 +86,63 @@ __device__ __forceinline__ bool bfs_candidate(const BfsPushArgs &a, bool valid, 
 // kTallyLines lines of kTallyLineWords words: [0] vertices reached, [2..3] their global column lengths, [4..5] their row lengths
 constexpr uint32_t kTallyLines = 8, kTallyLineWords = 8, kTallyRankWords = kTallyLines * kTallyLineWords, kTallyHeadWords = 64;
 
+// The streamed read-back of a BFS result (gl_levels_pack_stream, include/graphlily_hip.h): levels -> nibbles / bytes stored straight
+// into a page-locked host block, chunk by chunk, a flag word raised behind every chunk (system-scope release: the flag does not
+// overtake the data on its way to the host) and behind the tail words -- the host expands chunk k while chunk k + 1 crosses PCIe.
+struct LevelsPack {
+    const float4 *src = nullptr;
+    uint32_t *dst = nullptr;       // the block, as the device sees it; null: nothing to pack
+    uint32_t *flags = nullptr;     // nchunks flags, GL_LEVELS_FLAG_STRIDE_WORDS apart; the last one is the tail's
+    const uint32_t *tail = nullptr;
+    uint32_t nwords = 0, bits = 4, tail_words = 0, tail_at = 0, nchunks = 0;
+};
+
+template <int BITS>
+__device__ __forceinline__ uint32_t levels_pack_word(const float4 *__restrict__ src, uint32_t i) {
+    constexpr uint32_t M = (1u << BITS) - 1u;
+    if (BITS == 8) {
+        const float4 v = src[i];
+        return ((uint32_t)v.x & M) | (((uint32_t)v.y & M) << 8) | (((uint32_t)v.z & M) << 16) | (((uint32_t)v.w & M) << 24);
+    }
+    const float4 v = src[2u * i], w = src[2u * i + 1u];
+    return ((uint32_t)v.x & M) | (((uint32_t)v.y & M) << 4) | (((uint32_t)v.z & M) << 8) | (((uint32_t)v.w & M) << 12) |
+           (((uint32_t)w.x & M) << 16) | (((uint32_t)w.y & M) << 20) | (((uint32_t)w.z & M) << 24) | (((uint32_t)w.w & M) << 28);
+}
+
+// the whole workgroup: raise flag c once every thread's stores have left for the host.  ONE system-scope release per workgroup: every
+// wavefront waits until its stores have reached the L2 (s_waitcnt vmcnt(0): the compiler's workgroup-scope release waits for nothing,
+// one L1 serves the workgroup), the barrier, then thread 0's release -- the write-back of the L2 (the block's lines do sit there:
+// with the wait alone and a relaxed flag store, stale chunks reached the host behind their flags) and the flag behind it.
+// __threadfence_system() in every thread was a write-back walk of the L2 per WAVEFRONT: 756 of them made this pack 42 us long
+// instead of 31 and delayed its start by 34 us in every replay of the recorded schedule (profiles/r06_bfs_trace.txt).
+__device__ __forceinline__ void levels_pack_flag(const LevelsPack &k, uint32_t c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(k.flags + (size_t)c * GL_LEVELS_FLAG_STRIDE_WORDS, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// chunk c (< nchunks - 1) by the whole workgroup: 16 bytes per lane and store (1 KB per wavefront instruction: whole PCIe write
+// bursts), the odd words of the last chunk singly
+template <int BITS>
+__device__ __forceinline__ void levels_pack_chunk(const LevelsPack &k, uint32_t c) {
+    const uint32_t begin = c * GL_LEVELS_CHUNK_WORDS, end = min(k.nwords, begin + GL_LEVELS_CHUNK_WORDS), end4 = begin + ((end - begin) & ~3u);
+    for (uint32_t i = begin + 4u * threadIdx.x; i < end4; i += 4u * blockDim.x)
+        *reinterpret_cast<uint4 *>(k.dst + i) = make_uint4(levels_pack_word<BITS>(k.src, i), levels_pack_word<BITS>(k.src, i + 1u),
+                                                           levels_pack_word<BITS>(k.src, i + 2u), levels_pack_word<BITS>(k.src, i + 3u));
+    for (uint32_t i = end4 + threadIdx.x; i < end; i += blockDim.x) k.dst[i] = levels_pack_word<BITS>(k.src, i);
+    levels_pack_flag(k, c);
+}
+
+// the tail words (the schedule's control words), by the whole workgroup
+__device__ __forceinline__ void levels_pack_tail(const LevelsPack &k) {
+    for (uint32_t i = threadIdx.x; i < k.tail_words; i += blockDim.x) k.dst[k.tail_at + i] = k.tail[i];
+    levels_pack_flag(k, k.nchunks - 1u);
+}
+
+// gl_runtime.hip: checks the block (page-locked, device-visible, aligned) and fills the descriptor for n levels + tail_words words
+int levels_stream_describe(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *h_block,
+                           LevelsPack *out, const char *who);
+
 struct BfsShardArgs {
     const uint32_t *state_in;    // 16 control words: the state the previous launch stored (gl_bfs_bits_begin's in slots 1 and 2)
     uint32_t *state_out;         // workgroup 0 stores the state after slot - 1 here (null in slot 1: nothing to decide yet)

@@ -2,6 +2,7 @@
 // Replaces the OpenCL/XRT set-up of module/base_module.h:106-133 and the
 // cl::Buffer migrate/copy calls of the reference modules.
 #include "gl_common.h"
+#include "gl_bfs_shard.h"
 
 #include <chrono>
 #include <omp.h>
@@ -203,9 +204,12 @@ __global__ __launch_bounds__(256) void levels_pack_kernel(const float4 *__restri
 }
 
 constexpr uint32_t kLevelsChunkWords = GL_LEVELS_CHUNK_WORDS;
-// (gl_levels_pack_stream's kernel lives in gl_spmv_bool.hip, next to the BFS schedule's kernels it follows -- see there)
-int launch_levels_pack_stream(const float *d_levels, int bits, uint32_t *dst, uint32_t nwords, const uint32_t *d_tail, uint32_t tail_words,
-                              uint32_t tail_at, uint32_t *flags, uint32_t nchunks, hipStream_t s);
+// gl_levels_pack_stream (the device functions are gl_bfs_shard.h's): workgroup c packs chunk c, the last one delivers the tail words
+template <int BITS>
+__global__ __launch_bounds__(256) void levels_pack_stream_kernel(LevelsPack k) {
+    if (blockIdx.x + 1u < k.nchunks) levels_pack_chunk<BITS>(k, blockIdx.x);
+    else levels_pack_tail(k);
+}
 
 // gl_buf_d2h_levels: the same packing for a buffer that is only EXPECTED to hold small integers -- every value is checked
 // (a non-negative integer no larger than the field allows), a violation raises flag[0] and the caller falls back to the floats
@@ -1098,22 +1102,38 @@ int gl_levels_stream_arm(void *h_block, uint32_t n, int bits, uint32_t tail_word
     return GL_OK;
 }
 
-int gl_levels_pack_stream(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *h_block) {
-    GL_REQUIRE_INIT();
-    GL_ARG(d_levels != nullptr && h_block != nullptr && (bits == 4 || bits == 8) && (n & 7u) == 0);
-    GL_ARG((((uintptr_t)d_levels | (uintptr_t)h_block) & 15u) == 0 && (tail_words == 0 || d_tail != nullptr));
+}  // extern "C"
+namespace gl {
+int levels_stream_describe(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *h_block,
+                           LevelsPack *out, const char *who) {
+    if (!(d_levels != nullptr && h_block != nullptr && (bits == 4 || bits == 8) && (n & 7u) == 0 &&
+          (((uintptr_t)d_levels | (uintptr_t)h_block) & 15u) == 0 && (tail_words == 0 || d_tail != nullptr)))
+        return set_error(GL_ERR_INVALID_ARG, "%s: n levels (a multiple of 8) in a 16-byte aligned buffer, bits 4 or 8, a 16-byte aligned block", who);
     hipPointerAttribute_t at;
     void *dev_view = nullptr;
     if (hipPointerGetAttributes(&at, h_block) != hipSuccess || at.type != hipMemoryTypeHost ||
         hipHostGetDevicePointer(&dev_view, h_block, 0) != hipSuccess || dev_view == nullptr) {
         (void)hipGetLastError();
-        return gl::set_error(GL_ERR_INVALID_ARG, "gl_levels_pack_stream: the block must be page-locked host memory (gl_host_alloc)");
+        return set_error(GL_ERR_INVALID_ARG, "%s: the block must be page-locked host memory (gl_host_alloc)", who);
     }
     const LevelsStream L = levels_stream_layout(n, bits, tail_words);
-    uint32_t *dst = static_cast<uint32_t *>(dev_view);
-    const int rc = gl::launch_levels_pack_stream(d_levels, bits, dst, L.nwords, d_tail, tail_words, L.tail_at, dst + L.flags_at, L.nchunks,
-                                                 gl::ctx().stream);
+    out->src = reinterpret_cast<const float4 *>(d_levels);
+    out->dst = static_cast<uint32_t *>(dev_view);
+    out->flags = out->dst + L.flags_at;
+    out->tail = d_tail;
+    out->nwords = L.nwords, out->bits = (uint32_t)bits, out->tail_words = tail_words, out->tail_at = L.tail_at, out->nchunks = L.nchunks;
+    return GL_OK;
+}
+}  // namespace gl
+extern "C" {
+
+int gl_levels_pack_stream(const float *d_levels, uint32_t n, int bits, const uint32_t *d_tail, uint32_t tail_words, void *h_block) {
+    GL_REQUIRE_INIT();
+    gl::LevelsPack k;
+    const int rc = gl::levels_stream_describe(d_levels, n, bits, d_tail, tail_words, h_block, &k, "gl_levels_pack_stream");
     if (rc != GL_OK) return rc;
+    if (bits == 8) gl::levels_pack_stream_kernel<8><<<k.nchunks, 256, 0, gl::ctx().stream>>>(k);
+    else gl::levels_pack_stream_kernel<4><<<k.nchunks, 256, 0, gl::ctx().stream>>>(k);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

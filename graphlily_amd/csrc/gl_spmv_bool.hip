@@ -1184,53 +1184,6 @@ int bool_plan_build(gl_spmv_plan p, const uint32_t *h_indptr, const uint32_t *h_
     return GL_OK;
 }
 
-// ---- the read-back of a BFS schedule's result (gl_levels_pack_stream, gl_runtime.hip).  The kernel is HERE because a kernel of
-// another translation unit (another code object) behind the schedule's launches started 34 us after the last of them, in every
-// replay of the recorded graph (profiles/r06_bfs_trace.txt); one of this unit's starts like any other.
-// gl_levels_pack_stream: the same words stored straight into page-locked HOST memory, a chunk of kLevelsChunkWordsB per workgroup,
-// each chunk's flag raised behind its words (system-scope release: the flag does not overtake the data on its way to the host) --
-// the host expands chunk k while chunk k + 1 is still crossing PCIe.  The last workgroup delivers the tail words the same way.
-constexpr uint32_t kLevelsChunkWordsB = GL_LEVELS_CHUNK_WORDS;
-template <int BITS>
-__global__ __launch_bounds__(256) void levels_pack_stream_kernel(const float4 *__restrict__ src, uint32_t *__restrict__ dst, uint32_t nwords,
-                                                                 const uint32_t *__restrict__ tail, uint32_t tail_words, uint32_t tail_at,
-                                                                 uint32_t *__restrict__ flags, uint32_t nchunks) {
-    constexpr uint32_t M = (1u << BITS) - 1u;
-    const uint32_t c = blockIdx.x;
-    auto word = [&](uint32_t i) -> uint32_t {
-        if (BITS == 8) {
-            const float4 v = src[i];
-            return ((uint32_t)v.x & M) | (((uint32_t)v.y & M) << 8) | (((uint32_t)v.z & M) << 16) | (((uint32_t)v.w & M) << 24);
-        }
-        const float4 v = src[2u * i], w = src[2u * i + 1u];
-        return ((uint32_t)v.x & M) | (((uint32_t)v.y & M) << 4) | (((uint32_t)v.z & M) << 8) | (((uint32_t)v.w & M) << 12) |
-               (((uint32_t)w.x & M) << 16) | (((uint32_t)w.y & M) << 20) | (((uint32_t)w.z & M) << 24) | (((uint32_t)w.w & M) << 28);
-    };
-    if (c + 1u < nchunks) {
-        // 16 bytes per lane and store (1 KB per wavefront instruction: whole PCIe write bursts), the odd words of the last chunk singly
-        const uint32_t begin = c * kLevelsChunkWordsB, end = min(nwords, begin + kLevelsChunkWordsB), end4 = begin + ((end - begin) & ~3u);
-        for (uint32_t i = begin + 4u * threadIdx.x; i < end4; i += 1024u)
-            *reinterpret_cast<uint4 *>(dst + i) = make_uint4(word(i), word(i + 1u), word(i + 2u), word(i + 3u));
-        for (uint32_t i = end4 + threadIdx.x; i < end; i += 256u) dst[i] = word(i);
-    } else {
-        for (uint32_t i = threadIdx.x; i < tail_words; i += 256u) dst[tail_at + i] = tail[i];
-    }
-    __threadfence_system();   // every thread's stores have left for the host ...
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flags + (size_t)c * GL_LEVELS_FLAG_STRIDE_WORDS, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before the flag
-}
-
-
-int launch_levels_pack_stream(const float *d_levels, int bits, uint32_t *dst, uint32_t nwords, const uint32_t *d_tail, uint32_t tail_words,
-                              uint32_t tail_at, uint32_t *flags, uint32_t nchunks, hipStream_t s) {
-    if (bits == 8)
-        levels_pack_stream_kernel<8><<<nchunks, 256, 0, s>>>(reinterpret_cast<const float4 *>(d_levels), dst, nwords, d_tail, tail_words, tail_at, flags, nchunks);
-    else
-        levels_pack_stream_kernel<4><<<nchunks, 256, 0, s>>>(reinterpret_cast<const float4 *>(d_levels), dst, nwords, d_tail, tail_words, tail_at, flags, nchunks);
-    GL_LAUNCH_CHECK();
-    return GL_OK;
-}
-
 }  // namespace gl
 
 // gl_init loads this translation unit's code object up front (HIP defers that to the unit's first launch, which would put

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--calls", type=int, default=60)
     ap.add_argument("--near", action="store_true", help="bind the process to the CPUs of the GPU's NUMA node first")
     ap.add_argument("--modes", default="pull_push,pull")
+    ap.add_argument("--no-timed", action="store_true", help="skip the calls that time the schedule alone (their read-back is a launch of its own)")
     args = ap.parse_args()
     import torch
     from graphlily_amd import app, capi, datasets
@@ -63,9 +64,9 @@ def main():
             fn()
             capi.sync()
             ts.append((time.perf_counter() - t0) * 1e3)
-        bfs.time_schedule_ = True
-        sched = []
-        for _ in range(8):
+        bfs.time_schedule_ = not args.no_timed
+        sched = [0.0]
+        for _ in range(0 if args.no_timed else 8):
             fn()
             sched.append(bfs.schedule_ms_)
         bfs.time_schedule_ = False

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/bfstrace; mkdir -p /tmp/bfstrace
-timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/bfstrace -- python $R/scripts/bfs_call_times.py --graph ${GRAPH:-orkut} --calls 6 --modes ${MODES:-pull_push} > /tmp/bfstrace/out.txt 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/bfstrace -- python $R/scripts/bfs_call_times.py --graph ${GRAPH:-orkut} --calls 6 --no-timed --modes ${MODES:-pull_push} > /tmp/bfstrace/out.txt 2>&1
 f=$(find /tmp/bfstrace -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, collections
