@@ -972,8 +972,8 @@ static int host_expand_threads(size_t n) {
 
 int gl_host_unpack_threads(void) { return host_expand_threads(1u << 20); }
 
-// 16 level bytes -> 16 floats.  How they are stored (GRAPHLILY_HOST_STORES=cached|stream):
-//   cached  ordinary stores (the default since round 6): at cache speed when the destination's lines are still in the cores' caches,
+// 16 level bytes -> 16 floats.  How they are stored (levels_destination_is_warm below picks per call):
+//   cached  ordinary stores (round 6): at cache speed when the destination's lines are still in the cores' caches,
 //           which a result array that is recycled call after call is -- 12 MB over 16 threads are 0.8 MB each, an L2's worth; a
 //           line that is not cached costs a read-for-ownership first;
 //   stream  non-temporal stores past the caches: no read, but ~10 GB/s per core whatever the caches hold.
@@ -1015,10 +1015,27 @@ static inline void levels_expand_blocks_mode(float *h_dst, const uint8_t *src, s
 }
 }  // extern "C++"
 
-static inline void levels_expand_blocks(float *h_dst, const uint8_t *src, size_t b0, size_t b1, int bits) {
-    static const bool stream = getenv("GRAPHLILY_HOST_STORES") && !strcmp(getenv("GRAPHLILY_HOST_STORES"), "stream");
-    if (stream) levels_expand_blocks_mode<kStoreStream>(h_dst, src, b0, b1, bits);
-    else levels_expand_blocks_mode<kStoreCached>(h_dst, src, b0, b1, bits);
+static inline void levels_expand_blocks(float *h_dst, const uint8_t *src, size_t b0, size_t b1, int bits, bool cached) {
+    if (cached) levels_expand_blocks_mode<kStoreCached>(h_dst, src, b0, b1, bits);
+    else levels_expand_blocks_mode<kStoreStream>(h_dst, src, b0, b1, bits);
+}
+
+// Which stores a destination gets (one decision per call, by the calling thread): ordinary ones when it is one of the last few
+// destinations -- an array the caller recycles, whose lines the team's caches still hold -- and streaming ones for memory seen for
+// the first time (the reference's bench_bfs times ONE call into a vector allocated for it: 0.45 ms streamed, 0.50 with ordinary
+// stores and their read-for-ownership).  GRAPHLILY_HOST_STORES=cached|stream pins either.
+static bool levels_destination_is_warm(const float *h_dst) {
+    static const char *pin = getenv("GRAPHLILY_HOST_STORES");
+    static std::mutex lock;
+    static const float *recent[4] = {nullptr, nullptr, nullptr, nullptr};
+    static unsigned next = 0;
+    if (pin && !strcmp(pin, "stream")) return false;
+    if (pin && !strcmp(pin, "cached")) return true;
+    std::lock_guard<std::mutex> hold(lock);
+    for (const float *q : recent)
+        if (q == h_dst) return true;
+    recent[next++ & 3u] = h_dst;
+    return false;
 }
 
 // wait_stream: the team is started FIRST and its master waits for the library's stream while the other threads spin on a
@@ -1027,6 +1044,7 @@ static inline void levels_expand_blocks(float *h_dst, const uint8_t *src, size_t
 static int levels_unpack_impl(float *h_dst, const void *h_src, size_t n, int bits, bool wait_stream) {
     const int nt = host_expand_threads(n);
     (void)nt;
+    const bool warm = levels_destination_is_warm(h_dst);
     const uint8_t *src = static_cast<const uint8_t *>(h_src);
     int ready = wait_stream ? 0 : 1;
     hipError_t waited = hipSuccess;
@@ -1050,7 +1068,7 @@ static int levels_unpack_impl(float *h_dst, const void *h_src, size_t n, int bit
             }
         }
         const size_t b0 = nblk * t / T, b1 = nblk * (t + 1) / T;
-        if (waited == hipSuccess) levels_expand_blocks(h_dst, src, b0, b1, bits);
+        if (waited == hipSuccess) levels_expand_blocks(h_dst, src, b0, b1, bits, warm);
         _mm_sfence();
     }
     if (waited != hipSuccess) return gl::set_error(GL_ERR_HIP, "gl_sync_levels_unpack: %s", hipGetErrorString(waited));
@@ -1149,6 +1167,7 @@ int gl_sync_levels_unpack_stream(float *h_dst, const void *h_block, size_t n, in
     const int nt = host_expand_threads(n);
     (void)nt;
     const bool aligned = ((uintptr_t)h_dst & 15u) == 0;
+    const bool warm = levels_destination_is_warm(h_dst);
     const uint32_t levels_per_word = 32u / (uint32_t)bits;
     int drained = 0, missing = 0;
     hipError_t waited = hipSuccess;
@@ -1188,7 +1207,7 @@ int gl_sync_levels_unpack_stream(float *h_dst, const void *h_block, size_t n, in
                 const size_t w0 = (size_t)c * gl::kLevelsChunkWords, w1 = std::min<size_t>(L.nwords, w0 + gl::kLevelsChunkWords);
                 const size_t l0 = w0 * levels_per_word, l1 = w1 * levels_per_word;     // (a chunk holds whole 32-level blocks)
                 if (aligned) {
-                    levels_expand_blocks(h_dst, src, l0 / 32u, l1 / 32u, bits);
+                    levels_expand_blocks(h_dst, src, l0 / 32u, l1 / 32u, bits, warm);
                     for (size_t i = l1 / 32u * 32u; i < l1; i++)
                         h_dst[i] = bits == 8 ? (float)src[i] : (float)((src[i / 2u] >> (4u * (i & 1u))) & 15u);
                 } else {

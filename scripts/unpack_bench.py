@@ -16,7 +16,7 @@ src = capi.pinned_empty(n // 2, np.uint8)
 src[:] = np.random.default_rng(0).integers(0, 256, size=n // 2, dtype=np.uint8)
 bufs = [capi.pinned_empty(n, np.float32) for _ in range(2)]
 ts = []
-for i in range(200):
+for i in range(202):
     d = bufs[i & 1]
     t0 = time.perf_counter()
     capi.host_levels_unpack(d, src, n, 4)
