@@ -719,7 +719,7 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence, keep=None):
     res["exchange"] = type(comm).__name__ if comm.distributed else None
     if st and st.get("h8") is not None:
         # the host half of the packed read-back alone: the nibbles / bytes of the last run expanded to floats on the host threads
-        own, pbits = st["lev8_key"]
+        own, pbits = st["lev8_key"][:2]     # (own rows, bits per level, streamed?)
         dst = np.empty(own, np.float32)
         hs = []
         for _ in range(20):
@@ -728,7 +728,8 @@ def _bench_bfs(app, capi, comm, raw, iters, device, runs, fence, keep=None):
             hs.append(time.perf_counter() - t0)
         res["host_unpack_ms"] = round(float(np.median(hs)) * 1e3, 4)
         res["host_unpack"] = {"levels": own, "bits_per_level": pbits, "threads": capi.host_unpack_threads(),
-                              "bytes_over_pcie": int(st["h8"].nbytes), "float_bytes": 4 * own}
+                              "bytes_over_pcie": own * pbits // 8 + 4 * st["ctl_words"], "float_bytes": 4 * own,
+                              "streamed_in_chunks": bool(st["lev8_key"][2])}
     if st and st.get("graph_error"):
         res["graph_error"] = st["graph_error"]
     res["gteps_definition"] = "nnz x iterations / time (bench_bfs.cpp:68-71): NOMINAL edges, whatever the direction touched"

@@ -347,46 +347,58 @@ __device__ __forceinline__ void bfs_shard_scatter(const BfsPushArgs &a, uint32_t
 }
 
 // The bottom-up scan of the same kernel: a thread per row not reached yet, 64 rows per wavefront = one 64-bit word of the
-// next frontier (shard bounds are multiples of 64 rows: every word has one writer).  Wavefront `wv` of `nwv`; TWO words per
-// step, every load of a stage issued for both before the first use (few wavefronts fit next to the pull's LDS tile).
+// next frontier (shard bounds are multiples of 64 rows: every word has one writer).  Wavefront `wv` of `nwv`; GL_BFS_BU_ROWS words
+// per step, every load of a stage issued for all of them before the first use (few wavefronts fit next to the pull's LDS tile).
+#ifndef GL_BFS_BU_ROWS
+#define GL_BFS_BU_ROWS 2
+#endif
 __device__ __forceinline__ void bfs_shard_bottom_up(const BfsPushArgs &a, uint32_t wv, uint32_t nwv, uint32_t &fresh, uint32_t &work,
                                                     uint32_t &work_rows) {
     const uint32_t lane = threadIdx.x & 63u;
+    constexpr int R = GL_BFS_BU_ROWS;   // words (rows per lane) per step
     const uint32_t nwords64 = (a.row_end + 63u) >> 6;
-    for (uint32_t wd0 = (a.row_begin >> 6) + wv; wd0 < nwords64; wd0 += 2u * nwv) {
-        uint32_t row[2], beg[2], end[2], len[2];
-        bool hit[2], live[2];
-        float dv[2];
+    for (uint32_t wd0 = (a.row_begin >> 6) + wv; wd0 < nwords64; wd0 += (uint32_t)R * nwv) {
+        uint32_t row[R], beg[R], end[R], len[R];
+        bool hit[R], live[R];
+        float dv[R];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < R; u++) {
             row[u] = (wd0 + u * nwv) * 64u + lane;
             live[u] = row[u] < a.row_end;
             dv[u] = live[u] ? a.dist[row[u]] : 1.0f;
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < R; u++) {
             live[u] = live[u] && dv[u] == 0.0f;
             beg[u] = live[u] ? a.row_ptr[row[u] - a.row_begin] - a.nz_base : 0u;
             end[u] = live[u] ? a.row_ptr[row[u] - a.row_begin + 1u] - a.nz_base : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < R; u++) {
             len[u] = end[u] - beg[u];
             hit[u] = false;
         }
-        for (int step = 0; step < 8 && __any((!hit[0] && beg[0] < end[0]) || (!hit[1] && beg[1] < end[1])); step++) {
-            uint32_t c[2][4];
+        auto undecided = [&]() {
+            bool any = false;
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < R; u++) any = any || (!hit[u] && beg[u] < end[u]);
+            return any;
+        };
+        for (int step = 0; step < 8 && __any(undecided()); step++) {
+            uint32_t c[R][4];
+#pragma unroll
+            for (int u = 0; u < R; u++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) c[u][k] = (!hit[u] && beg[u] + k < end[u]) ? a.row_idx[beg[u] + k] : 0xffffffffu;
-            uint32_t any[2] = {0u, 0u};
+            uint32_t any[R];
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < R; u++) any[u] = 0u;
+#pragma unroll
+            for (int u = 0; u < R; u++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) any[u] |= c[u][k] < a.num_cols ? (a.bits_in[c[u][k] >> 5] >> (c[u][k] & 31u)) & 1u : 0u;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < R; u++) {
                 if (!hit[u] && beg[u] < end[u]) {
                     hit[u] = any[u] != 0u;
                     beg[u] += 4u;
@@ -394,7 +406,7 @@ __device__ __forceinline__ void bfs_shard_bottom_up(const BfsPushArgs &a, uint32
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < R; u++) {
             const uint32_t wd = wd0 + u * nwv;
             if (wd >= nwords64) continue;   // (wave-uniform)
             // rows still undecided after 32 entries are finished by the whole wavefront, 256 entries per step

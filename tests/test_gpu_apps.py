@@ -418,3 +418,26 @@ def test_bfs_byte_read_back_equals_the_float_one(gpu, monkeypatch):
             assert np.array_equal(b2.pull(0, 200), ref200)
             assert np.array_equal(b2.pull_push(0, 9, 0.01), ref9)      # (nibbles)
         assert b2.readback_["way"] == "packed"
+
+
+def test_bench_line_carries_the_packed_bfs_read_back(gpu):
+    """bench.py on a stand-in large enough for the packed read-back (>= 2^19 rows): the line's `bfs` object is complete -- both
+    modes, the read-back's choice, the host half timed alone -- and the headline repeats its numbers (round 6: a changed driver
+    field made this leg fail into {"error": ...} while every smaller bench test stayed green)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--scale", "0.25", "--bfs-runs", "2",
+                        "--no-cpu-baseline", "--no-six-graphs", "--no-spmspv", "--no-pattern"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    bfs = rec["bfs"]
+    assert "error" not in bfs, bfs
+    assert bfs["pull"]["reached"] == bfs["pull_push"]["reached"] > 0
+    assert bfs["host_unpack_ms"] > 0 and bfs["host_unpack"]["levels"] >= 1 << 19 and bfs["host_unpack"]["streamed_in_chunks"] is True
+    assert bfs["host_unpack"]["bytes_over_pcie"] < bfs["host_unpack"]["float_bytes"] // 4
+    assert rec["headline"]["bfs_pull_push_ms"] == bfs["pull_push"]["ms"] > 0
