@@ -680,6 +680,8 @@ class PageRank(_GraphApp):
             return B.download_result(vector, n)
         saved = self.SpMV_.semiring_
         self.SpMV_.set_semiring(M.SemiringType(M.kMulAdd, 1.0, float(teleport)))
+        # every result IS the next vector, untouched in between: the run's epilogue prepares the next run's packed x (one GPU)
+        chained = (not self.comm.distributed) and hasattr(self.SpMV_, "chain") and self.SpMV_.chain(True)
         try:
             for _ in range(num_iterations):
                 self.SpMV_.bind_vector_buf(vector)
@@ -688,6 +690,8 @@ class PageRank(_GraphApp):
                 self._gather(results)
                 vector, results = results, vector
         finally:
+            if chained:
+                self.SpMV_.chain(False)
             self.SpMV_.set_semiring(saved)
         B.sync()
         return B.download_result(vector, n)
@@ -768,12 +772,17 @@ class SSSP(_GraphApp):
         results = B.alloc(n, np.float32)
         # The reference copies results -> vector after every SpMV (eWiseAdd with 0, app/sssp.h:163); here the two
         # buffers swap roles instead: same values, one launch and 8n bytes less per iteration.
-        for _ in range(first_it, num_iterations + 1):
-            self.SpMV_.bind_vector_buf(vector)
-            self.SpMV_.bind_results_buf(results)
-            self.SpMV_.run()
-            self._gather(results)
-            vector, results = results, vector
+        chained = (not self.comm.distributed) and hasattr(self.SpMV_, "chain") and self.SpMV_.chain(True)   # (as in PageRank.pull)
+        try:
+            for _ in range(first_it, num_iterations + 1):
+                self.SpMV_.bind_vector_buf(vector)
+                self.SpMV_.bind_results_buf(results)
+                self.SpMV_.run()
+                self._gather(results)
+                vector, results = results, vector
+        finally:
+            if chained:
+                self.SpMV_.chain(False)
         B.sync()
         return B.download_result(vector, n)
 

@@ -38,7 +38,7 @@ EXPORTS = [
     "gl_spmv_run_typed", "gl_spmspv_run_typed", "gl_ewise_add_typed", "gl_assign_dense_typed", "gl_assign_sparse_typed",
     "gl_assign_sparse_new_frontier_typed", "gl_sparse_to_dense_typed",
     "gl_buf_alloc", "gl_buf_free", "gl_buf_h2d", "gl_buf_d2h", "gl_buf_d2d", "gl_buf_fill_f32", "gl_buf_fill_u32",     "gl_host_alloc", "gl_host_free", "gl_host_pool_alloc", "gl_host_pool_free", "gl_pool_trim", "gl_pool_stats", "gl_host_pool_reserve", "gl_host_fill_u32", "gl_host_sparse_to_dense",
-    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_describe", "gl_spmv_plan_export", "gl_spmv_run",
+    "gl_spmv_plan_create", "gl_spmv_plan_create_ex", "gl_spmv_plan_destroy", "gl_spmv_plan_describe", "gl_spmv_plan_export", "gl_spmv_run", "gl_spmv_plan_chain",
     "gl_spmv_plan_bits_words", "gl_pack_bits", "gl_unpack_bits", "gl_bfs_bits_begin_from", "gl_spmv_run_bits", "gl_bfs_pull_step",
     "gl_prof_begin", "gl_prof_end", "gl_span_begin", "gl_span_end",
     "gl_spmspv_plan_create", "gl_spmspv_plan_destroy", "gl_spmspv_plan_info", "gl_spmspv_run", "gl_spmspv_run_assign",
@@ -106,7 +106,7 @@ def lib():
         "gl_spmv_plan_create": [P(vp), u32, u32, vp, vp, vp, u32, u32],
         "gl_spmv_plan_create_ex": [P(vp), u32, u32, vp, vp, vp, u32, u32, u32],
         "gl_spmv_plan_destroy": [vp], "gl_spmv_plan_describe": [vp, vp],
-        "gl_spmv_plan_export": [vp, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)],
+        "gl_spmv_plan_export": [vp, i32, vp, ctypes.c_size_t, P(ctypes.c_size_t)], "gl_spmv_plan_chain": [vp, i32, P(i32)],
         "gl_spmv_plan_bits_words": [vp, P(u64)], "gl_pack_bits": [vp, u32, vp], "gl_unpack_bits": [vp, u32, vp], "gl_bfs_bits_begin_from": [vp, u32, vp, u32, vp, u32, vp, vp], "gl_spmv_run_bits": [vp, vp, vp, vp, f32, i32],
         "gl_bfs_pull_step": [vp, vp, vp, vp, f32],
         "gl_spmv_run": [vp, vp, vp, vp, i32, f32, i32],
@@ -389,6 +389,13 @@ class SpMVPlan:
         """gl_spmv_run_typed: the buffers hold 32-bit value words of `val_type` (GL_VAL_*)."""
         check(lib().gl_spmv_run_typed(ctypes.c_void_p(self.handle), _p(x), _p(mask), _p(y), int(op), int(zero_bits), int(mask_type),
                                       int(val_type)))
+
+    def chain(self, on):
+        """gl_spmv_plan_chain: while on, a run's epilogue also leaves y in the next run's packed form and a run on the previous
+        run's y skips the helper launch.  -> whether this plan can chain at all."""
+        active = ctypes.c_int(0)
+        check(lib().gl_spmv_plan_chain(ctypes.c_void_p(self.handle), 1 if on else 0, ctypes.byref(active)))
+        return bool(active.value)
 
     def export(self, name):
         """One of the plan's formatted device arrays (PLAN_ARRAYS) as uint32 words (gl_spmv_plan_export)."""

@@ -81,6 +81,11 @@ struct SpmvArgs {
     uint32_t row_begin;
     uint32_t tickets;         // 1: wavefronts draw iterations from the LDS ticket; 0: static split (A/B builds)
     const uint32_t *self_hot_cols;   // non-null: no helper launch ran -- every workgroup gathers its (small) hot table from x itself
+    // chained runs (gl_spmv_plan_chain): where y[row] goes in the NEXT run's packed vector / hot table (colmap: bit 31 = hot slot,
+    // 0xffffffff = nowhere), times chain_colval[row] in pattern plans; null: not chained
+    const uint32_t *chain_map = nullptr;
+    const float *chain_colval = nullptr;
+    float *chain_packed = nullptr, *chain_hot = nullptr;
 };
 
 // after the sweep: hub slots -> rows, then y (unsplit blocks) or this unit's plane (split blocks)
@@ -117,6 +122,14 @@ __device__ __forceinline__ void spmv_unit_epilogue(const SpmvArgs &a, typename T
                 if (!mask_allows_zero<MASK, OP>(a.mask[row])) out = 0.0f;
             }
             a.y[row] = out;
+            if (MASK == GL_NOMASK && a.chain_map) {   // y is the next run's x: its packed form, as spmv_spread_x_kernel would leave it
+                const uint32_t m = a.chain_map[row];
+                if (m != 0xffffffffu) {
+                    const float nx = a.chain_colval ? Semiring<OP>::mul(a.chain_colval[row], out) : out;
+                    if (m >> 31) a.chain_hot[m & 0x7fffffffu] = nx;
+                    else a.chain_packed[m] = nx;
+                }
+            }
         }
     } else {
         // split block: this unit's tile goes to its segment plane; spmv_combine_kernel folds the planes in
@@ -826,14 +839,35 @@ static int launch_spmv(gl_spmv_plan p, const SpmvArgs &a_in, hipStream_t s) {
         GL_LAUNCH_CHECK();
         return GL_OK;
     }
-    if (p->self_hot) {
-        // no helper launch: the workgroups gather their hot table themselves, the cold entries index x directly
+    // chained runs (gl_spmv_plan_chain): the previous run's epilogue left THIS x in packed form in the buffers p->chain_sel names, and
+    // this run's epilogue leaves y in the other pair
+    const bool can_chain = p->chain_on && MASK == GL_NOMASK && OP < 3 && OP != GL_OP_ANDOR && !a.run_flag && p->d_colmap && p->d_packed_twin;
+    bool x_ready = false;
+    if (can_chain) {
+        x_ready = p->chain_ptr == a.x && p->chain_op == OP;
+        const int cur = x_ready ? p->chain_sel : 0;
+        float *packed[2] = {p->pattern ? p->d_z : p->d_xc, p->d_packed_twin}, *hot[2] = {p->d_hot_x, p->d_hot_x_twin};
+        a.hot_x = hot[cur];
+        if (p->pattern) a.z = packed[cur];
+        else a.xg = packed[cur];
+        a.chain_map = p->d_colmap;
+        a.chain_colval = p->pattern ? p->d_colval_bycol : nullptr;
+        a.chain_packed = packed[cur ^ 1];
+        a.chain_hot = hot[cur ^ 1];
+        p->chain_ptr = a.y, p->chain_sel = cur ^ 1, p->chain_op = OP;
+    } else {
+        p->chain_ptr = nullptr;
+    }
+    float *packed_now = const_cast<float *>(p->pattern ? a.z : a.xg), *hot_now = const_cast<float *>(a.hot_x);
+    if (p->self_hot || x_ready) {
+        // no helper launch: the workgroups gather their hot table themselves, the cold entries index x directly -- or the previous
+        // run of a chain has left this x packed
     } else if (p->d_colmap) {
         if (p->pattern)
-            spmv_spread_x_kernel<OP, true><<<cdiv(p->num_cols, 1024), 256, 0, s>>>(a.x, p->d_colmap, p->d_colval_bycol, p->d_z, p->d_hot_x,
+            spmv_spread_x_kernel<OP, true><<<cdiv(p->num_cols, 1024), 256, 0, s>>>(a.x, p->d_colmap, p->d_colval_bycol, packed_now, hot_now,
                                                                                        p->num_cols, a.run_flag);
         else
-            spmv_spread_x_kernel<OP, false><<<cdiv(p->num_cols, 1024), 256, 0, s>>>(a.x, p->d_colmap, nullptr, p->d_xc, p->d_hot_x,
+            spmv_spread_x_kernel<OP, false><<<cdiv(p->num_cols, 1024), 256, 0, s>>>(a.x, p->d_colmap, nullptr, packed_now, hot_now,
                                                                                         p->num_cols, a.run_flag);
         GL_LAUNCH_CHECK();
     } else if (p->pattern) {
@@ -1699,6 +1733,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             gl_spmv_plan_destroy(p);
             return rc;
         }
+        p->packed_len = (size_t)gather_cols + 4u;
         hipError_t he = hipMalloc((void **)&p->d_z, ((size_t)gather_cols + 4u) * sizeof(float));   // whole groups of four
         if (he != hipSuccess) {
             gl_spmv_plan_destroy(p);
@@ -1714,6 +1749,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
             return rc;
         }
         if (!pattern) {
+            p->packed_len = (size_t)gather_cols + 4u;
             hipError_t he = hipMalloc((void **)&p->d_xc, ((size_t)gather_cols + 4u) * sizeof(float));
             if (he != hipSuccess) {
                 gl_spmv_plan_destroy(p);
@@ -1775,6 +1811,7 @@ int gl_spmv_plan_create_ex(gl_spmv_plan *plan, uint32_t num_rows, uint32_t num_c
     if (nhot_table) {
         (void)hipFree(p->d_hot_x);
         p->d_hot_x = nullptr;
+        p->hot_x_len = nhot_table;
         hipError_t he = hipMalloc((void **)&p->d_hot_x, (size_t)nhot_table * sizeof(float));
         if (he == hipSuccess) he = hipMemsetAsync(p->d_hot_x, 0, (size_t)nhot_table * sizeof(float), gl::ctx().stream);   // padding slots stay 0
         if (he != hipSuccess) {
@@ -1804,6 +1841,8 @@ int gl_spmv_plan_destroy(gl_spmv_plan p) {
     (void)hipFree(p->d_hot_colval);
     (void)hipFree(p->d_ccols);
     (void)hipFree(p->d_colmap);
+    (void)hipFree(p->d_packed_twin);
+    (void)hipFree(p->d_hot_x_twin);
     (void)hipFree(p->d_colval_bycol);
     (void)hipFree(p->d_xc);
     (void)hipFree(p->d_diag);
@@ -1961,6 +2000,39 @@ int gl_spmv_run(gl_spmv_plan p, const float *d_x, const float *d_mask, float *d_
         return gl::bool_plan_run(p, d_x, nullptr, d_mask, d_y, zero, mask_type, gl::ctx().stream);
     }
     return gl::spmv_run_general(p, d_x, d_mask, d_y, op, zero, mask_type, nullptr);
+}
+
+int gl_spmv_plan_chain(gl_spmv_plan p, int on, int *active) {
+    GL_REQUIRE_INIT();
+    GL_ARG(p != nullptr);
+    if (active) *active = 0;
+    p->chain_ptr = nullptr;
+    p->chain_on = false;
+    if (!on) return GL_OK;
+    // what a chained run needs: the streaming helper's column map (so y's packed form is one store per row), every block written by
+    // its own workgroup (no split plan: their y comes from the combining kernel), the whole square matrix (row r IS column r of the
+    // next x).  Anything else: the runs stay as they are -- the call is a hint, not a mode
+    if (p->boolean || p->reference_order || !p->d_colmap || p->segments > 1 || p->row_begin != 0 || p->row_end != p->num_rows ||
+        p->num_rows != p->num_cols || p->packed_len == 0)
+        return GL_OK;
+    if (!p->d_packed_twin) {
+        hipError_t e = hipMalloc((void **)&p->d_packed_twin, p->packed_len * sizeof(float));
+        if (e == hipSuccess) e = hipMemsetAsync(p->d_packed_twin, 0, p->packed_len * sizeof(float), gl::ctx().stream);
+        if (e == hipSuccess && p->hot_x_len) {
+            e = hipMalloc((void **)&p->d_hot_x_twin, p->hot_x_len * sizeof(float));
+            if (e == hipSuccess) e = hipMemsetAsync(p->d_hot_x_twin, 0, p->hot_x_len * sizeof(float), gl::ctx().stream);   // padding slots stay 0
+        }
+        if (e != hipSuccess) {
+            (void)hipFree(p->d_packed_twin);
+            (void)hipFree(p->d_hot_x_twin);
+            p->d_packed_twin = p->d_hot_x_twin = nullptr;
+            return gl::set_error(GL_ERR_HIP, "gl_spmv_plan_chain: %s", hipGetErrorString(e));
+        }
+        p->device_bytes += (p->packed_len + p->hot_x_len) * sizeof(float);
+    }
+    p->chain_on = true;
+    if (active) *active = 1;
+    return GL_OK;
 }
 
 int gl_spmv_run_typed(gl_spmv_plan p, const void *d_x, const void *d_mask, void *d_y, int op, uint32_t zero_bits, int mask_type,

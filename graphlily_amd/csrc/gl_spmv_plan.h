@@ -190,6 +190,15 @@ struct gl_spmv_plan_s {
     uint32_t ncompact = 0;           // 0: gather from x (z) directly
     uint32_t *d_ccols = nullptr;     // packed index -> column, ascending
     float *d_xc = nullptr;           // general plans: x[ccols[j]]
+    // CHAINED runs (gl_spmv_plan_chain; round 6): an iterative caller feeds every result straight back as the next x (PageRank, SSSP
+    // pull).  The epilogue of such a run also stores y in the next run's packed form -- its slot of the packed vector / hot table,
+    // times the column's value in pattern plans: what the helper launch would do -- into the TWIN of the buffers the run reads, and
+    // the next run skips the helper.  chain_ptr: the y whose packed form the buffers of `chain_sel` hold (null: none).
+    float *d_packed_twin = nullptr, *d_hot_x_twin = nullptr;
+    size_t packed_len = 0, hot_x_len = 0;   // floats in d_z / d_xc and in d_hot_x
+    bool chain_on = false;
+    const float *chain_ptr = nullptr;
+    int chain_sel = 0, chain_op = -1;
     uint32_t *d_colmap = nullptr;    // non-null: the vectors are refilled by one streaming pass over x (spmv_spread_x_kernel):
                                      // per column 0x80000000 | hot slot, packed index, or 0xffffffff
     float *d_colval_bycol = nullptr; // pattern plans in that mode: the column values indexed by column

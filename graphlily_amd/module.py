@@ -231,6 +231,15 @@ class SpMVModule(BaseModule):
                        self.mask_type_)
         self._finish(self.results_buf)
 
+    def chain(self, on):
+        """Extension (gl_spmv_plan_chain): the caller feeds every result straight back as the next vector and touches neither in
+        between (PageRank.pull, SSSP.pull) -- the run's epilogue then prepares the next run's packed x.  -> active?"""
+        if self.plan_ is None or not hasattr(self.plan_, "chain"):
+            return False
+        if on and os.environ.get("GRAPHLILY_SPMV_CHAIN", "1") == "0":      # (A/B and tests: every run launches its helper)
+            return False
+        return self.plan_.chain(on)
+
     # extensions for row-sharded (||,&&) runs: x as a bit vector (gl_spmv_plan_bits_words / gl_spmv_run_bits)
     def bits_words(self):
         if self.plan_ is None or (self.plan_.flags & capi.GL_PLAN_REFERENCE_ORDER):

@@ -74,11 +74,14 @@ public:
 
     aligned_dense_vec_t pull(graphlily::val_t damping, uint32_t num_iterations) {
         start_();
+        SpMV_->chain(true);   // every result is the next vector: the run's epilogue prepares the next run's packed x
         for (uint32_t iter = 1; iter <= num_iterations; iter++) {
             SpMV_->run();
             eWiseAdd_->run(matrix_num_rows_, (1 - damping) / matrix_num_rows_);   // the teleport term, the reference's expression (:87)
         }
-        return SpMV_->send_vector_device_to_host();
+        aligned_dense_vec_t rank = SpMV_->send_vector_device_to_host();
+        SpMV_->chain(false);
+        return rank;
     }
 
     // the reference's buckets (pagerank.h:93-147), every call followed by a device synchronisation

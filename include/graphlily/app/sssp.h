@@ -132,6 +132,7 @@ private:
     void pull_loop_(uint32_t iter, uint32_t num_iterations) {
         eWiseAdd_->bind_in_buf(SpMV_->results_buf);
         eWiseAdd_->bind_out_buf(SpMV_->vector_buf);
+        SpMV_->chain(true);   // (as in PageRank::pull; the callers read the vector back and end the chain)
         for (; iter <= num_iterations; iter++) {
             SpMV_->run();
             eWiseAdd_->run(matrix_num_rows_, 0);   // results -> vector (the pair runs as one SpMV + a swap: module/fusion.h)
@@ -177,7 +178,9 @@ public:
     aligned_dense_vec_t pull(uint32_t source, uint32_t num_iterations) {
         SpMV_->bind_vector_buf(device_dense_(source, semiring_.zero, 0));
         pull_loop_(1, num_iterations);
-        return SpMV_->send_vector_device_to_host();
+        aligned_dense_vec_t distance = SpMV_->send_vector_device_to_host();
+        SpMV_->chain(false);
+        return distance;
     }
 
     aligned_dense_vec_t push(uint32_t source, uint32_t num_iterations) {
@@ -202,7 +205,9 @@ public:
         // push -> pull (sssp.h:224-226 moves the distances through the host): the SpMV takes the distance buffer as its vector
         SpMV_->bind_vector_buf(SpMSpV_->mask_buf);
         pull_loop_(iter, num_iterations);
-        return SpMV_->send_vector_device_to_host();
+        aligned_dense_vec_t distance = SpMV_->send_vector_device_to_host();
+        SpMV_->chain(false);
+        return distance;
     }
 
     aligned_dense_float_vec_t compute_reference_results(uint32_t source, uint32_t num_iterations) {

@@ -208,6 +208,14 @@ public:
         results_buf = src_buf;
     }
 
+    // Extension (gl_spmv_plan_chain): the caller feeds every result straight back as the next vector and writes neither in between
+    // (PageRank::pull, SSSP::pull: SpMV + eWiseAdd run as one SpMV and a swap, module/fusion.h) -- a run's epilogue then leaves y
+    // in the next run's packed form and the next run skips its helper launch.  GRAPHLILY_SPMV_CHAIN=0: never.
+    void chain(bool on) {
+        static const bool allowed = !(getenv("GRAPHLILY_SPMV_CHAIN") && atoi(getenv("GRAPHLILY_SPMV_CHAIN")) == 0);
+        if (plan_ && (allowed || !on)) GRAPHLILY_CHECK(gl_spmv_plan_chain(plan_, on ? 1 : 0, nullptr));
+    }
+
     void run() {
         barrier_();
         if (!plan_serves_(semiring_.op)) {   // semiring switched after upload: re-format

@@ -270,6 +270,15 @@ int gl_bfs_pull_step(gl_spmv_plan plan, const uint32_t *d_bits_in, uint32_t *d_b
  * spmv_module.h:518-530). */
 int gl_spmv_run(gl_spmv_plan plan, const float *d_x, const float *d_mask, float *d_y,
                 int op, float zero, int mask_type);
+/* Extension for iterative callers that feed every result straight back as the next vector -- PageRank::pull and SSSP::pull swap
+ * their two buffers instead of copying (app/pagerank.h:84-88, app/sssp.h:157-165): while a plan is CHAINED, an unmasked float run's
+ * epilogue also stores y in the form the next run reads x in (its slots of the plan's packed vector and hot table, times the
+ * column's value in pattern plans), and a run whose d_x IS the previous run's d_y skips the helper launch that would build
+ * them (8 us of orkut's 0.21 ms PageRank iteration).  The caller promises that such a vector has not been written in between;
+ * results are bit-identical either way.  *active (may be NULL): whether the plan can chain at all -- the whole square matrix,
+ * unsplit blocks, the streaming helper; otherwise the call changes nothing.  on = 0 ends the chain (always do so before the
+ * vectors are handed to anything else). */
+int gl_spmv_plan_chain(gl_spmv_plan plan, int on, int *active);
 
 /* Measurement hook (bench.py roofline): between gl_prof_begin and gl_prof_end every launch of the
  * dominant SpMV kernel is bracketed by HIP events recorded on the stream it is launched on.

@@ -441,3 +441,63 @@ def test_bench_line_carries_the_packed_bfs_read_back(gpu):
     assert bfs["host_unpack_ms"] > 0 and bfs["host_unpack"]["levels"] >= 1 << 19 and bfs["host_unpack"]["streamed_in_chunks"] is True
     assert bfs["host_unpack"]["bytes_over_pcie"] < bfs["host_unpack"]["float_bytes"] // 4
     assert rec["headline"]["bfs_pull_push_ms"] == bfs["pull_push"]["ms"] > 0
+
+
+@pytest.mark.parametrize("name", ["rmat_sym_50K", "gplus_small", "uniform_10K_10"])
+def test_chained_spmv_runs_are_bit_identical(gpu, name, monkeypatch):
+    """gl_spmv_plan_chain (include/graphlily_hip.h): PageRank.pull and SSSP.pull feed every result straight back as the next
+    vector; chained, a run's epilogue leaves y in the next run's packed form (its slots of the packed vector and the hot table,
+    times the column's value in pattern plans) and the next run skips its helper launch.  Same bits as the unchained loop,
+    for both layouts the apps use, with the streaming helper forced (the planner picks it from a quarter of the columns on);
+    and a vector written between two runs is served by the helper again once the chain is off."""
+    from graphlily_amd import capi
+    set_knob(monkeypatch, "spmv_helper", 1)
+    m = named_matrix(name)
+    outs = {}
+    for chain in ("0", "1"):
+        monkeypatch.setenv("GRAPHLILY_SPMV_CHAIN", chain)
+        pr = app.PageRank(M.num_hbm_channels, 1024, 256)
+        pr.set_up_runtime()
+        pr.load_and_format_matrix(m, 0.9, True)
+        pr.send_matrix_host_to_device()
+        if chain == "1":
+            assert pr.SpMV_.chain(True) is True, "the plan must be able to chain for this test to mean anything"
+            pr.SpMV_.chain(False)
+        s = app.SSSP(M.num_hbm_channels, 1024, 512, 256, semiring=M.SemiringType(M.kAddMin, 0.0, 255.0))
+        s.set_up_runtime()
+        s.load_and_format_matrix(m, True)
+        s.send_matrix_host_to_device()
+        outs[chain] = (pr.pull(0.9, 7), pr.pull(0.9, 2), s.pull(0, 9), s.pull_push(0, 9, 0.1))
+    for a, b, what in zip(outs["0"], outs["1"], ("pagerank 7", "pagerank 2", "sssp pull", "sssp pull_push")):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), what
+    assert np.array_equal(outs["1"][2], O.sssp(_oracle_prepared(m, "sssp"), 0, 9, 255.0))
+    # the plan level: x = the previous y is only trusted while the chain is on
+    rng = np.random.default_rng(3)
+    mm = m.copy()
+    io.util_round_csr_matrix_dim(mm, 128, 128)
+    n = mm.num_rows
+    data = rng.random(mm.nnz, dtype=np.float32)
+    plan = capi.SpMVPlan(n, n, mm.adj_indptr, mm.adj_indices, data, 0, n, flags=capi.GL_PLAN_KEEP_VALUES)
+    x0 = rng.random(n, dtype=np.float32)
+    a, b = capi.DeviceBuffer.from_host(x0), capi.DeviceBuffer(4 * n)
+    def three_runs(chained):
+        a.write(x0)
+        if chained:
+            assert plan.chain(True)
+        plan.run(a, None, b, 0, 0.0, 0)
+        plan.run(b, None, a, 0, 0.0, 0)          # (chained: no helper, x comes packed from the first run's epilogue)
+        plan.run(a, None, b, 0, 0.0, 0)
+        if chained:
+            plan.chain(False)
+        return b.read(np.float32, n)
+    plain, chained = three_runs(False), three_runs(True)
+    assert np.array_equal(plain.view(np.uint32), chained.view(np.uint32))
+    # off again: a vector rewritten by the caller is read afresh
+    plan.run(a, None, b, 0, 0.0, 0)
+    y1 = b.read(np.float32, n)
+    b.write(x0)
+    plan.run(b, None, a, 0, 0.0, 0)
+    a2 = a.read(np.float32, n)
+    a.write(x0)
+    plan.run(a, None, b, 0, 0.0, 0)
+    assert np.array_equal(b.read(np.float32, n).view(np.uint32), a2.view(np.uint32)) and y1 is not None
